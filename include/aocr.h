@@ -1,0 +1,206 @@
+/* aocr.h -- C ABI of libaocr: the MI355X (gfx950) implementation of the
+ * CNN -> BiLSTM -> attention-decoder train / decode step of
+ * da03/torch-Attention-OCR.
+ *
+ * The reference has no FFI of its own: its hot path runs inside un-vendored
+ * Torch7 packages that src/train.lua:4-9 and src/model/model.lua:3-7 only
+ * `require`.  The entry points below are what a LuaJIT `ffi.cdef` (see
+ * INTEGRATION.md) or a ctypes binding (torch-attention-ocr_amd/aocr/_lib.py)
+ * binds instead; each one cites the reference code it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message is
+ *     available from aocr_last_error() (thread-local).  Nothing throws.
+ *   - all pointers named *_dev are DEVICE pointers (HBM) owned by the caller;
+ *     the library never allocates device memory: parameters, gradients and the
+ *     workspace arena are handed in at aocr_model_create().
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every
+ *     call only enqueues work on it and never synchronises.
+ *   - activations are fp32, channels-last (B,H,W,C); token ids are 1-based int32
+ *     (1 PAD, 2 GO, 3 EOS: src/train.lua:53).
+ *   - the ABI is not re-entrant per aocr_model (Lua is single threaded).
+ */
+#ifndef AOCR_H
+#define AOCR_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AOCR_VERSION 1
+#define AOCR_NUM_GROUPS 5           /* cnn, enc_fw, enc_bw, decoder, projector: model.lua:150 */
+#define AOCR_COMPUTE_F32 0          /* v_mfma_f32_32x32x2_f32, exact fp32 */
+#define AOCR_COMPUTE_BF16 1         /* bf16 operands, fp32 accumulate */
+
+typedef struct aocr_model aocr_model;
+
+/* Hyper-parameters: src/train.lua:41-62, src/model/model.lua:83-96. */
+typedef struct aocr_config {
+  int32_t batch_size;       /* max rows per step                        (-batch_size) */
+  int32_t img_h;            /* 32, src/data/data_gen.lua:16 */
+  int32_t max_img_w;        /* widest crop the workspace is sized for */
+  int32_t enc_hidden;       /* -encoder_num_hidden */
+  int32_t enc_layers;       /* -encoder_num_layers */
+  int32_t dec_layers;       /* -decoder_num_layers */
+  int32_t vocab;            /* -target_vocab_size (39) */
+  int32_t emb;              /* -target_embedding_size (20) */
+  int32_t input_feed;       /* -input_feed */
+  int32_t max_decoder_l;    /* -max_decoder_l (50) */
+  int32_t max_beam;         /* largest -beam_size the workspace is sized for */
+  int32_t compute;          /* AOCR_COMPUTE_* */
+} aocr_config;
+
+const char* aocr_last_error(void);
+int aocr_version(void);
+
+/* ---- parameter layout (replaces nn.Module:getParameters(), model.lua:163-168)
+ * One flat fp32 buffer holds the 5 groups back to back; within a group the order
+ * is Torch7's (module order, weight then bias).  Conv weights are stored
+ * [Cout][kH][kW][Cin] (channels-last taps); everything else as in Torch7. */
+int aocr_param_counts(const aocr_config* cfg, int64_t counts[AOCR_NUM_GROUPS]);
+/* Enumerate named tensors: returns 0 and fills the outputs for index < n, 1 past the end.
+ * offset is relative to the start of the flat buffer (not of the group). */
+int aocr_param_entry(const aocr_config* cfg, int32_t index, char name[64], int32_t* group,
+                     int64_t* offset, int32_t* ndim, int64_t shape[4]);
+/* BatchNorm running statistics (not parameters): [rm3(256) rv3 rm5(512) rv5 rm7(512) rv7]. */
+int64_t aocr_bn_state_count(void);
+
+size_t aocr_workspace_bytes(const aocr_config* cfg);
+
+/* ---- model handle (replaces Model:create/_build, model.lua:83-223) */
+int aocr_model_create(const aocr_config* cfg, float* params_dev, float* grads_dev,
+                      float* bn_state_dev, void* workspace_dev, size_t workspace_bytes,
+                      void* stream, aocr_model** out);
+int aocr_model_destroy(aocr_model* m);
+int aocr_model_set_stream(aocr_model* m, void* stream);
+
+/* ---- fused sequence-level entry points (what Model:step uses) */
+
+/* feval of model.lua:284-696 with forward_only=false: CNN forward (training-mode
+ * BatchNorm, running stats updated), encoder fw/bw loops, teacher-forced decoder
+ * loop, loss, hand-ordered BPTT, CNN backward.  Gradients are ZEROED then
+ * accumulated into grads_dev with d(loss) scaled by grad_scale (= 1/batch_size in
+ * the reference, model.lua:645-647; 1/global_batch under data parallelism).
+ * loss_dev[0] = sum of NLL over the step (un-scaled, = loss*batch_size of :701).
+ * images_dev (B,1,32,W) fp32 values 0..255; targets/targets_eval (B,L) int32
+ * (src/data/data_gen.lua:107-117). */
+int aocr_train_forward_backward(aocr_model* m, const float* images_dev, const int32_t* targets_dev,
+                                const int32_t* targets_eval_dev, int32_t B, int32_t W, int32_t L,
+                                float grad_scale, float* loss_dev);
+
+/* optim.sgd_list, src/optim/optim_sgd.lua:38-95 with the options the reference
+ * leaves at 0: per group, if ||g||_2 > clip then g *= clip/||g||_2; w -= lr*g.
+ * norms_dev (optional, 2*5 floats): {param norm, grad norm} per group, as printed
+ * by optim_sgd.lua:49.  A data-parallel all-reduce of grads_dev goes before this call. */
+int aocr_sgd_step(aocr_model* m, float lr, float clip, float* norms_dev);
+
+/* Teacher-forced forward only (no gradients).  training!=0 uses batch statistics
+ * in BatchNorm (without touching running stats); logits_dev (L,B,vocab) receives the
+ * pre-LogSoftMax projector output (output_projector.lua:5), loss_dev[0] the NLL sum. */
+int aocr_forward_logits(aocr_model* m, const float* images_dev, const int32_t* targets_dev,
+                        const int32_t* targets_eval_dev, int32_t B, int32_t W, int32_t L,
+                        int32_t training, float* logits_dev, float* loss_dev);
+
+/* feval with forward_only=true (model.lua:321-536, 570-627): eval-mode CNN, encoder,
+ * beam search over max_decoder_l steps (beam 1 = greedy), back-trace, then the
+ * teacher-forced gold pass.  labels_dev (B,max_decoder_l) int32, scores_dev (B),
+ * gold_scores_dev (B), loss_dev[0] = gold-pass NLL sum.  The dictionary (trie)
+ * constraint of model.lua:380-387,405-445,460-513 is not implemented. */
+int aocr_decode(aocr_model* m, const float* images_dev, const int32_t* targets_dev,
+                const int32_t* targets_eval_dev, int32_t B, int32_t W, int32_t L, int32_t beam,
+                int32_t* labels_dev, float* scores_dev, float* gold_scores_dev, float* loss_dev);
+
+/* Debug / parity taps: device pointer + shape of a named intermediate of the last
+ * step ("feats" (T,B,512), "context" (B,T,2He), "logits" (L,B,40), "dfeats", "dcontext"). */
+int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32_t* ndim, int64_t shape[4]);
+
+/* Times `iters` launches of one hot kernel of the LAST step's shape with HIP events
+ * on the model's stream; which: 0 = conv6 forward implicit GEMM (largest layer).
+ * ms_per_launch and flops_per_launch are host outputs (this call synchronises). */
+int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_per_launch, double* flops_per_launch);
+
+/* ---- module-level entry points (the nn.Module surface of src/model/*.lua) ---- */
+
+/* C[M,N] (ldc) = op(A) * op(B) (+bias[n]) ; a_kmajor: 1 = A stored [M][K] (lda), 0 = [K][M];
+ * b_kmajor: 1 = B stored [N][K] (ldb), 0 = [K][N].  nn.Linear forward is (1,1) with bias
+ * (LSTM.lua:79-88), its gradInput (1,0), its gradWeight (0,0).  accumulate: C += . */
+int aocr_gemm(void* stream, int32_t compute, const float* A_dev, int64_t lda, int32_t a_kmajor,
+              const float* B_dev, int64_t ldb, int32_t b_kmajor, float* C_dev, int64_t ldc,
+              int32_t M, int32_t N, int32_t K, const float* bias_dev, int32_t accumulate);
+
+/* cudnn.SpatialConvolution + cudnn.ReLU + cudnn.SpatialMaxPooling (cnn.lua:12-42), fused.
+ * x (B,H,W,Cin) channels-last; w [Cout][k][k][Cin]; stride 1.  pool: 0 none, 1 = 2x2/2, 2 = kH2 kW1 / (2,1).
+ * relu applies before the pool.  y is (B,Ho',Wo',Cout); idx (same shape, uint8, may be NULL when pool=0)
+ * records the arg-max position inside the window. */
+int aocr_conv2d_forward(void* stream, int32_t compute, const float* x_dev, const float* w_dev, const float* bias_dev,
+                        float* y_dev, uint8_t* idx_dev, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                        int32_t ksize, int32_t pad, int32_t relu, int32_t pool);
+/* gradInput / gradWeight+gradBias of the same layer w.r.t. the PRE-pool, PRE-relu output gradient dy (B,Ho,Wo,Cout). */
+int aocr_conv2d_backward_data(void* stream, int32_t compute, const float* dy_dev, const float* w_dev, float* dx_dev,
+                              int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t pad);
+int aocr_conv2d_backward_filter(void* stream, int32_t compute, const float* x_dev, const float* dy_dev, float* dw_dev,
+                                float* dbias_dev, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                                int32_t ksize, int32_t pad);
+/* Routes d(pooled) back through max-pool + ReLU: dy (B,Ho,Wo,C) from dpooled, idx and pooled (>0 test). */
+int aocr_unpool_relu_backward(void* stream, const float* dpooled_dev, const float* pooled_dev, const uint8_t* idx_dev,
+                              float* dy_dev, int32_t B, int32_t Ho, int32_t Wo, int32_t C, int32_t pool);
+
+/* First layer, cnn.lua:9-15 fused: (x-128)/128, conv 1->64 3x3 p1, ReLU, maxpool 2x2. x (B,32,W) -> y (B,16,W/2,64). */
+int aocr_conv1_forward(void* stream, const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,
+                       int32_t B, int32_t H, int32_t W);
+int aocr_conv1_backward(void* stream, const float* x_dev, const float* w_dev, const float* bias_dev,
+                        const float* dy_pooled_dev, float* dw_dev, float* dbias_dev, int32_t B, int32_t H, int32_t W);
+
+/* nn.SpatialBatchNormalization (+ the ReLU that follows it in cnn.lua:23-24,32-33,41-42).
+ * x,y (rows,C) channels-last.  training: batch stats (biased var, eps 1e-5), running stats updated with
+ * momentum 0.1 and unbiased var when update_running; save_dev gets [mean(C), invstd(C)].
+ * tb_rows>0 writes y transposed from (B,T,C) to (T,B,C) with B = tb_rows (cnn.lua:44-45 + model.lua:288). */
+int aocr_batchnorm_relu_forward(void* stream, const float* x_dev, float* y_dev, const float* weight_dev,
+                                const float* bias_dev, float* running_mean_dev, float* running_var_dev,
+                                float* save_dev, void* scratch_dev, int64_t rows, int32_t C, int32_t training,
+                                int32_t update_running, int32_t tb_rows);
+/* dy_out = d/dx of relu(bn(x)) given dA (gradient at the ReLU output) and y (the ReLU output).  dweight/dbias accumulate. */
+int aocr_batchnorm_relu_backward(void* stream, const float* x_dev, const float* y_dev, const float* dA_dev,
+                                 const float* weight_dev, const float* save_dev, float* dx_dev, float* dweight_dev,
+                                 float* dbias_dev, void* scratch_dev, int64_t rows, int32_t C, int32_t tb_rows);
+
+/* One LSTM cell, LSTM.lua:79-105 (gate order in,forget,out,g; two biases).  zx (B,4H) optional pre-computed
+ * input part; x (B,in) may be NULL when zx carries W_i2h x + b.  Outputs c,h (B,H) and gates (B,4H) post-activation. */
+int aocr_lstm_cell_forward(void* stream, int32_t compute, const float* x_dev, int32_t in_size, const float* h_prev_dev,
+                           const float* c_prev_dev, const float* w_i2h_dev, const float* b_i2h_dev,
+                           const float* w_h2h_dev, const float* b_h2h_dev, float* c_dev, float* h_dev,
+                           float* gates_dev, int32_t B, int32_t H);
+/* Backward of the cell given d(c_out), d(h_out): writes dz (B,4H), dc_prev; dx/dh_prev via aocr_gemm(dz, W). */
+int aocr_lstm_cell_backward(void* stream, const float* dc_dev, const float* dh_dev, const float* gates_dev,
+                            const float* c_prev_dev, const float* c_dev, float* dz_dev, float* dc_prev_dev,
+                            int32_t B, int32_t H);
+
+/* create_decoder_attn, LSTM.lua:124-162, the score/softmax/context core given q = W_a h_top:
+ * a = softmax_T(ctx . q), c = a . ctx.  ctx (B,T,Hd), q (B,Hd) -> a (B,T), c written at c_dev with row stride ldc. */
+int aocr_attention_forward(void* stream, const float* ctx_dev, const float* q_dev, float* a_dev, float* c_dev,
+                           int64_t ldc, int32_t B, int32_t T, int32_t Hd);
+/* given dc (row stride lddc): ds (B,T) = softmax-backward of the scores, dq (B,Hd). d(ctx) is assembled over all
+ * decoder steps by the fused path. */
+int aocr_attention_backward(void* stream, const float* ctx_dev, const float* q_dev, const float* a_dev,
+                            const float* dc_dev, int64_t lddc, float* ds_dev, float* dq_dev, int32_t B, int32_t T,
+                            int32_t Hd);
+
+/* nn.LogSoftMax + nn.ClassNLLCriterion(weights; PAD weight 0; sizeAverage=false): output_projector.lua:6,
+ * criterion.lua:3-8, model.lua:644-648.  logits (rows, ld) ; targets (rows) 1-based.  logp (rows,V) optional,
+ * dlogits (rows, ld) optional = grad_scale * w[y] * (softmax - onehot); nll_rows (rows) per-row weighted NLL. */
+int aocr_logsoftmax_nll(void* stream, const float* logits_dev, int64_t ld, const int32_t* targets_dev, float* logp_dev,
+                        float* dlogits_dev, float* nll_rows_dev, int64_t rows, int32_t V, float grad_scale);
+
+/* topk over beam*V candidates + finished-beam PAD masking, model.lua:399-404,446-458,516.
+ * logp (B*kin, V); beam_scores (B,kout) in/out; prev_tok (B*kin) or NULL at t=1 (kin=1).
+ * Outputs tokens (B,kout) 1-based, parents (B,kout) 0-based source beam. */
+int aocr_beam_select(void* stream, const float* logp_dev, const int32_t* prev_tok_dev, float* beam_scores_dev,
+                     int32_t* tokens_dev, int32_t* parents_dev, int32_t B, int32_t kin, int32_t kout, int32_t V);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AOCR_H */

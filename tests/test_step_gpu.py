@@ -1,0 +1,134 @@
+"""Fused-path parity: aocr.Model (HIP, through the C ABI) against the CPU float64 oracle on the same seeded
+inputs and injected weights: CNN features, context, decoder logits (the 1e-4 target of BASELINE.json), loss,
+every gradient tensor, the clipped SGD update, and greedy / beam decode + gold pass."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4          # BASELINE.json north_star: decoder logits within 1e-4 max-abs (fp32 MFMA path)
+
+
+def make(cfgkw, B, W, maxlen, compute="f32", seed=910820, max_decoder_l=12, max_beam=5):
+    import aocr
+    import oracle_torch as O
+    ocfg = O.OcrConfig(**cfgkw)
+    P = O.init_params(ocfg, seed)
+    st = O.init_bn_state()
+    img, tgt, tge, nnz = O.synth_batch(B, W, max_len=maxlen, min_len=min(2, maxlen))
+    m = aocr.Model()
+    m._set_structure(dict(encoder_num_hidden=ocfg.enc_hidden, encoder_num_layers=ocfg.enc_layers,
+                          decoder_num_layers=ocfg.dec_layers, input_feed=ocfg.input_feed))
+    m._set_runtime(dict(batch_size=B, max_img_w=W, max_decoder_l=max_decoder_l, max_beam=max_beam, compute=compute))
+    m.optim_state = {"learningRate": 0.1}
+    m._build()
+    m.set_parameters(P, st)
+    batch = [img, tgt, tge, nnz, [f"img{i}" for i in range(B)]]
+    return m, O, ocfg, P, st, batch
+
+
+def relerr(got, ref):
+    got = got.double(); ref = ref.double()
+    return ((got - ref).abs().max() / (ref.abs().max() + 1e-12)).item()
+
+
+CASES = [
+    dict(enc_hidden=32, enc_layers=1, dec_layers=2, input_feed=True),
+    dict(enc_hidden=32, enc_layers=1, dec_layers=2, input_feed=False),
+    dict(enc_hidden=32, enc_layers=1, dec_layers=1, input_feed=True),
+    dict(enc_hidden=48, enc_layers=2, dec_layers=3, input_feed=True),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_train_step_parity_small(cuda, case):
+    m, O, ocfg, P, st, batch = make(CASES[case], B=5, W=36, maxlen=6)
+    img, tgt, tge = (torch.from_numpy(np.asarray(x)) for x in batch[:3])
+    loss_ref, G, aux, st_new = O.train_step_manual(P, st, ocfg, img, tgt, tge)
+    loss = m.train_forward_backward(batch)
+    B = img.shape[0]
+    print(f"[parity] case {case}: loss hip {loss:.6f} oracle {float(loss_ref) * B:.6f}")
+    feats = m.get_tensor("feats").transpose(0, 1)               # (T,B,512) -> (B,T,512)
+    e = (feats.double() - aux["feats"]).abs().max().item(); print(f"[parity] feats max-abs {e:.3e}"); assert e < 2e-4
+    e = (m.get_tensor("context").double() - aux["context"]).abs().max().item(); print(f"[parity] context max-abs {e:.3e}"); assert e < 1e-4
+    lg = m.get_tensor("logits")[:, :, :ocfg.vocab]
+    e = (lg.double() - aux["logits"]).abs().max().item(); print(f"[parity] logits max-abs {e:.3e}"); assert e < LOGIT_TOL
+    assert abs(loss - float(loss_ref) * B) < 1e-3 * max(1.0, abs(float(loss_ref) * B))
+    e = relerr(m.get_tensor("dcontext"), aux["dctx"]); print(f"[parity] dcontext rel {e:.3e}"); assert e < 1e-3
+    e = relerr(m.get_tensor("dfeats").transpose(0, 1), aux["dfeats"]); print(f"[parity] dfeats rel {e:.3e}"); assert e < 1e-3
+    grads = m.get_gradients()
+    worst = 0.0
+    for k, g in G.items():
+        e = relerr(grads[k], g)
+        if g.abs().max() < 1e-9:                         # conv biases in front of BatchNorm have ~0 gradient
+            e = (grads[k].double() - g).abs().max().item()
+        worst = max(worst, e)
+        print(f"[parity] grad {k:22s} rel {e:.3e} (max {g.abs().max().item():.3e})")
+        assert e < 2e-3, k
+    # running statistics
+    bn = m.get_bn_state()
+    for k, v in st_new.items():
+        assert (bn[k].double() - v).abs().max().item() < 1e-5, k
+    # optimizer, optim_sgd.lua:38-95 (lr 0.1, clip 5 and a tight clip that is active)
+    for clip in (5.0, 0.05):
+        m.set_parameters(P, st)
+        m.train_forward_backward(batch)
+        norms = m.sgd_step(lr=0.1, clip=clip)
+        newP, nref = O.sgd_list(P, G, 0.1, clip)
+        for gi in range(5):
+            assert abs(norms[gi, 0] - nref[gi][0]) < 1e-4 * max(1, nref[gi][0])
+            assert abs(norms[gi, 1] - nref[gi][1]) < 2e-3 * max(1e-3, nref[gi][1]), (gi, norms[gi, 1], nref[gi][1])
+        got = m.get_parameters()
+        for k, v in newP.items():
+            assert (got[k].double() - v).abs().max().item() < 2e-5, k
+    m.shutdown()
+
+
+@pytest.mark.parametrize("case,beam", [(0, 1), (0, 5), (1, 3), (2, 1), (3, 5)])
+def test_decode_parity_small(cuda, case, beam):
+    m, O, ocfg, P, st, batch = make(CASES[case], B=4, W=36, maxlen=5, max_decoder_l=10)
+    # make running stats non-trivial so eval-mode BatchNorm is exercised
+    st = {k: (v + 0.05 if k.endswith("rm") else v * 1.3) for k, v in st.items()}
+    m.set_parameters(P, st)
+    img, tgt, tge = (torch.from_numpy(np.asarray(x)) for x in batch[:3])
+    ref = O.decode_beam(P, st, ocfg, img, tgt, tge, beam=beam, max_decoder_l=10)
+    loss, stats = m.step(batch, True, beam)
+    out = m._dec_out
+    print(f"[parity] decode case {case} beam {beam}: loss {loss:.5f} vs {float(ref['loss']):.5f}; labels[0] {out.labels[0].tolist()}")
+    assert np.array_equal(out.labels, ref["labels"].numpy().astype(np.int32))
+    assert np.abs(out.scores - ref["scores"].numpy()).max() < 2e-3
+    assert np.abs(out.gold_scores - ref["gold_scores"].numpy()).max() < 2e-3
+    assert abs(loss - float(ref["loss"])) < 2e-3 * max(1.0, float(ref["loss"]))
+    assert stats[1] == ref["num_correct"]
+    m.shutdown()
+
+
+def test_logits_c2_shape(cuda):
+    """BASELINE config C2: 32x100, B=64, He=256, Ld=2, input feed; decoder logits within 1e-4 of the fp64 oracle."""
+    m, O, ocfg, P, st, batch = make(dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True), B=64, W=100, maxlen=23,
+                                    max_decoder_l=24, max_beam=1)
+    img, tgt, tge = (torch.from_numpy(np.asarray(x)) for x in batch[:3])
+    with torch.no_grad():
+        r = O.forward_train(P, {k: v.clone() for k, v in st.items()}, ocfg, img, tgt, tge, training=True)
+    logits, loss = m.forward_logits(batch, training=True)
+    e = (logits.double() - r["logits"]).abs().max().item()
+    print(f"[parity] C2 logits max-abs {e:.3e} (mean |logit| {r['logits'].abs().mean().item():.3f}); loss {loss:.4f} vs {float(r['loss']) * 64:.4f}")
+    assert e < LOGIT_TOL
+    m.shutdown()
+
+
+def test_bf16_path_runs_close(cuda):
+    """bf16-operand MFMA path: stated tolerance 5e-2 max-abs on logits (fp32 accumulate, fp32 storage)."""
+    m, O, ocfg, P, st, batch = make(CASES[0], B=5, W=36, maxlen=6, compute="bf16")
+    img, tgt, tge = (torch.from_numpy(np.asarray(x)) for x in batch[:3])
+    loss_ref, G, aux, _ = O.train_step_manual(P, st, ocfg, img, tgt, tge)
+    loss = m.train_forward_backward(batch)
+    lg = m.get_tensor("logits")[:, :, :ocfg.vocab]
+    e = (lg.double() - aux["logits"]).abs().max().item()
+    print(f"[parity] bf16 logits max-abs {e:.3e}; loss {loss:.4f} vs {float(loss_ref) * 5:.4f}")
+    assert e < 5e-2
+    grads = m.get_gradients()
+    for k in ("proj.w", "dec.attn.wc", "enc_fw.l1.h2h.w", "cnn.conv6.w"):
+        r = relerr(grads[k], G[k]); print(f"[parity] bf16 grad {k} rel {r:.3e}"); assert r < 0.15, k
+    m.shutdown()

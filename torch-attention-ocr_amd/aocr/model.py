@@ -1,0 +1,375 @@
+"""Host-side mirror of the reference's `Model` class (src/model/model.lua:18-731).
+
+Same method names, argument meaning and error behaviour as the Lua class that
+src/train.lua drives (`create`, `load`, `step`, `save`, `vis`, `shutdown`, fields
+`global_step`, `optim_state.learningRate`), sitting directly on the C ABI of libaocr.
+PyTorch is used only as plumbing: device allocations, the HIP stream and
+`torch.distributed` (RCCL) for the data-parallel gradient all-reduce.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Config, check, lib, ptr
+
+PAD, GO, EOS = 1, 2, 3
+GROUPS = ["cnn", "enc_fw", "enc_bw", "dec", "proj"]
+
+_DEFAULTS = dict(  # src/train.lua:41-62
+    dropout=0.0, encoder_num_hidden=512, encoder_num_layers=1, decoder_num_layers=2, target_vocab_size=39,
+    target_embedding_size=20, max_encoder_l=80, max_decoder_l=50, input_feed=False, batch_size=400, prealloc=False,
+    learning_rate=0.1, seed=910820, img_h=32, max_img_w=100, max_beam=5, compute="f32")
+
+
+def _cfg_get(config, key):
+    if isinstance(config, dict):
+        return config.get(key, _DEFAULTS[key])
+    return getattr(config, key, _DEFAULTS[key])
+
+
+def numlist2str(ids):
+    """src/utils/utils.lua:119-134."""
+    return "".join(chr(v - 1 - 13 + 97) if v > 13 else chr(v - 1 - 3 + 48) for v in ids)
+
+
+def eval_word_err_rate(labels: np.ndarray, target_labels: np.ndarray, visualize: bool = False):
+    """evalWordErrRate, src/utils/utils.lua:136-175: sequences are cut at the first EOS (3) and compared exactly."""
+    B = labels.shape[0]
+    werr, pred, gold = 0.0, [], []
+    for b in range(B):
+        def cut(row):
+            out = []
+            for v in row:
+                if v == EOS:
+                    break
+                out.append(int(v))
+            return out
+        p, g = cut(labels[b]), cut(target_labels[b])
+        if visualize:
+            pred.append(numlist2str(p)); gold.append(numlist2str(g))
+        if p != g:
+            werr += 1
+    return werr, pred, gold
+
+
+class Model:
+    def __init__(self):
+        self._h = None
+        self.visualize = False
+        self.visualize_file = None
+        self.global_step = 0
+        self.optim_state = {}
+        self.last_norms = None
+
+    # ------------------------------------------------------------------ construction
+    def _set_structure(self, config):
+        g = lambda k: _cfg_get(config, k)
+        self.cnn_feature_size = 512
+        self.dropout = float(g("dropout"))
+        if self.dropout != 0.0:
+            raise NotImplementedError("dropout > 0 is not implemented on the HIP path (reference default is 0.0)")
+        self.encoder_num_hidden = int(g("encoder_num_hidden"))
+        self.encoder_num_layers = int(g("encoder_num_layers"))
+        self.decoder_num_hidden = 2 * self.encoder_num_hidden
+        self.decoder_num_layers = int(g("decoder_num_layers"))
+        self.target_vocab_size = int(g("target_vocab_size"))
+        self.target_embedding_size = int(g("target_embedding_size"))
+        self.input_feed = bool(g("input_feed"))
+
+    def _set_runtime(self, config):
+        g = lambda k: _cfg_get(config, k)
+        self.max_encoder_l = int(g("max_encoder_l"))
+        self.max_decoder_l = int(g("max_decoder_l"))
+        self.batch_size = int(g("batch_size"))
+        self.prealloc = bool(g("prealloc"))
+        self.img_h = int(g("img_h"))
+        self.max_img_w = int(g("max_img_w"))
+        self.max_beam = int(g("max_beam"))
+        comp = g("compute")
+        self.compute = _lib.COMPUTE_BF16 if comp in ("bf16", 1) else _lib.COMPUTE_F32
+
+    def create(self, config):
+        """model:create, model.lua:83-112: fresh parameters (Torch7 default init distributions [upstream])."""
+        self._set_structure(config)
+        self._set_runtime(config)
+        self.global_step = 0
+        self.optim_state = {"learningRate": float(_cfg_get(config, "learning_rate"))}
+        self._build()
+        self._init_parameters(int(_cfg_get(config, "seed")))
+        return self
+
+    def load(self, model_path, config=None):
+        """model:load, model.lua:45-80: structure from the checkpoint, max_*_l / batch_size from `config`."""
+        config = config or {}
+        assert os.path.isfile(model_path), f"Model {model_path} does not exist!"
+        ck = torch.load(model_path, map_location="cpu", weights_only=False)
+        self._set_structure(ck["config"])
+        merged = dict(ck["config"])
+        for k in ("max_encoder_l", "max_decoder_l", "batch_size", "prealloc", "img_h", "max_img_w", "max_beam", "compute"):
+            v = config.get(k) if isinstance(config, dict) else getattr(config, k, None)
+            if v is not None:
+                merged[k] = v
+        self._set_runtime(merged)
+        self.global_step = ck["global_step"]
+        self.optim_state = dict(ck["optim_state"])
+        self._build()
+        self.params.copy_(ck["params"].to(self.params.device))
+        self.bn_state.copy_(ck["bn_state"].to(self.params.device))
+        return self
+
+    def _build(self):
+        """model:_build, model.lua:115-223: flat parameter/gradient vectors + workspace, no cloned cells."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("aocr.Model needs a HIP device: the hot path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        assert self.target_vocab_size <= 40
+        self.config = dict(
+            dropout=self.dropout, encoder_num_hidden=self.encoder_num_hidden, encoder_num_layers=self.encoder_num_layers,
+            decoder_num_hidden=self.decoder_num_hidden, decoder_num_layers=self.decoder_num_layers,
+            target_vocab_size=self.target_vocab_size, target_embedding_size=self.target_embedding_size,
+            max_encoder_l=self.max_encoder_l, max_decoder_l=self.max_decoder_l, input_feed=self.input_feed,
+            batch_size=self.batch_size, prealloc=self.prealloc, img_h=self.img_h, max_img_w=self.max_img_w,
+            max_beam=self.max_beam, compute="bf16" if self.compute == _lib.COMPUTE_BF16 else "f32")
+        self.ccfg = Config(self.batch_size, self.img_h, self.max_img_w, self.encoder_num_hidden, self.encoder_num_layers,
+                           self.decoder_num_layers, self.target_vocab_size, self.target_embedding_size,
+                           int(self.input_feed), self.max_decoder_l, self.max_beam, self.compute)
+        self.table, self.group_counts = _lib.param_table(self.ccfg)
+        self.num_params = sum(self.group_counts)
+        self.group_offsets = np.concatenate([[0], np.cumsum(self.group_counts)]).astype(np.int64)
+        dev = self.device
+        self.params = torch.zeros(self.num_params, dtype=torch.float32, device=dev)       # model.lua:163-168
+        self.grad_params = torch.zeros(self.num_params, dtype=torch.float32, device=dev)
+        self.bn_state = torch.zeros(lib.aocr_bn_state_count(), dtype=torch.float32, device=dev)
+        self._reset_bn_state()
+        ws = lib.aocr_workspace_bytes(C.byref(self.ccfg))
+        if ws == 0:
+            raise _lib.AocrError(_lib.last_error())
+        self.workspace = torch.empty(ws, dtype=torch.uint8, device=dev)
+        self._scal = torch.zeros(16, dtype=torch.float32, device=dev)                       # loss + norms
+        h = C.c_void_p()
+        check(lib.aocr_model_create(C.byref(self.ccfg), ptr(self.params), ptr(self.grad_params), ptr(self.bn_state),
+                                    ptr(self.workspace), ws, self._stream(), C.byref(h)), "aocr_model_create")
+        self._h = h
+        self._dec_out = None
+        self.init_beam = False
+
+    def _reset_bn_state(self):
+        st = torch.zeros_like(self.bn_state)
+        o = 0
+        for c in (256, 512, 512):
+            st[o + c:o + 2 * c] = 1.0           # running_var = 1
+            o += 2 * c
+        self.bn_state.copy_(st)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _init_parameters(self, seed: int):
+        gen = torch.Generator().manual_seed(seed)
+        host = torch.zeros(self.num_params, dtype=torch.float32)
+        for name, group, off, shape in self.table:
+            n = int(np.prod(shape))
+            leaf = name.split(".")[-1]
+            if "conv" in name:
+                cout, kh, kw, cin = self._conv_shape(name)
+                stdv = 1.0 / math.sqrt(kh * kw * cin)
+            elif ".bn" in name:
+                stdv = None
+            elif name == "dec.lookup":
+                stdv = None
+            else:
+                wname = name[:-2] + ".w"
+                wshape = next(s for (nm, _, _, s) in self.table if nm == wname)
+                stdv = 1.0 / math.sqrt(wshape[1])
+            if name == "dec.lookup":
+                v = torch.randn(n, generator=gen)
+            elif ".bn" in name:
+                v = torch.rand(n, generator=gen) if leaf == "w" else torch.zeros(n)
+            else:
+                v = (torch.rand(n, generator=gen) * 2 - 1) * stdv
+            host[off:off + n] = v
+        self.params.copy_(host.to(self.device))
+
+    def _conv_shape(self, name):
+        base = name[:-2]
+        return next(s for (nm, _, _, s) in self.table if nm == base + ".w")
+
+    # ------------------------------------------------------------------ parameter import / export (Torch7 layouts)
+    def set_parameters(self, named: Dict[str, torch.Tensor], bn_state: Optional[Dict[str, torch.Tensor]] = None):
+        """Inject weights given in Torch7 layouts (conv [Cout][Cin][kH][kW], Linear [out][in])."""
+        host = torch.zeros(self.num_params, dtype=torch.float32)
+        for name, group, off, shape in self.table:
+            t = named[name].detach().to(torch.float32).cpu()
+            if len(shape) == 4:
+                t = t.permute(0, 2, 3, 1).contiguous()           # -> [Cout][kH][kW][Cin]
+            assert tuple(t.shape) == tuple(shape), (name, tuple(t.shape), shape)
+            host[off:off + t.numel()] = t.reshape(-1)
+        self.params.copy_(host.to(self.device))
+        if bn_state is not None:
+            parts = []
+            for i in (3, 5, 7):
+                parts += [bn_state[f"cnn.bn{i}.rm"].float().reshape(-1), bn_state[f"cnn.bn{i}.rv"].float().reshape(-1)]
+            self.bn_state.copy_(torch.cat(parts).to(self.device))
+
+    def _export(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        host = flat.detach().cpu()
+        out = {}
+        for name, group, off, shape in self.table:
+            n = int(np.prod(shape))
+            t = host[off:off + n].reshape(shape)
+            if len(shape) == 4:
+                t = t.permute(0, 3, 1, 2).contiguous()           # -> Torch7 [Cout][Cin][kH][kW]
+            out[name] = t.clone()
+        return out
+
+    def get_parameters(self):
+        return self._export(self.params)
+
+    def get_gradients(self):
+        return self._export(self.grad_params)
+
+    def get_bn_state(self):
+        host = self.bn_state.detach().cpu()
+        out, o = {}, 0
+        for i, c in ((3, 256), (5, 512), (7, 512)):
+            out[f"cnn.bn{i}.rm"] = host[o:o + c].clone(); out[f"cnn.bn{i}.rv"] = host[o + c:o + 2 * c].clone()
+            o += 2 * c
+        return out
+
+    def get_tensor(self, name: str) -> torch.Tensor:
+        """parity tap: copy of a named intermediate of the last step."""
+        p, nd, shape = C.c_void_p(), C.c_int32(), (C.c_int64 * 4)()
+        check(lib.aocr_get_tensor(self._h, name.encode(), C.byref(p), C.byref(nd), shape), "aocr_get_tensor")
+        shp = tuple(shape[i] for i in range(nd.value))
+        n = int(np.prod(shp))
+        off = p.value - self.workspace.data_ptr()                 # every tap lives inside the workspace arena
+        assert 0 <= off and off + 4 * n <= self.workspace.numel() and off % 4 == 0
+        return self.workspace[off:off + 4 * n].view(torch.float32).reshape(shp).cpu()
+
+    # ------------------------------------------------------------------ one step, model.lua:226-706
+    def _upload(self, batch):
+        dev = self.device
+        images = torch.as_tensor(batch[0]).to(device=dev, dtype=torch.float32).contiguous()     # localize(), utils.lua:96-102
+        targets = torch.as_tensor(batch[1]).to(device=dev, dtype=torch.int32).contiguous()
+        targets_eval = torch.as_tensor(batch[2]).to(device=dev, dtype=torch.int32).contiguous()
+        assert images.dim() == 4 and images.shape[1] == 1 and images.shape[2] == self.img_h
+        return images, targets, targets_eval
+
+    def step(self, batch, forward_only, beam_size=None, trie=None):
+        """Returns (loss*batch_size, [num_nonzeros, num_correct]) exactly like model:step (model.lua:695-705)."""
+        if trie is not None:
+            raise NotImplementedError("dictionary-constrained beam search (model.lua:405-445,460-513) is out of scope")
+        images, targets, targets_eval = self._upload(batch)
+        num_nonzeros = batch[3]
+        B, _, _, W = images.shape
+        target_l = targets.shape[1]
+        assert target_l <= self.max_decoder_l, f"max_decoder_l ({self.max_decoder_l}) < target_l ({target_l})!"
+        check(lib.aocr_model_set_stream(self._h, self._stream()))
+        loss_dev = self._scal[0:1]
+        if not forward_only:
+            world = 1
+            dist = torch.distributed
+            if dist.is_available() and dist.is_initialized():
+                world = dist.get_world_size()
+            # d(loss) / (global batch): model.lua:645-647 divides by the step's batch size
+            check(lib.aocr_train_forward_backward(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, target_l,
+                                                  1.0 / (B * world), ptr(loss_dev)), "aocr_train_forward_backward")
+            if world > 1:
+                # the one exchange step of data parallelism: sum gradients over ranks (RCCL over xGMI),
+                # inserted between feval and the per-group clip (optim_sgd.lua:38 -> :40)
+                dist.all_reduce(self.grad_params)
+                dist.all_reduce(loss_dev)
+            norms = self._scal[2:12]
+            check(lib.aocr_sgd_step(self._h, float(self.optim_state["learningRate"]), 5.0, ptr(norms)), "aocr_sgd_step")
+            self.last_norms = norms
+            return float(loss_dev.item()), [num_nonzeros, 0.0]
+        # forward only: beam search + gold pass
+        beam_size = beam_size or 1
+        beam_size = min(beam_size, self.target_vocab_size)
+        Lt = self.max_decoder_l
+        labels = torch.empty((B, Lt), dtype=torch.int32, device=self.device)
+        scores = torch.empty(B, dtype=torch.float32, device=self.device)
+        gold = torch.empty(B, dtype=torch.float32, device=self.device)
+        check(lib.aocr_decode(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, target_l, beam_size, ptr(labels),
+                              ptr(scores), ptr(gold), ptr(loss_dev)), "aocr_decode")
+        labels_h = labels.cpu().numpy()
+        tge = np.full((B, Lt), PAD, dtype=np.int32)
+        tge[:, :target_l] = targets_eval.cpu().numpy()
+        word_err, labels_pred, labels_gold = eval_word_err_rate(labels_h, tge, self.visualize)
+        accuracy = B - word_err
+        self._dec_out = SimpleNamespace(labels=labels_h, scores=scores.cpu().numpy(), gold_scores=gold.cpu().numpy())
+        if self.visualize and self.visualize_file is not None:
+            img_paths = batch[4]
+            for i in range(len(img_paths)):                                         # model.lua:628-633
+                self.visualize_file.write("%s\t%s\t%s\t%f\t%f\n" % (img_paths[i], labels_gold[i], labels_pred[i],
+                                                                    self._dec_out.scores[i], self._dec_out.gold_scores[i]))
+            self.visualize_file.flush()
+        return float(loss_dev.item()), [num_nonzeros, accuracy]
+
+    def forward_logits(self, batch, training=False):
+        """Teacher-forced decoder logits (L,B,V) and NLL sum (parity tap; the pre-LogSoftMax output of output_projector.lua:5)."""
+        images, targets, targets_eval = self._upload(batch)
+        B, _, _, W = images.shape
+        L = targets.shape[1]
+        check(lib.aocr_model_set_stream(self._h, self._stream()))
+        logits = torch.empty((L, B, self.target_vocab_size), dtype=torch.float32, device=self.device)
+        check(lib.aocr_forward_logits(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, L, int(training), ptr(logits),
+                                      ptr(self._scal[0:1])), "aocr_forward_logits")
+        return logits.cpu(), float(self._scal[0].item())
+
+    def train_forward_backward(self, batch, grad_scale=None):
+        """feval only (no parameter update): loss sum; gradients stay in self.grad_params."""
+        images, targets, targets_eval = self._upload(batch)
+        B, _, _, W = images.shape
+        L = targets.shape[1]
+        check(lib.aocr_model_set_stream(self._h, self._stream()))
+        check(lib.aocr_train_forward_backward(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, L,
+                                              (1.0 / B) if grad_scale is None else grad_scale, ptr(self._scal[0:1])),
+              "aocr_train_forward_backward")
+        return float(self._scal[0].item())
+
+    def sgd_step(self, lr=None, clip=5.0):
+        norms = self._scal[2:12]
+        check(lib.aocr_sgd_step(self._h, float(self.optim_state["learningRate"] if lr is None else lr), clip, ptr(norms)))
+        return norms.cpu().numpy().reshape(5, 2)
+
+    # ------------------------------------------------------------------ misc API of the reference class
+    def vis(self, output_dir):
+        """model:vis, model.lua:708-718."""
+        self.visualize = True
+        self.visualize_path = os.path.join(output_dir, "results.txt")
+        try:
+            self.visualize_file = open(self.visualize_path, "w")
+        except OSError:
+            print(f"Error: visualize file {self.visualize_path} cannot be created")
+            self.visualize = False
+            self.visualize_file = None
+
+    def save(self, model_path):
+        """model:save, model.lua:720-725 ({nets, config, global_step, optim_state}); nets = the flat parameter vector."""
+        torch.save({"params": self.params.detach().cpu(), "bn_state": self.bn_state.detach().cpu(), "config": self.config,
+                    "global_step": self.global_step, "optim_state": dict(self.optim_state)}, model_path)
+
+    def shutdown(self):
+        if self.visualize_file:
+            self.visualize_file.close()
+            self.visualize_file = None
+        if self._h is not None:
+            lib.aocr_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                lib.aocr_model_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

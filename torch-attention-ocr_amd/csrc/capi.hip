@@ -1,0 +1,360 @@
+// capi.hip -- the extern "C" surface declared in include/aocr.h.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include "model.h"
+
+using namespace aocr;
+
+static thread_local std::string g_err;
+static int fail(const char* fmt, ...) {
+  char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf; return 1;
+}
+static int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail("%s: %s", what, hipGetErrorString(e));
+  return 0;
+}
+#define REQUIRE(cond, ...) do { if (!(cond)) return fail(__VA_ARGS__); } while (0)
+
+static int check_cfg(const aocr_config* c) {
+  REQUIRE(c, "config is NULL");
+  REQUIRE(c->batch_size >= 1 && c->img_h >= 32 && c->img_h % 16 == 0, "bad batch_size/img_h");
+  REQUIRE(c->max_img_w >= 8, "max_img_w too small");
+  REQUIRE(c->enc_hidden >= 16 && c->enc_hidden % 16 == 0, "enc_hidden must be a multiple of 16");
+  REQUIRE(c->enc_layers >= 1 && c->enc_layers <= MAXL && c->dec_layers >= 1 && c->dec_layers <= MAXL, "layers must be 1..%d", MAXL);
+  REQUIRE(c->vocab >= 4 && c->vocab <= LOGIT_LD, "vocab must be 4..%d", LOGIT_LD);
+  REQUIRE(c->emb >= 1 && c->max_decoder_l >= 1 && c->max_beam >= 1, "bad emb/max_decoder_l/max_beam");
+  REQUIRE(c->compute == AOCR_COMPUTE_F32 || c->compute == AOCR_COMPUTE_BF16, "bad compute type");
+  return 0;
+}
+
+extern "C" {
+
+const char* aocr_last_error(void) { return g_err.c_str(); }
+int aocr_version(void) { return AOCR_VERSION; }
+
+int aocr_param_counts(const aocr_config* cfg, int64_t counts[AOCR_NUM_GROUPS]) {
+  if (check_cfg(cfg)) return 1;
+  Layout L = build_layout(*cfg);
+  for (int g = 0; g < AOCR_NUM_GROUPS; ++g) counts[g] = L.group_off[g + 1] - L.group_off[g];
+  return 0;
+}
+int aocr_param_entry(const aocr_config* cfg, int32_t index, char name[64], int32_t* group, int64_t* offset, int32_t* ndim,
+                     int64_t shape[4]) {
+  if (check_cfg(cfg)) return -1;
+  Layout L = build_layout(*cfg);
+  if (index < 0 || index >= (int)L.e.size()) return 1;
+  const ParamEntry& e = L.e[index];
+  snprintf(name, 64, "%s", e.name.c_str()); *group = e.group; *offset = e.offset; *ndim = e.ndim;
+  for (int i = 0; i < 4; ++i) shape[i] = e.shape[i];
+  return 0;
+}
+int64_t aocr_bn_state_count(void) { return 2 * (256 + 512 + 512); }
+
+static void bind_params(aocr_model* m) {
+  auto find = [&](const std::string& n) -> int64_t {
+    for (auto& e : m->layout.e) if (e.name == n) return e.offset;
+    return -1;
+  };
+  static const int convs[7][4] = {{1, 64, 3, 1}, {64, 128, 3, 1}, {128, 256, 3, 1}, {256, 256, 3, 1},
+                                  {256, 512, 3, 1}, {512, 512, 3, 1}, {512, 512, 2, 0}};
+  float* bnst = m->bn_state; int bi = 0;
+  for (int i = 1; i <= 7; ++i) {
+    char nm[64];
+    ConvP& c = m->conv[i]; c.cin = convs[i - 1][0]; c.cout = convs[i - 1][1]; c.ks = convs[i - 1][2]; c.pad = convs[i - 1][3];
+    snprintf(nm, 64, "cnn.conv%d.w", i); int64_t o = find(nm); c.w = m->params + o; c.dw = m->grads + o;
+    snprintf(nm, 64, "cnn.conv%d.b", i); o = find(nm); c.b = m->params + o; c.db = m->grads + o;
+    if (i == 3 || i == 5 || i == 7) {
+      BnP& b = m->bn[i]; b.C = c.cout;
+      snprintf(nm, 64, "cnn.bn%d.w", i); o = find(nm); b.w = m->params + o; b.dw = m->grads + o;
+      snprintf(nm, 64, "cnn.bn%d.b", i); o = find(nm); b.b = m->params + o; b.db = m->grads + o;
+      b.rm = bnst; b.rv = bnst + b.C; bnst += 2 * b.C;
+      b.save = m->bn_save + (size_t)bi * 1024; ++bi;
+    }
+  }
+  auto lstm = [&](const char* prefix, LstmP* arr, int layers, int in0, int H) {
+    for (int l = 1; l <= layers; ++l) {
+      char nm[64]; LstmP& p = arr[l - 1]; p.in = l == 1 ? in0 : H; int64_t o;
+      snprintf(nm, 64, "%s.l%d.i2h.w", prefix, l); o = find(nm); p.wi = m->params + o; p.dwi = m->grads + o;
+      snprintf(nm, 64, "%s.l%d.i2h.b", prefix, l); o = find(nm); p.bi = m->params + o; p.dbi = m->grads + o;
+      snprintf(nm, 64, "%s.l%d.h2h.w", prefix, l); o = find(nm); p.wh = m->params + o; p.dwh = m->grads + o;
+      snprintf(nm, 64, "%s.l%d.h2h.b", prefix, l); o = find(nm); p.bh = m->params + o; p.dbh = m->grads + o;
+    }
+  };
+  lstm("enc_fw", m->enc[0], m->Le, 512, m->He);
+  lstm("enc_bw", m->enc[1], m->Le, 512, m->He);
+  lstm("dec", m->dec, m->Ld, m->E + (m->cfg.input_feed ? m->Hd : 0), m->Hd);
+  int64_t o = find("dec.lookup"); m->lookup = m->params + o; m->dlookup = m->grads + o;
+  o = find("dec.attn.wa"); m->wa = m->params + o; m->dwa = m->grads + o;
+  o = find("dec.attn.wc"); m->wc = m->params + o; m->dwc = m->grads + o;
+  o = find("proj.w"); m->wo = m->params + o; m->dwo = m->grads + o;
+  o = find("proj.b"); m->bo = m->params + o; m->dbo = m->grads + o;
+}
+
+static void init_model_fields(aocr_model* m, const aocr_config* cfg) {
+  m->cfg = *cfg; m->bf16 = cfg->compute == AOCR_COMPUTE_BF16;
+  m->He = cfg->enc_hidden; m->Hd = 2 * cfg->enc_hidden; m->Le = cfg->enc_layers; m->Ld = cfg->dec_layers;
+  m->E = cfg->emb; m->V = cfg->vocab; m->last_valid = 0;
+}
+
+size_t aocr_workspace_bytes(const aocr_config* cfg) {
+  if (check_cfg(cfg)) return 0;
+  aocr_model* m = new (std::nothrow) aocr_model();
+  if (!m) return 0;
+  init_model_fields(m, cfg);
+  size_t r = model_carve(m, nullptr, 0) == 0 ? m->ws_bytes : 0;
+  delete m;
+  return r;
+}
+
+int aocr_model_create(const aocr_config* cfg, float* params_dev, float* grads_dev, float* bn_state_dev, void* workspace_dev,
+                      size_t workspace_bytes, void* stream, aocr_model** out) {
+  if (check_cfg(cfg)) return 1;
+  REQUIRE(params_dev && grads_dev && bn_state_dev && workspace_dev && out, "NULL pointer argument");
+  REQUIRE(((uintptr_t)params_dev & 15) == 0 && ((uintptr_t)grads_dev & 15) == 0 && ((uintptr_t)workspace_dev & 255) == 0,
+          "params/grads must be 16-byte and the workspace 256-byte aligned");
+  aocr_model* m = new (std::nothrow) aocr_model();
+  REQUIRE(m, "out of host memory");
+  init_model_fields(m, cfg);
+  m->s = (hipStream_t)stream; m->params = params_dev; m->grads = grads_dev; m->bn_state = bn_state_dev;
+  m->layout = build_layout(*cfg);
+  if (model_carve(m, workspace_dev, workspace_bytes) != 0) { delete m; return fail("workspace too small: need %zu bytes", aocr_workspace_bytes(cfg)); }
+  bind_params(m);
+  *out = m;
+  return 0;
+}
+int aocr_model_destroy(aocr_model* m) { delete m; return 0; }
+int aocr_model_set_stream(aocr_model* m, void* stream) { REQUIRE(m, "NULL model"); m->s = (hipStream_t)stream; return 0; }
+
+static int step_dims(aocr_model* m, int32_t B, int32_t W, int32_t L, Dims& d) {
+  REQUIRE(m, "NULL model");
+  REQUIRE(B >= 1 && B <= m->cfg.batch_size, "B=%d outside 1..%d", B, m->cfg.batch_size);
+  REQUIRE(W >= 8 && W <= m->cfg.max_img_w, "W=%d outside 8..%d", W, m->cfg.max_img_w);
+  REQUIRE(L >= 1 && L <= m->cfg.max_decoder_l, "max_decoder_l (%d) < target_l (%d)!", m->cfg.max_decoder_l, L);   // model.lua:264
+  REQUIRE(make_dims(m->cfg, B, W, L, d), "image too small for the CNN");
+  return 0;
+}
+
+int aocr_train_forward_backward(aocr_model* m, const float* images_dev, const int32_t* targets_dev, const int32_t* targets_eval_dev,
+                                int32_t B, int32_t W, int32_t L, float grad_scale, float* loss_dev) {
+  Dims d; if (step_dims(m, B, W, L, d)) return 1;
+  REQUIRE(images_dev && targets_dev && targets_eval_dev, "NULL input");
+  hipMemsetAsync(m->grads, 0, (size_t)m->layout.group_off[AOCR_NUM_GROUPS] * sizeof(float), m->s);      // model.lua:637-639
+  cnn_forward(m, images_dev, d, 1, 1);
+  encoder_forward(m, d);
+  decoder_tf_forward(m, d, targets_dev, 1, L, true);
+  loss_and_dlogits(m, d, targets_eval_dev, 1, L, grad_scale, true, loss_dev);
+  backward_all(m, images_dev, targets_dev, d);
+  m->last = d; m->last_valid = 1;
+  return check_launch("aocr_train_forward_backward");
+}
+
+int aocr_sgd_step(aocr_model* m, float lr, float clip, float* norms_dev) {
+  REQUIRE(m, "NULL model");
+  sgd_clip_update(m->s, m->params, m->grads, m->layout.group_off, lr, clip, norms_dev, m->sgd_scratch);
+  return check_launch("aocr_sgd_step");
+}
+
+int aocr_forward_logits(aocr_model* m, const float* images_dev, const int32_t* targets_dev, const int32_t* targets_eval_dev,
+                        int32_t B, int32_t W, int32_t L, int32_t training, float* logits_dev, float* loss_dev) {
+  Dims d; if (step_dims(m, B, W, L, d)) return 1;
+  REQUIRE(images_dev && targets_dev, "NULL input");
+  cnn_forward(m, images_dev, d, training, 0);
+  encoder_forward(m, d);
+  decoder_tf_forward(m, d, targets_dev, 1, L, false);
+  if (targets_eval_dev) loss_and_dlogits(m, d, targets_eval_dev, 1, L, 0.f, false, loss_dev);
+  if (logits_dev) copy2d(m->s, m->logits, LOGIT_LD, logits_dev, m->V, L * B, m->V);
+  m->last = d; m->last_valid = 1;
+  return check_launch("aocr_forward_logits");
+}
+
+__global__ void pad_targets_kernel(const int32_t* src, int32_t* dst, int B, int L, int Lt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Lt) return;
+  int b = i / Lt, t = i - b * Lt;
+  dst[i] = t < L ? src[b * L + t] : 1;                                    // model.lua:267-272: pad with PAD
+}
+
+int aocr_decode(aocr_model* m, const float* images_dev, const int32_t* targets_dev, const int32_t* targets_eval_dev, int32_t B,
+                int32_t W, int32_t L, int32_t beam, int32_t* labels_dev, float* scores_dev, float* gold_scores_dev, float* loss_dev) {
+  Dims d; if (step_dims(m, B, W, L, d)) return 1;
+  REQUIRE(images_dev && targets_dev && targets_eval_dev && labels_dev && scores_dev, "NULL argument");
+  if (beam > m->V) beam = m->V;                                           // model.lua:229
+  REQUIRE(beam >= 1 && beam <= m->cfg.max_beam, "beam=%d outside 1..%d", beam, m->cfg.max_beam);
+  const int Lt = m->cfg.max_decoder_l;                                    // model.lua:273: always max_decoder_l steps (S8)
+  hipLaunchKernelGGL(pad_targets_kernel, dim3(cdiv((int64_t)B * Lt, 256)), dim3(256), 0, m->s, targets_dev, m->tgt_pad, B, L, Lt);
+  hipLaunchKernelGGL(pad_targets_kernel, dim3(cdiv((int64_t)B * Lt, 256)), dim3(256), 0, m->s, targets_eval_dev, m->tge_pad, B, L, Lt);
+  d.L = Lt;
+  cnn_forward(m, images_dev, d, 0, 0);                                    // model.lua:280-281: evaluate()
+  encoder_forward(m, d);
+  decode_beam(m, d, m->tgt_pad, beam, labels_dev, scores_dev);
+  // gold pass, model.lua:589-627
+  decoder_tf_forward(m, d, m->tgt_pad, 1, Lt, false);
+  loss_and_dlogits(m, d, m->tge_pad, 1, Lt, 0.f, false, loss_dev);
+  if (gold_scores_dev) gold_scores(m->s, m->nll_rows, gold_scores_dev, Lt, B);
+  m->last = d; m->last_valid = 1;
+  return check_launch("aocr_decode");
+}
+
+int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32_t* ndim, int64_t shape[4]) {
+  REQUIRE(m && name && ptr_dev && ndim && shape, "NULL argument");
+  REQUIRE(m->last_valid, "no step has run yet");
+  const Dims& d = m->last; std::string n = name;
+  for (int i = 0; i < 4; ++i) shape[i] = 1;
+  if (n == "feats") { *ptr_dev = m->X; *ndim = 3; shape[0] = d.T; shape[1] = d.B; shape[2] = 512; }
+  else if (n == "dfeats") { *ptr_dev = m->dX; *ndim = 3; shape[0] = d.T; shape[1] = d.B; shape[2] = 512; }
+  else if (n == "context") { *ptr_dev = m->context; *ndim = 3; shape[0] = d.B; shape[1] = d.T; shape[2] = m->Hd; }
+  else if (n == "dcontext") { *ptr_dev = m->dctx; *ndim = 3; shape[0] = d.B; shape[1] = d.T; shape[2] = m->Hd; }
+  else if (n == "logits") { *ptr_dev = m->logits; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = LOGIT_LD; }
+  else if (n == "outs") { *ptr_dev = m->out_all + (size_t)d.B * m->Hd; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = m->Hd; }
+  else if (n == "conv1") { *ptr_dev = m->A1; *ndim = 4; shape[0] = d.B; shape[1] = d.H1; shape[2] = d.W1; shape[3] = 64; }
+  else if (n == "conv2") { *ptr_dev = m->A2; *ndim = 4; shape[0] = d.B; shape[1] = d.H2; shape[2] = d.W2; shape[3] = 128; }
+  else if (n == "conv6") { *ptr_dev = m->A6; *ndim = 4; shape[0] = d.B; shape[1] = d.H6; shape[2] = d.W2; shape[3] = 512; }
+  else return fail("unknown tensor '%s'", name);
+  return 0;
+}
+
+int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_per_launch, double* flops_per_launch) {
+  REQUIRE(m && ms_per_launch && flops_per_launch, "NULL argument");
+  REQUIRE(m->last_valid, "run a step first");
+  REQUIRE(which == 0, "unknown kernel id %d", which);
+  REQUIRE(iters >= 1, "iters must be >= 1");
+  const Dims& d = m->last;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto run = [&]() {
+    conv_forward(m->s, m->bf16, m->A5, m->conv[6].w, m->conv[6].b, m->A6, m->idx6, d.B, d.H4, d.W2, 512, 512, 3, 1, 1, 2);
+  };
+  run();
+  hipEventRecord(e0, m->s);
+  for (int i = 0; i < iters; ++i) run();
+  hipEventRecord(e1, m->s);
+  hipEventSynchronize(e1);
+  float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  *ms_per_launch = ms / iters;
+  *flops_per_launch = 2.0 * (double)d.B * d.H4 * d.W2 * 512.0 * (9.0 * 512.0);
+  return check_launch("aocr_profile_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
+// module-level entry points
+// ---------------------------------------------------------------------------------------------
+int aocr_gemm(void* stream, int32_t compute, const float* A_dev, int64_t lda, int32_t a_kmajor, const float* B_dev, int64_t ldb,
+              int32_t b_kmajor, float* C_dev, int64_t ldc, int32_t M, int32_t N, int32_t K, const float* bias_dev, int32_t accumulate) {
+  REQUIRE(A_dev && B_dev && C_dev && M >= 0 && N >= 0 && K >= 0, "bad gemm arguments");
+  int rc = gemm((hipStream_t)stream, compute == AOCR_COMPUTE_BF16, A_dev, lda, a_kmajor != 0, B_dev, ldb, b_kmajor != 0, C_dev, ldc,
+                M, N, K, bias_dev, nullptr, accumulate ? EP_ACCUM : 0);
+  REQUIRE(rc == 0, "gemm: the (A column-major, B row-major-by-K) combination is not supported");
+  return check_launch("aocr_gemm");
+}
+int aocr_conv2d_forward(void* stream, int32_t compute, const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,
+                        uint8_t* idx_dev, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t pad,
+                        int32_t relu, int32_t pool) {
+  REQUIRE(x_dev && w_dev && y_dev, "NULL argument");
+  REQUIRE(Cin % 16 == 0 && Cout % 16 == 0, "Cin and Cout must be multiples of 16 (the 1-channel first layer has its own entry point)");
+  REQUIRE(pool >= 0 && pool <= 2 && (pool == 0 || idx_dev), "bad pool mode / missing idx");
+  conv_forward((hipStream_t)stream, compute == AOCR_COMPUTE_BF16, x_dev, w_dev, bias_dev, y_dev, idx_dev, B, H, W, Cin, Cout, ksize, pad,
+               relu, pool);
+  return check_launch("aocr_conv2d_forward");
+}
+int aocr_conv2d_backward_data(void* stream, int32_t compute, const float* dy_dev, const float* w_dev, float* dx_dev, int32_t B, int32_t H,
+                              int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t pad) {
+  REQUIRE(dy_dev && w_dev && dx_dev && Cin % 16 == 0 && Cout % 16 == 0, "bad arguments");
+  conv_backward_data((hipStream_t)stream, compute == AOCR_COMPUTE_BF16, dy_dev, w_dev, dx_dev, B, H, W, Cin, Cout, ksize, pad);
+  return check_launch("aocr_conv2d_backward_data");
+}
+int aocr_conv2d_backward_filter(void* stream, int32_t compute, const float* x_dev, const float* dy_dev, float* dw_dev, float* dbias_dev,
+                                int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t pad) {
+  REQUIRE(x_dev && dy_dev && dw_dev && Cin % 16 == 0 && Cout % 16 == 0, "bad arguments");
+  conv_backward_filter((hipStream_t)stream, compute == AOCR_COMPUTE_BF16, x_dev, dy_dev, dw_dev, dbias_dev, B, H, W, Cin, Cout, ksize, pad);
+  return check_launch("aocr_conv2d_backward_filter");
+}
+int aocr_unpool_relu_backward(void* stream, const float* dpooled_dev, const float* pooled_dev, const uint8_t* idx_dev, float* dy_dev,
+                              int32_t B, int32_t Ho, int32_t Wo, int32_t C, int32_t pool) {
+  REQUIRE(dpooled_dev && pooled_dev && idx_dev && dy_dev && (pool == 1 || pool == 2) && C % 4 == 0, "bad arguments");
+  unpool_relu_backward((hipStream_t)stream, dpooled_dev, pooled_dev, idx_dev, dy_dev, B, Ho, Wo, C, pool);
+  return check_launch("aocr_unpool_relu_backward");
+}
+int aocr_conv1_forward(void* stream, const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int32_t B, int32_t H,
+                       int32_t W) {
+  REQUIRE(x_dev && w_dev && bias_dev && y_dev, "NULL argument");
+  conv1_forward((hipStream_t)stream, x_dev, w_dev, bias_dev, y_dev, B, H, W);
+  return check_launch("aocr_conv1_forward");
+}
+int aocr_conv1_backward(void* stream, const float* x_dev, const float* w_dev, const float* bias_dev, const float* dy_pooled_dev,
+                        float* dw_dev, float* dbias_dev, int32_t B, int32_t H, int32_t W) {
+  REQUIRE(x_dev && w_dev && bias_dev && dy_pooled_dev && dw_dev && dbias_dev, "NULL argument");
+  conv1_backward((hipStream_t)stream, x_dev, w_dev, bias_dev, dy_pooled_dev, dw_dev, dbias_dev, B, H, W);
+  return check_launch("aocr_conv1_backward");
+}
+int aocr_batchnorm_relu_forward(void* stream, const float* x_dev, float* y_dev, const float* weight_dev, const float* bias_dev,
+                                float* running_mean_dev, float* running_var_dev, float* save_dev, void* scratch_dev, int64_t rows,
+                                int32_t C, int32_t training, int32_t update_running, int32_t tb_rows) {
+  REQUIRE(x_dev && y_dev && weight_dev && bias_dev && running_mean_dev && running_var_dev && save_dev && scratch_dev, "NULL argument");
+  REQUIRE(C % 4 == 0 && C <= 512, "C must be a multiple of 4 and <= 512");
+  bn_relu_forward((hipStream_t)stream, x_dev, y_dev, weight_dev, bias_dev, running_mean_dev, running_var_dev, save_dev, scratch_dev, rows, C,
+                  training, update_running, tb_rows);
+  return check_launch("aocr_batchnorm_relu_forward");
+}
+int aocr_batchnorm_relu_backward(void* stream, const float* x_dev, const float* y_dev, const float* dA_dev, const float* weight_dev,
+                                 const float* save_dev, float* dx_dev, float* dweight_dev, float* dbias_dev, void* scratch_dev,
+                                 int64_t rows, int32_t C, int32_t tb_rows) {
+  REQUIRE(x_dev && y_dev && dA_dev && weight_dev && save_dev && dx_dev && dweight_dev && dbias_dev && scratch_dev, "NULL argument");
+  bn_relu_backward((hipStream_t)stream, x_dev, y_dev, dA_dev, weight_dev, save_dev, dx_dev, dweight_dev, dbias_dev, scratch_dev, rows, C,
+                   tb_rows);
+  return check_launch("aocr_batchnorm_relu_backward");
+}
+int aocr_lstm_cell_forward(void* stream, int32_t compute, const float* x_dev, int32_t in_size, const float* h_prev_dev,
+                           const float* c_prev_dev, const float* w_i2h_dev, const float* b_i2h_dev, const float* w_h2h_dev,
+                           const float* b_h2h_dev, float* c_dev, float* h_dev, float* gates_dev, int32_t B, int32_t H) {
+  REQUIRE(x_dev && h_prev_dev && c_prev_dev && w_i2h_dev && b_i2h_dev && w_h2h_dev && b_h2h_dev && c_dev && h_dev, "NULL argument");
+  REQUIRE(in_size % 16 == 0 && H % 16 == 0, "in_size and H must be multiples of 16");
+  GatesFwdArgs z;
+  z.a = make_loadk2(x_dev, in_size, in_size, h_prev_dev, H, H, B);
+  z.b = make_loadk2(w_i2h_dev, in_size, in_size, w_h2h_dev, H, H, 4 * H);
+  z.K = in_size + H;
+  EpGatesFwd& e = z.ep; e.zx = nullptr; e.ldzx = 0; e.b1 = b_i2h_dev; e.b2 = b_h2h_dev; e.c_prev = c_prev_dev; e.ldcp = H;
+  e.c_out = c_dev; e.ldc = H; e.h_out = h_dev; e.ldh = H; e.h_out2 = nullptr; e.ldh2 = 0; e.gates = gates_dev; e.ldg = 4 * H; e.M = B; e.H = H;
+  launch_small_gates_fwd((hipStream_t)stream, compute == AOCR_COMPUTE_BF16, 1, &z, B, H);
+  return check_launch("aocr_lstm_cell_forward");
+}
+int aocr_lstm_cell_backward(void* stream, const float* dc_dev, const float* dh_dev, const float* gates_dev, const float* c_prev_dev,
+                            const float* c_dev, float* dz_dev, float* dc_prev_dev, int32_t B, int32_t H) {
+  REQUIRE(dc_dev && dh_dev && gates_dev && c_prev_dev && c_dev && dz_dev && dc_prev_dev, "NULL argument");
+  GatesBwdArgs z;
+  z.a = make_loadk(dh_dev, H, B, 0); z.b = make_loadmn(dh_dev, H, H, 0); z.K = 0;     // no GEMM part: dh comes in through dh1
+  EpGatesBwd& e = z.ep; e.dh1 = dh_dev; e.ld1 = H; e.dh2 = nullptr; e.ld2 = 0; e.dc_in = dc_dev; e.lddc = H; e.gates = gates_dev; e.ldg = 4 * H;
+  e.c_prev = c_prev_dev; e.ldcp = H; e.c = c_dev; e.ldcc = H; e.dz = dz_dev; e.lddz = 4 * H; e.dc_out = dc_prev_dev; e.lddco = H; e.M = B; e.H = H;
+  launch_small_gates_bwd((hipStream_t)stream, false, 1, &z, B, H);
+  return check_launch("aocr_lstm_cell_backward");
+}
+int aocr_attention_forward(void* stream, const float* ctx_dev, const float* q_dev, float* a_dev, float* c_dev, int64_t ldc, int32_t B,
+                           int32_t T, int32_t Hd) {
+  REQUIRE(ctx_dev && q_dev && a_dev && c_dev && Hd % 4 == 0 && ldc % 4 == 0, "bad arguments");
+  attention_forward((hipStream_t)stream, ctx_dev, q_dev, a_dev, c_dev, ldc, B, T, Hd, 1);
+  return check_launch("aocr_attention_forward");
+}
+int aocr_attention_backward(void* stream, const float* ctx_dev, const float* q_dev, const float* a_dev, const float* dc_dev, int64_t lddc,
+                            float* ds_dev, float* dq_dev, int32_t B, int32_t T, int32_t Hd) {
+  REQUIRE(ctx_dev && a_dev && dc_dev && ds_dev && dq_dev && Hd % 4 == 0 && lddc % 4 == 0, "bad arguments");
+  attention_backward((hipStream_t)stream, ctx_dev, q_dev, a_dev, dc_dev, lddc, ds_dev, dq_dev, B, T, Hd);
+  return check_launch("aocr_attention_backward");
+}
+int aocr_logsoftmax_nll(void* stream, const float* logits_dev, int64_t ld, const int32_t* targets_dev, float* logp_dev, float* dlogits_dev,
+                        float* nll_rows_dev, int64_t rows, int32_t V, float grad_scale) {
+  REQUIRE(logits_dev && targets_dev && ld >= V, "bad arguments");
+  logsoftmax_nll((hipStream_t)stream, logits_dev, ld, targets_dev, 0, 1, (int)rows, logp_dev, dlogits_dev, nll_rows_dev, rows, V, grad_scale);
+  return check_launch("aocr_logsoftmax_nll");
+}
+int aocr_beam_select(void* stream, const float* logp_dev, const int32_t* prev_tok_dev, float* beam_scores_dev, int32_t* tokens_dev,
+                     int32_t* parents_dev, int32_t B, int32_t kin, int32_t kout, int32_t V) {
+  REQUIRE(logp_dev && beam_scores_dev && tokens_dev && parents_dev && kin >= 1 && kout >= 1 && kout <= kin * V, "bad arguments");
+  beam_select((hipStream_t)stream, logp_dev, prev_tok_dev, beam_scores_dev, tokens_dev, parents_dev, B, kin, kout, V);
+  return check_launch("aocr_beam_select");
+}
+
+}  // extern "C"

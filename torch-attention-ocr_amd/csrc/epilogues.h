@@ -1,0 +1,163 @@
+// epilogues.h -- accumulator consumers for mfma_gemm.h kernels.
+// quad<NT>(m, n, nstep, v): v[ni][i] is the result at row m+i (i = 0..3, m % 4 == 0) and
+// column n + nstep*ni -- or, for the gate epilogues, gate ni of hidden unit n.
+#pragma once
+#include "mfma_gemm.h"
+
+namespace aocr {
+
+enum : int { EP_RELU = 1, EP_TANH = 2, EP_ACCUM = 4, EP_ATOMIC = 8 };
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// C[m][n] = act(v + bias[n] + bias2[n]); columns >= N0 go to a second destination (C1, column n-N0).
+struct EpStore {
+  float* C; int64_t ldc; int M, N;
+  const float* bias; const float* bias2;
+  int flags;
+  float* C1; int64_t ldc1; int N0;       // optional split of the N range (C1 == nullptr: unused)
+  template <int NT> __device__ __forceinline__ void quad(int m, int n, int nstep, const float (&v)[NT][4]) const {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      int col = n + nstep * ni;
+      if (col >= N) continue;
+      float bb = 0.f;
+      if (bias) bb = bias[col];
+      if (bias2) bb += bias2[col];
+      float* base; int64_t ld; int cc;
+      if (C1 && col >= N0) { base = C1; ld = ldc1; cc = col - N0; } else { base = C; ld = ldc; cc = col; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int row = m + i;
+        if (row >= M) continue;
+        float x = v[ni][i] + bb;
+        if (flags & EP_RELU) x = fmaxf(x, 0.f);
+        if (flags & EP_TANH) x = tanhf(x);
+        float* p = base + (int64_t)row * ld + cc;
+        if (flags & EP_ATOMIC) atomicAdd(p, x);
+        else if (flags & EP_ACCUM) *p += x;
+        else *p = x;
+      }
+    }
+  }
+};
+
+// conv epilogue: bias, optional ReLU, optional fused max-pool (window = consecutive rows).
+struct EpConv {
+  float* y; uint8_t* idx; const float* bias; int Cout; int rows; int pmode; int relu;
+  template <int NT> __device__ __forceinline__ void quad(int m, int n, int nstep, const float (&v)[NT][4]) const {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      int col = n + nstep * ni;
+      if (col >= Cout) continue;
+      float bb = bias ? bias[col] : 0.f;
+      float x[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { x[i] = v[ni][i] + bb; if (relu) x[i] = fmaxf(x[i], 0.f); }
+      if (pmode == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (m + i < rows) y[(int64_t)(m + i) * Cout + col] = x[i];
+      } else if (pmode == 1) {
+        if (m < rows) {
+          float best = x[0]; int bi = 0;
+#pragma unroll
+          for (int i = 1; i < 4; ++i) if (x[i] > best) { best = x[i]; bi = i; }
+          int64_t o = (int64_t)(m >> 2) * Cout + col;
+          y[o] = best; if (idx) idx[o] = (uint8_t)bi;
+        }
+      } else {
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          int row = m + 2 * w;
+          if (row < rows) {
+            float a = x[2 * w], b = x[2 * w + 1];
+            int64_t o = (int64_t)(row >> 1) * Cout + col;
+            y[o] = (b > a) ? b : a; if (idx) idx[o] = (uint8_t)(b > a);
+          }
+        }
+      }
+    }
+  }
+};
+
+// LSTM cell forward, LSTM.lua:79-105: gates [in, forget, out, g]; v[g][i] = recurrent/input GEMM part.
+struct EpGatesFwd {
+  const float* zx; int64_t ldzx;          // optional pre-computed input part [m][g*H+j] (biases included)
+  const float* b1; const float* b2;       // optional biases [4H]
+  const float* c_prev; int64_t ldcp;
+  float* c_out; int64_t ldc;
+  float* h_out; int64_t ldh;
+  float* h_out2; int64_t ldh2;            // optional second copy of h (context slice / attention concat)
+  float* gates; int64_t ldg;              // optional, post-activation [m][g*H+j]
+  int M, H;
+  template <int NT> __device__ __forceinline__ void quad(int m, int j, int, const float (&v)[NT][4]) const {
+    static_assert(NT == 4, "gate epilogue needs the 4 gate tiles");
+    if (j >= H) return;
+    float bb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (b1) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bb[g] = b1[g * H + j] + b2[g * H + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int row = m + i;
+      if (row >= M) continue;
+      float z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        z[g] = v[g][i] + bb[g];
+        if (zx) z[g] += zx[(int64_t)row * ldzx + g * H + j];
+      }
+      float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), og = sigmoidf_(z[2]), gg = tanhf(z[3]);
+      float c = fg * c_prev[(int64_t)row * ldcp + j] + ig * gg;
+      float hh = og * tanhf(c);
+      c_out[(int64_t)row * ldc + j] = c;
+      h_out[(int64_t)row * ldh + j] = hh;
+      if (h_out2) h_out2[(int64_t)row * ldh2 + j] = hh;
+      if (gates) {
+        float* gp = gates + (int64_t)row * ldg + j;
+        gp[0] = ig; gp[H] = fg; gp[2 * H] = og; gp[3 * H] = gg;
+      }
+    }
+  }
+};
+
+// LSTM cell backward: v[0][i] = GEMM part of d(h_out) (recurrent or from the layer above).
+struct EpGatesBwd {
+  const float* dh1; int64_t ld1;          // optional extra d(h_out) terms [m][j]
+  const float* dh2; int64_t ld2;
+  const float* dc_in; int64_t lddc;       // optional d(c_out) [m][j]
+  const float* gates; int64_t ldg;
+  const float* c_prev; int64_t ldcp;
+  const float* c; int64_t ldcc;
+  float* dz; int64_t lddz;                // [m][g*H+j]
+  float* dc_out; int64_t lddco;           // d(c_prev)
+  int M, H;
+  template <int NT> __device__ __forceinline__ void quad(int m, int j, int, const float (&v)[NT][4]) const {
+    static_assert(NT == 1, "gate backward epilogue is single-tile");
+    if (j >= H) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int row = m + i;
+      if (row >= M) continue;
+      float dh = v[0][i];
+      if (dh1) dh += dh1[(int64_t)row * ld1 + j];
+      if (dh2) dh += dh2[(int64_t)row * ld2 + j];
+      const float* gp = gates + (int64_t)row * ldg + j;
+      float ig = gp[0], fg = gp[H], og = gp[2 * H], gg = gp[3 * H];
+      float tc = tanhf(c[(int64_t)row * ldcc + j]);
+      float dc = dh * og * (1.f - tc * tc);
+      if (dc_in) dc += dc_in[(int64_t)row * lddc + j];
+      float d_o = dh * tc;
+      float di = dc * gg, dg = dc * ig, df = dc * c_prev[(int64_t)row * ldcp + j];
+      float* zp = dz + (int64_t)row * lddz + j;
+      zp[0] = di * ig * (1.f - ig);
+      zp[H] = df * fg * (1.f - fg);
+      zp[2 * H] = d_o * og * (1.f - og);
+      zp[3 * H] = dg * (1.f - gg * gg);
+      dc_out[(int64_t)row * lddco + j] = dc * fg;
+    }
+  }
+};
+
+}  // namespace aocr

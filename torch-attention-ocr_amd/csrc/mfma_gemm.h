@@ -1,0 +1,324 @@
+// mfma_gemm.h -- MFMA matrix-product core shared by every contraction on the hot path.
+//
+// Design (gfx950 / CDNA4, 64-lane waves):
+//   * operands go global -> VGPR directly in MFMA fragment order (no LDS stage): the
+//     fp32-input MFMA (v_mfma_f32_32x32x2_f32) retires 4096 FLOP per 64 cycles, so one
+//     16-byte load per lane feeds four MFMAs; L1/L2 carry the small reuse between waves.
+//   * the two k-slots of a 32x32x2 MFMA are filled from a float4 (k = kb+4*half+s for
+//     step s): any k assignment is legal as long as A and B agree, and this one makes
+//     the K-contiguous operand a single dwordx4 load per 8-deep chunk.
+//   * bf16 mode converts the same fp32 operands to bf16 in registers
+//     (v_cvt_pk_bf16_f32) and issues v_mfma_f32_32x32x16_bf16 on 16-deep chunks.
+//   * "loaders" describe an operand (plain row-major, column-major, implicit im2col
+//     views of a channels-last tensor); "epilogues" consume the accumulator in quads of
+//     4 consecutive rows x 1 column (the 32x32 C/D layout puts rows 4h..4h+3 of a column
+//     in 4 consecutive registers), which is exactly a 2x2 / 2x1 max-pool window or the
+//     four LSTM gates of one hidden unit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aocr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// one operand fragment of a 32-row tile for one k-chunk: 4 floats (f32 mode, chunk 8)
+// or 8 floats (bf16 mode, chunk 16) per lane.
+template <int NV> struct Frag { float v[NV]; };
+
+template <bool BF16> struct Mode {
+  static constexpr int NV = BF16 ? 8 : 4;       // floats per lane per chunk
+  static constexpr int CHUNK = BF16 ? 16 : 8;   // k per chunk
+};
+
+// ---------------------------------------------------------------------------
+// loaders.  row(r) -> per-row context; load(frag, ctx, k) fills NV consecutive k
+// starting at k (k is a multiple of NV; out-of-range -> 0).
+// ---------------------------------------------------------------------------
+
+// K-contiguous: element(r,k) = p[r*ld + k]; optional second K segment (concatenated operands [x0 ; x1]).
+struct LoadK {
+  const float* p0; int64_t ld0; int K0;
+  const float* p1; int64_t ld1;
+  int rows; int K; int vec;                       // vec: 16-byte aligned -> dwordx4 loads
+  struct Ctx { const float* b0; const float* b1; bool ok; };
+  __device__ __forceinline__ Ctx row(int r) const {
+    Ctx c; c.ok = r < rows; int rr = c.ok ? r : 0;
+    c.b0 = p0 + (int64_t)rr * ld0; c.b1 = p1 ? p1 + (int64_t)rr * ld1 : p0;
+    return c;
+  }
+  template <int NV> __device__ __forceinline__ void load(Frag<NV>& f, const Ctx& c, int k) const {
+    const float* src = (k < K0) ? c.b0 + k : c.b1 + (k - K0);
+    if (c.ok && k + NV <= K && vec) {
+#pragma unroll
+      for (int j = 0; j < NV; j += 4) {
+        float4 t = *reinterpret_cast<const float4*>(src + j);
+        f.v[j] = t.x; f.v[j + 1] = t.y; f.v[j + 2] = t.z; f.v[j + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) f.v[j] = (c.ok && k + j < K) ? src[j] : 0.f;
+    }
+  }
+};
+
+// MN-contiguous: element(r,k) = p[k*ld + r]
+struct LoadMN {
+  const float* p; int64_t ld; int rows; int K;
+  struct Ctx { const float* b; bool ok; };
+  __device__ __forceinline__ Ctx row(int r) const { Ctx c; c.ok = r < rows; c.b = p + (c.ok ? r : 0); return c; }
+  template <int NV> __device__ __forceinline__ void load(Frag<NV>& f, const Ctx& c, int k) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) f.v[j] = (c.ok && k + j < K) ? c.b[(int64_t)(k + j) * ld] : 0.f;
+  }
+};
+
+// Implicit im2col of a channels-last tensor src (B,H,W,C), K-contiguous:
+//   row m  -> a pixel (b,y,x) of the "row grid" (Hr x Wr), ordered so that a pool window is
+//             4 (2x2) or 2 (2x1) consecutive rows when pmode != 0;
+//   k      -> (tap, c), tap = kh*KW + kw; element = src[b, y + sgn*kh + off, x + sgn*kw + off, c].
+// forward conv: sgn=+1, off=-pad over the input; data-gradient: sgn=-1, off=+pad over dY.
+struct LoadConvK {
+  const float* src; int H, W, C;
+  int KW, sgn, off;
+  int Hr, Wr;            // row grid (un-pooled)
+  int pmode, Hp, Wp;     // 0 none | 1 2x2 | 2 (kH2,kW1)
+  int rows, K;
+  struct Ctx { int b, y, x; bool ok; };
+  __device__ __forceinline__ Ctx row(int m) const {
+    Ctx c; c.ok = m < rows; int mm = c.ok ? m : 0;
+    if (pmode == 1) {
+      int win = mm >> 2, dy = (mm >> 1) & 1, dx = mm & 1;
+      int px = win % Wp; int t = win / Wp; int py = t % Hp; c.b = t / Hp;
+      c.y = 2 * py + dy; c.x = 2 * px + dx;
+    } else if (pmode == 2) {
+      int win = mm >> 1, dy = mm & 1;
+      c.x = win % Wr; int t = win / Wr; int py = t % Hp; c.b = t / Hp; c.y = 2 * py + dy;
+    } else {
+      c.x = mm % Wr; int t = mm / Wr; c.y = t % Hr; c.b = t / Hr;
+    }
+    return c;
+  }
+  template <int NV> __device__ __forceinline__ void load(Frag<NV>& f, const Ctx& c, int k) const {
+    int tap = k / C; int ch = k - tap * C; int kh = tap / KW; int kw = tap - kh * KW;
+    int sy = c.y + sgn * kh + off, sx = c.x + sgn * kw + off;
+    bool ok = c.ok && k < K && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+    if (ok) {
+      const float* s = src + (((int64_t)c.b * H + sy) * W + sx) * C + ch;
+#pragma unroll
+      for (int j = 0; j < NV; j += 4) {
+        float4 t = *reinterpret_cast<const float4*>(s + j);
+        f.v[j] = t.x; f.v[j + 1] = t.y; f.v[j + 2] = t.z; f.v[j + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) f.v[j] = 0.f;
+    }
+  }
+};
+
+// B operand of the data-gradient: element(n=ci, k=(tap,co)) = w[co][tap][ci], w stored [Cout][KK][Cin].
+struct LoadConvWT {
+  const float* w; int Cin, Cout, KK; int K;
+  struct Ctx { int ci; bool ok; };
+  __device__ __forceinline__ Ctx row(int r) const { Ctx c; c.ok = r < Cin; c.ci = c.ok ? r : 0; return c; }
+  template <int NV> __device__ __forceinline__ void load(Frag<NV>& f, const Ctx& c, int k) const {
+    int tap = k / Cout; int co = k - tap * Cout;       // NV consecutive k stay inside one tap (Cout % 16 == 0)
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      f.v[j] = (c.ok && k + j < K) ? w[((int64_t)(co + j) * KK + tap) * Cin + c.ci] : 0.f;
+  }
+};
+
+// B operand of the filter-gradient: element(n=(tap,ci), k=pixel p of the output grid) =
+//   x[b, y + kh - pad, x + kw - pad, ci]; x (B,H,W,Cin), output grid Ho x Wo in plain order.
+struct LoadConvXcol {
+  const float* x; int H, W, Cin; int KW, pad; int Ho, Wo; int N; int K;
+  struct Ctx { int kh, kw, ci; bool ok; };
+  __device__ __forceinline__ Ctx row(int n) const {
+    Ctx c; c.ok = n < N; int nn = c.ok ? n : 0; int tap = nn / Cin; c.ci = nn - tap * Cin;
+    c.kh = tap / KW; c.kw = tap - c.kh * KW; return c;
+  }
+  template <int NV> __device__ __forceinline__ void load(Frag<NV>& f, const Ctx& c, int k) const {
+    int px = k % Wo; int t = k / Wo; int py = t % Ho; int b = t / Ho;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      int sy = py + c.kh - pad, sx = px + c.kw - pad;
+      bool ok = c.ok && (k + j) < K && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+      f.v[j] = ok ? x[(((int64_t)b * H + sy) * W + sx) * Cin + c.ci] : 0.f;
+      if (++px == Wo) { px = 0; if (++py == Ho) { py = 0; ++b; } }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// MFMA step over one chunk
+// ---------------------------------------------------------------------------
+template <bool BF16, int WM, int WN>
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[WM][WN], const Frag<Mode<BF16>::NV> (&a)[WM],
+                                          const Frag<Mode<BF16>::NV> (&b)[WN]) {
+  if constexpr (BF16) {
+    bf16x8 ab[WM], bb[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ab[i][j] = (__bf16)a[i].v[j];
+#pragma unroll
+    for (int i = 0; i < WN; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bb[i][j] = (__bf16)b[i].v[j];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < WN; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[mi], bb[ni], acc[mi][ni], 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].v[s], b[ni].v[s], acc[mi][ni], 0, 0, 0);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// "big" kernel: 4 waves as 2x2, each wave a (32*WM) x (32*WN) tile.
+// grid = (ceil(N / (64*WN)), ceil(M / (64*WM)), ksplit); blockIdx.z owns k range
+// [z*kper, min(K,(z+1)*kper)).  Epilogue must be atomic/accumulating when ksplit > 1.
+// ---------------------------------------------------------------------------
+template <bool BF16, int WM, int WN, class AL, class BL, class EP>
+__global__ __launch_bounds__(256) void gemm_big_kernel(AL a, BL b, EP ep, int K, int kper) {
+  constexpr int NV = Mode<BF16>::NV, CH = Mode<BF16>::CHUNK;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * (64 * WM) + (wave >> 1) * (32 * WM);
+  const int n0 = blockIdx.x * (64 * WN) + (wave & 1) * (32 * WN);
+  const int kbeg = blockIdx.z * kper;
+  const int kend = min(K, kbeg + kper);
+
+  typename AL::Ctx ca[WM]; typename BL::Ctx cb[WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) ca[i] = a.row(m0 + 32 * i + r);
+#pragma unroll
+  for (int i = 0; i < WN; ++i) cb[i] = b.row(n0 + 32 * i + r);
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  Frag<NV> fa[WM], fb[WN], ga[WM], gb[WN];
+  if (kbeg < kend) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a.template load<NV>(fa[i], ca[i], kbeg + NV * h);
+#pragma unroll
+    for (int i = 0; i < WN; ++i) b.template load<NV>(fb[i], cb[i], kbeg + NV * h);
+  }
+  for (int kb = kbeg; kb < kend; kb += CH) {
+    const int kn = kb + CH;
+    if (kn < kend) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a.template load<NV>(ga[i], ca[i], kn + NV * h);
+#pragma unroll
+      for (int i = 0; i < WN; ++i) b.template load<NV>(gb[i], cb[i], kn + NV * h);
+    }
+    mma_chunk<BF16, WM, WN>(acc, fa, fb);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) fa[i] = ga[i];
+#pragma unroll
+    for (int i = 0; i < WN; ++i) fb[i] = gb[i];
+  }
+#pragma unroll
+  for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[WN][4];
+#pragma unroll
+      for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * q + i];
+      ep.template quad<WN>(m0 + 32 * mi + 8 * q + 4 * h, n0 + r, 32, v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// "small" kernel for the recurrent steps (M = batch): one 32 x (32*NT) output tile per
+// block, K split over the block's 4 waves and reduced through LDS.  With GATES the NT=4
+// tiles are the four gate blocks of the same 32 hidden units: B row = g*gate_stride + j.
+// blockIdx.z selects one of two argument sets (the two encoder directions).
+// ---------------------------------------------------------------------------
+template <class AL, class BL, class EP> struct SmallArgs { AL a; BL b; EP ep; int K; };
+
+template <bool BF16, int NT, bool GATES, class AL, class BL, class EP>
+__device__ __forceinline__ void gemm_small_body(const SmallArgs<AL, BL, EP>& g, int gate_stride, float* red) {
+  constexpr int NV = Mode<BF16>::NV, CH = Mode<BF16>::CHUNK;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 32;
+  const int n0 = GATES ? blockIdx.x * 32 : blockIdx.x * 32 * NT;
+  const int K = g.K;
+
+  typename AL::Ctx ca[1]; typename BL::Ctx cb[NT];
+  ca[0] = g.a.row(m0 + r);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) cb[i] = g.b.row(GATES ? i * gate_stride + n0 + r : n0 + 32 * i + r);
+
+  f32x16 acc[1][NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.f;
+
+  Frag<NV> fa[1], fb[NT], ga[1], gb[NT];
+  int kb = wave * CH;
+  if (kb < K) {
+    g.a.template load<NV>(fa[0], ca[0], kb + NV * h);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) g.b.template load<NV>(fb[i], cb[i], kb + NV * h);
+  }
+  for (; kb < K; kb += 4 * CH) {
+    const int kn = kb + 4 * CH;
+    if (kn < K) {
+      g.a.template load<NV>(ga[0], ca[0], kn + NV * h);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) g.b.template load<NV>(gb[i], cb[i], kn + NV * h);
+    }
+    mma_chunk<BF16, 1, NT>(acc, fa, fb);
+    fa[0] = ga[0];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) fb[i] = gb[i];
+  }
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[((wave * NT + ni) * 16 + e) * 64 + lane] = acc[0][ni][e];
+  __syncthreads();
+  const int q = wave;                       // this wave finalises rows 8q+4h .. +3
+  float v[NT][4];
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += red[((w * NT + ni) * 16 + 4 * q + i) * 64 + lane];
+      v[ni][i] = s;
+    }
+  g.ep.template quad<NT>(m0 + 8 * q + 4 * h, n0 + r, 32, v);
+}
+
+template <bool BF16, int NT, bool GATES, class AL, class BL, class EP>
+__global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs<AL, BL, EP> z0, SmallArgs<AL, BL, EP> z1,
+                                                         int gate_stride) {
+  __shared__ float red[4 * NT * 16 * 64];
+  if (blockIdx.z == 0) gemm_small_body<BF16, NT, GATES>(z0, gate_stride, red);
+  else gemm_small_body<BF16, NT, GATES>(z1, gate_stride, red);
+}
+
+}  // namespace aocr

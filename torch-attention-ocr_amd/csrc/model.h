@@ -1,0 +1,86 @@
+// model.h -- the aocr_model handle: parameter views, workspace carve-up and the fused step drivers.
+#pragma once
+#include <string>
+#include <vector>
+#include "../../include/aocr.h"
+#include "ops.h"
+
+namespace aocr {
+
+constexpr int MAXL = 4;          // max LSTM layers per stack
+constexpr int LOGIT_LD = 40;     // padded leading dimension of the (rows, vocab) logit buffers (vocab <= 40)
+
+struct ParamEntry { std::string name; int group; int64_t offset; int ndim; int64_t shape[4]; int64_t numel; };
+struct Layout { std::vector<ParamEntry> e; int64_t group_off[AOCR_NUM_GROUPS + 1]; };
+Layout build_layout(const aocr_config& c);
+
+struct ConvP { float *w, *b, *dw, *db; int cin, cout, ks, pad; };
+struct BnP { float *w, *b, *dw, *db, *rm, *rv, *save; int C; };
+struct LstmP { float *wi, *bi, *wh, *bh, *dwi, *dbi, *dwh, *dbh; int in; };
+
+struct Arena {
+  char* base; size_t off;
+  template <class T> T* get(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct Dims {                     // geometry of one step
+  int B, H, W, L, T;
+  int H1, W1, H2, W2, H4, H6, Ho7, Wo7;
+};
+bool make_dims(const aocr_config& c, int B, int W, int L, Dims& d);
+
+}  // namespace aocr
+
+struct aocr_model {
+  aocr_config cfg;
+  hipStream_t s;
+  bool bf16;
+  float *params, *grads, *bn_state;
+  aocr::Layout layout;
+  aocr::ConvP conv[8];            // 1..7
+  aocr::BnP bn[8];                // 3,5,7
+  aocr::LstmP enc[2][aocr::MAXL], dec[aocr::MAXL];
+  float *lookup, *dlookup, *wa, *dwa, *wc, *dwc, *wo, *bo, *dwo, *dbo;
+  int He, Hd, Le, Ld, E, V;
+
+  // ---- workspace
+  size_t ws_bytes;
+  // CNN
+  float *A1, *A2, *Y3, *A3, *A4, *Y5, *A5, *A6, *Y7, *X;
+  uint8_t *idx2, *idx4, *idx6;
+  float *G0, *G1, *dX;
+  void* bn_scratch; float* bn_save;
+  // encoder [dir][layer]
+  float *ezx[2][aocr::MAXL], *ehs[2][aocr::MAXL], *ecs[2][aocr::MAXL], *egates[2][aocr::MAXL], *edz[2][aocr::MAXL], *edc[2];
+  float *edxl[2];
+  float *context, *dctx;
+  // decoder, teacher-forced (rows = B, time-major)
+  float *emb_all, *zx1_all, *dhs[aocr::MAXL], *dcs[aocr::MAXL], *dgates[aocr::MAXL], *ddz[aocr::MAXL];
+  float *out_all, *cat_all, *q_all, *a_all, *logits, *dlogits, *nll_rows;
+  float *dout_proj, *dpre_all, *dcat_all, *ds_all, *dq_all, *demb_all;
+  float *dh_rec[aocr::MAXL], *dc_st[aocr::MAXL], *dfeed, *loss_tmp;
+  // decode (rows = B*beam)
+  float *bc[2][aocr::MAXL], *bh[2][aocr::MAXL], *bfeed[2], *bc_new[aocr::MAXL], *bh_new[aocr::MAXL];
+  float *bemb, *bzx1, *bq, *ba, *bcat, *bout, *blogits, *blogp, *beam_scores;
+  int32_t *btok, *bpar, *hist_tok, *hist_par, *tgt_pad, *tge_pad;
+  void* sgd_scratch;
+
+  aocr::Dims last;                // dims of the last step (for the parity taps)
+  int last_valid;
+};
+
+namespace aocr {
+int model_carve(aocr_model* m, void* base, size_t bytes);          // returns 0 / -1 (too small); base==nullptr: size only
+void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training, int update_running);
+void encoder_forward(aocr_model* m, const Dims& d);
+void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_t st, int64_t sb, bool keep_gates);
+void loss_and_dlogits(aocr_model* m, const Dims& d, const int32_t* tge, int64_t st, int64_t sb, float grad_scale, bool want_grad,
+                      float* loss_dev);
+void backward_all(aocr_model* m, const float* images, const int32_t* tgt, const Dims& d);
+void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int32_t* labels, float* scores);
+}  // namespace aocr

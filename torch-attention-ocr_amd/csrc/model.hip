@@ -1,0 +1,505 @@
+// model.hip -- fused sequence-level drivers: what Model:step's feval does (src/model/model.lua:284-696),
+// as straight-line kernel launches on one HIP stream with a native time loop in place of the reference's
+// cloned cells (model_utils.lua:3-50).  Weight gradients of every recurrent Linear are hoisted out of the
+// time loops into one large-K contraction each; the loops keep only what is truly sequential.
+#include "model.h"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace aocr {
+
+// ------------------------------------------------------------------------------------------------
+// parameter layout: Torch7 getParameters() order per group (module order, weight then bias), model.lua:150,163-168
+// ------------------------------------------------------------------------------------------------
+static void add_entry(Layout& L, int64_t& off, const std::string& name, int group, std::initializer_list<int64_t> shape) {
+  ParamEntry e; e.name = name; e.group = group; e.offset = off; e.ndim = (int)shape.size(); e.numel = 1;
+  int i = 0; for (int64_t v : shape) { e.shape[i++] = v; e.numel *= v; }
+  for (; i < 4; ++i) e.shape[i] = 1;
+  off += e.numel; L.e.push_back(e);
+}
+Layout build_layout(const aocr_config& c) {
+  Layout L; int64_t off = 0;
+  const int He = c.enc_hidden, Hd = 2 * He;
+  static const int convs[7][4] = {{1, 64, 3, 1}, {64, 128, 3, 1}, {128, 256, 3, 1}, {256, 256, 3, 1},
+                                  {256, 512, 3, 1}, {512, 512, 3, 1}, {512, 512, 2, 0}};
+  L.group_off[0] = 0;
+  for (int i = 0; i < 7; ++i) {                                            // cnn.lua:12-42
+    char nm[64];
+    snprintf(nm, 64, "cnn.conv%d.w", i + 1); add_entry(L, off, nm, 0, {convs[i][1], convs[i][2], convs[i][2], convs[i][0]});
+    snprintf(nm, 64, "cnn.conv%d.b", i + 1); add_entry(L, off, nm, 0, {convs[i][1]});
+    if (i == 2 || i == 4 || i == 6) {
+      snprintf(nm, 64, "cnn.bn%d.w", i + 1); add_entry(L, off, nm, 0, {convs[i][1]});
+      snprintf(nm, 64, "cnn.bn%d.b", i + 1); add_entry(L, off, nm, 0, {convs[i][1]});
+    }
+  }
+  L.group_off[1] = off;
+  auto lstm = [&](const char* prefix, int group, int in0, int H, int layers) {
+    for (int l = 1; l <= layers; ++l) {
+      int in = l == 1 ? in0 : H; char nm[64];
+      snprintf(nm, 64, "%s.l%d.i2h.w", prefix, l); add_entry(L, off, nm, group, {4 * H, in});
+      snprintf(nm, 64, "%s.l%d.i2h.b", prefix, l); add_entry(L, off, nm, group, {4 * H});
+      snprintf(nm, 64, "%s.l%d.h2h.w", prefix, l); add_entry(L, off, nm, group, {4 * H, H});
+      snprintf(nm, 64, "%s.l%d.h2h.b", prefix, l); add_entry(L, off, nm, group, {4 * H});
+    }
+  };
+  lstm("enc_fw", 1, 512, He, c.enc_layers); L.group_off[2] = off;
+  lstm("enc_bw", 2, 512, He, c.enc_layers); L.group_off[3] = off;
+  add_entry(L, off, "dec.lookup", 3, {c.vocab, c.emb});
+  lstm("dec", 3, c.emb + (c.input_feed ? Hd : 0), Hd, c.dec_layers);
+  add_entry(L, off, "dec.attn.wa", 3, {Hd, Hd});
+  add_entry(L, off, "dec.attn.wc", 3, {Hd, 2 * Hd});
+  L.group_off[4] = off;
+  add_entry(L, off, "proj.w", 4, {c.vocab, Hd});
+  add_entry(L, off, "proj.b", 4, {c.vocab});
+  L.group_off[5] = off;
+  return L;
+}
+
+bool make_dims(const aocr_config& c, int B, int W, int L, Dims& d) {
+  d.B = B; d.H = c.img_h; d.W = W; d.L = L;
+  d.H1 = d.H / 2; d.W1 = W / 2;               // after pool 1
+  d.H2 = d.H1 / 2; d.W2 = d.W1 / 2;           // after pool 2 (width stays W2 from here)
+  d.H4 = d.H2 / 2; d.H6 = d.H4 / 2;           // after the two (2,1) pools
+  d.Ho7 = d.H6 - 1; d.Wo7 = d.W2 - 1;         // conv7: 2x2, pad 0
+  d.T = d.Ho7 * d.Wo7;                        // View(512,-1), cnn.lua:44
+  return B >= 1 && d.Ho7 >= 1 && d.Wo7 >= 1 && L >= 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------------
+int model_carve(aocr_model* m, void* base, size_t bytes) {
+  const aocr_config& c = m->cfg;
+  Dims d; if (!make_dims(c, c.batch_size, c.max_img_w, c.max_decoder_l, d)) return -1;
+  Arena a; a.base = (char*)base; a.off = 0;
+  const size_t B = d.B, T = d.T, L = d.L, He = m->He, Hd = m->Hd, E = m->E;
+  const size_t R = B * (size_t)(c.max_beam > 1 ? c.max_beam : 1);
+  m->A1 = a.get<float>(B * d.H1 * d.W1 * 64);
+  m->A2 = a.get<float>(B * d.H2 * d.W2 * 128); m->idx2 = a.get<uint8_t>(B * d.H2 * d.W2 * 128);
+  m->Y3 = a.get<float>(B * d.H2 * d.W2 * 256); m->A3 = a.get<float>(B * d.H2 * d.W2 * 256);
+  m->A4 = a.get<float>(B * d.H4 * d.W2 * 256); m->idx4 = a.get<uint8_t>(B * d.H4 * d.W2 * 256);
+  m->Y5 = a.get<float>(B * d.H4 * d.W2 * 512); m->A5 = a.get<float>(B * d.H4 * d.W2 * 512);
+  m->A6 = a.get<float>(B * d.H6 * d.W2 * 512); m->idx6 = a.get<uint8_t>(B * d.H6 * d.W2 * 512);
+  m->Y7 = a.get<float>(B * T * 512); m->X = a.get<float>(T * B * 512); m->dX = a.get<float>(T * B * 512);
+  size_t gmax = B * d.H1 * d.W1 * 128;                                      // d(conv2 pre-pool output): the largest gradient map
+  m->G0 = a.get<float>(gmax); m->G1 = a.get<float>(gmax);
+  m->bn_scratch = a.get<char>(bn_scratch_bytes(512)); m->bn_save = a.get<float>(3 * 2 * 512);
+  for (int dir = 0; dir < 2; ++dir) {
+    for (int l = 0; l < m->Le; ++l) {
+      m->ezx[dir][l] = a.get<float>(T * B * 4 * He); m->ehs[dir][l] = a.get<float>((T + 2) * B * He);
+      m->ecs[dir][l] = a.get<float>((T + 2) * B * He); m->egates[dir][l] = a.get<float>(T * B * 4 * He);
+      m->edz[dir][l] = a.get<float>(T * B * 4 * He);
+    }
+    m->edc[dir] = a.get<float>(B * He); m->edxl[dir] = a.get<float>(T * B * He);
+  }
+  m->context = a.get<float>(B * T * Hd); m->dctx = a.get<float>(B * T * Hd);
+  m->emb_all = a.get<float>(L * B * E); m->zx1_all = a.get<float>(L * B * 4 * Hd);
+  for (int l = 0; l < m->Ld; ++l) {
+    m->dhs[l] = a.get<float>((L + 1) * B * Hd); m->dcs[l] = a.get<float>((L + 1) * B * Hd);
+    m->dgates[l] = a.get<float>(L * B * 4 * Hd); m->ddz[l] = a.get<float>(L * B * 4 * Hd);
+    m->dh_rec[l] = a.get<float>(B * Hd); m->dc_st[l] = a.get<float>(B * Hd);
+  }
+  m->out_all = a.get<float>((L + 1) * B * Hd); m->cat_all = a.get<float>(L * B * 2 * Hd);
+  m->q_all = a.get<float>(L * B * Hd); m->a_all = a.get<float>(L * B * T);
+  m->logits = a.get<float>(L * B * LOGIT_LD); m->dlogits = a.get<float>(L * B * LOGIT_LD); m->nll_rows = a.get<float>(L * B);
+  m->dout_proj = a.get<float>(L * B * Hd); m->dpre_all = a.get<float>(L * B * Hd); m->dcat_all = a.get<float>(L * B * 2 * Hd);
+  m->ds_all = a.get<float>(L * B * T); m->dq_all = a.get<float>(L * B * Hd); m->demb_all = a.get<float>(L * B * E);
+  m->dfeed = a.get<float>(B * Hd); m->loss_tmp = a.get<float>(64);
+  for (int p = 0; p < 2; ++p) {
+    for (int l = 0; l < m->Ld; ++l) { m->bc[p][l] = a.get<float>(R * Hd); m->bh[p][l] = a.get<float>(R * Hd); }
+    m->bfeed[p] = a.get<float>(R * Hd);
+  }
+  for (int l = 0; l < m->Ld; ++l) { m->bc_new[l] = a.get<float>(R * Hd); m->bh_new[l] = a.get<float>(R * Hd); }
+  m->bemb = a.get<float>(R * E); m->bzx1 = a.get<float>(R * 4 * Hd); m->bq = a.get<float>(R * Hd); m->ba = a.get<float>(R * T);
+  m->bcat = a.get<float>(R * 2 * Hd); m->bout = a.get<float>(R * Hd); m->blogits = a.get<float>(R * LOGIT_LD);
+  m->blogp = a.get<float>(R * m->V); m->beam_scores = a.get<float>(R);
+  m->btok = a.get<int32_t>(R); m->bpar = a.get<int32_t>(R);
+  m->hist_tok = a.get<int32_t>(L * R); m->hist_par = a.get<int32_t>(L * R);
+  m->tgt_pad = a.get<int32_t>(B * L); m->tge_pad = a.get<int32_t>(B * L);
+  m->sgd_scratch = a.get<char>(sgd_scratch_bytes());
+  m->ws_bytes = a.off + 256;
+  if (base && a.off > bytes) return -1;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CNN forward, cnn.lua:9-45.  Output X is time-major (T,B,512) (= cnn_output:transpose(1,2), model.lua:288).
+// ------------------------------------------------------------------------------------------------
+void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training, int update_running) {
+  hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
+  conv1_forward(s, images, m->conv[1].w, m->conv[1].b, m->A1, B, d.H, d.W);
+  conv_forward(s, bf, m->A1, m->conv[2].w, m->conv[2].b, m->A2, m->idx2, B, d.H1, d.W1, 64, 128, 3, 1, 1, 1);
+  conv_forward(s, bf, m->A2, m->conv[3].w, m->conv[3].b, m->Y3, nullptr, B, d.H2, d.W2, 128, 256, 3, 1, 0, 0);
+  bn_relu_forward(s, m->Y3, m->A3, m->bn[3].w, m->bn[3].b, m->bn[3].rm, m->bn[3].rv, m->bn[3].save, m->bn_scratch,
+                  (int64_t)B * d.H2 * d.W2, 256, training, update_running, 0);
+  conv_forward(s, bf, m->A3, m->conv[4].w, m->conv[4].b, m->A4, m->idx4, B, d.H2, d.W2, 256, 256, 3, 1, 1, 2);
+  conv_forward(s, bf, m->A4, m->conv[5].w, m->conv[5].b, m->Y5, nullptr, B, d.H4, d.W2, 256, 512, 3, 1, 0, 0);
+  bn_relu_forward(s, m->Y5, m->A5, m->bn[5].w, m->bn[5].b, m->bn[5].rm, m->bn[5].rv, m->bn[5].save, m->bn_scratch,
+                  (int64_t)B * d.H4 * d.W2, 512, training, update_running, 0);
+  conv_forward(s, bf, m->A5, m->conv[6].w, m->conv[6].b, m->A6, m->idx6, B, d.H4, d.W2, 512, 512, 3, 1, 1, 2);
+  conv_forward(s, bf, m->A6, m->conv[7].w, m->conv[7].b, m->Y7, nullptr, B, d.H6, d.W2, 512, 512, 2, 0, 0, 0);
+  bn_relu_forward(s, m->Y7, m->X, m->bn[7].w, m->bn[7].b, m->bn[7].rm, m->bn[7].rv, m->bn[7].save, m->bn_scratch,
+                  (int64_t)B * d.T, 512, training, update_running, B);
+}
+
+static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
+  hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
+  float *G0 = m->G0, *G1 = m->G1;
+  // bn7 + relu (dX is time-major, Y7 batch-major)
+  bn_relu_backward(s, m->Y7, m->X, m->dX, m->bn[7].w, m->bn[7].save, G0, m->bn[7].dw, m->bn[7].db, m->bn_scratch,
+                   (int64_t)B * d.T, 512, B);
+  conv_backward_filter(s, bf, m->A6, G0, m->conv[7].dw, m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0);
+  conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0);
+  unpool_relu_backward(s, G1, m->A6, m->idx6, G0, B, d.H4, d.W2, 512, 2);
+  conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1);
+  conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1);
+  bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
+                   (int64_t)B * d.H4 * d.W2, 512, 0);
+  conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1);
+  conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1);
+  unpool_relu_backward(s, G1, m->A4, m->idx4, G0, B, d.H2, d.W2, 256, 2);
+  conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1);
+  conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1);
+  bn_relu_backward(s, m->Y3, m->A3, G1, m->bn[3].w, m->bn[3].save, G0, m->bn[3].dw, m->bn[3].db, m->bn_scratch,
+                   (int64_t)B * d.H2 * d.W2, 256, 0);
+  conv_backward_filter(s, bf, m->A2, G0, m->conv[3].dw, m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1);
+  conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1);
+  unpool_relu_backward(s, G1, m->A2, m->idx2, G0, B, d.H1, d.W1, 128, 1);
+  conv_backward_filter(s, bf, m->A1, G0, m->conv[2].dw, m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1);
+  conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1);
+  conv1_backward(s, images, m->conv[1].w, m->conv[1].b, G1, m->conv[1].dw, m->conv[1].db, B, d.H, d.W);
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder, model.lua:291-316.  State slots: index t+1 holds step t; slot 0 / slot T+1 are the zero initial
+// states of the forward / backward direction.
+// ------------------------------------------------------------------------------------------------
+void encoder_forward(aocr_model* m, const Dims& d) {
+  hipStream_t s = m->s; const bool bf = m->bf16;
+  const int B = d.B, T = d.T, He = m->He, Hd = m->Hd;
+  const size_t slot = (size_t)B * He;
+  for (int l = 0; l < m->Le; ++l) {
+    for (int dir = 0; dir < 2; ++dir) {
+      const LstmP& p = m->enc[dir][l];
+      const float* xin = l == 0 ? m->X : m->ehs[dir][l - 1] + slot;        // Dropout(0) = identity (S6)
+      gemm(s, bf, xin, p.in, true, p.wi, p.in, true, m->ezx[dir][l], 4 * He, T * B, 4 * He, p.in, p.bi, p.bh, 0);
+      hipMemsetAsync(m->ehs[dir][l], 0, slot * sizeof(float), s);
+      hipMemsetAsync(m->ehs[dir][l] + (size_t)(T + 1) * slot, 0, slot * sizeof(float), s);
+      hipMemsetAsync(m->ecs[dir][l], 0, slot * sizeof(float), s);
+      hipMemsetAsync(m->ecs[dir][l] + (size_t)(T + 1) * slot, 0, slot * sizeof(float), s);
+    }
+    const bool top = l == m->Le - 1;
+    for (int i = 0; i < T; ++i) {
+      GatesFwdArgs z[2];
+      for (int dir = 0; dir < 2; ++dir) {
+        const LstmP& p = m->enc[dir][l];
+        const int t = dir == 0 ? i : T - 1 - i;
+        const int prev = dir == 0 ? t : t + 2;
+        float* hs = m->ehs[dir][l]; float* cs = m->ecs[dir][l];
+        z[dir].a = make_loadk(hs + prev * slot, He, B, He);
+        z[dir].b = make_loadk(p.wh, He, 4 * He, He);
+        z[dir].K = He;
+        EpGatesFwd& e = z[dir].ep;
+        e.zx = m->ezx[dir][l] + (size_t)t * B * 4 * He; e.ldzx = 4 * He; e.b1 = nullptr; e.b2 = nullptr;
+        e.c_prev = cs + prev * slot; e.ldcp = He;
+        e.c_out = cs + (size_t)(t + 1) * slot; e.ldc = He; e.h_out = hs + (size_t)(t + 1) * slot; e.ldh = He;
+        e.h_out2 = top ? m->context + (size_t)t * Hd + dir * He : nullptr; e.ldh2 = (int64_t)T * Hd;   // model.lua:303,315
+        e.gates = m->egates[dir][l] + (size_t)t * B * 4 * He; e.ldg = 4 * He; e.M = B; e.H = He;
+      }
+      launch_small_gates_fwd(s, bf, 2, z, B, He);
+    }
+  }
+}
+
+// BPTT through both encoder directions, model.lua:662-690.  On entry dc_st[0] / dh_rec[0] of the decoder hold
+// d c1(0) / d h1(0) (quirk S5: d h1(0) is passed on even when h1(0) was zeroed in the forward pass).
+static void encoder_backward(aocr_model* m, const Dims& d) {
+  hipStream_t s = m->s; const bool bf = m->bf16;
+  const int B = d.B, T = d.T, He = m->He, Hd = m->Hd;
+  const size_t slot = (size_t)B * He;
+  for (int l = m->Le - 1; l >= 0; --l) {
+    const bool top = l == m->Le - 1;
+    for (int dir = 0; dir < 2; ++dir) {
+      if (top) copy2d(s, m->dc_st[0] + dir * He, Hd, m->edc[dir], He, B, He);        // model.lua:666,680
+      else hipMemsetAsync(m->edc[dir], 0, slot * sizeof(float), s);
+    }
+    for (int i = 0; i < T; ++i) {
+      GatesBwdArgs z[2];
+      for (int dir = 0; dir < 2; ++dir) {
+        const LstmP& p = m->enc[dir][l];
+        const int t = dir == 0 ? T - 1 - i : i;
+        const int tn = dir == 0 ? t + 1 : t - 1;                                     // step processed just before
+        const int prev = dir == 0 ? t : t + 2;
+        float* dz = m->edz[dir][l];
+        z[dir].a = make_loadk(i == 0 ? dz : dz + (size_t)tn * B * 4 * He, 4 * He, B, i == 0 ? 0 : 4 * He);
+        z[dir].b = make_loadmn(p.wh, He, He, i == 0 ? 0 : 4 * He);
+        z[dir].K = i == 0 ? 0 : 4 * He;
+        EpGatesBwd& e = z[dir].ep;
+        if (top) { e.dh1 = m->dctx + (size_t)t * Hd + dir * He; e.ld1 = (int64_t)T * Hd; }    // model.lua:670,684
+        else { e.dh1 = m->edxl[dir] + (size_t)t * slot; e.ld1 = He; }
+        e.dh2 = (top && i == 0) ? m->dh_rec[0] + dir * He : nullptr; e.ld2 = Hd;               // model.lua:667,681
+        e.dc_in = m->edc[dir]; e.lddc = He;
+        e.gates = m->egates[dir][l] + (size_t)t * B * 4 * He; e.ldg = 4 * He;
+        e.c_prev = m->ecs[dir][l] + prev * slot; e.ldcp = He; e.c = m->ecs[dir][l] + (size_t)(t + 1) * slot; e.ldcc = He;
+        e.dz = dz + (size_t)t * B * 4 * He; e.lddz = 4 * He; e.dc_out = m->edc[dir]; e.lddco = He; e.M = B; e.H = He;
+      }
+      launch_small_gates_bwd(s, bf, 2, z, B, He);
+    }
+    for (int dir = 0; dir < 2; ++dir) {
+      const LstmP& p = m->enc[dir][l];
+      const float* xin = l == 0 ? m->X : m->ehs[dir][l - 1] + slot;
+      const float* hprev = m->ehs[dir][l] + (dir == 0 ? 0 : 2 * slot);
+      const float* dz = m->edz[dir][l];
+      gemm(s, bf, dz, 4 * He, false, xin, p.in, false, p.dwi, p.in, 4 * He, p.in, T * B, nullptr, nullptr, EP_ATOMIC);
+      gemm(s, bf, dz, 4 * He, false, hprev, He, false, p.dwh, He, 4 * He, He, T * B, nullptr, nullptr, EP_ATOMIC);
+      colsum_accum(s, dz, 4 * He, (int64_t)T * B, 4 * He, p.dbi);
+      colsum_accum(s, dz, 4 * He, (int64_t)T * B, 4 * He, p.dbh);
+      if (l == 0) gemm(s, bf, dz, 4 * He, true, p.wi, p.in, false, m->dX, 512, T * B, 512, 4 * He, nullptr, nullptr,
+                       dir == 0 ? 0 : EP_ACCUM);                                     // model.lua:675 copy, :689 add
+      else gemm(s, bf, dz, 4 * He, true, p.wi, p.in, false, m->edxl[dir], He, T * B, He, 4 * He, nullptr, nullptr, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder
+// ------------------------------------------------------------------------------------------------
+struct DecStepIO {
+  int R, ctx_div;
+  const float* zx1; const float* feed;
+  const float* c_prev[MAXL]; const float* h_prev[MAXL];
+  float* c_new[MAXL]; float* h_new[MAXL]; float* gates[MAXL];
+  float *q, *a, *cat, *out;
+};
+
+// one decoder clone forward, LSTM.lua:18-122: LSTM layers, then attention (LSTM.lua:124-162).
+static void dec_step_forward(aocr_model* m, const DecStepIO& io, int T) {
+  hipStream_t s = m->s; const bool bf = m->bf16;
+  const int R = io.R, Hd = m->Hd, E = m->E;
+  for (int l = 0; l < m->Ld; ++l) {
+    const LstmP& p = m->dec[l];
+    GatesFwdArgs z;
+    EpGatesFwd& e = z.ep;
+    if (l == 0) {
+      if (m->cfg.input_feed) {
+        z.a = make_loadk2(io.feed, Hd, Hd, io.h_prev[0], Hd, Hd, R);
+        z.b = make_loadk2(p.wi + E, p.in, Hd, p.wh, Hd, Hd, 4 * Hd);
+        z.K = 2 * Hd;
+      } else {
+        z.a = make_loadk(io.h_prev[0], Hd, R, Hd); z.b = make_loadk(p.wh, Hd, 4 * Hd, Hd); z.K = Hd;
+      }
+      e.zx = io.zx1; e.ldzx = 4 * Hd; e.b1 = nullptr; e.b2 = nullptr;
+    } else {
+      z.a = make_loadk2(io.h_new[l - 1], Hd, Hd, io.h_prev[l], Hd, Hd, R);
+      z.b = make_loadk2(p.wi, Hd, Hd, p.wh, Hd, Hd, 4 * Hd);
+      z.K = 2 * Hd;
+      e.zx = nullptr; e.ldzx = 0; e.b1 = p.bi; e.b2 = p.bh;
+    }
+    e.c_prev = io.c_prev[l]; e.ldcp = Hd; e.c_out = io.c_new[l]; e.ldc = Hd; e.h_out = io.h_new[l]; e.ldh = Hd;
+    const bool top = l == m->Ld - 1;
+    e.h_out2 = top ? io.cat + Hd : nullptr; e.ldh2 = 2 * Hd;                         // JoinTable [c ; h_top], LSTM.lua:153
+    e.gates = io.gates[l]; e.ldg = 4 * Hd; e.M = R; e.H = Hd;
+    launch_small_gates_fwd(s, bf, 1, &z, R, Hd);
+  }
+  {                                                                                  // q = W_a h_top, LSTM.lua:131
+    SmallKKArgs z; z.a = make_loadk(io.h_new[m->Ld - 1], Hd, R, Hd); z.b = make_loadk(m->wa, Hd, Hd, Hd); z.K = Hd;
+    z.ep = make_store(io.q, Hd, R, Hd);
+    launch_small_kk(s, bf, 1, &z, R, Hd);
+  }
+  attention_forward(s, m->context, io.q, io.a, io.cat, 2 * Hd, R, T, Hd, io.ctx_div);
+  {                                                                                  // out = tanh(W_c [c ; h]), LSTM.lua:155
+    SmallKKArgs z; z.a = make_loadk(io.cat, 2 * Hd, R, 2 * Hd); z.b = make_loadk(m->wc, 2 * Hd, Hd, 2 * Hd); z.K = 2 * Hd;
+    z.ep = make_store(io.out, Hd, R, Hd, nullptr, nullptr, EP_TANH);
+    launch_small_kk(s, bf, 1, &z, R, Hd);
+  }
+}
+
+// initial decoder state from the encoder's final states, model.lua:539-552 (+ quirk S5)
+static void dec_init_state(aocr_model* m, const Dims& d, float* const* c0, float* const* h0, float* feed0, int R) {
+  hipStream_t s = m->s; const int B = d.B, T = d.T, He = m->He, Hd = m->Hd; const size_t slot = (size_t)B * He;
+  (void)R;
+  const int lt = m->Le - 1;
+  for (int l = 0; l < m->Ld; ++l) {
+    hipMemsetAsync(c0[l], 0, (size_t)B * Hd * sizeof(float), s);
+    hipMemsetAsync(h0[l], 0, (size_t)B * Hd * sizeof(float), s);
+  }
+  if (feed0) hipMemsetAsync(feed0, 0, (size_t)B * Hd * sizeof(float), s);
+  // c1(0) = [c_fw(T) ; c_bw(1)]
+  copy2d(s, m->ecs[0][lt] + (size_t)T * slot, He, c0[0], Hd, B, He);
+  copy2d(s, m->ecs[1][lt] + (size_t)1 * slot, He, c0[0] + He, Hd, B, He);
+  const bool quirk_s5 = m->cfg.input_feed && m->Ld >= 2;     // model.lua:549-552 zeroes h1(0) instead of h2(0)
+  if (!quirk_s5) {
+    copy2d(s, m->ehs[0][lt] + (size_t)T * slot, He, h0[0], Hd, B, He);
+    copy2d(s, m->ehs[1][lt] + (size_t)1 * slot, He, h0[0] + He, Hd, B, He);
+  }
+}
+
+// teacher-forced decoder loop, model.lua:553-568 (train) / :604-627 (gold pass); the projector (model.lua:560)
+// is hoisted out of the loop: logits for all L steps in one contraction.
+void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_t st, int64_t sb, bool keep_gates) {
+  hipStream_t s = m->s; const bool bf = m->bf16;
+  const int B = d.B, T = d.T, L = d.L, Hd = m->Hd, E = m->E;
+  const size_t slot = (size_t)B * Hd;
+  embedding_gather(s, m->lookup, tgt, st, sb, m->emb_all, L, B, E);
+  const LstmP& p1 = m->dec[0];
+  gemm(s, bf, m->emb_all, E, true, p1.wi, p1.in, true, m->zx1_all, 4 * Hd, L * B, 4 * Hd, E, p1.bi, p1.bh, 0);
+  float* c0[MAXL]; float* h0[MAXL];
+  for (int l = 0; l < m->Ld; ++l) { c0[l] = m->dcs[l]; h0[l] = m->dhs[l]; }
+  dec_init_state(m, d, c0, h0, m->out_all, B);
+  for (int t = 0; t < L; ++t) {
+    DecStepIO io; io.R = B; io.ctx_div = 1;
+    io.zx1 = m->zx1_all + (size_t)t * B * 4 * Hd; io.feed = m->out_all + (size_t)t * slot;
+    for (int l = 0; l < m->Ld; ++l) {
+      io.c_prev[l] = m->dcs[l] + (size_t)t * slot; io.h_prev[l] = m->dhs[l] + (size_t)t * slot;
+      io.c_new[l] = m->dcs[l] + (size_t)(t + 1) * slot; io.h_new[l] = m->dhs[l] + (size_t)(t + 1) * slot;
+      io.gates[l] = keep_gates ? m->dgates[l] + (size_t)t * B * 4 * Hd : nullptr;
+    }
+    io.q = m->q_all + (size_t)t * slot; io.a = m->a_all + (size_t)t * B * T; io.cat = m->cat_all + (size_t)t * B * 2 * Hd;
+    io.out = m->out_all + (size_t)(t + 1) * slot;
+    dec_step_forward(m, io, T);
+  }
+  gemm(s, bf, m->out_all + slot, Hd, true, m->wo, Hd, true, m->logits, LOGIT_LD, L * B, m->V, Hd, m->bo, nullptr, 0);
+}
+
+void loss_and_dlogits(aocr_model* m, const Dims& d, const int32_t* tge, int64_t st, int64_t sb, float grad_scale, bool want_grad,
+                      float* loss_dev) {
+  const int64_t rows = (int64_t)d.L * d.B;
+  logsoftmax_nll(m->s, m->logits, LOGIT_LD, tge, st, sb, d.B, nullptr, want_grad ? m->dlogits : nullptr, m->nll_rows, rows, m->V,
+                 grad_scale);
+  if (loss_dev) sum_to_scalar(m->s, m->nll_rows, rows, loss_dev);
+}
+
+// decoder BPTT, model.lua:643-661, t = L..1.
+static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
+  hipStream_t s = m->s; const bool bf = m->bf16;
+  const int B = d.B, T = d.T, L = d.L, Hd = m->Hd, E = m->E, V = m->V, Ld = m->Ld;
+  const size_t slot = (size_t)B * Hd;
+  const int rows = L * B;
+  // projector backward for all steps at once (model.lua:648): d(out) part, gradWeight, gradBias
+  gemm(s, bf, m->dlogits, LOGIT_LD, true, m->wo, Hd, false, m->dout_proj, Hd, rows, Hd, V, nullptr, nullptr, 0);
+  gemm(s, bf, m->dlogits, LOGIT_LD, false, m->out_all + slot, Hd, false, m->dwo, Hd, V, Hd, rows, nullptr, nullptr, EP_ATOMIC);
+  colsum_accum(s, m->dlogits, LOGIT_LD, rows, V, m->dbo);
+  for (int l = 0; l < Ld; ++l) {
+    hipMemsetAsync(m->dh_rec[l], 0, slot * sizeof(float), s);
+    hipMemsetAsync(m->dc_st[l], 0, slot * sizeof(float), s);
+  }
+  for (int t = L - 1; t >= 0; --t) {
+    const bool last = t == L - 1;
+    const float* out_t = m->out_all + (size_t)(t + 1) * slot;
+    float* dpre = m->dpre_all + (size_t)t * slot;
+    float* dcat = m->dcat_all + (size_t)t * B * 2 * Hd;
+    // d(tanh) with the input-feed gradient of step t+1 added (model.lua:649,654-657)
+    dpre_tanh(s, m->dout_proj + (size_t)t * slot, (m->cfg.input_feed && !last) ? m->dfeed : nullptr, out_t, dpre, (int64_t)slot);
+    {                                                                 // d[c ; h_top] = dpre W_c
+      SmallKMNArgs z; z.a = make_loadk(dpre, Hd, B, Hd); z.b = make_loadmn(m->wc, 2 * Hd, 2 * Hd, Hd); z.K = Hd;
+      z.ep = make_store(dcat, 2 * Hd, B, 2 * Hd);
+      launch_small_kmn(s, bf, 1, &z, B, 2 * Hd);
+    }
+    attention_backward(s, m->context, m->q_all + (size_t)t * slot, m->a_all + (size_t)t * B * T, dcat, 2 * Hd,
+                       m->ds_all + (size_t)t * B * T, m->dq_all + (size_t)t * slot, B, T, Hd);
+    // top layer: d h_top = dq W_a + dcat[:, Hd:] + recurrent part
+    for (int l = Ld - 1; l >= 0; --l) {
+      GatesBwdArgs z; EpGatesBwd& e = z.ep;
+      if (l == Ld - 1) {
+        z.a = make_loadk(m->dq_all + (size_t)t * slot, Hd, B, Hd); z.b = make_loadmn(m->wa, Hd, Hd, Hd); z.K = Hd;
+        e.dh1 = dcat + Hd; e.ld1 = 2 * Hd;
+      } else {                                                        // from the layer above: dz_{l+1} W_{l+1,i2h}
+        const LstmP& pu = m->dec[l + 1];
+        z.a = make_loadk(m->ddz[l + 1] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd); z.b = make_loadmn(pu.wi, Hd, Hd, 4 * Hd);
+        z.K = 4 * Hd;
+        e.dh1 = nullptr; e.ld1 = 0;
+      }
+      e.dh2 = m->dh_rec[l]; e.ld2 = Hd;
+      e.dc_in = m->dc_st[l]; e.lddc = Hd;
+      e.gates = m->dgates[l] + (size_t)t * B * 4 * Hd; e.ldg = 4 * Hd;
+      e.c_prev = m->dcs[l] + (size_t)t * slot; e.ldcp = Hd; e.c = m->dcs[l] + (size_t)(t + 1) * slot; e.ldcc = Hd;
+      e.dz = m->ddz[l] + (size_t)t * B * 4 * Hd; e.lddz = 4 * Hd; e.dc_out = m->dc_st[l]; e.lddco = Hd; e.M = B; e.H = Hd;
+      launch_small_gates_bwd(s, bf, 1, &z, B, Hd);
+      {                                                               // recurrent part for step t-1: dz_l W_{l,h2h}
+        const LstmP& p = m->dec[l];
+        SmallKMNArgs r; r.a = make_loadk(m->ddz[l] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd);
+        r.b = make_loadmn(p.wh, Hd, Hd, 4 * Hd); r.K = 4 * Hd; r.ep = make_store(m->dh_rec[l], Hd, B, Hd);
+        launch_small_kmn(s, bf, 1, &r, B, Hd);
+      }
+    }
+    if (m->cfg.input_feed) {                                          // d(prev attention output) = dz_1 W_{1,i2h}[:, E:]
+      const LstmP& p = m->dec[0];
+      SmallKMNArgs r; r.a = make_loadk(m->ddz[0] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd);
+      r.b = make_loadmn(p.wi + E, p.in, Hd, 4 * Hd); r.K = 4 * Hd; r.ep = make_store(m->dfeed, Hd, B, Hd);
+      launch_small_kmn(s, bf, 1, &r, B, Hd);
+    }
+  }
+  // ---- hoisted parameter gradients (accGradParameters of every clone summed over time)
+  const float* h_top_all = m->dhs[Ld - 1] + slot;
+  gemm(s, bf, m->dpre_all, Hd, false, m->cat_all, 2 * Hd, false, m->dwc, 2 * Hd, Hd, 2 * Hd, rows, nullptr, nullptr, EP_ATOMIC);
+  gemm(s, bf, m->dq_all, Hd, false, h_top_all, Hd, false, m->dwa, Hd, Hd, Hd, rows, nullptr, nullptr, EP_ATOMIC);
+  for (int l = 0; l < Ld; ++l) {
+    const LstmP& p = m->dec[l]; const float* dz = m->ddz[l];
+    gemm(s, bf, dz, 4 * Hd, false, m->dhs[l], Hd, false, p.dwh, Hd, 4 * Hd, Hd, rows, nullptr, nullptr, EP_ATOMIC);
+    colsum_accum(s, dz, 4 * Hd, rows, 4 * Hd, p.dbi);
+    colsum_accum(s, dz, 4 * Hd, rows, 4 * Hd, p.dbh);
+    if (l == 0) {
+      gemm(s, bf, dz, 4 * Hd, false, m->emb_all, E, false, p.dwi, p.in, 4 * Hd, E, rows, nullptr, nullptr, EP_ATOMIC);
+      if (m->cfg.input_feed)
+        gemm(s, bf, dz, 4 * Hd, false, m->out_all, Hd, false, p.dwi + E, p.in, 4 * Hd, Hd, rows, nullptr, nullptr, EP_ATOMIC);
+      gemm(s, bf, dz, 4 * Hd, true, p.wi, p.in, false, m->demb_all, E, rows, E, 4 * Hd, nullptr, nullptr, 0);
+      embedding_scatter_accum(s, m->demb_all, tgt, 1, L, m->dlookup, L, B, E, V);
+    } else {
+      gemm(s, bf, dz, 4 * Hd, false, m->dhs[l - 1] + slot, Hd, false, p.dwi, Hd, 4 * Hd, Hd, rows, nullptr, nullptr, EP_ATOMIC);
+    }
+  }
+  // d(context), model.lua:652-653 summed over the loop
+  attention_dctx(s, m->a_all, m->ds_all, m->dcat_all, 2 * Hd, m->q_all, m->dctx, L, B, T, Hd);
+}
+
+void backward_all(aocr_model* m, const float* images, const int32_t* tgt, const Dims& d) {
+  decoder_backward(m, d, tgt);
+  encoder_backward(m, d);
+  cnn_backward(m, images, d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// beam search, model.lua:360-536 + back-trace :573-585.  Rows r = b*k + beam; the context is not replicated
+// (the attention kernel maps row -> image with ctx_div).
+// ------------------------------------------------------------------------------------------------
+void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int32_t* labels, float* scores) {
+  hipStream_t s = m->s; const bool bf = m->bf16;
+  const int B = d.B, T = d.T, Lt = d.L, Hd = m->Hd, E = m->E, V = m->V, Ld = m->Ld;
+  const int k = beam;
+  const LstmP& p1 = m->dec[0];
+  float* c0[MAXL]; float* h0[MAXL];
+  for (int l = 0; l < Ld; ++l) { c0[l] = m->bc[0][l]; h0[l] = m->bh[0][l]; }
+  dec_init_state(m, d, c0, h0, m->bfeed[0], B);
+  int cur = 0;
+  for (int t = 0; t < Lt; ++t) {
+    const int kin = t == 0 ? 1 : k, R = B * kin;
+    // embedding of the current input tokens (t = 0: the GO column of the targets, model.lua:388)
+    if (t == 0) embedding_gather(s, m->lookup, tgt, 0, Lt, m->bemb, 1, B, E);
+    else embedding_gather(s, m->lookup, m->btok, 0, 1, m->bemb, 1, R, E);
+    gemm(s, bf, m->bemb, E, true, p1.wi, p1.in, true, m->bzx1, 4 * Hd, R, 4 * Hd, E, p1.bi, p1.bh, 0);
+    DecStepIO io; io.R = R; io.ctx_div = kin; io.zx1 = m->bzx1; io.feed = m->bfeed[cur];
+    for (int l = 0; l < Ld; ++l) {
+      io.c_prev[l] = m->bc[cur][l]; io.h_prev[l] = m->bh[cur][l]; io.c_new[l] = m->bc_new[l]; io.h_new[l] = m->bh_new[l];
+      io.gates[l] = nullptr;
+    }
+    io.q = m->bq; io.a = m->ba; io.cat = m->bcat; io.out = m->bout;
+    dec_step_forward(m, io, T);
+    gemm(s, bf, m->bout, Hd, true, m->wo, Hd, true, m->blogits, LOGIT_LD, R, V, Hd, m->bo, nullptr, 0);
+    logsoftmax_nll(s, m->blogits, LOGIT_LD, m->btok, 0, 0, R, m->blogp, nullptr, nullptr, R, V, 0.f);
+    beam_select(s, m->blogp, t == 0 ? nullptr : m->btok, m->beam_scores, m->hist_tok + (size_t)t * B * k,
+                m->hist_par + (size_t)t * B * k, B, kin, k, V);
+    const int32_t* par = m->hist_par + (size_t)t * B * k;
+    const int nxt = cur ^ 1;
+    for (int l = 0; l < Ld; ++l) {                                     // model.lua:521-535: gather states by parent beam
+      gather_beam_rows(s, m->bc_new[l], Hd, m->bc[nxt][l], Hd, par, B, kin, k, Hd);
+      gather_beam_rows(s, m->bh_new[l], Hd, m->bh[nxt][l], Hd, par, B, kin, k, Hd);
+    }
+    if (m->cfg.input_feed) gather_beam_rows(s, m->bout, Hd, m->bfeed[nxt], Hd, par, B, kin, k, Hd);
+    hipMemcpyAsync(m->btok, m->hist_tok + (size_t)t * B * k, (size_t)B * k * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+    cur = nxt;
+  }
+  beam_backtrace(s, m->hist_tok, m->hist_par, m->beam_scores, labels, scores, Lt, B, k);
+}
+
+}  // namespace aocr

@@ -1,0 +1,106 @@
+// ops.h -- host-side launchers of every kernel on the hot path (all enqueue on a stream, none synchronise).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "epilogues.h"
+#include "mfma_gemm.h"
+
+namespace aocr {
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- helpers to build loaders
+inline LoadK make_loadk(const float* p, int64_t ld, int rows, int K) {
+  LoadK l; l.p0 = p; l.ld0 = ld; l.K0 = K; l.p1 = nullptr; l.ld1 = 0; l.rows = rows; l.K = K;
+  l.vec = (((uintptr_t)p & 15) == 0) && (ld % 4 == 0);
+  return l;
+}
+inline LoadK make_loadk2(const float* p0, int64_t ld0, int K0, const float* p1, int64_t ld1, int K1, int rows) {
+  LoadK l; l.p0 = p0; l.ld0 = ld0; l.K0 = K0; l.p1 = p1; l.ld1 = ld1; l.rows = rows; l.K = K0 + K1;
+  l.vec = (((uintptr_t)p0 & 15) == 0) && (ld0 % 4 == 0) && (((uintptr_t)p1 & 15) == 0) && (ld1 % 4 == 0) && (K0 % 16 == 0);
+  return l;
+}
+inline LoadMN make_loadmn(const float* p, int64_t ld, int rows, int K) {
+  LoadMN l; l.p = p; l.ld = ld; l.rows = rows; l.K = K; return l;
+}
+inline EpStore make_store(float* C, int64_t ldc, int M, int N, const float* bias = nullptr, const float* bias2 = nullptr,
+                          int flags = 0) {
+  EpStore e; e.C = C; e.ldc = ldc; e.M = M; e.N = N; e.bias = bias; e.bias2 = bias2; e.flags = flags;
+  e.C1 = nullptr; e.ldc1 = 0; e.N0 = N; return e;
+}
+
+// ---- MFMA contractions (ops_gemm.hip)
+// ksplit > 1 requires ep.flags & EP_ATOMIC.
+void launch_big_kk(hipStream_t s, bool bf16, const LoadK& a, const LoadK& b, const EpStore& ep, int M, int N, int K, int ksplit);
+void launch_big_kmn(hipStream_t s, bool bf16, const LoadK& a, const LoadMN& b, const EpStore& ep, int M, int N, int K, int ksplit);
+void launch_big_mnmn(hipStream_t s, bool bf16, const LoadMN& a, const LoadMN& b, const EpStore& ep, int M, int N, int K, int ksplit);
+void launch_conv_fwd(hipStream_t s, bool bf16, const LoadConvK& a, const LoadK& b, const EpConv& ep, int M, int N, int K);
+void launch_conv_dgrad(hipStream_t s, bool bf16, const LoadConvK& a, const LoadConvWT& b, const EpStore& ep, int M, int N, int K);
+void launch_conv_wgrad(hipStream_t s, bool bf16, const LoadMN& a, const LoadConvXcol& b, const EpStore& ep, int M, int N, int K, int ksplit);
+
+typedef SmallArgs<LoadK, LoadK, EpGatesFwd> GatesFwdArgs;
+typedef SmallArgs<LoadK, LoadK, EpStore> SmallKKArgs;
+typedef SmallArgs<LoadK, LoadMN, EpStore> SmallKMNArgs;
+typedef SmallArgs<LoadK, LoadMN, EpGatesBwd> GatesBwdArgs;
+// nz = 1 or 2 argument sets (blockIdx.z); M rows, H (or N) columns.
+void launch_small_gates_fwd(hipStream_t s, bool bf16, int nz, const GatesFwdArgs* z, int M, int H);
+void launch_small_kk(hipStream_t s, bool bf16, int nz, const SmallKKArgs* z, int M, int N);
+void launch_small_kmn(hipStream_t s, bool bf16, int nz, const SmallKMNArgs* z, int M, int N);
+void launch_small_gates_bwd(hipStream_t s, bool bf16, int nz, const GatesBwdArgs* z, int M, int H);
+
+// generic GEMM used by the C ABI and the hoisted projections; picks ksplit when allowed (atomic accumulate).
+int gemm(hipStream_t s, bool bf16, const float* A, int64_t lda, bool a_kmajor, const float* B, int64_t ldb, bool b_kmajor,
+          float* C, int64_t ldc, int M, int N, int K, const float* bias, const float* bias2, int flags);
+
+// ---- convolution layers (ops_gemm.hip)
+void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, const float* bias, float* y, uint8_t* idx,
+                  int B, int H, int W, int Cin, int Cout, int ks, int pad, int relu, int pool);
+void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* w, float* dx, int B, int H, int W, int Cin,
+                        int Cout, int ks, int pad);
+void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float* dy, float* dw, float* dbias, int B, int H,
+                          int W, int Cin, int Cout, int ks, int pad);
+
+// ---- everything that is not a contraction (ops_misc.hip)
+void conv1_forward(hipStream_t s, const float* x, const float* w, const float* bias, float* y, int B, int H, int W);
+void conv1_backward(hipStream_t s, const float* x, const float* w, const float* bias, const float* dyp, float* dw, float* db,
+                    int B, int H, int W);
+void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pooled, const uint8_t* idx, float* dy, int B,
+                          int Ho, int Wo, int C, int pool);
+size_t bn_scratch_bytes(int C);
+void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, const float* b, float* rm, float* rv,
+                     float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows);
+void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
+                      float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows);
+// ctx_div: rows r share context row r / ctx_div (beam search keeps one context per image, model.lua:373)
+void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a, float* c, int64_t ldc, int B, int T, int Hd,
+                       int ctx_div = 1);
+void attention_backward(hipStream_t s, const float* ctx, const float* q, const float* a, const float* dc, int64_t lddc,
+                        float* ds, float* dq, int B, int T, int Hd);
+// d(ctx)[b,t,:] = sum_l a[l,b,t]*dc[l,b,:] + ds[l,b,t]*q[l,b,:]   (dc row stride lddc)
+void attention_dctx(hipStream_t s, const float* a_all, const float* ds_all, const float* dc_all, int64_t lddc,
+                    const float* q_all, float* dctx, int L, int B, int T, int Hd);
+void logsoftmax_nll(hipStream_t s, const float* logits, int64_t ld, const int32_t* tgt, int64_t tgt_stride_t,
+                    int64_t tgt_stride_b, int Bt, float* logp, float* dlogits, float* nll_rows, int64_t rows, int V,
+                    float grad_scale);
+void sum_to_scalar(hipStream_t s, const float* x, int64_t n, float* out);                 // out[0] = sum x
+void gold_scores(hipStream_t s, const float* nll_rows, float* gold, int L, int B);       // gold[b] = -sum_t nll[t,b]
+void colsum_accum(hipStream_t s, const float* A, int64_t ld, int64_t rows, int N, float* out);   // out[n] += sum_r A[r][n]
+void embedding_gather(hipStream_t s, const float* table, const int32_t* tok, int64_t stride_t, int64_t stride_b, float* out,
+                      int L, int B, int E);
+void embedding_scatter_accum(hipStream_t s, const float* demb, const int32_t* tok, int64_t stride_t, int64_t stride_b,
+                             float* dtable, int L, int B, int E, int V);
+void dpre_tanh(hipStream_t s, const float* g1, const float* g2, const float* out, float* dpre, int64_t n);  // (g1+g2)*(1-out^2)
+void copy2d(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols);
+void sgd_clip_update(hipStream_t s, float* params, float* grads, const int64_t* group_off /*6 host values*/, float lr,
+                     float clip, float* norms_out, void* scratch);
+size_t sgd_scratch_bytes();
+void beam_select(hipStream_t s, const float* logp, const int32_t* prev_tok, float* beam_scores, int32_t* tokens,
+                 int32_t* parents, int B, int kin, int kout, int V);
+// dst[b*kout+i][:] = src[(kin==1 ? b : b*kin + parents[b*kout+i])][:]
+void gather_beam_rows(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, const int32_t* parents, int B,
+                      int kin, int kout, int width);
+void beam_backtrace(hipStream_t s, const int32_t* hist_tok, const int32_t* hist_par, const float* beam_scores,
+                    int32_t* labels, float* scores, int Lt, int B, int k);
+void fill_i32(hipStream_t s, int32_t* p, int32_t v, int64_t n);
+
+}  // namespace aocr

@@ -1,0 +1,681 @@
+// ops_misc.hip -- the HBM/L2-bound kernels of the hot path: first conv layer (K=9, fused normalise+conv+ReLU+pool),
+// BatchNorm, un-pooling, the attention score/softmax/context core, LogSoftMax+NLL, reductions, embedding,
+// clipped SGD and the beam-search bookkeeping.  All wave-width constants are 64 (gfx950).
+#include "ops.h"
+
+namespace aocr {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// =============================================================================================
+// conv1: cnn.lua:9-15.  x (B,H,W) raw 0..255 -> y (B,H/2,W/2,64) = maxpool2x2(relu(conv3x3((x-128)/128)+b)).
+// thread = (pool window, 4 output channels).  K = 9: HBM-bound on the y write; x stays in L1/L2.
+// =============================================================================================
+__device__ __forceinline__ void conv1_patch(const float* __restrict__ x, int b, int py, int px, int H, int W, float (&p)[4][4]) {
+  const float* xb = x + (int64_t)b * H * W;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int yy = 2 * py - 1 + i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int xx = 2 * px - 1 + j;
+      bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      p[i][j] = ok ? (xb[(int64_t)yy * W + xx] + (-128.0f)) * (1.0f / 128) : 0.f;   // zero padding applies to the normalised map
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int B, int H,
+                                                        int W, int Hp, int Wp) {
+  __shared__ float sw[64 * 9 + 64];
+  for (int i = threadIdx.x; i < 64 * 9 + 64; i += 256) sw[i] = i < 576 ? w[i] : bias[i - 576];
+  __syncthreads();
+  const int64_t total = (int64_t)B * Hp * Wp * 16;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    int cq = (int)(id & 15); int64_t win = id >> 4;
+    int px = (int)(win % Wp); int64_t t = win / Wp; int py = (int)(t % Hp); int b = (int)(t / Hp);
+    float p[4][4];
+    conv1_patch(x, b, py, px, H, W, p);
+    float out[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float* wc = sw + (cq * 4 + c) * 9;
+      float bb = sw[576 + cq * 4 + c];
+      float best = 0.f;                                        // relu floor
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          float s = bb;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) s = fmaf(wc[kh * 3 + kw], p[dy + kh][dx + kw], s);
+          best = fmaxf(best, s);
+        }
+      out[c] = best;
+    }
+    *reinterpret_cast<float4*>(y + win * 64 + cq * 4) = make_float4(out[0], out[1], out[2], out[3]);
+  }
+}
+
+// gradWeight/gradBias of conv1 (gradInput of the image is never used: model.lua:692 discards it).
+// Re-computes the 4 conv values of each window to route d(pooled) through pool+ReLU.
+__global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ dyp,
+                                                        float* __restrict__ dw, float* __restrict__ db, int B, int H, int W,
+                                                        int Hp, int Wp) {
+  __shared__ float sw[64 * 9 + 64];
+  __shared__ float sacc[64 * 10];
+  for (int i = threadIdx.x; i < 640; i += 256) { sw[i] = i < 576 ? w[i] : bias[i - 576]; sacc[i] = 0.f; }
+  __syncthreads();
+  const int cq = threadIdx.x & 15;
+  float acc[4][10];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[c][k] = 0.f;
+  const int64_t total = (int64_t)B * Hp * Wp * 16;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    int64_t win = id >> 4;                                      // (id & 15) == cq because the stride is a multiple of 16
+    int px = (int)(win % Wp); int64_t t = win / Wp; int py = (int)(t % Hp); int b = (int)(t / Hp);
+    float p[4][4];
+    conv1_patch(x, b, py, px, H, W, p);
+    float4 g4 = *reinterpret_cast<const float4*>(dyp + win * 64 + cq * 4);
+    float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float* wc = sw + (cq * 4 + c) * 9;
+      float bb = sw[576 + cq * 4 + c];
+      float best = 0.f; int bdy = -1, bdx = 0;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          float s = bb;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) s = fmaf(wc[kh * 3 + kw], p[dy + kh][dx + kw], s);
+          if (s > best) { best = s; bdy = dy; bdx = dx; }
+        }
+      if (bdy >= 0) {                                          // pooled value > 0: gradient reaches the arg-max
+        float gg = g[c];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) acc[c][kh * 3 + kw] = fmaf(gg, p[bdy + kh][bdx + kw], acc[c][kh * 3 + kw]);
+        acc[c][9] += gg;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) atomicAdd(&sacc[(cq * 4 + c) * 10 + k], acc[c][k]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 640; i += 256) {
+    int c = i / 10, k = i % 10;
+    if (k < 9) atomicAdd(&dw[c * 9 + k], sacc[i]); else atomicAdd(&db[c], sacc[i]);
+  }
+}
+
+void conv1_forward(hipStream_t s, const float* x, const float* w, const float* bias, float* y, int B, int H, int W) {
+  int Hp = H / 2, Wp = W / 2;
+  int64_t total = (int64_t)B * Hp * Wp * 16;
+  int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, y, B, H, W, Hp, Wp);
+}
+void conv1_backward(hipStream_t s, const float* x, const float* w, const float* bias, const float* dyp, float* dw, float* db,
+                    int B, int H, int W) {
+  int Hp = H / 2, Wp = W / 2;
+  int64_t total = (int64_t)B * Hp * Wp * 16;
+  int blocks = (int)std::min<int64_t>((total + 255) / 256, 1024);
+  hipLaunchKernelGGL(conv1_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, dyp, dw, db, B, H, W, Hp, Wp);
+}
+
+// =============================================================================================
+// un-pool + ReLU backward: dy (B,Ho,Wo,C) from d(pooled), arg-max index and the pooled value (>0 <=> ReLU passed).
+// =============================================================================================
+__global__ __launch_bounds__(256) void unpool_kernel(const float* __restrict__ dp, const float* __restrict__ pooled,
+                                                     const uint8_t* __restrict__ idx, float* __restrict__ dy, int B, int Ho,
+                                                     int Wo, int C, int pool, int Hp, int Wp) {
+  const int C4 = C >> 2;
+  const int64_t total = (int64_t)B * Hp * Wp * C4;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    int c4 = (int)(id % C4); int64_t win = id / C4;
+    int px = (int)(win % Wp); int64_t t = win / Wp; int py = (int)(t % Hp); int b = (int)(t / Hp);
+    float4 g = *reinterpret_cast<const float4*>(dp + win * C + c4 * 4);
+    float4 pv = *reinterpret_cast<const float4*>(pooled + win * C + c4 * 4);
+    uint32_t ii = *reinterpret_cast<const uint32_t*>(idx + win * C + c4 * 4);
+    float gv[4] = {pv.x > 0.f ? g.x : 0.f, pv.y > 0.f ? g.y : 0.f, pv.z > 0.f ? g.z : 0.f, pv.w > 0.f ? g.w : 0.f};
+    int iv[4] = {(int)(ii & 255), (int)((ii >> 8) & 255), (int)((ii >> 16) & 255), (int)(ii >> 24)};
+    const int npos = pool == 1 ? 4 : 2;
+    for (int pos = 0; pos < npos; ++pos) {
+      int y = 2 * py + (pool == 1 ? (pos >> 1) : pos);
+      int x = pool == 1 ? 2 * px + (pos & 1) : px;
+      float4 o = make_float4(iv[0] == pos ? gv[0] : 0.f, iv[1] == pos ? gv[1] : 0.f, iv[2] == pos ? gv[2] : 0.f,
+                             iv[3] == pos ? gv[3] : 0.f);
+      *reinterpret_cast<float4*>(dy + (((int64_t)b * Ho + y) * Wo + x) * C + c4 * 4) = o;
+    }
+  }
+}
+void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pooled, const uint8_t* idx, float* dy, int B, int Ho,
+                          int Wo, int C, int pool) {
+  int Hp = Ho / 2, Wp = pool == 1 ? Wo / 2 : Wo;
+  if ((Ho & 1) || (pool == 1 && (Wo & 1))) hipMemsetAsync(dy, 0, (size_t)B * Ho * Wo * C * sizeof(float), s);   // floor-mode leftovers
+  int64_t total = (int64_t)B * Hp * Wp * (C / 4);
+  int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(unpool_kernel, dim3(blocks), dim3(256), 0, s, dpooled, pooled, idx, dy, B, Ho, Wo, C, pool, Hp, Wp);
+}
+
+// =============================================================================================
+// BatchNorm (+ReLU).  Statistics are accumulated in fp64 (Torch7 accumulates in accreal=double [upstream]).
+// scratch layout: double part[BN_CHUNKS][C][2], then double fin[C][2].
+// =============================================================================================
+static const int BN_CHUNKS = 128;
+size_t bn_scratch_bytes(int C) { return (size_t)(BN_CHUNKS + 1) * C * 2 * sizeof(double); }
+
+// mode 0: (sum x, sum x^2);  mode 1: (sum dy, sum dy*xhat) with dy = dA*(y>0), xhat = (x-mean)*invstd
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ dA, const float* __restrict__ save,
+                                                         double* __restrict__ part, int64_t rows, int C, int mode,
+                                                         int tb_rows, int T) {
+  __shared__ double sh[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+  const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(rows, r0 + per);
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C) {
+    float mean = 0.f, inv = 0.f;
+    if (mode == 1) { mean = save[c]; inv = save[C + c]; }
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      float xv = x[r * C + c];
+      if (mode == 0) { s0 += (double)xv; s1 += (double)xv * (double)xv; }
+      else {
+        int64_t ro = r;
+        if (tb_rows > 0) { int64_t b = r / T, t = r - b * T; ro = t * tb_rows + b; }
+        float yy = y[ro * C + c];
+        float d = yy > 0.f ? dA[ro * C + c] : 0.f;
+        s0 += (double)d; s1 += (double)d * (double)((xv - mean) * inv);
+      }
+    }
+  }
+  sh[0][rl][cl] = s0; sh[1][rl][cl] = s1;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    double a = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
+    double b = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+    part[((int64_t)blockIdx.y * C + c) * 2] = a; part[((int64_t)blockIdx.y * C + c) * 2 + 1] = b;
+  }
+}
+
+__global__ void bn_fwd_finalize_kernel(const double* __restrict__ part, int nchunk, int64_t rows, int C, float* save,
+                                       float* rm, float* rv, int update_running) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, ss = 0;
+  for (int k = 0; k < nchunk; ++k) { s += part[((int64_t)k * C + c) * 2]; ss += part[((int64_t)k * C + c) * 2 + 1]; }
+  double n = (double)rows, mean = s / n, var = ss / n - mean * mean;
+  if (var < 0) var = 0;
+  save[c] = (float)mean; save[C + c] = (float)(1.0 / sqrt(var + 1e-5));
+  if (update_running) {                                         // momentum 0.1, unbiased variance [upstream THNN BatchNormalization]
+    double unb = rows > 1 ? var * n / (n - 1.0) : var;
+    rm[c] = (float)(0.1 * mean + 0.9 * (double)rm[c]);
+    rv[c] = (float)(0.1 * unb + 0.9 * (double)rv[c]);
+  }
+}
+__global__ void bn_eval_prepare_kernel(const float* rm, const float* rv, float* save, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) { save[c] = rm[c]; save[C + c] = (float)(1.0 / sqrt((double)rv[c] + 1e-5)); }
+}
+__global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            const float* __restrict__ save, int64_t rows, int C, int tb_rows,
+                                                            int T) {
+  const int C4 = C >> 2;
+  const int64_t total = rows * C4;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    int c = (int)(id % C4) * 4; int64_t r = id / C4;
+    float4 xv = *reinterpret_cast<const float4*>(x + r * C + c);
+    float4 m = *reinterpret_cast<const float4*>(save + c), iv = *reinterpret_cast<const float4*>(save + C + c);
+    float4 ww = *reinterpret_cast<const float4*>(w + c), bb = *reinterpret_cast<const float4*>(b + c);
+    float4 o;
+    o.x = fmaxf((xv.x - m.x) * iv.x * ww.x + bb.x, 0.f); o.y = fmaxf((xv.y - m.y) * iv.y * ww.y + bb.y, 0.f);
+    o.z = fmaxf((xv.z - m.z) * iv.z * ww.z + bb.z, 0.f); o.w = fmaxf((xv.w - m.w) * iv.w * ww.w + bb.w, 0.f);
+    int64_t ro = r;
+    if (tb_rows > 0) { int64_t bi = r / T, t = r - bi * T; ro = t * tb_rows + bi; }
+    *reinterpret_cast<float4*>(y + ro * C + c) = o;
+  }
+}
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nchunk, int64_t rows, int C, const float* save,
+                                       double* fin, float* dw, float* db) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, ss = 0;
+  for (int k = 0; k < nchunk; ++k) { s += part[((int64_t)k * C + c) * 2]; ss += part[((int64_t)k * C + c) * 2 + 1]; }
+  fin[c * 2] = s / (double)rows; fin[c * 2 + 1] = ss / (double)rows;
+  dw[c] += (float)ss; db[c] += (float)s;                        // gradWeight = sum dy*xhat, gradBias = sum dy
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ dA, const float* __restrict__ w,
+                                                           const float* __restrict__ save, const double* __restrict__ fin,
+                                                           float* __restrict__ dx, int64_t rows, int C, int tb_rows, int T) {
+  const int64_t total = rows * C;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    int c = (int)(id % C); int64_t r = id / C;
+    int64_t ro = r;
+    if (tb_rows > 0) { int64_t bi = r / T, t = r - bi * T; ro = t * tb_rows + bi; }
+    float d = y[ro * C + c] > 0.f ? dA[ro * C + c] : 0.f;
+    float inv = save[C + c];
+    float xh = (x[id] - save[c]) * inv;
+    dx[id] = (d - (float)fin[c * 2] - xh * (float)fin[c * 2 + 1]) * inv * w[c];
+  }
+}
+
+void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, const float* b, float* rm, float* rv,
+                     float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows) {
+  int T = tb_rows > 0 ? (int)(rows / tb_rows) : 0;
+  if (training) {
+    double* part = (double*)scratch;
+    int nchunk = (int)std::min<int64_t>(BN_CHUNKS, (rows + 63) / 64);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, x, nullptr, nullptr, nullptr, part, rows,
+                       C, 0, 0, 0);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, part, nchunk, rows, C, save, rm, rv,
+                       update_running);
+  } else {
+    hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, rm, rv, save, C);
+  }
+  int64_t total = rows * (C / 4);
+  int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(blocks), dim3(256), 0, s, x, y, w, b, save, rows, C, tb_rows, T);
+}
+void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
+                      float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows) {
+  int T = tb_rows > 0 ? (int)(rows / tb_rows) : 0;
+  double* part = (double*)scratch;
+  double* fin = part + (size_t)BN_CHUNKS * C * 2;
+  int nchunk = (int)std::min<int64_t>(BN_CHUNKS, (rows + 63) / 64);
+  hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, x, y, dA, save, part, rows, C, 1, tb_rows, T);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, part, nchunk, rows, C, save, fin, dw, db);
+  int64_t total = rows * C;
+  int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T);
+}
+
+// =============================================================================================
+// attention core, LSTM.lua:133-150: one workgroup per batch row.
+//   phase 1: r[t] = <ctx[b,t,:], u[b,:]>     (wave per t, lanes over Hd, wave reduction)
+//   phase 2: softmax (forward) or softmax-backward (backward) over T in LDS
+//   phase 3: o[:] = sum_t p[t] * ctx[b,t,:]  (threads over Hd)
+// forward:  u=q, p=a=softmax(r), o=c.   backward: u=dc, r=da, p=ds=a*(da-sum a*da), o=dq.
+// =============================================================================================
+template <bool BWD>
+__global__ __launch_bounds__(256) void attn_core_kernel(const float* __restrict__ ctx, const float* __restrict__ u, int64_t ldu,
+                                                        const float* __restrict__ a_in, float* __restrict__ p_out,
+                                                        float* __restrict__ o, int64_t ldo, int T, int Hd, int ctx_div) {
+  extern __shared__ float sm[];                // [T] scores + [8] scratch
+  float* sc = sm; float* red = sm + T;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* cb = ctx + (int64_t)(b / ctx_div) * T * Hd;
+  const float* ub = u + (int64_t)b * ldu;
+  for (int t = wave; t < T; t += 4) {
+    float s = 0.f;
+    for (int j = lane * 4; j < Hd; j += 256) {
+      float4 cv = *reinterpret_cast<const float4*>(cb + (int64_t)t * Hd + j);
+      float4 uv = *reinterpret_cast<const float4*>(ub + j);
+      s = fmaf(cv.x, uv.x, s); s = fmaf(cv.y, uv.y, s); s = fmaf(cv.z, uv.z, s); s = fmaf(cv.w, uv.w, s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) sc[t] = s;
+  }
+  __syncthreads();
+  if (!BWD) {
+    float m = -INFINITY;
+    for (int t = threadIdx.x; t < T; t += 256) m = fmaxf(m, sc[t]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) { float e = expf(sc[t] - m); sc[t] = e; sum += e; }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    sum = red[4] + red[5] + red[6] + red[7];
+    float inv = 1.f / sum;
+    for (int t = threadIdx.x; t < T; t += 256) { float a = sc[t] * inv; sc[t] = a; p_out[(int64_t)b * T + t] = a; }
+  } else {
+    float dot = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) dot += a_in[(int64_t)b * T + t] * sc[t];
+    dot = wave_sum(dot);
+    if (lane == 0) red[wave] = dot;
+    __syncthreads();
+    dot = red[0] + red[1] + red[2] + red[3];
+    for (int t = threadIdx.x; t < T; t += 256) {
+      float ds = a_in[(int64_t)b * T + t] * (sc[t] - dot); sc[t] = ds; p_out[(int64_t)b * T + t] = ds;
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x * 4; j < Hd; j += 1024) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < T; ++t) {
+      float p = sc[t];
+      float4 cv = *reinterpret_cast<const float4*>(cb + (int64_t)t * Hd + j);
+      acc.x = fmaf(p, cv.x, acc.x); acc.y = fmaf(p, cv.y, acc.y); acc.z = fmaf(p, cv.z, acc.z); acc.w = fmaf(p, cv.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(o + (int64_t)b * ldo + j) = acc;
+  }
+}
+void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a, float* c, int64_t ldc, int B, int T, int Hd,
+                       int ctx_div) {
+  size_t sh = (size_t)(T + 8) * sizeof(float);
+  hipLaunchKernelGGL((attn_core_kernel<false>), dim3(B), dim3(256), sh, s, ctx, q, (int64_t)Hd, nullptr, a, c, ldc, T, Hd, ctx_div);
+}
+void attention_backward(hipStream_t s, const float* ctx, const float* q, const float* a, const float* dc, int64_t lddc,
+                        float* ds, float* dq, int B, int T, int Hd) {
+  (void)q;
+  size_t sh = (size_t)(T + 8) * sizeof(float);
+  hipLaunchKernelGGL((attn_core_kernel<true>), dim3(B), dim3(256), sh, s, ctx, dc, lddc, a, ds, dq, (int64_t)Hd, T, Hd, 1);
+}
+
+// d(ctx)[b,t,j] = sum_l a[l,b,t]*dc[l,b,j] + ds[l,b,t]*q[l,b,j]  (model.lua:652-653 accumulated over the decoder loop)
+__global__ __launch_bounds__(256) void attn_dctx_kernel(const float* __restrict__ a_all, const float* __restrict__ ds_all,
+                                                        const float* __restrict__ dc_all, int64_t lddc,
+                                                        const float* __restrict__ q_all, float* __restrict__ dctx, int L, int B,
+                                                        int T, int Hd) {
+  const int H4 = Hd >> 2;
+  const int64_t total = (int64_t)B * T * H4;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    int j = (int)(id % H4) * 4; int64_t bt = id / H4; int t = (int)(bt % T); int b = (int)(bt / T);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = L - 1; l >= 0; --l) {                          // same order as the reference's t = L..1 loop
+      float av = a_all[((int64_t)l * B + b) * T + t], dv = ds_all[((int64_t)l * B + b) * T + t];
+      float4 dc = *reinterpret_cast<const float4*>(dc_all + ((int64_t)l * B + b) * lddc + j);
+      float4 qv = *reinterpret_cast<const float4*>(q_all + ((int64_t)l * B + b) * Hd + j);
+      acc.x += av * dc.x + dv * qv.x; acc.y += av * dc.y + dv * qv.y; acc.z += av * dc.z + dv * qv.z; acc.w += av * dc.w + dv * qv.w;
+    }
+    *reinterpret_cast<float4*>(dctx + ((int64_t)b * T + t) * Hd + j) = acc;
+  }
+}
+void attention_dctx(hipStream_t s, const float* a_all, const float* ds_all, const float* dc_all, int64_t lddc, const float* q_all,
+                    float* dctx, int L, int B, int T, int Hd) {
+  int64_t total = (int64_t)B * T * (Hd / 4);
+  int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(attn_dctx_kernel, dim3(blocks), dim3(256), 0, s, a_all, ds_all, dc_all, lddc, q_all, dctx, L, B, T, Hd);
+}
+
+// =============================================================================================
+// LogSoftMax + weighted NLL (+ gradient): output_projector.lua:6, criterion.lua:3-8, model.lua:644-648.
+// row = t*Bt + b; target id = tgt[t*stride_t + b*stride_b] (1-based; PAD=1 has weight 0).
+// =============================================================================================
+__global__ __launch_bounds__(256) void lsm_nll_kernel(const float* __restrict__ logits, int64_t ld, const int32_t* __restrict__ tgt,
+                                                      int64_t st, int64_t sb, int Bt, float* __restrict__ logp,
+                                                      float* __restrict__ dlogits, float* __restrict__ nll, int64_t rows, int V,
+                                                      float scale) {
+  int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const float* x = logits + r * ld;
+  float m = -INFINITY;
+  for (int v = 0; v < V; ++v) m = fmaxf(m, x[v]);
+  float sum = 0.f;
+  for (int v = 0; v < V; ++v) sum += expf(x[v] - m);
+  float lse = m + logf(sum);
+  int64_t t = r / Bt, b = r - t * Bt;
+  int y = tgt[t * st + b * sb] - 1;
+  float wy = (y == 0) ? 0.f : 1.f;                              // criterion.lua:5: weights[PAD] = 0
+  if (nll) nll[r] = -wy * (x[y] - lse);
+  if (logp) for (int v = 0; v < V; ++v) logp[r * V + v] = x[v] - lse;
+  if (dlogits) {
+    float g = scale * wy;
+    for (int v = 0; v < V; ++v) dlogits[r * ld + v] = g * (expf(x[v] - lse) - (v == y ? 1.f : 0.f));
+    for (int v = V; v < ld; ++v) dlogits[r * ld + v] = 0.f;
+  }
+}
+void logsoftmax_nll(hipStream_t s, const float* logits, int64_t ld, const int32_t* tgt, int64_t st, int64_t sb, int Bt,
+                    float* logp, float* dlogits, float* nll_rows, int64_t rows, int V, float grad_scale) {
+  hipLaunchKernelGGL(lsm_nll_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, logits, ld, tgt, st, sb, Bt, logp, dlogits, nll_rows,
+                     rows, V, grad_scale);
+}
+
+__global__ __launch_bounds__(256) void sum_scalar_kernel(const float* __restrict__ x, int64_t n, float* out) {
+  __shared__ double sh[4];
+  double s = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)x[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+void sum_to_scalar(hipStream_t s, const float* x, int64_t n, float* out) {
+  hipLaunchKernelGGL(sum_scalar_kernel, dim3(1), dim3(256), 0, s, x, n, out);
+}
+__global__ void gold_kernel(const float* __restrict__ nll, float* gold, int L, int B) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int t = 0; t < L; ++t) s -= nll[(int64_t)t * B + b];     // model.lua:614-618 (PAD rows carry weight 0)
+  gold[b] = s;
+}
+void gold_scores(hipStream_t s, const float* nll_rows, float* gold, int L, int B) {
+  hipLaunchKernelGGL(gold_kernel, dim3(cdiv(B, 128)), dim3(128), 0, s, nll_rows, gold, L, B);
+}
+
+// out[n] += sum_r A[r][n]   (bias gradients); one writer per column -> deterministic
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t ld, int64_t rows, int N, float* out) {
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (n < N) for (int64_t r = rl; r < rows; r += 4) s += A[r * ld + n];
+  sh[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && n < N) out[n] += sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl];
+}
+void colsum_accum(hipStream_t s, const float* A, int64_t ld, int64_t rows, int N, float* out) {
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(256), 0, s, A, ld, rows, N, out);
+}
+
+// nn.LookupTable forward / accGradParameters (LSTM.lua:55-56)
+__global__ void emb_gather_kernel(const float* __restrict__ table, const int32_t* __restrict__ tok, int64_t st, int64_t sb,
+                                  float* out, int L, int B, int E) {
+  int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (int64_t)L * B * E) return;
+  int e = (int)(id % E); int64_t r = id / E; int64_t t = r / B, b = r - t * B;
+  out[id] = table[(int64_t)(tok[t * st + b * sb] - 1) * E + e];
+}
+void embedding_gather(hipStream_t s, const float* table, const int32_t* tok, int64_t st, int64_t sb, float* out, int L, int B, int E) {
+  int64_t n = (int64_t)L * B * E;
+  hipLaunchKernelGGL(emb_gather_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, table, tok, st, sb, out, L, B, E);
+}
+__global__ __launch_bounds__(64) void emb_scatter_kernel(const float* __restrict__ demb, const int32_t* __restrict__ tok, int64_t st,
+                                                         int64_t sb, float* dtable, int L, int B, int E) {
+  const int v = blockIdx.x;                                     // one workgroup per vocabulary row: deterministic
+  for (int e = threadIdx.x; e < E; e += 64) {
+    float s = 0.f;
+    for (int t = L - 1; t >= 0; --t)
+      for (int b = 0; b < B; ++b)
+        if (tok[t * st + b * sb] - 1 == v) s += demb[((int64_t)t * B + b) * E + e];
+    dtable[(int64_t)v * E + e] += s;
+  }
+}
+void embedding_scatter_accum(hipStream_t s, const float* demb, const int32_t* tok, int64_t st, int64_t sb, float* dtable, int L,
+                             int B, int E, int V) {
+  hipLaunchKernelGGL(emb_scatter_kernel, dim3(V), dim3(64), 0, s, demb, tok, st, sb, dtable, L, B, E);
+}
+
+__global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                   const float* __restrict__ out, float* __restrict__ dpre, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float g = g1[i] + (g2 ? g2[i] : 0.f);
+  float o = out[i];
+  dpre[i] = g * (1.f - o * o);
+}
+void dpre_tanh(hipStream_t s, const float* g1, const float* g2, const float* out, float* dpre, int64_t n) {
+  hipLaunchKernelGGL(dpre_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, g1, g2, out, dpre, n);
+}
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst, int64_t ldd,
+                                                     int rows, int cols) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  int c = (int)(i % cols); int64_t r = i / cols;
+  dst[r * ldd + c] = src[r * lds + c];
+}
+void copy2d(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols) {
+  hipLaunchKernelGGL(copy2d_kernel, dim3(cdiv((int64_t)rows * cols, 256)), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
+}
+
+// =============================================================================================
+// optim.sgd_list (optim_sgd.lua:38-95): per-group L2 norms (fp64 accumulation), clip, update.  No host sync.
+// scratch: double part[5][2][SGD_BLOCKS]; float scale[5].
+// =============================================================================================
+static const int SGD_BLOCKS = 256;
+size_t sgd_scratch_bytes() { return (size_t)5 * 2 * SGD_BLOCKS * sizeof(double) + 8 * sizeof(float); }
+struct GroupOff { int64_t o[6]; };
+
+__global__ __launch_bounds__(256) void sgd_sumsq_kernel(const float* __restrict__ p, const float* __restrict__ g, GroupOff go,
+                                                        double* __restrict__ part) {
+  __shared__ double sh[2][4];
+  const int grp = blockIdx.y;
+  const int64_t beg = go.o[grp], end = go.o[grp + 1];
+  double sp = 0, sg = 0;
+  for (int64_t i = beg + (int64_t)blockIdx.x * 256 + threadIdx.x; i < end; i += (int64_t)gridDim.x * 256) {
+    double a = p[i], b = g[i]; sp += a * a; sg += b * b;
+  }
+  sp = wave_sum_d(sp); sg = wave_sum_d(sg);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = sp; sh[1][threadIdx.x >> 6] = sg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[((int64_t)grp * 2 + 0) * SGD_BLOCKS + blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    part[((int64_t)grp * 2 + 1) * SGD_BLOCKS + blockIdx.x] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+  }
+}
+__global__ void sgd_scale_kernel(const double* __restrict__ part, float clip, float* scale, float* norms) {
+  int grp = threadIdx.x;
+  if (grp >= 5) return;
+  double sp = 0, sg = 0;
+  for (int i = 0; i < SGD_BLOCKS; ++i) { sp += part[((int64_t)grp * 2) * SGD_BLOCKS + i]; sg += part[((int64_t)grp * 2 + 1) * SGD_BLOCKS + i]; }
+  double pn = sqrt(sp), gn = sqrt(sg);
+  scale[grp] = (gn > (double)clip) ? (float)((double)clip / gn) : 1.f;       // optim_sgd.lua:50-52
+  if (norms) { norms[grp * 2] = (float)pn; norms[grp * 2 + 1] = (float)gn; }
+}
+__global__ __launch_bounds__(256) void sgd_update_kernel(float* __restrict__ p, const float* __restrict__ g, GroupOff go,
+                                                         const float* __restrict__ scale, float lr) {
+  const int grp = blockIdx.y;
+  const int64_t beg = go.o[grp], end = go.o[grp + 1];
+  const float sc = scale[grp];
+  for (int64_t i = beg + (int64_t)blockIdx.x * 256 + threadIdx.x; i < end; i += (int64_t)gridDim.x * 256)
+    p[i] = p[i] - lr * (g[i] * sc);                             // optim_sgd.lua:52,90
+}
+void sgd_clip_update(hipStream_t s, float* params, float* grads, const int64_t* group_off, float lr, float clip, float* norms_out,
+                     void* scratch) {
+  GroupOff go; for (int i = 0; i < 6; ++i) go.o[i] = group_off[i];
+  double* part = (double*)scratch; float* scale = (float*)(part + 5 * 2 * SGD_BLOCKS);
+  hipLaunchKernelGGL(sgd_sumsq_kernel, dim3(SGD_BLOCKS, 5), dim3(256), 0, s, params, grads, go, part);
+  hipLaunchKernelGGL(sgd_scale_kernel, dim3(1), dim3(64), 0, s, part, clip, scale, norms_out);
+  hipLaunchKernelGGL(sgd_update_kernel, dim3(1024, 5), dim3(256), 0, s, params, grads, go, scale, lr);
+}
+
+// =============================================================================================
+// beam search bookkeeping, model.lua:399-404, 446-458, 516-535, 573-585.
+// =============================================================================================
+// one wave per batch row; candidates c = beam*V + v (v 0-based).  Selection: descending score, ties -> lowest index.
+__global__ __launch_bounds__(64) void beam_select_kernel(const float* __restrict__ logp, const int32_t* __restrict__ prev_tok,
+                                                         float* __restrict__ beam_scores, int32_t* __restrict__ tokens,
+                                                         int32_t* __restrict__ parents, int kin, int kout, int V) {
+  extern __shared__ float cand[];                               // kin*V
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int n = kin * V;
+  for (int c = lane; c < n; c += 64) {
+    int beam = c / V, v = c - beam * V;
+    int row = b * kin + beam;
+    float lp = logp[(int64_t)row * V + v];
+    if (prev_tok) {
+      int pt = prev_tok[row];
+      if (v == 0 && (pt == 1 || pt == 3)) lp = 0.f;             // model.lua:448-449: finished beams continue with PAD at zero cost
+      lp += beam_scores[b * kin + beam];                        // model.lua:450
+    }
+    cand[c] = lp;
+  }
+  __syncthreads();
+  for (int k = 0; k < kout; ++k) {
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int c = lane; c < n; c += 64) { float v = cand[c]; if (v > best) { best = v; bi = c; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+      cand[bi] = -INFINITY;
+      tokens[b * kout + k] = bi % V + 1;                        // model.lua:456-458
+      parents[b * kout + k] = bi / V;                           // model.lua:516 (0-based; S9 fixed at t=1: kin=1 -> 0)
+    }
+    __syncthreads();
+    if (lane == 0) ((volatile float*)cand)[n + k] = best;       // stash; written back after the loop (beam_scores is also an input)
+    __syncthreads();
+  }
+  for (int k = lane; k < kout; k += 64) beam_scores[b * kout + k] = cand[n + k];
+}
+void beam_select(hipStream_t s, const float* logp, const int32_t* prev_tok, float* beam_scores, int32_t* tokens, int32_t* parents,
+                 int B, int kin, int kout, int V) {
+  size_t sh = (size_t)(kin * V + kout) * sizeof(float);
+  hipLaunchKernelGGL(beam_select_kernel, dim3(B), dim3(64), sh, s, logp, prev_tok, beam_scores, tokens, parents, kin, kout, V);
+}
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst,
+                                                          int64_t ldd, const int32_t* __restrict__ parents, int B, int kin, int kout,
+                                                          int width) {
+  int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (int64_t)B * kout * width) return;
+  int c = (int)(id % width); int64_t r = id / width; int b = (int)(r / kout);
+  int sr = (kin == 1) ? b : b * kin + parents[r];
+  dst[r * ldd + c] = src[(int64_t)sr * lds + c];
+}
+void gather_beam_rows(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, const int32_t* parents, int B, int kin,
+                      int kout, int width) {
+  int64_t n = (int64_t)B * kout * width;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, src, lds, dst, ldd, parents, B, kin, kout, width);
+}
+__global__ void backtrace_kernel(const int32_t* __restrict__ hist_tok, const int32_t* __restrict__ hist_par,
+                                 const float* __restrict__ beam_scores, int32_t* labels, float* scores, int Lt, int B, int k) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float best = beam_scores[b * k]; int bi = 0;
+  for (int i = 1; i < k; ++i) if (beam_scores[b * k + i] > best) { best = beam_scores[b * k + i]; bi = i; }   // torch.max: first max
+  scores[b] = best;
+  int idx = bi;
+  for (int t = Lt - 1; t >= 0; --t) {
+    labels[(int64_t)b * Lt + t] = hist_tok[((int64_t)t * B + b) * k + idx];
+    idx = hist_par[((int64_t)t * B + b) * k + idx];
+  }
+}
+void beam_backtrace(hipStream_t s, const int32_t* hist_tok, const int32_t* hist_par, const float* beam_scores, int32_t* labels,
+                    float* scores, int Lt, int B, int k) {
+  hipLaunchKernelGGL(backtrace_kernel, dim3(cdiv(B, 128)), dim3(128), 0, s, hist_tok, hist_par, beam_scores, labels, scores, Lt, B, k);
+}
+__global__ void fill_i32_kernel(int32_t* p, int32_t v, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+void fill_i32(hipStream_t s, int32_t* p, int32_t v, int64_t n) {
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, v, n);
+}
+
+}  // namespace aocr
