@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the CNN -> BiLSTM -> attention-decoder hot path on MI355X.
+
+`python bench.py --gpus N --steps K --warmup W`  (N>1: launched by torch.distributed.run, one rank per GPU).
+A "step" = one full train step of the reference's feval + optim.sgd_list (forward, hand-ordered BPTT, clip, SGD
+[+ RCCL gradient all-reduce]) on one synthetic batch already resident in HBM.  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs): c3 (default) = 32x256 crops, batch 256 per GPU, He=256, Ld=2, input feed, L=24,
+bf16 operands / fp32 accumulate; c2 = 32x100, batch 64, fp32 MFMA.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "torch-attention-ocr_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOADS = {
+    "c3": dict(B=256, W=256, L=24, He=256, Le=1, Ld=2, compute="bf16", name="32x256 crops, batch 256/GPU, VGG-7 + BiLSTM(256) + 2-layer attn decoder, L=24"),
+    "c2": dict(B=64, W=100, L=24, He=256, Le=1, Ld=2, compute="f32", name="32x100 crops, batch 64/GPU, VGG-7 + BiLSTM(256) + 2-layer attn decoder, L=24"),
+}
+
+
+def flops_per_image(W, He, Le, Ld, L, E=20, V=39):
+    """2*M*N*K per contraction, forward; train = 3x."""
+    Hd = 2 * He
+    T = W // 4 - 1
+    cnn = 2 * (9 * 64 * 32 * W + 9 * 64 * 128 * 8 * W + 9 * 128 * 256 * 2 * W + 9 * 256 * 256 * 2 * W + 9 * 256 * 512 * W
+               + 9 * 512 * 512 * W + 4 * 512 * 512 * T)
+    enc = 2 * T * sum(2 * ((512 if l == 0 else He) + He) * 4 * He for l in range(Le))
+    dec = L * (sum(2 * ((E + Hd if l == 0 else Hd) + Hd) * 4 * Hd for l in range(Ld)) + 6 * Hd * Hd + 4 * T * Hd + 2 * Hd * V)
+    return cnn + enc + dec
+
+
+def cpu_baseline(wl, seconds_budget=25.0):
+    """The oracle (torch CPU restatement, fp32, all host cores) timed on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_torch as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.OcrConfig(enc_hidden=wl["He"], enc_layers=wl["Le"], dec_layers=wl["Ld"], input_feed=True)
+    P = {k: v.float() for k, v in O.init_params(cfg, 910820).items()}
+    st = {k: v.float() for k, v in O.init_bn_state().items()}
+    Bc = 8
+    img, tgt, tge, _ = O.synth_batch(Bc, wl["W"], max_len=wl["L"] - 1)
+    img = torch.from_numpy(img).float(); tgt = torch.from_numpy(tgt); tge = torch.from_numpy(tge)
+    t0 = time.time(); n = 0
+    while True:
+        loss, G, _, _ = O.train_step_manual(P, st, cfg, img, tgt, tge)
+        O.sgd_list(P, G, 0.1)
+        n += 1
+        el = time.time() - t0
+        if el > seconds_budget or n >= 8:
+            break
+    return {"value": Bc * n / el, "unit": "image-lines/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of batch {Bc} at 32x{wl['W']} (torch-CPU fp32 restatement, {cores} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--compute", default=None, choices=["f32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode-steps", type=int, default=3)
+    args = ap.parse_args()
+    wl = dict(WORKLOADS[args.workload])
+    if args.compute:
+        wl["compute"] = args.compute
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist = torch.distributed
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import aocr
+    B, W, L = wl["B"], wl["W"], wl["L"]
+    m = aocr.Model().create(dict(encoder_num_hidden=wl["He"], encoder_num_layers=wl["Le"], decoder_num_layers=wl["Ld"],
+                                 input_feed=True, batch_size=B, max_img_w=W, max_decoder_l=50, max_beam=1,
+                                 compute=wl["compute"], learning_rate=0.1, seed=910820))
+    if world > 1:
+        dist.broadcast(m.params, 0)                     # identical replicas
+    img, tgt, tge, nnz = aocr.synth.synth_batch(B, W, seed=1234 + rank, max_len=L - 1)
+    dev = m.device
+    images = torch.from_numpy(img).to(device=dev, dtype=torch.float32)
+    targets = torch.from_numpy(tgt).to(dev); targets_eval = torch.from_numpy(tge).to(dev)
+    assert targets.shape[1] == L
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        m.train_step_device(images, targets, targets_eval)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = m.train_step_device(images, targets, targets_eval)
+    sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    loss_val = float(loss.item())
+    lines_per_s = world * B * args.steps / el
+
+    # decode throughput (greedy, max_decoder_l = 50 steps + gold pass, the reference's -phase test step)
+    dec = None
+    if args.decode_steps > 0:
+        m.decode_device(images, targets, targets_eval, 1); sync()
+        t0 = time.perf_counter()
+        for _ in range(args.decode_steps):
+            m.decode_device(images, targets, targets_eval, 1)
+        sync()
+        eld = time.perf_counter() - t0
+        dec = world * B * 50 * args.decode_steps / eld
+
+    out = None
+    if rank == 0:
+        bf16 = wl["compute"] == "bf16"
+        ms, fl = m.profile_kernel(0, 20)
+        peak = 2500.0 if bf16 else 157.3
+        ach = fl / (ms * 1e-3) / 1e12
+        fpi = flops_per_image(W, wl["He"], wl["Le"], wl["Ld"], L)
+        out = {
+            "metric": "image-lines/sec (train step)", "value": lines_per_s, "unit": "image-lines/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {wl['name']}", "global_batch": world * B, "img": f"32x{W}",
+                       "decoder_steps": L, "parallelism": f"dp{world}", "input_feed": True},
+            "train_gflop_per_image": 3 * fpi / 1e9, "step_tflops": 3 * fpi * lines_per_s / 1e12,
+            "step_mfma_frac": 3 * fpi * lines_per_s / 1e12 / (peak * world),
+            "decode_chars_per_s": dec, "loss": loss_val,
+            "roofline": {"bound": "mfma", "kernel": "conv6 forward implicit GEMM (512->512 3x3 + ReLU + pool)",
+                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                         "ms_per_launch": ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(wl)
+    m.shutdown()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

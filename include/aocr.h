@@ -122,7 +122,7 @@ int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32
  * ms_per_launch and flops_per_launch are host outputs (this call synchronises). */
 int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_per_launch, double* flops_per_launch);
 
-/* ---- module-level entry points (the nn.Module surface of src/model/*.lua) ---- */
+/* ---- module-level entry points (the nn.Module surface of the files under src/model) ---- */
 
 /* C[M,N] (ldc) = op(A) * op(B) (+bias[n]) ; a_kmajor: 1 = A stored [M][K] (lda), 0 = [K][M];
  * b_kmajor: 1 = B stored [N][K] (ldb), 0 = [K][N].  nn.Linear forward is (1,1) with bias

@@ -25,8 +25,18 @@ def rnd(*shape, seed=0, scale=1.0):
     return (torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
 
 
+_KEEP = []
+
+
 def dev(t, dtype=torch.float32):
-    return t.to(dtype).cuda().contiguous()
+    """Upload and keep a reference: a.ptr(dev(x)) on a temporary would let the caching allocator recycle the
+    block for the next upload before the kernel has run."""
+    d = t.to(dtype).cuda().contiguous()
+    _KEEP.append(d)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:128]
+    return d
 
 
 def report(name, got, ref, tol):
@@ -79,24 +89,34 @@ def test_conv_forward_backward(cuda, B, H, W, Cin, Cout, ks, pad, relu, pool, co
     a.check(a.lib.aocr_conv2d_forward(stream(), compute, a.ptr(xd), a.ptr(wd), a.ptr(bd), a.ptr(yd), a.ptr(idx), B, H, W, Cin, Cout,
                                       ks, pad, relu, pool))
     report(f"conv fwd c{compute} {Cin}->{Cout} k{ks} pool{pool}", yd, nhwc(y.detach()), tol)
-    # backward: gradient at the (pooled) output
+    # backward: gradient at the (pooled) output.  Each kernel is checked on its own: un-pool against autograd
+    # (a near-tie inside a window may pick another arg-max in fp32 than in fp64, so a handful of flipped windows
+    # is tolerated), then dgrad / wgrad against torch.nn.grad on the DEVICE's dy.
     g = rnd(*y.shape, seed=4)
+    y0.retain_grad()
     y.backward(g)
     Ho, Wo = y0.shape[2], y0.shape[3]
     gd = dev(nhwc(g))
     if pool:
         dy = torch.zeros(B, Ho, Wo, Cout, device="cuda")
         a.check(a.lib.aocr_unpool_relu_backward(stream(), a.ptr(gd), a.ptr(yd), a.ptr(idx), a.ptr(dy), B, Ho, Wo, Cout, pool))
+        bad = ((dy.double().cpu() - nhwc(y0.grad)).abs() > 1e-6).sum().item()
+        print(f"[parity] unpool pool{pool}: {bad} of {dy.numel()} elements differ (arg-max near-ties)")
+        assert bad <= (max(4, dy.numel() // 20000) if compute == 0 else dy.numel() // 50)   # bf16 rounding flips more near-ties
     else:
         dy = gd
+    dyr = dy.double().cpu().permute(0, 3, 1, 2).contiguous()
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, w.detach(), dyr, padding=pad)
+    dw_ref = torch.nn.grad.conv2d_weight(x.detach(), w.shape, dyr, padding=pad)
+    db_ref = dyr.sum(dim=(0, 2, 3))
     dx = torch.zeros(B, H, W, Cin, device="cuda")
     a.check(a.lib.aocr_conv2d_backward_data(stream(), compute, a.ptr(dy), a.ptr(wd), a.ptr(dx), B, H, W, Cin, Cout, ks, pad))
-    report(f"conv dgrad c{compute} {Cin}->{Cout} k{ks} pool{pool}", dx, nhwc(x.grad), tol * 3)
+    report(f"conv dgrad c{compute} {Cin}->{Cout} k{ks} pool{pool}", dx, nhwc(dx_ref), tol * 3)
     dw = torch.zeros(Cout, ks, ks, Cin, device="cuda"); db = torch.zeros(Cout, device="cuda")
     a.check(a.lib.aocr_conv2d_backward_filter(stream(), compute, a.ptr(xd), a.ptr(dy), a.ptr(dw), a.ptr(db), B, H, W, Cin, Cout, ks, pad))
-    scale = max(1.0, w.grad.abs().max().item())
-    report(f"conv wgrad c{compute} {Cin}->{Cout} k{ks} pool{pool}", dw / scale, w.grad.permute(0, 2, 3, 1) / scale, tol * 3)
-    report(f"conv bgrad c{compute}", db / scale, b.grad / scale, tol * 3)
+    scale = max(1.0, dw_ref.abs().max().item())
+    report(f"conv wgrad c{compute} {Cin}->{Cout} k{ks} pool{pool}", dw / scale, dw_ref.permute(0, 2, 3, 1) / scale, tol * 3)
+    report(f"conv bgrad c{compute}", db / scale, db_ref / scale, tol * 3)
 
 
 @pytest.mark.parametrize("B,W", [(2, 36), (3, 100)])
@@ -210,7 +230,7 @@ def test_logsoftmax_nll(cuda):
     dl = scale * w[y - 1].unsqueeze(1) * (torch.exp(lp) - F.one_hot(y - 1, V))
     xd = torch.zeros(rows, ld, device="cuda"); xd[:, :V] = dev(x)
     lpd = torch.zeros(rows, V, device="cuda"); dld = torch.ones(rows, ld, device="cuda"); nd = torch.zeros(rows, device="cuda")
-    a.check(a.lib.aocr_logsoftmax_nll(stream(), a.ptr(xd), ld, a.ptr(y.to(torch.int32).cuda()), a.ptr(lpd), a.ptr(dld), a.ptr(nd), rows, V, scale))
+    a.check(a.lib.aocr_logsoftmax_nll(stream(), a.ptr(xd), ld, a.ptr(dev(y, torch.int32)), a.ptr(lpd), a.ptr(dld), a.ptr(nd), rows, V, scale))
     report("logp", lpd, lp, 1e-5); report("nll", nd, nll, 1e-5); report("dlogits", dld[:, :V], dl, 1e-6)
     assert float(dld[:, V:].abs().max()) == 0.0
 
@@ -232,7 +252,7 @@ def test_beam_select(cuda, kin, kout):
     bsd = torch.zeros(B, max(kin, kout), device="cuda").reshape(-1)
     bsd[:B * kin] = dev(bs).reshape(-1)
     tk = torch.zeros(B, kout, dtype=torch.int32, device="cuda"); pr = torch.zeros(B, kout, dtype=torch.int32, device="cuda")
-    a.check(a.lib.aocr_beam_select(stream(), a.ptr(dev(lp)), a.ptr(prev.cuda()) if kin > 1 else None, a.ptr(bsd), a.ptr(tk), a.ptr(pr), B, kin, kout, V))
+    a.check(a.lib.aocr_beam_select(stream(), a.ptr(dev(lp)), a.ptr(dev(prev, torch.int32)) if kin > 1 else None, a.ptr(bsd), a.ptr(tk), a.ptr(pr), B, kin, kout, V))
     assert torch.equal(tk.cpu().long(), toks), (tk.cpu(), toks)
     assert torch.equal(pr.cpu().long(), par)
     report("beam scores", bsd[:B * kout].reshape(B, kout), vals, 1e-5)

@@ -185,9 +185,10 @@ class Model:
                 stdv = None
             elif name == "dec.lookup":
                 stdv = None
-            else:
-                wname = name[:-2] + ".w"
-                wshape = next(s for (nm, _, _, s) in self.table if nm == wname)
+            elif len(shape) == 2:                                  # nn.Linear / LinearNoBias weight: 1/sqrt(fan_in)
+                stdv = 1.0 / math.sqrt(shape[1])
+            else:                                                  # bias: same stdv as its weight
+                wshape = next(s for (nm, _, _, s) in self.table if nm == name[:-2] + ".w")
                 stdv = 1.0 / math.sqrt(wshape[1])
             if name == "dec.lookup":
                 v = torch.randn(n, generator=gen)
@@ -263,6 +264,51 @@ class Model:
         assert images.dim() == 4 and images.shape[1] == 1 and images.shape[2] == self.img_h
         return images, targets, targets_eval
 
+    def train_step_device(self, images, targets, targets_eval):
+        """One optimisation step on inputs already resident in HBM; enqueues only (no host sync) and returns
+        the device scalar holding the step's NLL sum (summed over ranks under data parallelism)."""
+        B, _, _, W = images.shape
+        target_l = targets.shape[1]
+        assert target_l <= self.max_decoder_l, f"max_decoder_l ({self.max_decoder_l}) < target_l ({target_l})!"
+        check(lib.aocr_model_set_stream(self._h, self._stream()))
+        loss_dev = self._scal[0:1]
+        world = 1
+        dist = torch.distributed
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size()
+        # d(loss) / (global batch): model.lua:645-647 divides by the step's batch size
+        check(lib.aocr_train_forward_backward(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, target_l,
+                                              1.0 / (B * world), ptr(loss_dev)), "aocr_train_forward_backward")
+        if world > 1:
+            # the one exchange step of data parallelism: sum gradients over ranks (RCCL over xGMI),
+            # inserted between feval and the per-group clip (optim_sgd.lua:38 -> :40)
+            dist.all_reduce(self.grad_params)
+            dist.all_reduce(loss_dev)
+        norms = self._scal[2:12]
+        check(lib.aocr_sgd_step(self._h, float(self.optim_state["learningRate"]), 5.0, ptr(norms)), "aocr_sgd_step")
+        self.last_norms = norms
+        return loss_dev
+
+    def decode_device(self, images, targets, targets_eval, beam_size=1):
+        """forward_only feval on device-resident inputs; enqueues only.  Returns device tensors
+        (labels (B,max_decoder_l) int32, beam scores (B), gold scores (B), gold-pass NLL sum (1))."""
+        B, _, _, W = images.shape
+        Lt = self.max_decoder_l
+        check(lib.aocr_model_set_stream(self._h, self._stream()))
+        labels = torch.empty((B, Lt), dtype=torch.int32, device=self.device)
+        scores = torch.empty(B, dtype=torch.float32, device=self.device)
+        gold = torch.empty(B, dtype=torch.float32, device=self.device)
+        loss_dev = self._scal[0:1]
+        check(lib.aocr_decode(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, targets.shape[1], beam_size,
+                              ptr(labels), ptr(scores), ptr(gold), ptr(loss_dev)), "aocr_decode")
+        return labels, scores, gold, loss_dev
+
+    def profile_kernel(self, which=0, iters=20):
+        """HIP-event timing of one hot kernel at the last step's shape: (ms per launch, flops per launch)."""
+        ms, fl = C.c_float(), C.c_double()
+        check(lib.aocr_profile_kernel(self._h, which, iters, C.byref(ms), C.byref(fl)), "aocr_profile_kernel")
+        return ms.value, fl.value
+
     def step(self, batch, forward_only, beam_size=None, trie=None):
         """Returns (loss*batch_size, [num_nonzeros, num_correct]) exactly like model:step (model.lua:695-705)."""
         if trie is not None:
@@ -275,31 +321,13 @@ class Model:
         check(lib.aocr_model_set_stream(self._h, self._stream()))
         loss_dev = self._scal[0:1]
         if not forward_only:
-            world = 1
-            dist = torch.distributed
-            if dist.is_available() and dist.is_initialized():
-                world = dist.get_world_size()
-            # d(loss) / (global batch): model.lua:645-647 divides by the step's batch size
-            check(lib.aocr_train_forward_backward(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, target_l,
-                                                  1.0 / (B * world), ptr(loss_dev)), "aocr_train_forward_backward")
-            if world > 1:
-                # the one exchange step of data parallelism: sum gradients over ranks (RCCL over xGMI),
-                # inserted between feval and the per-group clip (optim_sgd.lua:38 -> :40)
-                dist.all_reduce(self.grad_params)
-                dist.all_reduce(loss_dev)
-            norms = self._scal[2:12]
-            check(lib.aocr_sgd_step(self._h, float(self.optim_state["learningRate"]), 5.0, ptr(norms)), "aocr_sgd_step")
-            self.last_norms = norms
+            loss_dev = self.train_step_device(images, targets, targets_eval)
             return float(loss_dev.item()), [num_nonzeros, 0.0]
         # forward only: beam search + gold pass
         beam_size = beam_size or 1
         beam_size = min(beam_size, self.target_vocab_size)
         Lt = self.max_decoder_l
-        labels = torch.empty((B, Lt), dtype=torch.int32, device=self.device)
-        scores = torch.empty(B, dtype=torch.float32, device=self.device)
-        gold = torch.empty(B, dtype=torch.float32, device=self.device)
-        check(lib.aocr_decode(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, target_l, beam_size, ptr(labels),
-                              ptr(scores), ptr(gold), ptr(loss_dev)), "aocr_decode")
+        labels, scores, gold, loss_dev = self.decode_device(images, targets, targets_eval, beam_size)
         labels_h = labels.cpu().numpy()
         tge = np.full((B, Lt), PAD, dtype=np.int32)
         tge[:, :target_l] = targets_eval.cpu().numpy()
