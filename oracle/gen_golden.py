@@ -1,0 +1,89 @@
+"""Generates tests/golden/*.npz from the CPU float64 oracle (oracle/oracle_torch.py).
+
+The reference (Lua/Torch7) holds no golden vectors and cannot run here ("parity unpinned", see the oracle header);
+these fixtures pin the ORACLE itself so that any later edit of it is caught, and give the GPU tests fixed targets.
+Inputs and weights are not stored: they are regenerated from the counter-based generator (seed in the file).
+
+    python oracle/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import oracle_torch as O  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+CASES = {
+    # name: (config kwargs, B, W, max_len)
+    "feed_ld2": (dict(enc_hidden=16, enc_layers=1, dec_layers=2, input_feed=True), 2, 36, 5),
+    "nofeed_ld2": (dict(enc_hidden=16, enc_layers=1, dec_layers=2, input_feed=False), 2, 36, 5),
+    "feed_ld1": (dict(enc_hidden=16, enc_layers=1, dec_layers=1, input_feed=True), 2, 36, 5),
+    "le2_ld3": (dict(enc_hidden=16, enc_layers=2, dec_layers=3, input_feed=True), 2, 36, 5),
+}
+SEED = 910820
+
+
+def probes(t, n=32):
+    """n deterministic probe entries of a tensor (flattened index = (i * 2654435761) % numel)."""
+    f = t.reshape(-1)
+    idx = (np.arange(n, dtype=np.int64) * 2654435761) % f.numel()
+    return f[torch.from_numpy(idx)].numpy()
+
+
+def run_case(kw, B, W, maxlen):
+    cfg = O.OcrConfig(**kw)
+    P, st = O.init_params(cfg, SEED), O.init_bn_state()
+    img, tgt, tge, nnz = O.synth_batch(B, W, max_len=maxlen, min_len=2)
+    img = torch.from_numpy(img); tgt = torch.from_numpy(tgt); tge = torch.from_numpy(tge)
+    loss, G, aux, st2 = O.train_step_manual(P, st, cfg, img, tgt, tge)
+    la, Ga, _, _ = O.train_step_autograd(P, st, cfg, img, tgt, tge)
+    assert max(float((G[k] - Ga[k]).abs().max()) for k in G) < 1e-12        # hand-rolled BPTT == autograd
+    out = dict(loss=np.float64(loss), nnz=np.int64(nnz),
+               feats_first=aux["feats"][:, :, :64].numpy(), feats_last=aux["feats"][:, :, -64:].numpy(),
+               context=aux["context"].numpy(), logits=aux["logits"].numpy())
+    newP, norms = O.sgd_list(P, G, 0.1, 5.0)
+    newP2, _ = O.sgd_list(P, G, 0.1, 0.05)
+    out["norms"] = np.array(norms)
+    for k in G:
+        out["g:" + k] = probes(G[k]); out["p5:" + k] = probes(newP[k]); out["p005:" + k] = probes(newP2[k])
+    for k, v in st2.items():
+        out["bn:" + k] = v.numpy()
+    # eval-mode forward with the updated running stats, greedy + beam-5 decode
+    for beam in (1, 5):
+        d = O.decode_beam(newP, st2, cfg, img, tgt, tge, beam=beam, max_decoder_l=8)
+        out[f"dec{beam}:labels"] = d["labels"].numpy(); out[f"dec{beam}:scores"] = d["scores"].numpy()
+        out[f"dec{beam}:gold"] = d["gold_scores"].numpy(); out[f"dec{beam}:loss"] = np.float64(d["loss"])
+        out[f"dec{beam}:correct"] = np.int64(d["num_correct"])
+    return out
+
+
+def leaf_fixtures():
+    """Hand-checkable known answers for the leaf ops."""
+    out = {}
+    x = torch.arange(16, dtype=torch.float64).reshape(1, 1, 4, 4)
+    out["pool_kh2_kw1"] = torch.nn.functional.max_pool2d(x, (2, 1), (2, 1)).numpy()      # cnn.lua:29: halves HEIGHT only
+    out["conv7_width"] = np.int64(torch.nn.functional.conv2d(torch.zeros(1, 1, 2, 25), torch.zeros(1, 1, 2, 2)).shape[3])
+    lp = torch.log_softmax(torch.tensor([[1.0, 2.0, 3.0], [0.5, 0.1, 0.2]], dtype=torch.float64), 1)
+    y = torch.tensor([1, 3]); w = torch.tensor([0.0, 1.0, 1.0], dtype=torch.float64)     # PAD (id 1) weight 0
+    out["nll_pad_weight0"] = np.float64(-(w[y - 1] * lp[torch.arange(2), y - 1]).sum())
+    g = {"cnn.x": torch.tensor([3.0, 4.0, 12.0], dtype=torch.float64)}                   # norm 13 > 5 -> scale 5/13
+    newp, norms = O.sgd_list({"cnn.x": torch.zeros(3, dtype=torch.float64)}, g, 1.0, 5.0)
+    out["clip_13_to_5"] = newp["cnn.x"].numpy()
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for name, (kw, B, W, ml) in CASES.items():
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **run_case(kw, B, W, ml))
+        print("wrote", name)
+    np.savez_compressed(os.path.join(OUT, "leaf_ops.npz"), **leaf_fixtures())
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, dist
 from ._lib import Config, check, lib, ptr
 
 PAD, GO, EOS = 1, 2, 3
@@ -272,18 +272,11 @@ class Model:
         assert target_l <= self.max_decoder_l, f"max_decoder_l ({self.max_decoder_l}) < target_l ({target_l})!"
         check(lib.aocr_model_set_stream(self._h, self._stream()))
         loss_dev = self._scal[0:1]
-        world = 1
-        dist = torch.distributed
-        if dist.is_available() and dist.is_initialized():
-            world = dist.get_world_size()
         # d(loss) / (global batch): model.lua:645-647 divides by the step's batch size
         check(lib.aocr_train_forward_backward(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, target_l,
-                                              1.0 / (B * world), ptr(loss_dev)), "aocr_train_forward_backward")
-        if world > 1:
-            # the one exchange step of data parallelism: sum gradients over ranks (RCCL over xGMI),
-            # inserted between feval and the per-group clip (optim_sgd.lua:38 -> :40)
-            dist.all_reduce(self.grad_params)
-            dist.all_reduce(loss_dev)
+                                              dist.grad_scale(B), ptr(loss_dev)), "aocr_train_forward_backward")
+        # the one exchange step of data parallelism (RCCL over xGMI), between feval and the per-group clip
+        dist.exchange(self.grad_params, loss_dev)
         norms = self._scal[2:12]
         check(lib.aocr_sgd_step(self._h, float(self.optim_state["learningRate"]), 5.0, ptr(norms)), "aocr_sgd_step")
         self.last_norms = norms

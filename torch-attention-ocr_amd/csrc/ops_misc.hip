@@ -477,19 +477,33 @@ void gold_scores(hipStream_t s, const float* nll_rows, float* gold, int L, int B
   hipLaunchKernelGGL(gold_kernel, dim3(cdiv(B, 128)), dim3(128), 0, s, nll_rows, gold, L, B);
 }
 
-// out[n] += sum_r A[r][n]   (bias gradients); one writer per column -> deterministic
+// out[n] += sum_r A[r][n]   (bias gradients).  grid = (column blocks of 64, row chunks); each block reduces its
+// chunk in registers + LDS and issues one 256-byte atomic add per wave-row (HBM-bound: reads A once).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t ld, int64_t rows, int N, float* out) {
   __shared__ float sh[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + cl;
-  float s = 0.f;
-  if (n < N) for (int64_t r = rl; r < rows; r += 4) s += A[r * ld + n];
-  sh[rl][cl] = s;
+  const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+  const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(rows, r0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (n < N) {
+    int64_t r = r0 + rl;
+    for (; r + 12 < r1; r += 16) {
+      s0 += A[r * ld + n]; s1 += A[(r + 4) * ld + n]; s2 += A[(r + 8) * ld + n]; s3 += A[(r + 12) * ld + n];
+    }
+    for (; r < r1; r += 4) s0 += A[r * ld + n];
+  }
+  sh[rl][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (rl == 0 && n < N) out[n] += sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl];
+  if (rl == 0 && n < N) {
+    float t = sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl];
+    if (gridDim.y == 1) out[n] += t; else atomicAdd(&out[n], t);
+  }
 }
 void colsum_accum(hipStream_t s, const float* A, int64_t ld, int64_t rows, int N, float* out) {
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(256), 0, s, A, ld, rows, N, out);
+  int nb = cdiv(N, 64);
+  int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, 2048 / nb), (rows + 255) / 256);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nb, chunks), dim3(256), 0, s, A, ld, rows, N, out);
 }
 
 // nn.LookupTable forward / accGradParameters (LSTM.lua:55-56)
@@ -504,20 +518,27 @@ void embedding_gather(hipStream_t s, const float* table, const int32_t* tok, int
   int64_t n = (int64_t)L * B * E;
   hipLaunchKernelGGL(emb_gather_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, table, tok, st, sb, out, L, B, E);
 }
-__global__ __launch_bounds__(64) void emb_scatter_kernel(const float* __restrict__ demb, const int32_t* __restrict__ tok, int64_t st,
-                                                         int64_t sb, float* dtable, int L, int B, int E) {
-  const int v = blockIdx.x;                                     // one workgroup per vocabulary row: deterministic
-  for (int e = threadIdx.x; e < E; e += 64) {
+__global__ __launch_bounds__(256) void emb_scatter_kernel(const float* __restrict__ demb, const int32_t* __restrict__ tok, int64_t st,
+                                                          int64_t sb, float* dtable, int L, int B, int E) {
+  __shared__ float sh[4];
+  const int v = blockIdx.x;                                     // one workgroup per vocabulary row: deterministic, no atomics
+  const int rows = L * B;
+  for (int e = 0; e < E; ++e) {
     float s = 0.f;
-    for (int t = L - 1; t >= 0; --t)
-      for (int b = 0; b < B; ++b)
-        if (tok[t * st + b * sb] - 1 == v) s += demb[((int64_t)t * B + b) * E + e];
-    dtable[(int64_t)v * E + e] += s;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+      int t = r / B, b = r - t * B;
+      if (tok[t * st + b * sb] - 1 == v) s += demb[(int64_t)r * E + e];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dtable[(int64_t)v * E + e] += sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
   }
 }
 void embedding_scatter_accum(hipStream_t s, const float* demb, const int32_t* tok, int64_t st, int64_t sb, float* dtable, int L,
                              int B, int E, int V) {
-  hipLaunchKernelGGL(emb_scatter_kernel, dim3(V), dim3(64), 0, s, demb, tok, st, sb, dtable, L, B, E);
+  hipLaunchKernelGGL(emb_scatter_kernel, dim3(V), dim3(256), 0, s, demb, tok, st, sb, dtable, L, B, E);
 }
 
 __global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
