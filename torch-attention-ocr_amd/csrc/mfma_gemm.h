@@ -248,6 +248,118 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(AL a, BL b, EP ep, int K,
 }
 
 // ---------------------------------------------------------------------------
+// LDS-tiled bf16 kernel for the large contractions (convolutions, hoisted projections, weight gradients).
+// 128 x 128 x 32 block tile, 4 waves as 2x2 (64x64 each = 2x2 MFMA 32x32x16 tiles), two LDS buffers:
+//   global (fp32, any loader) -> registers (issued before the MFMAs of the current tile: T14 split)
+//   -> v_cvt_pk_bf16_f32 -> ds_write_b128 into the other buffer after the MFMAs -> one barrier per k-step.
+// LDS image per operand: [128 rows][32 k] bf16 with an 80-byte row pitch: 20 dwords/row makes any 16 rows that
+// are distinct mod 16 hit 16 different 4-bank slots, so the ds_read_b128 fragment reads are conflict-free.
+// Blocks are renumbered so that the tiles of one M row-panel (which share the A operand) run on one XCD's L2.
+// ---------------------------------------------------------------------------
+template <class L> struct KContig { static constexpr bool v = true; };
+template <> struct KContig<LoadMN> { static constexpr bool v = false; };
+template <> struct KContig<LoadConvWT> { static constexpr bool v = false; };
+template <> struct KContig<LoadConvXcol> { static constexpr bool v = false; };
+
+constexpr int LDS_PITCH = 80;             // bytes per 32-k row of bf16 (64) + 16 pad
+
+template <class LD>
+struct Stager {                           // which (row, 8-k chunk) items of a 128x32 tile this thread stages
+  int row[2], chunk[2];
+  typename LD::Ctx ctx[2];
+  __device__ __forceinline__ void init(const LD& l, int base, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (KContig<LD>::v) { row[i] = (tid >> 2) + 64 * i; chunk[i] = tid & 3; }     // 4 lanes cover one row's 128 bytes
+      else { row[i] = tid & 127; chunk[i] = (tid >> 7) + 2 * i; }                   // lanes run along the contiguous dim
+      ctx[i] = l.row(base + row[i]);
+    }
+  }
+};
+
+template <class AL, class BL, class EP>
+__global__ __launch_bounds__(256) void gemm_lds_bf16_kernel(AL a, BL b, EP ep, int K, int kper, int gx, int gy) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][128 * LDS_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware renumbering (bijective form): consecutive renumbered ids share an XCD (ids are dealt round-robin to 8 XCDs)
+  const int nwg = gx * gy, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int m_blk = (bid / gx) * 128, n_blk = (bid % gx) * 128;
+  const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
+  const int nk = (kend - kbeg + 31) >> 5;
+
+  Stager<AL> sa; Stager<BL> sb;
+  sa.init(a, m_blk, tid); sb.init(b, n_blk, tid);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  Frag<8> ra[2], rb[2];
+  auto gload = [&](int kt) {
+    const int k0 = kbeg + (kt << 5);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a.template load<8>(ra[i], sa.ctx[i], k0 + 8 * sa.chunk[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b.template load<8>(rb[i], sb.ctx[i], k0 + 8 * sb.chunk[i]);
+  };
+  auto lwrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      bf16x8 va, vb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { va[j] = (__bf16)ra[i].v[j]; vb[j] = (__bf16)rb[i].v[j]; }
+      *reinterpret_cast<bf16x8*>(&lds[buf][0][sa.row[i] * LDS_PITCH + sa.chunk[i] * 16]) = va;
+      *reinterpret_cast<bf16x8*>(&lds[buf][1][sb.row[i] * LDS_PITCH + sb.chunk[i] * 16]) = vb;
+    }
+  };
+
+  if (nk > 0) { gload(0); lwrite(0); }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);                      // loads in flight under the MFMAs below
+    const unsigned char* la = &lds[buf][0][(wm * 64 + r) * LDS_PITCH + 16 * h];
+    const unsigned char* lb = &lds[buf][1][(wn * 64 + r) * LDS_PITCH + 16 * h];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8*>(la + i * 32 * LDS_PITCH + 32 * s);
+        bf[i] = *reinterpret_cast<const bf16x8*>(lb + i * 32 * LDS_PITCH + 32 * s);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lwrite(buf ^ 1);
+    __syncthreads();
+  }
+  const int m0 = m_blk + wm * 64, n0 = n_blk + wn * 64;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[2][4];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * q + i];
+      ep.template quad<2>(m0 + 32 * mi + 8 * q + 4 * h, n0 + r, 32, v);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // "small" kernel for the recurrent steps (M = batch): one 32 x (32*NT) output tile per
 // block, K split over the block's 4 waves and reduced through LDS.  With GATES the NT=4
 // tiles are the four gate blocks of the same 32 hidden units: B row = g*gate_stride + j.

@@ -8,14 +8,14 @@ namespace aocr {
 template <class AL, class BL, class EP>
 static void launch_big(hipStream_t s, bool bf16, const AL& a, const BL& b, const EP& ep, int M, int N, int K, int ksplit) {
   if (M <= 0 || N <= 0) return;
-  const int chunk = bf16 ? 16 : 8;
+  const int chunk = bf16 ? 32 : 8;
   if (ksplit < 1) ksplit = 1;
   int kper = cdiv(cdiv(K, ksplit), chunk) * chunk;
   if (kper < chunk) kper = chunk;
   ksplit = cdiv(K, kper); if (ksplit < 1) ksplit = 1;
-  dim3 grid(cdiv(N, 128), cdiv(M, 128), ksplit);
-  if (bf16) hipLaunchKernelGGL((gemm_big_kernel<true, 2, 2, AL, BL, EP>), grid, dim3(256), 0, s, a, b, ep, K, kper);
-  else      hipLaunchKernelGGL((gemm_big_kernel<false, 2, 2, AL, BL, EP>), grid, dim3(256), 0, s, a, b, ep, K, kper);
+  const int gx = cdiv(N, 128), gy = cdiv(M, 128);
+  if (bf16) hipLaunchKernelGGL((gemm_lds_bf16_kernel<AL, BL, EP>), dim3(gx * gy, 1, ksplit), dim3(256), 0, s, a, b, ep, K, kper, gx, gy);
+  else      hipLaunchKernelGGL((gemm_big_kernel<false, 2, 2, AL, BL, EP>), dim3(gx, gy, ksplit), dim3(256), 0, s, a, b, ep, K, kper);
 }
 
 void launch_big_kk(hipStream_t s, bool bf16, const LoadK& a, const LoadK& b, const EpStore& ep, int M, int N, int K, int ksplit) {
