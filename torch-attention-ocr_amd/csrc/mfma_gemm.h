@@ -65,12 +65,30 @@ struct LoadK {
 
 // MN-contiguous: element(r,k) = p[k*ld + r]
 struct LoadMN {
-  const float* p; int64_t ld; int rows; int K;
+  const float* p; int64_t ld; int rows; int K; int vec;
   struct Ctx { const float* b; bool ok; };
   __device__ __forceinline__ Ctx row(int r) const { Ctx c; c.ok = r < rows; c.b = p + (c.ok ? r : 0); return c; }
   template <int NV> __device__ __forceinline__ void load(Frag<NV>& f, const Ctx& c, int k) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j) f.v[j] = (c.ok && k + j < K) ? c.b[(int64_t)(k + j) * ld] : 0.f;
+  }
+  // micro-block interface of the LDS-tiled kernel: v[kk][j] = element(r + j, k + kk), 4 rows x 4 k, r % 4 == 0
+  struct Ctx4 { const float* b; int nv; };
+  __device__ __forceinline__ Ctx4 row4(int r) const {
+    Ctx4 c; c.nv = min(max(rows - r, 0), 4); c.b = p + (c.nv > 0 ? r : 0); return c;
+  }
+  __device__ __forceinline__ void load4x4(float (&v)[4][4], const Ctx4& c, int k) const {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const float* s = c.b + (int64_t)(k + kk) * ld;
+      if (k + kk < K && c.nv == 4 && vec) {
+        float4 t = *reinterpret_cast<const float4*>(s);
+        v[kk][0] = t.x; v[kk][1] = t.y; v[kk][2] = t.z; v[kk][3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[kk][j] = (k + kk < K && j < c.nv) ? s[j] : 0.f;
+      }
+    }
   }
 };
 
@@ -129,6 +147,18 @@ struct LoadConvWT {
     for (int j = 0; j < NV; ++j)
       f.v[j] = (c.ok && k + j < K) ? w[((int64_t)(co + j) * KK + tap) * Cin + c.ci] : 0.f;
   }
+  struct Ctx4 { int ci; bool ok; };
+  __device__ __forceinline__ Ctx4 row4(int r) const { Ctx4 c; c.ok = r + 3 < Cin; c.ci = c.ok ? r : 0; return c; }   // Cin % 4 == 0
+  __device__ __forceinline__ void load4x4(float (&v)[4][4], const Ctx4& c, int k) const {
+    int tap = k / Cout; int co = k - tap * Cout;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (c.ok && k + kk < K) {
+        float4 t = *reinterpret_cast<const float4*>(w + ((int64_t)(co + kk) * KK + tap) * Cin + c.ci);
+        v[kk][0] = t.x; v[kk][1] = t.y; v[kk][2] = t.z; v[kk][3] = t.w;
+      } else { v[kk][0] = v[kk][1] = v[kk][2] = v[kk][3] = 0.f; }
+    }
+  }
 };
 
 // B operand of the filter-gradient: element(n=(tap,ci), k=pixel p of the output grid) =
@@ -147,6 +177,24 @@ struct LoadConvXcol {
       int sy = py + c.kh - pad, sx = px + c.kw - pad;
       bool ok = c.ok && (k + j) < K && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
       f.v[j] = ok ? x[(((int64_t)b * H + sy) * W + sx) * Cin + c.ci] : 0.f;
+      if (++px == Wo) { px = 0; if (++py == Ho) { py = 0; ++b; } }
+    }
+  }
+  struct Ctx4 { int kh, kw, ci; bool ok; };
+  __device__ __forceinline__ Ctx4 row4(int n) const {                     // 4 consecutive ci of one tap (Cin % 4 == 0)
+    Ctx4 c; c.ok = n + 3 < N; int nn = c.ok ? n : 0; int tap = nn / Cin; c.ci = nn - tap * Cin;
+    c.kh = tap / KW; c.kw = tap - c.kh * KW; return c;
+  }
+  __device__ __forceinline__ void load4x4(float (&v)[4][4], const Ctx4& c, int k) const {
+    int px = k % Wo; int t = k / Wo; int py = t % Ho; int b = t / Ho;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      int sy = py + c.kh - pad, sx = px + c.kw - pad;
+      bool ok = c.ok && (k + kk) < K && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+      if (ok) {
+        float4 tt = *reinterpret_cast<const float4*>(x + (((int64_t)b * H + sy) * W + sx) * Cin + c.ci);
+        v[kk][0] = tt.x; v[kk][1] = tt.y; v[kk][2] = tt.z; v[kk][3] = tt.w;
+      } else { v[kk][0] = v[kk][1] = v[kk][2] = v[kk][3] = 0.f; }
       if (++px == Wo) { px = 0; if (++py == Ho) { py = 0; ++b; } }
     }
   }
@@ -263,16 +311,53 @@ template <> struct KContig<LoadConvXcol> { static constexpr bool v = false; };
 
 constexpr int LDS_PITCH = 80;             // bytes per 32-k row of bf16 (64) + 16 pad
 
-template <class LD>
-struct Stager {                           // which (row, 8-k chunk) items of a 128x32 tile this thread stages
-  int row[2], chunk[2];
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// Stages this thread's share of one 128 x 32 operand tile: global fp32 -> registers (load) -> bf16 in LDS (store).
+template <class LD, bool KC = KContig<LD>::v> struct Stager;
+
+// K-contiguous operand: two (row, 8-k) items per thread, 4 lanes cover one row's 128 bytes.
+template <class LD> struct Stager<LD, true> {
+  int row[2], chunk;
   typename LD::Ctx ctx[2];
+  Frag<8> reg[2];
   __device__ __forceinline__ void init(const LD& l, int base, int tid) {
+    chunk = tid & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { row[i] = (tid >> 2) + 64 * i; ctx[i] = l.row(base + row[i]); }
+  }
+  __device__ __forceinline__ void load(const LD& l, int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) l.template load<8>(reg[i], ctx[i], k0 + 8 * chunk);
+  }
+  __device__ __forceinline__ void store(unsigned char* tile) const {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (KContig<LD>::v) { row[i] = (tid >> 2) + 64 * i; chunk[i] = tid & 3; }     // 4 lanes cover one row's 128 bytes
-      else { row[i] = tid & 127; chunk[i] = (tid >> 7) + 2 * i; }                   // lanes run along the contiguous dim
-      ctx[i] = l.row(base + row[i]);
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (__bf16)reg[i].v[j];
+      *reinterpret_cast<bf16x8*>(tile + row[i] * LDS_PITCH + chunk * 16) = v;
+    }
+  }
+};
+
+// M/N-contiguous operand: one 4-row x 4-k micro-block per thread, loaded as 4 dwordx4 along the contiguous
+// dimension (32 lanes = 512 contiguous bytes) and transposed in registers into four 8-byte LDS writes.
+template <class LD> struct Stager<LD, false> {
+  int row4, k4;
+  typename LD::Ctx4 ctx;
+  float reg[4][4];
+  __device__ __forceinline__ void init(const LD& l, int base, int tid) {
+    row4 = (tid & 31) * 4; k4 = (tid >> 5) * 4; ctx = l.row4(base + row4);
+  }
+  __device__ __forceinline__ void load(const LD& l, int k0) { l.load4x4(reg, ctx, k0 + k4); }
+  __device__ __forceinline__ void store(unsigned char* tile) const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x4 v;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) v[kk] = (__bf16)reg[kk][j];
+      *reinterpret_cast<bf16x4*>(tile + (row4 + j) * LDS_PITCH + k4 * 2) = v;
     }
   }
 };
@@ -302,24 +387,8 @@ __global__ __launch_bounds__(256) void gemm_lds_bf16_kernel(AL a, BL b, EP ep, i
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  Frag<8> ra[2], rb[2];
-  auto gload = [&](int kt) {
-    const int k0 = kbeg + (kt << 5);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) a.template load<8>(ra[i], sa.ctx[i], k0 + 8 * sa.chunk[i]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) b.template load<8>(rb[i], sb.ctx[i], k0 + 8 * sb.chunk[i]);
-  };
-  auto lwrite = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      bf16x8 va, vb;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { va[j] = (__bf16)ra[i].v[j]; vb[j] = (__bf16)rb[i].v[j]; }
-      *reinterpret_cast<bf16x8*>(&lds[buf][0][sa.row[i] * LDS_PITCH + sa.chunk[i] * 16]) = va;
-      *reinterpret_cast<bf16x8*>(&lds[buf][1][sb.row[i] * LDS_PITCH + sb.chunk[i] * 16]) = vb;
-    }
-  };
+  auto gload = [&](int kt) { const int k0 = kbeg + (kt << 5); sa.load(a, k0); sb.load(b, k0); };
+  auto lwrite = [&](int buf) { sa.store(&lds[buf][0][0]); sb.store(&lds[buf][1][0]); };
 
   if (nk > 0) { gload(0); lwrite(0); }
   __syncthreads();

@@ -21,7 +21,9 @@ inline LoadK make_loadk2(const float* p0, int64_t ld0, int K0, const float* p1, 
   return l;
 }
 inline LoadMN make_loadmn(const float* p, int64_t ld, int rows, int K) {
-  LoadMN l; l.p = p; l.ld = ld; l.rows = rows; l.K = K; return l;
+  LoadMN l; l.p = p; l.ld = ld; l.rows = rows; l.K = K;
+  l.vec = (((uintptr_t)p & 15) == 0) && (ld % 4 == 0);
+  return l;
 }
 inline EpStore make_store(float* C, int64_t ldc, int M, int N, const float* bias = nullptr, const float* bias2 = nullptr,
                           int flags = 0) {
