@@ -304,31 +304,123 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(AL a, BL b, EP ep, int K,
 // are distinct mod 16 hit 16 different 4-bank slots, so the ds_read_b128 fragment reads are conflict-free.
 // Blocks are renumbered so that the tiles of one M row-panel (which share the A operand) run on one XCD's L2.
 // ---------------------------------------------------------------------------
+// ---- operands that already live in HBM as bf16 ("shadow" copies written by the producing kernels): half the
+// L2->L1 bytes of the fp32 loaders and no conversion work.  Only the LDS-tiled kernel reads them.
+typedef __bf16 bf16_t;
+
+// Each loader keeps a cursor that the stager advances by 32 k per tile, so the steady state has no integer division.
+
+// K-contiguous bf16: element(r,k) = p[r*ld + k]; 16-byte aligned rows (ld % 8 == 0).
+struct LoadKh {
+  const bf16_t* p; int64_t ld; int rows; int K;
+  struct Ctx { const bf16_t* b; bool ok; };
+  struct Cur { int k; };
+  __device__ __forceinline__ Ctx row(int r) const { Ctx c; c.ok = r < rows; c.b = p + (int64_t)(c.ok ? r : 0) * ld; return c; }
+  __device__ __forceinline__ Cur seek(int k) const { Cur c; c.k = k; return c; }
+  __device__ __forceinline__ void advance(Cur& c) const { c.k += 32; }
+  __device__ __forceinline__ uint4 load8(const Ctx& c, const Cur& u, int chunk) const {
+    int k = u.k + 8 * chunk;
+    if (c.ok && k + 8 <= K) return *reinterpret_cast<const uint4*>(c.b + k);
+    return make_uint4(0, 0, 0, 0);
+  }
+};
+// implicit im2col over a bf16 channels-last tensor (same geometry as LoadConvK); cursor = (kh, kw, first channel) of the tile
+struct LoadConvKh {
+  const bf16_t* src; LoadConvK g;          // g.src unused
+  typedef LoadConvK::Ctx Ctx;
+  struct Cur { int kh, kw, ch, k; };
+  __device__ __forceinline__ Ctx row(int m) const { return g.row(m); }
+  __device__ __forceinline__ Cur seek(int k) const {
+    Cur c; int tap = k / g.C; c.ch = k - tap * g.C; c.kh = tap / g.KW; c.kw = tap - c.kh * g.KW; c.k = k; return c;
+  }
+  __device__ __forceinline__ void advance(Cur& c) const {          // C % 32 == 0: a 32-wide tile never straddles a tap
+    c.k += 32; c.ch += 32;
+    if (c.ch >= g.C) { c.ch -= g.C; if (++c.kw == g.KW) { c.kw = 0; ++c.kh; } }
+  }
+  __device__ __forceinline__ uint4 load8(const Ctx& c, const Cur& u, int chunk) const {
+    int sy = c.y + g.sgn * u.kh + g.off, sx = c.x + g.sgn * u.kw + g.off;
+    bool ok = c.ok && u.k < g.K && (unsigned)sy < (unsigned)g.H && (unsigned)sx < (unsigned)g.W;
+    if (ok) return *reinterpret_cast<const uint4*>(src + (((int64_t)c.b * g.H + sy) * g.W + sx) * g.C + u.ch + 8 * chunk);
+    return make_uint4(0, 0, 0, 0);
+  }
+};
+// M/N-contiguous bf16: element(r,k) = p[k*ld + r]; micro-block = 8 rows x 4 k (4 dwordx4 along the rows)
+struct LoadMNh {
+  const bf16_t* p; int64_t ld; int rows; int K;
+  struct Ctx8 { const bf16_t* b; bool ok; };
+  struct Cur { int k; };
+  __device__ __forceinline__ Ctx8 row8(int r) const { Ctx8 c; c.ok = r + 7 < rows; c.b = p + (c.ok ? r : 0); return c; }
+  __device__ __forceinline__ Cur seek(const Ctx8&, int k) const { Cur c; c.k = k; return c; }
+  __device__ __forceinline__ void advance(Cur& c) const { c.k += 32; }
+  __device__ __forceinline__ void load8x4(uint4 (&v)[4], const Ctx8& c, const Cur& u) const {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      v[kk] = (c.ok && u.k + kk < K) ? *reinterpret_cast<const uint4*>(c.b + (int64_t)(u.k + kk) * ld) : make_uint4(0, 0, 0, 0);
+  }
+};
+// filter-gradient B operand over a bf16 input map (same geometry as LoadConvXcol); 8 consecutive ci of one tap;
+// cursor = output pixel (b, py, px) of the micro-block's first k
+struct LoadConvXcolh {
+  const bf16_t* x; LoadConvXcol g;
+  struct Ctx8 { int dy, dx, ci; bool ok; };     // dy = kh - pad, dx = kw - pad
+  struct Cur { int px, py, b, k; };
+  __device__ __forceinline__ Ctx8 row8(int n) const {
+    Ctx8 c; c.ok = n + 7 < g.N; int nn = c.ok ? n : 0; int tap = nn / g.Cin; c.ci = nn - tap * g.Cin;
+    int kh = tap / g.KW; c.dy = kh - g.pad; c.dx = tap - kh * g.KW - g.pad; return c;
+  }
+  __device__ __forceinline__ Cur seek(const Ctx8&, int k) const {
+    Cur c; c.k = k; c.px = k % g.Wo; int t = k / g.Wo; c.py = t % g.Ho; c.b = t / g.Ho; return c;
+  }
+  __device__ __forceinline__ void advance(Cur& c) const {
+    c.k += 32; c.px += 32;
+    while (c.px >= g.Wo) { c.px -= g.Wo; if (++c.py == g.Ho) { c.py = 0; ++c.b; } }
+  }
+  __device__ __forceinline__ void load8x4(uint4 (&v)[4], const Ctx8& c, const Cur& u) const {
+    int px = u.px, py = u.py, b = u.b;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      int sy = py + c.dy, sx = px + c.dx;
+      bool ok = c.ok && (u.k + kk) < g.K && (unsigned)sy < (unsigned)g.H && (unsigned)sx < (unsigned)g.W;
+      v[kk] = ok ? *reinterpret_cast<const uint4*>(x + (((int64_t)b * g.H + sy) * g.W + sx) * g.Cin + c.ci) : make_uint4(0, 0, 0, 0);
+      if (++px == g.Wo) { px = 0; if (++py == g.Ho) { py = 0; ++b; } }
+    }
+  }
+};
+
 template <class L> struct KContig { static constexpr bool v = true; };
 template <> struct KContig<LoadMN> { static constexpr bool v = false; };
 template <> struct KContig<LoadConvWT> { static constexpr bool v = false; };
 template <> struct KContig<LoadConvXcol> { static constexpr bool v = false; };
+template <> struct KContig<LoadMNh> { static constexpr bool v = false; };
+template <> struct KContig<LoadConvXcolh> { static constexpr bool v = false; };
+template <class L> struct SrcBf16 { static constexpr bool v = false; };
+template <> struct SrcBf16<LoadKh> { static constexpr bool v = true; };
+template <> struct SrcBf16<LoadConvKh> { static constexpr bool v = true; };
+template <> struct SrcBf16<LoadMNh> { static constexpr bool v = true; };
+template <> struct SrcBf16<LoadConvXcolh> { static constexpr bool v = true; };
 
 constexpr int LDS_PITCH = 80;             // bytes per 32-k row of bf16 (64) + 16 pad
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // Stages this thread's share of one 128 x 32 operand tile: global fp32 -> registers (load) -> bf16 in LDS (store).
-template <class LD, bool KC = KContig<LD>::v> struct Stager;
+template <class LD, bool KC = KContig<LD>::v, bool H16 = SrcBf16<LD>::v> struct Stager;
 
 // K-contiguous operand: two (row, 8-k) items per thread, 4 lanes cover one row's 128 bytes.
-template <class LD> struct Stager<LD, true> {
+template <class LD> struct Stager<LD, true, false> {
   int row[2], chunk;
   typename LD::Ctx ctx[2];
   Frag<8> reg[2];
-  __device__ __forceinline__ void init(const LD& l, int base, int tid) {
-    chunk = tid & 3;
+  int k0;
+  __device__ __forceinline__ void init(const LD& l, int base, int tid, int, int kbeg) {
+    chunk = tid & 3; k0 = kbeg;
 #pragma unroll
     for (int i = 0; i < 2; ++i) { row[i] = (tid >> 2) + 64 * i; ctx[i] = l.row(base + row[i]); }
   }
-  __device__ __forceinline__ void load(const LD& l, int k0) {
+  __device__ __forceinline__ void load(const LD& l) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) l.template load<8>(reg[i], ctx[i], k0 + 8 * chunk);
+    k0 += 32;
   }
   __device__ __forceinline__ void store(unsigned char* tile) const {
 #pragma unroll
@@ -343,14 +435,18 @@ template <class LD> struct Stager<LD, true> {
 
 // M/N-contiguous operand: one 4-row x 4-k micro-block per thread, loaded as 4 dwordx4 along the contiguous
 // dimension (32 lanes = 512 contiguous bytes) and transposed in registers into four 8-byte LDS writes.
-template <class LD> struct Stager<LD, false> {
+template <class LD> struct Stager<LD, false, false> {
   int row4, k4;
   typename LD::Ctx4 ctx;
-  float reg[4][4];
-  __device__ __forceinline__ void init(const LD& l, int base, int tid) {
-    row4 = (tid & 31) * 4; k4 = (tid >> 5) * 4; ctx = l.row4(base + row4);
+  float reg[4][4]; int k0;
+  __device__ __forceinline__ void init(const LD& l, int base, int tid, int, int kbeg) {
+    k0 = kbeg;
+    // lanes run over the 8 k-groups first: the 8-byte transposed LDS writes of 16 consecutive lanes then hit 16
+    // different bank pairs (rows 4 apart are 16 banks apart at the 80-byte pitch); each global row still gets
+    // whole 128-byte lines from the 8 lanes that share a k.
+    k4 = (tid & 7) * 4; row4 = (tid >> 3) * 4; ctx = l.row4(base + row4);
   }
-  __device__ __forceinline__ void load(const LD& l, int k0) { l.load4x4(reg, ctx, k0 + k4); }
+  __device__ __forceinline__ void load(const LD& l) { l.load4x4(reg, ctx, k0 + k4); k0 += 32; }
   __device__ __forceinline__ void store(unsigned char* tile) const {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -358,6 +454,55 @@ template <class LD> struct Stager<LD, false> {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) v[kk] = (__bf16)reg[kk][j];
       *reinterpret_cast<bf16x4*>(tile + (row4 + j) * LDS_PITCH + k4 * 2) = v;
+    }
+  }
+};
+
+// bf16 source, K-contiguous: two 16-byte items per thread, copied straight into LDS.
+template <class LD> struct Stager<LD, true, true> {
+  int row[2], chunk;
+  typename LD::Ctx ctx[2];
+  uint4 reg[2]; typename LD::Cur cur;
+  __device__ __forceinline__ void init(const LD& l, int base, int tid, int, int kbeg) {
+    chunk = tid & 3; cur = l.seek(kbeg);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { row[i] = (tid >> 2) + 64 * i; ctx[i] = l.row(base + row[i]); }
+  }
+  __device__ __forceinline__ void load(const LD& l) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) reg[i] = l.load8(ctx[i], cur, chunk);
+    l.advance(cur);
+  }
+  __device__ __forceinline__ void store(unsigned char* tile) const {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(tile + row[i] * LDS_PITCH + chunk * 16) = reg[i];
+  }
+};
+
+// bf16 source, M/N-contiguous: 128 micro-blocks of 8 rows x 4 k per tile, staged by one half of the workgroup
+// (half 0: threads 0-127, half 1: threads 128-255) -- 4 dwordx4 loads, 16-bit transpose in registers, 8 x 8-byte writes.
+template <class LD> struct Stager<LD, false, true> {
+  int row8, k4; bool active;
+  typename LD::Ctx8 ctx;
+  uint4 reg[4]; typename LD::Cur cur;
+  __device__ __forceinline__ void init(const LD& l, int base, int tid, int half, int kbeg) {
+    active = (tid >> 7) == half; int t = tid & 127;
+    k4 = (t & 7) * 4; row8 = (t >> 3) * 8; ctx = l.row8(base + row8); cur = l.seek(ctx, kbeg + k4);      // k-groups fastest: 2-way instead of 16-way write conflicts
+  }
+  __device__ __forceinline__ void load(const LD& l) { if (active) { l.load8x4(reg, ctx, cur); l.advance(cur); } }
+  __device__ __forceinline__ void store(unsigned char* tile) const {
+    if (!active) return;
+    const unsigned* w0 = reinterpret_cast<const unsigned*>(&reg[0]);
+    const unsigned* w1 = reinterpret_cast<const unsigned*>(&reg[1]);
+    const unsigned* w2 = reinterpret_cast<const unsigned*>(&reg[2]);
+    const unsigned* w3 = reinterpret_cast<const unsigned*>(&reg[3]);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {                       // dword d of each register holds rows 2d (low) and 2d+1 (high)
+      uint2 ev, od;
+      ev.x = (w0[d] & 0xffffu) | (w1[d] << 16); ev.y = (w2[d] & 0xffffu) | (w3[d] << 16);
+      od.x = (w0[d] >> 16) | (w1[d] & 0xffff0000u); od.y = (w2[d] >> 16) | (w3[d] & 0xffff0000u);
+      *reinterpret_cast<uint2*>(tile + (row8 + 2 * d) * LDS_PITCH + k4 * 2) = ev;
+      *reinterpret_cast<uint2*>(tile + (row8 + 2 * d + 1) * LDS_PITCH + k4 * 2) = od;
     }
   }
 };
@@ -377,7 +522,7 @@ __global__ __launch_bounds__(256) void gemm_lds_bf16_kernel(AL a, BL b, EP ep, i
   const int nk = (kend - kbeg + 31) >> 5;
 
   Stager<AL> sa; Stager<BL> sb;
-  sa.init(a, m_blk, tid); sb.init(b, n_blk, tid);
+  sa.init(a, m_blk, tid, 0, kbeg); sb.init(b, n_blk, tid, 1, kbeg);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -387,7 +532,7 @@ __global__ __launch_bounds__(256) void gemm_lds_bf16_kernel(AL a, BL b, EP ep, i
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  auto gload = [&](int kt) { const int k0 = kbeg + (kt << 5); sa.load(a, k0); sb.load(b, k0); };
+  auto gload = [&](int) { sa.load(a); sb.load(b); };      // tiles are visited in order: every stager keeps its own cursor
   auto lwrite = [&](int buf) { sa.store(&lds[buf][0][0]); sb.store(&lds[buf][1][0]); };
 
   if (nk > 0) { gload(0); lwrite(0); }

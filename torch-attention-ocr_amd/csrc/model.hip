@@ -84,6 +84,16 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
   m->Y7 = a.get<float>(B * T * 512); m->X = a.get<float>(T * B * 512); m->dX = a.get<float>(T * B * 512);
   size_t gmax = B * d.H1 * d.W1 * 128;                                      // d(conv2 pre-pool output): the largest gradient map
   m->G0 = a.get<float>(gmax); m->G1 = a.get<float>(gmax);
+  m->A1b = m->A2b = m->A3b = m->A4b = m->A5b = m->A6b = m->G0b = nullptr;
+  for (int i = 0; i < 8; ++i) { m->wb[i] = nullptr; m->wtb[i] = nullptr; }
+  if (m->bf16) {
+    m->A1b = a.get<bf16_t>(B * d.H1 * d.W1 * 64); m->A2b = a.get<bf16_t>(B * d.H2 * d.W2 * 128);
+    m->A3b = a.get<bf16_t>(B * d.H2 * d.W2 * 256); m->A4b = a.get<bf16_t>(B * d.H4 * d.W2 * 256);
+    m->A5b = a.get<bf16_t>(B * d.H4 * d.W2 * 512); m->A6b = a.get<bf16_t>(B * d.H6 * d.W2 * 512);
+    m->G0b = a.get<bf16_t>(gmax);
+    static const int wsz[8] = {0, 0, 128 * 9 * 64, 256 * 9 * 128, 256 * 9 * 256, 512 * 9 * 256, 512 * 9 * 512, 512 * 4 * 512};
+    for (int i = 2; i <= 7; ++i) { m->wb[i] = a.get<bf16_t>(wsz[i]); m->wtb[i] = a.get<bf16_t>(wsz[i]); }
+  }
   m->bn_scratch = a.get<char>(bn_scratch_bytes(512)); m->bn_save = a.get<float>(3 * 2 * 512);
   for (int dir = 0; dir < 2; ++dir) {
     for (int l = 0; l < m->Le; ++l) {
@@ -128,46 +138,49 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
 // ------------------------------------------------------------------------------------------------
 void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training, int update_running) {
   hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
-  conv1_forward(s, images, m->conv[1].w, m->conv[1].b, m->A1, B, d.H, d.W);
-  conv_forward(s, bf, m->A1, m->conv[2].w, m->conv[2].b, m->A2, m->idx2, B, d.H1, d.W1, 64, 128, 3, 1, 1, 1);
-  conv_forward(s, bf, m->A2, m->conv[3].w, m->conv[3].b, m->Y3, nullptr, B, d.H2, d.W2, 128, 256, 3, 1, 0, 0);
+  if (bf)                                                       // refresh the bf16 weight shadows (weights change every step)
+    for (int i = 2; i <= 7; ++i)
+      conv_weight_shadows(s, m->conv[i].w, m->wb[i], m->wtb[i], m->conv[i].cout, m->conv[i].ks * m->conv[i].ks, m->conv[i].cin);
+  conv1_forward(s, images, m->conv[1].w, m->conv[1].b, m->A1, B, d.H, d.W, m->A1b);
+  conv_forward(s, bf, m->A1, m->conv[2].w, m->conv[2].b, m->A2, m->idx2, B, d.H1, d.W1, 64, 128, 3, 1, 1, 1, m->A1b, m->wb[2], m->A2b);
+  conv_forward(s, bf, m->A2, m->conv[3].w, m->conv[3].b, m->Y3, nullptr, B, d.H2, d.W2, 128, 256, 3, 1, 0, 0, m->A2b, m->wb[3], nullptr);
   bn_relu_forward(s, m->Y3, m->A3, m->bn[3].w, m->bn[3].b, m->bn[3].rm, m->bn[3].rv, m->bn[3].save, m->bn_scratch,
-                  (int64_t)B * d.H2 * d.W2, 256, training, update_running, 0);
-  conv_forward(s, bf, m->A3, m->conv[4].w, m->conv[4].b, m->A4, m->idx4, B, d.H2, d.W2, 256, 256, 3, 1, 1, 2);
-  conv_forward(s, bf, m->A4, m->conv[5].w, m->conv[5].b, m->Y5, nullptr, B, d.H4, d.W2, 256, 512, 3, 1, 0, 0);
+                  (int64_t)B * d.H2 * d.W2, 256, training, update_running, 0, m->A3b);
+  conv_forward(s, bf, m->A3, m->conv[4].w, m->conv[4].b, m->A4, m->idx4, B, d.H2, d.W2, 256, 256, 3, 1, 1, 2, m->A3b, m->wb[4], m->A4b);
+  conv_forward(s, bf, m->A4, m->conv[5].w, m->conv[5].b, m->Y5, nullptr, B, d.H4, d.W2, 256, 512, 3, 1, 0, 0, m->A4b, m->wb[5], nullptr);
   bn_relu_forward(s, m->Y5, m->A5, m->bn[5].w, m->bn[5].b, m->bn[5].rm, m->bn[5].rv, m->bn[5].save, m->bn_scratch,
-                  (int64_t)B * d.H4 * d.W2, 512, training, update_running, 0);
-  conv_forward(s, bf, m->A5, m->conv[6].w, m->conv[6].b, m->A6, m->idx6, B, d.H4, d.W2, 512, 512, 3, 1, 1, 2);
-  conv_forward(s, bf, m->A6, m->conv[7].w, m->conv[7].b, m->Y7, nullptr, B, d.H6, d.W2, 512, 512, 2, 0, 0, 0);
+                  (int64_t)B * d.H4 * d.W2, 512, training, update_running, 0, m->A5b);
+  conv_forward(s, bf, m->A5, m->conv[6].w, m->conv[6].b, m->A6, m->idx6, B, d.H4, d.W2, 512, 512, 3, 1, 1, 2, m->A5b, m->wb[6], m->A6b);
+  conv_forward(s, bf, m->A6, m->conv[7].w, m->conv[7].b, m->Y7, nullptr, B, d.H6, d.W2, 512, 512, 2, 0, 0, 0, m->A6b, m->wb[7], nullptr);
   bn_relu_forward(s, m->Y7, m->X, m->bn[7].w, m->bn[7].b, m->bn[7].rm, m->bn[7].rv, m->bn[7].save, m->bn_scratch,
-                  (int64_t)B * d.T, 512, training, update_running, B);
+                  (int64_t)B * d.T, 512, training, update_running, B, nullptr);
 }
 
 static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
-  float *G0 = m->G0, *G1 = m->G1;
+  float *G0 = m->G0, *G1 = m->G1; bf16_t* G0b = m->G0b;
   // bn7 + relu (dX is time-major, Y7 batch-major)
   bn_relu_backward(s, m->Y7, m->X, m->dX, m->bn[7].w, m->bn[7].save, G0, m->bn[7].dw, m->bn[7].db, m->bn_scratch,
-                   (int64_t)B * d.T, 512, B);
-  conv_backward_filter(s, bf, m->A6, G0, m->conv[7].dw, m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0);
-  conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0);
-  unpool_relu_backward(s, G1, m->A6, m->idx6, G0, B, d.H4, d.W2, 512, 2);
-  conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1);
-  conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1);
+                   (int64_t)B * d.T, 512, B, G0b);
+  conv_backward_filter(s, bf, m->A6, G0, m->conv[7].dw, m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0, m->A6b, G0b);
+  conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0, G0b, m->wtb[7]);
+  unpool_relu_backward(s, G1, m->A6, m->idx6, G0, B, d.H4, d.W2, 512, 2, G0b);
+  conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, G0b);
+  conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, G0b, m->wtb[6]);
   bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
-                   (int64_t)B * d.H4 * d.W2, 512, 0);
-  conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1);
-  conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1);
-  unpool_relu_backward(s, G1, m->A4, m->idx4, G0, B, d.H2, d.W2, 256, 2);
-  conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1);
-  conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1);
+                   (int64_t)B * d.H4 * d.W2, 512, 0, G0b);
+  conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, G0b);
+  conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1, G0b, m->wtb[5]);
+  unpool_relu_backward(s, G1, m->A4, m->idx4, G0, B, d.H2, d.W2, 256, 2, G0b);
+  conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, G0b);
+  conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, G0b, m->wtb[4]);
   bn_relu_backward(s, m->Y3, m->A3, G1, m->bn[3].w, m->bn[3].save, G0, m->bn[3].dw, m->bn[3].db, m->bn_scratch,
-                   (int64_t)B * d.H2 * d.W2, 256, 0);
-  conv_backward_filter(s, bf, m->A2, G0, m->conv[3].dw, m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1);
-  conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1);
-  unpool_relu_backward(s, G1, m->A2, m->idx2, G0, B, d.H1, d.W1, 128, 1);
-  conv_backward_filter(s, bf, m->A1, G0, m->conv[2].dw, m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1);
-  conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1);
+                   (int64_t)B * d.H2 * d.W2, 256, 0, G0b);
+  conv_backward_filter(s, bf, m->A2, G0, m->conv[3].dw, m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, G0b);
+  conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1, G0b, m->wtb[3]);
+  unpool_relu_backward(s, G1, m->A2, m->idx2, G0, B, d.H1, d.W1, 128, 1, G0b);
+  conv_backward_filter(s, bf, m->A1, G0, m->conv[2].dw, m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1, m->A1b, G0b);
+  conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1, G0b, m->wtb[2]);
   conv1_backward(s, images, m->conv[1].w, m->conv[1].b, G1, m->conv[1].dw, m->conv[1].db, B, d.H, d.W);
 }
 

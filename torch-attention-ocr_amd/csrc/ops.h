@@ -55,24 +55,30 @@ int gemm(hipStream_t s, bool bf16, const float* A, int64_t lda, bool a_kmajor, c
           float* C, int64_t ldc, int M, int N, int K, const float* bias, const float* bias2, int flags);
 
 // ---- convolution layers (ops_gemm.hip)
+// xb/wb/dyb/wtb: optional bf16 shadows of the operands (both of a contraction's operands must be given to take the
+// bf16-source path); yb: optional bf16 shadow of the output to write.
 void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, const float* bias, float* y, uint8_t* idx,
-                  int B, int H, int W, int Cin, int Cout, int ks, int pad, int relu, int pool);
+                  int B, int H, int W, int Cin, int Cout, int ks, int pad, int relu, int pool,
+                  const bf16_t* xb = nullptr, const bf16_t* wb = nullptr, bf16_t* yb = nullptr);
 void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* w, float* dx, int B, int H, int W, int Cin,
-                        int Cout, int ks, int pad);
+                        int Cout, int ks, int pad, const bf16_t* dyb = nullptr, const bf16_t* wtb = nullptr);
 void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float* dy, float* dw, float* dbias, int B, int H,
-                          int W, int Cin, int Cout, int ks, int pad);
+                          int W, int Cin, int Cout, int ks, int pad, const bf16_t* xb = nullptr, const bf16_t* dyb = nullptr);
 
 // ---- everything that is not a contraction (ops_misc.hip)
-void conv1_forward(hipStream_t s, const float* x, const float* w, const float* bias, float* y, int B, int H, int W);
+void conv1_forward(hipStream_t s, const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
+                   bf16_t* yb = nullptr);
+void conv_weight_shadows(hipStream_t s, const float* w, bf16_t* wb, bf16_t* wtb, int Cout, int KK, int Cin);
 void conv1_backward(hipStream_t s, const float* x, const float* w, const float* bias, const float* dyp, float* dw, float* db,
                     int B, int H, int W);
 void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pooled, const uint8_t* idx, float* dy, int B,
-                          int Ho, int Wo, int C, int pool);
+                          int Ho, int Wo, int C, int pool, bf16_t* dyb = nullptr);
 size_t bn_scratch_bytes(int C);
 void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, const float* b, float* rm, float* rv,
-                     float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows);
+                     float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows,
+                     bf16_t* yb = nullptr);
 void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
-                      float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows);
+                      float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb = nullptr);
 // ctx_div: rows r share context row r / ctx_div (beam search keeps one context per image, model.lua:373)
 void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a, float* c, int64_t ldc, int B, int T, int Hd,
                        int ctx_div = 1);

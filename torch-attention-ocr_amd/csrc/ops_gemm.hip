@@ -5,17 +5,26 @@
 
 namespace aocr {
 
+static void split_k(int K, int chunk, int& ksplit, int& kper) {
+  if (ksplit < 1) ksplit = 1;
+  kper = cdiv(cdiv(K, ksplit), chunk) * chunk;
+  if (kper < chunk) kper = chunk;
+  ksplit = cdiv(K, kper); if (ksplit < 1) ksplit = 1;
+}
+// LDS-tiled bf16 kernel (any loader pair, fp32 or bf16 sources)
+template <class AL, class BL, class EP>
+static void launch_lds(hipStream_t s, const AL& a, const BL& b, const EP& ep, int M, int N, int K, int ksplit) {
+  if (M <= 0 || N <= 0) return;
+  int kper; split_k(K, 32, ksplit, kper);
+  const int gx = cdiv(N, 128), gy = cdiv(M, 128);
+  hipLaunchKernelGGL((gemm_lds_bf16_kernel<AL, BL, EP>), dim3(gx * gy, 1, ksplit), dim3(256), 0, s, a, b, ep, K, kper, gx, gy);
+}
 template <class AL, class BL, class EP>
 static void launch_big(hipStream_t s, bool bf16, const AL& a, const BL& b, const EP& ep, int M, int N, int K, int ksplit) {
   if (M <= 0 || N <= 0) return;
-  const int chunk = bf16 ? 32 : 8;
-  if (ksplit < 1) ksplit = 1;
-  int kper = cdiv(cdiv(K, ksplit), chunk) * chunk;
-  if (kper < chunk) kper = chunk;
-  ksplit = cdiv(K, kper); if (ksplit < 1) ksplit = 1;
-  const int gx = cdiv(N, 128), gy = cdiv(M, 128);
-  if (bf16) hipLaunchKernelGGL((gemm_lds_bf16_kernel<AL, BL, EP>), dim3(gx * gy, 1, ksplit), dim3(256), 0, s, a, b, ep, K, kper, gx, gy);
-  else      hipLaunchKernelGGL((gemm_big_kernel<false, 2, 2, AL, BL, EP>), dim3(gx, gy, ksplit), dim3(256), 0, s, a, b, ep, K, kper);
+  if (bf16) { launch_lds(s, a, b, ep, M, N, K, ksplit); return; }
+  int kper; split_k(K, 8, ksplit, kper);
+  hipLaunchKernelGGL((gemm_big_kernel<false, 2, 2, AL, BL, EP>), dim3(cdiv(N, 128), cdiv(M, 128), ksplit), dim3(256), 0, s, a, b, ep, K, kper);
 }
 
 void launch_big_kk(hipStream_t s, bool bf16, const LoadK& a, const LoadK& b, const EpStore& ep, int M, int N, int K, int ksplit) {
@@ -83,38 +92,61 @@ int gemm(hipStream_t s, bool bf16, const float* A, int64_t lda, bool a_k, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// convolution layers, channels-last.  Output grid Ho = H + 2*pad - ks + 1 (stride 1).
+// convolution layers, channels-last.  Output grid Ho = H + 2*pad - ks + 1 (stride 1).  When bf16 shadows of both
+// operands are supplied the bf16-source loaders are used (half the L2->L1 bytes, no conversion in the kernel).
 // ---------------------------------------------------------------------------------------------
+static LoadConvK make_convk(const float* src, int B, int Hs, int Ws, int C, int ks, int sgn, int off, int Hr, int Wr, int pool) {
+  LoadConvK a; a.src = src; a.H = Hs; a.W = Ws; a.C = C; a.KW = ks; a.sgn = sgn; a.off = off; a.Hr = Hr; a.Wr = Wr;
+  a.pmode = pool; a.Hp = Hr / 2; a.Wp = Wr / 2;
+  if (pool == 1) a.rows = B * a.Hp * a.Wp * 4; else if (pool == 2) a.rows = B * a.Hp * Wr * 2; else a.rows = B * Hr * Wr;
+  a.K = ks * ks * C;
+  return a;
+}
+
 void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, const float* bias, float* y, uint8_t* idx, int B,
-                  int H, int W, int Cin, int Cout, int ks, int pad, int relu, int pool) {
+                  int H, int W, int Cin, int Cout, int ks, int pad, int relu, int pool, const bf16_t* xb, const bf16_t* wb,
+                  bf16_t* yb) {
   const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
-  LoadConvK a; a.src = x; a.H = H; a.W = W; a.C = Cin; a.KW = ks; a.sgn = 1; a.off = -pad; a.Hr = Ho; a.Wr = Wo;
-  a.pmode = pool; a.Hp = Ho / 2; a.Wp = Wo / 2;
-  if (pool == 1) a.rows = B * a.Hp * a.Wp * 4; else if (pool == 2) a.rows = B * a.Hp * Wo * 2; else a.rows = B * Ho * Wo;
-  a.K = ks * ks * Cin;
-  LoadK b = make_loadk(w, a.K, Cout, a.K);
-  EpConv ep; ep.y = y; ep.idx = idx; ep.bias = bias; ep.Cout = Cout; ep.rows = a.rows; ep.pmode = pool; ep.relu = relu;
-  launch_conv_fwd(s, bf16, a, b, ep, a.rows, Cout, a.K);
+  LoadConvK a = make_convk(x, B, H, W, Cin, ks, 1, -pad, Ho, Wo, pool);
+  EpConv ep; ep.y = y; ep.idx = idx; ep.bias = bias; ep.Cout = Cout; ep.rows = a.rows; ep.pmode = pool; ep.relu = relu; ep.yb = yb;
+  if (bf16 && xb && wb) {
+    LoadConvKh ah; ah.src = xb; ah.g = a;
+    LoadKh bh; bh.p = wb; bh.ld = a.K; bh.rows = Cout; bh.K = a.K;
+    launch_lds(s, ah, bh, ep, a.rows, Cout, a.K, 1);
+  } else {
+    launch_conv_fwd(s, bf16, a, make_loadk(w, a.K, Cout, a.K), ep, a.rows, Cout, a.K);
+  }
 }
 
 void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* w, float* dx, int B, int H, int W, int Cin,
-                        int Cout, int ks, int pad) {
+                        int Cout, int ks, int pad, const bf16_t* dyb, const bf16_t* wtb) {
   const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
-  LoadConvK a; a.src = dy; a.H = Ho; a.W = Wo; a.C = Cout; a.KW = ks; a.sgn = -1; a.off = pad; a.Hr = H; a.Wr = W;
-  a.pmode = 0; a.Hp = 0; a.Wp = 0; a.rows = B * H * W; a.K = ks * ks * Cout;
-  LoadConvWT b; b.w = w; b.Cin = Cin; b.Cout = Cout; b.KK = ks * ks; b.K = a.K;
+  LoadConvK a = make_convk(dy, B, Ho, Wo, Cout, ks, -1, pad, H, W, 0);
   EpStore ep = make_store(dx, Cin, a.rows, Cin);
-  launch_conv_dgrad(s, bf16, a, b, ep, a.rows, Cin, a.K);
+  if (bf16 && dyb && wtb) {
+    LoadConvKh ah; ah.src = dyb; ah.g = a;
+    LoadKh bh; bh.p = wtb; bh.ld = a.K; bh.rows = Cin; bh.K = a.K;          // wtb [Cin][tap][Cout]: K-contiguous over (tap, co)
+    launch_lds(s, ah, bh, ep, a.rows, Cin, a.K, 1);
+  } else {
+    LoadConvWT b; b.w = w; b.Cin = Cin; b.Cout = Cout; b.KK = ks * ks; b.K = a.K;
+    launch_conv_dgrad(s, bf16, a, b, ep, a.rows, Cin, a.K);
+  }
 }
 
 void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float* dy, float* dw, float* dbias, int B, int H,
-                          int W, int Cin, int Cout, int ks, int pad) {
+                          int W, int Cin, int Cout, int ks, int pad, const bf16_t* xb, const bf16_t* dyb) {
   const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
   const int P = B * Ho * Wo, N = ks * ks * Cin;
-  LoadMN a = make_loadmn(dy, Cout, Cout, P);
   LoadConvXcol b; b.x = x; b.H = H; b.W = W; b.Cin = Cin; b.KW = ks; b.pad = pad; b.Ho = Ho; b.Wo = Wo; b.N = N; b.K = P;
   EpStore ep = make_store(dw, N, Cout, N, nullptr, nullptr, EP_ATOMIC);
-  launch_conv_wgrad(s, bf16, a, b, ep, Cout, N, P, pick_ksplit(Cout, N, P, bf16));
+  const int ksplit = pick_ksplit(Cout, N, P, bf16);
+  if (bf16 && xb && dyb) {
+    LoadMNh ah; ah.p = dyb; ah.ld = Cout; ah.rows = Cout; ah.K = P;
+    LoadConvXcolh bh; bh.x = xb; bh.g = b;
+    launch_lds(s, ah, bh, ep, Cout, N, P, ksplit);
+  } else {
+    launch_conv_wgrad(s, bf16, make_loadmn(dy, Cout, Cout, P), b, ep, Cout, N, P, ksplit);
+  }
   if (dbias) colsum_accum(s, dy, Cout, P, Cout, dbias);
 }
 

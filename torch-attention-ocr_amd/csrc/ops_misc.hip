@@ -40,8 +40,8 @@ __device__ __forceinline__ void conv1_patch(const float* __restrict__ x, int b, 
 }
 
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ y, int B, int H,
-                                                        int W, int Hp, int Wp) {
+                                                        const float* __restrict__ bias, float* __restrict__ y, bf16_t* __restrict__ yb,
+                                                        int B, int H, int W, int Hp, int Wp) {
   __shared__ float sw[64 * 9 + 64];
   for (int i = threadIdx.x; i < 64 * 9 + 64; i += 256) sw[i] = i < 576 ? w[i] : bias[i - 576];
   __syncthreads();
@@ -71,6 +71,10 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
       out[c] = best;
     }
     *reinterpret_cast<float4*>(y + win * 64 + cq * 4) = make_float4(out[0], out[1], out[2], out[3]);
+    if (yb) {
+      bf16x4 hb; hb[0] = (bf16_t)out[0]; hb[1] = (bf16_t)out[1]; hb[2] = (bf16_t)out[2]; hb[3] = (bf16_t)out[3];
+      *reinterpret_cast<bf16x4*>(yb + win * 64 + cq * 4) = hb;
+    }
   }
 }
 
@@ -135,11 +139,11 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
   }
 }
 
-void conv1_forward(hipStream_t s, const float* x, const float* w, const float* bias, float* y, int B, int H, int W) {
+void conv1_forward(hipStream_t s, const float* x, const float* w, const float* bias, float* y, int B, int H, int W, bf16_t* yb) {
   int Hp = H / 2, Wp = W / 2;
   int64_t total = (int64_t)B * Hp * Wp * 16;
   int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
-  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, y, B, H, W, Hp, Wp);
+  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, y, yb, B, H, W, Hp, Wp);
 }
 void conv1_backward(hipStream_t s, const float* x, const float* w, const float* bias, const float* dyp, float* dw, float* db,
                     int B, int H, int W) {
@@ -150,11 +154,31 @@ void conv1_backward(hipStream_t s, const float* x, const float* w, const float* 
 }
 
 // =============================================================================================
+// bf16 shadows of a conv weight tensor w [Cout][KK][Cin]: wb same layout (forward B operand, K-contiguous) and
+// wtb [Cin][KK][Cout] (data-gradient B operand, K-contiguous over (tap, co)).  Refreshed once per step.
+// =============================================================================================
+__global__ __launch_bounds__(256) void conv_weight_shadow_kernel(const float* __restrict__ w, bf16_t* __restrict__ wb,
+                                                                 bf16_t* __restrict__ wtb, int Cout, int KK, int Cin) {
+  const int64_t n = (int64_t)Cout * KK * Cin;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    int ci = (int)(i % Cin); int64_t t = i / Cin; int tap = (int)(t % KK); int co = (int)(t / KK);
+    bf16_t v = (bf16_t)w[i];
+    wb[i] = v;
+    wtb[((int64_t)ci * KK + tap) * Cout + co] = v;
+  }
+}
+void conv_weight_shadows(hipStream_t s, const float* w, bf16_t* wb, bf16_t* wtb, int Cout, int KK, int Cin) {
+  int64_t n = (int64_t)Cout * KK * Cin;
+  hipLaunchKernelGGL(conv_weight_shadow_kernel, dim3((int)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, w, wb, wtb,
+                     Cout, KK, Cin);
+}
+
+// =============================================================================================
 // un-pool + ReLU backward: dy (B,Ho,Wo,C) from d(pooled), arg-max index and the pooled value (>0 <=> ReLU passed).
 // =============================================================================================
 __global__ __launch_bounds__(256) void unpool_kernel(const float* __restrict__ dp, const float* __restrict__ pooled,
-                                                     const uint8_t* __restrict__ idx, float* __restrict__ dy, int B, int Ho,
-                                                     int Wo, int C, int pool, int Hp, int Wp) {
+                                                     const uint8_t* __restrict__ idx, float* __restrict__ dy, bf16_t* __restrict__ dyb,
+                                                     int B, int Ho, int Wo, int C, int pool, int Hp, int Wp) {
   const int C4 = C >> 2;
   const int64_t total = (int64_t)B * Hp * Wp * C4;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
@@ -171,17 +195,22 @@ __global__ __launch_bounds__(256) void unpool_kernel(const float* __restrict__ d
       int x = pool == 1 ? 2 * px + (pos & 1) : px;
       float4 o = make_float4(iv[0] == pos ? gv[0] : 0.f, iv[1] == pos ? gv[1] : 0.f, iv[2] == pos ? gv[2] : 0.f,
                              iv[3] == pos ? gv[3] : 0.f);
-      *reinterpret_cast<float4*>(dy + (((int64_t)b * Ho + y) * Wo + x) * C + c4 * 4) = o;
+      const int64_t off = (((int64_t)b * Ho + y) * Wo + x) * C + c4 * 4;
+      *reinterpret_cast<float4*>(dy + off) = o;
+      if (dyb) { bf16x4 hb; hb[0] = (bf16_t)o.x; hb[1] = (bf16_t)o.y; hb[2] = (bf16_t)o.z; hb[3] = (bf16_t)o.w; *reinterpret_cast<bf16x4*>(dyb + off) = hb; }
     }
   }
 }
 void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pooled, const uint8_t* idx, float* dy, int B, int Ho,
-                          int Wo, int C, int pool) {
+                          int Wo, int C, int pool, bf16_t* dyb) {
   int Hp = Ho / 2, Wp = pool == 1 ? Wo / 2 : Wo;
-  if ((Ho & 1) || (pool == 1 && (Wo & 1))) hipMemsetAsync(dy, 0, (size_t)B * Ho * Wo * C * sizeof(float), s);   // floor-mode leftovers
+  if ((Ho & 1) || (pool == 1 && (Wo & 1))) {                                      // floor-mode leftovers
+    hipMemsetAsync(dy, 0, (size_t)B * Ho * Wo * C * sizeof(float), s);
+    if (dyb) hipMemsetAsync(dyb, 0, (size_t)B * Ho * Wo * C * sizeof(bf16_t), s);
+  }
   int64_t total = (int64_t)B * Hp * Wp * (C / 4);
   int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
-  hipLaunchKernelGGL(unpool_kernel, dim3(blocks), dim3(256), 0, s, dpooled, pooled, idx, dy, B, Ho, Wo, C, pool, Hp, Wp);
+  hipLaunchKernelGGL(unpool_kernel, dim3(blocks), dim3(256), 0, s, dpooled, pooled, idx, dy, dyb, B, Ho, Wo, C, pool, Hp, Wp);
 }
 
 // =============================================================================================
@@ -248,7 +277,7 @@ __global__ void bn_eval_prepare_kernel(const float* rm, const float* rv, float* 
 __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             const float* __restrict__ save, int64_t rows, int C, int tb_rows,
-                                                            int T) {
+                                                            int T, bf16_t* __restrict__ yb) {
   const int C4 = C >> 2;
   const int64_t total = rows * C4;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
@@ -262,6 +291,7 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restr
     int64_t ro = r;
     if (tb_rows > 0) { int64_t bi = r / T, t = r - bi * T; ro = t * tb_rows + bi; }
     *reinterpret_cast<float4*>(y + ro * C + c) = o;
+    if (yb) { bf16x4 hb; hb[0] = (bf16_t)o.x; hb[1] = (bf16_t)o.y; hb[2] = (bf16_t)o.z; hb[3] = (bf16_t)o.w; *reinterpret_cast<bf16x4*>(yb + ro * C + c) = hb; }
   }
 }
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nchunk, int64_t rows, int C, const float* save,
@@ -276,7 +306,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nchu
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dA, const float* __restrict__ w,
                                                            const float* __restrict__ save, const double* __restrict__ fin,
-                                                           float* __restrict__ dx, int64_t rows, int C, int tb_rows, int T) {
+                                                           float* __restrict__ dx, int64_t rows, int C, int tb_rows, int T,
+                                                           bf16_t* __restrict__ dxb) {
   const int64_t total = rows * C;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
     int c = (int)(id % C); int64_t r = id / C;
@@ -285,12 +316,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     float d = y[ro * C + c] > 0.f ? dA[ro * C + c] : 0.f;
     float inv = save[C + c];
     float xh = (x[id] - save[c]) * inv;
-    dx[id] = (d - (float)fin[c * 2] - xh * (float)fin[c * 2 + 1]) * inv * w[c];
+    const float gx = (d - (float)fin[c * 2] - xh * (float)fin[c * 2 + 1]) * inv * w[c];
+    dx[id] = gx;
+    if (dxb) dxb[id] = (bf16_t)gx;
   }
 }
 
 void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, const float* b, float* rm, float* rv,
-                     float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows) {
+                     float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows, bf16_t* yb) {
   int T = tb_rows > 0 ? (int)(rows / tb_rows) : 0;
   if (training) {
     double* part = (double*)scratch;
@@ -304,10 +337,10 @@ void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, co
   }
   int64_t total = rows * (C / 4);
   int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
-  hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(blocks), dim3(256), 0, s, x, y, w, b, save, rows, C, tb_rows, T);
+  hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(blocks), dim3(256), 0, s, x, y, w, b, save, rows, C, tb_rows, T, yb);
 }
 void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
-                      float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows) {
+                      float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb) {
   int T = tb_rows > 0 ? (int)(rows / tb_rows) : 0;
   double* part = (double*)scratch;
   double* fin = part + (size_t)BN_CHUNKS * C * 2;
@@ -316,7 +349,7 @@ void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, part, nchunk, rows, C, save, fin, dw, db);
   int64_t total = rows * C;
   int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb);
 }
 
 // =============================================================================================
