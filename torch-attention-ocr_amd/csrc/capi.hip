@@ -83,6 +83,11 @@ static void bind_params(aocr_model* m) {
       snprintf(nm, 64, "%s.l%d.i2h.b", prefix, l); o = find(nm); p.bi = m->params + o; p.dbi = m->grads + o;
       snprintf(nm, 64, "%s.l%d.h2h.w", prefix, l); o = find(nm); p.wh = m->params + o; p.dwh = m->grads + o;
       snprintf(nm, 64, "%s.l%d.h2h.b", prefix, l); o = find(nm); p.bh = m->params + o; p.dbh = m->grads + o;
+      // recurrent-step views: the part of W_i2h that multiplies a hidden-size input (layer 1 of the decoder: the
+      // input-feed columns [E, E+Hd)), and W_h2h
+      const int skip = p.in - H;
+      p.swi.w = p.wi + (skip > 0 ? skip : 0); p.swi.ld = p.in; p.swi.R = 4 * H; p.swi.C = H;
+      p.swh.w = p.wh; p.swh.ld = H; p.swh.R = 4 * H; p.swh.C = H;
     }
   };
   lstm("enc_fw", m->enc[0], m->Le, 512, m->He);
@@ -91,6 +96,8 @@ static void bind_params(aocr_model* m) {
   int64_t o = find("dec.lookup"); m->lookup = m->params + o; m->dlookup = m->grads + o;
   o = find("dec.attn.wa"); m->wa = m->params + o; m->dwa = m->grads + o;
   o = find("dec.attn.wc"); m->wc = m->params + o; m->dwc = m->grads + o;
+  m->swa.w = m->wa; m->swa.ld = m->Hd; m->swa.R = m->Hd; m->swa.C = m->Hd;
+  m->swc.w = m->wc; m->swc.ld = 2 * m->Hd; m->swc.R = m->Hd; m->swc.C = 2 * m->Hd;
   o = find("proj.w"); m->wo = m->params + o; m->dwo = m->grads + o;
   o = find("proj.b"); m->bo = m->params + o; m->dbo = m->grads + o;
 }

@@ -61,6 +61,16 @@ struct LoadK {
       for (int j = 0; j < NV; ++j) f.v[j] = (c.ok && k + j < K) ? src[j] : 0.f;
     }
   }
+  // branch-free variant for the recurrent-step kernels: the caller guarantees 16-byte alignment and K, K0 multiples
+  // of the chunk; rows past the end were clamped to row 0 by row() and their results are dropped by the epilogue.
+  template <int NV> __device__ __forceinline__ void load_fast(Frag<NV>& f, const Ctx& c, int k) const {
+    const float* src = (k < K0) ? c.b0 + k : c.b1 + (k - K0);
+#pragma unroll
+    for (int j = 0; j < NV; j += 4) {
+      float4 t = *reinterpret_cast<const float4*>(src + j);
+      f.v[j] = t.x; f.v[j + 1] = t.y; f.v[j + 2] = t.z; f.v[j + 3] = t.w;
+    }
+  }
 };
 
 // MN-contiguous: element(r,k) = p[k*ld + r]
@@ -72,6 +82,7 @@ struct LoadMN {
 #pragma unroll
     for (int j = 0; j < NV; ++j) f.v[j] = (c.ok && k + j < K) ? c.b[(int64_t)(k + j) * ld] : 0.f;
   }
+  template <int NV> __device__ __forceinline__ void load_fast(Frag<NV>& f, const Ctx& c, int k) const { load<NV>(f, c, k); }
   // micro-block interface of the LDS-tiled kernel: v[kk][j] = element(r + j, k + kk), 4 rows x 4 k, r % 4 == 0
   struct Ctx4 { const float* b; int nv; };
   __device__ __forceinline__ Ctx4 row4(int r) const {
@@ -203,19 +214,26 @@ struct LoadConvXcol {
 // ---------------------------------------------------------------------------
 // MFMA step over one chunk
 // ---------------------------------------------------------------------------
-template <bool BF16, int WM, int WN>
-__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[WM][WN], const Frag<Mode<BF16>::NV> (&a)[WM],
-                                          const Frag<Mode<BF16>::NV> (&b)[WN]) {
+__device__ __forceinline__ bf16x8 to_bf16x8(const Frag<8>& f) {
+  bf16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (__bf16)f.v[j];
+  return v;
+}
+__device__ __forceinline__ bf16x8 to_bf16x8(const uint4& u) { return __builtin_bit_cast(bf16x8, u); }
+__device__ __forceinline__ bf16x8 to_bf16x8(const Frag<4>&) { return bf16x8{}; }     // never used (fp32 mode)
+__device__ __forceinline__ float frag_elem(const Frag<4>& f, int s) { return f.v[s]; }
+__device__ __forceinline__ float frag_elem(const Frag<8>&, int) { return 0.f; }       // never used (bf16 mode)
+__device__ __forceinline__ float frag_elem(const uint4&, int) { return 0.f; }
+
+template <bool BF16, int WM, int WN, class FA, class FB>
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[WM][WN], const FA (&a)[WM], const FB (&b)[WN]) {
   if constexpr (BF16) {
     bf16x8 ab[WM], bb[WN];
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+    for (int i = 0; i < WM; ++i) ab[i] = to_bf16x8(a[i]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) ab[i][j] = (__bf16)a[i].v[j];
-#pragma unroll
-    for (int i = 0; i < WN; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bb[i][j] = (__bf16)b[i].v[j];
+    for (int i = 0; i < WN; ++i) bb[i] = to_bf16x8(b[i]);
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
@@ -228,7 +246,7 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[WM][WN], const Frag<Mode
       for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].v[s], b[ni].v[s], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag_elem(a[mi], s), frag_elem(b[ni], s), acc[mi][ni], 0, 0, 0);
   }
 }
 
@@ -276,7 +294,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(AL a, BL b, EP ep, int K,
 #pragma unroll
       for (int i = 0; i < WN; ++i) b.template load<NV>(gb[i], cb[i], kn + NV * h);
     }
-    mma_chunk<BF16, WM, WN>(acc, fa, fb);
+    mma_chunk<BF16, WM, WN, Frag<NV>, Frag<NV>>(acc, fa, fb);
 #pragma unroll
     for (int i = 0; i < WM; ++i) fa[i] = ga[i];
 #pragma unroll
@@ -386,6 +404,29 @@ struct LoadConvXcolh {
     }
   }
 };
+
+// K-contiguous bf16 with an optional second K segment: the weight shadows read by the recurrent-step kernels.
+struct LoadKh2 {
+  const bf16_t* p0; int64_t ld0; int K0;
+  const bf16_t* p1; int64_t ld1;
+  int rows; int K;
+  struct Ctx { const bf16_t* b0; const bf16_t* b1; bool ok; };
+  __device__ __forceinline__ Ctx row(int r) const {
+    Ctx c; c.ok = r < rows; int rr = c.ok ? r : 0;
+    c.b0 = p0 + (int64_t)rr * ld0; c.b1 = p1 ? p1 + (int64_t)rr * ld1 : p0;
+    return c;
+  }
+  template <int NV> __device__ __forceinline__ void load(uint4& f, const Ctx& c, int k) const {
+    static_assert(NV == 8, "bf16 weight shadows are only read in bf16 mode");
+    const bf16_t* src = (k < K0) ? c.b0 + k : c.b1 + (k - K0);
+    f = (c.ok && k + 8 <= K) ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+  }
+  template <int NV> __device__ __forceinline__ void load_fast(uint4& f, const Ctx& c, int k) const {
+    f = *reinterpret_cast<const uint4*>((k < K0) ? c.b0 + k : c.b1 + (k - K0));
+  }
+};
+template <class L, int NV> struct FragOf { typedef Frag<NV> type; };
+template <int NV> struct FragOf<LoadKh2, NV> { typedef uint4 type; };
 
 template <class L> struct KContig { static constexpr bool v = true; };
 template <> struct KContig<LoadMN> { static constexpr bool v = false; };
@@ -601,24 +642,40 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgs<AL, BL, EP>& g, 
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.f;
 
-  Frag<NV> fa[1], fb[NT], ga[1], gb[NT];
-  int kb = wave * CH;
-  if (kb < K) {
-    g.a.template load<NV>(fa[0], ca[0], kb + NV * h);
+  typedef typename FragOf<AL, NV>::type FA; typedef typename FragOf<BL, NV>::type FB;
+  // The step kernels are latency-bound (one workgroup per CU, a serial chain of L2 round trips), so each wave keeps
+  // D chunks in flight: a ring of D fragment sets, refilled right after the MFMAs that consumed the slot.
+  // Each wave owns a CONTIGUOUS quarter of K and its D in-flight chunks are consecutive, so the 16-32 bytes a lane
+  // takes from its row per chunk add up to whole 128-byte lines inside the in-flight window (row-strided fragment
+  // loads with chunks interleaved across waves re-fetched every line several times through the 32 KB L1).
+  constexpr int D = 4;
+  const int kw = ((K + 4 * CH - 1) / (4 * CH)) * CH;        // K range per wave, multiple of CH
+  const int kend = min(K, (wave + 1) * kw);
+  FA fa[D][1]; FB fb[D][NT];
+  int kb = wave * kw;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) g.b.template load<NV>(fb[i], cb[i], kb + NV * h);
-  }
-  for (; kb < K; kb += 4 * CH) {
-    const int kn = kb + 4 * CH;
-    if (kn < K) {
-      g.a.template load<NV>(ga[0], ca[0], kn + NV * h);
+  for (int d = 0; d < D; ++d) {
+    const int kc = kb + d * CH;
+    if (kc < kend) {
+      g.a.template load_fast<NV>(fa[d][0], ca[0], kc + NV * h);
 #pragma unroll
-      for (int i = 0; i < NT; ++i) g.b.template load<NV>(gb[i], cb[i], kn + NV * h);
+      for (int i = 0; i < NT; ++i) g.b.template load_fast<NV>(fb[d][i], cb[i], kc + NV * h);
     }
-    mma_chunk<BF16, 1, NT>(acc, fa, fb);
-    fa[0] = ga[0];
+  }
+  for (; kb < kend; kb += D * CH) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i) fb[i] = gb[i];
+    for (int d = 0; d < D; ++d) {
+      const int kc = kb + d * CH;
+      if (kc < kend) {
+        mma_chunk<BF16, 1, NT, FA, FB>(acc, fa[d], fb[d]);
+        const int kn = kc + D * CH;
+        if (kn < kend) {
+          g.a.template load_fast<NV>(fa[d][0], ca[0], kn + NV * h);
+#pragma unroll
+          for (int i = 0; i < NT; ++i) g.b.template load_fast<NV>(fb[d][i], cb[i], kn + NV * h);
+        }
+      }
+    }
   }
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni)
@@ -639,12 +696,12 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgs<AL, BL, EP>& g, 
   g.ep.template quad<NT>(m0 + 8 * q + 4 * h, n0 + r, 32, v);
 }
 
+template <class AL, class BL, class EP> struct SmallArgs2 { SmallArgs<AL, BL, EP> z[2]; };
+
 template <bool BF16, int NT, bool GATES, class AL, class BL, class EP>
-__global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs<AL, BL, EP> z0, SmallArgs<AL, BL, EP> z1,
-                                                         int gate_stride) {
+__global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs2<AL, BL, EP> zz, int gate_stride) {
   __shared__ float red[4 * NT * 16 * 64];
-  if (blockIdx.z == 0) gemm_small_body<BF16, NT, GATES>(z0, gate_stride, red);
-  else gemm_small_body<BF16, NT, GATES>(z1, gate_stride, red);
+  gemm_small_body<BF16, NT, GATES>(zz.z[blockIdx.z], gate_stride, red);      // kernarg array: one body, scalar-indexed
 }
 
 }  // namespace aocr

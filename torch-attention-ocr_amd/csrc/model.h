@@ -16,7 +16,9 @@ Layout build_layout(const aocr_config& c);
 
 struct ConvP { float *w, *b, *dw, *db; int cin, cout, ks, pad; };
 struct BnP { float *w, *b, *dw, *db, *rm, *rv, *save; int C; };
-struct LstmP { float *wi, *bi, *wh, *bh, *dwi, *dbi, *dwh, *dbh; int in; };
+// bf16 shadows of one recurrent weight matrix W [R][C] (leading dimension ld, first column col0 of the fp32 tensor)
+struct ShW { const float* w; int64_t ld; int R, C; bf16_t* wb; bf16_t* wtb; };
+struct LstmP { float *wi, *bi, *wh, *bh, *dwi, *dbi, *dwh, *dbh; int in; ShW swi, swh; };
 
 struct Arena {
   char* base; size_t off;
@@ -46,6 +48,7 @@ struct aocr_model {
   aocr::BnP bn[8];                // 3,5,7
   aocr::LstmP enc[2][aocr::MAXL], dec[aocr::MAXL];
   float *lookup, *dlookup, *wa, *dwa, *wc, *dwc, *wo, *bo, *dwo, *dbo;
+  aocr::ShW swa, swc;
   int He, Hd, Le, Ld, E, V;
 
   // ---- workspace

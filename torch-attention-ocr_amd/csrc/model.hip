@@ -94,6 +94,14 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     static const int wsz[8] = {0, 0, 128 * 9 * 64, 256 * 9 * 128, 256 * 9 * 256, 512 * 9 * 256, 512 * 9 * 512, 512 * 4 * 512};
     for (int i = 2; i <= 7; ++i) { m->wb[i] = a.get<bf16_t>(wsz[i]); m->wtb[i] = a.get<bf16_t>(wsz[i]); }
   }
+  {                                                            // bf16 shadows of the recurrent weights (bf16 mode)
+    auto sh = [&](ShW& w, size_t R_, size_t C_) {
+      w.wb = m->bf16 ? a.get<bf16_t>(R_ * C_) : nullptr; w.wtb = m->bf16 ? a.get<bf16_t>(R_ * C_) : nullptr;
+    };
+    for (int dir = 0; dir < 2; ++dir) for (int l = 0; l < m->Le; ++l) { sh(m->enc[dir][l].swh, 4 * He, He); m->enc[dir][l].swi.wb = m->enc[dir][l].swi.wtb = nullptr; }
+    for (int l = 0; l < m->Ld; ++l) { sh(m->dec[l].swi, 4 * Hd, Hd); sh(m->dec[l].swh, 4 * Hd, Hd); }
+    sh(m->swa, Hd, Hd); sh(m->swc, Hd, 2 * Hd);
+  }
   m->bn_scratch = a.get<char>(bn_scratch_bytes(512)); m->bn_save = a.get<float>(3 * 2 * 512);
   for (int dir = 0; dir < 2; ++dir) {
     for (int l = 0; l < m->Le; ++l) {
@@ -134,10 +142,64 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// recurrent-step launch helpers: the B operand is a weight matrix W [R][C]; in bf16 mode its bf16 shadow (W for
+// y = x W^T, the transposed shadow for y = x W) is read, always K-contiguous; in fp32 mode W itself.
+// ------------------------------------------------------------------------------------------------
+static void refresh_rnn_shadows(aocr_model* m) {
+  if (!m->bf16) return;
+  auto up = [&](const ShW& w) { if (w.wb) weight_shadows(m->s, w.w, w.ld, w.R, w.C, w.wb, w.wtb); };
+  for (int dir = 0; dir < 2; ++dir) for (int l = 0; l < m->Le; ++l) up(m->enc[dir][l].swh);
+  for (int l = 0; l < m->Ld; ++l) { if (l > 0 || m->cfg.input_feed) up(m->dec[l].swi); up(m->dec[l].swh); }
+  up(m->swa); up(m->swc);
+}
+static LoadK bnt_f(const ShW* w0, const ShW* w1) {
+  return w1 ? make_loadk2(w0->w, w0->ld, w0->C, w1->w, w1->ld, w1->C, w0->R) : make_loadk(w0->w, w0->ld, w0->R, w0->C);
+}
+static LoadKh2 bnt_h(const ShW* w0, const ShW* w1) {
+  return w1 ? make_loadkh2(w0->wb, w0->C, w0->C, w1->wb, w1->C, w1->C, w0->R) : make_loadkh(w0->wb, w0->C, w0->R, w0->C);
+}
+// gates forward: z = [x0 ; x1] [W0 ; W1]^T (+ epilogue); nz argument sets
+static void run_gates_fwd(aocr_model* m, int nz, const LoadK* a, const ShW* const* w0, const ShW* const* w1, const EpGatesFwd* ep,
+                          int M, int H) {
+  if (m->bf16) {
+    GatesFwdArgsH z[2];
+    for (int i = 0; i < nz; ++i) { z[i].a = a[i]; z[i].b = bnt_h(w0[i], w1[i]); z[i].ep = ep[i]; z[i].K = a[i].K; }
+    launch_small_gates_fwd_h(m->s, nz, z, M, H);
+  } else {
+    GatesFwdArgs z[2];
+    for (int i = 0; i < nz; ++i) { z[i].a = a[i]; z[i].b = bnt_f(w0[i], w1[i]); z[i].ep = ep[i]; z[i].K = a[i].K; }
+    launch_small_gates_fwd(m->s, false, nz, z, M, H);
+  }
+}
+// y = x W^T through an EpStore
+static void run_store_nt(aocr_model* m, const LoadK& a, const ShW& w, const EpStore& ep, int M) {
+  if (m->bf16) { SmallArgsH z; z.a = a; z.b = bnt_h(&w, nullptr); z.ep = ep; z.K = a.K; launch_small_h(m->s, 1, &z, M, w.R); }
+  else { SmallKKArgs z; z.a = a; z.b = bnt_f(&w, nullptr); z.ep = ep; z.K = a.K; launch_small_kk(m->s, false, 1, &z, M, w.R); }
+}
+// y = x W through an EpStore (x is [M][R], y is [M][C])
+static void run_store_nn(aocr_model* m, const LoadK& a, const ShW& w, const EpStore& ep, int M) {
+  if (m->bf16) { SmallArgsH z; z.a = a; z.b = make_loadkh(w.wtb, w.R, w.C, w.R); z.ep = ep; z.K = a.K; launch_small_h(m->s, 1, &z, M, w.C); }
+  else { SmallKMNArgs z; z.a = a; z.b = make_loadmn(w.w, w.ld, w.C, a.K); z.ep = ep; z.K = a.K; launch_small_kmn(m->s, false, 1, &z, M, w.C); }
+}
+// gate backward: d(h) GEMM part = x W (K may be 0: no GEMM part)
+static void run_gates_bwd(aocr_model* m, int nz, const LoadK* a, const ShW* const* w, const EpGatesBwd* ep, int M, int H) {
+  if (m->bf16) {
+    GatesBwdArgsH z[2];
+    for (int i = 0; i < nz; ++i) { z[i].a = a[i]; z[i].b = make_loadkh(w[i]->wtb, w[i]->R, w[i]->C, a[i].K); z[i].ep = ep[i]; z[i].K = a[i].K; }
+    launch_small_gates_bwd_h(m->s, nz, z, M, H);
+  } else {
+    GatesBwdArgs z[2];
+    for (int i = 0; i < nz; ++i) { z[i].a = a[i]; z[i].b = make_loadmn(w[i]->w, w[i]->ld, w[i]->C, a[i].K); z[i].ep = ep[i]; z[i].K = a[i].K; }
+    launch_small_gates_bwd(m->s, false, nz, z, M, H);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // CNN forward, cnn.lua:9-45.  Output X is time-major (T,B,512) (= cnn_output:transpose(1,2), model.lua:288).
 // ------------------------------------------------------------------------------------------------
 void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training, int update_running) {
   hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
+  refresh_rnn_shadows(m);
   if (bf)                                                       // refresh the bf16 weight shadows (weights change every step)
     for (int i = 2; i <= 7; ++i)
       conv_weight_shadows(s, m->conv[i].w, m->wb[i], m->wtb[i], m->conv[i].cout, m->conv[i].ks * m->conv[i].ks, m->conv[i].cin);
@@ -204,23 +266,22 @@ void encoder_forward(aocr_model* m, const Dims& d) {
     }
     const bool top = l == m->Le - 1;
     for (int i = 0; i < T; ++i) {
-      GatesFwdArgs z[2];
+      LoadK la[2]; EpGatesFwd ee[2]; const ShW* w0[2]; const ShW* w1[2] = {nullptr, nullptr};
       for (int dir = 0; dir < 2; ++dir) {
         const LstmP& p = m->enc[dir][l];
         const int t = dir == 0 ? i : T - 1 - i;
         const int prev = dir == 0 ? t : t + 2;
         float* hs = m->ehs[dir][l]; float* cs = m->ecs[dir][l];
-        z[dir].a = make_loadk(hs + prev * slot, He, B, He);
-        z[dir].b = make_loadk(p.wh, He, 4 * He, He);
-        z[dir].K = He;
-        EpGatesFwd& e = z[dir].ep;
+        la[dir] = make_loadk(hs + prev * slot, He, B, He);
+        w0[dir] = &p.swh;
+        EpGatesFwd& e = ee[dir];
         e.zx = m->ezx[dir][l] + (size_t)t * B * 4 * He; e.ldzx = 4 * He; e.b1 = nullptr; e.b2 = nullptr;
         e.c_prev = cs + prev * slot; e.ldcp = He;
         e.c_out = cs + (size_t)(t + 1) * slot; e.ldc = He; e.h_out = hs + (size_t)(t + 1) * slot; e.ldh = He;
         e.h_out2 = top ? m->context + (size_t)t * Hd + dir * He : nullptr; e.ldh2 = (int64_t)T * Hd;   // model.lua:303,315
         e.gates = m->egates[dir][l] + (size_t)t * B * 4 * He; e.ldg = 4 * He; e.M = B; e.H = He;
       }
-      launch_small_gates_fwd(s, bf, 2, z, B, He);
+      run_gates_fwd(m, 2, la, w0, w1, ee, B, He);
     }
   }
 }
@@ -238,17 +299,16 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       else hipMemsetAsync(m->edc[dir], 0, slot * sizeof(float), s);
     }
     for (int i = 0; i < T; ++i) {
-      GatesBwdArgs z[2];
+      LoadK la[2]; EpGatesBwd ee[2]; const ShW* ww[2];
       for (int dir = 0; dir < 2; ++dir) {
         const LstmP& p = m->enc[dir][l];
         const int t = dir == 0 ? T - 1 - i : i;
         const int tn = dir == 0 ? t + 1 : t - 1;                                     // step processed just before
         const int prev = dir == 0 ? t : t + 2;
         float* dz = m->edz[dir][l];
-        z[dir].a = make_loadk(i == 0 ? dz : dz + (size_t)tn * B * 4 * He, 4 * He, B, i == 0 ? 0 : 4 * He);
-        z[dir].b = make_loadmn(p.wh, He, He, i == 0 ? 0 : 4 * He);
-        z[dir].K = i == 0 ? 0 : 4 * He;
-        EpGatesBwd& e = z[dir].ep;
+        la[dir] = make_loadk(i == 0 ? dz : dz + (size_t)tn * B * 4 * He, 4 * He, B, i == 0 ? 0 : 4 * He);
+        ww[dir] = &p.swh;
+        EpGatesBwd& e = ee[dir];
         if (top) { e.dh1 = m->dctx + (size_t)t * Hd + dir * He; e.ld1 = (int64_t)T * Hd; }    // model.lua:670,684
         else { e.dh1 = m->edxl[dir] + (size_t)t * slot; e.ld1 = He; }
         e.dh2 = (top && i == 0) ? m->dh_rec[0] + dir * He : nullptr; e.ld2 = Hd;               // model.lua:667,681
@@ -257,7 +317,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
         e.c_prev = m->ecs[dir][l] + prev * slot; e.ldcp = He; e.c = m->ecs[dir][l] + (size_t)(t + 1) * slot; e.ldcc = He;
         e.dz = dz + (size_t)t * B * 4 * He; e.lddz = 4 * He; e.dc_out = m->edc[dir]; e.lddco = He; e.M = B; e.H = He;
       }
-      launch_small_gates_bwd(s, bf, 2, z, B, He);
+      run_gates_bwd(m, 2, la, ww, ee, B, He);
     }
     for (int dir = 0; dir < 2; ++dir) {
       const LstmP& p = m->enc[dir][l];
@@ -292,40 +352,25 @@ static void dec_step_forward(aocr_model* m, const DecStepIO& io, int T) {
   const int R = io.R, Hd = m->Hd, E = m->E;
   for (int l = 0; l < m->Ld; ++l) {
     const LstmP& p = m->dec[l];
-    GatesFwdArgs z;
-    EpGatesFwd& e = z.ep;
+    LoadK la; EpGatesFwd e; const ShW* w0; const ShW* w1 = nullptr;
     if (l == 0) {
-      if (m->cfg.input_feed) {
-        z.a = make_loadk2(io.feed, Hd, Hd, io.h_prev[0], Hd, Hd, R);
-        z.b = make_loadk2(p.wi + E, p.in, Hd, p.wh, Hd, Hd, 4 * Hd);
-        z.K = 2 * Hd;
-      } else {
-        z.a = make_loadk(io.h_prev[0], Hd, R, Hd); z.b = make_loadk(p.wh, Hd, 4 * Hd, Hd); z.K = Hd;
-      }
+      if (m->cfg.input_feed) { la = make_loadk2(io.feed, Hd, Hd, io.h_prev[0], Hd, Hd, R); w0 = &p.swi; w1 = &p.swh; }
+      else { la = make_loadk(io.h_prev[0], Hd, R, Hd); w0 = &p.swh; }
       e.zx = io.zx1; e.ldzx = 4 * Hd; e.b1 = nullptr; e.b2 = nullptr;
     } else {
-      z.a = make_loadk2(io.h_new[l - 1], Hd, Hd, io.h_prev[l], Hd, Hd, R);
-      z.b = make_loadk2(p.wi, Hd, Hd, p.wh, Hd, Hd, 4 * Hd);
-      z.K = 2 * Hd;
+      la = make_loadk2(io.h_new[l - 1], Hd, Hd, io.h_prev[l], Hd, Hd, R); w0 = &p.swi; w1 = &p.swh;
       e.zx = nullptr; e.ldzx = 0; e.b1 = p.bi; e.b2 = p.bh;
     }
     e.c_prev = io.c_prev[l]; e.ldcp = Hd; e.c_out = io.c_new[l]; e.ldc = Hd; e.h_out = io.h_new[l]; e.ldh = Hd;
     const bool top = l == m->Ld - 1;
     e.h_out2 = top ? io.cat + Hd : nullptr; e.ldh2 = 2 * Hd;                         // JoinTable [c ; h_top], LSTM.lua:153
     e.gates = io.gates[l]; e.ldg = 4 * Hd; e.M = R; e.H = Hd;
-    launch_small_gates_fwd(s, bf, 1, &z, R, Hd);
+    run_gates_fwd(m, 1, &la, &w0, &w1, &e, R, Hd);
   }
-  {                                                                                  // q = W_a h_top, LSTM.lua:131
-    SmallKKArgs z; z.a = make_loadk(io.h_new[m->Ld - 1], Hd, R, Hd); z.b = make_loadk(m->wa, Hd, Hd, Hd); z.K = Hd;
-    z.ep = make_store(io.q, Hd, R, Hd);
-    launch_small_kk(s, bf, 1, &z, R, Hd);
-  }
+  run_store_nt(m, make_loadk(io.h_new[m->Ld - 1], Hd, R, Hd), m->swa, make_store(io.q, Hd, R, Hd), R);          // q = W_a h_top, LSTM.lua:131
   attention_forward(s, m->context, io.q, io.a, io.cat, 2 * Hd, R, T, Hd, io.ctx_div);
-  {                                                                                  // out = tanh(W_c [c ; h]), LSTM.lua:155
-    SmallKKArgs z; z.a = make_loadk(io.cat, 2 * Hd, R, 2 * Hd); z.b = make_loadk(m->wc, 2 * Hd, Hd, 2 * Hd); z.K = 2 * Hd;
-    z.ep = make_store(io.out, Hd, R, Hd, nullptr, nullptr, EP_TANH);
-    launch_small_kk(s, bf, 1, &z, R, Hd);
-  }
+  run_store_nt(m, make_loadk(io.cat, 2 * Hd, R, 2 * Hd), m->swc, make_store(io.out, Hd, R, Hd, nullptr, nullptr, EP_TANH), R);   // LSTM.lua:155
+  (void)E; (void)bf;
 }
 
 // initial decoder state from the encoder's final states, model.lua:539-552 (+ quirk S5)
@@ -404,23 +449,17 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
     float* dcat = m->dcat_all + (size_t)t * B * 2 * Hd;
     // d(tanh) with the input-feed gradient of step t+1 added (model.lua:649,654-657)
     dpre_tanh(s, m->dout_proj + (size_t)t * slot, (m->cfg.input_feed && !last) ? m->dfeed : nullptr, out_t, dpre, (int64_t)slot);
-    {                                                                 // d[c ; h_top] = dpre W_c
-      SmallKMNArgs z; z.a = make_loadk(dpre, Hd, B, Hd); z.b = make_loadmn(m->wc, 2 * Hd, 2 * Hd, Hd); z.K = Hd;
-      z.ep = make_store(dcat, 2 * Hd, B, 2 * Hd);
-      launch_small_kmn(s, bf, 1, &z, B, 2 * Hd);
-    }
+    run_store_nn(m, make_loadk(dpre, Hd, B, Hd), m->swc, make_store(dcat, 2 * Hd, B, 2 * Hd), B);      // d[c ; h_top] = dpre W_c
     attention_backward(s, m->context, m->q_all + (size_t)t * slot, m->a_all + (size_t)t * B * T, dcat, 2 * Hd,
                        m->ds_all + (size_t)t * B * T, m->dq_all + (size_t)t * slot, B, T, Hd);
     // top layer: d h_top = dq W_a + dcat[:, Hd:] + recurrent part
     for (int l = Ld - 1; l >= 0; --l) {
-      GatesBwdArgs z; EpGatesBwd& e = z.ep;
+      LoadK la; EpGatesBwd e; const ShW* ww;
       if (l == Ld - 1) {
-        z.a = make_loadk(m->dq_all + (size_t)t * slot, Hd, B, Hd); z.b = make_loadmn(m->wa, Hd, Hd, Hd); z.K = Hd;
+        la = make_loadk(m->dq_all + (size_t)t * slot, Hd, B, Hd); ww = &m->swa;
         e.dh1 = dcat + Hd; e.ld1 = 2 * Hd;
       } else {                                                        // from the layer above: dz_{l+1} W_{l+1,i2h}
-        const LstmP& pu = m->dec[l + 1];
-        z.a = make_loadk(m->ddz[l + 1] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd); z.b = make_loadmn(pu.wi, Hd, Hd, 4 * Hd);
-        z.K = 4 * Hd;
+        la = make_loadk(m->ddz[l + 1] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd); ww = &m->dec[l + 1].swi;
         e.dh1 = nullptr; e.ld1 = 0;
       }
       e.dh2 = m->dh_rec[l]; e.ld2 = Hd;
@@ -428,20 +467,12 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
       e.gates = m->dgates[l] + (size_t)t * B * 4 * Hd; e.ldg = 4 * Hd;
       e.c_prev = m->dcs[l] + (size_t)t * slot; e.ldcp = Hd; e.c = m->dcs[l] + (size_t)(t + 1) * slot; e.ldcc = Hd;
       e.dz = m->ddz[l] + (size_t)t * B * 4 * Hd; e.lddz = 4 * Hd; e.dc_out = m->dc_st[l]; e.lddco = Hd; e.M = B; e.H = Hd;
-      launch_small_gates_bwd(s, bf, 1, &z, B, Hd);
-      {                                                               // recurrent part for step t-1: dz_l W_{l,h2h}
-        const LstmP& p = m->dec[l];
-        SmallKMNArgs r; r.a = make_loadk(m->ddz[l] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd);
-        r.b = make_loadmn(p.wh, Hd, Hd, 4 * Hd); r.K = 4 * Hd; r.ep = make_store(m->dh_rec[l], Hd, B, Hd);
-        launch_small_kmn(s, bf, 1, &r, B, Hd);
-      }
+      run_gates_bwd(m, 1, &la, &ww, &e, B, Hd);
+      // recurrent part for step t-1: dz_l W_{l,h2h}
+      run_store_nn(m, make_loadk(m->ddz[l] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd), m->dec[l].swh, make_store(m->dh_rec[l], Hd, B, Hd), B);
     }
-    if (m->cfg.input_feed) {                                          // d(prev attention output) = dz_1 W_{1,i2h}[:, E:]
-      const LstmP& p = m->dec[0];
-      SmallKMNArgs r; r.a = make_loadk(m->ddz[0] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd);
-      r.b = make_loadmn(p.wi + E, p.in, Hd, 4 * Hd); r.K = 4 * Hd; r.ep = make_store(m->dfeed, Hd, B, Hd);
-      launch_small_kmn(s, bf, 1, &r, B, Hd);
-    }
+    if (m->cfg.input_feed)                                            // d(prev attention output) = dz_1 W_{1,i2h}[:, E:]
+      run_store_nn(m, make_loadk(m->ddz[0] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd), m->dec[0].swi, make_store(m->dfeed, Hd, B, Hd), B);
   }
   // ---- hoisted parameter gradients (accGradParameters of every clone summed over time)
   const float* h_top_all = m->dhs[Ld - 1] + slot;

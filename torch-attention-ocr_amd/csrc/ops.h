@@ -49,6 +49,21 @@ void launch_small_gates_fwd(hipStream_t s, bool bf16, int nz, const GatesFwdArgs
 void launch_small_kk(hipStream_t s, bool bf16, int nz, const SmallKKArgs* z, int M, int N);
 void launch_small_kmn(hipStream_t s, bool bf16, int nz, const SmallKMNArgs* z, int M, int N);
 void launch_small_gates_bwd(hipStream_t s, bool bf16, int nz, const GatesBwdArgs* z, int M, int H);
+// bf16 mode with bf16 weight shadows as the B operand (always K-contiguous: W for y = x W^T, W^T for y = x W)
+typedef SmallArgs<LoadK, LoadKh2, EpGatesFwd> GatesFwdArgsH;
+typedef SmallArgs<LoadK, LoadKh2, EpStore> SmallArgsH;
+typedef SmallArgs<LoadK, LoadKh2, EpGatesBwd> GatesBwdArgsH;
+void launch_small_gates_fwd_h(hipStream_t s, int nz, const GatesFwdArgsH* z, int M, int H);
+void launch_small_h(hipStream_t s, int nz, const SmallArgsH* z, int M, int N);
+void launch_small_gates_bwd_h(hipStream_t s, int nz, const GatesBwdArgsH* z, int M, int H);
+inline LoadKh2 make_loadkh(const bf16_t* p, int64_t ld, int rows, int K) {
+  LoadKh2 l; l.p0 = p; l.ld0 = ld; l.K0 = K; l.p1 = nullptr; l.ld1 = 0; l.rows = rows; l.K = K; return l;
+}
+inline LoadKh2 make_loadkh2(const bf16_t* p0, int64_t ld0, int K0, const bf16_t* p1, int64_t ld1, int K1, int rows) {
+  LoadKh2 l; l.p0 = p0; l.ld0 = ld0; l.K0 = K0; l.p1 = p1; l.ld1 = ld1; l.rows = rows; l.K = K0 + K1; return l;
+}
+// wb [R][C] = bf16(w[r*ld + c]), wtb [C][R] = its transpose (dense)
+void weight_shadows(hipStream_t s, const float* w, int64_t ld, int R, int C, bf16_t* wb, bf16_t* wtb);
 
 // generic GEMM used by the C ABI and the hoisted projections; picks ksplit when allowed (atomic accumulate).
 int gemm(hipStream_t s, bool bf16, const float* A, int64_t lda, bool a_kmajor, const float* B, int64_t ldb, bool b_kmajor,

@@ -50,11 +50,11 @@ template <int NT, bool GATES, class ARGS>
 static void launch_small(hipStream_t s, bool bf16, int nz, const ARGS* z, int M, int ncols, int gate_stride) {
   if (M <= 0 || ncols <= 0) return;
   dim3 grid(GATES ? cdiv(ncols, 32) : cdiv(ncols, 32 * NT), cdiv(M, 32), nz);
-  const ARGS& z0 = z[0]; const ARGS& z1 = z[nz > 1 ? 1 : 0];
-  if (bf16) hipLaunchKernelGGL((gemm_small_kernel<true, NT, GATES, decltype(z0.a), decltype(z0.b), decltype(z0.ep)>), grid,
-                               dim3(256), 0, s, z0, z1, gate_stride);
-  else      hipLaunchKernelGGL((gemm_small_kernel<false, NT, GATES, decltype(z0.a), decltype(z0.b), decltype(z0.ep)>), grid,
-                               dim3(256), 0, s, z0, z1, gate_stride);
+  SmallArgs2<decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)> zz; zz.z[0] = z[0]; zz.z[1] = z[nz > 1 ? 1 : 0];
+  if (bf16) hipLaunchKernelGGL((gemm_small_kernel<true, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid,
+                               dim3(256), 0, s, zz, gate_stride);
+  else      hipLaunchKernelGGL((gemm_small_kernel<false, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid,
+                               dim3(256), 0, s, zz, gate_stride);
 }
 void launch_small_gates_fwd(hipStream_t s, bool bf16, int nz, const GatesFwdArgs* z, int M, int H) {
   launch_small<4, true>(s, bf16, nz, z, M, H, H);
@@ -68,6 +68,18 @@ void launch_small_kmn(hipStream_t s, bool bf16, int nz, const SmallKMNArgs* z, i
 void launch_small_gates_bwd(hipStream_t s, bool bf16, int nz, const GatesBwdArgs* z, int M, int H) {
   launch_small<1, false>(s, bf16, nz, z, M, H, 0);
 }
+
+template <int NT, bool GATES, class ARGS>
+static void launch_small_bf16(hipStream_t s, int nz, const ARGS* z, int M, int ncols, int gate_stride) {
+  if (M <= 0 || ncols <= 0) return;
+  dim3 grid(GATES ? cdiv(ncols, 32) : cdiv(ncols, 32 * NT), cdiv(M, 32), nz);
+  SmallArgs2<decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)> zz; zz.z[0] = z[0]; zz.z[1] = z[nz > 1 ? 1 : 0];
+  hipLaunchKernelGGL((gemm_small_kernel<true, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid, dim3(256), 0, s,
+                     zz, gate_stride);
+}
+void launch_small_gates_fwd_h(hipStream_t s, int nz, const GatesFwdArgsH* z, int M, int H) { launch_small_bf16<4, true>(s, nz, z, M, H, H); }
+void launch_small_h(hipStream_t s, int nz, const SmallArgsH* z, int M, int N) { launch_small_bf16<1, false>(s, nz, z, M, N, 0); }
+void launch_small_gates_bwd_h(hipStream_t s, int nz, const GatesBwdArgsH* z, int M, int H) { launch_small_bf16<1, false>(s, nz, z, M, H, 0); }
 
 // number of K slices so that a launch has >= ~768 workgroups (256 CUs x 3) when accumulation is atomic
 static int pick_ksplit(int M, int N, int K, bool bf16) {

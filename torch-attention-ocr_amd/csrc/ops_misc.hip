@@ -173,6 +173,26 @@ void conv_weight_shadows(hipStream_t s, const float* w, bf16_t* wb, bf16_t* wtb,
                      Cout, KK, Cin);
 }
 
+__global__ __launch_bounds__(256) void weight_shadow_kernel(const float* __restrict__ w, int64_t ld, int R, int C,
+                                                            bf16_t* __restrict__ wb, bf16_t* __restrict__ wtb) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8 threads
+  for (int i = ty; i < 32; i += 8) {
+    int r = r0 + i, c = c0 + tx;
+    float v = (r < R && c < C) ? w[(int64_t)r * ld + c] : 0.f;
+    tile[i][tx] = v;
+    if (r < R && c < C) wb[(int64_t)r * C + c] = (bf16_t)v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    int c = c0 + i, r = r0 + tx;
+    if (r < R && c < C) wtb[(int64_t)c * R + r] = (bf16_t)tile[tx][i];
+  }
+}
+void weight_shadows(hipStream_t s, const float* w, int64_t ld, int R, int C, bf16_t* wb, bf16_t* wtb) {
+  hipLaunchKernelGGL(weight_shadow_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, s, w, ld, R, C, wb, wtb);
+}
+
 // =============================================================================================
 // un-pool + ReLU backward: dy (B,Ho,Wo,C) from d(pooled), arg-max index and the pooled value (>0 <=> ReLU passed).
 // =============================================================================================
