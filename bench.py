@@ -132,6 +132,10 @@ def main():
         peak = 2500.0 if bf16 else 157.3
         ach = fl / (ms * 1e-3) / 1e12
         fpi = flops_per_image(W, wl["He"], wl["Le"], wl["Ld"], L)
+        traffic = None                                   # PMC passes cannot run inside this process: value measured with
+        pmc = os.path.join(ROOT, "profiles", "r01_conv6_fwd_pmc.json")       # rocprofv3 --pmc (tools/pmc_traffic.py), C3 bf16 only
+        if bf16 and args.workload == "c3" and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
         out = {
             "metric": "image-lines/sec (train step)", "value": lines_per_s, "unit": "image-lines/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
@@ -142,7 +146,7 @@ def main():
             "step_mfma_frac": 3 * fpi * lines_per_s / 1e12 / (peak * world),
             "decode_chars_per_s": dec, "loss": loss_val,
             "roofline": {"bound": "mfma", "kernel": "conv6 forward implicit GEMM (512->512 3x3 + ReLU + pool)",
-                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                          "ms_per_launch": ms},
         }
         if not args.no_cpu_baseline and world == 1:
