@@ -38,6 +38,7 @@ CASES = [
     dict(enc_hidden=32, enc_layers=1, dec_layers=2, input_feed=False),
     dict(enc_hidden=32, enc_layers=1, dec_layers=1, input_feed=True),
     dict(enc_hidden=48, enc_layers=2, dec_layers=3, input_feed=True),
+    dict(enc_hidden=64, enc_layers=1, dec_layers=2, input_feed=True),     # every K a multiple of 64: staged bf16 step kernel
 ]
 
 
@@ -118,9 +119,10 @@ def test_logits_c2_shape(cuda):
     m.shutdown()
 
 
-def test_bf16_path_runs_close(cuda):
-    """bf16-operand MFMA path: stated tolerance 5e-2 max-abs on logits (fp32 accumulate, fp32 storage)."""
-    m, O, ocfg, P, st, batch = make(CASES[0], B=5, W=36, maxlen=6, compute="bf16")
+@pytest.mark.parametrize("case", [0, 4])
+def test_bf16_path_runs_close(cuda, case):
+    """bf16-operand MFMA path: stated tolerance 5e-2 max-abs on logits (fp32 accumulate, fp32 master copies)."""
+    m, O, ocfg, P, st, batch = make(CASES[case], B=5, W=36, maxlen=6, compute="bf16")
     img, tgt, tge = (torch.from_numpy(np.asarray(x)) for x in batch[:3])
     loss_ref, G, aux, _ = O.train_step_manual(P, st, ocfg, img, tgt, tge)
     loss = m.train_forward_backward(batch)

@@ -704,4 +704,118 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs2<AL, BL, EP> 
   gemm_small_body<BF16, NT, GATES>(zz.z[blockIdx.z], gate_stride, red);      // kernarg array: one body, scalar-indexed
 }
 
+// ---------------------------------------------------------------------------
+// bf16 recurrent-step kernel with WAVE-PRIVATE LDS staging.
+// gemm_small_kernel loads MFMA fragments straight from global memory: every wave-instruction then touches 32-64
+// different 128-byte lines and uses 16-32 bytes of each, and the CU's vector memory path (about one line per clock)
+// -- not bytes, not MFMA -- sets the time (measured ~37 GB/s per CU).  Here each wave streams its K quarter in
+// 64-deep chunks with full-line loads (A fp32: 4 rows x 256 B per instruction, B bf16 shadows: 8 rows x 128 B),
+// converts/copies them into its own LDS image (144-byte pitch: conflict-free ds_read_b128 fragments) and feeds the
+// MFMAs from there.  No workgroup barrier inside the K loop (LDS serves a wave's requests in order); the next
+// chunk's global loads are issued before the current chunk's MFMAs.  Requires K, K0 % 64 == 0, N % 32 == 0.
+// ---------------------------------------------------------------------------
+constexpr int STEP_PITCH = 144;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int NT> constexpr int step_lds_bytes() { return 4 * (1 + NT) * 32 * STEP_PITCH; }
+
+// global -> registers for one 64-deep chunk (kept as free functions with flat, statically indexed arrays: arrays
+// captured by reference in lambdas were demoted to LDS / scratch by the compiler)
+template <int NT, bool GATES>
+__device__ __forceinline__ void step_gload(const LoadK& a, const LoadKh2& b, int kc, const int (&arow)[8], int brow0, int gate_stride,
+                                           int ap, int bp, float4 (&ra)[8], u32x4 (&rb)[NT * 4]) {
+  const bool s1 = kc >= a.K0;
+  const float* pa = s1 ? a.p1 : a.p0; const int64_t lda = s1 ? a.ld1 : a.ld0;
+  const bf16_t* pb = s1 ? b.p1 : b.p0; const int64_t ldb = s1 ? b.ld1 : b.ld0;
+  const int kk = s1 ? kc - a.K0 : kc;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ra[i] = *reinterpret_cast<const float4*>(pa + (int64_t)arow[i] * lda + kk + 4 * ap);
+#pragma unroll
+  for (int t = 0; t < NT * 4; ++t) {
+    const int ni = t >> 2, i = t & 3;
+    const int row = (GATES ? ni * gate_stride : 32 * ni) + brow0 + 8 * i;
+    rb[t] = *reinterpret_cast<const u32x4*>(pb + (int64_t)row * ldb + kk + 8 * bp);
+  }
+}
+template <int NT>
+__device__ __forceinline__ void step_lwrite(unsigned char* la, unsigned char* lb, int ar, int ap, int br, int bp,
+                                            const float4 (&ra)[8], const u32x4 (&rb)[NT * 4]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    bf16x4 v; v[0] = (bf16_t)ra[i].x; v[1] = (bf16_t)ra[i].y; v[2] = (bf16_t)ra[i].z; v[3] = (bf16_t)ra[i].w;
+    *reinterpret_cast<bf16x4*>(la + (ar + 4 * i) * STEP_PITCH + ap * 8) = v;
+  }
+#pragma unroll
+  for (int t = 0; t < NT * 4; ++t)
+    *reinterpret_cast<u32x4*>(lb + ((t >> 2) * 32 + br + 8 * (t & 3)) * STEP_PITCH + bp * 16) = rb[t];
+}
+
+template <int NT, bool GATES, class EP>
+__global__ __launch_bounds__(256) void gemm_step_kernel(SmallArgs2<LoadK, LoadKh2, EP> zz, int gate_stride) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[step_lds_bytes<NT>()];
+  const SmallArgs<LoadK, LoadKh2, EP>& g = zz.z[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 32;
+  const int n0 = GATES ? blockIdx.x * 32 : blockIdx.x * 32 * NT;
+  const int K = g.K;
+  unsigned char* la = lds + wave * ((1 + NT) * 32 * STEP_PITCH);
+  unsigned char* lb = la + 32 * STEP_PITCH;
+  const int kw = ((K / 64 + 3) / 4) * 64;                   // this wave's K range (multiple of 64)
+  const int kbeg = wave * kw, kend = min(K, kbeg + kw);
+
+  // staging roles: A lane -> row (lane>>4) + 4i, 16-byte piece (lane&15) = 4 fp32 k; B lane -> row (lane>>3) + 8i, piece (lane&7) = 8 bf16 k
+  const int ar = lane >> 4, ap = lane & 15, br = lane >> 3, bp = lane & 7;
+  int arow[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) arow[i] = min(m0 + ar + 4 * i, g.a.rows - 1);        // rows past the end: any valid row, result dropped
+  const int brow0 = n0 + br;                                  // N % 32 == 0 so always valid
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  if (kbeg < kend) {
+    float4 ra[8]; u32x4 rb[NT * 4];
+    step_gload<NT, GATES>(g.a, g.b, kbeg, arow, brow0, gate_stride, ap, bp, ra, rb);
+    for (int kc = kbeg; kc < kend; kc += 64) {
+      __builtin_amdgcn_wave_barrier();
+      step_lwrite<NT>(la, lb, ar, ap, br, bp, ra, rb);
+      __builtin_amdgcn_wave_barrier();
+      if (kc + 64 < kend) step_gload<NT, GATES>(g.a, g.b, kc + 64, arow, brow0, gate_stride, ap, bp, ra, rb);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(la + r * STEP_PITCH + 32 * s + 16 * h);
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(lb + (ni * 32 + r) * STEP_PITCH + 32 * s + 16 * h);
+          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[ni], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // cross-wave reduction: every wave parks its accumulators in its own (now idle) LDS region
+  __builtin_amdgcn_wave_barrier();
+  float* red = reinterpret_cast<float*>(la);
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(ni * 16 + e) * 64 + lane] = acc[ni][e];
+  __syncthreads();
+  const int q = wave;
+  float v[NT][4];
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        s += reinterpret_cast<const float*>(lds + w * ((1 + NT) * 32 * STEP_PITCH))[(ni * 16 + 4 * q + i) * 64 + lane];
+      v[ni][i] = s;
+    }
+  g.ep.template quad<NT>(m0 + 8 * q + 4 * h, n0 + r, 32, v);
+}
+
 }  // namespace aocr
