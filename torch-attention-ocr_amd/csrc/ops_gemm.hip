@@ -88,12 +88,13 @@ void launch_small_gates_fwd_h(hipStream_t s, int nz, const GatesFwdArgsH* z, int
 void launch_small_h(hipStream_t s, int nz, const SmallArgsH* z, int M, int N) { launch_small_bf16<1, false>(s, nz, z, M, N, 0); }
 void launch_small_gates_bwd_h(hipStream_t s, int nz, const GatesBwdArgsH* z, int M, int H) { launch_small_bf16<1, false>(s, nz, z, M, H, 0); }
 
-// number of K slices so that a launch has >= ~768 workgroups (256 CUs x 3) when accumulation is atomic
+// number of K slices for an atomically accumulated contraction: fill ONE round of resident workgroups (256 CUs x 3 per CU)
+// without spilling into a mostly empty second round
 static int pick_ksplit(int M, int N, int K, bool bf16) {
-  int64_t blocks = (int64_t)cdiv(M, 128) * cdiv(N, 128);
-  int chunk = bf16 ? 16 : 8;
-  int ks = (int)((768 + blocks - 1) / blocks);
-  int maxks = K / (chunk * 16); if (maxks < 1) maxks = 1;
+  int64_t tiles = (int64_t)cdiv(M, 128) * cdiv(N, 128);
+  int chunk = bf16 ? 32 : 8;
+  int ks = (int)(768 / tiles);
+  int maxks = K / (chunk * 8); if (maxks < 1) maxks = 1;
   if (ks > maxks) ks = maxks;
   if (ks < 1) ks = 1;
   return ks;

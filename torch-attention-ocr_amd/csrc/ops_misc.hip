@@ -436,16 +436,96 @@ __global__ __launch_bounds__(256) void attn_core_kernel(const float* __restrict_
     *reinterpret_cast<float4*>(o + (int64_t)b * ldo + j) = acc;
   }
 }
+// Register-resident variant for T <= 64 and Hd = 256*NC (NC = 1, 2): the whole (T, Hd) context slice of one batch row
+// is loaded ONCE into registers (wave w holds rows t = w, w+4, ...; all 16*NC dwordx4 loads of a lane are in flight
+// together) and serves both the score pass and the weighted-sum pass.  Same phases and outputs as attn_core_kernel.
+template <int NC, bool BWD>
+__global__ __launch_bounds__(256) void attn_reg_kernel(const float* __restrict__ ctx, const float* __restrict__ u, int64_t ldu,
+                                                       const float* __restrict__ a_in, float* __restrict__ p_out,
+                                                       float* __restrict__ o, int64_t ldo, int T, int ctx_div) {
+  constexpr int Hd = 256 * NC;
+  __shared__ float sc[64];
+  __shared__ __attribute__((aligned(16))) float red[4][Hd];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* cb = ctx + (int64_t)(b / ctx_div) * T * Hd;
+  const float* ub = u + (int64_t)b * ldu;
+  float4 c[16][NC];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int t = wave + 4 * i;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc)
+      c[i][cc] = t < T ? *reinterpret_cast<const float4*>(cb + (int64_t)t * Hd + cc * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 uu[NC];
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) uu[cc] = *reinterpret_cast<const float4*>(ub + cc * 256 + lane * 4);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      s = fmaf(c[i][cc].x, uu[cc].x, s); s = fmaf(c[i][cc].y, uu[cc].y, s); s = fmaf(c[i][cc].z, uu[cc].z, s); s = fmaf(c[i][cc].w, uu[cc].w, s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) sc[wave + 4 * i] = s;
+  }
+  __syncthreads();
+  if (wave == 0) {                                             // T <= 64: one wave does the softmax / its backward
+    const bool ok = lane < T;
+    float v = ok ? sc[lane] : -INFINITY;
+    float p;
+    if (!BWD) {
+      float m = wave_max(v);
+      float e = ok ? expf(v - m) : 0.f;
+      float sum = wave_sum(e);
+      p = e * (1.f / sum);
+    } else {
+      float a = ok ? a_in[(int64_t)b * T + lane] : 0.f;
+      float dot = wave_sum(ok ? a * v : 0.f);
+      p = ok ? a * (v - dot) : 0.f;
+    }
+    sc[lane] = p;
+    if (ok) p_out[(int64_t)b * T + lane] = p;
+  }
+  __syncthreads();
+  float4 acc[NC];
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) acc[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float p = sc[wave + 4 * i];                          // rows >= T carry p = 0 and c = 0
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      acc[cc].x = fmaf(p, c[i][cc].x, acc[cc].x); acc[cc].y = fmaf(p, c[i][cc].y, acc[cc].y);
+      acc[cc].z = fmaf(p, c[i][cc].z, acc[cc].z); acc[cc].w = fmaf(p, c[i][cc].w, acc[cc].w);
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) *reinterpret_cast<float4*>(&red[wave][cc * 256 + lane * 4]) = acc[cc];
+  __syncthreads();
+  for (int j = threadIdx.x; j < Hd; j += 256) o[(int64_t)b * ldo + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+}
+
+template <bool BWD>
+static void attn_launch(hipStream_t s, const float* ctx, const float* u, int64_t ldu, const float* a_in, float* p_out, float* o,
+                        int64_t ldo, int B, int T, int Hd, int ctx_div) {
+  if (T <= 64 && Hd == 512)
+    hipLaunchKernelGGL((attn_reg_kernel<2, BWD>), dim3(B), dim3(256), 0, s, ctx, u, ldu, a_in, p_out, o, ldo, T, ctx_div);
+  else if (T <= 64 && Hd == 256)
+    hipLaunchKernelGGL((attn_reg_kernel<1, BWD>), dim3(B), dim3(256), 0, s, ctx, u, ldu, a_in, p_out, o, ldo, T, ctx_div);
+  else
+    hipLaunchKernelGGL((attn_core_kernel<BWD>), dim3(B), dim3(256), (size_t)(T + 8) * sizeof(float), s, ctx, u, ldu, a_in, p_out, o, ldo,
+                       T, Hd, ctx_div);
+}
 void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a, float* c, int64_t ldc, int B, int T, int Hd,
                        int ctx_div) {
-  size_t sh = (size_t)(T + 8) * sizeof(float);
-  hipLaunchKernelGGL((attn_core_kernel<false>), dim3(B), dim3(256), sh, s, ctx, q, (int64_t)Hd, nullptr, a, c, ldc, T, Hd, ctx_div);
+  attn_launch<false>(s, ctx, q, (int64_t)Hd, nullptr, a, c, ldc, B, T, Hd, ctx_div);
 }
 void attention_backward(hipStream_t s, const float* ctx, const float* q, const float* a, const float* dc, int64_t lddc,
                         float* ds, float* dq, int B, int T, int Hd) {
   (void)q;
-  size_t sh = (size_t)(T + 8) * sizeof(float);
-  hipLaunchKernelGGL((attn_core_kernel<true>), dim3(B), dim3(256), sh, s, ctx, dc, lddc, a, ds, dq, (int64_t)Hd, T, Hd, 1);
+  attn_launch<true>(s, ctx, dc, lddc, a, ds, dq, (int64_t)Hd, B, T, Hd, 1);
 }
 
 // d(ctx)[b,t,j] = sum_l a[l,b,t]*dc[l,b,j] + ds[l,b,t]*q[l,b,j]  (model.lua:652-653 accumulated over the decoder loop)
