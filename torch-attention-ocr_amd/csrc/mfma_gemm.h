@@ -548,18 +548,13 @@ template <class LD> struct Stager<LD, false, true> {
   }
 };
 
+// one 128 x 128 output tile over k in [kbeg, kend)
 template <class AL, class BL, class EP>
-__global__ __launch_bounds__(256) void gemm_lds_bf16_kernel(AL a, BL b, EP ep, int K, int kper, int gx, int gy) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][128 * LDS_PITCH];
+__device__ __forceinline__ void lds_tile(const AL& a, const BL& b, const EP& ep, int m_blk, int n_blk, int kbeg, int kend,
+                                         unsigned char (&lds)[2][2][128 * LDS_PITCH]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware renumbering (bijective form): consecutive renumbered ids share an XCD (ids are dealt round-robin to 8 XCDs)
-  const int nwg = gx * gy, orig = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int m_blk = (bid / gx) * 128, n_blk = (bid % gx) * 128;
-  const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
   const int nk = (kend - kbeg + 31) >> 5;
 
   Stager<AL> sa; Stager<BL> sb;
@@ -612,6 +607,35 @@ __global__ __launch_bounds__(256) void gemm_lds_bf16_kernel(AL a, BL b, EP ep, i
         for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * q + i];
       ep.template quad<2>(m0 + 32 * mi + 8 * q + 4 * h, n0 + r, 32, v);
     }
+}
+
+template <class AL, class BL, class EP>
+__global__ __launch_bounds__(256) void gemm_lds_bf16_kernel(AL a, BL b, EP ep, int K, int kper, int gx, int gy) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][128 * LDS_PITCH];
+  // XCD-aware renumbering (bijective form): consecutive renumbered ids share an XCD (ids are dealt round-robin to 8 XCDs)
+  const int nwg = gx * gy, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int kbeg = blockIdx.z * kper;
+  lds_tile(a, b, ep, (bid / gx) * 128, (bid % gx) * 128, kbeg, min(K, kbeg + kper), lds);
+}
+
+// Grouped form: up to 8 independent contractions of the same operand kinds in ONE launch (the hoisted weight gradients
+// of a recurrent stack are each too small to fill the chip; together their tiles do, without split-K atomics).
+template <class AL, class BL, class EP> struct GroupProblem { AL a; BL b; EP ep; int K, kper, gx, ksplit, first; };
+template <class AL, class BL, class EP> struct GroupArgs { int n, total; GroupProblem<AL, BL, EP> p[8]; };
+
+template <class AL, class BL, class EP>
+__global__ __launch_bounds__(256) void gemm_lds_grouped_kernel(GroupArgs<AL, BL, EP> g) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][128 * LDS_PITCH];
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.p[i].first) pi = i;
+  const GroupProblem<AL, BL, EP>& P = g.p[pi];
+  const int local = blockIdx.x - P.first;                   // tile-major, then k slice
+  const int tile = local / P.ksplit, z = local - tile * P.ksplit;
+  const int kbeg = z * P.kper;
+  lds_tile(P.a, P.b, P.ep, (tile / P.gx) * 128, (tile % P.gx) * 128, kbeg, min(P.K, kbeg + P.kper), lds);
 }
 
 // ---------------------------------------------------------------------------

@@ -319,19 +319,21 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       }
       run_gates_bwd(m, 2, la, ww, ee, B, He);
     }
+    WGradProblem wg[4]; int nwg = 0;
     for (int dir = 0; dir < 2; ++dir) {
       const LstmP& p = m->enc[dir][l];
       const float* xin = l == 0 ? m->X : m->ehs[dir][l - 1] + slot;
       const float* hprev = m->ehs[dir][l] + (dir == 0 ? 0 : 2 * slot);
       const float* dz = m->edz[dir][l];
-      gemm(s, bf, dz, 4 * He, false, xin, p.in, false, p.dwi, p.in, 4 * He, p.in, T * B, nullptr, nullptr, EP_ATOMIC);
-      gemm(s, bf, dz, 4 * He, false, hprev, He, false, p.dwh, He, 4 * He, He, T * B, nullptr, nullptr, EP_ATOMIC);
+      wg[nwg++] = WGradProblem{dz, 4 * He, xin, p.in, p.dwi, p.in, 4 * He, p.in, T * B};
+      wg[nwg++] = WGradProblem{dz, 4 * He, hprev, He, p.dwh, He, 4 * He, He, T * B};
       colsum_accum(s, dz, 4 * He, (int64_t)T * B, 4 * He, p.dbi);
       colsum_accum(s, dz, 4 * He, (int64_t)T * B, 4 * He, p.dbh);
       if (l == 0) gemm(s, bf, dz, 4 * He, true, p.wi, p.in, false, m->dX, 512, T * B, 512, 4 * He, nullptr, nullptr,
                        dir == 0 ? 0 : EP_ACCUM);                                     // model.lua:675 copy, :689 add
       else gemm(s, bf, dz, 4 * He, true, p.wi, p.in, false, m->edxl[dir], He, T * B, He, 4 * He, nullptr, nullptr, 0);
     }
+    grouped_wgrad(s, bf, wg, nwg);
   }
 }
 
@@ -476,23 +478,24 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   }
   // ---- hoisted parameter gradients (accGradParameters of every clone summed over time)
   const float* h_top_all = m->dhs[Ld - 1] + slot;
-  gemm(s, bf, m->dpre_all, Hd, false, m->cat_all, 2 * Hd, false, m->dwc, 2 * Hd, Hd, 2 * Hd, rows, nullptr, nullptr, EP_ATOMIC);
-  gemm(s, bf, m->dq_all, Hd, false, h_top_all, Hd, false, m->dwa, Hd, Hd, Hd, rows, nullptr, nullptr, EP_ATOMIC);
+  WGradProblem wg[16]; int nwg = 0;
+  wg[nwg++] = WGradProblem{m->dpre_all, Hd, m->cat_all, 2 * Hd, m->dwc, 2 * Hd, Hd, 2 * Hd, rows};
+  wg[nwg++] = WGradProblem{m->dq_all, Hd, h_top_all, Hd, m->dwa, Hd, Hd, Hd, rows};
   for (int l = 0; l < Ld; ++l) {
     const LstmP& p = m->dec[l]; const float* dz = m->ddz[l];
-    gemm(s, bf, dz, 4 * Hd, false, m->dhs[l], Hd, false, p.dwh, Hd, 4 * Hd, Hd, rows, nullptr, nullptr, EP_ATOMIC);
+    wg[nwg++] = WGradProblem{dz, 4 * Hd, m->dhs[l], Hd, p.dwh, Hd, 4 * Hd, Hd, rows};
     colsum_accum(s, dz, 4 * Hd, rows, 4 * Hd, p.dbi);
     colsum_accum(s, dz, 4 * Hd, rows, 4 * Hd, p.dbh);
     if (l == 0) {
-      gemm(s, bf, dz, 4 * Hd, false, m->emb_all, E, false, p.dwi, p.in, 4 * Hd, E, rows, nullptr, nullptr, EP_ATOMIC);
-      if (m->cfg.input_feed)
-        gemm(s, bf, dz, 4 * Hd, false, m->out_all, Hd, false, p.dwi + E, p.in, 4 * Hd, Hd, rows, nullptr, nullptr, EP_ATOMIC);
+      wg[nwg++] = WGradProblem{dz, 4 * Hd, m->emb_all, E, p.dwi, p.in, 4 * Hd, E, rows};
+      if (m->cfg.input_feed) wg[nwg++] = WGradProblem{dz, 4 * Hd, m->out_all, Hd, p.dwi + E, p.in, 4 * Hd, Hd, rows};
       gemm(s, bf, dz, 4 * Hd, true, p.wi, p.in, false, m->demb_all, E, rows, E, 4 * Hd, nullptr, nullptr, 0);
       embedding_scatter_accum(s, m->demb_all, tgt, 1, L, m->dlookup, L, B, E, V);
     } else {
-      gemm(s, bf, dz, 4 * Hd, false, m->dhs[l - 1] + slot, Hd, false, p.dwi, Hd, 4 * Hd, Hd, rows, nullptr, nullptr, EP_ATOMIC);
+      wg[nwg++] = WGradProblem{dz, 4 * Hd, m->dhs[l - 1] + slot, Hd, p.dwi, Hd, 4 * Hd, Hd, rows};
     }
   }
+  grouped_wgrad(s, bf, wg, nwg);
   // d(context), model.lua:652-653 summed over the loop
   attention_dctx(s, m->a_all, m->ds_all, m->dcat_all, 2 * Hd, m->q_all, m->dctx, L, B, T, Hd);
 }

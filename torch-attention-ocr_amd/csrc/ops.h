@@ -69,6 +69,11 @@ void weight_shadows(hipStream_t s, const float* w, int64_t ld, int R, int C, bf1
 int gemm(hipStream_t s, bool bf16, const float* A, int64_t lda, bool a_kmajor, const float* B, int64_t ldb, bool b_kmajor,
           float* C, int64_t ldc, int M, int N, int K, const float* bias, const float* bias2, int flags);
 
+// Grouped weight-gradient contractions C_i[M_i,N_i] += A_i^T B_i (A_i [K_i][M_i], B_i [K_i][N_i], all M/N-contiguous fp32):
+// one launch for up to 8 problems; K is split only as far as needed to fill the chip once.
+struct WGradProblem { const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int M, N, K; };
+void grouped_wgrad(hipStream_t s, bool bf16, const WGradProblem* p, int n);
+
 // ---- convolution layers (ops_gemm.hip)
 // xb/wb/dyb/wtb: optional bf16 shadows of the operands (both of a contraction's operands must be given to take the
 // bf16-source path); yb: optional bf16 shadow of the output to write.

@@ -111,6 +111,32 @@ int gemm(hipStream_t s, bool bf16, const float* A, int64_t lda, bool a_k, const 
   return 0;
 }
 
+void grouped_wgrad(hipStream_t s, bool bf16, const WGradProblem* p, int n) {
+  if (!bf16) {                                                // fp32 mode: one launch per problem
+    for (int i = 0; i < n; ++i)
+      gemm(s, false, p[i].A, p[i].lda, false, p[i].B, p[i].ldb, false, p[i].C, p[i].ldc, p[i].M, p[i].N, p[i].K, nullptr, nullptr, EP_ATOMIC);
+    return;
+  }
+  for (int base = 0; base < n; base += 8) {
+    const int cnt = std::min(8, n - base);
+    int64_t tiles = 0;
+    for (int i = 0; i < cnt; ++i) tiles += (int64_t)cdiv(p[base + i].M, 128) * cdiv(p[base + i].N, 128);
+    int ks = (int)(768 / tiles); if (ks < 1) ks = 1;          // common split: fill one resident round
+    GroupArgs<LoadMN, LoadMN, EpStore> g; g.n = cnt; int first = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const WGradProblem& q = p[base + i];
+      auto& P = g.p[i];
+      int ksplit = ks, kper; split_k(q.K, 32, ksplit, kper);
+      P.a = make_loadmn(q.A, q.lda, q.M, q.K); P.b = make_loadmn(q.B, q.ldb, q.N, q.K);
+      P.ep = make_store(q.C, q.ldc, q.M, q.N, nullptr, nullptr, ksplit > 1 ? EP_ATOMIC : EP_ACCUM);
+      P.K = q.K; P.kper = kper; P.gx = cdiv(q.N, 128); P.ksplit = ksplit; P.first = first;
+      first += cdiv(q.M, 128) * P.gx * ksplit;
+    }
+    g.total = first;
+    hipLaunchKernelGGL((gemm_lds_grouped_kernel<LoadMN, LoadMN, EpStore>), dim3(first), dim3(256), 0, s, g);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // convolution layers, channels-last.  Output grid Ho = H + 2*pad - ks + 1 (stride 1).  When bf16 shadows of both
 // operands are supplied the bf16-source loaders are used (half the L2->L1 bytes, no conversion in the kernel).
