@@ -445,10 +445,10 @@ constexpr int LDS_PITCH = 80;             // bytes per 32-k row of bf16 (64) + 1
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // Stages this thread's share of one 128 x 32 operand tile: global fp32 -> registers (load) -> bf16 in LDS (store).
-template <class LD, bool KC = KContig<LD>::v, bool H16 = SrcBf16<LD>::v> struct Stager;
+template <class LD, int BK = 32, bool KC = KContig<LD>::v, bool H16 = SrcBf16<LD>::v> struct Stager;
 
 // K-contiguous operand: two (row, 8-k) items per thread, 4 lanes cover one row's 128 bytes.
-template <class LD> struct Stager<LD, true, false> {
+template <class LD> struct Stager<LD, 32, true, false> {
   int row[2], chunk;
   typename LD::Ctx ctx[2];
   Frag<8> reg[2];
@@ -463,6 +463,7 @@ template <class LD> struct Stager<LD, true, false> {
     for (int i = 0; i < 2; ++i) l.template load<8>(reg[i], ctx[i], k0 + 8 * chunk);
     k0 += 32;
   }
+  __device__ __forceinline__ void skip(const LD&) { k0 += 32; }
   __device__ __forceinline__ void store(unsigned char* tile) const {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -476,7 +477,7 @@ template <class LD> struct Stager<LD, true, false> {
 
 // M/N-contiguous operand: one 4-row x 4-k micro-block per thread, loaded as 4 dwordx4 along the contiguous
 // dimension (32 lanes = 512 contiguous bytes) and transposed in registers into four 8-byte LDS writes.
-template <class LD> struct Stager<LD, false, false> {
+template <class LD> struct Stager<LD, 32, false, false> {
   int row4, k4;
   typename LD::Ctx4 ctx;
   float reg[4][4]; int k0;
@@ -488,6 +489,7 @@ template <class LD> struct Stager<LD, false, false> {
     k4 = (tid & 7) * 4; row4 = (tid >> 3) * 4; ctx = l.row4(base + row4);
   }
   __device__ __forceinline__ void load(const LD& l) { l.load4x4(reg, ctx, k0 + k4); k0 += 32; }
+  __device__ __forceinline__ void skip(const LD&) { k0 += 32; }
   __device__ __forceinline__ void store(unsigned char* tile) const {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -500,29 +502,35 @@ template <class LD> struct Stager<LD, false, false> {
 };
 
 // bf16 source, K-contiguous: two 16-byte items per thread, copied straight into LDS.
-template <class LD> struct Stager<LD, true, true> {
-  int row[2], chunk;
-  typename LD::Ctx ctx[2];
-  uint4 reg[2]; typename LD::Cur cur;
+template <class LD, int BK> struct Stager<LD, BK, true, true> {
+  static constexpr int CPR = BK / 8, NI = BK / 16, PITCH = BK * 2 + 16;      // chunks per row, items per thread, LDS row pitch
+  int row0, chunk;
+  typename LD::Ctx ctx[NI];
+  uint4 reg[NI]; typename LD::Cur cur;
   __device__ __forceinline__ void init(const LD& l, int base, int tid, int, int kbeg) {
-    chunk = tid & 3; cur = l.seek(kbeg);
+    chunk = tid & (CPR - 1); row0 = tid / CPR; cur = l.seek(kbeg);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { row[i] = (tid >> 2) + 64 * i; ctx[i] = l.row(base + row[i]); }
+    for (int i = 0; i < NI; ++i) ctx[i] = l.row(base + row0 + (256 / CPR) * i);
   }
   __device__ __forceinline__ void load(const LD& l) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) reg[i] = l.load8(ctx[i], cur, chunk);
-    l.advance(cur);
+    for (int i = 0; i < NI; ++i) reg[i] = l.load8(ctx[i], cur, chunk);
+#pragma unroll
+    for (int j = 0; j < BK / 32; ++j) l.advance(cur);
+  }
+  __device__ __forceinline__ void skip(const LD& l) {
+#pragma unroll
+    for (int j = 0; j < BK / 32; ++j) l.advance(cur);
   }
   __device__ __forceinline__ void store(unsigned char* tile) const {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(tile + row[i] * LDS_PITCH + chunk * 16) = reg[i];
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(tile + (row0 + (256 / CPR) * i) * PITCH + chunk * 16) = reg[i];
   }
 };
 
 // bf16 source, M/N-contiguous: 128 micro-blocks of 8 rows x 4 k per tile, staged by one half of the workgroup
 // (half 0: threads 0-127, half 1: threads 128-255) -- 4 dwordx4 loads, 16-bit transpose in registers, 8 x 8-byte writes.
-template <class LD> struct Stager<LD, false, true> {
+template <class LD> struct Stager<LD, 32, false, true> {
   int row8, k4; bool active;
   typename LD::Ctx8 ctx;
   uint4 reg[4]; typename LD::Cur cur;
@@ -531,6 +539,7 @@ template <class LD> struct Stager<LD, false, true> {
     k4 = (t & 7) * 4; row8 = (t >> 3) * 8; ctx = l.row8(base + row8); cur = l.seek(ctx, kbeg + k4);      // k-groups fastest: 2-way instead of 16-way write conflicts
   }
   __device__ __forceinline__ void load(const LD& l) { if (active) { l.load8x4(reg, ctx, cur); l.advance(cur); } }
+  __device__ __forceinline__ void skip(const LD& l) { if (active) l.advance(cur); }
   __device__ __forceinline__ void store(unsigned char* tile) const {
     if (!active) return;
     const unsigned* w0 = reinterpret_cast<const unsigned*>(&reg[0]);
@@ -548,17 +557,34 @@ template <class LD> struct Stager<LD, false, true> {
   }
 };
 
-// one 128 x 128 output tile over k in [kbeg, kend)
-template <class AL, class BL, class EP>
+// one 128 x 128 output tile over k in [kbeg, kend); BK = k per LDS tile (64 only for bf16 K-contiguous sources)
+template <int BK, class AL, class BL, class EP>
 __device__ __forceinline__ void lds_tile(const AL& a, const BL& b, const EP& ep, int m_blk, int n_blk, int kbeg, int kend,
-                                         unsigned char (&lds)[2][2][128 * LDS_PITCH]) {
+                                         unsigned char (&lds)[2][2][128 * (BK * 2 + 16)]) {
+  constexpr int PITCH = BK * 2 + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int nk = (kend - kbeg + 31) >> 5;
+  const int nk = (kend - kbeg + BK - 1) / BK;
 
-  Stager<AL> sa; Stager<BL> sb;
-  sa.init(a, m_blk, tid, 0, kbeg); sb.init(b, n_blk, tid, 1, kbeg);
+  // Register prefetch ring: D staging sets, set d holds tiles d, d+D, ...; the loads of tile kt+D are issued while tile kt
+  // is multiplied, so D-1 tiles of global latency stay in flight across the per-tile barrier (bf16 sources only: a
+  // set is 8-16 VGPRs there).  LDS stays double-buffered: tile kt+1 is written while tile kt is read.
+  // Measured (C3, conv layers): D = 2..3 costs a workgroup per CU (188 vs 152 VGPRs -> 2 instead of 3 resident) and
+  // runs 20-50 % SLOWER than D = 1; thread-level parallelism hides the load latency better than a deeper ring here.
+  constexpr int D = 1;
+  Stager<AL, BK> sa[D]; Stager<BL, BK> sb[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    sa[d].init(a, m_blk, tid, 0, kbeg); sb[d].init(b, n_blk, tid, 1, kbeg);
+#pragma unroll
+    for (int j = 0; j < d; ++j) { sa[d].skip(a); sb[d].skip(b); }
+  }
+  auto gload = [&](auto& xa, auto& xb) {
+    xa.load(a); xb.load(b);
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) { xa.skip(a); xb.skip(b); }
+  };
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -568,32 +594,37 @@ __device__ __forceinline__ void lds_tile(const AL& a, const BL& b, const EP& ep,
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  auto gload = [&](int) { sa.load(a); sb.load(b); };      // tiles are visited in order: every stager keeps its own cursor
-  auto lwrite = [&](int buf) { sa.store(&lds[buf][0][0]); sb.store(&lds[buf][1][0]); };
-
-  if (nk > 0) { gload(0); lwrite(0); }
+#pragma unroll
+  for (int d = 0; d < D; ++d) if (d < nk) gload(sa[d], sb[d]);
+  if (nk > 0) { sa[0].store(&lds[0][0][0]); sb[0].store(&lds[0][1][0]); }
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);                      // loads in flight under the MFMAs below
-    const unsigned char* la = &lds[buf][0][(wm * 64 + r) * LDS_PITCH + 16 * h];
-    const unsigned char* lb = &lds[buf][1][(wn * 64 + r) * LDS_PITCH + 16 * h];
+  for (int kt0 = 0; kt0 < nk; kt0 += D) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 af[2], bf[2];
+    for (int d = 0; d < D; ++d) {
+      const int kt = kt0 + d;
+      if (kt < nk) {
+        const int buf = kt & 1;
+        if (kt + D < nk) gload(sa[d], sb[d]);              // set d was copied to LDS one tile ago: free again
+        const unsigned char* la = &lds[buf][0][(wm * 64 + r) * PITCH + 16 * h];
+        const unsigned char* lb = &lds[buf][1][(wn * 64 + r) * PITCH + 16 * h];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8*>(la + i * 32 * LDS_PITCH + 32 * s);
-        bf[i] = *reinterpret_cast<const bf16x8*>(lb + i * 32 * LDS_PITCH + 32 * s);
+        for (int s = 0; s < BK / 16; ++s) {
+          bf16x8 af[2], bf[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            af[i] = *reinterpret_cast<const bf16x8*>(la + i * 32 * PITCH + 32 * s);
+            bf[i] = *reinterpret_cast<const bf16x8*>(lb + i * 32 * PITCH + 32 * s);
+          }
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (kt + 1 < nk) { sa[(d + 1) % D].store(&lds[buf ^ 1][0][0]); sb[(d + 1) % D].store(&lds[buf ^ 1][1][0]); }
+        __syncthreads();
       }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
     }
-    if (kt + 1 < nk) lwrite(buf ^ 1);
-    __syncthreads();
   }
   const int m0 = m_blk + wm * 64, n0 = n_blk + wn * 64;
 #pragma unroll
@@ -609,15 +640,15 @@ __device__ __forceinline__ void lds_tile(const AL& a, const BL& b, const EP& ep,
     }
 }
 
-template <class AL, class BL, class EP>
+template <class AL, class BL, class EP, int BK = 32>
 __global__ __launch_bounds__(256) void gemm_lds_bf16_kernel(AL a, BL b, EP ep, int K, int kper, int gx, int gy) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][128 * LDS_PITCH];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][128 * (BK * 2 + 16)];
   // XCD-aware renumbering (bijective form): consecutive renumbered ids share an XCD (ids are dealt round-robin to 8 XCDs)
   const int nwg = gx * gy, orig = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
   const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   const int kbeg = blockIdx.z * kper;
-  lds_tile(a, b, ep, (bid / gx) * 128, (bid % gx) * 128, kbeg, min(K, kbeg + kper), lds);
+  lds_tile<BK>(a, b, ep, (bid / gx) * 128, (bid % gx) * 128, kbeg, min(K, kbeg + kper), lds);
 }
 
 // Grouped form: up to 8 independent contractions of the same operand kinds in ONE launch (the hoisted weight gradients
@@ -635,7 +666,7 @@ __global__ __launch_bounds__(256) void gemm_lds_grouped_kernel(GroupArgs<AL, BL,
   const int local = blockIdx.x - P.first;                   // tile-major, then k slice
   const int tile = local / P.ksplit, z = local - tile * P.ksplit;
   const int kbeg = z * P.kper;
-  lds_tile(P.a, P.b, P.ep, (tile / P.gx) * 128, (tile % P.gx) * 128, kbeg, min(P.K, kbeg + P.kper), lds);
+  lds_tile<32>(P.a, P.b, P.ep, (tile / P.gx) * 128, (tile % P.gx) * 128, kbeg, min(P.K, kbeg + P.kper), lds);
 }
 
 // ---------------------------------------------------------------------------

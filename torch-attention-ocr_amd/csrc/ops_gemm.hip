@@ -19,6 +19,13 @@ static void launch_lds(hipStream_t s, const AL& a, const BL& b, const EP& ep, in
   const int gx = cdiv(N, 128), gy = cdiv(M, 128);
   hipLaunchKernelGGL((gemm_lds_bf16_kernel<AL, BL, EP>), dim3(gx * gy, 1, ksplit), dim3(256), 0, s, a, b, ep, K, kper, gx, gy);
 }
+// BK = 64 variant for bf16 K-contiguous operand pairs (conv forward / data gradient): half the barriers per FLOP
+template <class AL, class BL, class EP>
+[[maybe_unused]] static void launch_lds64(hipStream_t s, const AL& a, const BL& b, const EP& ep, int M, int N, int K) {
+  if (M <= 0 || N <= 0) return;
+  const int gx = cdiv(N, 128), gy = cdiv(M, 128);
+  hipLaunchKernelGGL((gemm_lds_bf16_kernel<AL, BL, EP, 64>), dim3(gx * gy, 1, 1), dim3(256), 0, s, a, b, ep, K, cdiv(K, 64) * 64, gx, gy);
+}
 template <class AL, class BL, class EP>
 static void launch_big(hipStream_t s, bool bf16, const AL& a, const BL& b, const EP& ep, int M, int N, int K, int ksplit) {
   if (M <= 0 || N <= 0) return;
@@ -158,7 +165,7 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
   if (bf16 && xb && wb) {
     LoadConvKh ah; ah.src = xb; ah.g = a;
     LoadKh bh; bh.p = wb; bh.ld = a.K; bh.rows = Cout; bh.K = a.K;
-    launch_lds(s, ah, bh, ep, a.rows, Cout, a.K, 1);
+    launch_lds(s, ah, bh, ep, a.rows, Cout, a.K, 1);       // (BK = 64 variant measured no faster: launch_lds64)
   } else {
     launch_conv_fwd(s, bf16, a, make_loadk(w, a.K, Cout, a.K), ep, a.rows, Cout, a.K);
   }
