@@ -641,7 +641,8 @@ __device__ __forceinline__ void lds_tile(const AL& a, const BL& b, const EP& ep,
 }
 
 template <class AL, class BL, class EP, int BK = 32>
-__global__ __launch_bounds__(256) void gemm_lds_bf16_kernel(AL a, BL b, EP ep, int K, int kper, int gx, int gy) {
+__global__ __launch_bounds__(256, (SrcBf16<AL>::v && SrcBf16<BL>::v) ? 4 : 1)      // bf16-source pairs fit 128 VGPRs: 4 workgroups per CU
+void gemm_lds_bf16_kernel(AL a, BL b, EP ep, int K, int kper, int gx, int gy) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][128 * (BK * 2 + 16)];
   // XCD-aware renumbering (bijective form): consecutive renumbered ids share an XCD (ids are dealt round-robin to 8 XCDs)
   const int nwg = gx * gy, orig = blockIdx.x;
