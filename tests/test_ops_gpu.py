@@ -149,7 +149,7 @@ def test_batchnorm_relu(cuda, rows, C, tb):
     y = F.relu(F.batch_norm(x, rm, rv, w, b, training=True, momentum=0.1, eps=1e-5))
     xd = dev(x.detach()); yd = torch.zeros(rows, C, device="cuda")
     rmd = torch.zeros(C, device="cuda"); rvd = torch.ones(C, device="cuda")
-    save = torch.zeros(2 * C, device="cuda"); scratch = torch.zeros(4 << 20, dtype=torch.uint8, device="cuda")
+    save = torch.zeros(2 * C, device="cuda"); scratch = torch.zeros(8 << 20, dtype=torch.uint8, device="cuda")
     a.check(a.lib.aocr_batchnorm_relu_forward(stream(), a.ptr(xd), a.ptr(yd), a.ptr(dev(w.detach())), a.ptr(dev(b.detach())), a.ptr(rmd),
                                               a.ptr(rvd), a.ptr(save), a.ptr(scratch), rows, C, 1, 1, tb))
     yref = y.detach()

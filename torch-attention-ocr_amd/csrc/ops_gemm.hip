@@ -97,10 +97,10 @@ void launch_small_gates_bwd_h(hipStream_t s, int nz, const GatesBwdArgsH* z, int
 
 // number of K slices for an atomically accumulated contraction: fill ONE round of resident workgroups (256 CUs x 3 per CU)
 // without spilling into a mostly empty second round
-static int pick_ksplit(int M, int N, int K, bool bf16) {
+static int pick_ksplit(int M, int N, int K, bool bf16, int slots = 768) {
   int64_t tiles = (int64_t)cdiv(M, 128) * cdiv(N, 128);
   int chunk = bf16 ? 32 : 8;
-  int ks = (int)(768 / tiles);
+  int ks = (int)(slots / tiles);
   int maxks = K / (chunk * 8); if (maxks < 1) maxks = 1;
   if (ks > maxks) ks = maxks;
   if (ks < 1) ks = 1;
@@ -192,7 +192,7 @@ void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float*
   const int P = B * Ho * Wo, N = ks * ks * Cin;
   LoadConvXcol b; b.x = x; b.H = H; b.W = W; b.Cin = Cin; b.KW = ks; b.pad = pad; b.Ho = Ho; b.Wo = Wo; b.N = N; b.K = P;
   EpStore ep = make_store(dw, N, Cout, N, nullptr, nullptr, EP_ATOMIC);
-  const int ksplit = pick_ksplit(Cout, N, P, bf16);
+  const int ksplit = pick_ksplit(Cout, N, P, bf16, (bf16 && xb && dyb) ? 1024 : 768);   // bf16-source kernel: 4 workgroups per CU
   if (bf16 && xb && dyb) {
     LoadMNh ah; ah.p = dyb; ah.ld = Cout; ah.rows = Cout; ah.K = P;
     LoadConvXcolh bh; bh.x = xb; bh.g = b;

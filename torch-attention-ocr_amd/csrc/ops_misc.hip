@@ -237,7 +237,7 @@ void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pool
 // BatchNorm (+ReLU).  Statistics are accumulated in fp64 (Torch7 accumulates in accreal=double [upstream]).
 // scratch layout: double part[BN_CHUNKS][C][2], then double fin[C][2].
 // =============================================================================================
-static const int BN_CHUNKS = 128;
+static const int BN_CHUNKS = 512;
 size_t bn_scratch_bytes(int C) { return (size_t)(BN_CHUNKS + 1) * C * 2 * sizeof(double); }
 
 // mode 0: (sum x, sum x^2);  mode 1: (sum dy, sum dy*xhat) with dy = dA*(y>0), xhat = (x-mean)*invstd
@@ -254,7 +254,16 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   if (c < C) {
     float mean = 0.f, inv = 0.f;
     if (mode == 1) { mean = save[c]; inv = save[C + c]; }
-    for (int64_t r = r0 + rl; r < r1; r += 4) {
+    int64_t r = r0 + rl;
+    if (mode == 0) {
+      double t0 = 0.0, t1 = 0.0;
+      for (; r + 4 < r1; r += 8) {                              // two independent rows per iteration
+        float xa = x[r * C + c], xb2 = x[(r + 4) * C + c];
+        s0 += (double)xa; s1 += (double)xa * (double)xa; t0 += (double)xb2; t1 += (double)xb2 * (double)xb2;
+      }
+      s0 += t0; s1 += t1;
+    }
+    for (; r < r1; r += 4) {
       float xv = x[r * C + c];
       if (mode == 0) { s0 += (double)xv; s1 += (double)xv * (double)xv; }
       else {
@@ -275,12 +284,27 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-__global__ void bn_fwd_finalize_kernel(const double* __restrict__ part, int nchunk, int64_t rows, int C, float* save,
-                                       float* rm, float* rv, int update_running) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0, ss = 0;
-  for (int k = 0; k < nchunk; ++k) { s += part[((int64_t)k * C + c) * 2]; ss += part[((int64_t)k * C + c) * 2 + 1]; }
+// sums the per-chunk partials of 16 channels with 256 threads (16 k-slices per channel, LDS tree): returns the totals to the
+// 16 threads with kslice == 0
+__device__ __forceinline__ bool bn_reduce_partials(const double* __restrict__ part, int nchunk, int C, int& c, double& s, double& ss) {
+  __shared__ double sh[2][16][17];
+  const int cl = threadIdx.x & 15, ks = threadIdx.x >> 4;
+  c = blockIdx.x * 16 + cl;
+  double a = 0, b = 0;
+  if (c < C)
+    for (int k = ks; k < nchunk; k += 16) { a += part[((int64_t)k * C + c) * 2]; b += part[((int64_t)k * C + c) * 2 + 1]; }
+  sh[0][ks][cl] = a; sh[1][ks][cl] = b;
+  __syncthreads();
+  if (ks != 0 || c >= C) return false;
+  s = 0; ss = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { s += sh[0][k][cl]; ss += sh[1][k][cl]; }
+  return true;
+}
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const double* __restrict__ part, int nchunk, int64_t rows, int C, float* save,
+                                                              float* rm, float* rv, int update_running) {
+  int c; double s, ss;
+  if (!bn_reduce_partials(part, nchunk, C, c, s, ss)) return;
   double n = (double)rows, mean = s / n, var = ss / n - mean * mean;
   if (var < 0) var = 0;
   save[c] = (float)mean; save[C + c] = (float)(1.0 / sqrt(var + 1e-5));
@@ -314,12 +338,10 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restr
     if (yb) { bf16x4 hb; hb[0] = (bf16_t)o.x; hb[1] = (bf16_t)o.y; hb[2] = (bf16_t)o.z; hb[3] = (bf16_t)o.w; *reinterpret_cast<bf16x4*>(yb + ro * C + c) = hb; }
   }
 }
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nchunk, int64_t rows, int C, const float* save,
-                                       double* fin, float* dw, float* db) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0, ss = 0;
-  for (int k = 0; k < nchunk; ++k) { s += part[((int64_t)k * C + c) * 2]; ss += part[((int64_t)k * C + c) * 2 + 1]; }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nchunk, int64_t rows, int C,
+                                                              const float* save, double* fin, float* dw, float* db) {
+  int c; double s, ss;
+  if (!bn_reduce_partials(part, nchunk, C, c, s, ss)) return;
   fin[c * 2] = s / (double)rows; fin[c * 2 + 1] = ss / (double)rows;
   dw[c] += (float)ss; db[c] += (float)s;                        // gradWeight = sum dy*xhat, gradBias = sum dy
 }
@@ -350,7 +372,7 @@ void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, co
     int nchunk = (int)std::min<int64_t>(BN_CHUNKS, (rows + 63) / 64);
     hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, x, nullptr, nullptr, nullptr, part, rows,
                        C, 0, 0, 0);
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, part, nchunk, rows, C, save, rm, rv,
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, part, nchunk, rows, C, save, rm, rv,
                        update_running);
   } else {
     hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, rm, rv, save, C);
@@ -366,7 +388,7 @@ void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float
   double* fin = part + (size_t)BN_CHUNKS * C * 2;
   int nchunk = (int)std::min<int64_t>(BN_CHUNKS, (rows + 63) / 64);
   hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, x, y, dA, save, part, rows, C, 1, tb_rows, T);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, part, nchunk, rows, C, save, fin, dw, db);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, part, nchunk, rows, C, save, fin, dw, db);
   int64_t total = rows * C;
   int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb);
