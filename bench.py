@@ -37,12 +37,10 @@ def flops_per_image(W, He, Le, Ld, L, E=20, V=39):
     return cnn + enc + dec
 
 
-def cpu_baseline(wl, seconds_budget=25.0):
-    """The oracle (torch CPU restatement, fp32, all host cores) timed on a bounded sample of the same workload."""
+def _cpu_baseline_worker(wl, threads, seconds_budget):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_torch as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     cfg = O.OcrConfig(enc_hidden=wl["He"], enc_layers=wl["Le"], dec_layers=wl["Ld"], input_feed=True)
     P = {k: v.float() for k, v in O.init_params(cfg, 910820).items()}
     st = {k: v.float() for k, v in O.init_bn_state().items()}
@@ -57,8 +55,27 @@ def cpu_baseline(wl, seconds_budget=25.0):
         el = time.time() - t0
         if el > seconds_budget or n >= 8:
             break
-    return {"value": Bc * n / el, "unit": "image-lines/s", "cores": cores, "kind": "port",
-            "sample": f"{n} train steps of batch {Bc} at 32x{wl['W']} (torch-CPU fp32 restatement, {cores} threads)"}
+    print(json.dumps({"value": Bc * n / el, "unit": "image-lines/s", "cores": threads, "kind": "port",
+                      "sample": f"{n} train steps of batch {Bc} at 32x{wl['W']} (torch-CPU fp32 restatement of the reference op order, "
+                                f"{threads} threads of {os.cpu_count()} host cores)"}))
+
+
+def cpu_baseline(wl, seconds_budget=20.0):
+    """The oracle (torch CPU restatement, fp32) timed on a bounded sample of the same workload, in a child process
+    with a hard timeout so the default run always ends within minutes.  16 threads: the per-timestep LSTM ops are
+    tiny and slow down badly when a 256-core host is oversubscribed."""
+    import subprocess
+    threads = min(16, os.cpu_count() or 1)
+    code = ("import json,sys; sys.argv=['bench.py']; import importlib.util as u; s=u.spec_from_file_location('bench', %r); "
+            "b=u.module_from_spec(s); s.loader.exec_module(b); b._cpu_baseline_worker(json.loads(%r), %d, %f)"
+            % (os.path.join(ROOT, "bench.py"), json.dumps(wl), threads, seconds_budget))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180, env=env)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:                                   # timeout or failure: report it, never stall the benchmark
+        return {"value": None, "unit": "image-lines/s", "cores": threads, "kind": "port", "sample": f"not measured: {type(e).__name__}"}
 
 
 def main():
