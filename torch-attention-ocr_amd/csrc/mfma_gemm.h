@@ -393,6 +393,11 @@ struct LoadConvXcolh {
     c.k += 32; c.px += 32;
     while (c.px >= g.Wo) { c.px -= g.Wo; if (++c.py == g.Ho) { c.py = 0; ++c.b; } }
   }
+  __device__ __forceinline__ uint4 load8(const Ctx8& c, const Cur& u) const {        // 8 channels of ONE pixel
+    int sy = u.py + c.dy, sx = u.px + c.dx;
+    bool ok = c.ok && u.k < g.K && (unsigned)sy < (unsigned)g.H && (unsigned)sx < (unsigned)g.W;
+    return ok ? *reinterpret_cast<const uint4*>(x + (((int64_t)u.b * g.H + sy) * g.W + sx) * g.Cin + c.ci) : make_uint4(0, 0, 0, 0);
+  }
   __device__ __forceinline__ void load8x4(uint4 (&v)[4], const Ctx8& c, const Cur& u) const {
     int px = u.px, py = u.py, b = u.b;
 #pragma unroll
@@ -650,6 +655,108 @@ void gemm_lds_bf16_kernel(AL a, BL b, EP ep, int K, int kper, int gx, int gy) {
   const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   const int kbeg = blockIdx.z * kper;
   lds_tile<BK>(a, b, ep, (bid / gx) * 128, (bid % gx) * 128, kbeg, min(K, kbeg + kper), lds);
+}
+
+// ---------------------------------------------------------------------------
+// Filter-gradient kernel with hardware-transposed LDS reads.
+// Both operands of dW = dY^T . Xcol are contiguous along M/N (channels) and strided along K (pixels).  Instead of
+// transposing 8x4 micro-blocks in registers, the tiles are copied into LDS as they are -- [32 k][128 channels] bf16, one
+// 16-byte piece per lane, 16 lanes = 256 contiguous bytes of one pixel row -- and the MFMA fragments (8 consecutive k
+// of one channel) are gathered with ds_read_b64_tr_b16: per group of 16 lanes it reads a 4(k) x 16(channel) block and
+// hands lane i the 4 k-values of channel i (probed on gfx950, tools/ubench/tr_probe.hip).  320-byte pitch: the 4 rows a
+// 32-lane half touches start 16 dwords apart -> conflict-free.
+// ---------------------------------------------------------------------------
+constexpr int TR_PITCH = 320;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 lds_tr_read(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+}
+
+template <class EP>
+__global__ __launch_bounds__(256, 4) void conv_wgrad_tr_kernel(LoadMNh a, LoadConvXcolh b, EP ep, int K, int kper, int gx, int gy) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][32 * TR_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int nwg = gx * gy, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int m_blk = (bid / gx) * 128, n_blk = (bid % gx) * 128;
+  const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
+  const int nk = (kend - kbeg + 31) >> 5;
+
+  // staging: thread -> k rows (tid>>4) and (tid>>4)+16, 16-byte piece (tid&15) = 8 channels
+  const int krow = tid >> 4, piece = tid & 15;
+  LoadMNh::Ctx8 ca = a.row8(m_blk + piece * 8);
+  LoadConvXcolh::Ctx8 cb = b.row8(n_blk + piece * 8);
+  LoadConvXcolh::Cur cur0 = b.seek(cb, kbeg + krow), cur1 = b.seek(cb, kbeg + krow + 16);
+  int ka = kbeg + krow;
+  uint4 ra[2], rb[2];
+  auto gload = [&]() {
+    ra[0] = (ca.ok && ka < a.K) ? *reinterpret_cast<const uint4*>(ca.b + (int64_t)ka * a.ld) : make_uint4(0, 0, 0, 0);
+    ra[1] = (ca.ok && ka + 16 < a.K) ? *reinterpret_cast<const uint4*>(ca.b + (int64_t)(ka + 16) * a.ld) : make_uint4(0, 0, 0, 0);
+    rb[0] = b.load8(cb, cur0); rb[1] = b.load8(cb, cur1);
+    ka += 32; b.advance(cur0); b.advance(cur1);
+  };
+  auto lwrite = [&](int buf) {
+    *reinterpret_cast<uint4*>(&lds[buf][0][krow * TR_PITCH + piece * 16]) = ra[0];
+    *reinterpret_cast<uint4*>(&lds[buf][0][(krow + 16) * TR_PITCH + piece * 16]) = ra[1];
+    *reinterpret_cast<uint4*>(&lds[buf][1][krow * TR_PITCH + piece * 16]) = rb[0];
+    *reinterpret_cast<uint4*>(&lds[buf][1][(krow + 16) * TR_PITCH + piece * 16]) = rb[1];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // transposed-read addressing: lane = 16g + 4q + p supplies row (.. + q), columns 16*(g&1) + 4p .. +3 of its 32-channel tile
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int tr_off = (8 * h + q) * TR_PITCH + (16 * (g & 1) + 4 * p) * 2;
+
+  if (nk > 0) { gload(); lwrite(0); }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload();
+    const unsigned char* la = &lds[buf][0][tr_off + (wm * 64) * 2];
+    const unsigned char* lb = &lds[buf][1][tr_off + (wn * 64) * 2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        s16x4 a0 = lds_tr_read(la + (16 * s) * TR_PITCH + i * 64), a1 = lds_tr_read(la + (16 * s + 4) * TR_PITCH + i * 64);
+        s16x4 b0 = lds_tr_read(lb + (16 * s) * TR_PITCH + i * 64), b1 = lds_tr_read(lb + (16 * s + 4) * TR_PITCH + i * 64);
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        af[i] = __builtin_bit_cast(bf16x8, av); bf[i] = __builtin_bit_cast(bf16x8, bv);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lwrite(buf ^ 1);
+    __syncthreads();
+  }
+  const int r = lane & 31;
+  const int m0 = m_blk + wm * 64, n0 = n_blk + wn * 64;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      float v[2][4];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * qq + i];
+      ep.template quad<2>(m0 + 32 * mi + 8 * qq + 4 * h, n0 + r, 32, v);
+    }
 }
 
 // Grouped form: up to 8 independent contractions of the same operand kinds in ONE launch (the hoisted weight gradients

@@ -196,7 +196,9 @@ void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float*
   if (bf16 && xb && dyb) {
     LoadMNh ah; ah.p = dyb; ah.ld = Cout; ah.rows = Cout; ah.K = P;
     LoadConvXcolh bh; bh.x = xb; bh.g = b;
-    launch_lds(s, ah, bh, ep, Cout, N, P, ksplit);
+    int ks = ksplit, kper; split_k(P, 32, ks, kper);
+    const int gx = cdiv(N, 128), gy = cdiv(Cout, 128);
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<EpStore>), dim3(gx * gy, 1, ks), dim3(256), 0, s, ah, bh, ep, P, kper, gx, gy);
   } else {
     launch_conv_wgrad(s, bf16, make_loadmn(dy, Cout, Cout, P), b, ep, Cout, N, P, ksplit);
   }
