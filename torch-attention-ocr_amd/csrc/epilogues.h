@@ -8,7 +8,17 @@ namespace aocr {
 
 enum : int { EP_RELU = 1, EP_TANH = 2, EP_ACCUM = 4, EP_ATOMIC = 8 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// Gate activations on the hardware transcendental unit (v_exp_f32 / v_rcp_f32, ~1-2 ulp): the library expf/tanhf cost
+// hundreds of VALU instructions per hidden unit and made the gate epilogue -- not the MFMAs -- the longest part of a
+// recurrent step.  Absolute error ~1e-7, two orders below the 1e-4 logit tolerance.
+__device__ __forceinline__ float fast_exp_(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + fast_exp_(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  const float ax = fminf(fabsf(x), 15.f);                     // tanh saturates to 1 - 2e-13 by |x| = 15; avoids inf/inf
+  const float e = fast_exp_(2.f * ax);
+  const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+  return copysignf(t, x);
+}
 
 // C[m][n] = act(v + bias[n] + bias2[n]); columns >= N0 go to a second destination (C1, column n-N0).
 struct EpStore {
@@ -16,6 +26,7 @@ struct EpStore {
   const float* bias; const float* bias2;
   int flags;
   float* C1; int64_t ldc1; int N0;       // optional split of the N range (C1 == nullptr: unused)
+  bf16_t* Cb = nullptr; int64_t ldcb = 0; // optional bf16 shadow of C (plain stores only)
   template <int NT> __device__ __forceinline__ void quad(int m, int n, int nstep, const float (&v)[NT][4]) const {
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
@@ -32,12 +43,33 @@ struct EpStore {
         if (row >= M) continue;
         float x = v[ni][i] + bb;
         if (flags & EP_RELU) x = fmaxf(x, 0.f);
-        if (flags & EP_TANH) x = tanhf(x);
+        if (flags & EP_TANH) x = tanhf_(x);
         float* p = base + (int64_t)row * ld + cc;
         if (flags & EP_ATOMIC) atomicAdd(p, x);
         else if (flags & EP_ACCUM) *p += x;
-        else *p = x;
+        else { *p = x; if (Cb && base == C) Cb[(int64_t)row * ldcb + cc] = (bf16_t)x; }
       }
+    }
+  }
+  // single-element form used by the recurrent-step kernel; prefetch() is issued BEFORE the K loop so that the
+  // epilogue's own operand loads overlap it instead of adding a second memory round trip after it
+  struct Pre {};
+  __device__ __forceinline__ Pre prefetch(int, int) const { return Pre{}; }
+  template <int NT> __device__ __forceinline__ void elem(int row, int n, int nstep, const float (&v)[NT], const Pre&) const {
+    if (row >= M) return;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      int col = n + nstep * ni;
+      if (col >= N) continue;
+      float x = v[ni];
+      if (bias) x += bias[col];
+      if (bias2) x += bias2[col];
+      if (flags & EP_RELU) x = fmaxf(x, 0.f);
+      if (flags & EP_TANH) x = tanhf_(x);
+      float* p = (C1 && col >= N0) ? C1 + (int64_t)row * ldc1 + (col - N0) : C + (int64_t)row * ldc + col;
+      if (flags & EP_ATOMIC) atomicAdd(p, x);
+      else if (flags & EP_ACCUM) *p += x;
+      else { *p = x; if (Cb && !(C1 && col >= N0)) Cb[(int64_t)row * ldcb + col] = (bf16_t)x; }
     }
   }
 };
@@ -94,6 +126,8 @@ struct EpGatesFwd {
   float* h_out2; int64_t ldh2;            // optional second copy of h (context slice / attention concat)
   float* gates; int64_t ldg;              // optional, post-activation [m][g*H+j]
   int M, H;
+  bf16_t* hb = nullptr; int64_t ldhb = 0;   // optional bf16 shadows of h_out / h_out2 (operands of the next contractions)
+  bf16_t* hb2 = nullptr; int64_t ldhb2 = 0;
   template <int NT> __device__ __forceinline__ void quad(int m, int j, int, const float (&v)[NT][4]) const {
     static_assert(NT == 4, "gate epilogue needs the 4 gate tiles");
     if (j >= H) return;
@@ -112,16 +146,51 @@ struct EpGatesFwd {
         z[g] = v[g][i] + bb[g];
         if (zx) z[g] += zx[(int64_t)row * ldzx + g * H + j];
       }
-      float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), og = sigmoidf_(z[2]), gg = tanhf(z[3]);
+      float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), og = sigmoidf_(z[2]), gg = tanhf_(z[3]);
       float c = fg * c_prev[(int64_t)row * ldcp + j] + ig * gg;
-      float hh = og * tanhf(c);
+      float hh = og * tanhf_(c);
       c_out[(int64_t)row * ldc + j] = c;
       h_out[(int64_t)row * ldh + j] = hh;
       if (h_out2) h_out2[(int64_t)row * ldh2 + j] = hh;
+      if (hb) hb[(int64_t)row * ldhb + j] = (bf16_t)hh;
+      if (hb2) hb2[(int64_t)row * ldhb2 + j] = (bf16_t)hh;
       if (gates) {
         float* gp = gates + (int64_t)row * ldg + j;
         gp[0] = ig; gp[H] = fg; gp[2 * H] = og; gp[3 * H] = gg;
       }
+    }
+  }
+  struct Pre { float zin[4]; float cp; };
+  __device__ __forceinline__ Pre prefetch(int row, int j) const {
+    Pre p; p.cp = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) p.zin[g] = 0.f;
+    if (j >= H || row >= M) return p;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (b1) p.zin[g] = b1[g * H + j] + b2[g * H + j];
+      if (zx) p.zin[g] += zx[(int64_t)row * ldzx + g * H + j];
+    }
+    p.cp = c_prev[(int64_t)row * ldcp + j];
+    return p;
+  }
+  template <int NT> __device__ __forceinline__ void elem(int row, int j, int, const float (&v)[NT], const Pre& pre) const {
+    static_assert(NT == 4, "gate epilogue needs the 4 gate tiles");
+    if (j >= H || row >= M) return;
+    float z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) z[g] = v[g] + pre.zin[g];
+    float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), og = sigmoidf_(z[2]), gg = tanhf_(z[3]);
+    float c = fg * pre.cp + ig * gg;
+    float hh = og * tanhf_(c);
+    c_out[(int64_t)row * ldc + j] = c;
+    h_out[(int64_t)row * ldh + j] = hh;
+    if (h_out2) h_out2[(int64_t)row * ldh2 + j] = hh;
+    if (hb) hb[(int64_t)row * ldhb + j] = (bf16_t)hh;
+    if (hb2) hb2[(int64_t)row * ldhb2 + j] = (bf16_t)hh;
+    if (gates) {
+      float* gp = gates + (int64_t)row * ldg + j;
+      gp[0] = ig; gp[H] = fg; gp[2 * H] = og; gp[3 * H] = gg;
     }
   }
 };
@@ -137,6 +206,7 @@ struct EpGatesBwd {
   float* dz; int64_t lddz;                // [m][g*H+j]
   float* dc_out; int64_t lddco;           // d(c_prev)
   int M, H;
+  bf16_t* dzb = nullptr; int64_t lddzb = 0; // optional bf16 shadow of dz
   template <int NT> __device__ __forceinline__ void quad(int m, int j, int, const float (&v)[NT][4]) const {
     static_assert(NT == 1, "gate backward epilogue is single-tile");
     if (j >= H) return;
@@ -149,18 +219,50 @@ struct EpGatesBwd {
       if (dh2) dh += dh2[(int64_t)row * ld2 + j];
       const float* gp = gates + (int64_t)row * ldg + j;
       float ig = gp[0], fg = gp[H], og = gp[2 * H], gg = gp[3 * H];
-      float tc = tanhf(c[(int64_t)row * ldcc + j]);
+      float tc = tanhf_(c[(int64_t)row * ldcc + j]);
       float dc = dh * og * (1.f - tc * tc);
       if (dc_in) dc += dc_in[(int64_t)row * lddc + j];
       float d_o = dh * tc;
       float di = dc * gg, dg = dc * ig, df = dc * c_prev[(int64_t)row * ldcp + j];
       float* zp = dz + (int64_t)row * lddz + j;
-      zp[0] = di * ig * (1.f - ig);
-      zp[H] = df * fg * (1.f - fg);
-      zp[2 * H] = d_o * og * (1.f - og);
-      zp[3 * H] = dg * (1.f - gg * gg);
+      const float z0 = di * ig * (1.f - ig), z1 = df * fg * (1.f - fg), z2 = d_o * og * (1.f - og), z3 = dg * (1.f - gg * gg);
+      zp[0] = z0; zp[H] = z1; zp[2 * H] = z2; zp[3 * H] = z3;
+      if (dzb) {
+        bf16_t* zb = dzb + (int64_t)row * lddzb + j;
+        zb[0] = (bf16_t)z0; zb[H] = (bf16_t)z1; zb[2 * H] = (bf16_t)z2; zb[3 * H] = (bf16_t)z3;
+      }
       dc_out[(int64_t)row * lddco + j] = dc * fg;
     }
+  }
+  struct Pre { float dh, dc, ig, fg, og, gg, c, cp; };
+  __device__ __forceinline__ Pre prefetch(int row, int j) const {
+    Pre p; p.dh = p.dc = p.ig = p.fg = p.og = p.gg = p.c = p.cp = 0.f;
+    if (j >= H || row >= M) return p;
+    if (dh1) p.dh = dh1[(int64_t)row * ld1 + j];
+    if (dh2) p.dh += dh2[(int64_t)row * ld2 + j];
+    if (dc_in) p.dc = dc_in[(int64_t)row * lddc + j];
+    const float* gp = gates + (int64_t)row * ldg + j;
+    p.ig = gp[0]; p.fg = gp[H]; p.og = gp[2 * H]; p.gg = gp[3 * H];
+    p.c = c[(int64_t)row * ldcc + j]; p.cp = c_prev[(int64_t)row * ldcp + j];
+    return p;
+  }
+  template <int NT> __device__ __forceinline__ void elem(int row, int j, int, const float (&v)[NT], const Pre& pre) const {
+    static_assert(NT == 1, "gate backward epilogue is single-tile");
+    if (j >= H || row >= M) return;
+    float dh = v[0] + pre.dh;
+    float ig = pre.ig, fg = pre.fg, og = pre.og, gg = pre.gg;
+    float tc = tanhf_(pre.c);
+    float dc = dh * og * (1.f - tc * tc) + pre.dc;
+    float d_o = dh * tc;
+    float di = dc * gg, dg = dc * ig, df = dc * pre.cp;
+    const float z0 = di * ig * (1.f - ig), z1 = df * fg * (1.f - fg), z2 = d_o * og * (1.f - og), z3 = dg * (1.f - gg * gg);
+    float* zp = dz + (int64_t)row * lddz + j;
+    zp[0] = z0; zp[H] = z1; zp[2 * H] = z2; zp[3 * H] = z3;
+    if (dzb) {
+      bf16_t* zb = dzb + (int64_t)row * lddzb + j;
+      zb[0] = (bf16_t)z0; zb[H] = (bf16_t)z1; zb[2 * H] = (bf16_t)z2; zb[3 * H] = (bf16_t)z3;
+    }
+    dc_out[(int64_t)row * lddco + j] = dc * fg;
   }
 };
 

@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace aocr {
 
@@ -444,6 +445,7 @@ template <> struct SrcBf16<LoadKh> { static constexpr bool v = true; };
 template <> struct SrcBf16<LoadConvKh> { static constexpr bool v = true; };
 template <> struct SrcBf16<LoadMNh> { static constexpr bool v = true; };
 template <> struct SrcBf16<LoadConvXcolh> { static constexpr bool v = true; };
+template <> struct SrcBf16<LoadKh2> { static constexpr bool v = true; };
 
 constexpr int LDS_PITCH = 80;             // bytes per 32-k row of bf16 (64) + 16 pad
 
@@ -881,17 +883,13 @@ constexpr int STEP_PITCH = 144;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int NT> constexpr int step_lds_bytes() { return 4 * (1 + NT) * 32 * STEP_PITCH; }
 
-// global -> registers for one 64-deep chunk (kept as free functions with flat, statically indexed arrays: arrays
-// captured by reference in lambdas were demoted to LDS / scratch by the compiler)
+// global -> registers for one 64-deep chunk (kept as free functions with flat, statically indexed arrays of native
+// vector types: arrays captured by reference in lambdas / HIP's uint4 struct were demoted to LDS or scratch)
 template <int NT, bool GATES>
-__device__ __forceinline__ void step_gload(const LoadK& a, const LoadKh2& b, int kc, const int (&arow)[8], int brow0, int gate_stride,
-                                           int ap, int bp, float4 (&ra)[8], u32x4 (&rb)[NT * 4]) {
-  const bool s1 = kc >= a.K0;
-  const float* pa = s1 ? a.p1 : a.p0; const int64_t lda = s1 ? a.ld1 : a.ld0;
+__device__ __forceinline__ void step_gload_b(const LoadKh2& b, int kc, int K0, int brow0, int gate_stride, int bp, u32x4 (&rb)[NT * 4]) {
+  const bool s1 = kc >= K0;
   const bf16_t* pb = s1 ? b.p1 : b.p0; const int64_t ldb = s1 ? b.ld1 : b.ld0;
-  const int kk = s1 ? kc - a.K0 : kc;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ra[i] = *reinterpret_cast<const float4*>(pa + (int64_t)arow[i] * lda + kk + 4 * ap);
+  const int kk = s1 ? kc - K0 : kc;
 #pragma unroll
   for (int t = 0; t < NT * 4; ++t) {
     const int ni = t >> 2, i = t & 3;
@@ -899,23 +897,46 @@ __device__ __forceinline__ void step_gload(const LoadK& a, const LoadKh2& b, int
     rb[t] = *reinterpret_cast<const u32x4*>(pb + (int64_t)row * ldb + kk + 8 * bp);
   }
 }
-template <int NT>
-__device__ __forceinline__ void step_lwrite(unsigned char* la, unsigned char* lb, int ar, int ap, int br, int bp,
-                                            const float4 (&ra)[8], const u32x4 (&rb)[NT * 4]) {
+// A from fp32 (8 x dwordx4: 4 rows x 256 B per instruction) ...
+__device__ __forceinline__ void step_gload_a(const LoadK& a, int kc, const int (&arow)[8], int ap, float4 (&ra)[8]) {
+  const bool s1 = kc >= a.K0;
+  const float* pa = s1 ? a.p1 : a.p0; const int64_t lda = s1 ? a.ld1 : a.ld0;
+  const int kk = s1 ? kc - a.K0 : kc;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ra[i] = *reinterpret_cast<const float4*>(pa + (int64_t)arow[i] * lda + kk + 4 * ap);
+}
+// ... or from its bf16 shadow (4 x dwordx4: 8 rows x 128 B per instruction)
+__device__ __forceinline__ void step_gload_a(const LoadKh2& a, int kc, const int (&arow)[4], int bp, u32x4 (&ra)[4]) {
+  const bool s1 = kc >= a.K0;
+  const bf16_t* pa = s1 ? a.p1 : a.p0; const int64_t lda = s1 ? a.ld1 : a.ld0;
+  const int kk = s1 ? kc - a.K0 : kc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u32x4*>(pa + (int64_t)arow[i] * lda + kk + 8 * bp);
+}
+__device__ __forceinline__ void step_lwrite_a(unsigned char* la, int ar, int ap, const float4 (&ra)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     bf16x4 v; v[0] = (bf16_t)ra[i].x; v[1] = (bf16_t)ra[i].y; v[2] = (bf16_t)ra[i].z; v[3] = (bf16_t)ra[i].w;
     *reinterpret_cast<bf16x4*>(la + (ar + 4 * i) * STEP_PITCH + ap * 8) = v;
   }
+}
+__device__ __forceinline__ void step_lwrite_a(unsigned char* la, int br, int bp, const u32x4 (&ra)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(la + (br + 8 * i) * STEP_PITCH + bp * 16) = ra[i];
+}
+template <int NT>
+__device__ __forceinline__ void step_lwrite_b(unsigned char* lb, int br, int bp, const u32x4 (&rb)[NT * 4]) {
 #pragma unroll
   for (int t = 0; t < NT * 4; ++t)
     *reinterpret_cast<u32x4*>(lb + ((t >> 2) * 32 + br + 8 * (t & 3)) * STEP_PITCH + bp * 16) = rb[t];
 }
 
-template <int NT, bool GATES, class EP>
-__global__ __launch_bounds__(256) void gemm_step_kernel(SmallArgs2<LoadK, LoadKh2, EP> zz, int gate_stride) {
+template <int NT, bool GATES, class AL, class EP>
+__global__ __launch_bounds__(256) void gemm_step_kernel(SmallArgs2<AL, LoadKh2, EP> zz, int gate_stride) {
+  constexpr bool AH = SrcBf16<AL>::v;                           // A operand read from its bf16 shadow
+  constexpr int NA = AH ? 4 : 8;
   __shared__ __attribute__((aligned(16))) unsigned char lds[step_lds_bytes<NT>()];
-  const SmallArgs<LoadK, LoadKh2, EP>& g = zz.z[blockIdx.z];
+  const SmallArgs<AL, LoadKh2, EP>& g = zz.z[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.y * 32;
@@ -926,11 +947,11 @@ __global__ __launch_bounds__(256) void gemm_step_kernel(SmallArgs2<LoadK, LoadKh
   const int kw = ((K / 64 + 3) / 4) * 64;                   // this wave's K range (multiple of 64)
   const int kbeg = wave * kw, kend = min(K, kbeg + kw);
 
-  // staging roles: A lane -> row (lane>>4) + 4i, 16-byte piece (lane&15) = 4 fp32 k; B lane -> row (lane>>3) + 8i, piece (lane&7) = 8 bf16 k
-  const int ar = lane >> 4, ap = lane & 15, br = lane >> 3, bp = lane & 7;
-  int arow[8];
+  // staging roles.  fp32 rows: lane -> row (lane>>4) + 4i, 16-byte piece (lane&15) = 4 k;  bf16 rows: row (lane>>3) + 8i, piece (lane&7) = 8 k
+  const int ar = AH ? (lane >> 3) : (lane >> 4), ap = AH ? (lane & 7) : (lane & 15), br = lane >> 3, bp = lane & 7;
+  int arow[NA];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) arow[i] = min(m0 + ar + 4 * i, g.a.rows - 1);        // rows past the end: any valid row, result dropped
+  for (int i = 0; i < NA; ++i) arow[i] = min(m0 + ar + (AH ? 8 : 4) * i, g.a.rows - 1);   // rows past the end: any valid row, result dropped
   const int brow0 = n0 + br;                                  // N % 32 == 0 so always valid
 
   f32x16 acc[NT];
@@ -939,14 +960,24 @@ __global__ __launch_bounds__(256) void gemm_step_kernel(SmallArgs2<LoadK, LoadKh
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
+  // the epilogue's own operands (zx, c_prev, gates, ...) are requested now so that they arrive during the K loop
+  typename EP::Pre pre[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) pre[e] = g.ep.prefetch(m0 + 8 * wave + 4 * h + e, n0 + r);
+
   if (kbeg < kend) {
-    float4 ra[8]; u32x4 rb[NT * 4];
-    step_gload<NT, GATES>(g.a, g.b, kbeg, arow, brow0, gate_stride, ap, bp, ra, rb);
+    typename std::conditional<AH, u32x4, float4>::type ra[NA]; u32x4 rb[NT * 4];
+    step_gload_a(g.a, kbeg, arow, ap, ra);
+    step_gload_b<NT, GATES>(g.b, kbeg, g.a.K0, brow0, gate_stride, bp, rb);
     for (int kc = kbeg; kc < kend; kc += 64) {
       __builtin_amdgcn_wave_barrier();
-      step_lwrite<NT>(la, lb, ar, ap, br, bp, ra, rb);
+      step_lwrite_a(la, ar, ap, ra);
+      step_lwrite_b<NT>(lb, br, bp, rb);
       __builtin_amdgcn_wave_barrier();
-      if (kc + 64 < kend) step_gload<NT, GATES>(g.a, g.b, kc + 64, arow, brow0, gate_stride, ap, bp, ra, rb);
+      if (kc + 64 < kend) {
+        step_gload_a(g.a, kc + 64, arow, ap, ra);
+        step_gload_b<NT, GATES>(g.b, kc + 64, g.a.K0, brow0, gate_stride, bp, rb);
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const bf16x8 af = *reinterpret_cast<const bf16x8*>(la + r * STEP_PITCH + 32 * s + 16 * h);
@@ -966,19 +997,19 @@ __global__ __launch_bounds__(256) void gemm_step_kernel(SmallArgs2<LoadK, LoadKh
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[(ni * 16 + e) * 64 + lane] = acc[ni][e];
   __syncthreads();
-  const int q = wave;
-  float v[NT][4];
+  // each thread finishes 4 elements (rows 8*wave + 4h + e of column r) straight from LDS
+  const float* r0 = reinterpret_cast<const float*>(lds);
+  constexpr int WSTRIDE = (1 + NT) * 32 * STEP_PITCH / 4;     // floats between two waves' regions
 #pragma unroll
-  for (int ni = 0; ni < NT; ++ni)
+  for (int e = 0; e < 4; ++e) {
+    float v[NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w)
-        s += reinterpret_cast<const float*>(lds + w * ((1 + NT) * 32 * STEP_PITCH))[(ni * 16 + 4 * q + i) * 64 + lane];
-      v[ni][i] = s;
+    for (int ni = 0; ni < NT; ++ni) {
+      const int idx = (ni * 16 + 4 * wave + e) * 64 + lane;
+      v[ni] = (r0[idx] + r0[idx + WSTRIDE]) + (r0[idx + 2 * WSTRIDE] + r0[idx + 3 * WSTRIDE]);
     }
-  g.ep.template quad<NT>(m0 + 8 * q + 4 * h, n0 + r, 32, v);
+    g.ep.template elem<NT>(m0 + 8 * wave + 4 * h + e, n0 + r, 32, v, pre[e]);
+  }
 }
 
 }  // namespace aocr

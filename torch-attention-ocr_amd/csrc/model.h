@@ -60,6 +60,8 @@ struct aocr_model {
   // bf16 shadows of the contraction operands (bf16 compute mode only; nullptr otherwise)
   aocr::bf16_t *A1b, *A2b, *A3b, *A4b, *A5b, *A6b, *G0b;
   aocr::bf16_t *wb[8], *wtb[8];
+  // bf16 shadows of the recurrent activations / gradients (written by the producing epilogues)
+  aocr::bf16_t *Xb, *ehs_b[2][aocr::MAXL], *edz_b[2][aocr::MAXL], *dhs_b[aocr::MAXL], *ddz_b[aocr::MAXL], *out_b, *cat_b, *dpre_b, *dq_b;
   void* bn_scratch; float* bn_save;
   // encoder [dir][layer]
   float *ezx[2][aocr::MAXL], *ehs[2][aocr::MAXL], *ecs[2][aocr::MAXL], *egates[2][aocr::MAXL], *edz[2][aocr::MAXL], *edc[2];

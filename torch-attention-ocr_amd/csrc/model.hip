@@ -112,6 +112,13 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     m->edc[dir] = a.get<float>(B * He); m->edxl[dir] = a.get<float>(T * B * He);
   }
   m->context = a.get<float>(B * T * Hd); m->dctx = a.get<float>(B * T * Hd);
+  {
+    auto hb = [&](size_t n) { return m->bf16 ? a.get<bf16_t>(n) : (bf16_t*)nullptr; };
+    m->Xb = hb(T * B * 512);
+    for (int dir = 0; dir < 2; ++dir) for (int l = 0; l < m->Le; ++l) { m->ehs_b[dir][l] = hb((T + 2) * B * He); m->edz_b[dir][l] = hb(T * B * 4 * He); }
+    for (int l = 0; l < m->Ld; ++l) { m->dhs_b[l] = hb((L + 1) * B * Hd); m->ddz_b[l] = hb(L * B * 4 * Hd); }
+    m->out_b = hb((L + 1) * B * Hd); m->cat_b = hb(L * B * 2 * Hd); m->dpre_b = hb(L * B * Hd); m->dq_b = hb(L * B * Hd);
+  }
   m->emb_all = a.get<float>(L * B * E); m->zx1_all = a.get<float>(L * B * 4 * Hd);
   for (int l = 0; l < m->Ld; ++l) {
     m->dhs[l] = a.get<float>((L + 1) * B * Hd); m->dcs[l] = a.get<float>((L + 1) * B * Hd);
@@ -158,10 +165,19 @@ static LoadK bnt_f(const ShW* w0, const ShW* w1) {
 static LoadKh2 bnt_h(const ShW* w0, const ShW* w1) {
   return w1 ? make_loadkh2(w0->wb, w0->C, w0->C, w1->wb, w1->C, w1->C, w0->R) : make_loadkh(w0->wb, w0->C, w0->R, w0->C);
 }
-// gates forward: z = [x0 ; x1] [W0 ; W1]^T (+ epilogue); nz argument sets
+static bool hh_ok(const LoadKh2* ah, int nz, int ncols) {        // staged kernel with both operands from bf16 shadows
+  if (!ah || ncols % 32 != 0) return false;
+  for (int i = 0; i < nz; ++i) if (!ah[i].p0 || ah[i].K <= 0 || ah[i].K % 64 != 0 || ah[i].K0 % 64 != 0) return false;
+  return true;
+}
+// gates forward: z = [x0 ; x1] [W0 ; W1]^T (+ epilogue); nz argument sets; ah = the same A operand as bf16 shadows (optional)
 static void run_gates_fwd(aocr_model* m, int nz, const LoadK* a, const ShW* const* w0, const ShW* const* w1, const EpGatesFwd* ep,
-                          int M, int H) {
-  if (m->bf16) {
+                          int M, int H, const LoadKh2* ah = nullptr) {
+  if (m->bf16 && hh_ok(ah, nz, H)) {
+    GatesFwdArgsHH z[2];
+    for (int i = 0; i < nz; ++i) { z[i].a = ah[i]; z[i].b = bnt_h(w0[i], w1[i]); z[i].ep = ep[i]; z[i].K = ah[i].K; }
+    launch_small_gates_fwd_hh(m->s, nz, z, M, H);
+  } else if (m->bf16) {
     GatesFwdArgsH z[2];
     for (int i = 0; i < nz; ++i) { z[i].a = a[i]; z[i].b = bnt_h(w0[i], w1[i]); z[i].ep = ep[i]; z[i].K = a[i].K; }
     launch_small_gates_fwd_h(m->s, nz, z, M, H);
@@ -172,18 +188,25 @@ static void run_gates_fwd(aocr_model* m, int nz, const LoadK* a, const ShW* cons
   }
 }
 // y = x W^T through an EpStore
-static void run_store_nt(aocr_model* m, const LoadK& a, const ShW& w, const EpStore& ep, int M) {
-  if (m->bf16) { SmallArgsH z; z.a = a; z.b = bnt_h(&w, nullptr); z.ep = ep; z.K = a.K; launch_small_h(m->s, 1, &z, M, w.R); }
+static void run_store_nt(aocr_model* m, const LoadK& a, const ShW& w, const EpStore& ep, int M, const LoadKh2* ah = nullptr) {
+  if (m->bf16 && hh_ok(ah, 1, w.R)) { SmallArgsHH z; z.a = *ah; z.b = bnt_h(&w, nullptr); z.ep = ep; z.K = ah->K; launch_small_hh(m->s, 1, &z, M, w.R); }
+  else if (m->bf16) { SmallArgsH z; z.a = a; z.b = bnt_h(&w, nullptr); z.ep = ep; z.K = a.K; launch_small_h(m->s, 1, &z, M, w.R); }
   else { SmallKKArgs z; z.a = a; z.b = bnt_f(&w, nullptr); z.ep = ep; z.K = a.K; launch_small_kk(m->s, false, 1, &z, M, w.R); }
 }
 // y = x W through an EpStore (x is [M][R], y is [M][C])
-static void run_store_nn(aocr_model* m, const LoadK& a, const ShW& w, const EpStore& ep, int M) {
-  if (m->bf16) { SmallArgsH z; z.a = a; z.b = make_loadkh(w.wtb, w.R, w.C, w.R); z.ep = ep; z.K = a.K; launch_small_h(m->s, 1, &z, M, w.C); }
+static void run_store_nn(aocr_model* m, const LoadK& a, const ShW& w, const EpStore& ep, int M, const LoadKh2* ah = nullptr) {
+  if (m->bf16 && hh_ok(ah, 1, w.C)) { SmallArgsHH z; z.a = *ah; z.b = make_loadkh(w.wtb, w.R, w.C, w.R); z.ep = ep; z.K = ah->K; launch_small_hh(m->s, 1, &z, M, w.C); }
+  else if (m->bf16) { SmallArgsH z; z.a = a; z.b = make_loadkh(w.wtb, w.R, w.C, w.R); z.ep = ep; z.K = a.K; launch_small_h(m->s, 1, &z, M, w.C); }
   else { SmallKMNArgs z; z.a = a; z.b = make_loadmn(w.w, w.ld, w.C, a.K); z.ep = ep; z.K = a.K; launch_small_kmn(m->s, false, 1, &z, M, w.C); }
 }
 // gate backward: d(h) GEMM part = x W (K may be 0: no GEMM part)
-static void run_gates_bwd(aocr_model* m, int nz, const LoadK* a, const ShW* const* w, const EpGatesBwd* ep, int M, int H) {
-  if (m->bf16) {
+static void run_gates_bwd(aocr_model* m, int nz, const LoadK* a, const ShW* const* w, const EpGatesBwd* ep, int M, int H,
+                          const LoadKh2* ah = nullptr) {
+  if (m->bf16 && hh_ok(ah, nz, H)) {
+    GatesBwdArgsHH z[2];
+    for (int i = 0; i < nz; ++i) { z[i].a = ah[i]; z[i].b = make_loadkh(w[i]->wtb, w[i]->R, w[i]->C, ah[i].K); z[i].ep = ep[i]; z[i].K = ah[i].K; }
+    launch_small_gates_bwd_hh(m->s, nz, z, M, H);
+  } else if (m->bf16) {
     GatesBwdArgsH z[2];
     for (int i = 0; i < nz; ++i) { z[i].a = a[i]; z[i].b = make_loadkh(w[i]->wtb, w[i]->R, w[i]->C, a[i].K); z[i].ep = ep[i]; z[i].K = a[i].K; }
     launch_small_gates_bwd_h(m->s, nz, z, M, H);
@@ -215,7 +238,7 @@ void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training
   conv_forward(s, bf, m->A5, m->conv[6].w, m->conv[6].b, m->A6, m->idx6, B, d.H4, d.W2, 512, 512, 3, 1, 1, 2, m->A5b, m->wb[6], m->A6b);
   conv_forward(s, bf, m->A6, m->conv[7].w, m->conv[7].b, m->Y7, nullptr, B, d.H6, d.W2, 512, 512, 2, 0, 0, 0, m->A6b, m->wb[7], nullptr);
   bn_relu_forward(s, m->Y7, m->X, m->bn[7].w, m->bn[7].b, m->bn[7].rm, m->bn[7].rv, m->bn[7].save, m->bn_scratch,
-                  (int64_t)B * d.T, 512, training, update_running, B, nullptr);
+                  (int64_t)B * d.T, 512, training, update_running, B, m->Xb);
 }
 
 static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
@@ -263,16 +286,21 @@ void encoder_forward(aocr_model* m, const Dims& d) {
       hipMemsetAsync(m->ehs[dir][l] + (size_t)(T + 1) * slot, 0, slot * sizeof(float), s);
       hipMemsetAsync(m->ecs[dir][l], 0, slot * sizeof(float), s);
       hipMemsetAsync(m->ecs[dir][l] + (size_t)(T + 1) * slot, 0, slot * sizeof(float), s);
+      if (m->ehs_b[dir][l]) {
+        hipMemsetAsync(m->ehs_b[dir][l], 0, slot * sizeof(bf16_t), s);
+        hipMemsetAsync(m->ehs_b[dir][l] + (size_t)(T + 1) * slot, 0, slot * sizeof(bf16_t), s);
+      }
     }
     const bool top = l == m->Le - 1;
     for (int i = 0; i < T; ++i) {
-      LoadK la[2]; EpGatesFwd ee[2]; const ShW* w0[2]; const ShW* w1[2] = {nullptr, nullptr};
+      LoadK la[2]; LoadKh2 lah[2]; EpGatesFwd ee[2]; const ShW* w0[2]; const ShW* w1[2] = {nullptr, nullptr};
       for (int dir = 0; dir < 2; ++dir) {
         const LstmP& p = m->enc[dir][l];
         const int t = dir == 0 ? i : T - 1 - i;
         const int prev = dir == 0 ? t : t + 2;
         float* hs = m->ehs[dir][l]; float* cs = m->ecs[dir][l];
         la[dir] = make_loadk(hs + prev * slot, He, B, He);
+        lah[dir] = make_loadkh(m->ehs_b[dir][l] ? m->ehs_b[dir][l] + prev * slot : nullptr, He, B, He);
         w0[dir] = &p.swh;
         EpGatesFwd& e = ee[dir];
         e.zx = m->ezx[dir][l] + (size_t)t * B * 4 * He; e.ldzx = 4 * He; e.b1 = nullptr; e.b2 = nullptr;
@@ -280,8 +308,9 @@ void encoder_forward(aocr_model* m, const Dims& d) {
         e.c_out = cs + (size_t)(t + 1) * slot; e.ldc = He; e.h_out = hs + (size_t)(t + 1) * slot; e.ldh = He;
         e.h_out2 = top ? m->context + (size_t)t * Hd + dir * He : nullptr; e.ldh2 = (int64_t)T * Hd;   // model.lua:303,315
         e.gates = m->egates[dir][l] + (size_t)t * B * 4 * He; e.ldg = 4 * He; e.M = B; e.H = He;
+        if (m->ehs_b[dir][l]) { e.hb = m->ehs_b[dir][l] + (size_t)(t + 1) * slot; e.ldhb = He; }
       }
-      run_gates_fwd(m, 2, la, w0, w1, ee, B, He);
+      run_gates_fwd(m, 2, la, w0, w1, ee, B, He, lah);
     }
   }
 }
@@ -299,7 +328,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       else hipMemsetAsync(m->edc[dir], 0, slot * sizeof(float), s);
     }
     for (int i = 0; i < T; ++i) {
-      LoadK la[2]; EpGatesBwd ee[2]; const ShW* ww[2];
+      LoadK la[2]; LoadKh2 lah[2]; EpGatesBwd ee[2]; const ShW* ww[2];
       for (int dir = 0; dir < 2; ++dir) {
         const LstmP& p = m->enc[dir][l];
         const int t = dir == 0 ? T - 1 - i : i;
@@ -307,6 +336,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
         const int prev = dir == 0 ? t : t + 2;
         float* dz = m->edz[dir][l];
         la[dir] = make_loadk(i == 0 ? dz : dz + (size_t)tn * B * 4 * He, 4 * He, B, i == 0 ? 0 : 4 * He);
+        lah[dir] = make_loadkh((i == 0 || !m->edz_b[dir][l]) ? nullptr : m->edz_b[dir][l] + (size_t)tn * B * 4 * He, 4 * He, B, i == 0 ? 0 : 4 * He);
         ww[dir] = &p.swh;
         EpGatesBwd& e = ee[dir];
         if (top) { e.dh1 = m->dctx + (size_t)t * Hd + dir * He; e.ld1 = (int64_t)T * Hd; }    // model.lua:670,684
@@ -316,8 +346,9 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
         e.gates = m->egates[dir][l] + (size_t)t * B * 4 * He; e.ldg = 4 * He;
         e.c_prev = m->ecs[dir][l] + prev * slot; e.ldcp = He; e.c = m->ecs[dir][l] + (size_t)(t + 1) * slot; e.ldcc = He;
         e.dz = dz + (size_t)t * B * 4 * He; e.lddz = 4 * He; e.dc_out = m->edc[dir]; e.lddco = He; e.M = B; e.H = He;
+        if (m->edz_b[dir][l]) { e.dzb = m->edz_b[dir][l] + (size_t)t * B * 4 * He; e.lddzb = 4 * He; }
       }
-      run_gates_bwd(m, 2, la, ww, ee, B, He);
+      run_gates_bwd(m, 2, la, ww, ee, B, He, lah);
     }
     WGradProblem wg[4]; int nwg = 0;
     for (int dir = 0; dir < 2; ++dir) {
@@ -346,6 +377,9 @@ struct DecStepIO {
   const float* c_prev[MAXL]; const float* h_prev[MAXL];
   float* c_new[MAXL]; float* h_new[MAXL]; float* gates[MAXL];
   float *q, *a, *cat, *out;
+  // bf16 shadows (teacher-forced path in bf16 mode; nullptr otherwise)
+  const bf16_t* feed_b = nullptr; const bf16_t* hb_prev[MAXL] = {nullptr, nullptr, nullptr, nullptr};
+  bf16_t* hb_new[MAXL] = {nullptr, nullptr, nullptr, nullptr}; bf16_t* cat_b = nullptr; bf16_t* out_b = nullptr;
 };
 
 // one decoder clone forward, LSTM.lua:18-122: LSTM layers, then attention (LSTM.lua:124-162).
@@ -354,29 +388,41 @@ static void dec_step_forward(aocr_model* m, const DecStepIO& io, int T) {
   const int R = io.R, Hd = m->Hd, E = m->E;
   for (int l = 0; l < m->Ld; ++l) {
     const LstmP& p = m->dec[l];
-    LoadK la; EpGatesFwd e; const ShW* w0; const ShW* w1 = nullptr;
+    LoadK la; LoadKh2 lah; EpGatesFwd e; const ShW* w0; const ShW* w1 = nullptr;
+    const bool sh = io.hb_new[0] != nullptr;
     if (l == 0) {
-      if (m->cfg.input_feed) { la = make_loadk2(io.feed, Hd, Hd, io.h_prev[0], Hd, Hd, R); w0 = &p.swi; w1 = &p.swh; }
-      else { la = make_loadk(io.h_prev[0], Hd, R, Hd); w0 = &p.swh; }
+      if (m->cfg.input_feed) {
+        la = make_loadk2(io.feed, Hd, Hd, io.h_prev[0], Hd, Hd, R); w0 = &p.swi; w1 = &p.swh;
+        lah = make_loadkh2(sh ? io.feed_b : nullptr, Hd, Hd, io.hb_prev[0], Hd, Hd, R);
+      } else { la = make_loadk(io.h_prev[0], Hd, R, Hd); w0 = &p.swh; lah = make_loadkh(sh ? io.hb_prev[0] : nullptr, Hd, R, Hd); }
       e.zx = io.zx1; e.ldzx = 4 * Hd; e.b1 = nullptr; e.b2 = nullptr;
     } else {
       la = make_loadk2(io.h_new[l - 1], Hd, Hd, io.h_prev[l], Hd, Hd, R); w0 = &p.swi; w1 = &p.swh;
+      lah = make_loadkh2(sh ? io.hb_new[l - 1] : nullptr, Hd, Hd, io.hb_prev[l], Hd, Hd, R);
       e.zx = nullptr; e.ldzx = 0; e.b1 = p.bi; e.b2 = p.bh;
     }
     e.c_prev = io.c_prev[l]; e.ldcp = Hd; e.c_out = io.c_new[l]; e.ldc = Hd; e.h_out = io.h_new[l]; e.ldh = Hd;
     const bool top = l == m->Ld - 1;
     e.h_out2 = top ? io.cat + Hd : nullptr; e.ldh2 = 2 * Hd;                         // JoinTable [c ; h_top], LSTM.lua:153
     e.gates = io.gates[l]; e.ldg = 4 * Hd; e.M = R; e.H = Hd;
-    run_gates_fwd(m, 1, &la, &w0, &w1, &e, R, Hd);
+    if (sh) { e.hb = io.hb_new[l]; e.ldhb = Hd; if (top) { e.hb2 = io.cat_b + Hd; e.ldhb2 = 2 * Hd; } }
+    run_gates_fwd(m, 1, &la, &w0, &w1, &e, R, Hd, &lah);
   }
-  run_store_nt(m, make_loadk(io.h_new[m->Ld - 1], Hd, R, Hd), m->swa, make_store(io.q, Hd, R, Hd), R);          // q = W_a h_top, LSTM.lua:131
-  attention_forward(s, m->context, io.q, io.a, io.cat, 2 * Hd, R, T, Hd, io.ctx_div);
-  run_store_nt(m, make_loadk(io.cat, 2 * Hd, R, 2 * Hd), m->swc, make_store(io.out, Hd, R, Hd, nullptr, nullptr, EP_TANH), R);   // LSTM.lua:155
+  {
+    const bool sh = io.hb_new[0] != nullptr;
+    LoadKh2 qa = make_loadkh(sh ? io.hb_new[m->Ld - 1] : nullptr, Hd, R, Hd);
+    run_store_nt(m, make_loadk(io.h_new[m->Ld - 1], Hd, R, Hd), m->swa, make_store(io.q, Hd, R, Hd), R, &qa);      // q = W_a h_top, LSTM.lua:131
+    attention_forward(s, m->context, io.q, io.a, io.cat, 2 * Hd, R, T, Hd, io.ctx_div, io.cat_b, 2 * Hd);
+    EpStore eo = make_store(io.out, Hd, R, Hd, nullptr, nullptr, EP_TANH);
+    eo.Cb = io.out_b; eo.ldcb = Hd;
+    LoadKh2 ca = make_loadkh(sh ? io.cat_b : nullptr, 2 * Hd, R, 2 * Hd);
+    run_store_nt(m, make_loadk(io.cat, 2 * Hd, R, 2 * Hd), m->swc, eo, R, &ca);                                       // LSTM.lua:155
+  }
   (void)E; (void)bf;
 }
 
 // initial decoder state from the encoder's final states, model.lua:539-552 (+ quirk S5)
-static void dec_init_state(aocr_model* m, const Dims& d, float* const* c0, float* const* h0, float* feed0, int R) {
+static void dec_init_state(aocr_model* m, const Dims& d, float* const* c0, float* const* h0, float* feed0, int R, bool shadows = false) {
   hipStream_t s = m->s; const int B = d.B, T = d.T, He = m->He, Hd = m->Hd; const size_t slot = (size_t)B * He;
   (void)R;
   const int lt = m->Le - 1;
@@ -385,6 +431,10 @@ static void dec_init_state(aocr_model* m, const Dims& d, float* const* c0, float
     hipMemsetAsync(h0[l], 0, (size_t)B * Hd * sizeof(float), s);
   }
   if (feed0) hipMemsetAsync(feed0, 0, (size_t)B * Hd * sizeof(float), s);
+  if (shadows) {
+    for (int l = 0; l < m->Ld; ++l) hipMemsetAsync(m->dhs_b[l], 0, (size_t)B * Hd * sizeof(bf16_t), s);
+    hipMemsetAsync(m->out_b, 0, (size_t)B * Hd * sizeof(bf16_t), s);
+  }
   // c1(0) = [c_fw(T) ; c_bw(1)]
   copy2d(s, m->ecs[0][lt] + (size_t)T * slot, He, c0[0], Hd, B, He);
   copy2d(s, m->ecs[1][lt] + (size_t)1 * slot, He, c0[0] + He, Hd, B, He);
@@ -392,6 +442,10 @@ static void dec_init_state(aocr_model* m, const Dims& d, float* const* c0, float
   if (!quirk_s5) {
     copy2d(s, m->ehs[0][lt] + (size_t)T * slot, He, h0[0], Hd, B, He);
     copy2d(s, m->ehs[1][lt] + (size_t)1 * slot, He, h0[0] + He, Hd, B, He);
+    if (shadows) {
+      copy2d_bf16(s, m->ehs[0][lt] + (size_t)T * slot, He, m->dhs_b[0], Hd, B, He);
+      copy2d_bf16(s, m->ehs[1][lt] + (size_t)1 * slot, He, m->dhs_b[0] + He, Hd, B, He);
+    }
   }
 }
 
@@ -406,7 +460,8 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
   gemm(s, bf, m->emb_all, E, true, p1.wi, p1.in, true, m->zx1_all, 4 * Hd, L * B, 4 * Hd, E, p1.bi, p1.bh, 0);
   float* c0[MAXL]; float* h0[MAXL];
   for (int l = 0; l < m->Ld; ++l) { c0[l] = m->dcs[l]; h0[l] = m->dhs[l]; }
-  dec_init_state(m, d, c0, h0, m->out_all, B);
+  const bool sh = m->bf16 && m->out_b != nullptr;
+  dec_init_state(m, d, c0, h0, m->out_all, B, sh);
   for (int t = 0; t < L; ++t) {
     DecStepIO io; io.R = B; io.ctx_div = 1;
     io.zx1 = m->zx1_all + (size_t)t * B * 4 * Hd; io.feed = m->out_all + (size_t)t * slot;
@@ -417,6 +472,10 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
     }
     io.q = m->q_all + (size_t)t * slot; io.a = m->a_all + (size_t)t * B * T; io.cat = m->cat_all + (size_t)t * B * 2 * Hd;
     io.out = m->out_all + (size_t)(t + 1) * slot;
+    if (sh) {
+      io.feed_b = m->out_b + (size_t)t * slot; io.out_b = m->out_b + (size_t)(t + 1) * slot; io.cat_b = m->cat_b + (size_t)t * B * 2 * Hd;
+      for (int l = 0; l < m->Ld; ++l) { io.hb_prev[l] = m->dhs_b[l] + (size_t)t * slot; io.hb_new[l] = m->dhs_b[l] + (size_t)(t + 1) * slot; }
+    }
     dec_step_forward(m, io, T);
   }
   gemm(s, bf, m->out_all + slot, Hd, true, m->wo, Hd, true, m->logits, LOGIT_LD, L * B, m->V, Hd, m->bo, nullptr, 0);
@@ -450,18 +509,23 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
     float* dpre = m->dpre_all + (size_t)t * slot;
     float* dcat = m->dcat_all + (size_t)t * B * 2 * Hd;
     // d(tanh) with the input-feed gradient of step t+1 added (model.lua:649,654-657)
-    dpre_tanh(s, m->dout_proj + (size_t)t * slot, (m->cfg.input_feed && !last) ? m->dfeed : nullptr, out_t, dpre, (int64_t)slot);
-    run_store_nn(m, make_loadk(dpre, Hd, B, Hd), m->swc, make_store(dcat, 2 * Hd, B, 2 * Hd), B);      // d[c ; h_top] = dpre W_c
+    const bool sh = m->bf16 && m->dpre_b != nullptr;
+    dpre_tanh(s, m->dout_proj + (size_t)t * slot, (m->cfg.input_feed && !last) ? m->dfeed : nullptr, out_t, dpre, (int64_t)slot,
+              sh ? m->dpre_b + (size_t)t * slot : nullptr);
+    LoadKh2 dpa = make_loadkh(sh ? m->dpre_b + (size_t)t * slot : nullptr, Hd, B, Hd);
+    run_store_nn(m, make_loadk(dpre, Hd, B, Hd), m->swc, make_store(dcat, 2 * Hd, B, 2 * Hd), B, &dpa);      // d[c ; h_top] = dpre W_c
     attention_backward(s, m->context, m->q_all + (size_t)t * slot, m->a_all + (size_t)t * B * T, dcat, 2 * Hd,
-                       m->ds_all + (size_t)t * B * T, m->dq_all + (size_t)t * slot, B, T, Hd);
+                       m->ds_all + (size_t)t * B * T, m->dq_all + (size_t)t * slot, B, T, Hd, sh ? m->dq_b + (size_t)t * slot : nullptr);
     // top layer: d h_top = dq W_a + dcat[:, Hd:] + recurrent part
     for (int l = Ld - 1; l >= 0; --l) {
-      LoadK la; EpGatesBwd e; const ShW* ww;
+      LoadK la; LoadKh2 lah; EpGatesBwd e; const ShW* ww;
       if (l == Ld - 1) {
         la = make_loadk(m->dq_all + (size_t)t * slot, Hd, B, Hd); ww = &m->swa;
+        lah = make_loadkh(sh ? m->dq_b + (size_t)t * slot : nullptr, Hd, B, Hd);
         e.dh1 = dcat + Hd; e.ld1 = 2 * Hd;
       } else {                                                        // from the layer above: dz_{l+1} W_{l+1,i2h}
         la = make_loadk(m->ddz[l + 1] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd); ww = &m->dec[l + 1].swi;
+        lah = make_loadkh(sh ? m->ddz_b[l + 1] + (size_t)t * B * 4 * Hd : nullptr, 4 * Hd, B, 4 * Hd);
         e.dh1 = nullptr; e.ld1 = 0;
       }
       e.dh2 = m->dh_rec[l]; e.ld2 = Hd;
@@ -469,12 +533,16 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
       e.gates = m->dgates[l] + (size_t)t * B * 4 * Hd; e.ldg = 4 * Hd;
       e.c_prev = m->dcs[l] + (size_t)t * slot; e.ldcp = Hd; e.c = m->dcs[l] + (size_t)(t + 1) * slot; e.ldcc = Hd;
       e.dz = m->ddz[l] + (size_t)t * B * 4 * Hd; e.lddz = 4 * Hd; e.dc_out = m->dc_st[l]; e.lddco = Hd; e.M = B; e.H = Hd;
-      run_gates_bwd(m, 1, &la, &ww, &e, B, Hd);
+      if (sh) { e.dzb = m->ddz_b[l] + (size_t)t * B * 4 * Hd; e.lddzb = 4 * Hd; }
+      run_gates_bwd(m, 1, &la, &ww, &e, B, Hd, &lah);
+      LoadKh2 dza = make_loadkh(sh ? m->ddz_b[l] + (size_t)t * B * 4 * Hd : nullptr, 4 * Hd, B, 4 * Hd);
       // recurrent part for step t-1: dz_l W_{l,h2h}
-      run_store_nn(m, make_loadk(m->ddz[l] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd), m->dec[l].swh, make_store(m->dh_rec[l], Hd, B, Hd), B);
+      run_store_nn(m, make_loadk(m->ddz[l] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd), m->dec[l].swh, make_store(m->dh_rec[l], Hd, B, Hd), B, &dza);
     }
-    if (m->cfg.input_feed)                                            // d(prev attention output) = dz_1 W_{1,i2h}[:, E:]
-      run_store_nn(m, make_loadk(m->ddz[0] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd), m->dec[0].swi, make_store(m->dfeed, Hd, B, Hd), B);
+    if (m->cfg.input_feed) {                                          // d(prev attention output) = dz_1 W_{1,i2h}[:, E:]
+      LoadKh2 dz0 = make_loadkh(sh ? m->ddz_b[0] + (size_t)t * B * 4 * Hd : nullptr, 4 * Hd, B, 4 * Hd);
+      run_store_nn(m, make_loadk(m->ddz[0] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd), m->dec[0].swi, make_store(m->dfeed, Hd, B, Hd), B, &dz0);
+    }
   }
   // ---- hoisted parameter gradients (accGradParameters of every clone summed over time)
   const float* h_top_all = m->dhs[Ld - 1] + slot;

@@ -53,6 +53,12 @@ void launch_small_gates_bwd(hipStream_t s, bool bf16, int nz, const GatesBwdArgs
 typedef SmallArgs<LoadK, LoadKh2, EpGatesFwd> GatesFwdArgsH;
 typedef SmallArgs<LoadK, LoadKh2, EpStore> SmallArgsH;
 typedef SmallArgs<LoadK, LoadKh2, EpGatesBwd> GatesBwdArgsH;
+typedef SmallArgs<LoadKh2, LoadKh2, EpGatesFwd> GatesFwdArgsHH;    // A read from its bf16 shadow as well
+typedef SmallArgs<LoadKh2, LoadKh2, EpStore> SmallArgsHH;
+typedef SmallArgs<LoadKh2, LoadKh2, EpGatesBwd> GatesBwdArgsHH;
+void launch_small_gates_fwd_hh(hipStream_t s, int nz, const GatesFwdArgsHH* z, int M, int H);
+void launch_small_hh(hipStream_t s, int nz, const SmallArgsHH* z, int M, int N);
+void launch_small_gates_bwd_hh(hipStream_t s, int nz, const GatesBwdArgsHH* z, int M, int H);
 void launch_small_gates_fwd_h(hipStream_t s, int nz, const GatesFwdArgsH* z, int M, int H);
 void launch_small_h(hipStream_t s, int nz, const SmallArgsH* z, int M, int N);
 void launch_small_gates_bwd_h(hipStream_t s, int nz, const GatesBwdArgsH* z, int M, int H);
@@ -101,9 +107,9 @@ void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float
                       float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb = nullptr);
 // ctx_div: rows r share context row r / ctx_div (beam search keeps one context per image, model.lua:373)
 void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a, float* c, int64_t ldc, int B, int T, int Hd,
-                       int ctx_div = 1);
+                       int ctx_div = 1, bf16_t* cb = nullptr, int64_t ldcb = 0);
 void attention_backward(hipStream_t s, const float* ctx, const float* q, const float* a, const float* dc, int64_t lddc,
-                        float* ds, float* dq, int B, int T, int Hd);
+                        float* ds, float* dq, int B, int T, int Hd, bf16_t* dqb = nullptr);
 // d(ctx)[b,t,:] = sum_l a[l,b,t]*dc[l,b,:] + ds[l,b,t]*q[l,b,:]   (dc row stride lddc)
 void attention_dctx(hipStream_t s, const float* a_all, const float* ds_all, const float* dc_all, int64_t lddc,
                     const float* q_all, float* dctx, int L, int B, int T, int Hd);
@@ -117,7 +123,8 @@ void embedding_gather(hipStream_t s, const float* table, const int32_t* tok, int
                       int L, int B, int E);
 void embedding_scatter_accum(hipStream_t s, const float* demb, const int32_t* tok, int64_t stride_t, int64_t stride_b,
                              float* dtable, int L, int B, int E, int V);
-void dpre_tanh(hipStream_t s, const float* g1, const float* g2, const float* out, float* dpre, int64_t n);  // (g1+g2)*(1-out^2)
+void dpre_tanh(hipStream_t s, const float* g1, const float* g2, const float* out, float* dpre, int64_t n, bf16_t* dpreb = nullptr);  // (g1+g2)*(1-out^2)
+void copy2d_bf16(hipStream_t s, const float* src, int64_t lds, bf16_t* dst, int64_t ldd, int rows, int cols);
 void copy2d(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols);
 void sgd_clip_update(hipStream_t s, float* params, float* grads, const int64_t* group_off /*6 host values*/, float lr,
                      float clip, float* norms_out, void* scratch);

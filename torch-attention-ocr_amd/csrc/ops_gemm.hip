@@ -85,12 +85,24 @@ static void launch_small_bf16(hipStream_t s, int nz, const ARGS* z, int M, int n
   for (int i = 0; i < nz; ++i)
     staged = staged && z[i].K > 0 && z[i].K % 64 == 0 && z[i].a.K0 % 64 == 0 && z[i].a.vec && z[i].b.ld0 % 8 == 0 &&
              (!z[i].b.p1 || z[i].b.ld1 % 8 == 0);
-  if (staged)
-    hipLaunchKernelGGL((gemm_step_kernel<NT, GATES, decltype(z[0].ep)>), grid, dim3(256), 0, s, zz, gate_stride);
-  else
-    hipLaunchKernelGGL((gemm_small_kernel<true, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid, dim3(256), 0, s,
-                       zz, gate_stride);
+  if (staged) {
+    hipLaunchKernelGGL((gemm_step_kernel<NT, GATES, decltype(z[0].a), decltype(z[0].ep)>), grid, dim3(256), 0, s, zz, gate_stride);
+    return;
+  }
+  hipLaunchKernelGGL((gemm_small_kernel<true, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid, dim3(256), 0, s,
+                     zz, gate_stride);
 }
+// both operands from bf16 shadows: only the staged kernel exists (callers check step_ok_hh first)
+template <int NT, bool GATES, class ARGS>
+static void launch_small_bf16_hh(hipStream_t s, int nz, const ARGS* z, int M, int ncols, int gate_stride) {
+  if (M <= 0 || ncols <= 0) return;
+  dim3 grid(GATES ? cdiv(ncols, 32) : cdiv(ncols, 32 * NT), cdiv(M, 32), nz);
+  SmallArgs2<decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)> zz; zz.z[0] = z[0]; zz.z[1] = z[nz > 1 ? 1 : 0];
+  hipLaunchKernelGGL((gemm_step_kernel<NT, GATES, decltype(z[0].a), decltype(z[0].ep)>), grid, dim3(256), 0, s, zz, gate_stride);
+}
+void launch_small_gates_fwd_hh(hipStream_t s, int nz, const GatesFwdArgsHH* z, int M, int H) { launch_small_bf16_hh<4, true>(s, nz, z, M, H, H); }
+void launch_small_hh(hipStream_t s, int nz, const SmallArgsHH* z, int M, int N) { launch_small_bf16_hh<1, false>(s, nz, z, M, N, 0); }
+void launch_small_gates_bwd_hh(hipStream_t s, int nz, const GatesBwdArgsHH* z, int M, int H) { launch_small_bf16_hh<1, false>(s, nz, z, M, H, 0); }
 void launch_small_gates_fwd_h(hipStream_t s, int nz, const GatesFwdArgsH* z, int M, int H) { launch_small_bf16<4, true>(s, nz, z, M, H, H); }
 void launch_small_h(hipStream_t s, int nz, const SmallArgsH* z, int M, int N) { launch_small_bf16<1, false>(s, nz, z, M, N, 0); }
 void launch_small_gates_bwd_h(hipStream_t s, int nz, const GatesBwdArgsH* z, int M, int H) { launch_small_bf16<1, false>(s, nz, z, M, H, 0); }

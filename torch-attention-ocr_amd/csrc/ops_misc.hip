@@ -404,7 +404,8 @@ void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float
 template <bool BWD>
 __global__ __launch_bounds__(256) void attn_core_kernel(const float* __restrict__ ctx, const float* __restrict__ u, int64_t ldu,
                                                         const float* __restrict__ a_in, float* __restrict__ p_out,
-                                                        float* __restrict__ o, int64_t ldo, int T, int Hd, int ctx_div) {
+                                                        float* __restrict__ o, int64_t ldo, int T, int Hd, int ctx_div,
+                                                        bf16_t* __restrict__ ob, int64_t ldob) {
   extern __shared__ float sm[];                // [T] scores + [8] scratch
   float* sc = sm; float* red = sm + T;
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(256) void attn_core_kernel(const float* __restrict_
       acc.x = fmaf(p, cv.x, acc.x); acc.y = fmaf(p, cv.y, acc.y); acc.z = fmaf(p, cv.z, acc.z); acc.w = fmaf(p, cv.w, acc.w);
     }
     *reinterpret_cast<float4*>(o + (int64_t)b * ldo + j) = acc;
+    if (ob) { bf16x4 hb; hb[0] = (bf16_t)acc.x; hb[1] = (bf16_t)acc.y; hb[2] = (bf16_t)acc.z; hb[3] = (bf16_t)acc.w; *reinterpret_cast<bf16x4*>(ob + (int64_t)b * ldob + j) = hb; }
   }
 }
 // Register-resident variant for T <= 64 and Hd = 256*NC (NC = 1, 2): the whole (T, Hd) context slice of one batch row
@@ -464,7 +466,8 @@ __global__ __launch_bounds__(256) void attn_core_kernel(const float* __restrict_
 template <int NC, bool BWD>
 __global__ __launch_bounds__(256) void attn_reg_kernel(const float* __restrict__ ctx, const float* __restrict__ u, int64_t ldu,
                                                        const float* __restrict__ a_in, float* __restrict__ p_out,
-                                                       float* __restrict__ o, int64_t ldo, int T, int ctx_div) {
+                                                       float* __restrict__ o, int64_t ldo, int T, int ctx_div, bf16_t* __restrict__ ob,
+                                                       int64_t ldob) {
   constexpr int Hd = 256 * NC;
   __shared__ float sc[64];
   __shared__ __attribute__((aligned(16))) float red[4][Hd];
@@ -526,28 +529,32 @@ __global__ __launch_bounds__(256) void attn_reg_kernel(const float* __restrict__
 #pragma unroll
   for (int cc = 0; cc < NC; ++cc) *reinterpret_cast<float4*>(&red[wave][cc * 256 + lane * 4]) = acc[cc];
   __syncthreads();
-  for (int j = threadIdx.x; j < Hd; j += 256) o[(int64_t)b * ldo + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+  for (int j = threadIdx.x; j < Hd; j += 256) {
+    const float v = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+    o[(int64_t)b * ldo + j] = v;
+    if (ob) ob[(int64_t)b * ldob + j] = (bf16_t)v;
+  }
 }
 
 template <bool BWD>
 static void attn_launch(hipStream_t s, const float* ctx, const float* u, int64_t ldu, const float* a_in, float* p_out, float* o,
-                        int64_t ldo, int B, int T, int Hd, int ctx_div) {
+                        int64_t ldo, int B, int T, int Hd, int ctx_div, bf16_t* ob, int64_t ldob) {
   if (T <= 64 && Hd == 512)
-    hipLaunchKernelGGL((attn_reg_kernel<2, BWD>), dim3(B), dim3(256), 0, s, ctx, u, ldu, a_in, p_out, o, ldo, T, ctx_div);
+    hipLaunchKernelGGL((attn_reg_kernel<2, BWD>), dim3(B), dim3(256), 0, s, ctx, u, ldu, a_in, p_out, o, ldo, T, ctx_div, ob, ldob);
   else if (T <= 64 && Hd == 256)
-    hipLaunchKernelGGL((attn_reg_kernel<1, BWD>), dim3(B), dim3(256), 0, s, ctx, u, ldu, a_in, p_out, o, ldo, T, ctx_div);
+    hipLaunchKernelGGL((attn_reg_kernel<1, BWD>), dim3(B), dim3(256), 0, s, ctx, u, ldu, a_in, p_out, o, ldo, T, ctx_div, ob, ldob);
   else
     hipLaunchKernelGGL((attn_core_kernel<BWD>), dim3(B), dim3(256), (size_t)(T + 8) * sizeof(float), s, ctx, u, ldu, a_in, p_out, o, ldo,
-                       T, Hd, ctx_div);
+                       T, Hd, ctx_div, ob, ldob);
 }
 void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a, float* c, int64_t ldc, int B, int T, int Hd,
-                       int ctx_div) {
-  attn_launch<false>(s, ctx, q, (int64_t)Hd, nullptr, a, c, ldc, B, T, Hd, ctx_div);
+                       int ctx_div, bf16_t* cb, int64_t ldcb) {
+  attn_launch<false>(s, ctx, q, (int64_t)Hd, nullptr, a, c, ldc, B, T, Hd, ctx_div, cb, ldcb);
 }
 void attention_backward(hipStream_t s, const float* ctx, const float* q, const float* a, const float* dc, int64_t lddc,
-                        float* ds, float* dq, int B, int T, int Hd) {
+                        float* ds, float* dq, int B, int T, int Hd, bf16_t* dqb) {
   (void)q;
-  attn_launch<true>(s, ctx, dc, lddc, a, ds, dq, (int64_t)Hd, B, T, Hd, 1);
+  attn_launch<true>(s, ctx, dc, lddc, a, ds, dq, (int64_t)Hd, B, T, Hd, 1, dqb, (int64_t)Hd);
 }
 
 // d(ctx)[b,t,j] = sum_l a[l,b,t]*dc[l,b,j] + ds[l,b,t]*q[l,b,j]  (model.lua:652-653 accumulated over the decoder loop)
@@ -697,15 +704,17 @@ void embedding_scatter_accum(hipStream_t s, const float* demb, const int32_t* to
 }
 
 __global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
-                                                   const float* __restrict__ out, float* __restrict__ dpre, int64_t n) {
+                                                   const float* __restrict__ out, float* __restrict__ dpre, int64_t n, bf16_t* __restrict__ dpreb) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float g = g1[i] + (g2 ? g2[i] : 0.f);
   float o = out[i];
-  dpre[i] = g * (1.f - o * o);
+  const float v = g * (1.f - o * o);
+  dpre[i] = v;
+  if (dpreb) dpreb[i] = (bf16_t)v;
 }
-void dpre_tanh(hipStream_t s, const float* g1, const float* g2, const float* out, float* dpre, int64_t n) {
-  hipLaunchKernelGGL(dpre_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, g1, g2, out, dpre, n);
+void dpre_tanh(hipStream_t s, const float* g1, const float* g2, const float* out, float* dpre, int64_t n, bf16_t* dpreb) {
+  hipLaunchKernelGGL(dpre_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, g1, g2, out, dpre, n, dpreb);
 }
 __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst, int64_t ldd,
                                                      int rows, int cols) {
@@ -713,6 +722,16 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ s
   if (i >= (int64_t)rows * cols) return;
   int c = (int)(i % cols); int64_t r = i / cols;
   dst[r * ldd + c] = src[r * lds + c];
+}
+__global__ __launch_bounds__(256) void copy2d_bf16_kernel(const float* __restrict__ src, int64_t lds, bf16_t* __restrict__ dst, int64_t ldd,
+                                                          int rows, int cols) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  int c = (int)(i % cols); int64_t r = i / cols;
+  dst[r * ldd + c] = (bf16_t)src[r * lds + c];
+}
+void copy2d_bf16(hipStream_t s, const float* src, int64_t lds, bf16_t* dst, int64_t ldd, int rows, int cols) {
+  hipLaunchKernelGGL(copy2d_bf16_kernel, dim3(cdiv((int64_t)rows * cols, 256)), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
 }
 void copy2d(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols) {
   hipLaunchKernelGGL(copy2d_kernel, dim3(cdiv((int64_t)rows * cols, 256)), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
