@@ -371,6 +371,9 @@ struct LoadMNh {
   __device__ __forceinline__ Ctx8 row8(int r) const { Ctx8 c; c.ok = r + 7 < rows; c.b = p + (c.ok ? r : 0); return c; }
   __device__ __forceinline__ Cur seek(const Ctx8&, int k) const { Cur c; c.k = k; return c; }
   __device__ __forceinline__ void advance(Cur& c) const { c.k += 32; }
+  __device__ __forceinline__ uint4 load8(const Ctx8& c, const Cur& u) const {        // 8 rows of ONE k
+    return (c.ok && u.k < K) ? *reinterpret_cast<const uint4*>(c.b + (int64_t)u.k * ld) : make_uint4(0, 0, 0, 0);
+  }
   __device__ __forceinline__ void load8x4(uint4 (&v)[4], const Ctx8& c, const Cur& u) const {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
@@ -674,23 +677,18 @@ __device__ __forceinline__ s16x4 lds_tr_read(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
 }
 
-template <class EP>
-__global__ __launch_bounds__(256, 4) void conv_wgrad_tr_kernel(LoadMNh a, LoadConvXcolh b, EP ep, int K, int kper, int gx, int gy) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][32 * TR_PITCH];
+template <class BL, class EP>
+__device__ __forceinline__ void tr_tile(const LoadMNh& a, const BL& b, const EP& ep, int m_blk, int n_blk, int kbeg, int kend,
+                                        unsigned char (&lds)[2][2][32 * TR_PITCH]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-  const int nwg = gx * gy, orig = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int m_blk = (bid / gx) * 128, n_blk = (bid % gx) * 128;
-  const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
   const int nk = (kend - kbeg + 31) >> 5;
 
   // staging: thread -> k rows (tid>>4) and (tid>>4)+16, 16-byte piece (tid&15) = 8 channels
   const int krow = tid >> 4, piece = tid & 15;
   LoadMNh::Ctx8 ca = a.row8(m_blk + piece * 8);
-  LoadConvXcolh::Ctx8 cb = b.row8(n_blk + piece * 8);
-  LoadConvXcolh::Cur cur0 = b.seek(cb, kbeg + krow), cur1 = b.seek(cb, kbeg + krow + 16);
+  typename BL::Ctx8 cb = b.row8(n_blk + piece * 8);
+  typename BL::Cur cur0 = b.seek(cb, kbeg + krow), cur1 = b.seek(cb, kbeg + krow + 16);
   int ka = kbeg + krow;
   uint4 ra[2], rb[2];
   auto gload = [&]() {
@@ -761,6 +759,16 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_kernel(LoadMNh a, LoadCo
     }
 }
 
+template <class EP>
+__global__ __launch_bounds__(256, 4) void conv_wgrad_tr_kernel(LoadMNh a, LoadConvXcolh b, EP ep, int K, int kper, int gx, int gy) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][32 * TR_PITCH];
+  const int nwg = gx * gy, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int kbeg = blockIdx.z * kper;
+  tr_tile(a, b, ep, (bid / gx) * 128, (bid % gx) * 128, kbeg, min(K, kbeg + kper), lds);
+}
+
 // Grouped form: up to 8 independent contractions of the same operand kinds in ONE launch (the hoisted weight gradients
 // of a recurrent stack are each too small to fill the chip; together their tiles do, without split-K atomics).
 template <class AL, class BL, class EP> struct GroupProblem { AL a; BL b; EP ep; int K, kper, gx, ksplit, first; };
@@ -777,6 +785,19 @@ __global__ __launch_bounds__(256) void gemm_lds_grouped_kernel(GroupArgs<AL, BL,
   const int tile = local / P.ksplit, z = local - tile * P.ksplit;
   const int kbeg = z * P.kper;
   lds_tile<32>(P.a, P.b, P.ep, (tile / P.gx) * 128, (tile % P.gx) * 128, kbeg, min(P.K, kbeg + P.kper), lds);
+}
+// the same grouping over bf16 shadows with transposed LDS reads (A_i [K][M], B_i [K][N] bf16)
+template <class EP>
+__global__ __launch_bounds__(256, 4) void wgrad_tr_grouped_kernel(GroupArgs<LoadMNh, LoadMNh, EP> g) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][32 * TR_PITCH];
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.p[i].first) pi = i;
+  const GroupProblem<LoadMNh, LoadMNh, EP>& P = g.p[pi];
+  const int local = blockIdx.x - P.first;
+  const int tile = local / P.ksplit, z = local - tile * P.ksplit;
+  const int kbeg = z * P.kper;
+  tr_tile(P.a, P.b, P.ep, (tile / P.gx) * 128, (tile % P.gx) * 128, kbeg, min(P.K, kbeg + P.kper), lds);
 }
 
 // ---------------------------------------------------------------------------

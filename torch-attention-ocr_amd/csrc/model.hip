@@ -356,8 +356,11 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       const float* xin = l == 0 ? m->X : m->ehs[dir][l - 1] + slot;
       const float* hprev = m->ehs[dir][l] + (dir == 0 ? 0 : 2 * slot);
       const float* dz = m->edz[dir][l];
-      wg[nwg++] = WGradProblem{dz, 4 * He, xin, p.in, p.dwi, p.in, 4 * He, p.in, T * B};
-      wg[nwg++] = WGradProblem{dz, 4 * He, hprev, He, p.dwh, He, 4 * He, He, T * B};
+      const bf16_t* dzb = m->edz_b[dir][l];
+      const bf16_t* xinb = l == 0 ? m->Xb : (m->ehs_b[dir][l - 1] ? m->ehs_b[dir][l - 1] + slot : nullptr);
+      const bf16_t* hprevb = m->ehs_b[dir][l] ? m->ehs_b[dir][l] + (dir == 0 ? 0 : 2 * slot) : nullptr;
+      wg[nwg++] = WGradProblem{dz, 4 * He, xin, p.in, p.dwi, p.in, 4 * He, p.in, T * B, dzb, xinb};
+      wg[nwg++] = WGradProblem{dz, 4 * He, hprev, He, p.dwh, He, 4 * He, He, T * B, dzb, hprevb};
       colsum_accum(s, dz, 4 * He, (int64_t)T * B, 4 * He, p.dbi);
       colsum_accum(s, dz, 4 * He, (int64_t)T * B, 4 * He, p.dbh);
       if (l == 0) gemm(s, bf, dz, 4 * He, true, p.wi, p.in, false, m->dX, 512, T * B, 512, 4 * He, nullptr, nullptr,
@@ -547,20 +550,22 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   // ---- hoisted parameter gradients (accGradParameters of every clone summed over time)
   const float* h_top_all = m->dhs[Ld - 1] + slot;
   WGradProblem wg[16]; int nwg = 0;
-  wg[nwg++] = WGradProblem{m->dpre_all, Hd, m->cat_all, 2 * Hd, m->dwc, 2 * Hd, Hd, 2 * Hd, rows};
-  wg[nwg++] = WGradProblem{m->dq_all, Hd, h_top_all, Hd, m->dwa, Hd, Hd, Hd, rows};
+  const bool sh = m->bf16 && m->dpre_b != nullptr;
+  wg[nwg++] = WGradProblem{m->dpre_all, Hd, m->cat_all, 2 * Hd, m->dwc, 2 * Hd, Hd, 2 * Hd, rows, m->dpre_b, m->cat_b};
+  wg[nwg++] = WGradProblem{m->dq_all, Hd, h_top_all, Hd, m->dwa, Hd, Hd, Hd, rows, m->dq_b, sh ? m->dhs_b[Ld - 1] + slot : nullptr};
   for (int l = 0; l < Ld; ++l) {
     const LstmP& p = m->dec[l]; const float* dz = m->ddz[l];
-    wg[nwg++] = WGradProblem{dz, 4 * Hd, m->dhs[l], Hd, p.dwh, Hd, 4 * Hd, Hd, rows};
+    const bf16_t* dzb = sh ? m->ddz_b[l] : nullptr;
+    wg[nwg++] = WGradProblem{dz, 4 * Hd, m->dhs[l], Hd, p.dwh, Hd, 4 * Hd, Hd, rows, dzb, sh ? m->dhs_b[l] : nullptr};
     colsum_accum(s, dz, 4 * Hd, rows, 4 * Hd, p.dbi);
     colsum_accum(s, dz, 4 * Hd, rows, 4 * Hd, p.dbh);
     if (l == 0) {
       wg[nwg++] = WGradProblem{dz, 4 * Hd, m->emb_all, E, p.dwi, p.in, 4 * Hd, E, rows};
-      if (m->cfg.input_feed) wg[nwg++] = WGradProblem{dz, 4 * Hd, m->out_all, Hd, p.dwi + E, p.in, 4 * Hd, Hd, rows};
+      if (m->cfg.input_feed) wg[nwg++] = WGradProblem{dz, 4 * Hd, m->out_all, Hd, p.dwi + E, p.in, 4 * Hd, Hd, rows, dzb, sh ? m->out_b : nullptr};
       gemm(s, bf, dz, 4 * Hd, true, p.wi, p.in, false, m->demb_all, E, rows, E, 4 * Hd, nullptr, nullptr, 0);
       embedding_scatter_accum(s, m->demb_all, tgt, 1, L, m->dlookup, L, B, E, V);
     } else {
-      wg[nwg++] = WGradProblem{dz, 4 * Hd, m->dhs[l - 1] + slot, Hd, p.dwi, Hd, 4 * Hd, Hd, rows};
+      wg[nwg++] = WGradProblem{dz, 4 * Hd, m->dhs[l - 1] + slot, Hd, p.dwi, Hd, 4 * Hd, Hd, rows, dzb, sh ? m->dhs_b[l - 1] + slot : nullptr};
     }
   }
   grouped_wgrad(s, bf, wg, nwg);

@@ -77,7 +77,8 @@ int gemm(hipStream_t s, bool bf16, const float* A, int64_t lda, bool a_kmajor, c
 
 // Grouped weight-gradient contractions C_i[M_i,N_i] += A_i^T B_i (A_i [K_i][M_i], B_i [K_i][N_i], all M/N-contiguous fp32):
 // one launch for up to 8 problems; K is split only as far as needed to fill the chip once.
-struct WGradProblem { const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int M, N, K; };
+struct WGradProblem { const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int M, N, K;
+                      const bf16_t* Ab = nullptr; const bf16_t* Bb = nullptr; };     // optional bf16 shadows of A and B (same lda/ldb)
 void grouped_wgrad(hipStream_t s, bool bf16, const WGradProblem* p, int n);
 
 // ---- convolution layers (ops_gemm.hip)

@@ -130,30 +130,45 @@ int gemm(hipStream_t s, bool bf16, const float* A, int64_t lda, bool a_k, const 
   return 0;
 }
 
+template <class LD, class KERNEL>
+static void grouped_launch(hipStream_t s, const WGradProblem* const* q, int cnt, int slots, bool shadows, KERNEL kernel) {
+  int64_t tiles = 0;
+  for (int i = 0; i < cnt; ++i) tiles += (int64_t)cdiv(q[i]->M, 128) * cdiv(q[i]->N, 128);
+  int ks = (int)(slots / tiles); if (ks < 1) ks = 1;          // common split: fill one resident round
+  GroupArgs<LD, LD, EpStore> g; g.n = cnt; int first = 0;
+  for (int i = 0; i < cnt; ++i) {
+    auto& P = g.p[i];
+    int ksplit = ks, kper; split_k(q[i]->K, 32, ksplit, kper);
+    if constexpr (std::is_same<LD, LoadMNh>::value) {
+      P.a.p = q[i]->Ab; P.a.ld = q[i]->lda; P.a.rows = q[i]->M; P.a.K = q[i]->K;
+      P.b.p = q[i]->Bb; P.b.ld = q[i]->ldb; P.b.rows = q[i]->N; P.b.K = q[i]->K;
+    } else {
+      P.a = make_loadmn(q[i]->A, q[i]->lda, q[i]->M, q[i]->K); P.b = make_loadmn(q[i]->B, q[i]->ldb, q[i]->N, q[i]->K);
+    }
+    P.ep = make_store(q[i]->C, q[i]->ldc, q[i]->M, q[i]->N, nullptr, nullptr, ksplit > 1 ? EP_ATOMIC : EP_ACCUM);
+    P.K = q[i]->K; P.kper = kper; P.gx = cdiv(q[i]->N, 128); P.ksplit = ksplit; P.first = first;
+    first += cdiv(q[i]->M, 128) * P.gx * ksplit;
+  }
+  g.total = first; (void)shadows;
+  hipLaunchKernelGGL(kernel, dim3(first), dim3(256), 0, s, g);
+}
+
 void grouped_wgrad(hipStream_t s, bool bf16, const WGradProblem* p, int n) {
   if (!bf16) {                                                // fp32 mode: one launch per problem
     for (int i = 0; i < n; ++i)
       gemm(s, false, p[i].A, p[i].lda, false, p[i].B, p[i].ldb, false, p[i].C, p[i].ldc, p[i].M, p[i].N, p[i].K, nullptr, nullptr, EP_ATOMIC);
     return;
   }
-  for (int base = 0; base < n; base += 8) {
-    const int cnt = std::min(8, n - base);
-    int64_t tiles = 0;
-    for (int i = 0; i < cnt; ++i) tiles += (int64_t)cdiv(p[base + i].M, 128) * cdiv(p[base + i].N, 128);
-    int ks = (int)(768 / tiles); if (ks < 1) ks = 1;          // common split: fill one resident round
-    GroupArgs<LoadMN, LoadMN, EpStore> g; g.n = cnt; int first = 0;
-    for (int i = 0; i < cnt; ++i) {
-      const WGradProblem& q = p[base + i];
-      auto& P = g.p[i];
-      int ksplit = ks, kper; split_k(q.K, 32, ksplit, kper);
-      P.a = make_loadmn(q.A, q.lda, q.M, q.K); P.b = make_loadmn(q.B, q.ldb, q.N, q.K);
-      P.ep = make_store(q.C, q.ldc, q.M, q.N, nullptr, nullptr, ksplit > 1 ? EP_ATOMIC : EP_ACCUM);
-      P.K = q.K; P.kper = kper; P.gx = cdiv(q.N, 128); P.ksplit = ksplit; P.first = first;
-      first += cdiv(q.M, 128) * P.gx * ksplit;
-    }
-    g.total = first;
-    hipLaunchKernelGGL((gemm_lds_grouped_kernel<LoadMN, LoadMN, EpStore>), dim3(first), dim3(256), 0, s, g);
+  // problems whose operands both have bf16 shadows (16-byte pieces: M, N, lda, ldb multiples of 8) take the transposed-read kernel
+  const WGradProblem* hs[16]; const WGradProblem* fs[16]; int nh = 0, nf = 0;
+  for (int i = 0; i < n && i < 16; ++i) {
+    const bool ok = p[i].Ab && p[i].Bb && p[i].M % 8 == 0 && p[i].N % 8 == 0 && p[i].lda % 8 == 0 && p[i].ldb % 8 == 0;
+    if (ok) hs[nh++] = &p[i]; else fs[nf++] = &p[i];
   }
+  for (int base = 0; base < nh; base += 8)
+    grouped_launch<LoadMNh>(s, hs + base, std::min(8, nh - base), 1024, true, wgrad_tr_grouped_kernel<EpStore>);
+  for (int base = 0; base < nf; base += 8)
+    grouped_launch<LoadMN>(s, fs + base, std::min(8, nf - base), 768, false, gemm_lds_grouped_kernel<LoadMN, LoadMN, EpStore>);
 }
 
 // ---------------------------------------------------------------------------------------------
