@@ -87,6 +87,7 @@ static void bind_params(aocr_model* m) {
       // input-feed columns [E, E+Hd)), and W_h2h
       const int skip = p.in - H;
       p.swi.w = p.wi + (skip > 0 ? skip : 0); p.swi.ld = p.in; p.swi.R = 4 * H; p.swi.C = H;
+      if (in0 == 512 && l == 1) { p.swi.w = p.wi; p.swi.C = 512; }                  // encoder layer 1: the whole W_i2h (hoisted GEMMs)
       p.swh.w = p.wh; p.swh.ld = H; p.swh.R = 4 * H; p.swh.C = H;
     }
   };

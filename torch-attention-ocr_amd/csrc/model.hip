@@ -98,7 +98,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     auto sh = [&](ShW& w, size_t R_, size_t C_) {
       w.wb = m->bf16 ? a.get<bf16_t>(R_ * C_) : nullptr; w.wtb = m->bf16 ? a.get<bf16_t>(R_ * C_) : nullptr;
     };
-    for (int dir = 0; dir < 2; ++dir) for (int l = 0; l < m->Le; ++l) { sh(m->enc[dir][l].swh, 4 * He, He); m->enc[dir][l].swi.wb = m->enc[dir][l].swi.wtb = nullptr; }
+    for (int dir = 0; dir < 2; ++dir) for (int l = 0; l < m->Le; ++l) { sh(m->enc[dir][l].swh, 4 * He, He); sh(m->enc[dir][l].swi, 4 * He, l == 0 ? 512 : He); }
     for (int l = 0; l < m->Ld; ++l) { sh(m->dec[l].swi, 4 * Hd, Hd); sh(m->dec[l].swh, 4 * Hd, Hd); }
     sh(m->swa, Hd, Hd); sh(m->swc, Hd, 2 * Hd);
   }
@@ -155,7 +155,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
 static void refresh_rnn_shadows(aocr_model* m) {
   if (!m->bf16) return;
   auto up = [&](const ShW& w) { if (w.wb) weight_shadows(m->s, w.w, w.ld, w.R, w.C, w.wb, w.wtb); };
-  for (int dir = 0; dir < 2; ++dir) for (int l = 0; l < m->Le; ++l) up(m->enc[dir][l].swh);
+  for (int dir = 0; dir < 2; ++dir) for (int l = 0; l < m->Le; ++l) { up(m->enc[dir][l].swh); up(m->enc[dir][l].swi); }
   for (int l = 0; l < m->Ld; ++l) { if (l > 0 || m->cfg.input_feed) up(m->dec[l].swi); up(m->dec[l].swh); }
   up(m->swa); up(m->swc);
 }
@@ -281,7 +281,11 @@ void encoder_forward(aocr_model* m, const Dims& d) {
     for (int dir = 0; dir < 2; ++dir) {
       const LstmP& p = m->enc[dir][l];
       const float* xin = l == 0 ? m->X : m->ehs[dir][l - 1] + slot;        // Dropout(0) = identity (S6)
-      gemm(s, bf, xin, p.in, true, p.wi, p.in, true, m->ezx[dir][l], 4 * He, T * B, 4 * He, p.in, p.bi, p.bh, 0);
+      const bf16_t* xinb = l == 0 ? m->Xb : (m->ehs_b[dir][l - 1] ? m->ehs_b[dir][l - 1] + slot : nullptr);
+      if (bf && xinb && p.swi.wb && p.in % 32 == 0)
+        gemm_hh(s, xinb, p.in, p.swi.wb, p.in, m->ezx[dir][l], 4 * He, T * B, 4 * He, p.in, p.bi, p.bh, 0);
+      else
+        gemm(s, bf, xin, p.in, true, p.wi, p.in, true, m->ezx[dir][l], 4 * He, T * B, 4 * He, p.in, p.bi, p.bh, 0);
       hipMemsetAsync(m->ehs[dir][l], 0, slot * sizeof(float), s);
       hipMemsetAsync(m->ehs[dir][l] + (size_t)(T + 1) * slot, 0, slot * sizeof(float), s);
       hipMemsetAsync(m->ecs[dir][l], 0, slot * sizeof(float), s);
@@ -363,9 +367,10 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       wg[nwg++] = WGradProblem{dz, 4 * He, hprev, He, p.dwh, He, 4 * He, He, T * B, dzb, hprevb};
       colsum_accum(s, dz, 4 * He, (int64_t)T * B, 4 * He, p.dbi);
       colsum_accum(s, dz, 4 * He, (int64_t)T * B, 4 * He, p.dbh);
-      if (l == 0) gemm(s, bf, dz, 4 * He, true, p.wi, p.in, false, m->dX, 512, T * B, 512, 4 * He, nullptr, nullptr,
-                       dir == 0 ? 0 : EP_ACCUM);                                     // model.lua:675 copy, :689 add
-      else gemm(s, bf, dz, 4 * He, true, p.wi, p.in, false, m->edxl[dir], He, T * B, He, 4 * He, nullptr, nullptr, 0);
+      float* dxo = l == 0 ? m->dX : m->edxl[dir];
+      const int dxf = (l == 0 && dir == 1) ? EP_ACCUM : 0;                          // model.lua:675 copy, :689 add
+      if (bf && dzb && p.swi.wtb) gemm_hh(s, dzb, 4 * He, p.swi.wtb, 4 * He, dxo, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dxf);
+      else gemm(s, bf, dz, 4 * He, true, p.wi, p.in, false, dxo, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dxf);
     }
     grouped_wgrad(s, bf, wg, nwg);
   }

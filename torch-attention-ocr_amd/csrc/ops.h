@@ -81,6 +81,10 @@ struct WGradProblem { const float* A; int64_t lda; const float* B; int64_t ldb; 
                       const bf16_t* Ab = nullptr; const bf16_t* Bb = nullptr; };     // optional bf16 shadows of A and B (same lda/ldb)
 void grouped_wgrad(hipStream_t s, bool bf16, const WGradProblem* p, int n);
 
+// C = A B^T (+bias) with both operands read from K-contiguous bf16 shadows (A [M][K], B [N][K])
+void gemm_hh(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
+             const float* bias, const float* bias2, int flags);
+
 // ---- convolution layers (ops_gemm.hip)
 // xb/wb/dyb/wtb: optional bf16 shadows of the operands (both of a contraction's operands must be given to take the
 // bf16-source path); yb: optional bf16 shadow of the output to write.

@@ -130,6 +130,13 @@ int gemm(hipStream_t s, bool bf16, const float* A, int64_t lda, bool a_k, const 
   return 0;
 }
 
+void gemm_hh(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
+             const float* bias, const float* bias2, int flags) {
+  LoadKh a; a.p = A; a.ld = lda; a.rows = M; a.K = K;
+  LoadKh b; b.p = B; b.ld = ldb; b.rows = N; b.K = K;
+  launch_lds(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K, 1);
+}
+
 template <class LD, class KERNEL>
 static void grouped_launch(hipStream_t s, const WGradProblem* const* q, int cnt, int slots, bool shadows, KERNEL kernel) {
   int64_t tiles = 0;
