@@ -266,7 +266,8 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   unpool_relu_backward(s, G1, m->A2, m->idx2, G0, B, d.H1, d.W1, 128, 1, G0b);
   conv_backward_filter(s, bf, m->A1, G0, m->conv[2].dw, m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1, m->A1b, G0b);
   conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1, G0b, m->wtb[2]);
-  conv1_backward(s, images, m->conv[1].w, m->conv[1].b, G1, m->conv[1].dw, m->conv[1].db, B, d.H, d.W);
+  conv1_backward(s, images, m->conv[1].w, m->conv[1].b, G1, m->conv[1].dw, m->conv[1].db, B, d.H, d.W,
+                 (size_t)B * d.H1 * d.W1 * 128 >= (size_t)4096 * 640 ? G0 : nullptr);      // G0 is free here: use it as the partial slab
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -101,7 +101,7 @@ void conv1_forward(hipStream_t s, const float* x, const float* w, const float* b
                    bf16_t* yb = nullptr);
 void conv_weight_shadows(hipStream_t s, const float* w, bf16_t* wb, bf16_t* wtb, int Cout, int KK, int Cin);
 void conv1_backward(hipStream_t s, const float* x, const float* w, const float* bias, const float* dyp, float* dw, float* db,
-                    int B, int H, int W);
+                    int B, int H, int W, float* scratch = nullptr);
 void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pooled, const uint8_t* idx, float* dy, int B,
                           int Ho, int Wo, int C, int pool, bf16_t* dyb = nullptr);
 size_t bn_scratch_bytes(int C);

@@ -83,10 +83,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ dyp,
                                                         float* __restrict__ dw, float* __restrict__ db, int B, int H, int W,
-                                                        int Hp, int Wp) {
+                                                        int Hp, int Wp, float* __restrict__ partial) {
   __shared__ float sw[64 * 9 + 64];
-  __shared__ float sacc[64 * 10];
-  for (int i = threadIdx.x; i < 640; i += 256) { sw[i] = i < 576 ? w[i] : bias[i - 576]; sacc[i] = 0.f; }
+  for (int i = threadIdx.x; i < 640; i += 256) sw[i] = i < 576 ? w[i] : bias[i - 576];
   __syncthreads();
   const int cq = threadIdx.x & 15;
   float acc[4][10];
@@ -128,14 +127,23 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
       }
     }
   }
+  // lanes l, l+16, l+32, l+48 of a wave hold the same channel quad: butterfly over them, then one LDS slot per wave
+  __shared__ float swave[4][640];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int k = 0; k < 10; ++k) atomicAdd(&sacc[(cq * 4 + c) * 10 + k], acc[c][k]);
+    for (int k = 0; k < 10; ++k) {
+      float v = acc[c][k];
+      v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      if (lane < 16) swave[wave][(cq * 4 + c) * 10 + k] = v;
+    }
   __syncthreads();
   for (int i = threadIdx.x; i < 640; i += 256) {
+    const float t = (swave[0][i] + swave[1][i]) + (swave[2][i] + swave[3][i]);
     int c = i / 10, k = i % 10;
-    if (k < 9) atomicAdd(&dw[c * 9 + k], sacc[i]); else atomicAdd(&db[c], sacc[i]);
+    if (partial) partial[(int64_t)blockIdx.x * 640 + (k < 9 ? c * 9 + k : 576 + c)] = t;     // per-workgroup slab, summed by colsum
+    else if (k < 9) atomicAdd(&dw[c * 9 + k], t); else atomicAdd(&db[c], t);
   }
 }
 
@@ -146,11 +154,17 @@ void conv1_forward(hipStream_t s, const float* x, const float* w, const float* b
   hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, y, yb, B, H, W, Hp, Wp);
 }
 void conv1_backward(hipStream_t s, const float* x, const float* w, const float* bias, const float* dyp, float* dw, float* db,
-                    int B, int H, int W) {
+                    int B, int H, int W, float* scratch) {
   int Hp = H / 2, Wp = W / 2;
   int64_t total = (int64_t)B * Hp * Wp * 16;
-  int blocks = (int)std::min<int64_t>((total + 255) / 256, 1024);
-  hipLaunchKernelGGL(conv1_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, dyp, dw, db, B, H, W, Hp, Wp);
+  // with a scratch slab (>= 4096*640 floats) every workgroup writes its partial sums and two column sums finish the job:
+  // no contended global atomics, more workgroups
+  int blocks = (int)std::min<int64_t>((total + 255) / 256, scratch ? 2048 : 1024);
+  hipLaunchKernelGGL(conv1_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, dyp, dw, db, B, H, W, Hp, Wp, scratch);
+  if (scratch) {
+    colsum_accum(s, scratch, 640, blocks, 576, dw);
+    colsum_accum(s, scratch + 576, 640, blocks, 64, db);
+  }
 }
 
 // =============================================================================================
