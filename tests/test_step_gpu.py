@@ -86,6 +86,25 @@ def test_train_step_parity_small(cuda, case):
     m.shutdown()
 
 
+@pytest.mark.parametrize("W,compute", [(70, "f32"), (132, "f32"), (70, "bf16"), (200, "bf16")])
+def test_ragged_widths(cuda, W, compute):
+    """Widths whose intermediate maps are odd (floor-mode pooling drops a column: cnn.lua:15,20) and a T > 64 case
+    (generic attention kernel); batch not a multiple of the 32-row tile."""
+    m, O, ocfg, P, st, batch = make(CASES[0], B=3, W=W, maxlen=5, compute=compute)
+    img, tgt, tge = (torch.from_numpy(np.asarray(x)) for x in batch[:3])
+    loss_ref, G, aux, _ = O.train_step_manual(P, st, ocfg, img, tgt, tge)
+    loss = m.train_forward_backward(batch)
+    lg = m.get_tensor("logits")[:, :, :ocfg.vocab]
+    e = (lg.double() - aux["logits"]).abs().max().item()
+    print(f"[parity] W={W} {compute}: T={aux['context'].shape[1]} logits max-abs {e:.3e}; loss {loss:.4f} vs {float(loss_ref) * 3:.4f}")
+    assert e < (LOGIT_TOL if compute == "f32" else 5e-2)
+    if compute == "f32":
+        grads = m.get_gradients()
+        for k in ("cnn.conv2.w", "cnn.conv4.w", "cnn.conv7.w", "enc_bw.l1.i2h.w", "dec.attn.wa", "dec.lookup"):
+            r = relerr(grads[k], G[k]); print(f"[parity] W={W} grad {k} rel {r:.3e}"); assert r < 2e-3, k
+    m.shutdown()
+
+
 @pytest.mark.parametrize("case,beam", [(0, 1), (0, 5), (1, 3), (2, 1), (3, 5)])
 def test_decode_parity_small(cuda, case, beam):
     m, O, ocfg, P, st, batch = make(CASES[case], B=4, W=36, maxlen=5, max_decoder_l=10)
