@@ -653,32 +653,46 @@ void gold_scores(hipStream_t s, const float* nll_rows, float* gold, int L, int B
   hipLaunchKernelGGL(gold_kernel, dim3(cdiv(B, 128)), dim3(128), 0, s, nll_rows, gold, L, B);
 }
 
-// out[n] += sum_r A[r][n]   (bias gradients).  grid = (column blocks of 64, row chunks); each block reduces its
-// chunk in registers + LDS and issues one 256-byte atomic add per wave-row (HBM-bound: reads A once).
+// out[n] += sum_r A[r][n]   (bias gradients).  grid = (column blocks of 64, row chunks); a workgroup is 16 row lanes x
+// 16 column quads (dwordx4 loads, two rows in flight per lane), reduced through LDS; one atomic per column per workgroup.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t ld, int64_t rows, int N, float* out) {
-  __shared__ float sh[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + cl;
+  __shared__ float sh[16][65];
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int n = blockIdx.x * 64 + cq * 4;
   const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
   const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(rows, r0 + per);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (n < N) {
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), t = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool vec = (n + 3 < N) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  if (vec) {
     int64_t r = r0 + rl;
-    for (; r + 12 < r1; r += 16) {
-      s0 += A[r * ld + n]; s1 += A[(r + 4) * ld + n]; s2 += A[(r + 8) * ld + n]; s3 += A[(r + 12) * ld + n];
+    for (; r + 16 < r1; r += 32) {
+      float4 a = *reinterpret_cast<const float4*>(A + r * ld + n), b = *reinterpret_cast<const float4*>(A + (r + 16) * ld + n);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
     }
-    for (; r < r1; r += 4) s0 += A[r * ld + n];
+    for (; r < r1; r += 16) { float4 a = *reinterpret_cast<const float4*>(A + r * ld + n); s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; }
+  } else {
+    for (int64_t r = r0 + rl; r < r1; r += 16) {
+      if (n < N) s.x += A[r * ld + n];
+      if (n + 1 < N) s.y += A[r * ld + n + 1];
+      if (n + 2 < N) s.z += A[r * ld + n + 2];
+      if (n + 3 < N) s.w += A[r * ld + n + 3];
+    }
   }
-  sh[rl][cl] = (s0 + s1) + (s2 + s3);
+  sh[rl][cq * 4] = s.x + t.x; sh[rl][cq * 4 + 1] = s.y + t.y; sh[rl][cq * 4 + 2] = s.z + t.z; sh[rl][cq * 4 + 3] = s.w + t.w;
   __syncthreads();
-  if (rl == 0 && n < N) {
-    float t = sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl];
-    if (gridDim.y == 1) out[n] += t; else atomicAdd(&out[n], t);
+  if (threadIdx.x < 64) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v += sh[i][threadIdx.x];
+      if (gridDim.y == 1) out[c] += v; else atomicAdd(&out[c], v);
+    }
   }
 }
 void colsum_accum(hipStream_t s, const float* A, int64_t ld, int64_t rows, int N, float* out) {
   int nb = cdiv(N, 64);
-  int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, 2048 / nb), (rows + 255) / 256);
+  int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, 2048 / nb), (rows + 511) / 512);
   hipLaunchKernelGGL(colsum_kernel, dim3(nb, chunks), dim3(256), 0, s, A, ld, rows, N, out);
 }
 
@@ -696,25 +710,31 @@ void embedding_gather(hipStream_t s, const float* table, const int32_t* tok, int
 }
 __global__ __launch_bounds__(256) void emb_scatter_kernel(const float* __restrict__ demb, const int32_t* __restrict__ tok, int64_t st,
                                                           int64_t sb, float* dtable, int L, int B, int E) {
-  __shared__ float sh[4];
-  const int v = blockIdx.x;                                     // one workgroup per vocabulary row: deterministic, no atomics
+  extern __shared__ float part[];                               // [row lanes][E]; one workgroup per vocabulary row, no atomics
+  const int v = blockIdx.x;
   const int rows = L * B;
-  for (int e = 0; e < E; ++e) {
-    float s = 0.f;
-    for (int r = threadIdx.x; r < rows; r += 256) {
+  const int nrl = 256 / E;                                      // row lanes (E <= 256)
+  const int e = threadIdx.x % E, rl = threadIdx.x / E;
+  float s = 0.f;
+  if (rl < nrl) {
+#pragma unroll 8
+    for (int r = rl; r < rows; r += nrl) {                      // unconditional loads: 8 independent rows in flight
       int t = r / B, b = r - t * B;
-      if (tok[t * st + b * sb] - 1 == v) s += demb[(int64_t)r * E + e];
+      const float d = demb[(int64_t)r * E + e];
+      s += (tok[t * st + b * sb] - 1 == v) ? d : 0.f;
     }
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) dtable[(int64_t)v * E + e] += sh[0] + sh[1] + sh[2] + sh[3];
-    __syncthreads();
+  }
+  if (rl < nrl) part[rl * E + e] = s;
+  __syncthreads();
+  if (threadIdx.x < E) {
+    float t = 0.f;
+    for (int i = 0; i < nrl; ++i) t += part[i * E + threadIdx.x];
+    dtable[(int64_t)v * E + threadIdx.x] += t;
   }
 }
 void embedding_scatter_accum(hipStream_t s, const float* demb, const int32_t* tok, int64_t st, int64_t sb, float* dtable, int L,
                              int B, int E, int V) {
-  hipLaunchKernelGGL(emb_scatter_kernel, dim3(V), dim3(256), 0, s, demb, tok, st, sb, dtable, L, B, E);
+  hipLaunchKernelGGL(emb_scatter_kernel, dim3(V), dim3(256), (size_t)256 * sizeof(float), s, demb, tok, st, sb, dtable, L, B, E);
 }
 
 __global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
