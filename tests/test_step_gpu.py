@@ -156,3 +156,60 @@ def test_bf16_path_runs_close(cuda, case):
         print(f"[parity] bf16 grad {k}: rel {relerr(grads[k], G[k]):.3e} cosine {cos:.5f}")
         assert cos > 0.97, k          # tiny-batch BatchNorm + pool arg-max flips make max-rel meaningless in bf16
     m.shutdown()
+
+
+def test_dma_conv_kernel_matches_tiled_kernel(cuda, monkeypatch):
+    """The 256x256x64 LDS-DMA conv kernel (forward + data gradient) against the 128x128 register-staged bf16 kernel on
+    the same bf16 operands: only the fp32 accumulation order differs, so features, logits and every gradient must agree
+    far inside the bf16-vs-oracle tolerance.  AOCR_FORCE_DMA=1 selects the DMA kernel wherever its shape rules hold
+    (it is otherwise chosen only when the grid fills the 256 CUs)."""
+    cfg = dict(enc_hidden=64, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for force in ("0", "1"):
+        monkeypatch.setenv("AOCR_FORCE_DMA", force)
+        m, O, ocfg, P, st, batch = make(cfg, B=6, W=72, maxlen=6, compute="bf16")
+        loss = m.train_forward_backward(batch)
+        out[force] = dict(loss=loss, feats=m.get_tensor("feats").clone(), conv6=m.get_tensor("conv6").clone(),
+                          logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.shutdown()
+    a, b = out["0"], out["1"]
+    for k in ("conv6", "feats", "logits"):
+        e = (a[k].double() - b[k].double()).abs().max().item()
+        print(f"[parity] dma-vs-tiled {k} max-abs {e:.3e}")
+        assert e < 2e-3, k        # bf16 re-rounding of activations that differ in the last fp32 bits
+    assert abs(a["loss"] - b["loss"]) < 1e-3 * max(1.0, abs(a["loss"]))
+    worst = 0.0
+    for k in a["grads"]:
+        e = relerr(b["grads"][k], a["grads"][k]); worst = max(worst, e)
+        assert e < 2e-2, (k, e)
+    print(f"[parity] dma-vs-tiled worst gradient rel {worst:.3e}")
+
+
+@pytest.mark.parametrize("He,B,W", [(64, 16, 40), (256, 32, 72), (128, 16, 36)])
+def test_seq_encoder_kernels_match_step_kernels(cuda, monkeypatch, He, B, W):
+    """Whole-sequence BiLSTM encoder kernels (one workgroup owns 16 batch rows for all T steps, weights re-streamed by
+    LDS-DMA) against the per-step kernels on the same bf16 operands: only fp32 summation order differs.
+    AOCR_NO_SEQ=1 forces the per-step path."""
+    cfg = dict(enc_hidden=He, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for no_seq in ("0", "1"):          # whole-sequence path first: it must not be able to inherit the other run's buffers
+        monkeypatch.setenv("AOCR_NO_SEQ", no_seq)
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=6, compute="bf16")
+        loss = m.train_forward_backward(batch)
+        out[no_seq] = dict(loss=loss, context=m.get_tensor("context").clone(), logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(),
+                           dfeats=m.get_tensor("dfeats").clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.shutdown()
+    a, b = out["1"], out["0"]
+    for k in ("context", "logits"):
+        e = (a[k].double() - b[k].double()).abs().max().item()
+        print(f"[parity] seq-vs-step He={He} {k} max-abs {e:.3e}")
+        assert e < 5e-3, k        # bf16 re-rounding of h(t) after a different fp32 summation order, compounded over T steps
+    assert abs(a["loss"] - b["loss"]) < 2e-3 * max(1.0, abs(a["loss"]))
+    e = relerr(b["dfeats"], a["dfeats"]); print(f"[parity] seq-vs-step dfeats rel {e:.3e}"); assert e < 3e-2
+    worst = 0.0
+    for k in a["grads"]:
+        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):      # bias in front of a BatchNorm: exact gradient 0, only rounding noise
+            continue
+        e = relerr(b["grads"][k], a["grads"][k]); worst = max(worst, e)
+        assert e < 3e-2, (k, e)
+    print(f"[parity] seq-vs-step worst gradient rel {worst:.3e}")

@@ -329,6 +329,12 @@ typedef __bf16 bf16_t;
 
 // Each loader keeps a cursor that the stager advances by 32 k per tile, so the steady state has no integer division.
 
+// pointer select without control flow (hipcc otherwise branches around the address arithmetic, which splits the K loop of
+// the LDS-DMA kernel into several basic blocks and makes its waitcnt insertion conservative)
+__device__ __forceinline__ const bf16_t* dma_select(bool ok, const bf16_t* p, const bf16_t* zero) {
+  const uint64_t m = ok ? ~0ull : 0ull;
+  return reinterpret_cast<const bf16_t*>((reinterpret_cast<uint64_t>(p) & m) | (reinterpret_cast<uint64_t>(zero) & ~m));
+}
 // K-contiguous bf16: element(r,k) = p[r*ld + k]; 16-byte aligned rows (ld % 8 == 0).
 struct LoadKh {
   const bf16_t* p; int64_t ld; int rows; int K;
@@ -341,6 +347,15 @@ struct LoadKh {
     int k = u.k + 8 * chunk;
     if (c.ok && k + 8 <= K) return *reinterpret_cast<const uint4*>(c.b + k);
     return make_uint4(0, 0, 0, 0);
+  }
+  // LDS-DMA staging (gemm_dma_bf16_kernel): per-row source pointer of this lane's 16-byte chunk, 32 k per tile
+  struct DRow { const bf16_t* b; };                   // nullptr: row outside the operand -> zero page
+  struct DCur { int k; };
+  __device__ __forceinline__ DRow drow(int r, int chunk) const { DRow d; d.b = r < rows ? p + (int64_t)r * ld + 8 * chunk : nullptr; return d; }
+  __device__ __forceinline__ DCur dseek(int k) const { DCur c; c.k = k; return c; }
+  __device__ __forceinline__ void dadvance(DCur& c) const { c.k += 32; }
+  __device__ __forceinline__ const bf16_t* dsrc(const DRow& d, const DCur& u, const bf16_t* zero) const {
+    return dma_select(d.b != nullptr && u.k < K, d.b + u.k, zero);
   }
 };
 // implicit im2col over a bf16 channels-last tensor (same geometry as LoadConvK); cursor = (kh, kw, first channel) of the tile
@@ -361,6 +376,25 @@ struct LoadConvKh {
     bool ok = c.ok && u.k < g.K && (unsigned)sy < (unsigned)g.H && (unsigned)sx < (unsigned)g.W;
     if (ok) return *reinterpret_cast<const uint4*>(src + (((int64_t)c.b * g.H + sy) * g.W + sx) * g.C + u.ch + 8 * chunk);
     return make_uint4(0, 0, 0, 0);
+  }
+  // LDS-DMA staging: C % 32 == 0, so a 32-k tile is 32 channels of ONE tap and (kh, kw, ch) are wave-uniform scalars;
+  // per row only the two bounds compares and a pointer select remain.  Taps outside the map read the zero page.
+  struct DRow { const bf16_t* b; int y, x; };         // b = &src[b, y+off, x+off, 8*chunk] (may point outside; never dereferenced then)
+  struct DCur { int kh, kw, ch, k; };
+  __device__ __forceinline__ DRow drow(int m, int chunk) const {
+    Ctx c = g.row(m); DRow d; d.y = c.ok ? c.y + g.off : -(1 << 20); d.x = c.x + g.off;
+    d.b = src + (((int64_t)c.b * g.H + (c.y + g.off)) * g.W + (c.x + g.off)) * g.C + 8 * chunk; return d;
+  }
+  __device__ __forceinline__ DCur dseek(int k) const { DCur c; int tap = k / g.C; c.ch = k - tap * g.C; c.kh = tap / g.KW; c.kw = tap - c.kh * g.KW; c.k = k; return c; }
+  __device__ __forceinline__ void dadvance(DCur& c) const {
+    c.ch += 32; c.k += 32;                            // branch-free: keeps the K loop of the DMA kernel one basic block
+    const int w = c.ch >= g.C; c.ch = w ? 0 : c.ch; c.kw += w;
+    const int w2 = c.kw == g.KW; c.kw = w2 ? 0 : c.kw; c.kh += w2;
+  }
+  __device__ __forceinline__ const bf16_t* dsrc(const DRow& d, const DCur& u, const bf16_t* zero) const {
+    int dy = g.sgn * u.kh, dx = g.sgn * u.kw;
+    bool ok = u.k < g.K && (unsigned)(d.y + dy) < (unsigned)g.H && (unsigned)(d.x + dx) < (unsigned)g.W;
+    return dma_select(ok, d.b + ((int64_t)(dy * g.W + dx) * g.C + u.ch), zero);
   }
 };
 // M/N-contiguous bf16: element(r,k) = p[k*ld + r]; micro-block = 8 rows x 4 k (4 dwordx4 along the rows)
@@ -660,6 +694,166 @@ void gemm_lds_bf16_kernel(AL a, BL b, EP ep, int K, int kper, int gx, int gy) {
   const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   const int kbeg = blockIdx.z * kper;
   lds_tile<BK>(a, b, ep, (bid / gx) * 128, (bid % gx) * 128, kbeg, min(K, kbeg + kper), lds);
+}
+
+// ---------------------------------------------------------------------------
+// 256 x 256 bf16 kernel with LDS-DMA staging (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.
+// 8 waves as 2(M) x 4(N), 128 x 64 outputs per wave (4 x 2 MFMA 32x32x16 tiles, 128 accumulator registers), one workgroup
+// per CU.  K advances in 32-wide tiles through a ring of four 32 KB LDS slots (A 256 x 64 B | B 256 x 64 B): tile t+4 is
+// issued while tile t is multiplied, so two to three tiles stay in flight across the single barrier per tile (raw
+// s_barrier + counted vmcnt; a __syncthreads() would drain them).  An LDS-DMA instruction writes 1 KiB lane-linearly = 16 rows of the
+// image, so the bank swizzle goes on the per-lane SOURCE address: the 16-byte piece at position p of row r holds k-chunk
+// p ^ ((r >> 2) & 3), which spreads every 16-lane group of the fragment ds_read_b128 over all 64 banks.
+// Every issue() is exactly 4 DMA instructions per lane (tiles past K read the zero page), which keeps the vmcnt
+// arithmetic uniform.  Both operands bf16, K-contiguous, K % 32 == 0.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void dma16(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <class AL, class BL, class EP, int ABL = 0, bool PIPE = true>      // PIPE: fragment reads pipelined across the barrier (inline asm); ABL: timing-only ablations (tools/ubench/dma_gemm.hip): 1 no in-loop DMA, 2 no MFMA, 4 no fragment reads
+__global__ __launch_bounds__(512, 1)
+void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t* zero) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 32768];          // the ONLY LDS object (a second one makes hipcc drain vmcnt)
+  const int nwg = gx * gy, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int m_blk = (bid / gx) * 256, n_blk = (bid % gx) * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, wm = wave >> 2, wn = wave & 3;
+
+  // staging role: rows (tid >> 2) + 128 j, LDS position tid & 3 of the row, logical chunk = position ^ swizzle(row)
+  const int srow = tid >> 2, chunk = (tid & 3) ^ ((tid >> 4) & 3);
+  typename AL::DRow ra[2]; typename BL::DRow rb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { ra[j] = a.drow(m_blk + 128 * j + srow, chunk); rb[j] = b.drow(n_blk + 128 * j + srow, chunk); }
+  typename AL::DCur ca = a.dseek(0); typename BL::DCur cb = b.dseek(0);
+  const int nk = K >> 5;
+  unsigned char* const wbase = lds + __builtin_amdgcn_readfirstlane(wave) * 1024;
+  int slot = 0;                                       // ring slot the next issue() fills
+  auto issue_a = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(a.dsrc(ra[j], ca, zero), wbase + slot * 32768 + j * 8192);
+    a.dadvance(ca);
+  };
+  auto issue_b = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(b.dsrc(rb[j], cb, zero), wbase + slot * 32768 + 16384 + j * 8192);
+    b.dadvance(cb); slot = (slot + 1) & 3;
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int swz = (r >> 2) & 3;
+  unsigned aoff[2], boff[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    aoff[s] = (wm * 128 + r) * 64 + (((2 * s + h) ^ swz) << 4);
+    boff[s] = 16384 + (wn * 64 + r) * 64 + (((2 * s + h) ^ swz) << 4);
+  }
+
+  // Fragment reads are software-pipelined across the barrier: the k 16..31 half of tile t is fetched under the MFMAs of
+  // its k 0..15 half, and the first half of tile t+1 under the MFMAs of the second half of tile t -- right after the
+  // barrier the MFMA pipe already has operands in registers.  The reads are inline asm with hand-counted lgkmcnt waits
+  // (hipcc's own insertion waits lgkmcnt(0) for the loop-carried half, i.e. for the reads just issued); every wait is
+  // followed by sched_barrier(0) so that no MFMA is hoisted above it.
+  const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
+  bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
+#define AOCR_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+  auto read0 = [&](int sl) {
+    const unsigned pa = lbase + sl * 32768 + aoff[0], pb = lbase + sl * 32768 + boff[0];
+    AOCR_DSR(fa0[0], pa, 0); AOCR_DSR(fa0[1], pa, 2048); AOCR_DSR(fb0[0], pb, 0); AOCR_DSR(fb0[1], pb, 2048);
+    AOCR_DSR(fa0[2], pa, 4096); AOCR_DSR(fa0[3], pa, 6144);
+  };
+  auto read1 = [&](int sl) {
+    const unsigned pa = lbase + sl * 32768 + aoff[1], pb = lbase + sl * 32768 + boff[1];
+    AOCR_DSR(fa1[0], pa, 0); AOCR_DSR(fa1[1], pa, 2048); AOCR_DSR(fb1[0], pb, 0); AOCR_DSR(fb1[1], pb, 2048);
+    AOCR_DSR(fa1[2], pa, 4096); AOCR_DSR(fa1[3], pa, 6144);
+  };
+#undef AOCR_DSR
+  if constexpr (!PIPE) {                                // plain form: compiler-managed reads, tile kt+3 issued under tile kt
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { issue_a(); issue_b(); }
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const unsigned char* L = lds + (kt & 3) * 32768;
+      bf16x8 af[2][4], bf[2][2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[s2][mi] = *reinterpret_cast<const bf16x8*>(L + aoff[s2] + mi * 2048);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bf[s2][ni] = *reinterpret_cast<const bf16x8*>(L + boff[s2] + ni * 2048);
+      }
+      if constexpr (!(ABL & 1)) issue_a();
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], bf[0][ni], acc[mi][ni], 0, 0, 0);
+      if constexpr (!(ABL & 1)) issue_b();
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][mi], bf[1][ni], acc[mi][ni], 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+  for (int t = 0; t < 3; ++t) { issue_a(); issue_b(); }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                         // tile 0 is resident
+  issue_a(); issue_b();                                 // tile 3
+  read0(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    if constexpr (!(ABL & 4)) read1(kt & 3);
+    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");  // the six older reads (first half, issued one barrier ago) are back
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(ABL & 2)) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[mi], fb0[ni], acc[mi][ni], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // own pieces of tile kt+1 landed (kt+2, kt+3 in flight); own reads of tile kt done
+    __builtin_amdgcn_s_barrier();                       // ... everyone's: tile kt+1 is resident and slot kt is free
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(ABL & 1)) issue_a();                // tile kt+4 -> the slot of tile kt
+    if constexpr (!(ABL & 4)) read0((kt + 1) & 3);
+    if constexpr (!(ABL & 1)) issue_b();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(ABL & 2)) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[mi], fb1[ni], acc[mi][ni], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the trailing (zero-page) tiles must land before the LDS is released
+  const int m0 = m_blk + wm * 128, n0 = n_blk + wn * 64;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[2][4];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * q + i];
+      ep.template quad<2>(m0 + 32 * mi + 8 * q + 4 * h, n0 + r, 32, v);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -17,7 +17,7 @@ Layout build_layout(const aocr_config& c);
 struct ConvP { float *w, *b, *dw, *db; int cin, cout, ks, pad; };
 struct BnP { float *w, *b, *dw, *db, *rm, *rv, *save; int C; };
 // bf16 shadows of one recurrent weight matrix W [R][C] (leading dimension ld, first column col0 of the fp32 tensor)
-struct ShW { const float* w; int64_t ld; int R, C; bf16_t* wb; bf16_t* wtb; };
+struct ShW { const float* w; int64_t ld; int R, C; bf16_t* wb; bf16_t* wtb; float* wtf; };   // wtf: fp32 transpose [C][R] (fp32 mode)
 struct LstmP { float *wi, *bi, *wh, *bh, *dwi, *dbi, *dwh, *dbh; int in; ShW swi, swh; };
 
 struct Arena {
@@ -60,6 +60,7 @@ struct aocr_model {
   // bf16 shadows of the contraction operands (bf16 compute mode only; nullptr otherwise)
   aocr::bf16_t *A1b, *A2b, *A3b, *A4b, *A5b, *A6b, *G0b;
   aocr::bf16_t *wb[8], *wtb[8];
+  float* wtf[8];                  // fp32 mode: conv taps re-laid as [Cin][tap][Cout] (K-contiguous B operand of the data gradient)
   // bf16 shadows of the recurrent activations / gradients (written by the producing epilogues)
   aocr::bf16_t *Xb, *ehs_b[2][aocr::MAXL], *edz_b[2][aocr::MAXL], *dhs_b[aocr::MAXL], *ddz_b[aocr::MAXL], *out_b, *cat_b, *dpre_b, *dq_b;
   void* bn_scratch; float* bn_save;

@@ -85,7 +85,11 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
   size_t gmax = B * d.H1 * d.W1 * 128;                                      // d(conv2 pre-pool output): the largest gradient map
   m->G0 = a.get<float>(gmax); m->G1 = a.get<float>(gmax);
   m->A1b = m->A2b = m->A3b = m->A4b = m->A5b = m->A6b = m->G0b = nullptr;
-  for (int i = 0; i < 8; ++i) { m->wb[i] = nullptr; m->wtb[i] = nullptr; }
+  for (int i = 0; i < 8; ++i) { m->wb[i] = nullptr; m->wtb[i] = nullptr; m->wtf[i] = nullptr; }
+  if (!m->bf16) {
+    static const int wsz32[8] = {0, 0, 128 * 9 * 64, 256 * 9 * 128, 256 * 9 * 256, 512 * 9 * 256, 512 * 9 * 512, 512 * 4 * 512};
+    for (int i = 2; i <= 7; ++i) m->wtf[i] = a.get<float>(wsz32[i]);
+  }
   if (m->bf16) {
     m->A1b = a.get<bf16_t>(B * d.H1 * d.W1 * 64); m->A2b = a.get<bf16_t>(B * d.H2 * d.W2 * 128);
     m->A3b = a.get<bf16_t>(B * d.H2 * d.W2 * 256); m->A4b = a.get<bf16_t>(B * d.H4 * d.W2 * 256);
@@ -97,6 +101,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
   {                                                            // bf16 shadows of the recurrent weights (bf16 mode)
     auto sh = [&](ShW& w, size_t R_, size_t C_) {
       w.wb = m->bf16 ? a.get<bf16_t>(R_ * C_) : nullptr; w.wtb = m->bf16 ? a.get<bf16_t>(R_ * C_) : nullptr;
+      w.wtf = m->bf16 ? nullptr : a.get<float>(R_ * C_);
     };
     for (int dir = 0; dir < 2; ++dir) for (int l = 0; l < m->Le; ++l) { sh(m->enc[dir][l].swh, 4 * He, He); sh(m->enc[dir][l].swi, 4 * He, l == 0 ? 512 : He); }
     for (int l = 0; l < m->Ld; ++l) { sh(m->dec[l].swi, 4 * Hd, Hd); sh(m->dec[l].swh, 4 * Hd, Hd); }
@@ -153,8 +158,10 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
 // y = x W^T, the transposed shadow for y = x W) is read, always K-contiguous; in fp32 mode W itself.
 // ------------------------------------------------------------------------------------------------
 static void refresh_rnn_shadows(aocr_model* m) {
-  if (!m->bf16) return;
-  auto up = [&](const ShW& w) { if (w.wb) weight_shadows(m->s, w.w, w.ld, w.R, w.C, w.wb, w.wtb); };
+  auto up = [&](const ShW& w) {
+    if (w.wb) weight_shadows(m->s, w.w, w.ld, w.R, w.C, w.wb, w.wtb);
+    else if (w.wtf) transpose_f32(m->s, w.w, w.ld, w.R, w.C, w.wtf);
+  };
   for (int dir = 0; dir < 2; ++dir) for (int l = 0; l < m->Le; ++l) { up(m->enc[dir][l].swh); up(m->enc[dir][l].swi); }
   for (int l = 0; l < m->Ld; ++l) { if (l > 0 || m->cfg.input_feed) up(m->dec[l].swi); up(m->dec[l].swh); }
   up(m->swa); up(m->swc);
@@ -197,6 +204,7 @@ static void run_store_nt(aocr_model* m, const LoadK& a, const ShW& w, const EpSt
 static void run_store_nn(aocr_model* m, const LoadK& a, const ShW& w, const EpStore& ep, int M, const LoadKh2* ah = nullptr) {
   if (m->bf16 && hh_ok(ah, 1, w.C)) { SmallArgsHH z; z.a = *ah; z.b = make_loadkh(w.wtb, w.R, w.C, w.R); z.ep = ep; z.K = ah->K; launch_small_hh(m->s, 1, &z, M, w.C); }
   else if (m->bf16) { SmallArgsH z; z.a = a; z.b = make_loadkh(w.wtb, w.R, w.C, w.R); z.ep = ep; z.K = a.K; launch_small_h(m->s, 1, &z, M, w.C); }
+  else if (w.wtf) { SmallKKArgs z; z.a = a; z.b = make_loadk(w.wtf, w.R, w.C, w.R); z.ep = ep; z.K = a.K; launch_small_kk(m->s, false, 1, &z, M, w.C); }
   else { SmallKMNArgs z; z.a = a; z.b = make_loadmn(w.w, w.ld, w.C, a.K); z.ep = ep; z.K = a.K; launch_small_kmn(m->s, false, 1, &z, M, w.C); }
 }
 // gate backward: d(h) GEMM part = x W (K may be 0: no GEMM part)
@@ -211,6 +219,12 @@ static void run_gates_bwd(aocr_model* m, int nz, const LoadK* a, const ShW* cons
     for (int i = 0; i < nz; ++i) { z[i].a = a[i]; z[i].b = make_loadkh(w[i]->wtb, w[i]->R, w[i]->C, a[i].K); z[i].ep = ep[i]; z[i].K = a[i].K; }
     launch_small_gates_bwd_h(m->s, nz, z, M, H);
   } else {
+    if (w[0]->wtf) {                                          // fp32 mode with K-contiguous transposed weights
+      GatesBwdKKArgs z[2];
+      for (int i = 0; i < nz; ++i) { z[i].a = a[i]; z[i].b = make_loadk(w[i]->wtf, w[i]->R, w[i]->C, a[i].K); z[i].ep = ep[i]; z[i].K = a[i].K; }
+      launch_small_gates_bwd_kk(m->s, nz, z, M, H);
+      return;
+    }
     GatesBwdArgs z[2];
     for (int i = 0; i < nz; ++i) { z[i].a = a[i]; z[i].b = make_loadmn(w[i]->w, w[i]->ld, w[i]->C, a[i].K); z[i].ep = ep[i]; z[i].K = a[i].K; }
     launch_small_gates_bwd(m->s, false, nz, z, M, H);
@@ -223,9 +237,10 @@ static void run_gates_bwd(aocr_model* m, int nz, const LoadK* a, const ShW* cons
 void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training, int update_running) {
   hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
   refresh_rnn_shadows(m);
-  if (bf)                                                       // refresh the bf16 weight shadows (weights change every step)
-    for (int i = 2; i <= 7; ++i)
-      conv_weight_shadows(s, m->conv[i].w, m->wb[i], m->wtb[i], m->conv[i].cout, m->conv[i].ks * m->conv[i].ks, m->conv[i].cin);
+  for (int i = 2; i <= 7; ++i) {                                // refresh the re-laid weight copies (weights change every step)
+    if (bf) conv_weight_shadows(s, m->conv[i].w, m->wb[i], m->wtb[i], m->conv[i].cout, m->conv[i].ks * m->conv[i].ks, m->conv[i].cin);
+    else conv_weight_transpose_f32(s, m->conv[i].w, m->wtf[i], m->conv[i].cout, m->conv[i].ks * m->conv[i].ks, m->conv[i].cin);
+  }
   conv1_forward(s, images, m->conv[1].w, m->conv[1].b, m->A1, B, d.H, d.W, m->A1b);
   conv_forward(s, bf, m->A1, m->conv[2].w, m->conv[2].b, m->A2, m->idx2, B, d.H1, d.W1, 64, 128, 3, 1, 1, 1, m->A1b, m->wb[2], m->A2b);
   conv_forward(s, bf, m->A2, m->conv[3].w, m->conv[3].b, m->Y3, nullptr, B, d.H2, d.W2, 128, 256, 3, 1, 0, 0, m->A2b, m->wb[3], nullptr);
@@ -248,24 +263,24 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   bn_relu_backward(s, m->Y7, m->X, m->dX, m->bn[7].w, m->bn[7].save, G0, m->bn[7].dw, m->bn[7].db, m->bn_scratch,
                    (int64_t)B * d.T, 512, B, G0b);
   conv_backward_filter(s, bf, m->A6, G0, m->conv[7].dw, m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0, m->A6b, G0b);
-  conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0, G0b, m->wtb[7]);
+  conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0, G0b, m->wtb[7], m->wtf[7]);
   unpool_relu_backward(s, G1, m->A6, m->idx6, G0, B, d.H4, d.W2, 512, 2, G0b);
   conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, G0b);
-  conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, G0b, m->wtb[6]);
+  conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, G0b, m->wtb[6], m->wtf[6]);
   bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
                    (int64_t)B * d.H4 * d.W2, 512, 0, G0b);
   conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, G0b);
-  conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1, G0b, m->wtb[5]);
+  conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1, G0b, m->wtb[5], m->wtf[5]);
   unpool_relu_backward(s, G1, m->A4, m->idx4, G0, B, d.H2, d.W2, 256, 2, G0b);
   conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, G0b);
-  conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, G0b, m->wtb[4]);
+  conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, G0b, m->wtb[4], m->wtf[4]);
   bn_relu_backward(s, m->Y3, m->A3, G1, m->bn[3].w, m->bn[3].save, G0, m->bn[3].dw, m->bn[3].db, m->bn_scratch,
                    (int64_t)B * d.H2 * d.W2, 256, 0, G0b);
   conv_backward_filter(s, bf, m->A2, G0, m->conv[3].dw, m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, G0b);
-  conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1, G0b, m->wtb[3]);
+  conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1, G0b, m->wtb[3], m->wtf[3]);
   unpool_relu_backward(s, G1, m->A2, m->idx2, G0, B, d.H1, d.W1, 128, 1, G0b);
   conv_backward_filter(s, bf, m->A1, G0, m->conv[2].dw, m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1, m->A1b, G0b);
-  conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1, G0b, m->wtb[2]);
+  conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1, G0b, m->wtb[2], m->wtf[2]);
   conv1_backward(s, images, m->conv[1].w, m->conv[1].b, G1, m->conv[1].dw, m->conv[1].db, B, d.H, d.W,
                  (size_t)B * d.H1 * d.W1 * 128 >= (size_t)4096 * 640 ? G0 : nullptr);      // G0 is free here: use it as the partial slab
 }
@@ -274,6 +289,16 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
 // encoder, model.lua:291-316.  State slots: index t+1 holds step t; slot 0 / slot T+1 are the zero initial
 // states of the forward / backward direction.
 // ------------------------------------------------------------------------------------------------
+// The whole-sequence encoder kernels (rnn_seq.hip) need bf16 shadows, B % 16 == 0, He in {64,128,256} and one CU per
+// workgroup; AOCR_NO_SEQ=1 forces the per-step kernels (parity tests compare the two).
+static bool seq_kernels_ok(const aocr_model* m, int B) {
+  if (!m->bf16 || !m->ehs_b[0][0] || !m->enc[0][0].swh.wb) return false;
+  const char* e = getenv("AOCR_NO_SEQ");
+  if (e && e[0] == '1') return false;
+  static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  return enc_seq_supported(B, m->He, cus);
+}
+
 void encoder_forward(aocr_model* m, const Dims& d) {
   hipStream_t s = m->s; const bool bf = m->bf16;
   const int B = d.B, T = d.T, He = m->He, Hd = m->Hd;
@@ -297,6 +322,17 @@ void encoder_forward(aocr_model* m, const Dims& d) {
       }
     }
     const bool top = l == m->Le - 1;
+    if (getenv("AOCR_TRACE")) fprintf(stderr, "[aocr] encoder layer %d forward: %s kernels\n", l, seq_kernels_ok(m, B) ? "whole-sequence" : "per-step");
+    if (seq_kernels_ok(m, B)) {                         // whole-sequence kernel: one launch for all T steps of both directions
+      EncSeqFwdArgs a; a.B = B; a.T = T; a.He = He; a.Hd = Hd;
+      for (int dir = 0; dir < 2; ++dir) {
+        EncSeqDir& e = a.d[dir];
+        e.w = m->enc[dir][l].swh.wb; e.zx = m->ezx[dir][l]; e.hs = m->ehs[dir][l]; e.cs = m->ecs[dir][l]; e.hsb = m->ehs_b[dir][l];
+        e.gates = m->egates[dir][l]; e.ctx = top ? m->context + dir * He : nullptr; e.reverse = dir;
+      }
+      enc_seq_forward(s, a);
+      continue;
+    }
     for (int i = 0; i < T; ++i) {
       LoadK la[2]; LoadKh2 lah[2]; EpGatesFwd ee[2]; const ShW* w0[2]; const ShW* w1[2] = {nullptr, nullptr};
       for (int dir = 0; dir < 2; ++dir) {
@@ -371,6 +407,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       float* dxo = l == 0 ? m->dX : m->edxl[dir];
       const int dxf = (l == 0 && dir == 1) ? EP_ACCUM : 0;                          // model.lua:675 copy, :689 add
       if (bf && dzb && p.swi.wtb) gemm_hh(s, dzb, 4 * He, p.swi.wtb, 4 * He, dxo, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dxf);
+      else if (p.swi.wtf) gemm(s, bf, dz, 4 * He, true, p.swi.wtf, 4 * He, true, dxo, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dxf);
       else gemm(s, bf, dz, 4 * He, true, p.wi, p.in, false, dxo, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dxf);
     }
     grouped_wgrad(s, bf, wg, nwg);

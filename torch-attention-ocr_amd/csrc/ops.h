@@ -49,6 +49,8 @@ void launch_small_gates_fwd(hipStream_t s, bool bf16, int nz, const GatesFwdArgs
 void launch_small_kk(hipStream_t s, bool bf16, int nz, const SmallKKArgs* z, int M, int N);
 void launch_small_kmn(hipStream_t s, bool bf16, int nz, const SmallKMNArgs* z, int M, int N);
 void launch_small_gates_bwd(hipStream_t s, bool bf16, int nz, const GatesBwdArgs* z, int M, int H);
+typedef SmallArgs<LoadK, LoadK, EpGatesBwd> GatesBwdKKArgs;     // fp32 mode, B = fp32 transposed weights (K-contiguous)
+void launch_small_gates_bwd_kk(hipStream_t s, int nz, const GatesBwdKKArgs* z, int M, int H);
 // bf16 mode with bf16 weight shadows as the B operand (always K-contiguous: W for y = x W^T, W^T for y = x W)
 typedef SmallArgs<LoadK, LoadKh2, EpGatesFwd> GatesFwdArgsH;
 typedef SmallArgs<LoadK, LoadKh2, EpStore> SmallArgsH;
@@ -70,6 +72,8 @@ inline LoadKh2 make_loadkh2(const bf16_t* p0, int64_t ld0, int K0, const bf16_t*
 }
 // wb [R][C] = bf16(w[r*ld + c]), wtb [C][R] = its transpose (dense)
 void weight_shadows(hipStream_t s, const float* w, int64_t ld, int R, int C, bf16_t* wb, bf16_t* wtb);
+void transpose_f32(hipStream_t s, const float* w, int64_t ld, int R, int C, float* wt);                    // wt [C][R]
+void conv_weight_transpose_f32(hipStream_t s, const float* w, float* wt, int Cout, int KK, int Cin);     // wt [Cin][KK][Cout]
 
 // generic GEMM used by the C ABI and the hoisted projections; picks ksplit when allowed (atomic accumulate).
 int gemm(hipStream_t s, bool bf16, const float* A, int64_t lda, bool a_kmajor, const float* B, int64_t ldb, bool b_kmajor,
@@ -92,7 +96,7 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
                   int B, int H, int W, int Cin, int Cout, int ks, int pad, int relu, int pool,
                   const bf16_t* xb = nullptr, const bf16_t* wb = nullptr, bf16_t* yb = nullptr);
 void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* w, float* dx, int B, int H, int W, int Cin,
-                        int Cout, int ks, int pad, const bf16_t* dyb = nullptr, const bf16_t* wtb = nullptr);
+                        int Cout, int ks, int pad, const bf16_t* dyb = nullptr, const bf16_t* wtb = nullptr, const float* wtf = nullptr);
 void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float* dy, float* dw, float* dbias, int B, int H,
                           int W, int Cin, int Cout, int ks, int pad, const bf16_t* xb = nullptr, const bf16_t* dyb = nullptr);
 
@@ -143,4 +147,17 @@ void beam_backtrace(hipStream_t s, const int32_t* hist_tok, const int32_t* hist_
                     int32_t* labels, float* scores, int Lt, int B, int k);
 void fill_i32(hipStream_t s, int32_t* p, int32_t v, int64_t n);
 
+// ---- whole-sequence encoder recurrence (rnn_seq.hip): one workgroup owns 16 batch rows of one direction for all T steps
+struct EncSeqDir {
+  const bf16_t* w;         // recurrent weight, bf16 [4He][He]
+  const float* zx;         // pre-computed input part incl. both biases, fp32 [T][B][4He]
+  float* hs; float* cs;    // state slots [(T+2)][B][He]: slot t+1 holds step t
+  bf16_t* hsb;             // bf16 shadow of hs
+  float* gates;            // saved post-activation gates [T][B][4He]
+  float* ctx;              // context + dir*He (element (b,t,j) at ctx[(b*T + t)*Hd + j]) or nullptr below the top layer
+  int reverse;             // 1: the direction that walks t = T-1 .. 0
+};
+struct EncSeqFwdArgs { EncSeqDir d[2]; int B, T, He, Hd; };
+bool enc_seq_supported(int B, int He, int blocks_limit);
+void enc_seq_forward(hipStream_t s, const EncSeqFwdArgs& a);
 }  // namespace aocr

@@ -19,6 +19,25 @@ static void launch_lds(hipStream_t s, const AL& a, const BL& b, const EP& ep, in
   const int gx = cdiv(N, 128), gy = cdiv(M, 128);
   hipLaunchKernelGGL((gemm_lds_bf16_kernel<AL, BL, EP>), dim3(gx * gy, 1, ksplit), dim3(256), 0, s, a, b, ep, K, kper, gx, gy);
 }
+// 256 x 256 x 32 LDS-DMA kernel (bf16 K-contiguous operand pairs).  One workgroup per CU, so it is chosen only when the grid
+// fills whole rounds of the 256 CUs well; AOCR_FORCE_DMA=1 forces it wherever its shape constraints hold (parity tests).
+__device__ __attribute__((aligned(16))) unsigned char g_zero_page[64];
+static const bf16_t* zero_page() {
+  static const bf16_t* z = [] { void* p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_page)); return (const bf16_t*)p; }();
+  return z;
+}
+static bool dma_forced() { const char* e = getenv("AOCR_FORCE_DMA"); return e && e[0] == '1'; }     // read per call: tests toggle it
+static bool dma_eligible(int M, int N, int K, int C) {
+  if (N % 256 || K % 32 || C % 32 || M < 256) return false;
+  if (dma_forced()) return true;
+  const int blocks = cdiv(M, 256) * (N / 256), rounds = cdiv(blocks, 256);
+  return blocks >= 200 && blocks * 10 >= rounds * 256 * 8;          // >= 80 % of the CU-rounds it occupies
+}
+template <class AL, class BL, class EP>
+static void launch_dma(hipStream_t s, const AL& a, const BL& b, const EP& ep, int M, int N, int K) {
+  const int gx = N / 256, gy = cdiv(M, 256);
+  hipLaunchKernelGGL((gemm_dma_bf16_kernel<AL, BL, EP>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page());
+}
 // BK = 64 variant for bf16 K-contiguous operand pairs (conv forward / data gradient): half the barriers per FLOP
 template <class AL, class BL, class EP>
 [[maybe_unused]] static void launch_lds64(hipStream_t s, const AL& a, const BL& b, const EP& ep, int M, int N, int K) {
@@ -72,6 +91,7 @@ void launch_small_kk(hipStream_t s, bool bf16, int nz, const SmallKKArgs* z, int
 void launch_small_kmn(hipStream_t s, bool bf16, int nz, const SmallKMNArgs* z, int M, int N) {
   launch_small<1, false>(s, bf16, nz, z, M, N, 0);
 }
+void launch_small_gates_bwd_kk(hipStream_t s, int nz, const GatesBwdKKArgs* z, int M, int H) { launch_small<1, false>(s, false, nz, z, M, H, 0); }
 void launch_small_gates_bwd(hipStream_t s, bool bf16, int nz, const GatesBwdArgs* z, int M, int H) {
   launch_small<1, false>(s, bf16, nz, z, M, H, 0);
 }
@@ -199,21 +219,25 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
   if (bf16 && xb && wb) {
     LoadConvKh ah; ah.src = xb; ah.g = a;
     LoadKh bh; bh.p = wb; bh.ld = a.K; bh.rows = Cout; bh.K = a.K;
-    launch_lds(s, ah, bh, ep, a.rows, Cout, a.K, 1);       // (BK = 64 variant measured no faster: launch_lds64)
+    if (dma_eligible(a.rows, Cout, a.K, Cin)) launch_dma(s, ah, bh, ep, a.rows, Cout, a.K);
+    else launch_lds(s, ah, bh, ep, a.rows, Cout, a.K, 1);       // (BK = 64 variant measured no faster: launch_lds64)
   } else {
     launch_conv_fwd(s, bf16, a, make_loadk(w, a.K, Cout, a.K), ep, a.rows, Cout, a.K);
   }
 }
 
 void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* w, float* dx, int B, int H, int W, int Cin,
-                        int Cout, int ks, int pad, const bf16_t* dyb, const bf16_t* wtb) {
+                        int Cout, int ks, int pad, const bf16_t* dyb, const bf16_t* wtb, const float* wtf) {
   const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
   LoadConvK a = make_convk(dy, B, Ho, Wo, Cout, ks, -1, pad, H, W, 0);
   EpStore ep = make_store(dx, Cin, a.rows, Cin);
   if (bf16 && dyb && wtb) {
     LoadConvKh ah; ah.src = dyb; ah.g = a;
     LoadKh bh; bh.p = wtb; bh.ld = a.K; bh.rows = Cin; bh.K = a.K;          // wtb [Cin][tap][Cout]: K-contiguous over (tap, co)
-    launch_lds(s, ah, bh, ep, a.rows, Cin, a.K, 1);
+    if (dma_eligible(a.rows, Cin, a.K, Cout)) launch_dma(s, ah, bh, ep, a.rows, Cin, a.K);
+    else launch_lds(s, ah, bh, ep, a.rows, Cin, a.K, 1);
+  } else if (wtf) {                                          // fp32 taps re-laid [Cin][tap][Cout]: K-contiguous dwordx4 loads
+    launch_big(s, bf16, a, make_loadk(wtf, a.K, Cin, a.K), ep, a.rows, Cin, a.K, 1);
   } else {
     LoadConvWT b; b.w = w; b.Cin = Cin; b.Cout = Cout; b.KK = ks * ks; b.K = a.K;
     launch_conv_dgrad(s, bf16, a, b, ep, a.rows, Cin, a.K);

@@ -203,6 +203,27 @@ __global__ __launch_bounds__(256) void weight_shadow_kernel(const float* __restr
     if (r < R && c < C) wtb[(int64_t)c * R + r] = (bf16_t)tile[tx][i];
   }
 }
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ w, int64_t ld, int R, int C, float* __restrict__ wt) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) { int r = r0 + i, c = c0 + tx; tile[i][tx] = (r < R && c < C) ? w[(int64_t)r * ld + c] : 0.f; }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) { int c = c0 + i, r = r0 + tx; if (r < R && c < C) wt[(int64_t)c * R + r] = tile[tx][i]; }
+}
+void transpose_f32(hipStream_t s, const float* w, int64_t ld, int R, int C, float* wt) {
+  hipLaunchKernelGGL(transpose_f32_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, s, w, ld, R, C, wt);
+}
+__global__ __launch_bounds__(256) void conv_weight_transpose_f32_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int KK, int Cin) {
+  const int64_t n = (int64_t)Cout * KK * Cin;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    int ci = (int)(i % Cin); int64_t t = i / Cin; int tap = (int)(t % KK); int co = (int)(t / KK);
+    wt[((int64_t)ci * KK + tap) * Cout + co] = w[i];
+  }
+}
+void conv_weight_transpose_f32(hipStream_t s, const float* w, float* wt, int Cout, int KK, int Cin) {
+  int64_t n = (int64_t)Cout * KK * Cin;
+  hipLaunchKernelGGL(conv_weight_transpose_f32_kernel, dim3((int)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, w, wt, Cout, KK, Cin);
+}
 void weight_shadows(hipStream_t s, const float* w, int64_t ld, int R, int C, bf16_t* wb, bf16_t* wtb) {
   hipLaunchKernelGGL(weight_shadow_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, s, w, ld, R, C, wb, wtb);
 }
