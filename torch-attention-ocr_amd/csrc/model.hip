@@ -368,7 +368,22 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       if (top) copy2d(s, m->dc_st[0] + dir * He, Hd, m->edc[dir], He, B, He);        // model.lua:666,680
       else hipMemsetAsync(m->edc[dir], 0, slot * sizeof(float), s);
     }
-    for (int i = 0; i < T; ++i) {
+    const bool seq = seq_kernels_ok(m, B) && m->edz_b[0][l] && m->enc[0][l].swh.wtb;
+    if (getenv("AOCR_TRACE")) fprintf(stderr, "[aocr] encoder layer %d backward: %s kernels\n", l, seq ? "whole-sequence" : "per-step");
+    if (seq) {
+      EncSeqBwdArgs a; a.B = B; a.T = T; a.He = He;
+      for (int dir = 0; dir < 2; ++dir) {
+        EncSeqBwdDir& e = a.d[dir];
+        e.wt = m->enc[dir][l].swh.wtb;
+        if (top) { e.dh1 = m->dctx + dir * He; e.dh1_row = (int64_t)T * Hd; e.dh1_t = Hd; }      // model.lua:670,684
+        else { e.dh1 = m->edxl[dir]; e.dh1_row = He; e.dh1_t = (int64_t)slot; }
+        e.dh2 = top ? m->dh_rec[0] + dir * He : nullptr; e.dh2_row = Hd;                            // model.lua:667,681
+        e.dc = m->edc[dir]; e.gates = m->egates[dir][l]; e.cs = m->ecs[dir][l];
+        e.dz = m->edz[dir][l]; e.dzb = m->edz_b[dir][l]; e.forward_dir = dir == 0;
+      }
+      enc_seq_backward(s, a);
+    }
+    for (int i = 0; i < T && !seq; ++i) {
       LoadK la[2]; LoadKh2 lah[2]; EpGatesBwd ee[2]; const ShW* ww[2];
       for (int dir = 0; dir < 2; ++dir) {
         const LstmP& p = m->enc[dir][l];

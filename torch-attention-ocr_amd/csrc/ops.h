@@ -157,7 +157,21 @@ struct EncSeqDir {
   float* ctx;              // context + dir*He (element (b,t,j) at ctx[(b*T + t)*Hd + j]) or nullptr below the top layer
   int reverse;             // 1: the direction that walks t = T-1 .. 0
 };
-struct EncSeqFwdArgs { EncSeqDir d[2]; int B, T, He, Hd; };
+struct EncSeqFwdArgs { EncSeqDir d[2]; int B, T, He, Hd; int abl = 0; unsigned long long* dbg = nullptr; };
+struct EncSeqBwdDir {
+  const bf16_t* wt;        // transposed recurrent weight, bf16 [He][4He]
+  const float* dh1;        // d h(t) from above: element (row, t, j) at dh1[row*dh1_row + t*dh1_t + j]
+  int64_t dh1_row, dh1_t;
+  const float* dh2;        // extra d h for the FIRST processed step (decoder initial state), row stride dh2_row; or nullptr
+  int64_t dh2_row;
+  float* dc;               // [B][He]: in = d c entering the first processed step, out = d c leaving the last one
+  const float* gates;      // saved gates [T][B][4He]
+  const float* cs;         // cell-state slots [(T+2)][B][He]
+  float* dz; bf16_t* dzb;  // out: d z [T][B][4He], fp32 and bf16
+  int forward_dir;         // 1: the direction whose forward pass walked t = 0..T-1 (its BPTT walks T-1..0, c_prev = slot t)
+};
+struct EncSeqBwdArgs { EncSeqBwdDir d[2]; int B, T, He; };
 bool enc_seq_supported(int B, int He, int blocks_limit);
+void enc_seq_backward(hipStream_t s, const EncSeqBwdArgs& a);
 void enc_seq_forward(hipStream_t s, const EncSeqFwdArgs& a);
 }  // namespace aocr
