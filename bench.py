@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--compute", default=None, choices=["f32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-steps", type=int, default=3)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C2 fp32 secondary measurement")
     args = ap.parse_args()
     wl = dict(WORKLOADS[args.workload])
     if args.compute:
@@ -142,6 +143,25 @@ def main():
         eld = time.perf_counter() - t0
         dec = world * B * 50 * args.decode_steps / eld
 
+    # secondary line (N = 1 only): BASELINE.json configs[1] = C2 in exact-fp32 MFMA mode (the 1e-4 logit-parity configuration)
+    c2 = None
+    if world == 1 and args.workload == "c3" and not args.no_secondary:
+        w2 = WORKLOADS["c2"]
+        m2 = aocr.Model().create(dict(encoder_num_hidden=w2["He"], encoder_num_layers=w2["Le"], decoder_num_layers=w2["Ld"],
+                                      input_feed=True, batch_size=w2["B"], max_img_w=w2["W"], max_decoder_l=50, max_beam=1,
+                                      compute="f32", learning_rate=0.1, seed=910820))
+        i2, t2, e2, _ = aocr.synth.synth_batch(w2["B"], w2["W"], seed=1234, max_len=w2["L"] - 1)
+        i2 = torch.from_numpy(i2).to(device=dev, dtype=torch.float32); t2 = torch.from_numpy(t2).to(dev); e2 = torch.from_numpy(e2).to(dev)
+        for _ in range(3):
+            m2.train_step_device(i2, t2, e2)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10):
+            m2.train_step_device(i2, t2, e2)
+        torch.cuda.synchronize(); e = time.perf_counter() - t0
+        c2 = {"workload": "c2: " + w2["name"], "dtype": "f32", "steps": 10, "ms_per_step": 1e3 * e / 10, "value": w2["B"] * 10 / e,
+              "unit": "image-lines/s"}
+        m2.shutdown()
+
     out = None
     if rank == 0:
         bf16 = wl["compute"] == "bf16"
@@ -161,7 +181,7 @@ def main():
                        "decoder_steps": L, "parallelism": f"dp{world}", "input_feed": True},
             "train_gflop_per_image": 3 * fpi / 1e9, "step_tflops": 3 * fpi * lines_per_s / 1e12,
             "step_mfma_frac": 3 * fpi * lines_per_s / 1e12 / (peak * world),
-            "decode_chars_per_s": dec, "loss": loss_val,
+            "decode_chars_per_s": dec, "loss": loss_val, "secondary": c2,
             "roofline": {"bound": "mfma", "kernel": "conv6 forward implicit GEMM (512->512 3x3 + ReLU + pool)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                          "ms_per_launch": ms},
