@@ -429,7 +429,18 @@ struct LoadConvXcolh {
   }
   __device__ __forceinline__ void advance(Cur& c) const {
     c.k += 32; c.px += 32;
-    while (c.px >= g.Wo) { c.px -= g.Wo; if (++c.py == g.Ho) { c.py = 0; ++c.b; } }
+    if (g.Wo >= 32) {                                   // at most one row wrap: no per-lane loop (uniform branch)
+      const int w = c.px >= g.Wo; c.px -= w ? g.Wo : 0; c.py += w;
+      const int w2 = c.py == g.Ho; c.py = w2 ? 0 : c.py; c.b += w2;
+    } else {
+      while (c.px >= g.Wo) { c.px -= g.Wo; if (++c.py == g.Ho) { c.py = 0; ++c.b; } }
+    }
+  }
+  // LDS-DMA staging (conv_wgrad_dma_kernel): source pointer of 8 channels of ONE pixel, zero page outside the map / past kend
+  __device__ __forceinline__ const bf16_t* dsrc8(const Ctx8& c, const Cur& u, int kend, const bf16_t* zero) const {
+    int sy = u.py + c.dy, sx = u.px + c.dx;
+    bool ok = c.ok && u.k < kend && (unsigned)sy < (unsigned)g.H && (unsigned)sx < (unsigned)g.W;
+    return dma_select(ok, x + (((int64_t)u.b * g.H + sy) * g.W + sx) * g.Cin + c.ci, zero);
   }
   __device__ __forceinline__ uint4 load8(const Ctx8& c, const Cur& u) const {        // 8 channels of ONE pixel
     int sy = u.py + c.dy, sx = u.px + c.dx;
@@ -961,6 +972,126 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_kernel(LoadMNh a, LoadCo
   const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   const int kbeg = blockIdx.z * kper;
   tr_tile(a, b, ep, (bid / gx) * 128, (bid % gx) * 128, kbeg, min(K, kbeg + kper), lds);
+}
+
+// ---------------------------------------------------------------------------
+// Filter gradient on the LDS-DMA skeleton of gemm_dma_bf16_kernel: 256 (Cout) x 256 (tap, ci) tiles, 8 waves, K = output
+// pixels in 32-deep tiles through the 4-slot ring.  Both operands are contiguous along M/N, so a tile is [32 k][256
+// channels] bf16 = 512 B per pixel row and a 1-KiB DMA piece is two pixel rows; fragments are gathered with
+// ds_read_b64_tr_b16 as in conv_wgrad_tr_kernel.  No padding is possible in a DMA image, so the bank spread comes from
+// an XOR on the source side: the 64-byte segment sg of pixel row k is stored at segment position sg ^ (k & 3); the four
+// pixel rows one transposed read touches then sit in four different quarters of the 256-byte bank row.
+// The im2col operand's piece addresses are per lane: (tap, ci) is a lane constant, the pixel cursor advances by 32.
+// ---------------------------------------------------------------------------
+template <class EP>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_dma_kernel(LoadMNh a, LoadConvXcolh b, EP ep, int K, int kper, int gx, int gy, const bf16_t* zero) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 32768];          // the ONLY LDS object
+  // (Giving every XCD its own K range, so that co-resident workgroups stream the same pixel rows through one L2, was
+  // measured 1.5-2.5x SLOWER than this plain tile-major / split-major order: conv6 635 vs 380 us.)
+  const int nwg = gx * gy, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3), zsp = blockIdx.z;
+  const int m_blk = (bid / gx) * 256, n_blk = (bid % gx) * 256;
+  const int kbeg = zsp * kper, kend = min(K, kbeg + kper);
+  const int nk = kend > kbeg ? (kend - kbeg + 31) >> 5 : 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, wm = wave >> 2, wn = wave & 3;
+
+  // staging role: pieces 2 wave, 2 wave + 1 of each operand; piece pi = pixel rows 2pi, 2pi+1; lane -> row 2pi + (lane>>5),
+  // 16-byte position lane & 31 of the row, which holds logical chunk ((pos>>2) ^ (row & 3)) << 2 | (pos & 3)
+  int krow[2], chunk[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    krow[j] = 2 * (2 * wave + j) + (lane >> 5);
+    const int pos = lane & 31;
+    chunk[j] = ((((pos >> 2) ^ (krow[j] & 3)) << 2) | (pos & 3));
+  }
+  LoadMNh::Ctx8 ca[2]; typename LoadConvXcolh::Ctx8 cb[2]; typename LoadConvXcolh::Cur cur[2]; int ka[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    ca[j] = a.row8(m_blk + 8 * chunk[j]); cb[j] = b.row8(n_blk + 8 * chunk[j]);
+    cur[j] = b.seek(cb[j], kbeg + krow[j]); ka[j] = kbeg + krow[j];
+  }
+  unsigned char* const wbase = lds + (2 * wave) * 1024;
+  int slot = 0;
+  auto issue = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bf16_t* pa = dma_select(ca[j].ok && ka[j] < kend, ca[j].b + (int64_t)ka[j] * a.ld, zero);
+      dma16(pa, wbase + slot * 32768 + j * 1024);
+      ka[j] += 32;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      dma16(b.dsrc8(cb[j], cur[j], kend, zero), wbase + slot * 32768 + 16384 + j * 1024);
+      b.advance(cur[j]);
+    }
+    slot = (slot + 1) & 3;
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // transposed-read addressing (cf. tr_tile): lane = 16g + 4q + p supplies pixel row (.. + q), channels 16 (g&1) + 4p .. +3
+  const int g = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
+  const unsigned rowoff = (8 * h + q) * 512 + (16 * (g & 1) + 4 * p4) * 2;
+  unsigned aseg[4], bseg[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aseg[i] = rowoff + (((wm * 4 + i) ^ q) << 6);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) bseg[i] = 16384 + rowoff + (((wn * 2 + i) ^ q) << 6);
+
+#pragma unroll
+  for (int t = 0; t < 3; ++t) issue();
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // this wave's pieces of tile kt have landed (two later tiles in flight)
+    __builtin_amdgcn_s_barrier();                       // ... everyone's have, and everyone is done reading tile kt-1
+    const unsigned char* L = lds + (kt & 3) * 32768;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    bf16x8 af[2][4], bf[2][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s16x4 lo = lds_tr_read(L + aseg[i] + (16 * s2) * 512), hi = lds_tr_read(L + aseg[i] + (16 * s2 + 4) * 512);
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        af[s2][i] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        s16x4 lo = lds_tr_read(L + bseg[i] + (16 * s2) * 512), hi = lds_tr_read(L + bseg[i] + (16 * s2 + 4) * 512);
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bf[s2][i] = __builtin_bit_cast(bf16x8, v);
+      }
+    }
+    issue();                                            // tile kt+3 -> the slot of tile kt-1
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s2][mi], bf[s2][ni], acc[mi][ni], 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const int r = lane & 31;
+  const int m0 = m_blk + wm * 128, n0 = n_blk + wn * 64;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      float v[2][4];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * qq + i];
+      ep.template quad<2>(m0 + 32 * mi + 8 * qq + 4 * h, n0 + r, 32, v);
+    }
 }
 
 // Grouped form: up to 8 independent contractions of the same operand kinds in ONE launch (the hoisted weight gradients
