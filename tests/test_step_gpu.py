@@ -213,3 +213,48 @@ def test_seq_encoder_kernels_match_step_kernels(cuda, monkeypatch, He, B, W):
         e = relerr(b["grads"][k], a["grads"][k]); worst = max(worst, e)
         assert e < 3e-2, (k, e)
     print(f"[parity] seq-vs-step worst gradient rel {worst:.3e}")
+
+
+def test_c3_full_size_kernel_paths_agree(cuda, monkeypatch):
+    """BASELINE config C3 at full size (32x256, B=256, He=256, L=24, bf16): the production dispatch (256x256 LDS-DMA conv /
+    filter-gradient kernels, whole-sequence encoder kernels -- chosen by shape, no forcing) against the 128x128 and
+    per-step kernels (AOCR_NO_DMA=1, AOCR_NO_SEQ=1) on the same seeded batch and weights.  Size-independent property: the
+    two kernel families compute the same contractions, so logits / loss / every gradient agree to fp32-summation-order
+    noise amplified by bf16 re-rounding."""
+    cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("AOCR_NO_DMA", knob); monkeypatch.setenv("AOCR_NO_SEQ", knob)
+        m, O, ocfg, P, st, batch = make(cfg, B=256, W=256, maxlen=23, compute="bf16", max_decoder_l=24, max_beam=1)
+        loss = m.train_forward_backward(batch)
+        out[knob] = dict(loss=loss, feats=m.get_tensor("feats").clone(), logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(),
+                         grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.shutdown()
+    a, b = out["1"], out["0"]
+    e = (a["feats"].double() - b["feats"].double()).abs().max().item(); print(f"[parity] C3 full size: feats max-abs {e:.3e}"); assert e < 2e-3
+    e = (a["logits"].double() - b["logits"].double()).abs().max().item(); print(f"[parity] C3 full size: logits max-abs {e:.3e}"); assert e < 5e-3
+    assert abs(a["loss"] - b["loss"]) < 2e-3 * abs(a["loss"])
+    worst = ("", 0.0)
+    for k in a["grads"]:
+        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):
+            continue
+        e = relerr(b["grads"][k], a["grads"][k])
+        if e > worst[1]: worst = (k, e)
+        assert e < 3e-2, (k, e)
+    print(f"[parity] C3 full size: worst gradient rel {worst[1]:.3e} ({worst[0]})")
+
+
+def test_logits_c3_shape_bf16(cuda):
+    """BASELINE config C3 at full size through the production bf16 dispatch: decoder logits against the fp64 oracle
+    (stated bf16 tolerance 5e-2 max-abs; fp32 accumulation, fp32 master copies)."""
+    m, O, ocfg, P, st, batch = make(dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True), B=256, W=256, maxlen=23,
+                                    compute="bf16", max_decoder_l=24, max_beam=1)
+    img, tgt, tge = (torch.from_numpy(np.asarray(x)) for x in batch[:3])
+    with torch.no_grad():
+        r = O.forward_train(P, {k: v.clone() for k, v in st.items()}, ocfg, img, tgt, tge, training=True)
+    logits, loss = m.forward_logits(batch, training=True)
+    e = (logits.double() - r["logits"]).abs().max().item()
+    print(f"[parity] C3 bf16 logits max-abs {e:.3e} (mean |logit| {r['logits'].abs().mean().item():.3f}); loss {loss:.4f} vs {float(r['loss']) * 256:.4f}")
+    assert e < 5e-2
+    assert abs(loss - float(r["loss"]) * 256) < 2e-3 * abs(loss)
+    m.shutdown()

@@ -27,8 +27,9 @@ static const bf16_t* zero_page() {
   return z;
 }
 static bool dma_forced() { const char* e = getenv("AOCR_FORCE_DMA"); return e && e[0] == '1'; }     // read per call: tests toggle it
+static bool dma_disabled() { const char* e = getenv("AOCR_NO_DMA"); return e && e[0] == '1'; }       // tests: compare against the 128 x 128 kernels
 static bool dma_eligible(int M, int N, int K, int C) {
-  if (N % 256 || K % 32 || C % 32 || M < 256) return false;
+  if (N % 256 || K % 32 || C % 32 || M < 256 || dma_disabled()) return false;
   if (dma_forced()) return true;
   const int blocks = cdiv(M, 256) * (N / 256), rounds = cdiv(blocks, 256);
   return blocks >= 200 && blocks * 10 >= rounds * 256 * 8;          // >= 80 % of the CU-rounds it occupies
@@ -257,7 +258,7 @@ void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float*
     // 256 x 256 LDS-DMA kernel when Cout and N fill its tiles (measured on workload C3: conv4/5/6 249/239/427 -> 220/223/380 us;
     // conv7 (N = 2048) and conv3 (N = 1152) are no faster and stay on the 128 x 128 kernel)
     const int tiles = cdiv(N, 256) * (Cout / 256);
-    if (Cout % 256 == 0 && Cin % 8 == 0 && (dma_forced() || (P >= 8192 && tiles <= 256 && N % 256 == 0 && N >= 2304))) {
+    if (Cout % 256 == 0 && Cin % 8 == 0 && !dma_disabled() && (dma_forced() || (P >= 8192 && tiles <= 256 && N % 256 == 0 && N >= 2304))) {
       int ks2 = tiles >= 128 ? (tiles >= 200 ? 1 : 2) : 256 / tiles, kper2; split_k(P, 32, ks2, kper2);      // one round of the 256 CUs
       hipLaunchKernelGGL((conv_wgrad_dma_kernel<EpStore>), dim3(tiles, 1, ks2), dim3(512), 0, s, ah, bh, ep, P, kper2, cdiv(N, 256), Cout / 256, zero_page());
       if (dbias) colsum_accum(s, dy, Cout, P, Cout, dbias);
