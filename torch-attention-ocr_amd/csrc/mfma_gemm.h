@@ -868,6 +868,101 @@ void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t
 }
 
 // ---------------------------------------------------------------------------
+// Narrow-N variant of the LDS-DMA kernel for the layers with 128 or 64 output columns (conv2 forward, the data
+// gradients of conv2 / conv3): 256 x (64 NT) tiles, 8 waves as 4(M) x 2(N), 64 x (32 NT) outputs per wave.  The
+// accumulators are small (32 NT VGPRs), so TWO workgroups share a CU -- one's epilogue (HBM-write bound) overlaps the
+// other's K loop -- with a 3-slot ring per workgroup (tile t+2 issued under tile t).  Same source-side swizzle, zero
+// page and barrier / vmcnt discipline as gemm_dma_bf16_kernel; for NT = 1 only waves 0-3 stage the 64-row B tile, so
+// the per-tile piece count (and the vmcnt immediate) is wave-dependent.
+// ---------------------------------------------------------------------------
+template <class AL, class BL, class EP, int NT>
+__global__ __launch_bounds__(512, 2)
+void gemm_dma_narrow_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t* zero) {
+  constexpr int BN = 64 * NT, SLOT = 16384 + BN * 64;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * SLOT];             // the ONLY LDS object
+  const int nwg = gx * gy, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int m_blk = (bid / gx) * 256, n_blk = (bid % gx) * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+
+  const int srow = tid >> 2, chunk = (tid & 3) ^ ((tid >> 4) & 3);
+  const bool stage_b = NT == 2 || wave < 4;             // wave-uniform
+  typename AL::DRow ra[2]; typename BL::DRow rb;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) ra[j] = a.drow(m_blk + 128 * j + srow, chunk);
+  rb = b.drow(n_blk + srow, chunk);                     // rows 0 .. BN-1 (threads past BN * 4 never issue it)
+  typename AL::DCur ca = a.dseek(0); typename BL::DCur cb = b.dseek(0);
+  const int nk = K >> 5;
+  unsigned char* const wbase = lds + wave * 1024;
+  int slot = 0;
+  auto issue = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(a.dsrc(ra[j], ca, zero), wbase + slot * SLOT + j * 8192);
+    a.dadvance(ca);
+    if (stage_b) dma16(b.dsrc(rb, cb, zero), wbase + slot * SLOT + 16384);
+    b.dadvance(cb);
+    slot = slot == 2 ? 0 : slot + 1;
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int swz = (r >> 2) & 3;
+  unsigned aoff[2], boff[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    aoff[s] = (wm * 64 + r) * 64 + (((2 * s + h) ^ swz) << 4);
+    boff[s] = 16384 + (wn * 32 * NT + r) * 64 + (((2 * s + h) ^ swz) << 4);
+  }
+
+  issue(); issue();
+  int rslot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (stage_b) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // this wave's pieces of tile kt have landed (tile kt+1 in flight)
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // ... everyone's have, and everyone is done reading tile kt-1
+    const unsigned char* L = lds + rslot * SLOT;
+    rslot = rslot == 2 ? 0 : rslot + 1;
+    bf16x8 af[2][2], bf[2][NT];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) af[s2][mi] = *reinterpret_cast<const bf16x8*>(L + aoff[s2] + mi * 2048);
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) bf[s2][ni] = *reinterpret_cast<const bf16x8*>(L + boff[s2] + ni * 2048);
+    }
+    issue();                                            // tile kt+2 -> the slot of tile kt-1
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s2][mi], bf[s2][ni], acc[mi][ni], 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (zero-page) tiles must land before the LDS is released
+  const int m0 = m_blk + wm * 64, n0 = n_blk + wn * 32 * NT;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[NT][4];
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * q + i];
+      ep.template quad<NT>(m0 + 32 * mi + 8 * q + 4 * h, n0 + r, 32, v);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Filter-gradient kernel with hardware-transposed LDS reads.
 // Both operands of dW = dY^T . Xcol are contiguous along M/N (channels) and strided along K (pixels).  Instead of
 // transposing 8x4 micro-blocks in registers, the tiles are copied into LDS as they are -- [32 k][128 channels] bf16, one

@@ -34,6 +34,17 @@ static bool dma_eligible(int M, int N, int K, int C) {
   const int blocks = cdiv(M, 256) * (N / 256), rounds = cdiv(blocks, 256);
   return blocks >= 200 && blocks * 10 >= rounds * 256 * 8;          // >= 80 % of the CU-rounds it occupies
 }
+// narrow variant: N = 128 or 64 (two workgroups per CU)
+static bool dma_narrow_eligible(int M, int N, int K, int C) {
+  if ((N != 128 && N != 64) || K % 32 || C % 32 || M < 256 || dma_disabled()) return false;
+  return dma_forced() || cdiv(M, 256) >= 400;
+}
+template <class AL, class BL, class EP>
+static void launch_dma_narrow(hipStream_t s, const AL& a, const BL& b, const EP& ep, int M, int N, int K) {
+  const int gy = cdiv(M, 256);
+  if (N == 128) hipLaunchKernelGGL((gemm_dma_narrow_kernel<AL, BL, EP, 2>), dim3(gy), dim3(512), 0, s, a, b, ep, K, 1, gy, zero_page());
+  else          hipLaunchKernelGGL((gemm_dma_narrow_kernel<AL, BL, EP, 1>), dim3(gy), dim3(512), 0, s, a, b, ep, K, 1, gy, zero_page());
+}
 template <class AL, class BL, class EP>
 static void launch_dma(hipStream_t s, const AL& a, const BL& b, const EP& ep, int M, int N, int K) {
   const int gx = N / 256, gy = cdiv(M, 256);
@@ -221,6 +232,7 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
     LoadConvKh ah; ah.src = xb; ah.g = a;
     LoadKh bh; bh.p = wb; bh.ld = a.K; bh.rows = Cout; bh.K = a.K;
     if (dma_eligible(a.rows, Cout, a.K, Cin)) launch_dma(s, ah, bh, ep, a.rows, Cout, a.K);
+    else if (dma_narrow_eligible(a.rows, Cout, a.K, Cin)) launch_dma_narrow(s, ah, bh, ep, a.rows, Cout, a.K);
     else launch_lds(s, ah, bh, ep, a.rows, Cout, a.K, 1);       // (BK = 64 variant measured no faster: launch_lds64)
   } else {
     launch_conv_fwd(s, bf16, a, make_loadk(w, a.K, Cout, a.K), ep, a.rows, Cout, a.K);
@@ -236,6 +248,7 @@ void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* 
     LoadConvKh ah; ah.src = dyb; ah.g = a;
     LoadKh bh; bh.p = wtb; bh.ld = a.K; bh.rows = Cin; bh.K = a.K;          // wtb [Cin][tap][Cout]: K-contiguous over (tap, co)
     if (dma_eligible(a.rows, Cin, a.K, Cout)) launch_dma(s, ah, bh, ep, a.rows, Cin, a.K);
+    else if (dma_narrow_eligible(a.rows, Cin, a.K, Cout)) launch_dma_narrow(s, ah, bh, ep, a.rows, Cin, a.K);
     else launch_lds(s, ah, bh, ep, a.rows, Cin, a.K, 1);
   } else if (wtf) {                                          // fp32 taps re-laid [Cin][tap][Cout]: K-contiguous dwordx4 loads
     launch_big(s, bf16, a, make_loadk(wtf, a.K, Cin, a.K), ep, a.rows, Cin, a.K, 1);
