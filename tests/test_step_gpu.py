@@ -150,7 +150,8 @@ def test_bf16_path_runs_close(cuda, case, B):
     print(f"[parity] bf16 logits max-abs {e:.3e}; loss {loss:.4f} vs {float(loss_ref) * B:.4f}")
     assert e < 5e-2
     grads = m.get_gradients()
-    for k in ("proj.w", "dec.attn.wc", "enc_fw.l1.h2h.w", "enc_bw.l1.h2h.w", "enc_fw.l1.i2h.w", "cnn.conv6.w"):
+    for k in ("proj.w", "dec.attn.wc", "enc_fw.l1.h2h.w", "enc_bw.l1.h2h.w", "enc_fw.l1.i2h.w", "cnn.conv6.w", "cnn.conv2.b", "cnn.conv4.b",
+              "cnn.conv6.b"):
         a, b = grads[k].double().reshape(-1), G[k].double().reshape(-1)
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
         print(f"[parity] bf16 grad {k}: rel {relerr(grads[k], G[k]):.3e} cosine {cos:.5f}")

@@ -264,22 +264,22 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
                    (int64_t)B * d.T, 512, B, G0b);
   conv_backward_filter(s, bf, m->A6, G0, m->conv[7].dw, m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0, m->A6b, G0b);
   conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0, G0b, m->wtb[7], m->wtf[7]);
-  unpool_relu_backward(s, G1, m->A6, m->idx6, G0, B, d.H4, d.W2, 512, 2, G0b);
-  conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, G0b);
+  unpool_relu_backward(s, G1, m->A6, m->idx6, bf ? nullptr : G0, B, d.H4, d.W2, 512, 2, G0b, bf ? m->conv[6].db : nullptr, bf ? G0 : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
+  conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, bf ? nullptr : m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, G0b);
   conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, G0b, m->wtb[6], m->wtf[6]);
   bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
                    (int64_t)B * d.H4 * d.W2, 512, 0, G0b);
   conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, G0b);
   conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1, G0b, m->wtb[5], m->wtf[5]);
-  unpool_relu_backward(s, G1, m->A4, m->idx4, G0, B, d.H2, d.W2, 256, 2, G0b);
-  conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, G0b);
+  unpool_relu_backward(s, G1, m->A4, m->idx4, bf ? nullptr : G0, B, d.H2, d.W2, 256, 2, G0b, bf ? m->conv[4].db : nullptr, bf ? G0 : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
+  conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, bf ? nullptr : m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, G0b);
   conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, G0b, m->wtb[4], m->wtf[4]);
   bn_relu_backward(s, m->Y3, m->A3, G1, m->bn[3].w, m->bn[3].save, G0, m->bn[3].dw, m->bn[3].db, m->bn_scratch,
                    (int64_t)B * d.H2 * d.W2, 256, 0, G0b);
   conv_backward_filter(s, bf, m->A2, G0, m->conv[3].dw, m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, G0b);
   conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1, G0b, m->wtb[3], m->wtf[3]);
-  unpool_relu_backward(s, G1, m->A2, m->idx2, G0, B, d.H1, d.W1, 128, 1, G0b);
-  conv_backward_filter(s, bf, m->A1, G0, m->conv[2].dw, m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1, m->A1b, G0b);
+  unpool_relu_backward(s, G1, m->A2, m->idx2, bf ? nullptr : G0, B, d.H1, d.W1, 128, 1, G0b, bf ? m->conv[2].db : nullptr, bf ? G0 : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
+  conv_backward_filter(s, bf, m->A1, G0, m->conv[2].dw, bf ? nullptr : m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1, m->A1b, G0b);
   conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1, G0b, m->wtb[2], m->wtf[2]);
   conv1_backward(s, images, m->conv[1].w, m->conv[1].b, G1, m->conv[1].dw, m->conv[1].db, B, d.H, d.W,
                  (size_t)B * d.H1 * d.W1 * 128 >= (size_t)4096 * 640 ? G0 : nullptr);      // G0 is free here: use it as the partial slab

@@ -107,7 +107,8 @@ void conv_weight_shadows(hipStream_t s, const float* w, bf16_t* wb, bf16_t* wtb,
 void conv1_backward(hipStream_t s, const float* x, const float* w, const float* bias, const float* dyp, float* dw, float* db,
                     int B, int H, int W, float* scratch = nullptr);
 void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pooled, const uint8_t* idx, float* dy, int B,
-                          int Ho, int Wo, int C, int pool, bf16_t* dyb = nullptr);
+                          int Ho, int Wo, int C, int pool, bf16_t* dyb = nullptr, float* dbias = nullptr,
+                          float* partial = nullptr);   // dbias + partial (>= 2048*C floats scratch): fused bias gradient; dy may then be null
 size_t bn_scratch_bytes(int C);
 void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, const float* b, float* rm, float* rv,
                      float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows,
