@@ -260,23 +260,25 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
   float *G0 = m->G0, *G1 = m->G1; bf16_t* G0b = m->G0b;
   // bn7 + relu (dX is time-major, Y7 batch-major)
-  bn_relu_backward(s, m->Y7, m->X, m->dX, m->bn[7].w, m->bn[7].save, G0, m->bn[7].dw, m->bn[7].db, m->bn_scratch,
-                   (int64_t)B * d.T, 512, B, G0b);
-  conv_backward_filter(s, bf, m->A6, G0, m->conv[7].dw, m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0, m->A6b, G0b);
+  // bf16 mode: the BatchNorm backward writes only the bf16 shadow of its gradient, takes the ReLU mask from the bf16 output
+  // shadow and accumulates the preceding conv's bias gradient (fp32 G0 is free there: partial slab)
+  bn_relu_backward(s, m->Y7, m->X, m->dX, m->bn[7].w, m->bn[7].save, bf ? nullptr : G0, m->bn[7].dw, m->bn[7].db, m->bn_scratch,
+                   (int64_t)B * d.T, 512, B, G0b, bf ? m->Xb : nullptr, bf ? m->conv[7].db : nullptr, bf ? G0 : nullptr);
+  conv_backward_filter(s, bf, m->A6, G0, m->conv[7].dw, bf ? nullptr : m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0, m->A6b, G0b);
   conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0, G0b, m->wtb[7], m->wtf[7]);
   unpool_relu_backward(s, G1, m->A6, m->idx6, bf ? nullptr : G0, B, d.H4, d.W2, 512, 2, G0b, bf ? m->conv[6].db : nullptr, bf ? G0 : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
   conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, bf ? nullptr : m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, G0b);
   conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, G0b, m->wtb[6], m->wtf[6]);
-  bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
-                   (int64_t)B * d.H4 * d.W2, 512, 0, G0b);
-  conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, G0b);
+  bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, bf ? nullptr : G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
+                   (int64_t)B * d.H4 * d.W2, 512, 0, G0b, bf ? m->A5b : nullptr, bf ? m->conv[5].db : nullptr, bf ? G0 : nullptr);
+  conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, bf ? nullptr : m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, G0b);
   conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1, G0b, m->wtb[5], m->wtf[5]);
   unpool_relu_backward(s, G1, m->A4, m->idx4, bf ? nullptr : G0, B, d.H2, d.W2, 256, 2, G0b, bf ? m->conv[4].db : nullptr, bf ? G0 : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
   conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, bf ? nullptr : m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, G0b);
   conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, G0b, m->wtb[4], m->wtf[4]);
-  bn_relu_backward(s, m->Y3, m->A3, G1, m->bn[3].w, m->bn[3].save, G0, m->bn[3].dw, m->bn[3].db, m->bn_scratch,
-                   (int64_t)B * d.H2 * d.W2, 256, 0, G0b);
-  conv_backward_filter(s, bf, m->A2, G0, m->conv[3].dw, m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, G0b);
+  bn_relu_backward(s, m->Y3, m->A3, G1, m->bn[3].w, m->bn[3].save, bf ? nullptr : G0, m->bn[3].dw, m->bn[3].db, m->bn_scratch,
+                   (int64_t)B * d.H2 * d.W2, 256, 0, G0b, bf ? m->A3b : nullptr, bf ? m->conv[3].db : nullptr, bf ? G0 : nullptr);
+  conv_backward_filter(s, bf, m->A2, G0, m->conv[3].dw, bf ? nullptr : m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, G0b);
   conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1, G0b, m->wtb[3], m->wtf[3]);
   unpool_relu_backward(s, G1, m->A2, m->idx2, bf ? nullptr : G0, B, d.H1, d.W1, 128, 1, G0b, bf ? m->conv[2].db : nullptr, bf ? G0 : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
   conv_backward_filter(s, bf, m->A1, G0, m->conv[2].dw, bf ? nullptr : m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1, m->A1b, G0b);
@@ -417,8 +419,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       const bf16_t* hprevb = m->ehs_b[dir][l] ? m->ehs_b[dir][l] + (dir == 0 ? 0 : 2 * slot) : nullptr;
       wg[nwg++] = WGradProblem{dz, 4 * He, xin, p.in, p.dwi, p.in, 4 * He, p.in, T * B, dzb, xinb};
       wg[nwg++] = WGradProblem{dz, 4 * He, hprev, He, p.dwh, He, 4 * He, He, T * B, dzb, hprevb};
-      colsum_accum(s, dz, 4 * He, (int64_t)T * B, 4 * He, p.dbi);
-      colsum_accum(s, dz, 4 * He, (int64_t)T * B, 4 * He, p.dbh);
+      colsum_accum(s, dz, 4 * He, (int64_t)T * B, 4 * He, p.dbi, p.dbh);        // both biases see the same d z (LSTM.lua:79-88)
       float* dxo = l == 0 ? m->dX : m->edxl[dir];
       const int dxf = (l == 0 && dir == 1) ? EP_ACCUM : 0;                          // model.lua:675 copy, :689 add
       if (bf && dzb && p.swi.wtb) gemm_hh(s, dzb, 4 * He, p.swi.wtb, 4 * He, dxo, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dxf);
@@ -615,8 +616,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
     const LstmP& p = m->dec[l]; const float* dz = m->ddz[l];
     const bf16_t* dzb = sh ? m->ddz_b[l] : nullptr;
     wg[nwg++] = WGradProblem{dz, 4 * Hd, m->dhs[l], Hd, p.dwh, Hd, 4 * Hd, Hd, rows, dzb, sh ? m->dhs_b[l] : nullptr};
-    colsum_accum(s, dz, 4 * Hd, rows, 4 * Hd, p.dbi);
-    colsum_accum(s, dz, 4 * Hd, rows, 4 * Hd, p.dbh);
+    colsum_accum(s, dz, 4 * Hd, rows, 4 * Hd, p.dbi, p.dbh);
     if (l == 0) {
       wg[nwg++] = WGradProblem{dz, 4 * Hd, m->emb_all, E, p.dwi, p.in, 4 * Hd, E, rows};
       if (m->cfg.input_feed) wg[nwg++] = WGradProblem{dz, 4 * Hd, m->out_all, Hd, p.dwi + E, p.in, 4 * Hd, Hd, rows, dzb, sh ? m->out_b : nullptr};

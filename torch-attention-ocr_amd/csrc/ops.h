@@ -114,7 +114,9 @@ void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, co
                      float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows,
                      bf16_t* yb = nullptr);
 void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
-                      float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb = nullptr);
+                      float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb = nullptr,
+                      const bf16_t* yb = nullptr, float* conv_dbias = nullptr, float* partial = nullptr);
+// yb: bf16 shadow of y (ReLU mask source); conv_dbias + partial (>= 4096*256 floats): fused bias gradient of the preceding conv, dx may then be null
 // ctx_div: rows r share context row r / ctx_div (beam search keeps one context per image, model.lua:373)
 void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a, float* c, int64_t ldc, int B, int T, int Hd,
                        int ctx_div = 1, bf16_t* cb = nullptr, int64_t ldcb = 0);
@@ -128,7 +130,7 @@ void logsoftmax_nll(hipStream_t s, const float* logits, int64_t ld, const int32_
                     float grad_scale);
 void sum_to_scalar(hipStream_t s, const float* x, int64_t n, float* out);                 // out[0] = sum x
 void gold_scores(hipStream_t s, const float* nll_rows, float* gold, int L, int B);       // gold[b] = -sum_t nll[t,b]
-void colsum_accum(hipStream_t s, const float* A, int64_t ld, int64_t rows, int N, float* out);   // out[n] += sum_r A[r][n]
+void colsum_accum(hipStream_t s, const float* A, int64_t ld, int64_t rows, int N, float* out, float* out2 = nullptr);   // out[n] (and out2[n]) += sum_r A[r][n]
 void embedding_gather(hipStream_t s, const float* table, const int32_t* tok, int64_t stride_t, int64_t stride_b, float* out,
                       int L, int B, int E);
 void embedding_scatter_accum(hipStream_t s, const float* demb, const int32_t* tok, int64_t stride_t, int64_t stride_b,

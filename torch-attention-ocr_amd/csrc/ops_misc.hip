@@ -307,7 +307,7 @@ size_t bn_scratch_bytes(int C) { return (size_t)(BN_CHUNKS + 1) * C * 2 * sizeof
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ dA, const float* __restrict__ save,
                                                          double* __restrict__ part, int64_t rows, int C, int mode,
-                                                         int tb_rows, int T) {
+                                                         int tb_rows, int T, const bf16_t* __restrict__ yb) {
   __shared__ double sh[2][4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
       else {
         int64_t ro = r;
         if (tb_rows > 0) { int64_t b = r / T, t = r - b * T; ro = t * tb_rows + b; }
-        float yy = y[ro * C + c];
+        float yy = yb ? (float)yb[ro * C + c] : y[ro * C + c];          // only the sign matters (ReLU mask): the bf16 shadow has it
         float d = yy > 0.f ? dA[ro * C + c] : 0.f;
         s0 += (double)d; s1 += (double)d * (double)((xv - mean) * inv);
       }
@@ -408,23 +408,42 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
   fin[c * 2] = s / (double)rows; fin[c * 2 + 1] = ss / (double)rows;
   dw[c] += (float)ss; db[c] += (float)s;                        // gradWeight = sum dy*xhat, gradBias = sum dy
 }
+// F32OUT = false / BIAS = true (bf16 mode): only the bf16 shadow of dx is written (every consumer reads the shadow) and the
+// gradient of the preceding conv's bias, sum_rows dx[., c], is accumulated per thread (the grid stride is a multiple of C, so a
+// thread keeps its channel) into a flat partial slab that a small column sum finishes.
+template <bool F32OUT, bool BIAS>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dA, const float* __restrict__ w,
                                                            const float* __restrict__ save, const double* __restrict__ fin,
                                                            float* __restrict__ dx, int64_t rows, int C, int tb_rows, int T,
-                                                           bf16_t* __restrict__ dxb) {
-  const int64_t total = rows * C;
+                                                           bf16_t* __restrict__ dxb, const bf16_t* __restrict__ yb,
+                                                           float* __restrict__ partial) {
+  const int C4 = C >> 2;                                // one channel quad per thread and iteration (16-byte accesses)
+  const int64_t total = rows * C4;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
-    int c = (int)(id % C); int64_t r = id / C;
+    const int c = (int)(id % C4) * 4; const int64_t r = id / C4;
     int64_t ro = r;
     if (tb_rows > 0) { int64_t bi = r / T, t = r - bi * T; ro = t * tb_rows + bi; }
-    float d = y[ro * C + c] > 0.f ? dA[ro * C + c] : 0.f;
-    float inv = save[C + c];
-    float xh = (x[id] - save[c]) * inv;
-    const float gx = (d - (float)fin[c * 2] - xh * (float)fin[c * 2 + 1]) * inv * w[c];
-    dx[id] = gx;
-    if (dxb) dxb[id] = (bf16_t)gx;
+    float yy[4];
+    if (yb) { bf16x4 t4 = *reinterpret_cast<const bf16x4*>(yb + ro * C + c); yy[0] = (float)t4[0]; yy[1] = (float)t4[1]; yy[2] = (float)t4[2]; yy[3] = (float)t4[3]; }
+    else { float4 t4 = *reinterpret_cast<const float4*>(y + ro * C + c); yy[0] = t4.x; yy[1] = t4.y; yy[2] = t4.z; yy[3] = t4.w; }
+    const float4 da4 = *reinterpret_cast<const float4*>(dA + ro * C + c);
+    const float4 x4 = *reinterpret_cast<const float4*>(x + r * C + c);
+    const float da[4] = {da4.x, da4.y, da4.z, da4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+    float gx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float d = yy[k] > 0.f ? da[k] : 0.f;
+      const float inv = save[C + c + k];
+      const float xh = (xv[k] - save[c + k]) * inv;
+      gx[k] = (d - (float)fin[(c + k) * 2] - xh * (float)fin[(c + k) * 2 + 1]) * inv * w[c + k];
+      if (BIAS) bsum[k] += gx[k];
+    }
+    if (F32OUT) *reinterpret_cast<float4*>(dx + r * C + c) = make_float4(gx[0], gx[1], gx[2], gx[3]);
+    if (dxb) { bf16x4 hb; hb[0] = (bf16_t)gx[0]; hb[1] = (bf16_t)gx[1]; hb[2] = (bf16_t)gx[2]; hb[3] = (bf16_t)gx[3]; *reinterpret_cast<bf16x4*>(dxb + r * C + c) = hb; }
   }
+  if (BIAS) *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 256 + threadIdx.x) * 4) = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
 }
 
 void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, const float* b, float* rm, float* rv,
@@ -434,7 +453,7 @@ void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, co
     double* part = (double*)scratch;
     int nchunk = (int)std::min<int64_t>(BN_CHUNKS, (rows + 63) / 64);
     hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, x, nullptr, nullptr, nullptr, part, rows,
-                       C, 0, 0, 0);
+                       C, 0, 0, 0, nullptr);
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, part, nchunk, rows, C, save, rm, rv,
                        update_running);
   } else {
@@ -445,16 +464,27 @@ void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, co
   hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(blocks), dim3(256), 0, s, x, y, w, b, save, rows, C, tb_rows, T, yb);
 }
 void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
-                      float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb) {
+                      float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb,
+                      const bf16_t* yb, float* conv_dbias, float* partial) {
   int T = tb_rows > 0 ? (int)(rows / tb_rows) : 0;
   double* part = (double*)scratch;
   double* fin = part + (size_t)BN_CHUNKS * C * 2;
   int nchunk = (int)std::min<int64_t>(BN_CHUNKS, (rows + 63) / 64);
-  hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, x, y, dA, save, part, rows, C, 1, tb_rows, T);
+  hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, x, y, dA, save, part, rows, C, 1, tb_rows, T, yb);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, part, nchunk, rows, C, save, fin, dw, db);
-  int64_t total = rows * C;
+  const int C4 = C / 4;
+  int64_t total = rows * C4;
   int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb);
+  if (conv_dbias && partial && dxb && 256 % C4 == 0) {  // fused bias gradient of the preceding conv (+ optional fp32 output)
+    // the grid stride (blocks * 256 quads) is a multiple of C4, so a thread keeps its channel quad: the flat partial slab
+    // [blocks * 256][4] is a [blocks * 256 / C4][C] matrix whose column sums are the bias gradient
+    int fb = (int)std::min<int64_t>((total + 255) / 256, 2048);
+    if (dx) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), dim3(fb), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, partial);
+    else    hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), dim3(fb), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, partial);
+    colsum_accum(s, partial, C, (int64_t)fb * 256 / C4, C, conv_dbias);
+    return;
+  }
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), dim3(blocks), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, nullptr);
 }
 
 // =============================================================================================
@@ -704,7 +734,7 @@ void gold_scores(hipStream_t s, const float* nll_rows, float* gold, int L, int B
 
 // out[n] += sum_r A[r][n]   (bias gradients).  grid = (column blocks of 64, row chunks); a workgroup is 16 row lanes x
 // 16 column quads (dwordx4 loads, two rows in flight per lane), reduced through LDS; one atomic per column per workgroup.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t ld, int64_t rows, int N, float* out) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t ld, int64_t rows, int N, float* out, float* out2) {
   __shared__ float sh[16][65];
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int n = blockIdx.x * 64 + cq * 4;
@@ -736,13 +766,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A
 #pragma unroll
       for (int i = 0; i < 16; ++i) v += sh[i][threadIdx.x];
       if (gridDim.y == 1) out[c] += v; else atomicAdd(&out[c], v);
+      if (out2) { if (gridDim.y == 1) out2[c] += v; else atomicAdd(&out2[c], v); }      // second accumulator of the same sums (the two LSTM biases)
     }
   }
 }
-void colsum_accum(hipStream_t s, const float* A, int64_t ld, int64_t rows, int N, float* out) {
+void colsum_accum(hipStream_t s, const float* A, int64_t ld, int64_t rows, int N, float* out, float* out2) {
   int nb = cdiv(N, 64);
   int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, 2048 / nb), (rows + 511) / 512);
-  hipLaunchKernelGGL(colsum_kernel, dim3(nb, chunks), dim3(256), 0, s, A, ld, rows, N, out);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nb, chunks), dim3(256), 0, s, A, ld, rows, N, out, out2);
 }
 
 // nn.LookupTable forward / accGradParameters (LSTM.lua:55-56)
