@@ -244,11 +244,11 @@ void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training
   conv1_forward(s, images, m->conv[1].w, m->conv[1].b, m->A1, B, d.H, d.W, m->A1b);
   conv_forward(s, bf, m->A1, m->conv[2].w, m->conv[2].b, m->A2, m->idx2, B, d.H1, d.W1, 64, 128, 3, 1, 1, 1, m->A1b, m->wb[2], m->A2b);
   conv_forward(s, bf, m->A2, m->conv[3].w, m->conv[3].b, m->Y3, nullptr, B, d.H2, d.W2, 128, 256, 3, 1, 0, 0, m->A2b, m->wb[3], nullptr);
-  bn_relu_forward(s, m->Y3, m->A3, m->bn[3].w, m->bn[3].b, m->bn[3].rm, m->bn[3].rv, m->bn[3].save, m->bn_scratch,
+  bn_relu_forward(s, m->Y3, bf ? nullptr : m->A3, m->bn[3].w, m->bn[3].b, m->bn[3].rm, m->bn[3].rv, m->bn[3].save, m->bn_scratch,
                   (int64_t)B * d.H2 * d.W2, 256, training, update_running, 0, m->A3b);
   conv_forward(s, bf, m->A3, m->conv[4].w, m->conv[4].b, m->A4, m->idx4, B, d.H2, d.W2, 256, 256, 3, 1, 1, 2, m->A3b, m->wb[4], m->A4b);
   conv_forward(s, bf, m->A4, m->conv[5].w, m->conv[5].b, m->Y5, nullptr, B, d.H4, d.W2, 256, 512, 3, 1, 0, 0, m->A4b, m->wb[5], nullptr);
-  bn_relu_forward(s, m->Y5, m->A5, m->bn[5].w, m->bn[5].b, m->bn[5].rm, m->bn[5].rv, m->bn[5].save, m->bn_scratch,
+  bn_relu_forward(s, m->Y5, bf ? nullptr : m->A5, m->bn[5].w, m->bn[5].b, m->bn[5].rm, m->bn[5].rv, m->bn[5].save, m->bn_scratch,
                   (int64_t)B * d.H4 * d.W2, 512, training, update_running, 0, m->A5b);
   conv_forward(s, bf, m->A5, m->conv[6].w, m->conv[6].b, m->A6, m->idx6, B, d.H4, d.W2, 512, 512, 3, 1, 1, 2, m->A5b, m->wb[6], m->A6b);
   conv_forward(s, bf, m->A6, m->conv[7].w, m->conv[7].b, m->Y7, nullptr, B, d.H6, d.W2, 512, 512, 2, 0, 0, 0, m->A6b, m->wb[7], nullptr);

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restr
     o.z = fmaxf((xv.z - m.z) * iv.z * ww.z + bb.z, 0.f); o.w = fmaxf((xv.w - m.w) * iv.w * ww.w + bb.w, 0.f);
     int64_t ro = r;
     if (tb_rows > 0) { int64_t bi = r / T, t = r - bi * T; ro = t * tb_rows + bi; }
-    *reinterpret_cast<float4*>(y + ro * C + c) = o;
+    if (y) *reinterpret_cast<float4*>(y + ro * C + c) = o;        // y == nullptr: only the bf16 shadow is kept (bf16 mode, inner layers)
     if (yb) { bf16x4 hb; hb[0] = (bf16_t)o.x; hb[1] = (bf16_t)o.y; hb[2] = (bf16_t)o.z; hb[3] = (bf16_t)o.w; *reinterpret_cast<bf16x4*>(yb + ro * C + c) = hb; }
   }
 }
