@@ -1302,7 +1302,7 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgs<AL, BL, EP>& g, 
   g.ep.template quad<NT>(m0 + 8 * q + 4 * h, n0 + r, 32, v);
 }
 
-template <class AL, class BL, class EP> struct SmallArgs2 { SmallArgs<AL, BL, EP> z[2]; };
+template <class AL, class BL, class EP> struct SmallArgs2 { SmallArgs<AL, BL, EP> z[3]; };     // up to three problems per launch (blockIdx.z)
 
 template <bool BF16, int NT, bool GATES, class AL, class BL, class EP>
 __global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs2<AL, BL, EP> zz, int gate_stride) {

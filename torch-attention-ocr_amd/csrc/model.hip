@@ -207,6 +207,18 @@ static void run_store_nn(aocr_model* m, const LoadK& a, const ShW& w, const EpSt
   else if (w.wtf) { SmallKKArgs z; z.a = a; z.b = make_loadk(w.wtf, w.R, w.C, w.R); z.ep = ep; z.K = a.K; launch_small_kk(m->s, false, 1, &z, M, w.C); }
   else { SmallKMNArgs z; z.a = a; z.b = make_loadmn(w.w, w.ld, w.C, a.K); z.ep = ep; z.K = a.K; launch_small_kmn(m->s, false, 1, &z, M, w.C); }
 }
+// up to three independent y_i = x_i W_i of the same shape in ONE launch (bf16 shadows on both sides); otherwise one launch each
+static void run_store_nn_group(aocr_model* m, int n, const LoadK* a, const ShW* const* w, const EpStore* ep, int M, const LoadKh2* ah) {
+  bool same = m->bf16 && hh_ok(ah, n, w[0]->C);
+  for (int i = 1; i < n && same; ++i) same = w[i]->C == w[0]->C;
+  if (same) {
+    SmallArgsHH z[3];
+    for (int i = 0; i < n; ++i) { z[i].a = ah[i]; z[i].b = make_loadkh(w[i]->wtb, w[i]->R, w[i]->C, w[i]->R); z[i].ep = ep[i]; z[i].K = ah[i].K; }
+    launch_small_hh(m->s, n, z, M, w[0]->C);
+    return;
+  }
+  for (int i = 0; i < n; ++i) run_store_nn(m, a[i], *w[i], ep[i], M, ah ? &ah[i] : nullptr);
+}
 // gate backward: d(h) GEMM part = x W (K may be 0: no GEMM part)
 static void run_gates_bwd(aocr_model* m, int nz, const LoadK* a, const ShW* const* w, const EpGatesBwd* ep, int M, int H,
                           const LoadKh2* ah = nullptr) {
@@ -597,13 +609,32 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
       e.dz = m->ddz[l] + (size_t)t * B * 4 * Hd; e.lddz = 4 * Hd; e.dc_out = m->dc_st[l]; e.lddco = Hd; e.M = B; e.H = Hd;
       if (sh) { e.dzb = m->ddz_b[l] + (size_t)t * B * 4 * Hd; e.lddzb = 4 * Hd; }
       run_gates_bwd(m, 1, &la, &ww, &e, B, Hd, &lah);
-      LoadKh2 dza = make_loadkh(sh ? m->ddz_b[l] + (size_t)t * B * 4 * Hd : nullptr, 4 * Hd, B, 4 * Hd);
-      // recurrent part for step t-1: dz_l W_{l,h2h}
-      run_store_nn(m, make_loadk(m->ddz[l] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd), m->dec[l].swh, make_store(m->dh_rec[l], Hd, B, Hd), B, &dza);
     }
-    if (m->cfg.input_feed) {                                          // d(prev attention output) = dz_1 W_{1,i2h}[:, E:]
-      LoadKh2 dz0 = make_loadkh(sh ? m->ddz_b[0] + (size_t)t * B * 4 * Hd : nullptr, 4 * Hd, B, 4 * Hd);
-      run_store_nn(m, make_loadk(m->ddz[0] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd), m->dec[0].swi, make_store(m->dfeed, Hd, B, Hd), B, &dz0);
+    // Products of this step's d z that are only consumed at step t-1 -- the recurrent parts dz_l W_{l,h2h} and the
+    // input-feed gradient d(prev attention output) = dz_1 W_{1,i2h}[:, E:] -- are independent: one grouped launch.
+    {
+      LoadK ga[3]; LoadKh2 gah[3]; const ShW* gw[3]; EpStore gep[3]; int n = 0;
+      for (int l = Ld - 1; l >= 0 && n < 3; --l) {
+        const size_t zo = (size_t)t * B * 4 * Hd;
+        ga[n] = make_loadk(m->ddz[l] + zo, 4 * Hd, B, 4 * Hd); gah[n] = make_loadkh(sh ? m->ddz_b[l] + zo : nullptr, 4 * Hd, B, 4 * Hd);
+        gw[n] = &m->dec[l].swh; gep[n] = make_store(m->dh_rec[l], Hd, B, Hd); ++n;
+      }
+      const bool feed_grouped = m->cfg.input_feed && n < 3 && Ld <= 2;
+      if (feed_grouped) {
+        const size_t zo = (size_t)t * B * 4 * Hd;
+        ga[n] = make_loadk(m->ddz[0] + zo, 4 * Hd, B, 4 * Hd); gah[n] = make_loadkh(sh ? m->ddz_b[0] + zo : nullptr, 4 * Hd, B, 4 * Hd);
+        gw[n] = &m->dec[0].swi; gep[n] = make_store(m->dfeed, Hd, B, Hd); ++n;
+      }
+      if (Ld <= 3) run_store_nn_group(m, n, ga, gw, gep, B, gah);
+      else for (int l = Ld - 1; l >= 0; --l) {           // more layers than one launch groups: one launch each
+        const size_t zo = (size_t)t * B * 4 * Hd;
+        LoadKh2 dza = make_loadkh(sh ? m->ddz_b[l] + zo : nullptr, 4 * Hd, B, 4 * Hd);
+        run_store_nn(m, make_loadk(m->ddz[l] + zo, 4 * Hd, B, 4 * Hd), m->dec[l].swh, make_store(m->dh_rec[l], Hd, B, Hd), B, &dza);
+      }
+      if (m->cfg.input_feed && !feed_grouped) {
+        LoadKh2 dz0 = make_loadkh(sh ? m->ddz_b[0] + (size_t)t * B * 4 * Hd : nullptr, 4 * Hd, B, 4 * Hd);
+        run_store_nn(m, make_loadk(m->ddz[0] + (size_t)t * B * 4 * Hd, 4 * Hd, B, 4 * Hd), m->dec[0].swi, make_store(m->dfeed, Hd, B, Hd), B, &dz0);
+      }
     }
   }
   // ---- hoisted parameter gradients (accGradParameters of every clone summed over time)

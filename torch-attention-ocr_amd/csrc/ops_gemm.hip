@@ -88,7 +88,7 @@ template <int NT, bool GATES, class ARGS>
 static void launch_small(hipStream_t s, bool bf16, int nz, const ARGS* z, int M, int ncols, int gate_stride) {
   if (M <= 0 || ncols <= 0) return;
   dim3 grid(GATES ? cdiv(ncols, 32) : cdiv(ncols, 32 * NT), cdiv(M, 32), nz);
-  SmallArgs2<decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)> zz; zz.z[0] = z[0]; zz.z[1] = z[nz > 1 ? 1 : 0];
+  SmallArgs2<decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)> zz; zz.z[0] = z[0]; zz.z[1] = z[nz > 1 ? 1 : 0]; zz.z[2] = z[nz > 2 ? 2 : 0];
   if (bf16) hipLaunchKernelGGL((gemm_small_kernel<true, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid,
                                dim3(256), 0, s, zz, gate_stride);
   else      hipLaunchKernelGGL((gemm_small_kernel<false, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid,
@@ -112,7 +112,7 @@ template <int NT, bool GATES, class ARGS>
 static void launch_small_bf16(hipStream_t s, int nz, const ARGS* z, int M, int ncols, int gate_stride) {
   if (M <= 0 || ncols <= 0) return;
   dim3 grid(GATES ? cdiv(ncols, 32) : cdiv(ncols, 32 * NT), cdiv(M, 32), nz);
-  SmallArgs2<decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)> zz; zz.z[0] = z[0]; zz.z[1] = z[nz > 1 ? 1 : 0];
+  SmallArgs2<decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)> zz; zz.z[0] = z[0]; zz.z[1] = z[nz > 1 ? 1 : 0]; zz.z[2] = z[nz > 2 ? 2 : 0];
   bool staged = ncols % 32 == 0;                              // wave-private-LDS kernel: full-line loads, needs 64-aligned K
   for (int i = 0; i < nz; ++i)
     staged = staged && z[i].K > 0 && z[i].K % 64 == 0 && z[i].a.K0 % 64 == 0 && z[i].a.vec && z[i].b.ld0 % 8 == 0 &&
@@ -129,7 +129,7 @@ template <int NT, bool GATES, class ARGS>
 static void launch_small_bf16_hh(hipStream_t s, int nz, const ARGS* z, int M, int ncols, int gate_stride) {
   if (M <= 0 || ncols <= 0) return;
   dim3 grid(GATES ? cdiv(ncols, 32) : cdiv(ncols, 32 * NT), cdiv(M, 32), nz);
-  SmallArgs2<decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)> zz; zz.z[0] = z[0]; zz.z[1] = z[nz > 1 ? 1 : 0];
+  SmallArgs2<decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)> zz; zz.z[0] = z[0]; zz.z[1] = z[nz > 1 ? 1 : 0]; zz.z[2] = z[nz > 2 ? 2 : 0];
   hipLaunchKernelGGL((gemm_step_kernel<NT, GATES, decltype(z[0].a), decltype(z[0].ep)>), grid, dim3(256), 0, s, zz, gate_stride);
 }
 void launch_small_gates_fwd_hh(hipStream_t s, int nz, const GatesFwdArgsHH* z, int M, int H) { launch_small_bf16_hh<4, true>(s, nz, z, M, H, H); }
