@@ -217,6 +217,14 @@ static void run_store_nn_group(aocr_model* m, int n, const LoadK* a, const ShW* 
     launch_small_hh(m->s, n, z, M, w[0]->C);
     return;
   }
+  bool same32 = !m->bf16;                               // fp32 mode: the same grouping over the fp32 transposed weights
+  for (int i = 0; i < n && same32; ++i) same32 = w[i]->wtf != nullptr && w[i]->C == w[0]->C;
+  if (same32) {
+    SmallKKArgs z[3];
+    for (int i = 0; i < n; ++i) { z[i].a = a[i]; z[i].b = make_loadk(w[i]->wtf, w[i]->R, w[i]->C, w[i]->R); z[i].ep = ep[i]; z[i].K = a[i].K; }
+    launch_small_kk(m->s, false, n, z, M, w[0]->C);
+    return;
+  }
   for (int i = 0; i < n; ++i) run_store_nn(m, a[i], *w[i], ep[i], M, ah ? &ah[i] : nullptr);
 }
 // gate backward: d(h) GEMM part = x W (K may be 0: no GEMM part)
