@@ -27,6 +27,8 @@ struct EpStore {
   int flags;
   float* C1; int64_t ldc1; int N0;       // optional split of the N range (C1 == nullptr: unused)
   bf16_t* Cb = nullptr; int64_t ldcb = 0; // optional bf16 shadow of C (plain stores only)
+  // optional tanh-backward fusion (decoder BPTT, model.lua:649,654-657): x <- (x + dg[m][n]) * (1 - dout[m][n]^2)
+  const float* dg = nullptr; const float* dout = nullptr; int64_t ldd = 0;
   template <int NT> __device__ __forceinline__ void quad(int m, int n, int nstep, const float (&v)[NT][4]) const {
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
@@ -44,6 +46,7 @@ struct EpStore {
         float x = v[ni][i] + bb;
         if (flags & EP_RELU) x = fmaxf(x, 0.f);
         if (flags & EP_TANH) x = tanhf_(x);
+        if (dg) { const float o = dout[(int64_t)row * ldd + col]; x = (x + dg[(int64_t)row * ldd + col]) * (1.f - o * o); }
         float* p = base + (int64_t)row * ld + cc;
         if (flags & EP_ATOMIC) atomicAdd(p, x);
         else if (flags & EP_ACCUM) *p += x;
@@ -66,6 +69,7 @@ struct EpStore {
       if (bias2) x += bias2[col];
       if (flags & EP_RELU) x = fmaxf(x, 0.f);
       if (flags & EP_TANH) x = tanhf_(x);
+      if (dg) { const float o = dout[(int64_t)row * ldd + col]; x = (x + dg[(int64_t)row * ldd + col]) * (1.f - o * o); }
       float* p = (C1 && col >= N0) ? C1 + (int64_t)row * ldc1 + (col - N0) : C + (int64_t)row * ldc + col;
       if (flags & EP_ATOMIC) atomicAdd(p, x);
       else if (flags & EP_ACCUM) *p += x;

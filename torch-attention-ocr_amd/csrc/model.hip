@@ -585,15 +585,18 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
     hipMemsetAsync(m->dh_rec[l], 0, slot * sizeof(float), s);
     hipMemsetAsync(m->dc_st[l], 0, slot * sizeof(float), s);
   }
+  const bool feed_fused = m->cfg.input_feed && Ld <= 2;  // the feed product joins the grouped launch and carries the tanh backward
   for (int t = L - 1; t >= 0; --t) {
     const bool last = t == L - 1;
     const float* out_t = m->out_all + (size_t)(t + 1) * slot;
     float* dpre = m->dpre_all + (size_t)t * slot;
     float* dcat = m->dcat_all + (size_t)t * B * 2 * Hd;
-    // d(tanh) with the input-feed gradient of step t+1 added (model.lua:649,654-657)
+    // d(tanh) with the input-feed gradient of step t+1 added (model.lua:649,654-657).  With input feed the product
+    // d(prev attention output) of step t+1 already wrote dpre(t) through its epilogue (see the grouped launch below).
     const bool sh = m->bf16 && m->dpre_b != nullptr;
-    dpre_tanh(s, m->dout_proj + (size_t)t * slot, (m->cfg.input_feed && !last) ? m->dfeed : nullptr, out_t, dpre, (int64_t)slot,
-              sh ? m->dpre_b + (size_t)t * slot : nullptr);
+    if (!m->cfg.input_feed || last || !feed_fused)
+      dpre_tanh(s, m->dout_proj + (size_t)t * slot, (m->cfg.input_feed && !last) ? m->dfeed : nullptr, out_t, dpre, (int64_t)slot,
+                sh ? m->dpre_b + (size_t)t * slot : nullptr);
     LoadKh2 dpa = make_loadkh(sh ? m->dpre_b + (size_t)t * slot : nullptr, Hd, B, Hd);
     run_store_nn(m, make_loadk(dpre, Hd, B, Hd), m->swc, make_store(dcat, 2 * Hd, B, 2 * Hd), B, &dpa);      // d[c ; h_top] = dpre W_c
     attention_backward(s, m->context, m->q_all + (size_t)t * slot, m->a_all + (size_t)t * B * T, dcat, 2 * Hd,
@@ -631,7 +634,13 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
       if (feed_grouped) {
         const size_t zo = (size_t)t * B * 4 * Hd;
         ga[n] = make_loadk(m->ddz[0] + zo, 4 * Hd, B, 4 * Hd); gah[n] = make_loadkh(sh ? m->ddz_b[0] + zo : nullptr, 4 * Hd, B, 4 * Hd);
-        gw[n] = &m->dec[0].swi; gep[n] = make_store(m->dfeed, Hd, B, Hd); ++n;
+        gw[n] = &m->dec[0].swi;
+        if (t > 0) {                                      // writes dpre(t-1) = (dout_proj(t-1) + this product) * (1 - out(t-1)^2) directly
+          gep[n] = make_store(m->dpre_all + (size_t)(t - 1) * slot, Hd, B, Hd);
+          gep[n].dg = m->dout_proj + (size_t)(t - 1) * slot; gep[n].dout = m->out_all + (size_t)t * slot; gep[n].ldd = Hd;
+          if (sh) { gep[n].Cb = m->dpre_b + (size_t)(t - 1) * slot; gep[n].ldcb = Hd; }
+        } else gep[n] = make_store(m->dfeed, Hd, B, Hd);  // step 0: nothing consumes it
+        ++n;
       }
       if (Ld <= 3) run_store_nn_group(m, n, ga, gw, gep, B, gah);
       else for (int l = Ld - 1; l >= 0; --l) {           // more layers than one launch groups: one launch each
