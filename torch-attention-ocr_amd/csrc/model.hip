@@ -508,15 +508,14 @@ static void dec_init_state(aocr_model* m, const Dims& d, float* const* c0, float
   hipStream_t s = m->s; const int B = d.B, T = d.T, He = m->He, Hd = m->Hd; const size_t slot = (size_t)B * He;
   (void)R;
   const int lt = m->Le - 1;
-  for (int l = 0; l < m->Ld; ++l) {
-    hipMemsetAsync(c0[l], 0, (size_t)B * Hd * sizeof(float), s);
-    hipMemsetAsync(h0[l], 0, (size_t)B * Hd * sizeof(float), s);
-  }
-  if (feed0) hipMemsetAsync(feed0, 0, (size_t)B * Hd * sizeof(float), s);
+  ZeroList zl;                                          // MAXL = 4 layers: at most 4*3 + 2 = 14 regions
+  for (int l = 0; l < m->Ld; ++l) { zl.add(c0[l], (size_t)B * Hd * sizeof(float)); zl.add(h0[l], (size_t)B * Hd * sizeof(float)); }
+  if (feed0) zl.add(feed0, (size_t)B * Hd * sizeof(float));
   if (shadows) {
-    for (int l = 0; l < m->Ld; ++l) hipMemsetAsync(m->dhs_b[l], 0, (size_t)B * Hd * sizeof(bf16_t), s);
-    hipMemsetAsync(m->out_b, 0, (size_t)B * Hd * sizeof(bf16_t), s);
+    for (int l = 0; l < m->Ld; ++l) zl.add(m->dhs_b[l], (size_t)B * Hd * sizeof(bf16_t));
+    zl.add(m->out_b, (size_t)B * Hd * sizeof(bf16_t));
   }
+  zero_many(s, zl);
   // c1(0) = [c_fw(T) ; c_bw(1)]
   copy2d(s, m->ecs[0][lt] + (size_t)T * slot, He, c0[0], Hd, B, He);
   copy2d(s, m->ecs[1][lt] + (size_t)1 * slot, He, c0[0] + He, Hd, B, He);
@@ -581,10 +580,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   gemm(s, bf, m->dlogits, LOGIT_LD, true, m->wo, Hd, false, m->dout_proj, Hd, rows, Hd, V, nullptr, nullptr, 0);
   gemm(s, bf, m->dlogits, LOGIT_LD, false, m->out_all + slot, Hd, false, m->dwo, Hd, V, Hd, rows, nullptr, nullptr, EP_ATOMIC);
   colsum_accum(s, m->dlogits, LOGIT_LD, rows, V, m->dbo);
-  for (int l = 0; l < Ld; ++l) {
-    hipMemsetAsync(m->dh_rec[l], 0, slot * sizeof(float), s);
-    hipMemsetAsync(m->dc_st[l], 0, slot * sizeof(float), s);
-  }
+  { ZeroList zl; for (int l = 0; l < Ld; ++l) { zl.add(m->dh_rec[l], slot * sizeof(float)); zl.add(m->dc_st[l], slot * sizeof(float)); } zero_many(s, zl); }
   const bool feed_fused = m->cfg.input_feed && Ld <= 2;  // the feed product joins the grouped launch and carries the tanh backward
   for (int t = L - 1; t >= 0; --t) {
     const bool last = t == L - 1;

@@ -130,6 +130,9 @@ void logsoftmax_nll(hipStream_t s, const float* logits, int64_t ld, const int32_
                     float grad_scale);
 void sum_to_scalar(hipStream_t s, const float* x, int64_t n, float* out);                 // out[0] = sum x
 void gold_scores(hipStream_t s, const float* nll_rows, float* gold, int L, int B);       // gold[b] = -sum_t nll[t,b]
+struct ZeroList { void* p[16]; size_t bytes[16]; int n = 0;
+  void add(void* q, size_t b) { if (q && b && n < 16) { p[n] = q; bytes[n] = b; ++n; } } };
+void zero_many(hipStream_t s, const ZeroList& z);    // all listed regions (16-byte aligned) in one launch
 void colsum_accum(hipStream_t s, const float* A, int64_t ld, int64_t rows, int N, float* out, float* out2 = nullptr);   // out[n] (and out2[n]) += sum_r A[r][n]
 void embedding_gather(hipStream_t s, const float* table, const int32_t* tok, int64_t stride_t, int64_t stride_b, float* out,
                       int L, int B, int E);

@@ -4,6 +4,7 @@
 #include "ops.h"
 
 namespace aocr {
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -829,6 +830,18 @@ __global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ g1,
 }
 void dpre_tanh(hipStream_t s, const float* g1, const float* g2, const float* out, float* dpre, int64_t n, bf16_t* dpreb) {
   hipLaunchKernelGGL(dpre_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, g1, g2, out, dpre, n, dpreb);
+}
+// several small regions zeroed by ONE launch (each hipMemsetAsync is its own ~5 us dispatch on the step's critical path)
+__global__ __launch_bounds__(256) void zero_many_kernel(ZeroList z) {
+  unsigned char* p = (unsigned char*)z.p[blockIdx.y];
+  const size_t n = z.bytes[blockIdx.y], n16 = n >> 4;
+  u32x4v* p16 = reinterpret_cast<u32x4v*>(p);            // regions are 16-byte aligned (workspace carve)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p16[i] = u32x4v{0u, 0u, 0u, 0u};
+  if (blockIdx.x == 0) for (size_t i = (n16 << 4) + threadIdx.x; i < n; i += 256) p[i] = 0;
+}
+void zero_many(hipStream_t s, const ZeroList& z) {
+  if (z.n <= 0) return;
+  hipLaunchKernelGGL(zero_many_kernel, dim3(32, z.n), dim3(256), 0, s, z);
 }
 __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst, int64_t ldd,
                                                      int rows, int cols) {
