@@ -141,7 +141,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     m->bfeed[p] = a.get<float>(R * Hd);
   }
   for (int l = 0; l < m->Ld; ++l) { m->bc_new[l] = a.get<float>(R * Hd); m->bh_new[l] = a.get<float>(R * Hd); }
-  m->bemb = a.get<float>(R * E); m->bzx1 = a.get<float>(R * 4 * Hd); m->bq = a.get<float>(R * Hd); m->ba = a.get<float>(R * T);
+  m->bemb = a.get<float>(R * E); m->bzx1 = a.get<float>(R * 4 * Hd); m->bzx_tab = a.get<float>((size_t)m->V * 4 * Hd); m->bq = a.get<float>(R * Hd); m->ba = a.get<float>(R * T);
   m->bcat = a.get<float>(R * 2 * Hd); m->bout = a.get<float>(R * Hd); m->blogits = a.get<float>(R * LOGIT_LD);
   m->blogp = a.get<float>(R * m->V); m->beam_scores = a.get<float>(R);
   m->btok = a.get<int32_t>(R); m->bpar = a.get<int32_t>(R);
@@ -695,32 +695,42 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
   float* c0[MAXL]; float* h0[MAXL];
   for (int l = 0; l < Ld; ++l) { c0[l] = m->bc[0][l]; h0[l] = m->bh[0][l]; }
   dec_init_state(m, d, c0, h0, m->bfeed[0], B);
+  // The embedding part of the first layer's gate input depends on the token only: one table row per vocabulary entry
+  // (lookup W_i2h[:, :E]^T + both biases, LSTM.lua:55-56,79-80), gathered per step instead of a K = 20 GEMM per step.
+  gemm(s, bf, m->lookup, E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * Hd, V, 4 * Hd, E, p1.bi, p1.bh, 0);
   int cur = 0;
   for (int t = 0; t < Lt; ++t) {
     const int kin = t == 0 ? 1 : k, R = B * kin;
-    // embedding of the current input tokens (t = 0: the GO column of the targets, model.lua:388)
-    if (t == 0) embedding_gather(s, m->lookup, tgt, 0, Lt, m->bemb, 1, B, E);
-    else embedding_gather(s, m->lookup, m->btok, 0, 1, m->bemb, 1, R, E);
-    gemm(s, bf, m->bemb, E, true, p1.wi, p1.in, true, m->bzx1, 4 * Hd, R, 4 * Hd, E, p1.bi, p1.bh, 0);
+    // current input tokens (t = 0: the GO column of the targets, model.lua:388; later: the tokens chosen one step ago)
+    const int32_t* tok = t == 0 ? tgt : m->hist_tok + (size_t)(t - 1) * B * k;
+    token_rows(s, m->bzx_tab, tok, t == 0 ? Lt : 1, m->bzx1, R, 4 * Hd);
+    const int nxt = cur ^ 1;
+    const bool direct = k == 1;                         // greedy: the parent of every row is itself, no state gather needed
     DecStepIO io; io.R = R; io.ctx_div = kin; io.zx1 = m->bzx1; io.feed = m->bfeed[cur];
     for (int l = 0; l < Ld; ++l) {
-      io.c_prev[l] = m->bc[cur][l]; io.h_prev[l] = m->bh[cur][l]; io.c_new[l] = m->bc_new[l]; io.h_new[l] = m->bh_new[l];
+      io.c_prev[l] = m->bc[cur][l]; io.h_prev[l] = m->bh[cur][l];
+      io.c_new[l] = direct ? m->bc[nxt][l] : m->bc_new[l]; io.h_new[l] = direct ? m->bh[nxt][l] : m->bh_new[l];
       io.gates[l] = nullptr;
     }
-    io.q = m->bq; io.a = m->ba; io.cat = m->bcat; io.out = m->bout;
+    float* out = (direct && m->cfg.input_feed) ? m->bfeed[nxt] : m->bout;
+    io.q = m->bq; io.a = m->ba; io.cat = m->bcat; io.out = out;
     dec_step_forward(m, io, T);
-    gemm(s, bf, m->bout, Hd, true, m->wo, Hd, true, m->blogits, LOGIT_LD, R, V, Hd, m->bo, nullptr, 0);
-    logsoftmax_nll(s, m->blogits, LOGIT_LD, m->btok, 0, 0, R, m->blogp, nullptr, nullptr, R, V, 0.f);
-    beam_select(s, m->blogp, t == 0 ? nullptr : m->btok, m->beam_scores, m->hist_tok + (size_t)t * B * k,
-                m->hist_par + (size_t)t * B * k, B, kin, k, V);
-    const int32_t* par = m->hist_par + (size_t)t * B * k;
-    const int nxt = cur ^ 1;
-    for (int l = 0; l < Ld; ++l) {                                     // model.lua:521-535: gather states by parent beam
-      gather_beam_rows(s, m->bc_new[l], Hd, m->bc[nxt][l], Hd, par, B, kin, k, Hd);
-      gather_beam_rows(s, m->bh_new[l], Hd, m->bh[nxt][l], Hd, par, B, kin, k, Hd);
+    {                                                   // projector (V = 39 columns): 32 x 32 tiles, not two 128-row tiles
+      SmallKKArgs z; z.a = make_loadk(out, Hd, R, Hd); z.b = make_loadk(m->wo, Hd, V, Hd);
+      z.ep = make_store(m->blogits, LOGIT_LD, R, V, m->bo, nullptr, 0); z.K = Hd;
+      launch_small_kk(s, bf, 1, &z, R, V);
     }
-    if (m->cfg.input_feed) gather_beam_rows(s, m->bout, Hd, m->bfeed[nxt], Hd, par, B, kin, k, Hd);
-    hipMemcpyAsync(m->btok, m->hist_tok + (size_t)t * B * k, (size_t)B * k * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+    logsoftmax_nll(s, m->blogits, LOGIT_LD, tgt, 0, 0, R, m->blogp, nullptr, nullptr, R, V, 0.f);
+    beam_select(s, m->blogp, t == 0 ? nullptr : tok, m->beam_scores, m->hist_tok + (size_t)t * B * k,
+                m->hist_par + (size_t)t * B * k, B, kin, k, V);
+    if (!direct) {
+      const int32_t* par = m->hist_par + (size_t)t * B * k;
+      for (int l = 0; l < Ld; ++l) {                                   // model.lua:521-535: gather states by parent beam
+        gather_beam_rows(s, m->bc_new[l], Hd, m->bc[nxt][l], Hd, par, B, kin, k, Hd);
+        gather_beam_rows(s, m->bh_new[l], Hd, m->bh[nxt][l], Hd, par, B, kin, k, Hd);
+      }
+      if (m->cfg.input_feed) gather_beam_rows(s, m->bout, Hd, m->bfeed[nxt], Hd, par, B, kin, k, Hd);
+    }
     cur = nxt;
   }
   beam_backtrace(s, m->hist_tok, m->hist_par, m->beam_scores, labels, scores, Lt, B, k);

@@ -704,8 +704,36 @@ __global__ __launch_bounds__(256) void lsm_nll_kernel(const float* __restrict__ 
     for (int v = V; v < ld; ++v) dlogits[r * ld + v] = 0.f;
   }
 }
+// V <= 64: one wave per row, lane = class (the one-thread-per-row form walks V three times serially: 16 us for 256 rows)
+__global__ __launch_bounds__(256) void lsm_nll_wave_kernel(const float* __restrict__ logits, int64_t ld, const int32_t* __restrict__ tgt,
+                                                           int64_t st, int64_t sb, int Bt, float* __restrict__ logp,
+                                                           float* __restrict__ dlogits, float* __restrict__ nll, int64_t rows, int V,
+                                                           float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float xv = lane < V ? logits[r * ld + lane] : -INFINITY;
+  const float m = wave_max(xv);
+  const float sum = wave_sum(lane < V ? expf(xv - m) : 0.f);
+  const float lse = m + logf(sum);
+  const int64_t t = r / Bt, b = r - t * Bt;
+  const int y = tgt[t * st + b * sb] - 1;
+  const float wy = (y == 0) ? 0.f : 1.f;                        // criterion.lua:5: weights[PAD] = 0
+  if (nll && lane == y) nll[r] = -wy * (xv - lse);
+  if (logp && lane < V) logp[r * V + lane] = xv - lse;
+  if (dlogits) {
+    const float g = scale * wy;
+    if (lane < V) dlogits[r * ld + lane] = g * (expf(xv - lse) - (lane == y ? 1.f : 0.f));
+    for (int v = V + lane; v < ld; v += 64) dlogits[r * ld + v] = 0.f;
+  }
+}
 void logsoftmax_nll(hipStream_t s, const float* logits, int64_t ld, const int32_t* tgt, int64_t st, int64_t sb, int Bt,
                     float* logp, float* dlogits, float* nll_rows, int64_t rows, int V, float grad_scale) {
+  if (V <= 64) {
+    hipLaunchKernelGGL(lsm_nll_wave_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, logits, ld, tgt, st, sb, Bt, logp, dlogits, nll_rows,
+                       rows, V, grad_scale);
+    return;
+  }
   hipLaunchKernelGGL(lsm_nll_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, logits, ld, tgt, st, sb, Bt, logp, dlogits, nll_rows,
                      rows, V, grad_scale);
 }
@@ -969,6 +997,19 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   int c = (int)(id % width); int64_t r = id / width; int b = (int)(r / kout);
   int sr = (kin == 1) ? b : b * kin + parents[r];
   dst[r * ldd + c] = src[(int64_t)sr * lds + c];
+}
+// dst[r][:] = table[tok[r*stride] - 1][:]  (decode: the embedding part of the first layer's gate input, one table row per token)
+__global__ __launch_bounds__(256) void token_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ tok, int64_t stride,
+                                                         float* __restrict__ dst, int R, int width4) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (int64_t)R * width4) return;
+  const int c = (int)(id % width4); const int64_t r = id / width4;
+  const int v = tok[r * stride] - 1;
+  reinterpret_cast<float4*>(dst)[r * width4 + c] = reinterpret_cast<const float4*>(table)[(int64_t)v * width4 + c];
+}
+void token_rows(hipStream_t s, const float* table, const int32_t* tok, int64_t stride, float* dst, int R, int width) {
+  const int64_t n = (int64_t)R * (width / 4);
+  hipLaunchKernelGGL(token_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, table, tok, stride, dst, R, width / 4);
 }
 void gather_beam_rows(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, const int32_t* parents, int B, int kin,
                       int kout, int width) {
