@@ -720,9 +720,9 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
       z.ep = make_store(m->blogits, LOGIT_LD, R, V, m->bo, nullptr, 0); z.K = Hd;
       launch_small_kk(s, bf, 1, &z, R, V);
     }
-    logsoftmax_nll(s, m->blogits, LOGIT_LD, tgt, 0, 0, R, m->blogp, nullptr, nullptr, R, V, 0.f);
+    if (V > 64) logsoftmax_nll(s, m->blogits, LOGIT_LD, tgt, 0, 0, R, m->blogp, nullptr, nullptr, R, V, 0.f);
     beam_select(s, m->blogp, t == 0 ? nullptr : tok, m->beam_scores, m->hist_tok + (size_t)t * B * k,
-                m->hist_par + (size_t)t * B * k, B, kin, k, V);
+                m->hist_par + (size_t)t * B * k, B, kin, k, V, m->blogits, LOGIT_LD);      // LogSoftMax fused for V <= 64
     if (!direct) {
       const int32_t* par = m->hist_par + (size_t)t * B * k;
       for (int l = 0; l < Ld; ++l) {                                   // model.lua:521-535: gather states by parent beam

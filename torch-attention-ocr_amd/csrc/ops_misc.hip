@@ -949,14 +949,25 @@ void sgd_clip_update(hipStream_t s, float* params, float* grads, const int64_t* 
 // one wave per batch row; candidates c = beam*V + v (v 0-based).  Selection: descending score, ties -> lowest index.
 __global__ __launch_bounds__(64) void beam_select_kernel(const float* __restrict__ logp, const int32_t* __restrict__ prev_tok,
                                                          float* __restrict__ beam_scores, int32_t* __restrict__ tokens,
-                                                         int32_t* __restrict__ parents, int kin, int kout, int V) {
+                                                         int32_t* __restrict__ parents, int kin, int kout, int V,
+                                                         const float* __restrict__ logits, int64_t ldl) {
   extern __shared__ float cand[];                               // kin*V
   const int b = blockIdx.x, lane = threadIdx.x;
   const int n = kin * V;
+  if (logits) {                                                 // fused LogSoftMax (V <= 64: lane = class), output_projector.lua:6
+    for (int beam = 0; beam < kin; ++beam) {
+      const int row = b * kin + beam;
+      const float xv = lane < V ? logits[(int64_t)row * ldl + lane] : -INFINITY;
+      const float mx = wave_max(xv);
+      const float sum = wave_sum(lane < V ? expf(xv - mx) : 0.f);
+      if (lane < V) cand[beam * V + lane] = xv - (mx + logf(sum));
+    }
+    __syncthreads();
+  }
   for (int c = lane; c < n; c += 64) {
     int beam = c / V, v = c - beam * V;
     int row = b * kin + beam;
-    float lp = logp[(int64_t)row * V + v];
+    float lp = logits ? cand[c] : logp[(int64_t)row * V + v];
     if (prev_tok) {
       int pt = prev_tok[row];
       if (v == 0 && (pt == 1 || pt == 3)) lp = 0.f;             // model.lua:448-449: finished beams continue with PAD at zero cost
@@ -985,9 +996,10 @@ __global__ __launch_bounds__(64) void beam_select_kernel(const float* __restrict
   for (int k = lane; k < kout; k += 64) beam_scores[b * kout + k] = cand[n + k];
 }
 void beam_select(hipStream_t s, const float* logp, const int32_t* prev_tok, float* beam_scores, int32_t* tokens, int32_t* parents,
-                 int B, int kin, int kout, int V) {
+                 int B, int kin, int kout, int V, const float* logits, int64_t ldl) {
   size_t sh = (size_t)(kin * V + kout) * sizeof(float);
-  hipLaunchKernelGGL(beam_select_kernel, dim3(B), dim3(64), sh, s, logp, prev_tok, beam_scores, tokens, parents, kin, kout, V);
+  if (V > 64) logits = nullptr;                                 // the fused LogSoftMax needs one lane per class
+  hipLaunchKernelGGL(beam_select_kernel, dim3(B), dim3(64), sh, s, logp, prev_tok, beam_scores, tokens, parents, kin, kout, V, logits, ldl);
 }
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst,
                                                           int64_t ldd, const int32_t* __restrict__ parents, int B, int kin, int kout,
