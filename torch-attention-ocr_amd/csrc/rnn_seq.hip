@@ -23,6 +23,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#ifndef SEQ_RES_FWD
+#define SEQ_RES_FWD 12               // weight units (of 32 per wave at He = 256) that never leave the registers, forward kernel
+#endif
+#ifndef SEQ_RES_BWD
+#define SEQ_RES_BWD 4                // ... backward kernel (which also keeps 56 prefetched epilogue inputs in registers)
+#endif
 constexpr int SEQ_R = 4;                       // ring depth in units of 2 KiB (one 16-column tile x 64 k)
 constexpr int SEQ_RING = SEQ_R * 2048;         // bytes per wave
 constexpr int SEQ_ZXB = 8192;                  // per-wave staging of this step's pre-computed input part: 16 rows x 4 gates x 32 units fp32
@@ -66,7 +72,8 @@ __global__ __launch_bounds__(512, 1) void enc_seq_fwd_kernel(EncSeqFwdArgs p) {
   constexpr int He = 32 * NKS, U = (NKS / 2) * 8, PITCH = He * 2 + 32;
   // The first RES units (k 0..63 of all 8 column tiles) never leave the registers (64 VGPRs); the other NS = U - RES are
   // streamed.  At He = 256 that cuts the per-step stream from 512 to 384 KB per workgroup.
-  constexpr int RES = U > 8 ? 8 : 0, NS = U - RES;
+  constexpr int RES = U > SEQ_RES_FWD ? SEQ_RES_FWD : (U > 8 ? 8 : 0), NS = U - RES;
+  static_assert(NS % SEQ_R == 0, "streamed units must fill whole ring rounds");
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];       // the ONLY LDS object
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
@@ -314,7 +321,8 @@ void enc_seq_forward(hipStream_t s, const EncSeqFwdArgs& a0) {
 template <int NKS>
 __global__ __launch_bounds__(512, 1) void enc_seq_bwd_kernel(EncSeqBwdArgs p) {
   constexpr int He = 32 * NKS, KG = 4 * He, U = (KG / 64) * 2, APITCH = KG * 2 + 32;
-  constexpr int RES = U > 8 ? 8 : 0, NS = U - RES;
+  constexpr int RES = U > 8 ? SEQ_RES_BWD : 0, NS = U - RES;
+  static_assert(NS % SEQ_R == 0, "streamed units must fill whole ring rounds");
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
