@@ -159,7 +159,8 @@ def test_bf16_path_runs_close(cuda, case, B):
     m.shutdown()
 
 
-def test_dma_conv_kernel_matches_tiled_kernel(cuda, monkeypatch):
+@pytest.mark.parametrize("B,W", [(6, 72), (3, 200)])
+def test_dma_conv_kernel_matches_tiled_kernel(cuda, monkeypatch, B, W):
     """The 256x256x64 LDS-DMA conv kernel (forward + data gradient) against the 128x128 register-staged bf16 kernel on
     the same bf16 operands: only the fp32 accumulation order differs, so features, logits and every gradient must agree
     far inside the bf16-vs-oracle tolerance.  AOCR_FORCE_DMA=1 selects the DMA kernel wherever its shape rules hold
@@ -168,7 +169,7 @@ def test_dma_conv_kernel_matches_tiled_kernel(cuda, monkeypatch):
     out = {}
     for force in ("0", "1"):
         monkeypatch.setenv("AOCR_FORCE_DMA", force)
-        m, O, ocfg, P, st, batch = make(cfg, B=6, W=72, maxlen=6, compute="bf16")
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=6, compute="bf16")
         loss = m.train_forward_backward(batch)
         out[force] = dict(loss=loss, feats=m.get_tensor("feats").clone(), conv6=m.get_tensor("conv6").clone(),
                           logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
@@ -181,17 +182,19 @@ def test_dma_conv_kernel_matches_tiled_kernel(cuda, monkeypatch):
     assert abs(a["loss"] - b["loss"]) < 1e-3 * max(1.0, abs(a["loss"]))
     worst = 0.0
     for k in a["grads"]:
+        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):      # bias in front of a BatchNorm: exact gradient 0, only rounding noise
+            continue
         e = relerr(b["grads"][k], a["grads"][k]); worst = max(worst, e)
         assert e < 2e-2, (k, e)
     print(f"[parity] dma-vs-tiled worst gradient rel {worst:.3e}")
 
 
-@pytest.mark.parametrize("He,B,W", [(64, 16, 40), (256, 32, 72), (128, 16, 36)])
-def test_seq_encoder_kernels_match_step_kernels(cuda, monkeypatch, He, B, W):
+@pytest.mark.parametrize("He,B,W,Le", [(64, 16, 40, 1), (256, 32, 72, 1), (128, 16, 36, 1), (64, 16, 44, 2), (256, 16, 36, 2)])
+def test_seq_encoder_kernels_match_step_kernels(cuda, monkeypatch, He, B, W, Le):
     """Whole-sequence BiLSTM encoder kernels (one workgroup owns 16 batch rows for all T steps, weights re-streamed by
     LDS-DMA) against the per-step kernels on the same bf16 operands: only fp32 summation order differs.
     AOCR_NO_SEQ=1 forces the per-step path."""
-    cfg = dict(enc_hidden=He, enc_layers=1, dec_layers=2, input_feed=True)
+    cfg = dict(enc_hidden=He, enc_layers=Le, dec_layers=2, input_feed=True)      # Le = 2: the lower layer takes its d h from the layer above
     out = {}
     for no_seq in ("0", "1"):          # whole-sequence path first: it must not be able to inherit the other run's buffers
         monkeypatch.setenv("AOCR_NO_SEQ", no_seq)
