@@ -219,9 +219,9 @@ int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32
   else if (n == "dcontext") { *ptr_dev = m->dctx; *ndim = 3; shape[0] = d.B; shape[1] = d.T; shape[2] = m->Hd; }
   else if (n == "logits") { *ptr_dev = m->logits; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = LOGIT_LD; }
   else if (n == "outs") { *ptr_dev = m->out_all + (size_t)d.B * m->Hd; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = m->Hd; }
-  else if (n == "conv1") { *ptr_dev = m->A1; *ndim = 4; shape[0] = d.B; shape[1] = d.H1; shape[2] = d.W1; shape[3] = 64; }
-  else if (n == "conv2") { *ptr_dev = m->A2; *ndim = 4; shape[0] = d.B; shape[1] = d.H2; shape[2] = d.W2; shape[3] = 128; }
-  else if (n == "conv6") { *ptr_dev = m->A6; *ndim = 4; shape[0] = d.B; shape[1] = d.H6; shape[2] = d.W2; shape[3] = 512; }
+  else if (n == "conv1") { if (m->bf16) bf16_to_f32(m->s, m->A1b, m->A1, (int64_t)d.B * d.H1 * d.W1 * 64); *ptr_dev = m->A1; *ndim = 4; shape[0] = d.B; shape[1] = d.H1; shape[2] = d.W1; shape[3] = 64; }
+  else if (n == "conv2") { if (m->bf16) bf16_to_f32(m->s, m->A2b, m->A2, (int64_t)d.B * d.H2 * d.W2 * 128); *ptr_dev = m->A2; *ndim = 4; shape[0] = d.B; shape[1] = d.H2; shape[2] = d.W2; shape[3] = 128; }
+  else if (n == "conv6") { if (m->bf16) bf16_to_f32(m->s, m->A6b, m->A6, (int64_t)d.B * d.H6 * d.W2 * 512); *ptr_dev = m->A6; *ndim = 4; shape[0] = d.B; shape[1] = d.H6; shape[2] = d.W2; shape[3] = 512; }
   else return fail("unknown tensor '%s'", name);
   return 0;
 }
@@ -234,7 +234,7 @@ int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_p
   const Dims& d = m->last;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto run = [&]() {
-    conv_forward(m->s, m->bf16, m->A5, m->conv[6].w, m->conv[6].b, m->A6, m->idx6, d.B, d.H4, d.W2, 512, 512, 3, 1, 1, 2, m->A5b, m->wb[6],
+    conv_forward(m->s, m->bf16, m->A5, m->conv[6].w, m->conv[6].b, m->bf16 ? nullptr : m->A6, m->idx6, d.B, d.H4, d.W2, 512, 512, 3, 1, 1, 2, m->A5b, m->wb[6],
                  m->A6b);                                   // exactly the launch cnn_forward makes for conv6
   };
   run();

@@ -80,7 +80,7 @@ struct EpStore {
 
 // conv epilogue: bias, optional ReLU, optional fused max-pool (window = consecutive rows).
 struct EpConv {
-  float* y; uint8_t* idx; const float* bias; int Cout; int rows; int pmode; int relu;
+  float* y; uint8_t* idx; const float* bias; int Cout; int rows; int pmode; int relu;   // y may be null when yb is given (bf16 mode keeps only the shadow)
   bf16_t* yb;                              // optional bf16 shadow of y (operand of the next contraction)
   template <int NT> __device__ __forceinline__ void quad(int m, int n, int nstep, const float (&v)[NT][4]) const {
 #pragma unroll
@@ -94,7 +94,7 @@ struct EpConv {
       if (pmode == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (m + i < rows) {
-          y[(int64_t)(m + i) * Cout + col] = x[i];
+          if (y) y[(int64_t)(m + i) * Cout + col] = x[i];
           if (yb) yb[(int64_t)(m + i) * Cout + col] = (bf16_t)x[i];
         }
       } else if (pmode == 1) {
@@ -103,7 +103,8 @@ struct EpConv {
 #pragma unroll
           for (int i = 1; i < 4; ++i) if (x[i] > best) { best = x[i]; bi = i; }
           int64_t o = (int64_t)(m >> 2) * Cout + col;
-          y[o] = best; if (idx) idx[o] = (uint8_t)bi; if (yb) yb[o] = (bf16_t)best;
+          if (y) y[o] = best;
+          if (idx) idx[o] = (uint8_t)bi; if (yb) yb[o] = (bf16_t)best;
         }
       } else {
 #pragma unroll
@@ -112,7 +113,8 @@ struct EpConv {
           if (row < rows) {
             float a = x[2 * w], b = x[2 * w + 1];
             int64_t o = (int64_t)(row >> 1) * Cout + col;
-            y[o] = (b > a) ? b : a; if (idx) idx[o] = (uint8_t)(b > a); if (yb) yb[o] = (bf16_t)((b > a) ? b : a);
+            if (y) y[o] = (b > a) ? b : a;
+            if (idx) idx[o] = (uint8_t)(b > a); if (yb) yb[o] = (bf16_t)((b > a) ? b : a);
           }
         }
       }

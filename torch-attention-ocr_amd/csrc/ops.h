@@ -108,7 +108,9 @@ void conv1_backward(hipStream_t s, const float* x, const float* w, const float* 
                     int B, int H, int W, float* scratch = nullptr);
 void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pooled, const uint8_t* idx, float* dy, int B,
                           int Ho, int Wo, int C, int pool, bf16_t* dyb = nullptr, float* dbias = nullptr,
-                          float* partial = nullptr);   // dbias + partial (>= 2048*C floats scratch): fused bias gradient; dy may then be null
+                          float* partial = nullptr, const bf16_t* pooledb = nullptr);
+// dbias + partial (>= 2048*C floats scratch): fused bias gradient, dy may then be null; pooledb: bf16 shadow of pooled (mask source)
+void bf16_to_f32(hipStream_t s, const bf16_t* src, float* dst, int64_t n);
 size_t bn_scratch_bytes(int C);
 void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, const float* b, float* rm, float* rv,
                      float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows,

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
         }
       out[c] = best;
     }
-    *reinterpret_cast<float4*>(y + win * 64 + cq * 4) = make_float4(out[0], out[1], out[2], out[3]);
+    if (y) *reinterpret_cast<float4*>(y + win * 64 + cq * 4) = make_float4(out[0], out[1], out[2], out[3]);
     if (yb) {
       bf16x4 hb; hb[0] = (bf16_t)out[0]; hb[1] = (bf16_t)out[1]; hb[2] = (bf16_t)out[2]; hb[3] = (bf16_t)out[3];
       *reinterpret_cast<bf16x4*>(yb + win * 64 + cq * 4) = hb;
@@ -238,7 +238,8 @@ void weight_shadows(hipStream_t s, const float* w, int64_t ld, int R, int C, bf1
 template <bool F32OUT, bool BIAS>
 __global__ __launch_bounds__(256) void unpool_kernel(const float* __restrict__ dp, const float* __restrict__ pooled,
                                                      const uint8_t* __restrict__ idx, float* __restrict__ dy, bf16_t* __restrict__ dyb,
-                                                     float* __restrict__ dbias, int B, int Ho, int Wo, int C, int pool, int Hp, int Wp) {
+                                                     float* __restrict__ dbias, int B, int Ho, int Wo, int C, int pool, int Hp, int Wp,
+                                                     const bf16_t* __restrict__ pooledb) {
   const int C4 = C >> 2;
   const int64_t total = (int64_t)B * Hp * Wp * C4;
   float bs[4] = {0.f, 0.f, 0.f, 0.f};                 // BIAS: the grid stride is a multiple of C4, so a thread keeps its channel quad
@@ -246,7 +247,9 @@ __global__ __launch_bounds__(256) void unpool_kernel(const float* __restrict__ d
     int c4 = (int)(id % C4); int64_t win = id / C4;
     int px = (int)(win % Wp); int64_t t = win / Wp; int py = (int)(t % Hp); int b = (int)(t / Hp);
     float4 g = *reinterpret_cast<const float4*>(dp + win * C + c4 * 4);
-    float4 pv = *reinterpret_cast<const float4*>(pooled + win * C + c4 * 4);
+    float4 pv;                                            // only its sign is used (ReLU mask): the bf16 shadow of the pooled map has it
+    if (pooledb) { bf16x4 t4 = *reinterpret_cast<const bf16x4*>(pooledb + win * C + c4 * 4); pv = make_float4((float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]); }
+    else pv = *reinterpret_cast<const float4*>(pooled + win * C + c4 * 4);
     uint32_t ii = *reinterpret_cast<const uint32_t*>(idx + win * C + c4 * 4);
     float gv[4] = {pv.x > 0.f ? g.x : 0.f, pv.y > 0.f ? g.y : 0.f, pv.z > 0.f ? g.z : 0.f, pv.w > 0.f ? g.w : 0.f};
     int iv[4] = {(int)(ii & 255), (int)((ii >> 8) & 255), (int)((ii >> 16) & 255), (int)(ii >> 24)};
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(256) void unpool_kernel(const float* __restrict__ d
   }
 }
 void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pooled, const uint8_t* idx, float* dy, int B, int Ho,
-                          int Wo, int C, int pool, bf16_t* dyb, float* dbias, float* partial) {
+                          int Wo, int C, int pool, bf16_t* dyb, float* dbias, float* partial, const bf16_t* pooledb) {
   int Hp = Ho / 2, Wp = pool == 1 ? Wo / 2 : Wo;
   if ((Ho & 1) || (pool == 1 && (Wo & 1))) {                                      // floor-mode leftovers
     if (dy) hipMemsetAsync(dy, 0, (size_t)B * Ho * Wo * C * sizeof(float), s);
@@ -288,13 +291,13 @@ void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pool
   const int C4 = C / 4;
   if (dbias && partial && dyb && (256 % C4 == 0)) {     // fused bias gradient: per-workgroup partial rows, then one small column sum
     int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);             // grid stride 2048*256 is a multiple of every C4 | 256
-    if (dy) hipLaunchKernelGGL((unpool_kernel<true, true>), dim3(blocks), dim3(256), 0, s, dpooled, pooled, idx, dy, dyb, partial, B, Ho, Wo, C, pool, Hp, Wp);
-    else    hipLaunchKernelGGL((unpool_kernel<false, true>), dim3(blocks), dim3(256), 0, s, dpooled, pooled, idx, dy, dyb, partial, B, Ho, Wo, C, pool, Hp, Wp);
+    if (dy) hipLaunchKernelGGL((unpool_kernel<true, true>), dim3(blocks), dim3(256), 0, s, dpooled, pooled, idx, dy, dyb, partial, B, Ho, Wo, C, pool, Hp, Wp, pooledb);
+    else    hipLaunchKernelGGL((unpool_kernel<false, true>), dim3(blocks), dim3(256), 0, s, dpooled, pooled, idx, dy, dyb, partial, B, Ho, Wo, C, pool, Hp, Wp, pooledb);
     colsum_accum(s, partial, C, blocks, C, dbias);
     return;
   }
   int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
-  hipLaunchKernelGGL((unpool_kernel<true, false>), dim3(blocks), dim3(256), 0, s, dpooled, pooled, idx, dy, dyb, nullptr, B, Ho, Wo, C, pool, Hp, Wp);
+  hipLaunchKernelGGL((unpool_kernel<true, false>), dim3(blocks), dim3(256), 0, s, dpooled, pooled, idx, dy, dyb, nullptr, B, Ho, Wo, C, pool, Hp, Wp, pooledb);
 }
 
 // =============================================================================================
@@ -884,6 +887,12 @@ __global__ __launch_bounds__(256) void copy2d_bf16_kernel(const float* __restric
   if (i >= (int64_t)rows * cols) return;
   int c = (int)(i % cols); int64_t r = i / cols;
   dst[r * ldd + c] = (bf16_t)src[r * lds + c];
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (float)src[i];
+}
+void bf16_to_f32(hipStream_t s, const bf16_t* src, float* dst, int64_t n) {
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((int)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, src, dst, n);
 }
 void copy2d_bf16(hipStream_t s, const float* src, int64_t lds, bf16_t* dst, int64_t ldd, int rows, int cols) {
   hipLaunchKernelGGL(copy2d_bf16_kernel, dim3(cdiv((int64_t)rows * cols, 256)), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
