@@ -16,14 +16,14 @@ __global__ void fill(bf16_t* p, size_t n, unsigned seed) {
   }
 }
 
-template <int ABL, bool PIPE = true> static int run(const LoadConvKh& a, const LoadKh& b, const EpConv& ep, int M, int N, int K, const bf16_t* zero, const char* name) {
+template <int ABL, bool PIPE = true, bool PAIRS = false> static int run(const LoadConvKh& a, const LoadKh& b, const EpConv& ep, int M, int N, int K, const bf16_t* zero, const char* name) {
   const int gx = N / 256, gy = (M + 255) / 256;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_dma_bf16_kernel<LoadConvKh, LoadKh, EpConv, ABL, PIPE>), dim3(gx * gy), dim3(512), 0, 0, a, b, ep, K, gx, gy, zero);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_dma_bf16_kernel<LoadConvKh, LoadKh, EpConv, ABL, PIPE, PAIRS>), dim3(gx * gy), dim3(512), 0, 0, a, b, ep, K, gx, gy, zero);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   const int it = 20;
-  for (int i = 0; i < it; ++i) hipLaunchKernelGGL((gemm_dma_bf16_kernel<LoadConvKh, LoadKh, EpConv, ABL, PIPE>), dim3(gx * gy), dim3(512), 0, 0, a, b, ep, K, gx, gy, zero);
+  for (int i = 0; i < it; ++i) hipLaunchKernelGGL((gemm_dma_bf16_kernel<LoadConvKh, LoadKh, EpConv, ABL, PIPE, PAIRS>), dim3(gx * gy), dim3(512), 0, 0, a, b, ep, K, gx, gy, zero);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   double us = ms * 1e3 / it;
@@ -55,9 +55,14 @@ int main() {
   run<3>(a, b, ep, M, N, K, zero, "reads + barrier only");
   run<5>(a, b, ep, M, N, K, zero, "MFMA + barrier only");
   run<7>(a, b, ep, M, N, K, zero, "barrier + epilogue only");
+  { EpConv e2 = ep; e2.y = nullptr; run<7>(a, b, e2, M, N, K, zero, "barrier + epilogue only, no fp32 y");
+    run<0, false>(a, b, e2, M, N, K, zero, "full kernel, plain reads, no fp32 y");
+    e2.idx = nullptr; run<7>(a, b, e2, M, N, K, zero, "barrier + epilogue only, bf16 y only");
+    e2.yb = nullptr; run<7>(a, b, e2, M, N, K, zero, "barrier + epilogue only, no stores at all"); }
   for (int rep = 0; rep < 3; ++rep) {
     run<0, true>(a, b, ep, M, N, K, zero, "full kernel, pipelined reads");
     run<0, false>(a, b, ep, M, N, K, zero, "full kernel, plain reads");
+    run<0, false, true>(a, b, ep, M, N, K, zero, "full kernel, two tiles per barrier");
   }
   return 0;
 }

@@ -722,7 +722,7 @@ __device__ __forceinline__ void dma16(const void* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <class AL, class BL, class EP, int ABL = 0, bool PIPE = false>     // PIPE: fragment reads pipelined across the barrier (inline asm; measured 4-7 % slower); ABL: timing-only ablations (tools/ubench/dma_gemm.hip): 1 no in-loop DMA, 2 no MFMA, 4 no fragment reads
+template <class AL, class BL, class EP, int ABL = 0, bool PIPE = false, bool PAIRS = false>     // PAIRS: two K tiles per barrier; PIPE: fragment reads pipelined across the barrier (inline asm; measured 4-7 % slower); ABL: timing-only ablations (tools/ubench/dma_gemm.hip): 1 no in-loop DMA, 2 no MFMA, 4 no fragment reads
 __global__ __launch_bounds__(512, 1)
 void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t* zero) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 32768];          // the ONLY LDS object (a second one makes hipcc drain vmcnt)
@@ -788,7 +788,36 @@ void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t
     AOCR_DSR(fa1[2], pa, 4096); AOCR_DSR(fa1[3], pa, 6144);
   };
 #undef AOCR_DSR
-  if constexpr (!PIPE) {                                // plain form: compiler-managed reads, tile kt+3 issued under tile kt
+  if constexpr (!PIPE && PAIRS) {                       // two K tiles per barrier: 72 instead of 144 barriers at K = 4608 (a bare
+    // s_waitcnt + s_barrier iteration costs ~0.1 us: 30 us of the 300 us launch, tools/ubench/dma_gemm.hip).  Ring = two pairs of
+    // slots; pair p+1 is issued right after the barrier that ends pair p-1 and lands under the 32 MFMAs per wave of pair p.
+    const int npairs = (nk + 1) >> 1;                   // an odd last tile is padded by a zero-page tile
+    issue_a(); issue_b(); issue_a(); issue_b();
+    for (int pr = 0; pr < npairs; ++pr) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of pair pr have landed
+      __builtin_amdgcn_s_barrier();                     // ... everyone's have, and everyone is done reading pair pr-1
+      if constexpr (!(ABL & 1)) { issue_a(); issue_b(); issue_a(); issue_b(); }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const unsigned char* L = lds + (((pr & 1) << 1) + half) * 32768;
+        bf16x8 af[2][4], bf[2][2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) af[s2][mi] = *reinterpret_cast<const bf16x8*>(L + aoff[s2] + mi * 2048);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) bf[s2][ni] = *reinterpret_cast<const bf16x8*>(L + boff[s2] + ni * 2048);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s2][mi], bf[s2][ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+  } else if constexpr (!PIPE) {                         // plain form: compiler-managed reads, tile kt+3 issued under tile kt
 #pragma unroll
     for (int t = 0; t < 3; ++t) { issue_a(); issue_b(); }
     for (int kt = 0; kt < nk; ++kt) {
