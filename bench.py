@@ -162,6 +162,32 @@ def main():
               "unit": "image-lines/s"}
         m2.shutdown()
 
+    # data path: 255*rgb2y + image.scale of one C3 batch of decoded 48x384 RGB line images to 32x256,
+    # inputs resident in HBM; HBM-bound, reported against the 8 TB/s peak (algorithmic bytes = uint8 source + fp32 output)
+    dp = None
+    if world == 1 and not args.no_secondary:
+        import ctypes as C
+        from aocr.data import ImageDesc
+        n, sh, sw, ow = B, 48, 384, W
+        src = torch.randint(0, 256, (n * sh * sw * 3,), dtype=torch.uint8, device=dev)
+        desc = (ImageDesc * n)(*[ImageDesc(i * sh * sw * 3, sh, sw, 3, 0) for i in range(n)])
+        dsc = torch.from_numpy(np.frombuffer(bytes(desc), np.uint8).copy()).to(dev)
+        outp = torch.empty((n, 1, 32, ow), dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        run = lambda: aocr.check(aocr.lib.aocr_preprocess_lines(st, aocr.ptr(src), aocr.ptr(dsc), n, 32, ow, aocr.ptr(outp)))
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record(); torch.cuda.synchronize()
+        msd = e0.elapsed_time(e1) / 20
+        byts = n * (sh * sw * 3 + 32 * ow * 4)
+        dp = {"kernel": "aocr_preprocess_lines (rgb2y + image.scale 48x384x3 -> 32x%d)" % ow, "images_per_s": n / (msd * 1e-3),
+              "ms_per_batch": msd, "bound": "hbm", "achieved_GBps": byts / (msd * 1e-3) / 1e9, "peak_GBps": 8000.0,
+              "frac": byts / (msd * 1e-3) / 1e9 / 8000.0}
+
     out = None
     if rank == 0:
         bf16 = wl["compute"] == "bf16"
@@ -181,7 +207,7 @@ def main():
                        "decoder_steps": L, "parallelism": f"dp{world}", "input_feed": True},
             "train_gflop_per_image": 3 * fpi / 1e9, "step_tflops": 3 * fpi * lines_per_s / 1e12,
             "step_mfma_frac": 3 * fpi * lines_per_s / 1e12 / (peak * world),
-            "decode_chars_per_s": dec, "loss": loss_val, "secondary": c2,
+            "decode_chars_per_s": dec, "loss": loss_val, "secondary": c2, "data_path": dp,
             "roofline": {"bound": "mfma", "kernel": "conv6 forward implicit GEMM (512->512 3x3 + ReLU + pool)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                          "ms_per_launch": ms},

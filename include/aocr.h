@@ -200,6 +200,20 @@ int aocr_logsoftmax_nll(void* stream, const float* logits_dev, int64_t ld, const
 int aocr_beam_select(void* stream, const float* logp_dev, const int32_t* prev_tok_dev, float* beam_scores_dev,
                      int32_t* tokens_dev, int32_t* parents_dev, int32_t B, int32_t kin, int32_t kout, int32_t V);
 
+/* ---- data path ----------------------------------------------------------------------------------
+ * data_gen.lua:68-79: img = 255 * image.rgb2y(img); img = image.scale(img, imgW, 32) for every decoded image of a batch
+ * (all images of a batch share imgW: the loader buckets by width, data_gen.lua:91-99).
+ * src_dev: the decoded images back to back, uint8, interleaved HWC with 1 (already gray) or 3 (RGB) channels;
+ * desc_dev[i]: where image i starts and its size; out_dev (n_images, 1, out_h, out_w) fp32 in 0..255.
+ * Arithmetic: single precision, operation for operation that of torch/image's rgb2y and scaleBilinear (rows to out_w first,
+ * then columns to out_h; enlarging interpolates with scale (src-1)/(dst-1), shrinking averages the covered source span). */
+typedef struct aocr_image_desc {
+  int64_t offset;      /* byte offset of the image inside src_dev */
+  int32_t height, width, channels, reserved;
+} aocr_image_desc;
+int aocr_preprocess_lines(void* stream, const uint8_t* src_dev, const aocr_image_desc* desc_dev, int32_t n_images,
+                          int32_t out_h, int32_t out_w, float* out_dev);
+
 #ifdef __cplusplus
 }
 #endif

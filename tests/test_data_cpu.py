@@ -1,0 +1,98 @@
+"""Data path, CPU side: the oracle's restatement of data_gen.lua / utils.lua (label ids, target width rule, the image.scale
+arithmetic on hand-checkable cases, bucketing and target assembly) and the host-side DataGen mirror's list/bucket logic."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+import data_oracle as D  # noqa: E402
+
+
+def test_str2numlist():
+    assert D.str2numlist("a0z9") == [2, 14, 4, 39, 13, 3]          # utils.lua:104-118: digits 4..13, letters 14..39, GO=2, EOS=3
+    assert D.str2numlist("") == [2, 3]
+
+
+def test_target_width_rule():
+    assert D.target_width(32, 100, 8.0, force_width=None) == 100
+    assert D.target_width(20, 400, 8.0, force_width=None) == 256    # aspect clamped to max_aspect_ratio
+    assert D.target_width(64, 10, 8.0, force_width=None) == 16      # ... and to 0.5 from below
+    assert D.target_width(50, 75, 8.0, force_width=None) == 48      # ceil(1.5 * 32)
+    assert D.target_width(50, 75, 8.0) == 100                       # data_gen.lua:78 override
+
+
+def test_scale_line_known_answers():
+    f = np.float32
+    # enlarging 3 -> 5: scale (3-1)/(5-1) = 0.5: samples at 0, .5, 1, 1.5, 2
+    np.testing.assert_array_equal(D._scale_line(np.array([0, 10, 20], f), 5), np.array([0, 5, 10, 15, 20], f))
+    # shrinking 4 -> 2: averages of disjoint halves
+    np.testing.assert_array_equal(D._scale_line(np.array([1, 3, 5, 7], f), 2), np.array([2, 6], f))
+    # shrinking 3 -> 2: spans [0,1.5) and [1.5,3): (a + .5 b)/1.5, (.5 b + c)/1.5
+    got = D._scale_line(np.array([3, 6, 9], f), 2)
+    np.testing.assert_allclose(got, np.array([4, 8], f), rtol=1e-6)
+    np.testing.assert_array_equal(D._scale_line(np.array([7, 8], f), 2), np.array([7, 8], f))
+    np.testing.assert_array_equal(D._scale_line(np.array([7], f), 3), np.array([7, 7, 7], f))
+
+
+def test_rgb2y_and_constant_image():
+    img = np.full((10, 20, 3), 200, np.uint8)
+    g = D.rgb2y255(img)
+    assert abs(float(g[0, 0]) - 200.0) < 1e-3                      # weights sum to 1
+    out = D.preprocess(img, 8.0)
+    assert out.shape == (32, 100) and np.abs(out - g[0, 0]).max() < 1e-3
+    gray = np.arange(12, dtype=np.uint8).reshape(3, 4)
+    np.testing.assert_array_equal(D.rgb2y255(gray), gray.astype(np.float32))
+
+
+def _mk(n_lines, widths, rng):
+    imgs, lines = {}, []
+    for i in range(n_lines):
+        w = widths[i % len(widths)]
+        imgs[f"im{i}"] = rng.integers(0, 256, (20, w), dtype=np.uint8)
+        lines.append([f"im{i}", "ab" + "c" * (i % 3)])
+    return imgs, lines
+
+
+def test_datagen_buckets_and_flush():
+    rng = np.random.default_rng(0)
+    imgs, lines = _mk(7, [20, 60], rng)                             # target widths 32 and 96 with the aspect rule
+    imgs["im3"] = None                                              # a failed load is skipped
+    g = D.DataGen(lines, lambda p: imgs[p], max_aspect_ratio=8.0, force_width=None)
+    b1 = g.next_batch(2)                                            # im0 (w32), im1 (w96), im2 (w32) -> bucket 32 full first
+    assert b1[0].shape == (2, 1, 32, 32) and b1[4] == ["im0", "im2"]
+    assert b1[1].tolist() == [[2, 14, 15, 1, 1], [2, 14, 15, 16, 16]]        # targets: GO + chars ("ab", "abcc"), padded with 1
+    assert b1[2].tolist() == [[14, 15, 3, 1, 1], [14, 15, 16, 16, 3]] and b1[3] == 3 + 5
+    b2 = g.next_batch(2)                                            # im3 skipped; im4 (w32), im5 (w96) -> bucket 96 = {im1, im5}
+    assert b2[0].shape == (2, 1, 32, 96) and b2[4] == ["im1", "im5"]
+    b3 = g.next_batch(2)                                            # im6 (w32) joins im4
+    assert b3[4] == ["im4", "im6"]
+    assert g.next_batch(2) is None and g.cursor == 0                # exhausted: rewind (data_gen.lua:126-130)
+    g2 = D.DataGen(lines[:3], lambda p: imgs[p], 8.0, force_width=None)
+    assert g2.next_batch(2)[4] == ["im0", "im2"]
+    tail = g2.next_batch(2)                                         # leftover bucket flushed with its real size
+    assert tail[0].shape[0] == 1 and tail[4] == ["im1"]
+    assert g2.next_batch(2) is None
+
+
+def test_host_datagen_list_and_labels(tmp_path):
+    """aocr.data.DataGen: list-file parsing, PGM/NPY readers, bucket bookkeeping (no GPU: _emit is not reached)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "torch-attention-ocr_amd"))
+    data = pytest.importorskip("aocr.data")
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, (12, 30), dtype=np.uint8)
+    with open(tmp_path / "x.pgm", "wb") as f:
+        f.write(b"P5\n# comment\n30 12\n255\n" + a.tobytes())
+    np.save(tmp_path / "y.npy", rng.integers(0, 256, (12, 30, 3), dtype=np.uint8))
+    (tmp_path / "list.txt").write_text("x.pgm abc\ny.npy 12\nmissing.pgm zz\n")
+    np.testing.assert_array_equal(data.load_image(str(tmp_path / "x.pgm")), a)
+    assert data.load_image(str(tmp_path / "y.npy")).shape == (12, 30, 3)
+    assert data.load_image(str(tmp_path / "missing.pgm")) is None
+    g = data.DataGen(str(tmp_path), "list.txt", 8.0)
+    assert g.size() == 3 and data.str2numlist("a0") == D.str2numlist("a0")
+    assert g._width(12, 30) == 100
+    g.force_width = None
+    assert g._width(12, 30) == D.target_width(12, 30, 8.0, None) == 80
+    with pytest.raises(FileNotFoundError):
+        data.DataGen(str(tmp_path), "nope.txt", 8.0)

@@ -8,6 +8,8 @@ from . import _lib                      # noqa: F401  (raises ImportError when l
 from ._lib import AocrError, Config, COMPUTE_BF16, COMPUTE_F32, lib, last_error, check, ptr, param_table
 from .model import Model, eval_word_err_rate, numlist2str, GROUPS
 from . import synth
+from . import data
+from .data import DataGen
 
-__all__ = ["Model", "AocrError", "Config", "COMPUTE_F32", "COMPUTE_BF16", "lib", "last_error", "check", "ptr",
+__all__ = ["Model", "DataGen", "data", "AocrError", "Config", "COMPUTE_F32", "COMPUTE_BF16", "lib", "last_error", "check", "ptr",
            "param_table", "eval_word_err_rate", "numlist2str", "GROUPS", "synth"]

@@ -68,6 +68,7 @@ SIGNATURES = {
     "aocr_attention_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32]),
     "aocr_attention_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32]),
     "aocr_logsoftmax_nll": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _f32]),
+    "aocr_preprocess_lines": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "aocr_beam_select": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32]),
 }
 

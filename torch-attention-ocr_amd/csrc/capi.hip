@@ -366,4 +366,12 @@ int aocr_beam_select(void* stream, const float* logp_dev, const int32_t* prev_to
   return check_launch("aocr_beam_select");
 }
 
+int aocr_preprocess_lines(void* stream, const uint8_t* src_dev, const aocr_image_desc* desc_dev, int32_t n_images, int32_t out_h,
+                          int32_t out_w, float* out_dev) {
+  REQUIRE(src_dev && desc_dev && out_dev, "NULL argument");
+  REQUIRE(n_images >= 0 && out_h >= 1 && out_w >= 1, "bad sizes: n_images=%d out_h=%d out_w=%d", n_images, out_h, out_w);
+  preprocess_lines((hipStream_t)stream, src_dev, desc_dev, n_images, out_h, out_w, out_dev);
+  return check_launch("aocr_preprocess_lines");
+}
+
 }  // extern "C"

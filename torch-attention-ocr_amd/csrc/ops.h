@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "aocr.h"
 #include "epilogues.h"
 #include "mfma_gemm.h"
 
@@ -184,4 +185,6 @@ struct EncSeqBwdArgs { EncSeqBwdDir d[2]; int B, T, He; };
 bool enc_seq_supported(int B, int He, int blocks_limit);
 void enc_seq_backward(hipStream_t s, const EncSeqBwdArgs& a);
 void enc_seq_forward(hipStream_t s, const EncSeqFwdArgs& a);
+// data path (data.hip): 255*rgb2y + image.scale to (out_h, out_w) for n images sharing out_w
+void preprocess_lines(hipStream_t s, const uint8_t* src, const aocr_image_desc* desc, int n_images, int out_h, int out_w, float* out);
 }  // namespace aocr
