@@ -166,10 +166,9 @@ void gemm_hh(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64
              const float* bias, const float* bias2, int flags) {
   LoadKh a; a.p = A; a.ld = lda; a.rows = M; a.K = K;
   LoadKh b; b.p = B; b.ld = ldb; b.rows = N; b.K = K;
-  // the 256 x 256 LDS-DMA kernel when the grid fills the CUs (the hoisted encoder projections at C3: 63 x 4 tiles); both
-  // operands need 16-byte aligned rows (lda, ldb multiples of 8) for the 16-byte DMA pieces
-  if (lda % 8 == 0 && ldb % 8 == 0 && dma_eligible(M, N, K, K)) launch_dma(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K);
-  else launch_lds(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K, 1);
+  // (the 256 x 256 LDS-DMA kernel was measured slower here: K = 512 is only 16 tiles deep -- hoisted encoder projection at C3,
+  // 63 x 4 workgroups: 56 / 47 us against 47 / 43 us)
+  launch_lds(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K, 1);
 }
 
 template <class LD, class KERNEL>
