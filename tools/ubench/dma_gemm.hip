@@ -63,6 +63,7 @@ int main() {
     run<0, true>(a, b, ep, M, N, K, zero, "full kernel, pipelined reads");
     run<0, false>(a, b, ep, M, N, K, zero, "full kernel, plain reads");
     run<0, false, true>(a, b, ep, M, N, K, zero, "full kernel, two tiles per barrier");
+    run<8, false>(a, b, ep, M, N, K, zero, "full kernel, s_setprio around the MFMA blocks");
   }
   return 0;
 }

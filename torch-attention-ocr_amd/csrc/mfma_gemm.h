@@ -833,17 +833,21 @@ void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t
         for (int ni = 0; ni < 2; ++ni) bf[s2][ni] = *reinterpret_cast<const bf16x8*>(L + boff[s2] + ni * 2048);
       }
       if constexpr (!(ABL & 1)) issue_a();
+      if constexpr (ABL & 8) __builtin_amdgcn_s_setprio(1);      // experiment: raise the wave's priority over its MFMA block
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], bf[0][ni], acc[mi][ni], 0, 0, 0);
+      if constexpr (ABL & 8) __builtin_amdgcn_s_setprio(0);
       if constexpr (!(ABL & 1)) issue_b();
+      if constexpr (ABL & 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][mi], bf[1][ni], acc[mi][ni], 0, 0, 0);
+      if constexpr (ABL & 8) __builtin_amdgcn_s_setprio(0);
     }
   } else {
 #pragma unroll
