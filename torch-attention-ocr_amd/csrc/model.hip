@@ -717,14 +717,17 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
     float* out = (direct && m->cfg.input_feed) ? m->bfeed[nxt] : m->bout;
     io.q = m->bq; io.a = m->ba; io.cat = m->bcat; io.out = out;
     dec_step_forward(m, io, T);
-    {                                                   // projector (V = 39 columns): 32 x 32 tiles, not two 128-row tiles
+    if (V <= 64 && Hd % 4 == 0) {                        // projector + LogSoftMax + selection in one launch
+      project_select(s, out, Hd, m->wo, m->bo, Hd, t == 0 ? nullptr : tok, m->beam_scores, m->hist_tok + (size_t)t * B * k,
+                     m->hist_par + (size_t)t * B * k, B, kin, k, V);
+    } else {
       SmallKKArgs z; z.a = make_loadk(out, Hd, R, Hd); z.b = make_loadk(m->wo, Hd, V, Hd);
       z.ep = make_store(m->blogits, LOGIT_LD, R, V, m->bo, nullptr, 0); z.K = Hd;
       launch_small_kk(s, bf, 1, &z, R, V);
+      logsoftmax_nll(s, m->blogits, LOGIT_LD, tgt, 0, 0, R, m->blogp, nullptr, nullptr, R, V, 0.f);
+      beam_select(s, m->blogp, t == 0 ? nullptr : tok, m->beam_scores, m->hist_tok + (size_t)t * B * k,
+                  m->hist_par + (size_t)t * B * k, B, kin, k, V);
     }
-    if (V > 64) logsoftmax_nll(s, m->blogits, LOGIT_LD, tgt, 0, 0, R, m->blogp, nullptr, nullptr, R, V, 0.f);
-    beam_select(s, m->blogp, t == 0 ? nullptr : tok, m->beam_scores, m->hist_tok + (size_t)t * B * k,
-                m->hist_par + (size_t)t * B * k, B, kin, k, V, m->blogits, LOGIT_LD);      // LogSoftMax fused for V <= 64
     if (!direct) {
       const int32_t* par = m->hist_par + (size_t)t * B * k;
       for (int l = 0; l < Ld; ++l) {                                   // model.lua:521-535: gather states by parent beam

@@ -150,6 +150,9 @@ size_t sgd_scratch_bytes();
 void beam_select(hipStream_t s, const float* logp, const int32_t* prev_tok, float* beam_scores, int32_t* tokens,
                  int32_t* parents, int B, int kin, int kout, int V, const float* logits = nullptr, int64_t ldl = 0);
 // logits != nullptr (and V <= 64): raw projector outputs, the LogSoftMax is applied inside (logp is then unused)
+// projector + LogSoftMax + beam bookkeeping of one decode step in one launch (V <= 64, Hd % 4 == 0)
+void project_select(hipStream_t s, const float* h, int64_t ldh, const float* wo, const float* bo, int Hd, const int32_t* prev_tok,
+                    float* beam_scores, int32_t* tokens, int32_t* parents, int B, int kin, int kout, int V);
 void token_rows(hipStream_t s, const float* table, const int32_t* tok, int64_t stride, float* dst, int R, int width);   // dst[r] = table[tok[r*stride]-1]
 // dst[b*kout+i][:] = src[(kin==1 ? b : b*kin + parents[b*kout+i])][:]
 void gather_beam_rows(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, const int32_t* parents, int B,

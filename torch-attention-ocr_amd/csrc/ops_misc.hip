@@ -1004,6 +1004,68 @@ __global__ __launch_bounds__(64) void beam_select_kernel(const float* __restrict
   }
   for (int k = lane; k < kout; k += 64) beam_scores[b * kout + k] = cand[n + k];
 }
+// Decode step tail in ONE launch: projector (output_projector.lua:3-8: logits = W_o h + b), LogSoftMax, finished-beam masking,
+// score accumulation and top-k selection (model.lua:399-404,446-458,516).  One workgroup per batch element; the kin x V logits are
+// 512-long fp32 dot products spread over the 4 waves (lanes stride the hidden dimension), then the selection of beam_select_kernel.
+__global__ __launch_bounds__(256) void project_select_kernel(const float* __restrict__ h, int64_t ldh, const float* __restrict__ wo,
+                                                             const float* __restrict__ bo, int Hd, const int32_t* __restrict__ prev_tok,
+                                                             float* __restrict__ beam_scores, int32_t* __restrict__ tokens,
+                                                             int32_t* __restrict__ parents, int kin, int kout, int V) {
+  extern __shared__ float cand[];                               // kin*V (+ kout stash)
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = kin * V;
+#pragma unroll 4
+  for (int c = wave; c < n; c += 4) {                           // logits (unrolled: the loads of the next outputs overlap the reductions)
+    const int beam = c / V, v = c - beam * V;
+    const float* hr = h + (int64_t)(b * kin + beam) * ldh;
+    const float* wr = wo + (int64_t)v * Hd;
+    float s = 0.f;
+    for (int j = lane * 4; j < Hd; j += 256) {
+      const float4 a = *reinterpret_cast<const float4*>(hr + j), w4 = *reinterpret_cast<const float4*>(wr + j);
+      s = fmaf(a.x, w4.x, s); s = fmaf(a.y, w4.y, s); s = fmaf(a.z, w4.z, s); s = fmaf(a.w, w4.w, s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) cand[c] = s + bo[v];
+  }
+  __syncthreads();
+  if (wave == 0) {                                              // LogSoftMax per beam row (V <= 64), masking, running score
+    for (int beam = 0; beam < kin; ++beam) {
+      const int row = b * kin + beam;
+      const float xv = lane < V ? cand[beam * V + lane] : -INFINITY;
+      const float mx = wave_max(xv);
+      const float sum = wave_sum(lane < V ? expf(xv - mx) : 0.f);
+      float lp = xv - (mx + logf(sum));
+      if (prev_tok) {
+        const int pt = prev_tok[row];
+        if (lane == 0 && (pt == 1 || pt == 3)) lp = 0.f;        // model.lua:448-449
+        lp += beam_scores[row];                                 // model.lua:450
+      }
+      if (lane < V) cand[beam * V + lane] = lp;
+    }
+    for (int k = 0; k < kout; ++k) {                            // top-k: descending score, ties -> lowest index (single wave: no barriers)
+      float best = -INFINITY; int bi = 0x7fffffff;
+      for (int c = lane; c < n; c += 64) { float v = cand[c]; if (v > best) { best = v; bi = c; } }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      if (lane == 0) {
+        cand[bi] = -INFINITY; cand[n + k] = best;
+        tokens[b * kout + k] = bi % V + 1;
+        parents[b * kout + k] = bi / V;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    for (int k = lane; k < kout; k += 64) beam_scores[b * kout + k] = cand[n + k];
+  }
+}
+void project_select(hipStream_t s, const float* h, int64_t ldh, const float* wo, const float* bo, int Hd, const int32_t* prev_tok,
+                    float* beam_scores, int32_t* tokens, int32_t* parents, int B, int kin, int kout, int V) {
+  size_t sh = (size_t)(kin * V + kout) * sizeof(float);
+  hipLaunchKernelGGL(project_select_kernel, dim3(B), dim3(256), sh, s, h, ldh, wo, bo, Hd, prev_tok, beam_scores, tokens, parents, kin, kout, V);
+}
 void beam_select(hipStream_t s, const float* logp, const int32_t* prev_tok, float* beam_scores, int32_t* tokens, int32_t* parents,
                  int B, int kin, int kout, int V, const float* logits, int64_t ldl) {
   size_t sh = (size_t)(kin * V + kout) * sizeof(float);
