@@ -75,8 +75,8 @@ struct aocr_model {
   float *dh_rec[aocr::MAXL], *dc_st[aocr::MAXL], *dfeed, *loss_tmp;
   // decode (rows = B*beam)
   float *bc[2][aocr::MAXL], *bh[2][aocr::MAXL], *bfeed[2], *bc_new[aocr::MAXL], *bh_new[aocr::MAXL];
-  float *bemb, *bzx1, *bzx_tab, *bq, *ba, *bcat, *bout, *blogits, *blogp, *beam_scores;     // bzx_tab [V][4Hd]: per-token first-layer gate input
-  int32_t *btok, *bpar, *hist_tok, *hist_par, *tgt_pad, *tge_pad;
+  float *bzx1, *bzx_tab, *bq, *ba, *bcat, *bout, *blogits, *blogp, *beam_scores;     // bzx_tab [V][4Hd]: per-token first-layer gate input
+  int32_t *hist_tok, *hist_par, *tgt_pad, *tge_pad;
   void* sgd_scratch;
 
   aocr::Dims last;                // dims of the last step (for the parity taps)

@@ -141,10 +141,9 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     m->bfeed[p] = a.get<float>(R * Hd);
   }
   for (int l = 0; l < m->Ld; ++l) { m->bc_new[l] = a.get<float>(R * Hd); m->bh_new[l] = a.get<float>(R * Hd); }
-  m->bemb = a.get<float>(R * E); m->bzx1 = a.get<float>(R * 4 * Hd); m->bzx_tab = a.get<float>((size_t)m->V * 4 * Hd); m->bq = a.get<float>(R * Hd); m->ba = a.get<float>(R * T);
+  m->bzx1 = a.get<float>(R * 4 * Hd); m->bzx_tab = a.get<float>((size_t)m->V * 4 * Hd); m->bq = a.get<float>(R * Hd); m->ba = a.get<float>(R * T);
   m->bcat = a.get<float>(R * 2 * Hd); m->bout = a.get<float>(R * Hd); m->blogits = a.get<float>(R * LOGIT_LD);
   m->blogp = a.get<float>(R * m->V); m->beam_scores = a.get<float>(R);
-  m->btok = a.get<int32_t>(R); m->bpar = a.get<int32_t>(R);
   m->hist_tok = a.get<int32_t>(L * R); m->hist_par = a.get<int32_t>(L * R);
   m->tgt_pad = a.get<int32_t>(B * L); m->tge_pad = a.get<int32_t>(B * L);
   m->sgd_scratch = a.get<char>(sgd_scratch_bytes());
