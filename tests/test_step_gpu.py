@@ -262,3 +262,35 @@ def test_logits_c3_shape_bf16(cuda):
     assert e < 5e-2
     assert abs(loss - float(r["loss"]) * 256) < 2e-3 * abs(loss)
     m.shutdown()
+
+
+def test_train_step_parity_c2_shape(cuda):
+    """BASELINE config C2 at full size (32x100, B=64, He=256, Ld=2, input feed, L=24), exact-fp32 MFMA mode: loss and EVERY
+    gradient tensor of the fused train step against the fp64 oracle's hand-ordered BPTT (the small-shape test checks the
+    same at B=5)."""
+    m, O, ocfg, P, st, batch = make(dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True), B=64, W=100, maxlen=23,
+                                    max_decoder_l=24, max_beam=1)
+    img, tgt, tge = (torch.from_numpy(np.asarray(x)) for x in batch[:3])
+    loss_ref, G, aux, st_new = O.train_step_manual(P, st, ocfg, img, tgt, tge)
+    loss = m.train_forward_backward(batch)
+    assert abs(loss - float(loss_ref) * 64) < 1e-4 * abs(loss)
+    grads = m.get_gradients()
+    worst = ("", 0.0); bad = []
+    for k, g in G.items():
+        e = relerr(grads[k], g)
+        if g.abs().max() < 1e-9:                         # conv biases in front of BatchNorm have ~0 gradient
+            e = (grads[k].double() - g).abs().max().item()
+        a, b = grads[k].double().reshape(-1), g.double().reshape(-1)
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-300)) if b.norm() > 1e-9 else 1.0
+        if e > worst[1]: worst = (k, e)
+        print(f"[parity] C2 grad {k:22s} rel {e:.3e} cosine {cos:.7f}")
+        # Everything from conv7 upwards must match to fp32 accuracy.  Below the (2,1) pool after conv6 a handful of the 1.6 M
+        # pooling windows are fp32-vs-fp64 near-ties (arg-max) or sit within rounding of the ReLU threshold; each flip moves ONE
+        # term of a random-sign sum over ~51 k pixels, which is a percent-level change of single weight-gradient entries
+        # (max-norm) but leaves the direction untouched -- so those layers are held to the cosine.
+        early = k.startswith("cnn.") and not k.startswith(("cnn.conv7", "cnn.bn7"))
+        if (early and (cos < 0.9995 or e > 5e-2)) or (not early and e > 2e-3):
+            bad.append((k, e, cos))
+    assert not bad, bad
+    print(f"[parity] C2 full size fp32: loss {loss:.4f} vs {float(loss_ref) * 64:.4f}; {len(G)} gradient tensors, worst rel {worst[1]:.3e} ({worst[0]})")
+    m.shutdown()
