@@ -294,3 +294,25 @@ def test_train_step_parity_c2_shape(cuda):
     assert not bad, bad
     print(f"[parity] C2 full size fp32: loss {loss:.4f} vs {float(loss_ref) * 64:.4f}; {len(G)} gradient tensors, worst rel {worst[1]:.3e} ({worst[0]})")
     m.shutdown()
+
+
+@pytest.mark.parametrize("beam", [1, 3])
+def test_decode_parity_c2_shape(cuda, beam):
+    """BASELINE config C2 at full size, eval-mode BatchNorm, 50 decode steps + gold pass: labels, beam scores, gold scores and
+    the gold-pass loss against the fp64 oracle's decode (model.lua:321-627)."""
+    m, O, ocfg, P, st, batch = make(dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True), B=64, W=100, maxlen=23,
+                                    max_decoder_l=50, max_beam=3)
+    st = {k: (v + 0.05 if k.endswith("rm") else v * 1.3) for k, v in st.items()}
+    m.set_parameters(P, st)
+    img, tgt, tge = (torch.from_numpy(np.asarray(x)) for x in batch[:3])
+    ref = O.decode_beam(P, st, ocfg, img, tgt, tge, beam=beam, max_decoder_l=50)
+    loss, stats = m.step(batch, True, beam)
+    out = m._dec_out
+    same = (out.labels == ref["labels"].numpy().astype(np.int32)).all(axis=1)
+    print(f"[parity] C2 decode beam {beam}: {int(same.sum())}/64 label sequences identical; loss {loss:.4f} vs {float(ref['loss']):.4f}; "
+          f"scores max-abs {np.abs(out.scores - ref['scores'].numpy())[same].max():.2e}")
+    assert same.sum() >= 63                      # a near-tie between two tokens may flip one sequence in fp32
+    assert np.abs(out.scores - ref["scores"].numpy())[same].max() < 5e-3
+    assert np.abs(out.gold_scores - ref["gold_scores"].numpy()).max() < 5e-3
+    assert abs(loss - float(ref["loss"])) < 2e-3 * max(1.0, float(ref["loss"]))
+    m.shutdown()
