@@ -235,7 +235,7 @@ int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_p
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto run = [&]() {
     conv_forward(m->s, m->bf16, m->A5, m->conv[6].w, m->conv[6].b, m->bf16 ? nullptr : m->A6, m->idx6, d.B, d.H4, d.W2, 512, 512, 3, 1, 1, 2, m->A5b, m->wb[6],
-                 m->A6b);                                   // exactly the launch cnn_forward makes for conv6
+                 m->A6b, 1);                                // exactly the launch cnn_forward makes for conv6 (distinct symbol: TAG = 1)
   };
   run();
   hipEventRecord(e0, m->s);

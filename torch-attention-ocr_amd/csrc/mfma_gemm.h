@@ -722,7 +722,7 @@ __device__ __forceinline__ void dma16(const void* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <class AL, class BL, class EP, int ABL = 0, bool PIPE = false, bool PAIRS = false>     // PAIRS: two K tiles per barrier; PIPE: fragment reads pipelined across the barrier (inline asm; measured 4-7 % slower); ABL: timing-only ablations (tools/ubench/dma_gemm.hip): 1 no in-loop DMA, 2 no MFMA, 4 no fragment reads
+template <class AL, class BL, class EP, int ABL = 0, bool PIPE = false, bool PAIRS = false, int TAG = 0>     // TAG: distinct symbol for aocr_profile_kernel's launches (so that rocprofv3 --stats lists them on their own row); PAIRS: two K tiles per barrier; PIPE: fragment reads pipelined across the barrier (inline asm; measured 4-7 % slower); ABL: timing-only ablations (tools/ubench/dma_gemm.hip): 1 no in-loop DMA, 2 no MFMA, 4 no fragment reads
 __global__ __launch_bounds__(512, 1)
 void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t* zero) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 32768];          // the ONLY LDS object (a second one makes hipcc drain vmcnt)

@@ -46,9 +46,10 @@ static void launch_dma_narrow(hipStream_t s, const AL& a, const BL& b, const EP&
   else          hipLaunchKernelGGL((gemm_dma_narrow_kernel<AL, BL, EP, 1>), dim3(gy), dim3(512), 0, s, a, b, ep, K, 1, gy, zero_page());
 }
 template <class AL, class BL, class EP>
-static void launch_dma(hipStream_t s, const AL& a, const BL& b, const EP& ep, int M, int N, int K) {
+static void launch_dma(hipStream_t s, const AL& a, const BL& b, const EP& ep, int M, int N, int K, int tag = 0) {
   const int gx = N / 256, gy = cdiv(M, 256);
-  hipLaunchKernelGGL((gemm_dma_bf16_kernel<AL, BL, EP>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page());
+  if (tag) hipLaunchKernelGGL((gemm_dma_bf16_kernel<AL, BL, EP, 0, false, false, 1>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page());
+  else hipLaunchKernelGGL((gemm_dma_bf16_kernel<AL, BL, EP>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page());
 }
 // BK = 64 variant for bf16 K-contiguous operand pairs (conv forward / data gradient): half the barriers per FLOP
 template <class AL, class BL, class EP>
@@ -226,14 +227,14 @@ static LoadConvK make_convk(const float* src, int B, int Hs, int Ws, int C, int 
 
 void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, const float* bias, float* y, uint8_t* idx, int B,
                   int H, int W, int Cin, int Cout, int ks, int pad, int relu, int pool, const bf16_t* xb, const bf16_t* wb,
-                  bf16_t* yb) {
+                  bf16_t* yb, int profile_tag) {
   const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
   LoadConvK a = make_convk(x, B, H, W, Cin, ks, 1, -pad, Ho, Wo, pool);
   EpConv ep; ep.y = y; ep.idx = idx; ep.bias = bias; ep.Cout = Cout; ep.rows = a.rows; ep.pmode = pool; ep.relu = relu; ep.yb = yb;
   if (bf16 && xb && wb) {
     LoadConvKh ah; ah.src = xb; ah.g = a;
     LoadKh bh; bh.p = wb; bh.ld = a.K; bh.rows = Cout; bh.K = a.K;
-    if (dma_eligible(a.rows, Cout, a.K, Cin)) launch_dma(s, ah, bh, ep, a.rows, Cout, a.K);
+    if (dma_eligible(a.rows, Cout, a.K, Cin)) launch_dma(s, ah, bh, ep, a.rows, Cout, a.K, profile_tag);
     else if (dma_narrow_eligible(a.rows, Cout, a.K, Cin)) launch_dma_narrow(s, ah, bh, ep, a.rows, Cout, a.K);
     else launch_lds(s, ah, bh, ep, a.rows, Cout, a.K, 1);       // (BK = 64 variant measured no faster: launch_lds64)
   } else {
