@@ -77,12 +77,29 @@ def leaf_fixtures():
     return out
 
 
+def data_fixture():
+    """Data path (oracle/data_oracle.py): 255*rgb2y + image.scale of counter-generated images, labels, target widths."""
+    import data_oracle as D
+    out = {}
+    shapes = [(20, 37, 3), (64, 300, 3), (48, 100, 1), (7, 500, 1), (33, 129, 3)]
+    for i, (h, w, c) in enumerate(shapes):
+        a = np.floor(O.counter_uniform(SEED, 2000 + i, h * w * c) * 256.0).astype(np.uint8).reshape(h, w, c)
+        a = a[:, :, 0] if c == 1 else a
+        for force in (100, None):
+            img_w = D.target_width(h, w, 8.0, force)
+            out[f"img{i}:w{force}"] = np.int64(img_w)
+            out[f"img{i}:out{force}"] = D.scale_bilinear(D.rgb2y255(a), img_w)
+    out["labels"] = np.array(D.str2numlist("a0z9hello42"), dtype=np.int64)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     for name, (kw, B, W, ml) in CASES.items():
         np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **run_case(kw, B, W, ml))
         print("wrote", name)
     np.savez_compressed(os.path.join(OUT, "leaf_ops.npz"), **leaf_fixtures())
+    np.savez_compressed(os.path.join(OUT, "data_path.npz"), **data_fixture())
 
 
 if __name__ == "__main__":

@@ -96,3 +96,15 @@ def test_host_datagen_list_and_labels(tmp_path):
     assert g._width(12, 30) == D.target_width(12, 30, 8.0, None) == 80
     with pytest.raises(FileNotFoundError):
         data.DataGen(str(tmp_path), "nope.txt", 8.0)
+
+
+def test_data_oracle_matches_golden():
+    """oracle/data_oracle.py against its committed fixture tests/golden/data_path.npz (made by oracle/gen_golden.py)."""
+    import importlib.util
+    root = os.path.join(os.path.dirname(__file__), "..")
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(root, "oracle", "gen_golden.py"))
+    g = importlib.util.module_from_spec(spec); spec.loader.exec_module(g)
+    got, ref = g.data_fixture(), np.load(os.path.join(os.path.dirname(__file__), "golden", "data_path.npz"))
+    assert set(got) == set(ref.files)
+    for k in ref.files:
+        np.testing.assert_array_equal(np.asarray(got[k]), ref[k], err_msg=k)

@@ -79,3 +79,24 @@ def test_datagen_feeds_model_step(cuda, tmp_path):
     loss, stats = m.step(batch, forward_only=False)
     assert np.isfinite(loss) and stats[0] == batch[3]
     m.shutdown()
+
+
+def test_preprocess_matches_golden_fixture(cuda):
+    """aocr_preprocess_lines against the committed fixture tests/golden/data_path.npz (inputs regenerated from the counter-based
+    generator; expected outputs come from the file), bit for bit."""
+    import importlib.util
+    import aocr
+    root = os.path.join(os.path.dirname(__file__), "..")
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(root, "oracle", "gen_golden.py"))
+    g = importlib.util.module_from_spec(spec); spec.loader.exec_module(g)
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "data_path.npz"))
+    shapes = [(20, 37, 3), (64, 300, 3), (48, 100, 1), (7, 500, 1), (33, 129, 3)]
+    for i, (h, w, c) in enumerate(shapes):
+        a = np.floor(g.O.counter_uniform(g.SEED, 2000 + i, h * w * c) * 256.0).astype(np.uint8).reshape(h, w, c)
+        a = np.ascontiguousarray(a[:, :, 0]) if c == 1 else a
+        for force in (100, None):
+            img_w = int(ref[f"img{i}:w{force}"])
+            got = aocr.data.preprocess_batch([a], img_w).cpu().numpy()[0, 0]
+            np.testing.assert_array_equal(got, ref[f"img{i}:out{force}"], err_msg=f"img{i} force {force}")
+    assert aocr.data.str2numlist("a0z9hello42") == ref["labels"].tolist()
+    print("[parity] preprocess: 10 fixture outputs bit-identical")
