@@ -189,7 +189,8 @@ def test_dma_conv_kernel_matches_tiled_kernel(cuda, monkeypatch, B, W):
     print(f"[parity] dma-vs-tiled worst gradient rel {worst:.3e}")
 
 
-@pytest.mark.parametrize("He,B,W,Le", [(64, 16, 40, 1), (256, 32, 72, 1), (128, 16, 36, 1), (64, 16, 44, 2), (256, 16, 36, 2)])
+@pytest.mark.parametrize("He,B,W,Le", [(64, 16, 40, 1), (256, 32, 72, 1), (128, 16, 36, 1), (64, 16, 44, 2), (256, 16, 36, 2),
+                                        (64, 16, 800, 1)])          # W = 800: T = 199 steps (BASELINE C4 upper width)
 def test_seq_encoder_kernels_match_step_kernels(cuda, monkeypatch, He, B, W, Le):
     """Whole-sequence BiLSTM encoder kernels (one workgroup owns 16 batch rows for all T steps, weights re-streamed by
     LDS-DMA) against the per-step kernels on the same bf16 operands: only fp32 summation order differs.
