@@ -1359,7 +1359,7 @@ template <int NT> constexpr int step_lds_bytes() { return 4 * (1 + NT) * 32 * ST
 
 // global -> registers for one 64-deep chunk (kept as free functions with flat, statically indexed arrays of native
 // vector types: arrays captured by reference in lambdas / HIP's uint4 struct were demoted to LDS or scratch)
-template <int NT, bool GATES>
+template <int NT, int GATES>
 __device__ __forceinline__ void step_gload_b(const LoadKh2& b, int kc, int K0, int brow0, int gate_stride, int bp, u32x4 (&rb)[NT * 4]) {
   const bool s1 = kc >= K0;
   const bf16_t* pb = s1 ? b.p1 : b.p0; const int64_t ldb = s1 ? b.ld1 : b.ld0;
@@ -1367,7 +1367,9 @@ __device__ __forceinline__ void step_gload_b(const LoadKh2& b, int kc, int K0, i
 #pragma unroll
   for (int t = 0; t < NT * 4; ++t) {
     const int ni = t >> 2, i = t & 3;
-    const int row = (GATES ? ni * gate_stride : 32 * ni) + brow0 + 8 * i;
+    // GATES == 2 (half tiles): tile ni, tile row q = br + 8i -> gate 2ni + (q >> 4) = 2ni + (i >> 1), hidden unit n0 + (q & 15)
+    const int row = GATES == 2 ? (2 * ni + (i >> 1)) * gate_stride + brow0 + 8 * (i & 1)
+                               : (GATES ? ni * gate_stride : 32 * ni) + brow0 + 8 * i;
     rb[t] = *reinterpret_cast<const u32x4*>(pb + (int64_t)row * ldb + kk + 8 * bp);
   }
 }
@@ -1405,7 +1407,10 @@ __device__ __forceinline__ void step_lwrite_b(unsigned char* lb, int br, int bp,
     *reinterpret_cast<u32x4*>(lb + ((t >> 2) * 32 + br + 8 * (t & 3)) * STEP_PITCH + bp * 16) = rb[t];
 }
 
-template <int NT, bool GATES, class AL, class EP>
+// GATES: 0 plain (NT column tiles of 32); 1 gate tiles (tile = gate, 32 hidden units per workgroup, NT = 4); 2 HALF gate tiles
+// (NT = 2: tile t carries gates 2t and 2t+1 of 16 hidden units in its column halves, so a workgroup loads and multiplies half
+// the weights and twice as many workgroups share the step: 128 -> 256 at Hd = 512, B = 256; the epilogue pairs lanes l and l^16).
+template <int NT, int GATES, class AL, class EP>
 __global__ __launch_bounds__(256) void gemm_step_kernel(SmallArgs2<AL, LoadKh2, EP> zz, int gate_stride) {
   constexpr bool AH = SrcBf16<AL>::v;                           // A operand read from its bf16 shadow
   constexpr int NA = AH ? 4 : 8;
@@ -1414,7 +1419,7 @@ __global__ __launch_bounds__(256) void gemm_step_kernel(SmallArgs2<AL, LoadKh2, 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.y * 32;
-  const int n0 = GATES ? blockIdx.x * 32 : blockIdx.x * 32 * NT;
+  const int n0 = GATES == 2 ? blockIdx.x * 16 : (GATES ? blockIdx.x * 32 : blockIdx.x * 32 * NT);
   const int K = g.K;
   unsigned char* la = lds + wave * ((1 + NT) * 32 * STEP_PITCH);
   unsigned char* lb = la + 32 * STEP_PITCH;
@@ -1437,7 +1442,7 @@ __global__ __launch_bounds__(256) void gemm_step_kernel(SmallArgs2<AL, LoadKh2, 
   // the epilogue's own operands (zx, c_prev, gates, ...) are requested now so that they arrive during the K loop
   typename EP::Pre pre[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) pre[e] = g.ep.prefetch(m0 + 8 * wave + 4 * h + e, n0 + r);
+  for (int e = 0; e < 4; ++e) pre[e] = g.ep.prefetch(m0 + 8 * wave + 4 * h + e, GATES == 2 ? n0 + (r & 15) : n0 + r);
 
   if (kbeg < kend) {
     typename std::conditional<AH, u32x4, float4>::type ra[NA]; u32x4 rb[NT * 4];
@@ -1482,7 +1487,12 @@ __global__ __launch_bounds__(256) void gemm_step_kernel(SmallArgs2<AL, LoadKh2, 
       const int idx = (ni * 16 + 4 * wave + e) * 64 + lane;
       v[ni] = (r0[idx] + r0[idx + WSTRIDE]) + (r0[idx + 2 * WSTRIDE] + r0[idx + 3 * WSTRIDE]);
     }
-    g.ep.template elem<NT>(m0 + 8 * wave + 4 * h + e, n0 + r, 32, v, pre[e]);
+    if constexpr (GATES == 2) {                                 // lane l < 16 of each 32-lane half: [i, o] here, [f, g] in lane l + 16
+      float v4[4] = {v[0], __shfl_xor(v[0], 16, 64), v[1], __shfl_xor(v[1], 16, 64)};
+      if (r < 16) g.ep.template elem<4>(m0 + 8 * wave + 4 * h + e, n0 + r, 32, v4, pre[e]);
+    } else {
+      g.ep.template elem<NT>(m0 + 8 * wave + 4 * h + e, n0 + r, 32, v, pre[e]);
+    }
   }
 }
 

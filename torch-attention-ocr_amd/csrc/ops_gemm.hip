@@ -109,6 +109,12 @@ void launch_small_gates_bwd(hipStream_t s, bool bf16, int nz, const GatesBwdArgs
   launch_small<1, false>(s, bf16, nz, z, M, H, 0);
 }
 
+// half gate tiles (16 hidden units x 4 gates per workgroup) when the 32-unit grid would leave CUs idle; AOCR_NO_HALF_TILES=1 disables
+static bool half_gate_tiles(int H, int M, int nz) {
+  const char* e = getenv("AOCR_NO_HALF_TILES");
+  if (e && e[0] == '1') return false;
+  return H % 16 == 0 && (H / 32) * cdiv(M, 32) * nz < 200;
+}
 template <int NT, bool GATES, class ARGS>
 static void launch_small_bf16(hipStream_t s, int nz, const ARGS* z, int M, int ncols, int gate_stride) {
   if (M <= 0 || ncols <= 0) return;
@@ -119,7 +125,13 @@ static void launch_small_bf16(hipStream_t s, int nz, const ARGS* z, int M, int n
     staged = staged && z[i].K > 0 && z[i].K % 64 == 0 && z[i].a.K0 % 64 == 0 && z[i].a.vec && z[i].b.ld0 % 8 == 0 &&
              (!z[i].b.p1 || z[i].b.ld1 % 8 == 0);
   if (staged) {
-    hipLaunchKernelGGL((gemm_step_kernel<NT, GATES, decltype(z[0].a), decltype(z[0].ep)>), grid, dim3(256), 0, s, zz, gate_stride);
+    if constexpr (GATES && NT == 4) {
+      if (half_gate_tiles(ncols, M, nz)) {
+        hipLaunchKernelGGL((gemm_step_kernel<2, 2, decltype(z[0].a), decltype(z[0].ep)>), dim3(ncols / 16, cdiv(M, 32), nz), dim3(256), 0, s, zz, gate_stride);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((gemm_step_kernel<NT, GATES ? 1 : 0, decltype(z[0].a), decltype(z[0].ep)>), grid, dim3(256), 0, s, zz, gate_stride);
     return;
   }
   hipLaunchKernelGGL((gemm_small_kernel<true, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid, dim3(256), 0, s,
@@ -131,7 +143,13 @@ static void launch_small_bf16_hh(hipStream_t s, int nz, const ARGS* z, int M, in
   if (M <= 0 || ncols <= 0) return;
   dim3 grid(GATES ? cdiv(ncols, 32) : cdiv(ncols, 32 * NT), cdiv(M, 32), nz);
   SmallArgs2<decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)> zz; zz.z[0] = z[0]; zz.z[1] = z[nz > 1 ? 1 : 0]; zz.z[2] = z[nz > 2 ? 2 : 0];
-  hipLaunchKernelGGL((gemm_step_kernel<NT, GATES, decltype(z[0].a), decltype(z[0].ep)>), grid, dim3(256), 0, s, zz, gate_stride);
+  if constexpr (GATES && NT == 4) {
+    if (half_gate_tiles(ncols, M, nz)) {
+      hipLaunchKernelGGL((gemm_step_kernel<2, 2, decltype(z[0].a), decltype(z[0].ep)>), dim3(ncols / 16, cdiv(M, 32), nz), dim3(256), 0, s, zz, gate_stride);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((gemm_step_kernel<NT, GATES ? 1 : 0, decltype(z[0].a), decltype(z[0].ep)>), grid, dim3(256), 0, s, zz, gate_stride);
 }
 void launch_small_gates_fwd_hh(hipStream_t s, int nz, const GatesFwdArgsHH* z, int M, int H) { launch_small_bf16_hh<4, true>(s, nz, z, M, H, H); }
 void launch_small_hh(hipStream_t s, int nz, const SmallArgsHH* z, int M, int N) { launch_small_bf16_hh<1, false>(s, nz, z, M, N, 0); }
