@@ -133,7 +133,7 @@ def main():
     lines_per_s = world * B * args.steps / el
 
     # decode throughput (greedy, max_decoder_l = 50 steps + gold pass, the reference's -phase test step)
-    dec = None
+    dec = None; dec_dict = None
     if args.decode_steps > 0:
         m.decode_device(images, targets, targets_eval, 1); sync()
         t0 = time.perf_counter()
@@ -142,6 +142,22 @@ def main():
         sync()
         eld = time.perf_counter() - t0
         dec = world * B * 50 * args.decode_steps / eld
+        # the same step under -use_dictionary: a synthetic 90 k-word lexicon as a device-resident flat trie,
+        # admissibility tested inside the selection kernel (the reference walks Lua tables per image, beam and candidate)
+        rng = np.random.default_rng(1234)
+        lens = rng.integers(3, 11, size=90000)
+        letters = rng.integers(0, 26, size=int(lens.sum())).astype(np.uint8) + 97
+        words, o = [], 0
+        for n in lens:
+            words.append(letters[o:o + n].tobytes().decode()); o += int(n)
+        trie = aocr.build_trie(words).to(dev)
+        m.decode_device(images, targets, targets_eval, 1, trie); sync()
+        t0 = time.perf_counter()
+        for _ in range(args.decode_steps):
+            m.decode_device(images, targets, targets_eval, 1, trie)
+        sync()
+        dec_dict = {"chars_per_s": world * B * 50 * args.decode_steps / (time.perf_counter() - t0), "words": len(words),
+                    "trie_nodes": trie.n_nodes, "trie_bytes": int(trie.mask.nbytes + trie.base.nbytes + trie.child.nbytes)}
 
     # secondary line (N = 1 only): BASELINE.json configs[1] = C2 in exact-fp32 MFMA mode (the 1e-4 logit-parity configuration)
     c2 = None
@@ -207,7 +223,7 @@ def main():
                        "decoder_steps": L, "parallelism": f"dp{world}", "input_feed": True},
             "train_gflop_per_image": 3 * fpi / 1e9, "step_tflops": 3 * fpi * lines_per_s / 1e12,
             "step_mfma_frac": 3 * fpi * lines_per_s / 1e12 / (peak * world),
-            "decode_chars_per_s": dec, "loss": loss_val, "secondary": c2, "data_path": dp,
+            "decode_chars_per_s": dec, "decode_dict": dec_dict, "loss": loss_val, "secondary": c2, "data_path": dp,
             "roofline": {"bound": "mfma", "kernel": "conv6 forward implicit GEMM (512->512 3x3 + ReLU + pool)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                          "ms_per_launch": ms},

@@ -107,11 +107,32 @@ int aocr_forward_logits(aocr_model* m, const float* images_dev, const int32_t* t
 /* feval with forward_only=true (model.lua:321-536, 570-627): eval-mode CNN, encoder,
  * beam search over max_decoder_l steps (beam 1 = greedy), back-trace, then the
  * teacher-forced gold pass.  labels_dev (B,max_decoder_l) int32, scores_dev (B),
- * gold_scores_dev (B), loss_dev[0] = gold-pass NLL sum.  The dictionary (trie)
- * constraint of model.lua:380-387,405-445,460-513 is not implemented. */
+ * gold_scores_dev (B), loss_dev[0] = gold-pass NLL sum.  No dictionary (trie == nil). */
 int aocr_decode(aocr_model* m, const float* images_dev, const int32_t* targets_dev,
                 const int32_t* targets_eval_dev, int32_t B, int32_t W, int32_t L, int32_t beam,
                 int32_t* labels_dev, float* scores_dev, float* gold_scores_dev, float* loss_dev);
+
+/* The dictionary trie of loadDictionary (utils.lua:177-218) in flat, device-resident form.
+ * Node 0 is the start symbol's node (trie[2]).  Node n has a child for vocab id v (1-based,
+ * v <= 64) iff bit v-1 of child_mask_dev[n] is set; the children of n are
+ * child_dev[child_base_dev[n] ...] in ascending v.  A node reached through EOS (3) is an
+ * ordinary node (childless unless -allow_digit_prefix made it the root, utils.lua:193-198). */
+typedef struct aocr_trie {
+  const uint64_t* child_mask_dev;   /* [n_nodes] */
+  const int32_t* child_base_dev;    /* [n_nodes] */
+  const int32_t* child_dev;         /* [n_edges] */
+  int32_t n_nodes, n_edges;
+} aocr_trie;
+
+/* aocr_decode with -use_dictionary (model.lua:380-387,405-445,460-513): at every step only
+ * candidates whose token continues the beam's trie node are admissible (after the first step
+ * PAD always is, :469); when fewer than `beam` candidates are admissible the best admissible one
+ * fills the remaining beams (:419-433; the same rule replaces the broken fallback of :477-497).
+ * trie == NULL is aocr_decode.  Needs target_vocab_size <= 64. */
+int aocr_decode_dict(aocr_model* m, const float* images_dev, const int32_t* targets_dev,
+                     const int32_t* targets_eval_dev, int32_t B, int32_t W, int32_t L, int32_t beam,
+                     const aocr_trie* trie, int32_t* labels_dev, float* scores_dev,
+                     float* gold_scores_dev, float* loss_dev);
 
 /* Debug / parity taps: device pointer + shape of a named intermediate of the last
  * step ("feats" (T,B,512), "context" (B,T,2He), "logits" (L,B,40), "dfeats", "dcontext"). */
@@ -199,6 +220,20 @@ int aocr_logsoftmax_nll(void* stream, const float* logits_dev, int64_t ld, const
  * Outputs tokens (B,kout) 1-based, parents (B,kout) 0-based source beam. */
 int aocr_beam_select(void* stream, const float* logp_dev, const int32_t* prev_tok_dev, float* beam_scores_dev,
                      int32_t* tokens_dev, int32_t* parents_dev, int32_t B, int32_t kin, int32_t kout, int32_t V);
+
+/* The same selection under the dictionary constraint (model.lua:405-445, 460-513):
+ * loc_in_dev (B*kin) trie node of every input beam (ignored at t=1, prev_tok_dev == NULL: all
+ * beams start at node 0), loc_out_dev (B,kout) node of every selected beam.  V <= 64. */
+int aocr_beam_select_dict(void* stream, const float* logp_dev, const int32_t* prev_tok_dev, float* beam_scores_dev,
+                          int32_t* tokens_dev, int32_t* parents_dev, int32_t B, int32_t kin, int32_t kout, int32_t V,
+                          const aocr_trie* trie, const int32_t* loc_in_dev, int32_t* loc_out_dev);
+
+/* evalWordErrRate's comparison (utils.lua:136-175) on device: both (B,L) id rows are cut at
+ * their first EOS (3) and string.levenshtein (utils.lua:55-94) is taken between them.
+ * dist_dev (B) edit distance (0 <=> the word is right, :168-171); target_len_dev (B) or NULL:
+ * length of the cut target (the denominator of the edit-distance accuracy, :172, README.md:11). */
+int aocr_edit_distance(void* stream, const int32_t* labels_dev, const int32_t* targets_dev, int32_t B, int32_t L,
+                       int32_t* dist_dev, int32_t* target_len_dev);
 
 /* ---- data path ----------------------------------------------------------------------------------
  * data_gen.lua:68-79: img = 255 * image.rgb2y(img); img = image.scale(img, imgW, 32) for every decoded image of a batch

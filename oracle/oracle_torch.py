@@ -497,11 +497,13 @@ def _topk_sorted(scores: torch.Tensor, k: int):
 
 
 @torch.no_grad()
-def decode_beam(P, bn_state, cfg: OcrConfig, images, targets, targets_eval, beam: int = 1, max_decoder_l: int = 50):
+def decode_beam(P, bn_state, cfg: OcrConfig, images, targets, targets_eval, beam: int = 1, max_decoder_l: int = 50, trie=None):
     """forward_only step: beam search (beam=1 -> greedy), back-trace, exact-match
     accuracy and the teacher-forced gold pass.  Deviations from the reference,
     both documented in DESIGN.md: S9 (t=1 parent index is computed from a 0-based
-    id, i.e. always beam 1) and S10 (top-k order = sorted, ties to lowest index)."""
+    id, i.e. always beam 1) and S10 (top-k order = sorted, ties to lowest index).
+    trie: root node from oracle/dict_oracle.load_dictionary (-use_dictionary,
+    model.lua:380-387,405-445,460-513) or None."""
     B = images.shape[0]
     V, Hd, Ld = cfg.vocab, cfg.dec_hidden, cfg.dec_layers
     k = min(beam, V)
@@ -522,7 +524,15 @@ def decode_beam(P, bn_state, cfg: OcrConfig, images, targets, targets_eval, beam
         ctx_t = context if t == 0 else ctx_k
         c, h, out, _ = decoder_step_fwd(P, cfg, tok, ctx_t, feed, c, h)
         _, logp = projector_fwd(out, P["proj.w"], P["proj.b"])
-        if t == 0:
+        if t == 0 and trie is not None:
+            from dict_oracle import select_first
+            sel = [select_first(logp[b].tolist(), trie, k) for b in range(B)]          # :405-445
+            cur = torch.tensor([x[0] for x in sel], dtype=torch.int64)
+            beam_scores = torch.tensor([x[1] for x in sel], dtype=logp.dtype)
+            nodes = [x[2] for x in sel]
+            parents = torch.zeros(B, k, dtype=torch.int64)
+            src = torch.arange(B).unsqueeze(1).expand(B, k).reshape(-1)
+        elif t == 0:
             beam_scores, raw = _topk_sorted(logp, k)                         # :402
             cur = raw + 1
             parents = torch.zeros(B, k, dtype=torch.int64)                   # S9 fixed: parent beam 0
@@ -532,7 +542,14 @@ def decode_beam(P, bn_state, cfg: OcrConfig, images, targets, targets_eval, beam
             fin = (tok == PAD) | (tok == EOS)
             logp[fin, PAD - 1] = 0.0                                         # :448-449
             total = (logp.view(B, k, V) + beam_scores.unsqueeze(2)).reshape(B, k * V)   # :450
-            beam_scores, raw = _topk_sorted(total, k)                        # :452
+            if trie is not None:
+                from dict_oracle import select_next
+                sel = [select_next(total[b].tolist(), nodes[b], k, V) for b in range(B)]   # :460-513
+                raw = torch.tensor([x[1] for x in sel], dtype=torch.int64)
+                beam_scores = torch.tensor([x[2] for x in sel], dtype=logp.dtype)
+                nodes = [x[3] for x in sel]
+            else:
+                beam_scores, raw = _topk_sorted(total, k)                    # :452
             cur = raw % V + 1                                                # :456-458
             parents = raw // V                                               # :516
             src = (parents + (torch.arange(B) * k).unsqueeze(1)).reshape(-1)

@@ -20,6 +20,12 @@ class AocrError(RuntimeError):
     pass
 
 
+class TrieDesc(C.Structure):
+    """mirror of `aocr_trie` (include/aocr.h)."""
+    _fields_ = [("child_mask_dev", C.c_void_p), ("child_base_dev", C.c_void_p), ("child_dev", C.c_void_p),
+                ("n_nodes", C.c_int32), ("n_edges", C.c_int32)]
+
+
 class Config(C.Structure):
     """mirror of `aocr_config` (include/aocr.h)."""
     _fields_ = [(n, C.c_int32) for n in (
@@ -52,6 +58,7 @@ SIGNATURES = {
     "aocr_sgd_step": (C.c_int, [_vp, _f32, _f32, _vp]),
     "aocr_forward_logits": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "aocr_decode": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "aocr_decode_dict": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "aocr_get_tensor": (C.c_int, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i64)]),
     "aocr_profile_kernel": (C.c_int, [_vp, _i32, _i32, C.POINTER(_f32), C.POINTER(C.c_double)]),
     "aocr_gemm": (C.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _i32]),
@@ -68,6 +75,8 @@ SIGNATURES = {
     "aocr_attention_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32]),
     "aocr_attention_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32]),
     "aocr_logsoftmax_nll": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _f32]),
+    "aocr_beam_select_dict": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "aocr_edit_distance": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "aocr_preprocess_lines": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "aocr_beam_select": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32]),
 }

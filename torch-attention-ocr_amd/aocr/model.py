@@ -19,6 +19,7 @@ import torch
 
 from . import _lib, dist
 from ._lib import Config, check, lib, ptr
+from .dictionary import edit_distance_device
 
 PAD, GO, EOS = 1, 2, 3
 GROUPS = ["cnn", "enc_fw", "enc_bw", "dec", "proj"]
@@ -282,9 +283,10 @@ class Model:
         self.last_norms = norms
         return loss_dev
 
-    def decode_device(self, images, targets, targets_eval, beam_size=1):
+    def decode_device(self, images, targets, targets_eval, beam_size=1, trie=None):
         """forward_only feval on device-resident inputs; enqueues only.  Returns device tensors
-        (labels (B,max_decoder_l) int32, beam scores (B), gold scores (B), gold-pass NLL sum (1))."""
+        (labels (B,max_decoder_l) int32, beam scores (B), gold scores (B), gold-pass NLL sum (1)).
+        trie: an `aocr.dictionary.Trie` already on this device (-use_dictionary, model.lua:380-387,405-445,460-513) or None."""
         B, _, _, W = images.shape
         Lt = self.max_decoder_l
         check(lib.aocr_model_set_stream(self._h, self._stream()))
@@ -292,8 +294,13 @@ class Model:
         scores = torch.empty(B, dtype=torch.float32, device=self.device)
         gold = torch.empty(B, dtype=torch.float32, device=self.device)
         loss_dev = self._scal[0:1]
-        check(lib.aocr_decode(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, targets.shape[1], beam_size,
-                              ptr(labels), ptr(scores), ptr(gold), ptr(loss_dev)), "aocr_decode")
+        if trie is None:
+            check(lib.aocr_decode(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, targets.shape[1], beam_size,
+                                  ptr(labels), ptr(scores), ptr(gold), ptr(loss_dev)), "aocr_decode")
+        else:
+            desc = trie.desc()
+            check(lib.aocr_decode_dict(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, targets.shape[1], beam_size,
+                                       C.byref(desc), ptr(labels), ptr(scores), ptr(gold), ptr(loss_dev)), "aocr_decode_dict")
         return labels, scores, gold, loss_dev
 
     def profile_kernel(self, which=0, iters=20):
@@ -304,9 +311,9 @@ class Model:
 
     def step(self, batch, forward_only, beam_size=None, trie=None):
         """Returns (loss*batch_size, [num_nonzeros, num_correct]) exactly like model:step (model.lua:695-705)."""
-        if trie is not None:
-            raise NotImplementedError("dictionary-constrained beam search (model.lua:405-445,460-513) is out of scope")
         images, targets, targets_eval = self._upload(batch)
+        if trie is not None and trie._dev is None:
+            trie.to(self.device)
         num_nonzeros = batch[3]
         B, _, _, W = images.shape
         target_l = targets.shape[1]
@@ -320,13 +327,20 @@ class Model:
         beam_size = beam_size or 1
         beam_size = min(beam_size, self.target_vocab_size)
         Lt = self.max_decoder_l
-        labels, scores, gold, loss_dev = self.decode_device(images, targets, targets_eval, beam_size)
+        labels, scores, gold, loss_dev = self.decode_device(images, targets, targets_eval, beam_size, trie)
+        # word scoring on device (evalWordErrRate, utils.lua:136-175): one Levenshtein distance per row, a word is right iff it is 0
+        tge_dev = torch.full((B, Lt), PAD, dtype=torch.int32, device=self.device)
+        tge_dev[:, :target_l] = targets_eval
+        dist, tlen = edit_distance_device(labels, tge_dev, self._stream())
         labels_h = labels.cpu().numpy()
-        tge = np.full((B, Lt), PAD, dtype=np.int32)
-        tge[:, :target_l] = targets_eval.cpu().numpy()
-        word_err, labels_pred, labels_gold = eval_word_err_rate(labels_h, tge, self.visualize)
+        dist_h, tlen_h = dist.cpu().numpy(), tlen.cpu().numpy()
+        word_err = float((dist_h != 0).sum())
+        labels_pred, labels_gold = [], []
+        if self.visualize:
+            _, labels_pred, labels_gold = eval_word_err_rate(labels_h, tge_dev.cpu().numpy(), True)
         accuracy = B - word_err
-        self._dec_out = SimpleNamespace(labels=labels_h, scores=scores.cpu().numpy(), gold_scores=gold.cpu().numpy())
+        self._dec_out = SimpleNamespace(labels=labels_h, scores=scores.cpu().numpy(), gold_scores=gold.cpu().numpy(),
+                                        edit_distance=dist_h, target_len=tlen_h)
         if self.visualize and self.visualize_file is not None:
             img_paths = batch[4]
             for i in range(len(img_paths)):                                         # model.lua:628-633

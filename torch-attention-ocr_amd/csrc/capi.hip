@@ -189,8 +189,21 @@ __global__ void pad_targets_kernel(const int32_t* src, int32_t* dst, int B, int 
 
 int aocr_decode(aocr_model* m, const float* images_dev, const int32_t* targets_dev, const int32_t* targets_eval_dev, int32_t B,
                 int32_t W, int32_t L, int32_t beam, int32_t* labels_dev, float* scores_dev, float* gold_scores_dev, float* loss_dev) {
+  return aocr_decode_dict(m, images_dev, targets_dev, targets_eval_dev, B, W, L, beam, nullptr, labels_dev, scores_dev, gold_scores_dev,
+                          loss_dev);
+}
+static int check_trie(const aocr_trie* t, int V) {
+  REQUIRE(t->child_mask_dev && t->child_base_dev && (t->child_dev || t->n_edges == 0), "trie: NULL array");
+  REQUIRE(t->n_nodes >= 1 && t->n_edges >= 0, "trie: n_nodes=%d n_edges=%d", t->n_nodes, t->n_edges);
+  REQUIRE(V <= 64, "dictionary decoding needs target_vocab_size <= 64 (got %d)", V);
+  return 0;
+}
+int aocr_decode_dict(aocr_model* m, const float* images_dev, const int32_t* targets_dev, const int32_t* targets_eval_dev, int32_t B,
+                     int32_t W, int32_t L, int32_t beam, const aocr_trie* trie, int32_t* labels_dev, float* scores_dev,
+                     float* gold_scores_dev, float* loss_dev) {
   Dims d; if (step_dims(m, B, W, L, d)) return 1;
   REQUIRE(images_dev && targets_dev && targets_eval_dev && labels_dev && scores_dev, "NULL argument");
+  if (trie && check_trie(trie, m->V)) return 1;
   if (beam > m->V) beam = m->V;                                           // model.lua:229
   REQUIRE(beam >= 1 && beam <= m->cfg.max_beam, "beam=%d outside 1..%d", beam, m->cfg.max_beam);
   const int Lt = m->cfg.max_decoder_l;                                    // model.lua:273: always max_decoder_l steps (S8)
@@ -199,13 +212,13 @@ int aocr_decode(aocr_model* m, const float* images_dev, const int32_t* targets_d
   d.L = Lt;
   cnn_forward(m, images_dev, d, 0, 0);                                    // model.lua:280-281: evaluate()
   encoder_forward(m, d);
-  decode_beam(m, d, m->tgt_pad, beam, labels_dev, scores_dev);
+  decode_beam(m, d, m->tgt_pad, beam, labels_dev, scores_dev, trie);
   // gold pass, model.lua:589-627
   decoder_tf_forward(m, d, m->tgt_pad, 1, Lt, false);
   loss_and_dlogits(m, d, m->tge_pad, 1, Lt, 0.f, false, loss_dev);
   if (gold_scores_dev) gold_scores(m->s, m->nll_rows, gold_scores_dev, Lt, B);
   m->last = d; m->last_valid = 1;
-  return check_launch("aocr_decode");
+  return check_launch(trie ? "aocr_decode_dict" : "aocr_decode");
 }
 
 int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32_t* ndim, int64_t shape[4]) {
@@ -364,6 +377,23 @@ int aocr_beam_select(void* stream, const float* logp_dev, const int32_t* prev_to
   REQUIRE(logp_dev && beam_scores_dev && tokens_dev && parents_dev && kin >= 1 && kout >= 1 && kout <= kin * V, "bad arguments");
   beam_select((hipStream_t)stream, logp_dev, prev_tok_dev, beam_scores_dev, tokens_dev, parents_dev, B, kin, kout, V);
   return check_launch("aocr_beam_select");
+}
+int aocr_beam_select_dict(void* stream, const float* logp_dev, const int32_t* prev_tok_dev, float* beam_scores_dev, int32_t* tokens_dev,
+                          int32_t* parents_dev, int32_t B, int32_t kin, int32_t kout, int32_t V, const aocr_trie* trie,
+                          const int32_t* loc_in_dev, int32_t* loc_out_dev) {
+  REQUIRE(logp_dev && beam_scores_dev && tokens_dev && parents_dev && kin >= 1 && kout >= 1 && kout <= kin * V, "bad arguments");
+  REQUIRE(trie && loc_out_dev && (loc_in_dev || !prev_tok_dev) && loc_in_dev != loc_out_dev, "trie / node arrays missing or aliased");
+  if (check_trie(trie, V)) return 1;
+  TrieView tv{(const unsigned long long*)trie->child_mask_dev, trie->child_base_dev, trie->child_dev, loc_in_dev, loc_out_dev};
+  beam_select((hipStream_t)stream, logp_dev, prev_tok_dev, beam_scores_dev, tokens_dev, parents_dev, B, kin, kout, V, nullptr, 0, &tv);
+  return check_launch("aocr_beam_select_dict");
+}
+int aocr_edit_distance(void* stream, const int32_t* labels_dev, const int32_t* targets_dev, int32_t B, int32_t L, int32_t* dist_dev,
+                       int32_t* target_len_dev) {
+  REQUIRE(labels_dev && targets_dev && dist_dev, "NULL argument");
+  REQUIRE(B >= 0 && L >= 1 && (size_t)(L + 1) * 256 <= 160 * 1024, "bad sizes: B=%d L=%d", B, L);
+  if (B > 0) edit_distance((hipStream_t)stream, labels_dev, targets_dev, B, L, dist_dev, target_len_dev);
+  return check_launch("aocr_edit_distance");
 }
 
 int aocr_preprocess_lines(void* stream, const uint8_t* src_dev, const aocr_image_desc* desc_dev, int32_t n_images, int32_t out_h,

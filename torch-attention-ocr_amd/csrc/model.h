@@ -76,7 +76,7 @@ struct aocr_model {
   // decode (rows = B*beam)
   float *bc[2][aocr::MAXL], *bh[2][aocr::MAXL], *bfeed[2], *bc_new[aocr::MAXL], *bh_new[aocr::MAXL];
   float *bzx1, *bzx_tab, *bq, *ba, *bcat, *bout, *blogits, *blogp, *beam_scores;     // bzx_tab [V][4Hd]: per-token first-layer gate input
-  int32_t *hist_tok, *hist_par, *tgt_pad, *tge_pad;
+  int32_t *hist_tok, *hist_par, *tgt_pad, *tge_pad, *trie_loc[2];   // trie_loc: dictionary node of every beam (ping-pong)
   void* sgd_scratch;
 
   aocr::Dims last;                // dims of the last step (for the parity taps)
@@ -91,5 +91,6 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
 void loss_and_dlogits(aocr_model* m, const Dims& d, const int32_t* tge, int64_t st, int64_t sb, float grad_scale, bool want_grad,
                       float* loss_dev);
 void backward_all(aocr_model* m, const float* images, const int32_t* tgt, const Dims& d);
-void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int32_t* labels, float* scores);
+void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int32_t* labels, float* scores,
+                 const aocr_trie* trie = nullptr);
 }  // namespace aocr

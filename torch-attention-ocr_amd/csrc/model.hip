@@ -146,6 +146,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
   m->blogp = a.get<float>(R * m->V); m->beam_scores = a.get<float>(R);
   m->hist_tok = a.get<int32_t>(L * R); m->hist_par = a.get<int32_t>(L * R);
   m->tgt_pad = a.get<int32_t>(B * L); m->tge_pad = a.get<int32_t>(B * L);
+  m->trie_loc[0] = a.get<int32_t>(R); m->trie_loc[1] = a.get<int32_t>(R);
   m->sgd_scratch = a.get<char>(sgd_scratch_bytes());
   m->ws_bytes = a.off + 256;
   if (base && a.off > bytes) return -1;
@@ -688,7 +689,7 @@ void backward_all(aocr_model* m, const float* images, const int32_t* tgt, const 
 // beam search, model.lua:360-536 + back-trace :573-585.  Rows r = b*k + beam; the context is not replicated
 // (the attention kernel maps row -> image with ctx_div).
 // ------------------------------------------------------------------------------------------------
-void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int32_t* labels, float* scores) {
+void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int32_t* labels, float* scores, const aocr_trie* trie) {
   hipStream_t s = m->s; const bool bf = m->bf16;
   const int B = d.B, T = d.T, Lt = d.L, Hd = m->Hd, E = m->E, V = m->V, Ld = m->Ld;
   const int k = beam;
@@ -716,16 +717,23 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
     float* out = (direct && m->cfg.input_feed) ? m->bfeed[nxt] : m->bout;
     io.q = m->bq; io.a = m->ba; io.cat = m->bcat; io.out = out;
     dec_step_forward(m, io, T);
+    // dictionary constraint: the node of every beam ping-pongs between trie_loc[0/1] (model.lua:380-387: all beams start at trie[2])
+    TrieView tvs{}; const TrieView* tv = nullptr;
+    if (trie) {
+      tvs = TrieView{(const unsigned long long*)trie->child_mask_dev, trie->child_base_dev, trie->child_dev, m->trie_loc[t & 1],
+                     m->trie_loc[(t & 1) ^ 1]};
+      tv = &tvs;
+    }
     if (V <= 64 && Hd % 4 == 0) {                        // projector + LogSoftMax + selection in one launch
       project_select(s, out, Hd, m->wo, m->bo, Hd, t == 0 ? nullptr : tok, m->beam_scores, m->hist_tok + (size_t)t * B * k,
-                     m->hist_par + (size_t)t * B * k, B, kin, k, V);
+                     m->hist_par + (size_t)t * B * k, B, kin, k, V, tv);
     } else {
       SmallKKArgs z; z.a = make_loadk(out, Hd, R, Hd); z.b = make_loadk(m->wo, Hd, V, Hd);
       z.ep = make_store(m->blogits, LOGIT_LD, R, V, m->bo, nullptr, 0); z.K = Hd;
       launch_small_kk(s, bf, 1, &z, R, V);
       logsoftmax_nll(s, m->blogits, LOGIT_LD, tgt, 0, 0, R, m->blogp, nullptr, nullptr, R, V, 0.f);
       beam_select(s, m->blogp, t == 0 ? nullptr : tok, m->beam_scores, m->hist_tok + (size_t)t * B * k,
-                  m->hist_par + (size_t)t * B * k, B, kin, k, V);
+                  m->hist_par + (size_t)t * B * k, B, kin, k, V, nullptr, 0, tv);
     }
     if (!direct) {
       const int32_t* par = m->hist_par + (size_t)t * B * k;

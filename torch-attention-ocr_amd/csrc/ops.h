@@ -148,12 +148,16 @@ void copy2d(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ld
 void sgd_clip_update(hipStream_t s, float* params, float* grads, const int64_t* group_off /*6 host values*/, float lr,
                      float clip, float* norms_out, void* scratch);
 size_t sgd_scratch_bytes();
+// flat dictionary trie + the per-beam node ids of one decode step (mask == nullptr: unconstrained); needs V <= 64
+struct TrieView { const unsigned long long* mask; const int32_t* base; const int32_t* child; const int32_t* loc_in; int32_t* loc_out; };
 void beam_select(hipStream_t s, const float* logp, const int32_t* prev_tok, float* beam_scores, int32_t* tokens,
-                 int32_t* parents, int B, int kin, int kout, int V, const float* logits = nullptr, int64_t ldl = 0);
+                 int32_t* parents, int B, int kin, int kout, int V, const float* logits = nullptr, int64_t ldl = 0,
+                 const TrieView* tv = nullptr);
 // logits != nullptr (and V <= 64): raw projector outputs, the LogSoftMax is applied inside (logp is then unused)
 // projector + LogSoftMax + beam bookkeeping of one decode step in one launch (V <= 64, Hd % 4 == 0)
 void project_select(hipStream_t s, const float* h, int64_t ldh, const float* wo, const float* bo, int Hd, const int32_t* prev_tok,
-                    float* beam_scores, int32_t* tokens, int32_t* parents, int B, int kin, int kout, int V);
+                    float* beam_scores, int32_t* tokens, int32_t* parents, int B, int kin, int kout, int V,
+                    const TrieView* tv = nullptr);
 void token_rows(hipStream_t s, const float* table, const int32_t* tok, int64_t stride, float* dst, int R, int width);   // dst[r] = table[tok[r*stride]-1]
 // dst[b*kout+i][:] = src[(kin==1 ? b : b*kin + parents[b*kout+i])][:]
 void gather_beam_rows(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, const int32_t* parents, int B,
@@ -161,6 +165,8 @@ void gather_beam_rows(hipStream_t s, const float* src, int64_t lds, float* dst, 
 void beam_backtrace(hipStream_t s, const int32_t* hist_tok, const int32_t* hist_par, const float* beam_scores,
                     int32_t* labels, float* scores, int Lt, int B, int k);
 void fill_i32(hipStream_t s, int32_t* p, int32_t v, int64_t n);
+// Levenshtein distance between two id rows cut at the first EOS (utils.lua:55-94 over the strings of utils.lua:136-168)
+void edit_distance(hipStream_t s, const int32_t* labels, const int32_t* targets, int B, int L, int32_t* dist, int32_t* target_len);
 
 // ---- whole-sequence encoder recurrence (rnn_seq.hip): one workgroup owns 16 batch rows of one direction for all T steps
 struct EncSeqDir {

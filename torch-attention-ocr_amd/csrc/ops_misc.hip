@@ -955,13 +955,27 @@ void sgd_clip_update(hipStream_t s, float* params, float* grads, const int64_t* 
 // =============================================================================================
 // beam search bookkeeping, model.lua:399-404, 446-458, 516-535, 573-585.
 // =============================================================================================
+// Dictionary constraint (model.lua:380-387,405-445,460-513 over the trie of utils.lua:177-218).  The trie is flat: node n has a
+// child for vocab id v (1-based) iff bit v-1 of mask[n] is set; its children are child[base[n] ..] in ascending v.  Node 0 is the
+// start symbol's node (trie[2]).  A candidate (beam, v) is admissible iff the beam's node has that child, or -- after the first
+// step -- v is PAD (model.lua:469); PAD keeps the node, any other token moves to the child (:499-506).
+__device__ __forceinline__ bool trie_ok(const TrieView& tv, int node, int v0, bool first) {
+  return (!first && v0 == 0) || ((tv.mask[node] >> v0) & 1ull);
+}
+__device__ __forceinline__ int trie_next(const TrieView& tv, int node, int v0, bool first) {
+  if (!first && v0 == 0) return node;
+  const unsigned long long mk = tv.mask[node];
+  if (!((mk >> v0) & 1ull)) return node;                        // only reachable when the trie admits nothing at all
+  return tv.child[tv.base[node] + __popcll(mk & ((1ull << v0) - 1ull))];
+}
 // one wave per batch row; candidates c = beam*V + v (v 0-based).  Selection: descending score, ties -> lowest index.
 __global__ __launch_bounds__(64) void beam_select_kernel(const float* __restrict__ logp, const int32_t* __restrict__ prev_tok,
                                                          float* __restrict__ beam_scores, int32_t* __restrict__ tokens,
                                                          int32_t* __restrict__ parents, int kin, int kout, int V,
-                                                         const float* __restrict__ logits, int64_t ldl) {
+                                                         const float* __restrict__ logits, int64_t ldl, TrieView tv) {
   extern __shared__ float cand[];                               // kin*V
   const int b = blockIdx.x, lane = threadIdx.x;
+  const bool first = prev_tok == nullptr;
   const int n = kin * V;
   if (logits) {                                                 // fused LogSoftMax (V <= 64: lane = class), output_projector.lua:6
     for (int beam = 0; beam < kin; ++beam) {
@@ -982,9 +996,11 @@ __global__ __launch_bounds__(64) void beam_select_kernel(const float* __restrict
       if (v == 0 && (pt == 1 || pt == 3)) lp = 0.f;             // model.lua:448-449: finished beams continue with PAD at zero cost
       lp += beam_scores[b * kin + beam];                        // model.lua:450
     }
+    if (tv.mask && !trie_ok(tv, first ? 0 : tv.loc_in[row], v, first)) lp = -INFINITY;   // model.lua:413,469
     cand[c] = lp;
   }
   __syncthreads();
+  float first_best = -INFINITY; int first_bi = 0;
   for (int k = 0; k < kout; ++k) {
     float best = -INFINITY; int bi = 0x7fffffff;
     for (int c = lane; c < n; c += 64) { float v = cand[c]; if (v > best) { best = v; bi = c; } }
@@ -993,10 +1009,15 @@ __global__ __launch_bounds__(64) void beam_select_kernel(const float* __restrict
       float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
       if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
+    if (tv.mask) {                                              // fewer admissible candidates than beams: repeat the best one,
+      if (bi == 0x7fffffff) { best = first_best; bi = first_bi; }   // model.lua:419-433 (and the intent of :477-497, S11)
+      if (k == 0) { first_best = best; first_bi = bi; }
+    }
     if (lane == 0) {
       cand[bi] = -INFINITY;
       tokens[b * kout + k] = bi % V + 1;                        // model.lua:456-458
       parents[b * kout + k] = bi / V;                           // model.lua:516 (0-based; S9 fixed at t=1: kin=1 -> 0)
+      if (tv.mask) tv.loc_out[b * kout + k] = trie_next(tv, first ? 0 : tv.loc_in[b * kin + bi / V], bi % V, first);   // :434-439,499-507
     }
     __syncthreads();
     if (lane == 0) ((volatile float*)cand)[n + k] = best;       // stash; written back after the loop (beam_scores is also an input)
@@ -1010,9 +1031,10 @@ __global__ __launch_bounds__(64) void beam_select_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void project_select_kernel(const float* __restrict__ h, int64_t ldh, const float* __restrict__ wo,
                                                              const float* __restrict__ bo, int Hd, const int32_t* __restrict__ prev_tok,
                                                              float* __restrict__ beam_scores, int32_t* __restrict__ tokens,
-                                                             int32_t* __restrict__ parents, int kin, int kout, int V) {
+                                                             int32_t* __restrict__ parents, int kin, int kout, int V, TrieView tv) {
   extern __shared__ float cand[];                               // kin*V (+ kout stash)
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool first = prev_tok == nullptr;
   const int n = kin * V;
 #pragma unroll 4
   for (int c = wave; c < n; c += 4) {                           // logits (unrolled: the loads of the next outputs overlap the reductions)
@@ -1040,8 +1062,10 @@ __global__ __launch_bounds__(256) void project_select_kernel(const float* __rest
         if (lane == 0 && (pt == 1 || pt == 3)) lp = 0.f;        // model.lua:448-449
         lp += beam_scores[row];                                 // model.lua:450
       }
+      if (tv.mask && lane < V && !trie_ok(tv, first ? 0 : tv.loc_in[row], lane, first)) lp = -INFINITY;   // model.lua:413,469
       if (lane < V) cand[beam * V + lane] = lp;
     }
+    float first_best = -INFINITY; int first_bi = 0;
     for (int k = 0; k < kout; ++k) {                            // top-k: descending score, ties -> lowest index (single wave: no barriers)
       float best = -INFINITY; int bi = 0x7fffffff;
       for (int c = lane; c < n; c += 64) { float v = cand[c]; if (v > best) { best = v; bi = c; } }
@@ -1050,10 +1074,15 @@ __global__ __launch_bounds__(256) void project_select_kernel(const float* __rest
         float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
       }
+      if (tv.mask) {                                            // model.lua:419-433: repeat the best admissible candidate
+        if (bi == 0x7fffffff) { best = first_best; bi = first_bi; }
+        if (k == 0) { first_best = best; first_bi = bi; }
+      }
       if (lane == 0) {
         cand[bi] = -INFINITY; cand[n + k] = best;
         tokens[b * kout + k] = bi % V + 1;
         parents[b * kout + k] = bi / V;
+        if (tv.mask) tv.loc_out[b * kout + k] = trie_next(tv, first ? 0 : tv.loc_in[b * kin + bi / V], bi % V, first);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1062,15 +1091,17 @@ __global__ __launch_bounds__(256) void project_select_kernel(const float* __rest
   }
 }
 void project_select(hipStream_t s, const float* h, int64_t ldh, const float* wo, const float* bo, int Hd, const int32_t* prev_tok,
-                    float* beam_scores, int32_t* tokens, int32_t* parents, int B, int kin, int kout, int V) {
+                    float* beam_scores, int32_t* tokens, int32_t* parents, int B, int kin, int kout, int V, const TrieView* tv) {
   size_t sh = (size_t)(kin * V + kout) * sizeof(float);
-  hipLaunchKernelGGL(project_select_kernel, dim3(B), dim3(256), sh, s, h, ldh, wo, bo, Hd, prev_tok, beam_scores, tokens, parents, kin, kout, V);
+  hipLaunchKernelGGL(project_select_kernel, dim3(B), dim3(256), sh, s, h, ldh, wo, bo, Hd, prev_tok, beam_scores, tokens, parents, kin, kout, V,
+                     tv ? *tv : TrieView{});
 }
 void beam_select(hipStream_t s, const float* logp, const int32_t* prev_tok, float* beam_scores, int32_t* tokens, int32_t* parents,
-                 int B, int kin, int kout, int V, const float* logits, int64_t ldl) {
+                 int B, int kin, int kout, int V, const float* logits, int64_t ldl, const TrieView* tv) {
   size_t sh = (size_t)(kin * V + kout) * sizeof(float);
   if (V > 64) logits = nullptr;                                 // the fused LogSoftMax needs one lane per class
-  hipLaunchKernelGGL(beam_select_kernel, dim3(B), dim3(64), sh, s, logp, prev_tok, beam_scores, tokens, parents, kin, kout, V, logits, ldl);
+  hipLaunchKernelGGL(beam_select_kernel, dim3(B), dim3(64), sh, s, logp, prev_tok, beam_scores, tokens, parents, kin, kout, V, logits, ldl,
+                     tv ? *tv : TrieView{});
 }
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst,
                                                           int64_t ldd, const int32_t* __restrict__ parents, int B, int kin, int kout,
@@ -1122,6 +1153,36 @@ __global__ void fill_i32_kernel(int32_t* p, int32_t v, int64_t n) {
 }
 void fill_i32(hipStream_t s, int32_t* p, int32_t v, int64_t n) {
   hipLaunchKernelGGL(fill_i32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, v, n);
+}
+
+// Levenshtein distance of two id rows, each cut at its first EOS (3): string.levenshtein (utils.lua:55-94) applied to the strings
+// evalWordErrRate builds (utils.lua:141-168; numlist2str is injective on ids, so ids compare like the bytes).  One lane per row;
+// the single DP row lives in LDS as [j][lane] (conflict-free), the left/diagonal neighbours in registers.
+__global__ __launch_bounds__(64) void edit_distance_kernel(const int32_t* __restrict__ labels, const int32_t* __restrict__ targets,
+                                                           int B, int L, int32_t* __restrict__ dist, int32_t* __restrict__ target_len) {
+  extern __shared__ int32_t dp[];                               // (L+1) * 64
+  const int lane = threadIdx.x, b = blockIdx.x * 64 + lane;
+  if (b >= B) return;
+  const int32_t* p = labels + (int64_t)b * L; const int32_t* g = targets + (int64_t)b * L;
+  int lp = 0, lg = 0;
+  while (lp < L && p[lp] != 3) ++lp;
+  while (lg < L && g[lg] != 3) ++lg;
+  for (int j = 0; j <= lg; ++j) dp[j * 64 + lane] = j;          // row i = 0
+  for (int i = 1; i <= lp; ++i) {
+    const int32_t pc = p[i - 1];
+    int diag = dp[lane]; int left = i; dp[lane] = i;
+    for (int j = 1; j <= lg; ++j) {
+      const int up = dp[j * 64 + lane];
+      const int v = min(min(up + 1, left + 1), diag + (pc == g[j - 1] ? 0 : 1));
+      dp[j * 64 + lane] = v; diag = up; left = v;
+    }
+  }
+  dist[b] = dp[lg * 64 + lane];
+  if (target_len) target_len[b] = lg;
+}
+void edit_distance(hipStream_t s, const int32_t* labels, const int32_t* targets, int B, int L, int32_t* dist, int32_t* target_len) {
+  hipLaunchKernelGGL(edit_distance_kernel, dim3(cdiv(B, 64)), dim3(64), (size_t)(L + 1) * 64 * sizeof(int32_t), s, labels, targets, B, L,
+                     dist, target_len);
 }
 
 }  // namespace aocr
