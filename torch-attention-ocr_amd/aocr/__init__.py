@@ -11,7 +11,8 @@ from . import synth
 from . import data
 from .data import DataGen
 from . import dictionary
+from . import t7, checkpoint
 from .dictionary import Trie, load_dictionary, build_trie, levenshtein
 
-__all__ = ["Model", "DataGen", "data", "dictionary", "Trie", "load_dictionary", "build_trie", "levenshtein", "AocrError", "Config", "COMPUTE_F32", "COMPUTE_BF16", "lib", "last_error", "check", "ptr",
+__all__ = ["Model", "DataGen", "data", "dictionary", "t7", "checkpoint", "Trie", "load_dictionary", "build_trie", "levenshtein", "AocrError", "Config", "COMPUTE_F32", "COMPUTE_BF16", "lib", "last_error", "check", "ptr",
            "param_table", "eval_word_err_rate", "numlist2str", "GROUPS", "synth"]

@@ -111,6 +111,10 @@ class Model:
         """model:load, model.lua:45-80: structure from the checkpoint, max_*_l / batch_size from `config`."""
         config = config or {}
         assert os.path.isfile(model_path), f"Model {model_path} does not exist!"
+        with open(model_path, "rb") as f:
+            magic = f.read(4)
+        if magic[:2] != b"PK":                       # not a torch.save zip: a Torch7 file (the reference's checkpoint or our flat export)
+            return self._load_t7(model_path, config)
         ck = torch.load(model_path, map_location="cpu", weights_only=False)
         self._set_structure(ck["config"])
         merged = dict(ck["config"])
@@ -124,6 +128,24 @@ class Model:
         self._build()
         self.params.copy_(ck["params"].to(self.params.device))
         self.bn_state.copy_(ck["bn_state"].to(self.params.device))
+        return self
+
+    def _load_t7(self, model_path, config):
+        """model:load on a Torch7-serialized checkpoint (model.lua:51-59): aocr.checkpoint pulls the tensors out of the nets."""
+        from .checkpoint import read_t7_checkpoint
+        ck = read_t7_checkpoint(model_path)
+        merged = dict(_DEFAULTS); merged.update({k: v for k, v in ck["config"].items() if v is not None})
+        self._set_structure(merged)
+        for k in ("max_encoder_l", "max_decoder_l", "batch_size", "prealloc", "img_h", "max_img_w", "max_beam", "compute"):
+            v = config.get(k) if isinstance(config, dict) else getattr(config, k, None)
+            if v is not None:
+                merged[k] = v
+        self._set_runtime(merged)
+        self.global_step = ck["global_step"]
+        self.optim_state = dict(ck["optim_state"]) or {"learningRate": float(merged["learning_rate"])}
+        self._build()
+        self.set_parameters({k: torch.from_numpy(v) for k, v in ck["params"].items()},
+                            {k: torch.from_numpy(v) for k, v in ck["bn_state"].items()})
         return self
 
     def _build(self):
@@ -389,7 +411,13 @@ class Model:
             self.visualize_file = None
 
     def save(self, model_path):
-        """model:save, model.lua:720-725 ({nets, config, global_step, optim_state}); nets = the flat parameter vector."""
+        """model:save, model.lua:720-725 ({nets, config, global_step, optim_state}); nets = the flat parameter vector.
+        A path ending in .t7 is written in Torch7 serialization instead (aocr.checkpoint.write_flat_checkpoint)."""
+        if str(model_path).endswith(".t7"):
+            from .checkpoint import write_flat_checkpoint
+            write_flat_checkpoint(model_path, {k: v.numpy() for k, v in self.get_parameters().items()},
+                                  {k: v.numpy() for k, v in self.get_bn_state().items()}, self.config, self.global_step, self.optim_state)
+            return
         torch.save({"params": self.params.detach().cpu(), "bn_state": self.bn_state.detach().cpu(), "config": self.config,
                     "global_step": self.global_step, "optim_state": dict(self.optim_state)}, model_path)
 
