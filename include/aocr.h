@@ -97,6 +97,14 @@ int aocr_train_forward_backward(aocr_model* m, const float* images_dev, const in
  * by optim_sgd.lua:49.  A data-parallel all-reduce of grads_dev goes before this call. */
 int aocr_sgd_step(aocr_model* m, float lr, float clip, float* norms_dev);
 
+/* optim.adadelta_list, src/optim/optim_adadelta.lua:19-62 (the optimizer the reference ships
+ * next to sgd_list), one fused pass over all parameters: var = rho*var + (1-rho)*g^2;
+ * delta = sqrt(acc+eps)/sqrt(var+eps)*g; w -= delta; acc = rho*acc + (1-rho)*delta^2.
+ * state_dev: 2*n floats {paramVariance | accDelta} (n = sum of aocr_param_counts), zeroed by
+ * the caller before the first step and kept between steps.  weight_decay: g += wd*w first
+ * (what optim_adadelta.lua:37 means; the line itself would raise).  No clipping (:31-57). */
+int aocr_adadelta_step(aocr_model* m, float rho, float eps, float weight_decay, float* state_dev);
+
 /* Teacher-forced forward only (no gradients).  training!=0 uses batch statistics
  * in BatchNorm (without touching running stats); logits_dev (L,B,vocab) receives the
  * pre-LogSoftMax projector output (output_projector.lua:5), loss_dev[0] the NLL sum. */

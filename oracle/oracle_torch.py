@@ -487,6 +487,21 @@ def sgd_list(P, G, lr: float, clip: float = 5.0):
     return newP, norms
 
 
+def adadelta_list(P, G, state, rho: float = 0.9, eps: float = 1e-6, wd: float = 0.0):
+    """src/optim/optim_adadelta.lua:19-62, tensor op by tensor op; `state` maps name -> {"var", "acc"} (created on first use,
+    :43-47).  wd follows the intent of :37 (dfdy:add(wd, y)); the line as written indexes the gradient TABLE and would raise."""
+    newP = {}
+    for k in P:
+        g = G[k] + wd * P[k] if wd != 0 else G[k]
+        st = state.setdefault(k, {"var": torch.zeros_like(P[k]), "acc": torch.zeros_like(P[k])})
+        st["var"] = st["var"] * rho + (1 - rho) * g * g                           # :48
+        std = (st["var"] + eps).sqrt()                                            # :49
+        delta = (st["acc"] + eps).sqrt() / std * g                                # :50
+        newP[k] = P[k] - delta                                                    # :51
+        st["acc"] = st["acc"] * rho + (1 - rho) * delta * delta                   # :52
+    return newP
+
+
 # ----------------------------------------------------------------------------
 # decode (model.lua:321-536, 570-627)
 # ----------------------------------------------------------------------------

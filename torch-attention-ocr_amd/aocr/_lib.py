@@ -56,6 +56,7 @@ SIGNATURES = {
     "aocr_model_set_stream": (C.c_int, [_vp, _vp]),
     "aocr_train_forward_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "aocr_sgd_step": (C.c_int, [_vp, _f32, _f32, _vp]),
+    "aocr_adadelta_step": (C.c_int, [_vp, _f32, _f32, _f32, _vp]),
     "aocr_forward_logits": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "aocr_decode": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "aocr_decode_dict": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -398,6 +398,21 @@ class Model:
         check(lib.aocr_sgd_step(self._h, float(self.optim_state["learningRate"] if lr is None else lr), clip, ptr(norms)))
         return norms.cpu().numpy().reshape(5, 2)
 
+    def format_norms(self):
+        """the lines optim_sgd.lua:49 prints every step, from the norms the last step() left on the device; reading them is the only
+        host sync, so the reference's per-step print becomes an on-demand report."""
+        if self.last_norms is None:
+            return []
+        n = self.last_norms.cpu().numpy().reshape(5, 2)
+        return ["i: %d, param norm: %f, grad norm: %f" % (i + 1, n[i, 0], n[i, 1]) for i in range(5)]
+
+    def adadelta_step(self, rho=0.9, eps=1e-6, weight_decay=0.0):
+        """optim.adadelta_list (src/optim/optim_adadelta.lua:19-62) on the gradients of the last train_forward_backward; the state
+        {paramVariance | accDelta} lives in `self.adadelta_state` (2 x num_params floats on the device)."""
+        if getattr(self, "adadelta_state", None) is None:
+            self.adadelta_state = torch.zeros(2 * self.num_params, dtype=torch.float32, device=self.device)
+        check(lib.aocr_adadelta_step(self._h, rho, eps, weight_decay, ptr(self.adadelta_state)), "aocr_adadelta_step")
+
     # ------------------------------------------------------------------ misc API of the reference class
     def vis(self, output_dir):
         """model:vis, model.lua:708-718."""

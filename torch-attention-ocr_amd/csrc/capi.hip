@@ -167,6 +167,14 @@ int aocr_sgd_step(aocr_model* m, float lr, float clip, float* norms_dev) {
   return check_launch("aocr_sgd_step");
 }
 
+int aocr_adadelta_step(aocr_model* m, float rho, float eps, float weight_decay, float* state_dev) {
+  REQUIRE(m && state_dev, "NULL argument");
+  REQUIRE(rho >= 0.f && rho < 1.f && eps > 0.f, "rho=%g eps=%g out of range", rho, eps);
+  const int64_t n = m->layout.group_off[AOCR_NUM_GROUPS];
+  adadelta_update(m->s, m->params, m->grads, state_dev, state_dev + n, n, rho, eps, weight_decay);
+  return check_launch("aocr_adadelta_step");
+}
+
 int aocr_forward_logits(aocr_model* m, const float* images_dev, const int32_t* targets_dev, const int32_t* targets_eval_dev,
                         int32_t B, int32_t W, int32_t L, int32_t training, float* logits_dev, float* loss_dev) {
   Dims d; if (step_dims(m, B, W, L, d)) return 1;

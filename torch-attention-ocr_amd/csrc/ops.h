@@ -148,6 +148,7 @@ void copy2d(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ld
 void sgd_clip_update(hipStream_t s, float* params, float* grads, const int64_t* group_off /*6 host values*/, float lr,
                      float clip, float* norms_out, void* scratch);
 size_t sgd_scratch_bytes();
+void adadelta_update(hipStream_t s, float* params, float* grads, float* var, float* acc, int64_t n, float rho, float eps, float wd);
 // flat dictionary trie + the per-beam node ids of one decode step (mask == nullptr: unconstrained); needs V <= 64
 struct TrieView { const unsigned long long* mask; const int32_t* base; const int32_t* child; const int32_t* loc_in; int32_t* loc_out; };
 void beam_select(hipStream_t s, const float* logp, const int32_t* prev_tok, float* beam_scores, int32_t* tokens,

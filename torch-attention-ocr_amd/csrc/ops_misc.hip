@@ -952,6 +952,28 @@ void sgd_clip_update(hipStream_t s, float* params, float* grads, const int64_t* 
   hipLaunchKernelGGL(sgd_update_kernel, dim3(1024, 5), dim3(256), 0, s, params, grads, go, scale, lr);
 }
 
+// optim.adadelta_list, src/optim/optim_adadelta.lua:19-62, fused into one pass over the flat vectors (the reference walks the 5
+// groups with 9 tensor ops each).  var = rho*var + (1-rho) g^2; delta = sqrt(acc+eps)/sqrt(var+eps) * g; x -= delta;
+// acc = rho*acc + (1-rho) delta^2.  Weight decay is what line 37 means (g += wd*x; the line itself indexes the table of
+// gradients and would raise).  HBM-bound: 4 reads + 3 writes of 4 bytes per parameter.
+__global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ x, float* __restrict__ g, float* __restrict__ var,
+                                                       float* __restrict__ acc, int64_t n, float rho, float eps, float wd) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float xv = x[i];
+    float gv = g[i];
+    if (wd != 0.f) { gv = fmaf(wd, xv, gv); g[i] = gv; }
+    const float v = var[i] * rho + (1.f - rho) * gv * gv;                        // :48
+    const float d = sqrtf(acc[i] + eps) / sqrtf(v + eps) * gv;                   // :49-50
+    x[i] = xv - d;                                                               // :51
+    acc[i] = acc[i] * rho + (1.f - rho) * d * d;                                 // :52
+    var[i] = v;
+  }
+}
+void adadelta_update(hipStream_t s, float* params, float* grads, float* var, float* acc, int64_t n, float rho, float eps, float wd) {
+  hipLaunchKernelGGL(adadelta_kernel, dim3(2048), dim3(256), 0, s, params, grads, var, acc, n, rho, eps, wd);
+}
+
 // =============================================================================================
 // beam search bookkeeping, model.lua:399-404, 446-458, 516-535, 573-585.
 // =============================================================================================
