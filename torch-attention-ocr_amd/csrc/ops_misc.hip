@@ -24,121 +24,149 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 // =============================================================================================
 // conv1: cnn.lua:9-15.  x (B,H,W) raw 0..255 -> y (B,H/2,W/2,64) = maxpool2x2(relu(conv3x3((x-128)/128)+b)).
-// thread = (pool window, 4 output channels).  K = 9: HBM-bound on the y write; x stays in L1/L2.
+// K = 9: VALU work (36 FMAs per window and channel) over an HBM-bound y write; x stays in L1/L2.
 // =============================================================================================
-__device__ __forceinline__ void conv1_patch(const float* __restrict__ x, int b, int py, int px, int H, int W, float (&p)[4][4]) {
-  const float* xb = x + (int64_t)b * H * W;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int yy = 2 * py - 1 + i;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int xx = 2 * px - 1 + j;
-      bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-      p[i][j] = ok ? (xb[(int64_t)yy * W + xx] + (-128.0f)) * (1.0f / 128) : 0.f;   // zero padding applies to the normalised map
-    }
+// lane = output channel, wave = a strip of up to 32 pooling windows of one image row (the layout of conv1_bwd_kernel below):
+// the normalised 4 x (2S+2) patch of the strip goes through a wave-private LDS block and is read back as broadcasts.
+constexpr int C1S = 32;                                         // windows per strip
+__device__ __forceinline__ void conv1_stage(const float* __restrict__ xb, int py, int px0, int H, int W, int lane,
+                                            float (&sx)[4][2 * C1S + 4]) {
+  // columns 2*px0-1 .. 2*px0+2*C1S of rows 2*py-1 .. 2*py+2; zero padding applies to the normalised map (cnn.lua:9-12)
+  for (int e = lane; e < 4 * (2 * C1S + 2); e += 64) {
+    const int i = e / (2 * C1S + 2), j = e - i * (2 * C1S + 2);
+    const int yy = 2 * py - 1 + i, xx = 2 * px0 - 1 + j;
+    const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    sx[i][j] = ok ? (xb[(int64_t)yy * W + xx] + (-128.0f)) * (1.0f / 128) : 0.f;
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, bf16_t* __restrict__ yb,
                                                         int B, int H, int W, int Hp, int Wp) {
-  __shared__ float sw[64 * 9 + 64];
-  for (int i = threadIdx.x; i < 64 * 9 + 64; i += 256) sw[i] = i < 576 ? w[i] : bias[i - 576];
-  __syncthreads();
-  const int64_t total = (int64_t)B * Hp * Wp * 16;
-  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
-    int cq = (int)(id & 15); int64_t win = id >> 4;
-    int px = (int)(win % Wp); int64_t t = win / Wp; int py = (int)(t % Hp); int b = (int)(t / Hp);
-    float p[4][4];
-    conv1_patch(x, b, py, px, H, W, p);
-    float out[4];
+  __shared__ float sx[4][4][2 * C1S + 4];                       // [wave][row][col]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float wk[9];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float* wc = sw + (cq * 4 + c) * 9;
-      float bb = sw[576 + cq * 4 + c];
-      float best = 0.f;                                        // relu floor
+  for (int k = 0; k < 9; ++k) wk[k] = w[lane * 9 + k];
+  const float bb = bias[lane];
+  const int spr = (Wp + C1S - 1) / C1S;
+  const int64_t nstrips = (int64_t)B * Hp * spr;
+  for (int64_t st = (int64_t)blockIdx.x * 4 + wave; st < nstrips; st += (int64_t)gridDim.x * 4) {
+    const int sp = (int)(st % spr); const int64_t t = st / spr; const int py = (int)(t % Hp), b = (int)(t / Hp);
+    const int px0 = sp * C1S, nw = min(C1S, Wp - px0);
+    conv1_stage(x + (int64_t)b * H * W, py, px0, H, W, lane, sx[wave]);
+    const int64_t o0 = (((int64_t)b * Hp + py) * Wp + px0) * 64 + lane;
+#pragma unroll 1
+    for (int w0 = 0; w0 < nw; w0 += 4) {
+      float p[4][10];
 #pragma unroll
-      for (int dy = 0; dy < 2; ++dy)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-          float s = bb;
-#pragma unroll
-          for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) s = fmaf(wc[kh * 3 + kw], p[dy + kh][dx + kw], s);
-          best = fmaxf(best, s);
+        for (int j = 0; j < 10; j += 2) {
+          const float2 v = *reinterpret_cast<const float2*>(&sx[wave][i][2 * w0 + j]);
+          p[i][j] = v.x; p[i][j + 1] = v.y;
         }
-      out[c] = best;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float best = 0.f;                                       // relu floor
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            float s2 = bb;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+              for (int kw = 0; kw < 3; ++kw) s2 = fmaf(wk[kh * 3 + kw], p[dy + kh][2 * u + dx + kw], s2);
+            best = fmaxf(best, s2);
+          }
+        if (w0 + u < nw) {
+          if (y) y[o0 + (int64_t)(w0 + u) * 64] = best;
+          if (yb) yb[o0 + (int64_t)(w0 + u) * 64] = (bf16_t)best;
+        }
+      }
     }
-    if (y) *reinterpret_cast<float4*>(y + win * 64 + cq * 4) = make_float4(out[0], out[1], out[2], out[3]);
-    if (yb) {
-      bf16x4 hb; hb[0] = (bf16_t)out[0]; hb[1] = (bf16_t)out[1]; hb[2] = (bf16_t)out[2]; hb[3] = (bf16_t)out[3];
-      *reinterpret_cast<bf16x4*>(yb + win * 64 + cq * 4) = hb;
-    }
+    __builtin_amdgcn_wave_barrier();                            // the next strip overwrites this wave's block
   }
 }
 
 // gradWeight/gradBias of conv1 (gradInput of the image is never used: model.lua:692 discards it).
 // Re-computes the 4 conv values of each window to route d(pooled) through pool+ReLU.
+// lane = output channel, wave = a strip of up to 32 pooling windows of one image row: the 4 x (2S+2) input patch of the strip is
+// normalised once into a wave-private LDS row block and read back as broadcasts (every lane needs the same 16 values per window),
+// d(pooled) is one coalesced 256-byte row per window.  Per window and lane: 36 FMAs to re-evaluate the four conv outputs, the
+// arg-max/ReLU routing as four masked copies of g, 36 FMAs into the nine tap accumulators -- no dynamic register indexing.
 __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ dyp,
                                                         float* __restrict__ dw, float* __restrict__ db, int B, int H, int W,
                                                         int Hp, int Wp, float* __restrict__ partial) {
-  __shared__ float sw[64 * 9 + 64];
-  for (int i = threadIdx.x; i < 640; i += 256) sw[i] = i < 576 ? w[i] : bias[i - 576];
-  __syncthreads();
-  const int cq = threadIdx.x & 15;
-  float acc[4][10];
+  __shared__ float sx[4][4][2 * C1S + 4];                       // [wave][row][col]
+  __shared__ float swave[4][640];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float wk[9];
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int k = 0; k < 9; ++k) wk[k] = w[lane * 9 + k];
+  const float bb = bias[lane];
+  float acc[9], accb = 0.f;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) acc[c][k] = 0.f;
-  const int64_t total = (int64_t)B * Hp * Wp * 16;
-  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
-    int64_t win = id >> 4;                                      // (id & 15) == cq because the stride is a multiple of 16
-    int px = (int)(win % Wp); int64_t t = win / Wp; int py = (int)(t % Hp); int b = (int)(t / Hp);
-    float p[4][4];
-    conv1_patch(x, b, py, px, H, W, p);
-    float4 g4 = *reinterpret_cast<const float4*>(dyp + win * 64 + cq * 4);
-    float g[4] = {g4.x, g4.y, g4.z, g4.w};
+  for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+  const int spr = (Wp + C1S - 1) / C1S;                         // strips per image row
+  const int64_t nstrips = (int64_t)B * Hp * spr;
+  for (int64_t st = (int64_t)blockIdx.x * 4 + wave; st < nstrips; st += (int64_t)gridDim.x * 4) {
+    const int sp = (int)(st % spr); const int64_t t = st / spr; const int py = (int)(t % Hp), b = (int)(t / Hp);
+    const int px0 = sp * C1S, nw = min(C1S, Wp - px0);
+    conv1_stage(x + (int64_t)b * H * W, py, px0, H, W, lane, sx[wave]);
+    const float* gp = dyp + (((int64_t)b * Hp + py) * Wp + px0) * 64 + lane;
+#pragma unroll 1
+    for (int w0 = 0; w0 < nw; w0 += 4) {
+      float g[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float* wc = sw + (cq * 4 + c) * 9;
-      float bb = sw[576 + cq * 4 + c];
-      float best = 0.f; int bdy = -1, bdx = 0;
+      for (int u = 0; u < 4; ++u) g[u] = (w0 + u < nw) ? gp[(int64_t)(w0 + u) * 64] : 0.f;
+      float p[4][10];                                           // columns 2*w0 .. 2*w0+9 of the staged block (broadcast reads)
 #pragma unroll
-      for (int dy = 0; dy < 2; ++dy)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-          float s = bb;
+        for (int j = 0; j < 10; j += 2) {
+          const float2 v = *reinterpret_cast<const float2*>(&sx[wave][i][2 * w0 + j]);
+          p[i][j] = v.x; p[i][j + 1] = v.y;
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float sv[4];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            float s2 = bb;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+              for (int kw = 0; kw < 3; ++kw) s2 = fmaf(wk[kh * 3 + kw], p[dy + kh][2 * u + dx + kw], s2);
+            sv[dy * 2 + dx] = s2;
+          }
+        // first strict maximum above the ReLU floor, in the order (0,0),(0,1),(1,0),(1,1) -- the forward's fmaxf chain
+        float best = 0.f; int bi = -1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (sv[q] > best) { best = sv[q]; bi = q; }
+        const float gg = g[u];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float gq = bi == q ? gg : 0.f;
+          const int dy = q >> 1, dx = q & 1;
 #pragma unroll
           for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) s = fmaf(wc[kh * 3 + kw], p[dy + kh][dx + kw], s);
-          if (s > best) { best = s; bdy = dy; bdx = dx; }
+            for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = fmaf(gq, p[dy + kh][2 * u + dx + kw], acc[kh * 3 + kw]);
         }
-      if (bdy >= 0) {                                          // pooled value > 0: gradient reaches the arg-max
-        float gg = g[c];
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) acc[c][kh * 3 + kw] = fmaf(gg, p[bdy + kh][bdx + kw], acc[c][kh * 3 + kw]);
-        acc[c][9] += gg;
+        accb += bi >= 0 ? gg : 0.f;
       }
     }
+    __builtin_amdgcn_wave_barrier();                            // the next strip overwrites this wave's block
   }
-  // lanes l, l+16, l+32, l+48 of a wave hold the same channel quad: butterfly over them, then one LDS slot per wave
-  __shared__ float swave[4][640];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int k = 0; k < 10; ++k) {
-      float v = acc[c][k];
-      v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-      if (lane < 16) swave[wave][(cq * 4 + c) * 10 + k] = v;
-    }
+  for (int k = 0; k < 9; ++k) swave[wave][lane * 10 + k] = acc[k];
+  swave[wave][lane * 10 + 9] = accb;
   __syncthreads();
   for (int i = threadIdx.x; i < 640; i += 256) {
     const float t = (swave[0][i] + swave[1][i]) + (swave[2][i] + swave[3][i]);
@@ -150,17 +178,17 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
 
 void conv1_forward(hipStream_t s, const float* x, const float* w, const float* bias, float* y, int B, int H, int W, bf16_t* yb) {
   int Hp = H / 2, Wp = W / 2;
-  int64_t total = (int64_t)B * Hp * Wp * 16;
-  int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+  int64_t strips = (int64_t)B * Hp * ((Wp + C1S - 1) / C1S);
+  int blocks = (int)std::min<int64_t>((strips + 3) / 4, 4096);
   hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, y, yb, B, H, W, Hp, Wp);
 }
 void conv1_backward(hipStream_t s, const float* x, const float* w, const float* bias, const float* dyp, float* dw, float* db,
                     int B, int H, int W, float* scratch) {
   int Hp = H / 2, Wp = W / 2;
-  int64_t total = (int64_t)B * Hp * Wp * 16;
+  int64_t strips = (int64_t)B * Hp * ((Wp + C1S - 1) / C1S);
   // with a scratch slab (>= 4096*640 floats) every workgroup writes its partial sums and two column sums finish the job:
   // no contended global atomics, more workgroups
-  int blocks = (int)std::min<int64_t>((total + 255) / 256, scratch ? 2048 : 1024);
+  int blocks = (int)std::min<int64_t>((strips + 3) / 4, scratch ? 2048 : 1024);
   hipLaunchKernelGGL(conv1_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, dyp, dw, db, B, H, W, Hp, Wp, scratch);
   if (scratch) {
     colsum_accum(s, scratch, 640, blocks, 576, dw);
