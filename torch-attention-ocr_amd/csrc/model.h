@@ -68,6 +68,7 @@ struct aocr_model {
   float *ezx[2][aocr::MAXL], *ehs[2][aocr::MAXL], *ecs[2][aocr::MAXL], *egates[2][aocr::MAXL], *edz[2][aocr::MAXL], *edc[2];
   float *edxl[2];
   float *context, *dctx;
+  aocr::bf16_t* context_b;        // bf16 shadow of the context for the attention kernels (bf16 mode)
   // decoder, teacher-forced (rows = B, time-major)
   float *emb_all, *zx1_all, *dhs[aocr::MAXL], *dcs[aocr::MAXL], *dgates[aocr::MAXL], *ddz[aocr::MAXL];
   float *out_all, *cat_all, *q_all, *a_all, *logits, *dlogits, *nll_rows;

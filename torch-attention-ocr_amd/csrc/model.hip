@@ -117,6 +117,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     m->edc[dir] = a.get<float>(B * He); m->edxl[dir] = a.get<float>(T * B * He);
   }
   m->context = a.get<float>(B * T * Hd); m->dctx = a.get<float>(B * T * Hd);
+  m->context_b = m->bf16 ? a.get<bf16_t>(B * T * Hd) : nullptr;
   {
     auto hb = [&](size_t n) { return m->bf16 ? a.get<bf16_t>(n) : (bf16_t*)nullptr; };
     m->Xb = hb(T * B * 512);
@@ -378,6 +379,8 @@ void encoder_forward(aocr_model* m, const Dims& d) {
       run_gates_fwd(m, 2, la, w0, w1, ee, B, He, lah);
     }
   }
+  // bf16 mode: the attention kernels of the decoder (2 x L launches per step) read the context from a bf16 shadow
+  if (m->context_b) copy2d_bf16(s, m->context, Hd, m->context_b, Hd, B * T, Hd);
 }
 
 // BPTT through both encoder directions, model.lua:662-690.  On entry dc_st[0] / dh_rec[0] of the decoder hold
@@ -496,7 +499,7 @@ static void dec_step_forward(aocr_model* m, const DecStepIO& io, int T) {
     const bool sh = io.hb_new[0] != nullptr;
     LoadKh2 qa = make_loadkh(sh ? io.hb_new[m->Ld - 1] : nullptr, Hd, R, Hd);
     run_store_nt(m, make_loadk(io.h_new[m->Ld - 1], Hd, R, Hd), m->swa, make_store(io.q, Hd, R, Hd), R, &qa);      // q = W_a h_top, LSTM.lua:131
-    attention_forward(s, m->context, io.q, io.a, io.cat, 2 * Hd, R, T, Hd, io.ctx_div, io.cat_b, 2 * Hd);
+    attention_forward(s, m->context, io.q, io.a, io.cat, 2 * Hd, R, T, Hd, io.ctx_div, io.cat_b, 2 * Hd, m->context_b);
     EpStore eo = make_store(io.out, Hd, R, Hd, nullptr, nullptr, EP_TANH);
     eo.Cb = io.out_b; eo.ldcb = Hd;
     LoadKh2 ca = make_loadkh(sh ? io.cat_b : nullptr, 2 * Hd, R, 2 * Hd);
@@ -598,7 +601,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
     LoadKh2 dpa = make_loadkh(sh ? m->dpre_b + (size_t)t * slot : nullptr, Hd, B, Hd);
     run_store_nn(m, make_loadk(dpre, Hd, B, Hd), m->swc, make_store(dcat, 2 * Hd, B, 2 * Hd), B, &dpa);      // d[c ; h_top] = dpre W_c
     attention_backward(s, m->context, m->q_all + (size_t)t * slot, m->a_all + (size_t)t * B * T, dcat, 2 * Hd,
-                       m->ds_all + (size_t)t * B * T, m->dq_all + (size_t)t * slot, B, T, Hd, sh ? m->dq_b + (size_t)t * slot : nullptr);
+                       m->ds_all + (size_t)t * B * T, m->dq_all + (size_t)t * slot, B, T, Hd, sh ? m->dq_b + (size_t)t * slot : nullptr, m->context_b);
     // top layer: d h_top = dq W_a + dcat[:, Hd:] + recurrent part
     for (int l = Ld - 1; l >= 0; --l) {
       LoadK la; LoadKh2 lah; EpGatesBwd e; const ShW* ww;

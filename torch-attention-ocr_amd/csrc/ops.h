@@ -123,9 +123,10 @@ void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float
 // yb: bf16 shadow of y (ReLU mask source); conv_dbias + partial (>= 4096*256 floats): fused bias gradient of the preceding conv, dx may then be null
 // ctx_div: rows r share context row r / ctx_div (beam search keeps one context per image, model.lua:373)
 void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a, float* c, int64_t ldc, int B, int T, int Hd,
-                       int ctx_div = 1, bf16_t* cb = nullptr, int64_t ldcb = 0);
+                       int ctx_div = 1, bf16_t* cb = nullptr, int64_t ldcb = 0, const bf16_t* ctxb = nullptr);
 void attention_backward(hipStream_t s, const float* ctx, const float* q, const float* a, const float* dc, int64_t lddc,
-                        float* ds, float* dq, int B, int T, int Hd, bf16_t* dqb = nullptr);
+                        float* ds, float* dq, int B, int T, int Hd, bf16_t* dqb = nullptr, const bf16_t* ctxb = nullptr);
+// ctxb: bf16 shadow of ctx, read instead of ctx by the register-resident kernels (T <= 64, Hd in {256, 512})
 // d(ctx)[b,t,:] = sum_l a[l,b,t]*dc[l,b,:] + ds[l,b,t]*q[l,b,:]   (dc row stride lddc)
 void attention_dctx(hipStream_t s, const float* a_all, const float* ds_all, const float* dc_all, int64_t lddc,
                     const float* q_all, float* dctx, int L, int B, int T, int Hd);

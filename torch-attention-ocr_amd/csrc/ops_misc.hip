@@ -588,8 +588,16 @@ __global__ __launch_bounds__(256) void attn_core_kernel(const float* __restrict_
 // Register-resident variant for T <= 64 and Hd = 256*NC (NC = 1, 2): the whole (T, Hd) context slice of one batch row
 // is loaded ONCE into registers (wave w holds rows t = w, w+4, ...; all 16*NC dwordx4 loads of a lane are in flight
 // together) and serves both the score pass and the weighted-sum pass.  Same phases and outputs as attn_core_kernel.
-template <int NC, bool BWD>
-__global__ __launch_bounds__(256) void attn_reg_kernel(const float* __restrict__ ctx, const float* __restrict__ u, int64_t ldu,
+__device__ __forceinline__ float4 attn_load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 attn_load4(const bf16_t* p) {
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+// CT = bf16_t (bf16 compute mode): the context is read from its bf16 shadow -- 16.5 MB instead of 33 MB per launch at C3, which is
+// what this kernel's duration is made of (one workgroup per batch row streams its whole (T, Hd) slice), and small enough to stay
+// in the XCD's L2 between the 2 x 24 launches of a step (batch row b always lands on XCD b % 8).
+template <int NC, bool BWD, class CT>
+__global__ __launch_bounds__(256) void attn_reg_kernel(const CT* __restrict__ ctx, const float* __restrict__ u, int64_t ldu,
                                                        const float* __restrict__ a_in, float* __restrict__ p_out,
                                                        float* __restrict__ o, int64_t ldo, int T, int ctx_div, bf16_t* __restrict__ ob,
                                                        int64_t ldob) {
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(256) void attn_reg_kernel(const float* __restrict__
   __shared__ float sc[64];
   __shared__ __attribute__((aligned(16))) float red[4][Hd];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* cb = ctx + (int64_t)(b / ctx_div) * T * Hd;
+  const CT* cb = ctx + (int64_t)(b / ctx_div) * T * Hd;
   const float* ub = u + (int64_t)b * ldu;
   float4 c[16][NC];
 #pragma unroll
@@ -605,7 +613,7 @@ __global__ __launch_bounds__(256) void attn_reg_kernel(const float* __restrict__
     const int t = wave + 4 * i;
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc)
-      c[i][cc] = t < T ? *reinterpret_cast<const float4*>(cb + (int64_t)t * Hd + cc * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      c[i][cc] = t < T ? attn_load4(cb + (int64_t)t * Hd + cc * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float4 uu[NC];
 #pragma unroll
@@ -661,25 +669,103 @@ __global__ __launch_bounds__(256) void attn_reg_kernel(const float* __restrict__
   }
 }
 
+// bf16-context form of attn_reg_kernel for Hd = 512: one 16-byte load per lane and context row (8 bf16), so the (T, 512) slice
+// of a batch row is 16 load instructions per lane instead of 32 -- the kernel is bound by load issue/latency, not by bytes
+// (reading the bf16 shadow with 8-byte loads was slower than fp32: 15.5 vs 12.2 us).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <bool BWD, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_reg_h512_kernel(const bf16_t* __restrict__ ctx, const float* __restrict__ u, int64_t ldu,
+                                                            const float* __restrict__ a_in, float* __restrict__ p_out,
+                                                            float* __restrict__ o, int64_t ldo, int T, int ctx_div,
+                                                            bf16_t* __restrict__ ob, int64_t ldob) {
+  constexpr int Hd = 512, RW = 64 / NW;                        // RW context rows per wave
+  __shared__ float sc[64];
+  __shared__ __attribute__((aligned(16))) float red[NW][Hd];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bf16_t* cb = ctx + (int64_t)(b / ctx_div) * T * Hd + lane * 8;
+  const float* ub = u + (int64_t)b * ldu + lane * 8;
+  bf16x8 c[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    const int t = wave + NW * i;
+    if (t < T) c[i] = *reinterpret_cast<const bf16x8*>(cb + (int64_t)t * Hd);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) c[i][e] = (bf16_t)0.f;
+    }
+  }
+  const float4 u0 = *reinterpret_cast<const float4*>(ub), u1 = *reinterpret_cast<const float4*>(ub + 4);
+  const float uu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf((float)c[i][e], uu[e], s);
+    s = wave_sum(s);
+    if (lane == 0) sc[wave + NW * i] = s;
+  }
+  __syncthreads();
+  if (wave == 0) {                                             // T <= 64: one wave does the softmax / its backward
+    const bool ok = lane < T;
+    float v = ok ? sc[lane] : -INFINITY;
+    float p;
+    if (!BWD) {
+      float m = wave_max(v);
+      float e = ok ? expf(v - m) : 0.f;
+      float sum = wave_sum(e);
+      p = e * (1.f / sum);
+    } else {
+      float a = ok ? a_in[(int64_t)b * T + lane] : 0.f;
+      float dot = wave_sum(ok ? a * v : 0.f);
+      p = ok ? a * (v - dot) : 0.f;
+    }
+    sc[lane] = p;
+    if (ok) p_out[(int64_t)b * T + lane] = p;
+  }
+  __syncthreads();
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    const float p = sc[wave + NW * i];                          // rows >= T carry p = 0 and c = 0
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, (float)c[i][e], acc[e]);
+  }
+  *reinterpret_cast<float4*>(&red[wave][lane * 8]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  *reinterpret_cast<float4*>(&red[wave][lane * 8 + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  __syncthreads();
+  for (int j = threadIdx.x; j < Hd; j += 64 * NW) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; q += 4) v += (red[q][j] + red[q + 1][j]) + (red[q + 2][j] + red[q + 3][j]);
+    o[(int64_t)b * ldo + j] = v;
+    if (ob) ob[(int64_t)b * ldob + j] = (bf16_t)v;
+  }
+}
+
+constexpr int ATTN_NW = 16;
 template <bool BWD>
 static void attn_launch(hipStream_t s, const float* ctx, const float* u, int64_t ldu, const float* a_in, float* p_out, float* o,
-                        int64_t ldo, int B, int T, int Hd, int ctx_div, bf16_t* ob, int64_t ldob) {
-  if (T <= 64 && Hd == 512)
-    hipLaunchKernelGGL((attn_reg_kernel<2, BWD>), dim3(B), dim3(256), 0, s, ctx, u, ldu, a_in, p_out, o, ldo, T, ctx_div, ob, ldob);
+                        int64_t ldo, int B, int T, int Hd, int ctx_div, bf16_t* ob, int64_t ldob, const bf16_t* ctxb) {
+  if (T <= 64 && Hd == 512 && ctxb && ldu % 4 == 0)
+    hipLaunchKernelGGL((attn_reg_h512_kernel<BWD, ATTN_NW>), dim3(B), dim3(64 * ATTN_NW), 0, s, ctxb, u, ldu, a_in, p_out, o, ldo, T, ctx_div, ob, ldob);
+  else if (T <= 64 && Hd == 512)
+    hipLaunchKernelGGL((attn_reg_kernel<2, BWD, float>), dim3(B), dim3(256), 0, s, ctx, u, ldu, a_in, p_out, o, ldo, T, ctx_div, ob, ldob);
   else if (T <= 64 && Hd == 256)
-    hipLaunchKernelGGL((attn_reg_kernel<1, BWD>), dim3(B), dim3(256), 0, s, ctx, u, ldu, a_in, p_out, o, ldo, T, ctx_div, ob, ldob);
+    hipLaunchKernelGGL((attn_reg_kernel<1, BWD, float>), dim3(B), dim3(256), 0, s, ctx, u, ldu, a_in, p_out, o, ldo, T, ctx_div, ob, ldob);
   else
     hipLaunchKernelGGL((attn_core_kernel<BWD>), dim3(B), dim3(256), (size_t)(T + 8) * sizeof(float), s, ctx, u, ldu, a_in, p_out, o, ldo,
                        T, Hd, ctx_div, ob, ldob);
 }
 void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a, float* c, int64_t ldc, int B, int T, int Hd,
-                       int ctx_div, bf16_t* cb, int64_t ldcb) {
-  attn_launch<false>(s, ctx, q, (int64_t)Hd, nullptr, a, c, ldc, B, T, Hd, ctx_div, cb, ldcb);
+                       int ctx_div, bf16_t* cb, int64_t ldcb, const bf16_t* ctxb) {
+  attn_launch<false>(s, ctx, q, (int64_t)Hd, nullptr, a, c, ldc, B, T, Hd, ctx_div, cb, ldcb, ctxb);
 }
 void attention_backward(hipStream_t s, const float* ctx, const float* q, const float* a, const float* dc, int64_t lddc,
-                        float* ds, float* dq, int B, int T, int Hd, bf16_t* dqb) {
+                        float* ds, float* dq, int B, int T, int Hd, bf16_t* dqb, const bf16_t* ctxb) {
   (void)q;
-  attn_launch<true>(s, ctx, dc, lddc, a, ds, dq, (int64_t)Hd, B, T, Hd, 1, dqb, (int64_t)Hd);
+  attn_launch<true>(s, ctx, dc, lddc, a, ds, dq, (int64_t)Hd, B, T, Hd, 1, dqb, (int64_t)Hd, ctxb);
 }
 
 // d(ctx)[b,t,j] = sum_l a[l,b,t]*dc[l,b,j] + ds[l,b,t]*q[l,b,j]  (model.lua:652-653 accumulated over the decoder loop)
