@@ -1355,7 +1355,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs2<AL, BL, EP> 
 // ---------------------------------------------------------------------------
 constexpr int STEP_PITCH = 144;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-template <int NT> constexpr int step_lds_bytes() { return 4 * (1 + NT) * 32 * STEP_PITCH; }
+template <int NT, int NW = 4> constexpr int step_lds_bytes() { return NW * (1 + NT) * 32 * STEP_PITCH; }
 
 // global -> registers for one 64-deep chunk (kept as free functions with flat, statically indexed arrays of native
 // vector types: arrays captured by reference in lambdas / HIP's uint4 struct were demoted to LDS or scratch)
@@ -1410,11 +1410,14 @@ __device__ __forceinline__ void step_lwrite_b(unsigned char* lb, int br, int bp,
 // GATES: 0 plain (NT column tiles of 32); 1 gate tiles (tile = gate, 32 hidden units per workgroup, NT = 4); 2 HALF gate tiles
 // (NT = 2: tile t carries gates 2t and 2t+1 of 16 hidden units in its column halves, so a workgroup loads and multiplies half
 // the weights and twice as many workgroups share the step: 128 -> 256 at Hd = 512, B = 256; the epilogue pairs lanes l and l^16).
-template <int NT, int GATES, class AL, class EP>
-__global__ __launch_bounds__(256) void gemm_step_kernel(SmallArgs2<AL, LoadKh2, EP> zz, int gate_stride) {
+// NW waves share K (4, or 8 where the LDS allows): one workgroup per CU means the waves of ONE workgroup are all the memory-level
+// parallelism a CU has, and these launches are a load -> MFMA -> reduce latency chain.
+template <int NT, int GATES, class AL, class EP, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_step_kernel(SmallArgs2<AL, LoadKh2, EP> zz, int gate_stride) {
   constexpr bool AH = SrcBf16<AL>::v;                           // A operand read from its bf16 shadow
   constexpr int NA = AH ? 4 : 8;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[step_lds_bytes<NT>()];
+  constexpr int E = 16 / NW;                                    // accumulator rows finished per thread
+  __shared__ __attribute__((aligned(16))) unsigned char lds[step_lds_bytes<NT, NW>()];
   const SmallArgs<AL, LoadKh2, EP>& g = zz.z[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -1423,7 +1426,7 @@ __global__ __launch_bounds__(256) void gemm_step_kernel(SmallArgs2<AL, LoadKh2, 
   const int K = g.K;
   unsigned char* la = lds + wave * ((1 + NT) * 32 * STEP_PITCH);
   unsigned char* lb = la + 32 * STEP_PITCH;
-  const int kw = ((K / 64 + 3) / 4) * 64;                   // this wave's K range (multiple of 64)
+  const int kw = ((K / 64 + NW - 1) / NW) * 64;             // this wave's K range (multiple of 64)
   const int kbeg = wave * kw, kend = min(K, kbeg + kw);
 
   // staging roles.  fp32 rows: lane -> row (lane>>4) + 4i, 16-byte piece (lane&15) = 4 k;  bf16 rows: row (lane>>3) + 8i, piece (lane&7) = 8 k
@@ -1440,9 +1443,11 @@ __global__ __launch_bounds__(256) void gemm_step_kernel(SmallArgs2<AL, LoadKh2, 
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
   // the epilogue's own operands (zx, c_prev, gates, ...) are requested now so that they arrive during the K loop
-  typename EP::Pre pre[4];
+  // accumulator index i = E*wave + e of a 32x32 tile sits in row 8*(i/4) + 4h + i%4
+  const int orow = NW == 4 ? m0 + 8 * wave + 4 * h : m0 + 8 * (wave >> 1) + 4 * h + 2 * (wave & 1);
+  typename EP::Pre pre[E];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) pre[e] = g.ep.prefetch(m0 + 8 * wave + 4 * h + e, GATES == 2 ? n0 + (r & 15) : n0 + r);
+  for (int e = 0; e < E; ++e) pre[e] = g.ep.prefetch(orow + e, GATES == 2 ? n0 + (r & 15) : n0 + r);
 
   if (kbeg < kend) {
     typename std::conditional<AH, u32x4, float4>::type ra[NA]; u32x4 rb[NT * 4];
@@ -1476,22 +1481,24 @@ __global__ __launch_bounds__(256) void gemm_step_kernel(SmallArgs2<AL, LoadKh2, 
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[(ni * 16 + e) * 64 + lane] = acc[ni][e];
   __syncthreads();
-  // each thread finishes 4 elements (rows 8*wave + 4h + e of column r) straight from LDS
+  // each thread finishes E elements (rows orow + e of column r) straight from LDS
   const float* r0 = reinterpret_cast<const float*>(lds);
   constexpr int WSTRIDE = (1 + NT) * 32 * STEP_PITCH / 4;     // floats between two waves' regions
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
+  for (int e = 0; e < E; ++e) {
     float v[NT];
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
-      const int idx = (ni * 16 + 4 * wave + e) * 64 + lane;
+      const int idx = (ni * 16 + E * wave + e) * 64 + lane;
       v[ni] = (r0[idx] + r0[idx + WSTRIDE]) + (r0[idx + 2 * WSTRIDE] + r0[idx + 3 * WSTRIDE]);
+      if constexpr (NW == 8)
+        v[ni] += (r0[idx + 4 * WSTRIDE] + r0[idx + 5 * WSTRIDE]) + (r0[idx + 6 * WSTRIDE] + r0[idx + 7 * WSTRIDE]);
     }
     if constexpr (GATES == 2) {                                 // lane l < 16 of each 32-lane half: [i, o] here, [f, g] in lane l + 16
       float v4[4] = {v[0], __shfl_xor(v[0], 16, 64), v[1], __shfl_xor(v[1], 16, 64)};
-      if (r < 16) g.ep.template elem<4>(m0 + 8 * wave + 4 * h + e, n0 + r, 32, v4, pre[e]);
+      if (r < 16) g.ep.template elem<4>(orow + e, n0 + r, 32, v4, pre[e]);
     } else {
-      g.ep.template elem<NT>(m0 + 8 * wave + 4 * h + e, n0 + r, 32, v, pre[e]);
+      g.ep.template elem<NT>(orow + e, n0 + r, 32, v, pre[e]);
     }
   }
 }

@@ -110,6 +110,7 @@ void launch_small_gates_bwd(hipStream_t s, bool bf16, int nz, const GatesBwdArgs
 }
 
 // half gate tiles (16 hidden units x 4 gates per workgroup) when the 32-unit grid would leave CUs idle; AOCR_NO_HALF_TILES=1 disables
+static bool step_waves8() { static const bool on = getenv("AOCR_STEP_WAVES4") == nullptr; return on; }
 static bool half_gate_tiles(int H, int M, int nz) {
   const char* e = getenv("AOCR_NO_HALF_TILES");
   if (e && e[0] == '1') return false;
@@ -127,7 +128,16 @@ static void launch_small_bf16(hipStream_t s, int nz, const ARGS* z, int M, int n
   if (staged) {
     if constexpr (GATES && NT == 4) {
       if (half_gate_tiles(ncols, M, nz)) {
-        hipLaunchKernelGGL((gemm_step_kernel<2, 2, decltype(z[0].a), decltype(z[0].ep)>), dim3(ncols / 16, cdiv(M, 32), nz), dim3(256), 0, s, zz, gate_stride);
+        if (step_waves8())
+          hipLaunchKernelGGL((gemm_step_kernel<2, 2, decltype(z[0].a), decltype(z[0].ep), 8>), dim3(ncols / 16, cdiv(M, 32), nz), dim3(512), 0, s, zz, gate_stride);
+        else
+          hipLaunchKernelGGL((gemm_step_kernel<2, 2, decltype(z[0].a), decltype(z[0].ep)>), dim3(ncols / 16, cdiv(M, 32), nz), dim3(256), 0, s, zz, gate_stride);
+        return;
+      }
+    }
+    if constexpr (NT <= 2) {
+      if (step_waves8()) {
+        hipLaunchKernelGGL((gemm_step_kernel<NT, GATES ? 1 : 0, decltype(z[0].a), decltype(z[0].ep), 8>), grid, dim3(512), 0, s, zz, gate_stride);
         return;
       }
     }
@@ -145,7 +155,16 @@ static void launch_small_bf16_hh(hipStream_t s, int nz, const ARGS* z, int M, in
   SmallArgs2<decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)> zz; zz.z[0] = z[0]; zz.z[1] = z[nz > 1 ? 1 : 0]; zz.z[2] = z[nz > 2 ? 2 : 0];
   if constexpr (GATES && NT == 4) {
     if (half_gate_tiles(ncols, M, nz)) {
-      hipLaunchKernelGGL((gemm_step_kernel<2, 2, decltype(z[0].a), decltype(z[0].ep)>), dim3(ncols / 16, cdiv(M, 32), nz), dim3(256), 0, s, zz, gate_stride);
+      if (step_waves8())
+        hipLaunchKernelGGL((gemm_step_kernel<2, 2, decltype(z[0].a), decltype(z[0].ep), 8>), dim3(ncols / 16, cdiv(M, 32), nz), dim3(512), 0, s, zz, gate_stride);
+      else
+        hipLaunchKernelGGL((gemm_step_kernel<2, 2, decltype(z[0].a), decltype(z[0].ep)>), dim3(ncols / 16, cdiv(M, 32), nz), dim3(256), 0, s, zz, gate_stride);
+      return;
+    }
+  }
+  if constexpr (NT <= 2) {
+    if (step_waves8()) {
+      hipLaunchKernelGGL((gemm_step_kernel<NT, GATES ? 1 : 0, decltype(z[0].a), decltype(z[0].ep), 8>), grid, dim3(512), 0, s, zz, gate_stride);
       return;
     }
   }
