@@ -1261,7 +1261,7 @@ __global__ __launch_bounds__(256, 4) void wgrad_tr_grouped_kernel(GroupArgs<Load
 // ---------------------------------------------------------------------------
 template <class AL, class BL, class EP> struct SmallArgs { AL a; BL b; EP ep; int K; };
 
-template <bool BF16, int NT, bool GATES, class AL, class BL, class EP>
+template <bool BF16, int NT, bool GATES, int NW, class AL, class BL, class EP>
 __device__ __forceinline__ void gemm_small_body(const SmallArgs<AL, BL, EP>& g, int gate_stride, float* red) {
   constexpr int NV = Mode<BF16>::NV, CH = Mode<BF16>::CHUNK;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1288,7 +1288,7 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgs<AL, BL, EP>& g, 
   // takes from its row per chunk add up to whole 128-byte lines inside the in-flight window (row-strided fragment
   // loads with chunks interleaved across waves re-fetched every line several times through the 32 KB L1).
   constexpr int D = 4;
-  const int kw = ((K + 4 * CH - 1) / (4 * CH)) * CH;        // K range per wave, multiple of CH
+  const int kw = ((K + NW * CH - 1) / (NW * CH)) * CH;      // K range per wave, multiple of CH
   const int kend = min(K, (wave + 1) * kw);
   FA fa[D][1]; FB fb[D][NT];
   int kb = wave * kw;
@@ -1321,6 +1321,7 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgs<AL, BL, EP>& g, 
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[((wave * NT + ni) * 16 + e) * 64 + lane] = acc[0][ni][e];
   __syncthreads();
+  if (NW > 4 && wave >= 4) return;          // waves 4.. only contribute partial sums
   const int q = wave;                       // this wave finalises rows 8q+4h .. +3
   float v[NT][4];
 #pragma unroll
@@ -1329,7 +1330,7 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgs<AL, BL, EP>& g, 
     for (int i = 0; i < 4; ++i) {
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) s += red[((w * NT + ni) * 16 + 4 * q + i) * 64 + lane];
+      for (int w = 0; w < NW; ++w) s += red[((w * NT + ni) * 16 + 4 * q + i) * 64 + lane];
       v[ni][i] = s;
     }
   g.ep.template quad<NT>(m0 + 8 * q + 4 * h, n0 + r, 32, v);
@@ -1337,10 +1338,10 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgs<AL, BL, EP>& g, 
 
 template <class AL, class BL, class EP> struct SmallArgs2 { SmallArgs<AL, BL, EP> z[3]; };     // up to three problems per launch (blockIdx.z)
 
-template <bool BF16, int NT, bool GATES, class AL, class BL, class EP>
-__global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs2<AL, BL, EP> zz, int gate_stride) {
-  __shared__ float red[4 * NT * 16 * 64];
-  gemm_small_body<BF16, NT, GATES>(zz.z[blockIdx.z], gate_stride, red);      // kernarg array: one body, scalar-indexed
+template <bool BF16, int NT, bool GATES, class AL, class BL, class EP, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_small_kernel(SmallArgs2<AL, BL, EP> zz, int gate_stride) {
+  __shared__ float red[NW * NT * 16 * 64];
+  gemm_small_body<BF16, NT, GATES, NW>(zz.z[blockIdx.z], gate_stride, red);  // kernarg array: one body, scalar-indexed
 }
 
 // ---------------------------------------------------------------------------

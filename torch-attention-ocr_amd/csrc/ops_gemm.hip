@@ -85,6 +85,7 @@ void launch_conv_wgrad(hipStream_t s, bool bf16, const LoadMN& a, const LoadConv
   launch_big(s, bf16, a, b, ep, M, N, K, ksplit);
 }
 
+static bool step_waves8() { static const bool on = getenv("AOCR_STEP_WAVES4") == nullptr; return on; }
 template <int NT, bool GATES, class ARGS>
 static void launch_small(hipStream_t s, bool bf16, int nz, const ARGS* z, int M, int ncols, int gate_stride) {
   if (M <= 0 || ncols <= 0) return;
@@ -92,6 +93,9 @@ static void launch_small(hipStream_t s, bool bf16, int nz, const ARGS* z, int M,
   SmallArgs2<decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)> zz; zz.z[0] = z[0]; zz.z[1] = z[nz > 1 ? 1 : 0]; zz.z[2] = z[nz > 2 ? 2 : 0];
   if (bf16) hipLaunchKernelGGL((gemm_small_kernel<true, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid,
                                dim3(256), 0, s, zz, gate_stride);
+  else if (step_waves8())
+    hipLaunchKernelGGL((gemm_small_kernel<false, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep), 8>), grid, dim3(512), 0, s,
+                       zz, gate_stride);
   else      hipLaunchKernelGGL((gemm_small_kernel<false, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid,
                                dim3(256), 0, s, zz, gate_stride);
 }
@@ -110,7 +114,6 @@ void launch_small_gates_bwd(hipStream_t s, bool bf16, int nz, const GatesBwdArgs
 }
 
 // half gate tiles (16 hidden units x 4 gates per workgroup) when the 32-unit grid would leave CUs idle; AOCR_NO_HALF_TILES=1 disables
-static bool step_waves8() { static const bool on = getenv("AOCR_STEP_WAVES4") == nullptr; return on; }
 static bool half_gate_tiles(int H, int M, int nz) {
   const char* e = getenv("AOCR_NO_HALF_TILES");
   if (e && e[0] == '1') return false;

@@ -1164,7 +1164,8 @@ __global__ __launch_bounds__(64) void beam_select_kernel(const float* __restrict
 // Decode step tail in ONE launch: projector (output_projector.lua:3-8: logits = W_o h + b), LogSoftMax, finished-beam masking,
 // score accumulation and top-k selection (model.lua:399-404,446-458,516).  One workgroup per batch element; the kin x V logits are
 // 512-long fp32 dot products spread over the 4 waves (lanes stride the hidden dimension), then the selection of beam_select_kernel.
-__global__ __launch_bounds__(256) void project_select_kernel(const float* __restrict__ h, int64_t ldh, const float* __restrict__ wo,
+constexpr int PS_NW = 16;                                      // waves per batch element: one logit per wave at a time
+__global__ __launch_bounds__(64 * PS_NW) void project_select_kernel(const float* __restrict__ h, int64_t ldh, const float* __restrict__ wo,
                                                              const float* __restrict__ bo, int Hd, const int32_t* __restrict__ prev_tok,
                                                              float* __restrict__ beam_scores, int32_t* __restrict__ tokens,
                                                              int32_t* __restrict__ parents, int kin, int kout, int V, TrieView tv) {
@@ -1173,7 +1174,7 @@ __global__ __launch_bounds__(256) void project_select_kernel(const float* __rest
   const bool first = prev_tok == nullptr;
   const int n = kin * V;
 #pragma unroll 4
-  for (int c = wave; c < n; c += 4) {                           // logits (unrolled: the loads of the next outputs overlap the reductions)
+  for (int c = wave; c < n; c += PS_NW) {                       // logits (unrolled: the loads of the next outputs overlap the reductions)
     const int beam = c / V, v = c - beam * V;
     const float* hr = h + (int64_t)(b * kin + beam) * ldh;
     const float* wr = wo + (int64_t)v * Hd;
@@ -1229,7 +1230,7 @@ __global__ __launch_bounds__(256) void project_select_kernel(const float* __rest
 void project_select(hipStream_t s, const float* h, int64_t ldh, const float* wo, const float* bo, int Hd, const int32_t* prev_tok,
                     float* beam_scores, int32_t* tokens, int32_t* parents, int B, int kin, int kout, int V, const TrieView* tv) {
   size_t sh = (size_t)(kin * V + kout) * sizeof(float);
-  hipLaunchKernelGGL(project_select_kernel, dim3(B), dim3(256), sh, s, h, ldh, wo, bo, Hd, prev_tok, beam_scores, tokens, parents, kin, kout, V,
+  hipLaunchKernelGGL(project_select_kernel, dim3(B), dim3(64 * PS_NW), sh, s, h, ldh, wo, bo, Hd, prev_tok, beam_scores, tokens, parents, kin, kout, V,
                      tv ? *tv : TrieView{});
 }
 void beam_select(hipStream_t s, const float* logp, const int32_t* prev_tok, float* beam_scores, int32_t* tokens, int32_t* parents,
