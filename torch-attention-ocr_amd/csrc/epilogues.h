@@ -134,6 +134,8 @@ struct EpGatesFwd {
   int M, H;
   bf16_t* hb = nullptr; int64_t ldhb = 0;   // optional bf16 shadows of h_out / h_out2 (operands of the next contractions)
   bf16_t* hb2 = nullptr; int64_t ldhb2 = 0;
+  const int32_t* zx_tok = nullptr; int64_t zx_tok_stride = 1;   // optional: zx is a per-token table, row r reads table row zx_tok[r*stride]-1
+  __device__ __forceinline__ int64_t zrow(int row) const { return zx_tok ? (int64_t)(zx_tok[(int64_t)row * zx_tok_stride] - 1) : (int64_t)row; }
   template <int NT> __device__ __forceinline__ void quad(int m, int j, int, const float (&v)[NT][4]) const {
     static_assert(NT == 4, "gate epilogue needs the 4 gate tiles");
     if (j >= H) return;
@@ -150,7 +152,7 @@ struct EpGatesFwd {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         z[g] = v[g][i] + bb[g];
-        if (zx) z[g] += zx[(int64_t)row * ldzx + g * H + j];
+        if (zx) z[g] += zx[zrow(row) * ldzx + g * H + j];
       }
       float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), og = sigmoidf_(z[2]), gg = tanhf_(z[3]);
       float c = fg * c_prev[(int64_t)row * ldcp + j] + ig * gg;
@@ -175,7 +177,7 @@ struct EpGatesFwd {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       if (b1) p.zin[g] = b1[g * H + j] + b2[g * H + j];
-      if (zx) p.zin[g] += zx[(int64_t)row * ldzx + g * H + j];
+      if (zx) p.zin[g] += zx[zrow(row) * ldzx + g * H + j];
     }
     p.cp = c_prev[(int64_t)row * ldcp + j];
     return p;

@@ -461,6 +461,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
 struct DecStepIO {
   int R, ctx_div;
   const float* zx1; const float* feed;
+  const int32_t* zx_tok = nullptr; int64_t zx_tok_stride = 1;   // zx1 is a per-token table (decode): row r uses table row zx_tok[r*stride]-1
   const float* c_prev[MAXL]; const float* h_prev[MAXL];
   float* c_new[MAXL]; float* h_new[MAXL]; float* gates[MAXL];
   float *q, *a, *cat, *out;
@@ -482,7 +483,7 @@ static void dec_step_forward(aocr_model* m, const DecStepIO& io, int T) {
         la = make_loadk2(io.feed, Hd, Hd, io.h_prev[0], Hd, Hd, R); w0 = &p.swi; w1 = &p.swh;
         lah = make_loadkh2(sh ? io.feed_b : nullptr, Hd, Hd, io.hb_prev[0], Hd, Hd, R);
       } else { la = make_loadk(io.h_prev[0], Hd, R, Hd); w0 = &p.swh; lah = make_loadkh(sh ? io.hb_prev[0] : nullptr, Hd, R, Hd); }
-      e.zx = io.zx1; e.ldzx = 4 * Hd; e.b1 = nullptr; e.b2 = nullptr;
+      e.zx = io.zx1; e.ldzx = 4 * Hd; e.b1 = nullptr; e.b2 = nullptr; e.zx_tok = io.zx_tok; e.zx_tok_stride = io.zx_tok_stride;
     } else {
       la = make_loadk2(io.h_new[l - 1], Hd, Hd, io.h_prev[l], Hd, Hd, R); w0 = &p.swi; w1 = &p.swh;
       lah = make_loadkh2(sh ? io.hb_new[l - 1] : nullptr, Hd, Hd, io.hb_prev[l], Hd, Hd, R);
@@ -708,10 +709,10 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
     const int kin = t == 0 ? 1 : k, R = B * kin;
     // current input tokens (t = 0: the GO column of the targets, model.lua:388; later: the tokens chosen one step ago)
     const int32_t* tok = t == 0 ? tgt : m->hist_tok + (size_t)(t - 1) * B * k;
-    token_rows(s, m->bzx_tab, tok, t == 0 ? Lt : 1, m->bzx1, R, 4 * Hd);
     const int nxt = cur ^ 1;
     const bool direct = k == 1;                         // greedy: the parent of every row is itself, no state gather needed
-    DecStepIO io; io.R = R; io.ctx_div = kin; io.zx1 = m->bzx1; io.feed = m->bfeed[cur];
+    DecStepIO io; io.R = R; io.ctx_div = kin; io.feed = m->bfeed[cur];
+    io.zx1 = m->bzx_tab; io.zx_tok = tok; io.zx_tok_stride = t == 0 ? Lt : 1;     // the gate epilogue gathers the token's table row
     for (int l = 0; l < Ld; ++l) {
       io.c_prev[l] = m->bc[cur][l]; io.h_prev[l] = m->bh[cur][l];
       io.c_new[l] = direct ? m->bc[nxt][l] : m->bc_new[l]; io.h_new[l] = direct ? m->bh[nxt][l] : m->bh_new[l];
