@@ -329,6 +329,7 @@ void encoder_forward(aocr_model* m, const Dims& d) {
   const int B = d.B, T = d.T, He = m->He, Hd = m->Hd;
   const size_t slot = (size_t)B * He;
   for (int l = 0; l < m->Le; ++l) {
+    ZeroList zl;
     for (int dir = 0; dir < 2; ++dir) {
       const LstmP& p = m->enc[dir][l];
       const float* xin = l == 0 ? m->X : m->ehs[dir][l - 1] + slot;        // Dropout(0) = identity (S6)
@@ -337,15 +338,14 @@ void encoder_forward(aocr_model* m, const Dims& d) {
         gemm_hh(s, xinb, p.in, p.swi.wb, p.in, m->ezx[dir][l], 4 * He, T * B, 4 * He, p.in, p.bi, p.bh, 0);
       else
         gemm(s, bf, xin, p.in, true, p.wi, p.in, true, m->ezx[dir][l], 4 * He, T * B, 4 * He, p.in, p.bi, p.bh, 0);
-      hipMemsetAsync(m->ehs[dir][l], 0, slot * sizeof(float), s);
-      hipMemsetAsync(m->ehs[dir][l] + (size_t)(T + 1) * slot, 0, slot * sizeof(float), s);
-      hipMemsetAsync(m->ecs[dir][l], 0, slot * sizeof(float), s);
-      hipMemsetAsync(m->ecs[dir][l] + (size_t)(T + 1) * slot, 0, slot * sizeof(float), s);
+      // zero initial states of both directions (slot 0 / slot T+1): one launch for the layer instead of 6 memsets per direction
+      zl.add(m->ehs[dir][l], slot * sizeof(float)); zl.add(m->ehs[dir][l] + (size_t)(T + 1) * slot, slot * sizeof(float));
+      zl.add(m->ecs[dir][l], slot * sizeof(float)); zl.add(m->ecs[dir][l] + (size_t)(T + 1) * slot, slot * sizeof(float));
       if (m->ehs_b[dir][l]) {
-        hipMemsetAsync(m->ehs_b[dir][l], 0, slot * sizeof(bf16_t), s);
-        hipMemsetAsync(m->ehs_b[dir][l] + (size_t)(T + 1) * slot, 0, slot * sizeof(bf16_t), s);
+        zl.add(m->ehs_b[dir][l], slot * sizeof(bf16_t)); zl.add(m->ehs_b[dir][l] + (size_t)(T + 1) * slot, slot * sizeof(bf16_t));
       }
     }
+    zero_many(s, zl);
     const bool top = l == m->Le - 1;
     if (getenv("AOCR_TRACE")) fprintf(stderr, "[aocr] encoder layer %d forward: %s kernels\n", l, seq_kernels_ok(m, B) ? "whole-sequence" : "per-step");
     if (seq_kernels_ok(m, B)) {                         // whole-sequence kernel: one launch for all T steps of both directions
