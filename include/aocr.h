@@ -91,6 +91,17 @@ int aocr_train_forward_backward(aocr_model* m, const float* images_dev, const in
                                 const int32_t* targets_eval_dev, int32_t B, int32_t W, int32_t L,
                                 float grad_scale, float* loss_dev);
 
+/* Data-parallel overlap: the flat gradient vector completes back to front
+ * during the backward pass -- bucket 0 = decoder + projector groups, 1 = both encoder groups,
+ * 2 = the CNN from conv5 upwards, 3 = conv1..conv4 -- and an event marks each point.
+ * aocr_grad_buckets gives the [begin, end) float ranges of the buckets inside grads_dev;
+ * aocr_stream_wait_grads makes `stream` wait until bucket `bucket` of the LAST enqueued
+ * aocr_train_forward_backward is complete, so that its all-reduce can run on a second stream
+ * beside the rest of the backward pass.  The caller joins that stream before aocr_sgd_step. */
+#define AOCR_GRAD_BUCKETS 4
+int aocr_grad_buckets(const aocr_config* cfg, int64_t begin[AOCR_GRAD_BUCKETS], int64_t end[AOCR_GRAD_BUCKETS]);
+int aocr_stream_wait_grads(aocr_model* m, int32_t bucket, void* stream);
+
 /* optim.sgd_list, src/optim/optim_sgd.lua:38-95 with the options the reference
  * leaves at 0: per group, if ||g||_2 > clip then g *= clip/||g||_2; w -= lr*g.
  * norms_dev (optional, 2*5 floats): {param norm, grad norm} per group, as printed

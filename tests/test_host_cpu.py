@@ -65,7 +65,14 @@ def _dp_worker(rank, world, port, q):
                           for k in Pg])
         return flat, nll_sum.detach().reshape(1)
     g, loss = grads(img[sl], t[sl], te[sl], adist.grad_scale(2))         # 1/(local * world) = 1/global
+    g2, loss2 = g.clone(), loss.clone()
     adist.exchange(g, loss)                                              # the one collective of the hot path
+    # the bucketed form used on the GPU (buckets back to front, in the order the backward pass completes them)
+    n = g2.numel(); cut = [0, n // 7, n // 3, (3 * n) // 4, n]
+    ranges = [(cut[3], cut[4]), (cut[2], cut[3]), (cut[1], cut[2]), (cut[0], cut[1])]
+    waited = []
+    adist.exchange_overlapped(g2, loss2, ranges, lambda k, stream: waited.append(k), None)
+    assert waited == [0, 1, 2, 3] and torch.equal(g2, g) and torch.equal(loss2, loss)
     gfull, lfull = grads(img, t, te, 1.0 / 4)
     q.put((rank, float((g - gfull).abs().max()), float((loss - lfull).abs().max()), adist.world_size()))
     dist.destroy_process_group()
@@ -84,3 +91,21 @@ def test_data_parallel_exchange_gloo_world2():
         p.join(60)
     for rank, gerr, lerr, w in res:
         assert w == 2 and gerr < 1e-12 and lerr < 1e-10, (rank, gerr, lerr)
+
+
+def test_gradient_buckets_partition_the_flat_vector():
+    """aocr_grad_buckets (host-only): four disjoint ranges covering the flat vector, listed in the order the backward pass
+    completes them -- decoder + projector, encoders, CNN from conv5 upwards, conv1..conv4."""
+    import aocr
+    from aocr import dist as adist
+    from aocr._lib import Config
+    cfg = Config(batch_size=4, img_h=32, max_img_w=100, enc_hidden=256, enc_layers=1, dec_layers=2, vocab=39, emb=20, input_feed=1,
+                 max_decoder_l=50, max_beam=1, compute=1)
+    table, counts = aocr.param_table(cfg)
+    off = {name: o for name, g, o, shape in table}
+    n = sum(counts)
+    r = adist.bucket_ranges(cfg)
+    assert r[0] == (off["dec.lookup"], n) and r[1] == (off["enc_fw.l1.i2h.w"], off["dec.lookup"])
+    assert r[2] == (off["cnn.conv5.w"], off["enc_fw.l1.i2h.w"]) and r[3] == (0, off["cnn.conv5.w"])
+    covered = sorted(r)
+    assert covered[0][0] == 0 and covered[-1][1] == n and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))

@@ -55,6 +55,8 @@ SIGNATURES = {
     "aocr_model_destroy": (C.c_int, [_vp]),
     "aocr_model_set_stream": (C.c_int, [_vp, _vp]),
     "aocr_train_forward_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "aocr_grad_buckets": (C.c_int, [_cfgp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "aocr_stream_wait_grads": (C.c_int, [_vp, _i32, _vp]),
     "aocr_sgd_step": (C.c_int, [_vp, _f32, _f32, _vp]),
     "aocr_adadelta_step": (C.c_int, [_vp, _f32, _f32, _f32, _vp]),
     "aocr_forward_logits": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

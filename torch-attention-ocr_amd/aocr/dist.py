@@ -6,6 +6,11 @@ statistics and the scalar loss, so each rank runs the full step on its slice wit
 gradient vectors with one all-reduce placed between feval and the per-group clip (optim_sgd.lua:38 -> :40), so
 every rank clips and updates identically.  `torch.distributed` backend "nccl" is RCCL over xGMI on ROCm; the
 same code runs on gloo for the CPU tests.  BatchNorm statistics stay per-rank (documented deviation).
+
+The flat gradient vector completes back to front during the backward pass (decoder + projector, encoders, CNN from conv7
+down); `exchange_overlapped` sums it in the four buckets the library marks with events (`aocr_grad_buckets`,
+`aocr_stream_wait_grads`) on a second stream, so that on xGMI -- point-to-point links, a ring all-reduce of 48.7 MB costs
+about a millisecond at 8 GPUs -- only the last 3.8 MB bucket (conv1..conv4) is exposed after the backward pass.
 """
 from __future__ import annotations
 
@@ -27,3 +32,35 @@ def exchange(flat_grads: torch.Tensor, loss: torch.Tensor) -> None:
     if world_size() > 1:
         torch.distributed.all_reduce(flat_grads)
         torch.distributed.all_reduce(loss)
+
+
+def bucket_ranges(cfg):
+    """[(begin, end)] float ranges of the gradient buckets in completion order (`aocr_grad_buckets`)."""
+    import ctypes as C
+    from ._lib import check, lib
+    b, e = (C.c_int64 * 4)(), (C.c_int64 * 4)()
+    check(lib.aocr_grad_buckets(C.byref(cfg), b, e), "aocr_grad_buckets")
+    return [(int(b[i]), int(e[i])) for i in range(4)]
+
+
+def exchange_overlapped(flat_grads: torch.Tensor, loss: torch.Tensor, ranges, wait_bucket, comm_stream=None) -> None:
+    """Bucketed form of `exchange`: for each bucket k (in completion order) `wait_bucket(k, stream)` makes the communication
+    stream wait for the bucket's gradient-ready event, then the bucket is summed over ranks; the caller's stream joins the
+    communication stream at the end.  On CPU tensors (gloo tests) `comm_stream` is None and the buckets are summed in order."""
+    if world_size() <= 1:
+        return
+    d = torch.distributed
+    if comm_stream is None:
+        for k, (b, e) in enumerate(ranges):
+            wait_bucket(k, None)
+            d.all_reduce(flat_grads[b:e])
+        d.all_reduce(loss)
+        return
+    main = torch.cuda.current_stream(flat_grads.device)
+    with torch.cuda.stream(comm_stream):
+        for k, (b, e) in enumerate(ranges):
+            wait_bucket(k, comm_stream)
+            d.all_reduce(flat_grads[b:e])            # enqueued behind the event; returns without a host sync
+            if k == 0:
+                d.all_reduce(loss)                   # the loss is final before the backward pass starts
+    main.wait_stream(comm_stream)                    # the clip + update need every bucket

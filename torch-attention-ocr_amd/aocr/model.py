@@ -69,6 +69,8 @@ class Model:
         self.global_step = 0
         self.optim_state = {}
         self.last_norms = None
+        self._comm_stream = None
+        self._buckets = None
 
     # ------------------------------------------------------------------ construction
     def _set_structure(self, config):
@@ -298,12 +300,20 @@ class Model:
         # d(loss) / (global batch): model.lua:645-647 divides by the step's batch size
         check(lib.aocr_train_forward_backward(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, target_l,
                                               dist.grad_scale(B), ptr(loss_dev)), "aocr_train_forward_backward")
-        # the one exchange step of data parallelism (RCCL over xGMI), between feval and the per-group clip
-        dist.exchange(self.grad_params, loss_dev)
+        # the one exchange step of data parallelism (RCCL over xGMI), between feval and the per-group clip; bucketed in the order
+        # the backward pass completes the gradient vector and run on a second stream beside it
+        if dist.world_size() > 1:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=self.device)
+                self._buckets = dist.bucket_ranges(self.ccfg)
+            dist.exchange_overlapped(self.grad_params, loss_dev, self._buckets, self._wait_bucket, self._comm_stream)
         norms = self._scal[2:12]
         check(lib.aocr_sgd_step(self._h, float(self.optim_state["learningRate"]), 5.0, ptr(norms)), "aocr_sgd_step")
         self.last_norms = norms
         return loss_dev
+
+    def _wait_bucket(self, k, stream):
+        check(lib.aocr_stream_wait_grads(self._h, k, C.c_void_p(stream.cuda_stream)), "aocr_stream_wait_grads")
 
     def decode_device(self, images, targets, targets_eval, beam_size=1, trie=None):
         """forward_only feval on device-resident inputs; enqueues only.  Returns device tensors

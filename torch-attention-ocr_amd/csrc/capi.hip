@@ -132,10 +132,15 @@ int aocr_model_create(const aocr_config* cfg, float* params_dev, float* grads_de
   m->layout = build_layout(*cfg);
   if (model_carve(m, workspace_dev, workspace_bytes) != 0) { delete m; return fail("workspace too small: need %zu bytes", aocr_workspace_bytes(cfg)); }
   bind_params(m);
+  for (int i = 0; i < 4; ++i)
+    if (hipEventCreateWithFlags(&m->grad_ev[i], hipEventDisableTiming) != hipSuccess) { aocr_model_destroy(m); return fail("hipEventCreate failed"); }
   *out = m;
   return 0;
 }
-int aocr_model_destroy(aocr_model* m) { delete m; return 0; }
+int aocr_model_destroy(aocr_model* m) {
+  if (m) for (int i = 0; i < 4; ++i) if (m->grad_ev[i]) hipEventDestroy(m->grad_ev[i]);
+  delete m; return 0;
+}
 int aocr_model_set_stream(aocr_model* m, void* stream) { REQUIRE(m, "NULL model"); m->s = (hipStream_t)stream; return 0; }
 
 static int step_dims(aocr_model* m, int32_t B, int32_t W, int32_t L, Dims& d) {
@@ -159,6 +164,29 @@ int aocr_train_forward_backward(aocr_model* m, const float* images_dev, const in
   backward_all(m, images_dev, targets_dev, d);
   m->last = d; m->last_valid = 1;
   return check_launch("aocr_train_forward_backward");
+}
+
+static int64_t conv5_offset(const Layout& l) {
+  for (const ParamEntry& e : l.e) if (e.name == "cnn.conv5.w") return e.offset;
+  return 0;
+}
+int aocr_grad_buckets(const aocr_config* cfg, int64_t begin[AOCR_GRAD_BUCKETS], int64_t end[AOCR_GRAD_BUCKETS]) {
+  if (check_cfg(cfg)) return 1;
+  REQUIRE(begin && end, "NULL argument");
+  const Layout l = build_layout(*cfg);
+  const int64_t c5 = conv5_offset(l);
+  begin[0] = l.group_off[3]; end[0] = l.group_off[AOCR_NUM_GROUPS];       // decoder + projector
+  begin[1] = l.group_off[1]; end[1] = l.group_off[3];                     // both encoder directions
+  begin[2] = c5;             end[2] = l.group_off[1];                     // CNN from conv5 upwards
+  begin[3] = 0;              end[3] = c5;                                 // conv1 .. conv4 (+ bn3)
+  return 0;
+}
+int aocr_stream_wait_grads(aocr_model* m, int32_t bucket, void* stream) {
+  REQUIRE(m, "NULL model");
+  REQUIRE(bucket >= 0 && bucket < AOCR_GRAD_BUCKETS, "bucket %d outside 0..%d", bucket, AOCR_GRAD_BUCKETS - 1);
+  REQUIRE(m->last_valid, "no train step has been enqueued yet");
+  if (hipStreamWaitEvent((hipStream_t)stream, m->grad_ev[bucket], 0) != hipSuccess) return fail("hipStreamWaitEvent failed");
+  return 0;
 }
 
 int aocr_sgd_step(aocr_model* m, float lr, float clip, float* norms_dev) {

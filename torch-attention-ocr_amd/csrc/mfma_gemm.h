@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_step_kernel(SmallArgs2<AL, LoadK
 
   // the epilogue's own operands (zx, c_prev, gates, ...) are requested now so that they arrive during the K loop
   // accumulator index i = E*wave + e of a 32x32 tile sits in row 8*(i/4) + 4h + i%4
-  const int orow = NW == 4 ? m0 + 8 * wave + 4 * h : m0 + 8 * (wave >> 1) + 4 * h + 2 * (wave & 1);
+  const int orow = m0 + 8 * ((E * wave) >> 2) + 4 * h + ((E * wave) & 3);
   typename EP::Pre pre[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) pre[e] = g.ep.prefetch(orow + e, GATES == 2 ? n0 + (r & 15) : n0 + r);
@@ -1492,8 +1492,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_step_kernel(SmallArgs2<AL, LoadK
     for (int ni = 0; ni < NT; ++ni) {
       const int idx = (ni * 16 + E * wave + e) * 64 + lane;
       v[ni] = (r0[idx] + r0[idx + WSTRIDE]) + (r0[idx + 2 * WSTRIDE] + r0[idx + 3 * WSTRIDE]);
-      if constexpr (NW == 8)
-        v[ni] += (r0[idx + 4 * WSTRIDE] + r0[idx + 5 * WSTRIDE]) + (r0[idx + 6 * WSTRIDE] + r0[idx + 7 * WSTRIDE]);
+#pragma unroll
+      for (int q = 4; q < NW; q += 4)
+        v[ni] += (r0[idx + q * WSTRIDE] + r0[idx + (q + 1) * WSTRIDE]) + (r0[idx + (q + 2) * WSTRIDE] + r0[idx + (q + 3) * WSTRIDE]);
     }
     if constexpr (GATES == 2) {                                 // lane l < 16 of each 32-lane half: [i, o] here, [f, g] in lane l + 16
       float v4[4] = {v[0], __shfl_xor(v[0], 16, 64), v[1], __shfl_xor(v[1], 16, 64)};

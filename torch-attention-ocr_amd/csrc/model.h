@@ -80,6 +80,8 @@ struct aocr_model {
   int32_t *hist_tok, *hist_par, *tgt_pad, *tge_pad, *trie_loc[2];   // trie_loc: dictionary node of every beam (ping-pong)
   void* sgd_scratch;
 
+  hipEvent_t grad_ev[4];          // gradient-ready points of the backward pass (aocr_grad_buckets)
+  int64_t conv5_off;              // offset of cnn.conv5.w in the flat vectors: the CNN group is split there
   aocr::Dims last;                // dims of the last step (for the parity taps)
   int last_valid;
 };

@@ -295,6 +295,7 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, bf ? nullptr : G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
                    (int64_t)B * d.H4 * d.W2, 512, 0, G0b, bf ? m->A5b : nullptr, bf ? m->conv[5].db : nullptr, bf ? G0 : nullptr);
   conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, bf ? nullptr : m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, G0b);
+  hipEventRecord(m->grad_ev[2], s);                             // every CNN gradient from conv5.w upwards is complete
   conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1, G0b, m->wtb[5], m->wtf[5]);
   unpool_relu_backward(s, G1, m->A4, m->idx4, bf ? nullptr : G0, B, d.H2, d.W2, 256, 2, G0b, bf ? m->conv[4].db : nullptr, bf ? G0 : nullptr, bf ? m->A4b : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
   conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, bf ? nullptr : m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, G0b);
@@ -683,10 +684,16 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   attention_dctx(s, m->a_all, m->ds_all, m->dcat_all, 2 * Hd, m->q_all, m->dctx, L, B, T, Hd);
 }
 
+// The flat gradient vector completes back to front: decoder + projector groups, then both encoder groups, then the CNN from conv7
+// down.  An event marks each point so that a data-parallel caller can start summing a bucket while the rest of the backward pass
+// still runs (aocr_grad_buckets / aocr_stream_wait_grads).
 void backward_all(aocr_model* m, const float* images, const int32_t* tgt, const Dims& d) {
   decoder_backward(m, d, tgt);
+  hipEventRecord(m->grad_ev[0], m->s);
   encoder_backward(m, d);
+  hipEventRecord(m->grad_ev[1], m->s);
   cnn_backward(m, images, d);
+  hipEventRecord(m->grad_ev[3], m->s);
 }
 
 // ------------------------------------------------------------------------------------------------

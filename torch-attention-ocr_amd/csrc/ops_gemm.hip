@@ -85,6 +85,7 @@ void launch_conv_wgrad(hipStream_t s, bool bf16, const LoadMN& a, const LoadConv
   launch_big(s, bf16, a, b, ep, M, N, K, ksplit);
 }
 
+static bool step_waves16() { static const bool on = getenv("AOCR_STEP_WAVES16") != nullptr; return on; }
 static bool step_waves8() { static const bool on = getenv("AOCR_STEP_WAVES4") == nullptr; return on; }
 template <int NT, bool GATES, class ARGS>
 static void launch_small(hipStream_t s, bool bf16, int nz, const ARGS* z, int M, int ncols, int gate_stride) {
@@ -138,6 +139,12 @@ static void launch_small_bf16(hipStream_t s, int nz, const ARGS* z, int M, int n
         return;
       }
     }
+    if constexpr (NT == 1) {
+      if (step_waves8() && step_waves16() && z[0].K >= 1024) {                    // 147 KB of LDS; 64 k per wave at K = 1024
+        hipLaunchKernelGGL((gemm_step_kernel<NT, GATES ? 1 : 0, decltype(z[0].a), decltype(z[0].ep), 16>), grid, dim3(1024), 0, s, zz, gate_stride);
+        return;
+      }
+    }
     if constexpr (NT <= 2) {
       if (step_waves8()) {
         hipLaunchKernelGGL((gemm_step_kernel<NT, GATES ? 1 : 0, decltype(z[0].a), decltype(z[0].ep), 8>), grid, dim3(512), 0, s, zz, gate_stride);
@@ -162,6 +169,12 @@ static void launch_small_bf16_hh(hipStream_t s, int nz, const ARGS* z, int M, in
         hipLaunchKernelGGL((gemm_step_kernel<2, 2, decltype(z[0].a), decltype(z[0].ep), 8>), dim3(ncols / 16, cdiv(M, 32), nz), dim3(512), 0, s, zz, gate_stride);
       else
         hipLaunchKernelGGL((gemm_step_kernel<2, 2, decltype(z[0].a), decltype(z[0].ep)>), dim3(ncols / 16, cdiv(M, 32), nz), dim3(256), 0, s, zz, gate_stride);
+      return;
+    }
+  }
+  if constexpr (NT == 1) {
+    if (step_waves8() && step_waves16() && z[0].K >= 1024) {
+      hipLaunchKernelGGL((gemm_step_kernel<NT, GATES ? 1 : 0, decltype(z[0].a), decltype(z[0].ep), 16>), grid, dim3(1024), 0, s, zz, gate_stride);
       return;
     }
   }
