@@ -302,7 +302,9 @@ class Model:
                                               dist.grad_scale(B), ptr(loss_dev)), "aocr_train_forward_backward")
         # the one exchange step of data parallelism (RCCL over xGMI), between feval and the per-group clip; bucketed in the order
         # the backward pass completes the gradient vector and run on a second stream beside it
-        if dist.world_size() > 1:
+        if dist.world_size() > 1 and os.environ.get("AOCR_NO_OVERLAP"):
+            dist.exchange(self.grad_params, loss_dev)             # one all-reduce after the backward pass (A/B against the overlap)
+        elif dist.world_size() > 1:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=self.device)
                 self._buckets = dist.bucket_ranges(self.ccfg)
