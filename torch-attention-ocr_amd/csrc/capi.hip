@@ -132,6 +132,11 @@ int aocr_model_create(const aocr_config* cfg, float* params_dev, float* grads_de
   m->layout = build_layout(*cfg);
   if (model_carve(m, workspace_dev, workspace_bytes) != 0) { delete m; return fail("workspace too small: need %zu bytes", aocr_workspace_bytes(cfg)); }
   bind_params(m);
+  build_shadow_jobs(m);
+  if (!m->shadow_host.empty() &&
+      hipMemcpy(m->shadow_dev, m->shadow_host.data(), m->shadow_host.size() * sizeof(ShadowJob), hipMemcpyHostToDevice) != hipSuccess) {
+    delete m; return fail("upload of the shadow job table failed");
+  }
   for (int i = 0; i < 4; ++i)
     if (hipEventCreateWithFlags(&m->grad_ev[i], hipEventDisableTiming) != hipSuccess) { aocr_model_destroy(m); return fail("hipEventCreate failed"); }
   *out = m;

@@ -80,6 +80,8 @@ struct aocr_model {
   int32_t *hist_tok, *hist_par, *tgt_pad, *tge_pad, *trie_loc[2];   // trie_loc: dictionary node of every beam (ping-pong)
   void* sgd_scratch;
 
+  std::vector<aocr::ShadowJob> shadow_host;   // bf16 mode: job table of the one-launch weight shadow refresh
+  aocr::ShadowJob* shadow_dev; int shadow_tiles;
   hipEvent_t grad_ev[4];          // gradient-ready points of the backward pass (aocr_grad_buckets)
   int64_t conv5_off;              // offset of cnn.conv5.w in the flat vectors: the CNN group is split there
   aocr::Dims last;                // dims of the last step (for the parity taps)
@@ -87,6 +89,7 @@ struct aocr_model {
 };
 
 namespace aocr {
+void build_shadow_jobs(aocr_model* m);                              // after bind_params + model_carve
 int model_carve(aocr_model* m, void* base, size_t bytes);          // returns 0 / -1 (too small); base==nullptr: size only
 void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training, int update_running);
 void encoder_forward(aocr_model* m, const Dims& d);

@@ -149,6 +149,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
   m->tgt_pad = a.get<int32_t>(B * L); m->tge_pad = a.get<int32_t>(B * L);
   m->trie_loc[0] = a.get<int32_t>(R); m->trie_loc[1] = a.get<int32_t>(R);
   m->sgd_scratch = a.get<char>(sgd_scratch_bytes());
+  m->shadow_dev = m->bf16 ? a.get<ShadowJob>(128) : nullptr;
   m->ws_bytes = a.off + 256;
   if (base && a.off > bytes) return -1;
   return 0;
@@ -158,6 +159,27 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
 // recurrent-step launch helpers: the B operand is a weight matrix W [R][C]; in bf16 mode its bf16 shadow (W for
 // y = x W^T, the transposed shadow for y = x W) is read, always K-contiguous; in fp32 mode W itself.
 // ------------------------------------------------------------------------------------------------
+// bf16 mode: every shadow piece of the model (recurrent matrices; conv weights tap by tap) as one job table
+void build_shadow_jobs(aocr_model* m) {
+  m->shadow_host.clear(); m->shadow_tiles = 0;
+  if (!m->bf16 || !m->shadow_dev) return;
+  auto add = [&](const float* w, bf16_t* wb, bf16_t* wtb, int64_t ld, int64_t ldb, int64_t ldt, int R, int C) {
+    ShadowJob j{w, wb, wtb, ld, ldb, ldt, R, C, m->shadow_tiles, cdiv(C, 32)};
+    m->shadow_tiles += cdiv(C, 32) * cdiv(R, 32);
+    m->shadow_host.push_back(j);
+  };
+  auto up = [&](const ShW& w) { if (w.wb) add(w.w, w.wb, w.wtb, w.ld, w.C, w.R, w.R, w.C); };
+  for (int dir = 0; dir < 2; ++dir) for (int l = 0; l < m->Le; ++l) { up(m->enc[dir][l].swh); up(m->enc[dir][l].swi); }
+  for (int l = 0; l < m->Ld; ++l) { if (l > 0 || m->cfg.input_feed) up(m->dec[l].swi); up(m->dec[l].swh); }
+  up(m->swa); up(m->swc);
+  for (int i = 2; i <= 7; ++i) {
+    const ConvP& c = m->conv[i]; const int KK = c.ks * c.ks;
+    for (int tap = 0; tap < KK; ++tap)
+      add(c.w + (size_t)tap * c.cin, m->wb[i] + (size_t)tap * c.cin, m->wtb[i] + (size_t)tap * c.cout, (int64_t)KK * c.cin,
+          (int64_t)KK * c.cin, (int64_t)KK * c.cout, c.cout, c.cin);
+  }
+  if (m->shadow_host.size() > 128) { m->shadow_host.clear(); m->shadow_tiles = 0; }      // table too small: per-matrix launches
+}
 static void refresh_rnn_shadows(aocr_model* m) {
   auto up = [&](const ShW& w) {
     if (w.wb) weight_shadows(m->s, w.w, w.ld, w.R, w.C, w.wb, w.wtb);
@@ -257,10 +279,14 @@ static void run_gates_bwd(aocr_model* m, int nz, const LoadK* a, const ShW* cons
 // ------------------------------------------------------------------------------------------------
 void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training, int update_running) {
   hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
-  refresh_rnn_shadows(m);
-  for (int i = 2; i <= 7; ++i) {                                // refresh the re-laid weight copies (weights change every step)
-    if (bf) conv_weight_shadows(s, m->conv[i].w, m->wb[i], m->wtb[i], m->conv[i].cout, m->conv[i].ks * m->conv[i].ks, m->conv[i].cin);
-    else conv_weight_transpose_f32(s, m->conv[i].w, m->wtf[i], m->conv[i].cout, m->conv[i].ks * m->conv[i].ks, m->conv[i].cin);
+  if (bf && !m->shadow_host.empty()) {                          // every bf16 shadow of the step in one launch
+    shadow_jobs(s, m->shadow_dev, (int)m->shadow_host.size(), m->shadow_tiles);
+  } else {
+    refresh_rnn_shadows(m);
+    for (int i = 2; i <= 7; ++i) {                              // refresh the re-laid weight copies (weights change every step)
+      if (bf) conv_weight_shadows(s, m->conv[i].w, m->wb[i], m->wtb[i], m->conv[i].cout, m->conv[i].ks * m->conv[i].ks, m->conv[i].cin);
+      else conv_weight_transpose_f32(s, m->conv[i].w, m->wtf[i], m->conv[i].cout, m->conv[i].ks * m->conv[i].ks, m->conv[i].cin);
+    }
   }
   // bf16 mode: the pooled conv outputs exist only as bf16 shadows (every consumer -- next conv, filter gradient, ReLU mask of the
   // un-pool -- reads the shadow; aocr_get_tensor materialises fp32 on demand)

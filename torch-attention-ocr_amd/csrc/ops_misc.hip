@@ -232,6 +232,31 @@ __global__ __launch_bounds__(256) void weight_shadow_kernel(const float* __restr
     if (r < R && c < C) wtb[(int64_t)c * R + r] = (bf16_t)tile[tx][i];
   }
 }
+// All bf16 weight shadows of a step in ONE launch: a device-resident job table (built once: the pointers never change) lists
+// 2-D pieces w [R][C] (leading dimension ld) -> wb [R][C] (ldb) and its transpose wtb [C][R] (ldt); a conv weight [Cout][tap][Cin]
+// is one piece per tap (wtb is [Cin][tap][Cout]).  16 separate launches cost ~100 us of dispatch latency for ~20 us of traffic.
+__global__ __launch_bounds__(256) void shadow_jobs_kernel(const ShadowJob* __restrict__ jobs, int njobs) {
+  __shared__ float tile[32][33];
+  int j = 0;
+  for (int i = 1; i < njobs; ++i) if ((int)blockIdx.x >= jobs[i].tile0) j = i;      // uniform scan over <= 64 entries
+  const ShadowJob J = jobs[j];
+  const int t = blockIdx.x - J.tile0;
+  const int c0 = (t % J.tx) * 32, r0 = (t / J.tx) * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    const float v = (r < J.R && c < J.C) ? J.w[(int64_t)r * J.ld + c] : 0.f;
+    tile[i][tx] = v;
+    if (r < J.R && c < J.C) J.wb[(int64_t)r * J.ldb + c] = (bf16_t)v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < J.R && c < J.C) J.wtb[(int64_t)c * J.ldt + r] = (bf16_t)tile[tx][i];
+  }
+}
+void shadow_jobs(hipStream_t s, const ShadowJob* jobs_dev, int njobs, int total_tiles) {
+  if (njobs > 0) hipLaunchKernelGGL(shadow_jobs_kernel, dim3(total_tiles), dim3(256), 0, s, jobs_dev, njobs);
+}
 __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ w, int64_t ld, int R, int C, float* __restrict__ wt) {
   __shared__ float tile[32][33];
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
