@@ -9,6 +9,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- BEFORE libaocr.so: the process must end up with ONE HIP runtime, the one PyTorch loads.  Loading
+#                libaocr.so first pulls in /opt/rocm's libamdhip64 next to PyTorch's own copy, and the library then sees no device
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaocr.so")
 

@@ -138,7 +138,10 @@ int aocr_model_create(const aocr_config* cfg, float* params_dev, float* grads_de
     delete m; return fail("upload of the shadow job table failed");
   }
   for (int i = 0; i < 4; ++i)
-    if (hipEventCreateWithFlags(&m->grad_ev[i], hipEventDisableTiming) != hipSuccess) { aocr_model_destroy(m); return fail("hipEventCreate failed"); }
+  {
+    const hipError_t e = hipEventCreateWithFlags(&m->grad_ev[i], hipEventDisableTiming);
+    if (e != hipSuccess) { aocr_model_destroy(m); return fail("hipEventCreateWithFlags failed: %s", hipGetErrorString(e)); }
+  }
   *out = m;
   return 0;
 }
