@@ -95,10 +95,16 @@ def main():
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("AOCR_BENCH_ONE_GPU"):            # debugging aid: all ranks on device 0 (with AOCR_BENCH_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dist = torch.distributed
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("AOCR_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     import aocr
     B, W, L = wl["B"], wl["W"], wl["L"]
     m = aocr.Model().create(dict(encoder_num_hidden=wl["He"], encoder_num_layers=wl["Le"], decoder_num_layers=wl["Ld"],
@@ -131,6 +137,12 @@ def main():
         el = float(t.item())
     loss_val = float(loss.item())
     lines_per_s = world * B * args.steps / el
+    replica_drift = None
+    if world > 1:                                       # every rank must hold the same parameters after the timed steps
+        cs = m.params.double().abs().sum().reshape(1)
+        hi, lo = cs.clone(), cs.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX); dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        replica_drift = float((hi - lo).item())
 
     # decode throughput (greedy, max_decoder_l = 50 steps + gold pass, the reference's -phase test step)
     dec = None; dec_dict = None
@@ -223,7 +235,7 @@ def main():
                        "decoder_steps": L, "parallelism": f"dp{world}", "input_feed": True},
             "train_gflop_per_image": 3 * fpi / 1e9, "step_tflops": 3 * fpi * lines_per_s / 1e12,
             "step_mfma_frac": 3 * fpi * lines_per_s / 1e12 / (peak * world),
-            "decode_chars_per_s": dec, "decode_dict": dec_dict, "loss": loss_val, "secondary": c2, "data_path": dp,
+            "decode_chars_per_s": dec, "decode_dict": dec_dict, "replica_drift": replica_drift, "loss": loss_val, "secondary": c2, "data_path": dp,
             "roofline": {"bound": "mfma", "kernel": "conv6 forward implicit GEMM (512->512 3x3 + ReLU + pool)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                          "ms_per_launch": ms},
