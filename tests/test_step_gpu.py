@@ -380,3 +380,41 @@ def test_overlapped_exchange_waits_for_gradient_buckets(cuda, monkeypatch):
         assert (g - 2 * g0).abs().max().item() <= 1e-4 * g0.abs().max().item()
         assert abs(loss.item() - 2 * l0.item()) <= 1e-5 * abs(l0.item())
     m.shutdown()
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_tall_strips_two_layer_encoder_beam5(cuda, compute):
+    """The structure of BASELINE.json configs[4] at test size: line strips taller than 32 (the CNN leaves Ho7 > 1 rows, View(512,-1)
+    of cnn.lua:44 strings them row-major into the sequence), a 2-layer BiLSTM encoder and beam-width-5 decoding."""
+    import aocr
+    import oracle_torch as O
+    B, H, W = 4, 64, 40                                  # -> 3 x 9 feature positions, T = 27
+    ocfg = O.OcrConfig(enc_hidden=64, enc_layers=2, dec_layers=2, input_feed=True)
+    P, st = O.init_params(ocfg, 11), O.init_bn_state()
+    st = {k: (v + 0.05 if k.endswith("rm") else v * 1.3) for k, v in st.items()}
+    img, tgt, tge, nnz = O.synth_batch(B, W, max_len=5, min_len=2, H=H)
+    m = aocr.Model()
+    m._set_structure(dict(encoder_num_hidden=64, encoder_num_layers=2, decoder_num_layers=2, input_feed=True))
+    m._set_runtime(dict(batch_size=B, img_h=H, max_img_w=W, max_decoder_l=10, max_beam=5, compute=compute))
+    m.optim_state = {"learningRate": 0.1}
+    m._build()
+    m.set_parameters(P, st)
+    batch = [img, tgt, tge, nnz, [f"img{i}" for i in range(B)]]
+    ti, tt, te = (torch.from_numpy(np.asarray(x)) for x in (img, tgt, tge))
+    loss_ref, G, aux, _ = O.train_step_manual(P, st, ocfg, ti, tt, te)
+    loss = m.train_forward_backward(batch)
+    assert aux["context"].shape[1] == 27
+    lg = m.get_tensor("logits")[:, :, :ocfg.vocab]
+    e = (lg.double() - aux["logits"]).abs().max().item()
+    print(f"[parity] tall strips {compute}: T={aux['context'].shape[1]} logits max-abs {e:.3e}; loss {loss:.4f} vs {float(loss_ref) * B:.4f}")
+    assert e < (LOGIT_TOL if compute == "f32" else 5e-2)
+    if compute == "f32":
+        grads = m.get_gradients()
+        for k in ("cnn.conv7.w", "cnn.conv4.w", "enc_fw.l2.i2h.w", "enc_bw.l1.h2h.w", "dec.attn.wa"):
+            r = relerr(grads[k], G[k]); assert r < 2e-3, (k, r)
+        m.set_parameters(P, st)
+        ref = O.decode_beam(P, st, ocfg, ti, tt, te, beam=5, max_decoder_l=10)
+        _, stats = m.step(batch, True, 5)
+        assert np.array_equal(m._dec_out.labels, ref["labels"].numpy().astype(np.int32))
+        assert np.abs(m._dec_out.scores - ref["scores"].numpy()).max() < 2e-3
+    m.shutdown()
