@@ -1261,19 +1261,22 @@ __global__ __launch_bounds__(256, 4) void wgrad_tr_grouped_kernel(GroupArgs<Load
 // ---------------------------------------------------------------------------
 template <class AL, class BL, class EP> struct SmallArgs { AL a; BL b; EP ep; int K; };
 
-template <bool BF16, int NT, bool GATES, int NW, class AL, class BL, class EP>
+// QG (quarter gate tiles, NT = 1): the ONE 32-column tile of a workgroup carries all four gates of 8 hidden units (column j = gate
+// j >> 3 of unit n0 + (j & 7)), so a small batch still spreads over H / 8 workgroups per row block instead of H / 32 (C2, batch 64:
+// 128 instead of 32 workgroups per decoder layer and step); the epilogue gathers a unit's four gate values from lanes j, j+8, j+16, j+24.
+template <bool BF16, int NT, bool GATES, int NW, bool QG, class AL, class BL, class EP>
 __device__ __forceinline__ void gemm_small_body(const SmallArgs<AL, BL, EP>& g, int gate_stride, float* red) {
   constexpr int NV = Mode<BF16>::NV, CH = Mode<BF16>::CHUNK;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.y * 32;
-  const int n0 = GATES ? blockIdx.x * 32 : blockIdx.x * 32 * NT;
+  const int n0 = QG ? blockIdx.x * 8 : (GATES ? blockIdx.x * 32 : blockIdx.x * 32 * NT);
   const int K = g.K;
 
   typename AL::Ctx ca[1]; typename BL::Ctx cb[NT];
   ca[0] = g.a.row(m0 + r);
 #pragma unroll
-  for (int i = 0; i < NT; ++i) cb[i] = g.b.row(GATES ? i * gate_stride + n0 + r : n0 + 32 * i + r);
+  for (int i = 0; i < NT; ++i) cb[i] = g.b.row(QG ? (r >> 3) * gate_stride + n0 + (r & 7) : (GATES ? i * gate_stride + n0 + r : n0 + 32 * i + r));
 
   f32x16 acc[1][NT];
 #pragma unroll
@@ -1333,15 +1336,24 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgs<AL, BL, EP>& g, 
       for (int w = 0; w < NW; ++w) s += red[((w * NT + ni) * 16 + 4 * q + i) * 64 + lane];
       v[ni][i] = s;
     }
-  g.ep.template quad<NT>(m0 + 8 * q + 4 * h, n0 + r, 32, v);
+  if constexpr (QG) {
+    float v4[4][4];
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v4[gt][i] = __shfl(v[0][i], (lane & 32) + 8 * gt + (r & 7), 64);
+    if (r < 8) g.ep.template quad<4>(m0 + 8 * q + 4 * h, n0 + r, 32, v4);
+  } else {
+    g.ep.template quad<NT>(m0 + 8 * q + 4 * h, n0 + r, 32, v);
+  }
 }
 
 template <class AL, class BL, class EP> struct SmallArgs2 { SmallArgs<AL, BL, EP> z[3]; };     // up to three problems per launch (blockIdx.z)
 
-template <bool BF16, int NT, bool GATES, class AL, class BL, class EP, int NW = 4>
+template <bool BF16, int NT, bool GATES, class AL, class BL, class EP, int NW = 4, bool QG = false>
 __global__ __launch_bounds__(64 * NW) void gemm_small_kernel(SmallArgs2<AL, BL, EP> zz, int gate_stride) {
   __shared__ float red[NW * NT * 16 * 64];
-  gemm_small_body<BF16, NT, GATES, NW>(zz.z[blockIdx.z], gate_stride, red);  // kernarg array: one body, scalar-indexed
+  gemm_small_body<BF16, NT, GATES, NW, QG>(zz.z[blockIdx.z], gate_stride, red);  // kernarg array: one body, scalar-indexed
 }
 
 // ---------------------------------------------------------------------------

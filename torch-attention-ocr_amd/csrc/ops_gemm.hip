@@ -85,6 +85,10 @@ void launch_conv_wgrad(hipStream_t s, bool bf16, const LoadMN& a, const LoadConv
   launch_big(s, bf16, a, b, ep, M, N, K, ksplit);
 }
 
+static bool quarter_gate_tiles(int H, int M, int nz) {
+  static const bool off = getenv("AOCR_NO_QUARTER_TILES") != nullptr;
+  return !off && H % 8 == 0 && (H / 32) * cdiv(M, 32) * nz < 128;
+}
 static bool step_waves16() { static const bool on = getenv("AOCR_STEP_WAVES16") != nullptr; return on; }
 static bool step_waves8() { static const bool on = getenv("AOCR_STEP_WAVES4") == nullptr; return on; }
 template <int NT, bool GATES, class ARGS>
@@ -92,13 +96,26 @@ static void launch_small(hipStream_t s, bool bf16, int nz, const ARGS* z, int M,
   if (M <= 0 || ncols <= 0) return;
   dim3 grid(GATES ? cdiv(ncols, 32) : cdiv(ncols, 32 * NT), cdiv(M, 32), nz);
   SmallArgs2<decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)> zz; zz.z[0] = z[0]; zz.z[1] = z[nz > 1 ? 1 : 0]; zz.z[2] = z[nz > 2 ? 2 : 0];
-  if (bf16) hipLaunchKernelGGL((gemm_small_kernel<true, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid,
-                               dim3(256), 0, s, zz, gate_stride);
-  else if (step_waves8())
+  if (bf16) {
+    hipLaunchKernelGGL((gemm_small_kernel<true, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid, dim3(256), 0, s, zz,
+                       gate_stride);
+    return;
+  }
+  if constexpr (GATES && NT == 4) {
+    if (quarter_gate_tiles(ncols, M, nz)) {
+      // small batch: 8 hidden units x 4 gates per workgroup (the A and B tiles are loaded straight from global memory here, so
+      // the narrower tile costs nothing but a shuffle in the epilogue)
+      hipLaunchKernelGGL((gemm_small_kernel<false, 1, true, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep), 8, true>),
+                         dim3(ncols / 8, cdiv(M, 32), nz), dim3(512), 0, s, zz, gate_stride);
+      return;
+    }
+  }
+  if (step_waves8())
     hipLaunchKernelGGL((gemm_small_kernel<false, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep), 8>), grid, dim3(512), 0, s,
                        zz, gate_stride);
-  else      hipLaunchKernelGGL((gemm_small_kernel<false, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid,
-                               dim3(256), 0, s, zz, gate_stride);
+  else
+    hipLaunchKernelGGL((gemm_small_kernel<false, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid, dim3(256), 0, s,
+                       zz, gate_stride);
 }
 void launch_small_gates_fwd(hipStream_t s, bool bf16, int nz, const GatesFwdArgs* z, int M, int H) {
   launch_small<4, true>(s, bf16, nz, z, M, H, H);
