@@ -418,3 +418,37 @@ def test_tall_strips_two_layer_encoder_beam5(cuda, compute):
         assert np.array_equal(m._dec_out.labels, ref["labels"].numpy().astype(np.int32))
         assert np.abs(m._dec_out.scores - ref["scores"].numpy()).max() < 2e-3
     m.shutdown()
+
+
+@pytest.mark.parametrize("compute,B,W", [("bf16", 256, 256), ("f32", 64, 100)])
+def test_full_size_properties(cuda, compute, B, W):
+    """Size-independent properties at BASELINE's full sizes (C3 bf16, C2 fp32), no oracle needed:
+    (1) the backward pass is LINEAR in d(loss): scaling the loss gradient by 4 scales every parameter gradient by 4 (a power of two:
+        exact in floating point up to the order of the split-K atomics);
+    (2) the step is EQUIVARIANT under a permutation of the batch: logits permute with the images, the loss and the parameter
+        gradients do not change (BatchNorm statistics, the loss and every weight gradient are sums over the batch)."""
+    m, O, ocfg, P, st, batch = make(dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True), B=B, W=W, maxlen=23,
+                                    compute=compute, max_decoder_l=24, max_beam=1)
+    img, tgt, tge, nnz, names = batch
+    loss1 = m.train_forward_backward(batch, grad_scale=1.0 / B)
+    g1 = {k: v.clone() for k, v in m.get_gradients().items()}
+    lg1 = m.get_tensor("logits")[:, :, :ocfg.vocab].clone()
+    loss4 = m.train_forward_backward(batch, grad_scale=4.0 / B)
+    g4 = m.get_gradients()
+    assert loss4 == pytest.approx(loss1, rel=1e-6)
+    noisy = ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b")          # bias in front of BatchNorm: the gradient is rounding noise only
+    worst = max(relerr(g4[k], 4 * g1[k]) for k in g1 if k not in noisy)
+    print(f"[property] {compute} B={B}: linearity in d(loss): worst rel {worst:.2e}")
+    assert worst < (2e-3 if compute == "bf16" else 2e-4)
+    perm = np.random.default_rng(0).permutation(B)
+    pbatch = [np.asarray(img)[perm], np.asarray(tgt)[perm], np.asarray(tge)[perm], nnz, [names[i] for i in perm]]
+    lossp = m.train_forward_backward(pbatch, grad_scale=1.0 / B)
+    gp = m.get_gradients()
+    lgp = m.get_tensor("logits")[:, :, :ocfg.vocab]
+    e = (lgp - lg1[:, perm]).abs().max().item()
+    worst = max(relerr(gp[k], g1[k]) for k in g1 if k not in noisy)
+    print(f"[property] {compute} B={B}: batch permutation: logits max-abs {e:.2e}, loss {lossp:.3f} vs {loss1:.3f}, worst gradient rel {worst:.2e}")
+    assert e < (2e-2 if compute == "bf16" else 2e-5)
+    assert lossp == pytest.approx(loss1, rel=(1e-4 if compute == "bf16" else 1e-6))
+    assert worst < (3e-2 if compute == "bf16" else 1e-3)
+    m.shutdown()
