@@ -153,3 +153,32 @@ def test_decode_with_dictionary_small(cuda, case, beam, digit_prefix):
             cut = ids[:ids.index(3) + 1] if 3 in ids else [v for v in ids if v != 1]
             assert trie.walk([v for v in cut if v != 1]) is not None, ids
     m.shutdown()
+
+
+def test_dictionary_decode_full_size_property(cuda):
+    """C3 geometry (batch 256, 32x256, bf16), beam 3, a 20 k-word lexicon: whatever the random weights prefer, every decoded row
+    must spell a path of the trie (PAD keeps the node, model.lua:469,502-503) -- a size-independent property of the constraint."""
+    import aocr
+    from test_step_gpu import make
+    m, O, ocfg, P, st, batch = make(dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True), B=256, W=256, maxlen=23,
+                                    compute="bf16", max_decoder_l=30, max_beam=3)
+    P = dict(P); P["proj.b"] = P["proj.b"].clone(); P["proj.b"][:3] -= 4.0
+    m.set_parameters(P, st)
+    rng = random.Random(1)
+    words = _words(rng, 20000, "abcdefghijklmnopqrstuvwxyz", 3, 9)
+    trie = aocr.build_trie(words).to(cuda)
+    m.step(batch, True, 3, trie)
+    labels = m._dec_out.labels
+    assert labels.shape == (256, 30)
+    distinct = set()
+    for row in labels:
+        ids = [int(v) for v in row if v != 1]                      # PAD never moves the node
+        assert trie.walk(ids) is not None, ids
+        distinct.add(tuple(ids))
+    free_labels = None
+    m.step(batch, True, 3)
+    free_labels = m._dec_out.labels
+    off_path = sum(trie.walk([int(v) for v in row if v != 1]) is None for row in free_labels)
+    print(f"[property] dictionary decode at C3 size: 256/256 rows on a trie path ({len(distinct)} distinct); unconstrained: {256 - off_path}/256")
+    assert off_path > 128                                          # the same weights without the constraint leave the lexicon
+    m.shutdown()
