@@ -186,6 +186,43 @@ def synth_batch(B: int, W: int, seed: int = 1234, min_len: int = 4, max_len: int
 
 
 # ----------------------------------------------------------------------------
+# optional operand rounding: the product's bf16 compute mode rounds BOTH operands of every
+# contraction (conv2..conv7, every Linear, the attention context) to bf16 and accumulates in
+# fp32.  `operand_rounding("bf16")` makes this restatement round the same operands (straight-
+# through in the backward pass: gradients stay float64), so that ReLU masks and pool arg-max
+# routes are those of the rounded forward pass and the bf16 path can be held to a tight bound.
+# Default: identity (the reference's arithmetic, untouched).
+# ----------------------------------------------------------------------------
+class _RoundBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+_ROUND = [None]
+
+
+class operand_rounding:
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _ROUND[0]; _ROUND[0] = self.mode
+        return self
+
+    def __exit__(self, *a):
+        _ROUND[0] = self.prev
+
+
+def _q(x):
+    return _RoundBF16.apply(x) if _ROUND[0] == "bf16" else x
+
+
+# ----------------------------------------------------------------------------
 # forward building blocks
 # ----------------------------------------------------------------------------
 def cnn_forward(P, bn_state, images, training: bool, update_running: bool = True):
@@ -194,7 +231,10 @@ def cnn_forward(P, bn_state, images, training: bool, update_running: bool = True
     for l in CNN_LAYERS:
         if l[0] == "conv":
             _, i, cin, cout, k, pad = l
-            x = F.conv2d(x, P[f"cnn.conv{i}.w"], P[f"cnn.conv{i}.b"], stride=1, padding=pad)
+            if i == 1:                                                   # K = 9: the product computes conv1 in fp32 in both modes
+                x = F.conv2d(x, P[f"cnn.conv{i}.w"], P[f"cnn.conv{i}.b"], stride=1, padding=pad)
+            else:
+                x = F.conv2d(_q(x), _q(P[f"cnn.conv{i}.w"]), P[f"cnn.conv{i}.b"], stride=1, padding=pad)
         elif l[0] == "relu":
             x = F.relu(x)
         elif l[0] == "pool":
@@ -216,7 +256,7 @@ def cnn_forward(P, bn_state, images, training: bool, update_running: bool = True
 def lstm_cell_fwd(x, c_prev, h_prev, Wi, bi, Wh, bh):
     """src/model/LSTM.lua:79-105; gate order [in, forget, out, g]."""
     H = c_prev.shape[1]
-    z = x @ Wi.t() + bi + h_prev @ Wh.t() + bh
+    z = _q(x) @ _q(Wi).t() + bi + _q(h_prev) @ _q(Wh).t() + bh
     i = torch.sigmoid(z[:, 0:H]); f = torch.sigmoid(z[:, H:2 * H])
     o = torch.sigmoid(z[:, 2 * H:3 * H]); g = torch.tanh(z[:, 3 * H:4 * H])
     c = f * c_prev + i * g
@@ -239,12 +279,13 @@ def lstm_cell_bwd(dc_out, dh_out, cache, x, c_prev, h_prev, Wi, Wh):
 
 def attn_fwd(h_top, ctx, Wa, Wc):
     """src/model/LSTM.lua:124-162 (Luong 'general' attention + combine, no bias)."""
-    q = h_top @ Wa.t()                                            # LinearNoBias, LSTM.lua:131
+    q = _q(h_top) @ _q(Wa).t()                                    # LinearNoBias, LSTM.lua:131
+    ctx = _q(ctx)
     s = torch.bmm(ctx, q.unsqueeze(2)).squeeze(2)                 # MM + Sum(3), :135-138
     a = torch.softmax(s, dim=1)                                   # :139-141
     c = torch.bmm(a.unsqueeze(1), ctx).squeeze(1)                 # :145-150
     cat = torch.cat([c, h_top], dim=1)                            # :153
-    out = torch.tanh(cat @ Wc.t())                                # :155
+    out = torch.tanh(_q(cat) @ _q(Wc).t())                        # :155
     return out, (q, a, c, cat)
 
 
@@ -267,7 +308,7 @@ def attn_bwd(dout, out, cache, h_top, ctx, Wa, Wc):
 
 def projector_fwd(x, Wo, bo):
     """output_projector.lua:3-8: Linear + LogSoftMax.  Returns (logits, logp)."""
-    logits = x @ Wo.t() + bo
+    logits = _q(x) @ _q(Wo).t() + bo
     return logits, torch.log_softmax(logits, dim=1)
 
 

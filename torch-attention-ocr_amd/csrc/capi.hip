@@ -279,6 +279,12 @@ int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32
   else if (n == "conv1") { if (m->bf16) bf16_to_f32(m->s, m->A1b, m->A1, (int64_t)d.B * d.H1 * d.W1 * 64); *ptr_dev = m->A1; *ndim = 4; shape[0] = d.B; shape[1] = d.H1; shape[2] = d.W1; shape[3] = 64; }
   else if (n == "conv2") { if (m->bf16) bf16_to_f32(m->s, m->A2b, m->A2, (int64_t)d.B * d.H2 * d.W2 * 128); *ptr_dev = m->A2; *ndim = 4; shape[0] = d.B; shape[1] = d.H2; shape[2] = d.W2; shape[3] = 128; }
   else if (n == "conv6") { if (m->bf16) bf16_to_f32(m->s, m->A6b, m->A6, (int64_t)d.B * d.H6 * d.W2 * 512); *ptr_dev = m->A6; *ndim = 4; shape[0] = d.B; shape[1] = d.H6; shape[2] = d.W2; shape[3] = 512; }
+  else if (n == "g0") {                                   // debugging aid (AOCR_DBG_STOP=1|2): the gradient map the CNN backward pass stopped at
+    const char* e = getenv("AOCR_DBG_STOP"); const int stop = e ? atoi(e) : 0;
+    const int64_t cnt = stop == 1 ? (int64_t)d.B * d.T * 512 : (int64_t)d.B * d.H4 * d.W2 * 512;
+    if (m->bf16) bf16_to_f32(m->s, m->G0b, m->G0, cnt);
+    *ptr_dev = m->G0; *ndim = 4; shape[0] = d.B; shape[1] = stop == 1 ? d.Ho7 : d.H4; shape[2] = stop == 1 ? d.Wo7 : d.W2; shape[3] = 512;
+  }
   else return fail("unknown tensor '%s'", name);
   return 0;
 }

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 namespace aocr {
 
@@ -313,9 +314,13 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   // shadow and accumulates the preceding conv's bias gradient (fp32 G0 is free there: partial slab)
   bn_relu_backward(s, m->Y7, m->X, m->dX, m->bn[7].w, m->bn[7].save, bf ? nullptr : G0, m->bn[7].dw, m->bn[7].db, m->bn_scratch,
                    (int64_t)B * d.T, 512, B, G0b, bf ? m->Xb : nullptr, bf ? m->conv[7].db : nullptr, bf ? G0 : nullptr);
+  const char* dbg_stop = getenv("AOCR_DBG_STOP");          // debugging aid: leave the gradient map of a stage in place (tap "g0")
+  const int stop = dbg_stop ? atoi(dbg_stop) : 0;
+  if (stop == 1) return;
   conv_backward_filter(s, bf, m->A6, G0, m->conv[7].dw, bf ? nullptr : m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0, m->A6b, G0b);
   conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0, G0b, m->wtb[7], m->wtf[7]);
   unpool_relu_backward(s, G1, m->A6, m->idx6, bf ? nullptr : G0, B, d.H4, d.W2, 512, 2, G0b, bf ? m->conv[6].db : nullptr, bf ? G0 : nullptr, bf ? m->A6b : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
+  if (stop == 2) return;
   conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, bf ? nullptr : m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, G0b);
   conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, G0b, m->wtb[6], m->wtf[6]);
   bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, bf ? nullptr : G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
