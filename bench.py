@@ -1,101 +1,139 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the CNN -> BiLSTM -> attention-decoder hot path on MI355X.
 
-`python bench.py --gpus N --steps K --warmup W`  (N>1: launched by torch.distributed.run, one rank per GPU).
+`python bench.py --gpus N --steps K --warmup W`  (N>1: launched by torch.distributed.run, one rank per GPU; a bare
+`python bench.py --gpus N` starts that launcher itself as a child process, before anything touches a GPU).
 A "step" = one full train step of the reference's feval + optim.sgd_list (forward, hand-ordered BPTT, clip, SGD
 [+ RCCL gradient all-reduce]) on one synthetic batch already resident in HBM.  Rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json configs): c3 (default) = 32x256 crops, batch 256 per GPU, He=256, Ld=2, input feed, L=24,
-bf16 operands / fp32 accumulate; c2 = 32x100, batch 64, fp32 MFMA.
+bf16 operands / fp32 accumulate; c2 = 32x100, batch 64, fp32 MFMA; ref = the reference's own default shape
+(src/train.lua:41,47: batch 400, He=512) in bf16.
+--scaling weak (default): the per-GPU batch is fixed; strong: the GLOBAL batch is the workload's batch, split over the ranks.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "torch-attention-ocr_amd"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 WORKLOADS = {
     "c3": dict(B=256, W=256, L=24, He=256, Le=1, Ld=2, compute="bf16", name="32x256 crops, batch 256/GPU, VGG-7 + BiLSTM(256) + 2-layer attn decoder, L=24"),
     "c2": dict(B=64, W=100, L=24, He=256, Le=1, Ld=2, compute="f32", name="32x100 crops, batch 64/GPU, VGG-7 + BiLSTM(256) + 2-layer attn decoder, L=24"),
+    "ref": dict(B=400, W=100, L=24, He=512, Le=1, Ld=2, compute="bf16", name="32x100 crops, batch 400/GPU, VGG-7 + BiLSTM(512) + 2-layer attn decoder (train.lua defaults), L=24"),
 }
+PEAK = {"bf16": 2500.0, "f32": 157.3}          # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0
 
 
-def flops_per_image(W, He, Le, Ld, L, E=20, V=39):
-    """2*M*N*K per contraction, forward; train = 3x."""
-    Hd = 2 * He
-    T = W // 4 - 1
-    cnn = 2 * (9 * 64 * 32 * W + 9 * 64 * 128 * 8 * W + 9 * 128 * 256 * 2 * W + 9 * 256 * 256 * 2 * W + 9 * 256 * 512 * W
-               + 9 * 512 * 512 * W + 4 * 512 * 512 * T)
-    enc = 2 * T * sum(2 * ((512 if l == 0 else He) + He) * 4 * He for l in range(Le))
-    dec = L * (sum(2 * ((E + Hd if l == 0 else Hd) + Hd) * 4 * Hd for l in range(Ld)) + 6 * Hd * Hd + 4 * T * Hd + 2 * Hd * V)
-    return cnn + enc + dec
+def flops(W, He, Le, Ld, L, E=20, V=39):
+    """Algorithmic forward FLOPs per image-line by family (2*M*N*K per contraction)."""
+    Hd, T = 2 * He, W // 4 - 1
+    conv1 = 2 * 9 * 64 * 32 * W
+    convs = 2 * (9 * 64 * 128 * 8 * W + 9 * 128 * 256 * 2 * W + 9 * 256 * 256 * 2 * W + 9 * 256 * 512 * W + 9 * 512 * 512 * W + 4 * 512 * 512 * T)
+    enc_in = 2 * T * sum(2 * (512 if l == 0 else He) * 4 * He for l in range(Le))        # hoisted input projections
+    enc_rec = 2 * T * Le * 2 * He * 4 * He                                                # recurrent h . W_h2h
+    dec_emb = L * 2 * E * 4 * Hd                                                          # hoisted embedding part of layer 1
+    dec_chain = L * (sum(2 * ((Hd if l == 0 else Hd) + Hd) * 4 * Hd for l in range(Ld)) + 6 * Hd * Hd + 4 * T * Hd)
+    proj = L * 2 * Hd * V
+    return dict(conv1=conv1, convs=convs, enc_in=enc_in, enc_rec=enc_rec, dec_emb=dec_emb, dec_chain=dec_chain, proj=proj,
+                total=conv1 + convs + enc_in + enc_rec + dec_emb + dec_chain + proj)
 
 
-def _cpu_baseline_worker(wl, threads, seconds_budget):
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+# ------------------------------------------------------------------------------------------------ CPU baseline (child process)
+def _cpu_baseline_worker(wl, budget_s):
+    """oracle/cpu_ref: the C++/OpenMP restatement of the reference's CPU op order, fp64 (the reference's CPU tensors)
+    and fp32, on ALL host cores, at the workload's full batch when the host gets through it inside the budget."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "oracle", "cpu_ref"))
+    import numpy as np
+    import cpu_ref as R
     import oracle_torch as O
-    torch.set_num_threads(threads)
+    cores = R.threads()
     cfg = O.OcrConfig(enc_hidden=wl["He"], enc_layers=wl["Le"], dec_layers=wl["Ld"], input_feed=True)
-    P = {k: v.float() for k, v in O.init_params(cfg, 910820).items()}
-    st = {k: v.float() for k, v in O.init_bn_state().items()}
-    Bc = 8
-    img, tgt, tge, _ = O.synth_batch(Bc, wl["W"], max_len=wl["L"] - 1)
-    img = torch.from_numpy(img).float(); tgt = torch.from_numpy(tgt); tge = torch.from_numpy(tge)
-    loss, G, _, _ = O.train_step_manual(P, st, cfg, img, tgt, tge)          # untimed warm-up step (thread pool, allocator)
-    t0 = time.time(); n = 0
-    while True:
-        loss, G, _, _ = O.train_step_manual(P, st, cfg, img, tgt, tge)
-        O.sgd_list(P, G, 0.1)
-        n += 1
-        el = time.time() - t0
-        if el > seconds_budget or n >= 64:               # about 10 s of wall time on 16 threads
-            break
-    print(json.dumps({"value": Bc * n / el, "unit": "image-lines/s", "cores": threads, "kind": "port",
-                      "sample": f"{n} train steps of batch {Bc} at 32x{wl['W']} (torch-CPU fp32 restatement of the reference op order, "
-                                f"{threads} threads of {os.cpu_count()} host cores)"}))
+    names = [s[0] for s in O.param_spec(cfg)]
+    flat = R.flatten({k: v.numpy() for k, v in O.init_params(cfg, 910820).items()}, names)
+    bn = np.concatenate([np.zeros(256), np.ones(256), np.zeros(512), np.ones(512), np.zeros(512), np.ones(512)])
+    rc = R.make_cfg(wl["He"], wl["Le"], wl["Ld"], True)
+
+    def run(B, dtype):
+        img, tgt, tge, _ = O.synth_batch(B, wl["W"], max_len=wl["L"] - 1)
+        t0 = time.time()
+        r = R.train_step(rc, flat, bn, img, tgt, tge, dtype=dtype)
+        R.sgd(rc, flat, r["grads"], 0.1, 5.0, dtype=dtype)
+        return time.time() - t0
+    Bc = min(wl["B"], max(8, cores // 4))
+    run(Bc, np.float32)                                      # warm-up (thread pool, page faults)
+    t_cal = run(Bc, np.float32)                              # calibration: lines/s at a small batch
+    est_full = t_cal / Bc * wl["B"] * 1.6                    # fp32 + fp64 pass at the full batch, fp64 ~ 1.6 x
+    B = wl["B"] if est_full * 2 < budget_s else max(Bc, int(wl["B"] * budget_s / (est_full * 2)) // 8 * 8)
+    t32 = run(B, np.float32)
+    t64 = run(B, np.float64)
+    # greedy decode of the same lines (50 steps + gold pass), fp64, bounded batch
+    Bd = min(B, 64)
+    img, tgt, tge, _ = O.synth_batch(Bd, wl["W"], max_len=wl["L"] - 1)
+    t0 = time.time(); R.decode(rc, flat, bn, img, tgt, tge, 1, 50); td = time.time() - t0
+    print(json.dumps({"value": B / t64, "unit": "image-lines/s", "cores": cores, "kind": "port",
+                      "impl": "cpp-restatement: oracle/cpu_ref (im2col+GEMM conv, per-timestep LSTM, unfused attention, OpenMP), checked "
+                              "against tests/golden in the CPU suite",
+                      "dtype": "f64", "batch": B, "value_f32": B / t32, "decode_chars_per_s_f64": Bd * 50 / td,
+                      "sample": f"1 train step (forward + BPTT + clip + SGD) of batch {B} at 32x{wl['W']} in fp64 ({t64:.1f} s) and one in fp32 "
+                                f"({t32:.1f} s), after a warm-up step of batch {Bc}; greedy decode of {Bd} lines ({td:.1f} s); "
+                                f"{cores} OpenMP threads = all {os.cpu_count()} host cores"}))
 
 
-def cpu_baseline(wl, seconds_budget=10.0):
-    """The oracle (torch CPU restatement, fp32) timed on a bounded sample of the same workload, in a child process
-    with a hard timeout so the default run always ends within minutes.  16 threads: the per-timestep LSTM ops are
-    tiny and slow down badly when a 256-core host is oversubscribed."""
-    import subprocess
-    threads = min(16, os.cpu_count() or 1)
+def cpu_baseline(wl, budget_s=40.0):
     code = ("import json,sys; sys.argv=['bench.py']; import importlib.util as u; s=u.spec_from_file_location('bench', %r); "
-            "b=u.module_from_spec(s); s.loader.exec_module(b); b._cpu_baseline_worker(json.loads(%r), %d, %f)"
-            % (os.path.join(ROOT, "bench.py"), json.dumps(wl), threads, seconds_budget))
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+            "b=u.module_from_spec(s); s.loader.exec_module(b); b._cpu_baseline_worker(json.loads(%r), %f)"
+            % (os.path.join(ROOT, "bench.py"), json.dumps(wl), budget_s))
+    n = os.cpu_count() or 1
+    env = dict(os.environ, OMP_NUM_THREADS=str(n), OMP_PROC_BIND="false", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
-        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180, env=env)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:                                   # timeout or failure: report it, never stall the benchmark
-        return {"value": None, "unit": "image-lines/s", "cores": threads, "kind": "port", "sample": f"not measured: {type(e).__name__}"}
+        return {"value": None, "unit": "image-lines/s", "cores": n, "kind": "port", "sample": f"not measured: {type(e).__name__}"}
 
 
-def main():
+# ------------------------------------------------------------------------------------------------ main
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--compute", default=None, choices=["f32", "bf16"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-steps", type=int, default=3)
-    ap.add_argument("--no-secondary", action="store_true", help="skip the C2 fp32 secondary measurement")
-    args = ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C2 fp32 and data-path secondary measurements")
+    ap.add_argument("--sustain-seconds", type=float, default=1.5, help="keep stepping after the timed steps until this much GPU time has passed")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # not under a launcher: start one as a CHILD (never exec from a process that may touch the GPU) and relay its output
+        port = 29500 + os.getpid() % 2000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-GPU run as {args.gpus} GPUs")
+
+    import numpy as np
+    import torch
     wl = dict(WORKLOADS[args.workload])
     if args.compute:
         wl["compute"] = args.compute
-
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("AOCR_BENCH_ONE_GPU"):            # debugging aid: all ranks on device 0 (with AOCR_BENCH_BACKEND=gloo)
         local = 0
     torch.cuda.set_device(local)
@@ -107,12 +145,17 @@ def main():
         else:
             dist.init_process_group(backend)
     import aocr
-    B, W, L = wl["B"], wl["W"], wl["L"]
+    global_B = wl["B"] * world if args.scaling == "weak" else wl["B"]
+    assert global_B % world == 0, "strong scaling needs the global batch to divide by the rank count"
+    B, W, L = global_B // world, wl["W"], wl["L"]
     m = aocr.Model().create(dict(encoder_num_hidden=wl["He"], encoder_num_layers=wl["Le"], decoder_num_layers=wl["Ld"],
                                  input_feed=True, batch_size=B, max_img_w=W, max_decoder_l=50, max_beam=1,
                                  compute=wl["compute"], learning_rate=0.1, seed=910820))
+    rccl_ranks = None
     if world > 1:
-        dist.broadcast(m.params, 0)                     # identical replicas
+        dist.broadcast(m.params, 0); dist.broadcast(m.bn_state, 0)       # identical replicas (parameters and running statistics)
+        probe = torch.ones(1, device=m.device); dist.all_reduce(probe)   # an actual collective: how many ranks does it span?
+        rccl_ranks = int(probe.item())
     img, tgt, tge, nnz = aocr.synth.synth_batch(B, W, seed=1234 + rank, max_len=L - 1)
     dev = m.device
     images = torch.from_numpy(img).to(device=dev, dtype=torch.float32)
@@ -124,20 +167,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step():
+        return m.train_step_device(images, targets, targets_eval)
+
     for _ in range(args.warmup):
-        m.train_step_device(images, targets, targets_eval)
+        step()
     sync()
+    # ---- the timed region: EXACTLY --steps steps between two barriers + device syncs; per-step HIP events ride along on the same stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = m.train_step_device(images, targets, targets_eval)
+    ev[0].record()
+    for i in range(args.steps):
+        loss = step()
+        ev[i + 1].record()
     sync()
     el = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    per_step = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)])
     loss_val = float(loss.item())
-    lines_per_s = world * B * args.steps / el
+    lines_per_s = global_B * args.steps / el
+    # ---- steady state: keep the GPU busy long enough for an external sampler, report it separately (never `value`)
+    sustained = None
+    if args.sustain_seconds > 0:
+        n = max(args.steps, int(args.sustain_seconds / max(el / args.steps, 1e-4)) + 1)
+        sync(); t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        sync()
+        es = time.perf_counter() - t0
+        sustained = {"steps": n, "seconds": es, "ms_per_step": 1e3 * es / n, "image_lines_per_s": global_B * n / es}
     replica_drift = None
     if world > 1:                                       # every rank must hold the same parameters after the timed steps
         cs = m.params.double().abs().sum().reshape(1)
@@ -145,7 +206,30 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX); dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         replica_drift = float((hi - lo).item())
 
-    # decode throughput (greedy, max_decoder_l = 50 steps + gold pass, the reference's -phase test step)
+    fl = flops(W, wl["He"], wl["Le"], wl["Ld"], L)
+    peak = PEAK[wl["compute"]]
+    # ---- per-family HIP-event timing of one step (library marks, include/aocr.h AOCR_PROF_*), rank 0
+    families = None
+    if rank == 0:
+        fam = m.profile_families(step, repeats=3)
+        # algorithmic FLOPs per image of each family: the three conv passes; both recurrences of the encoder (h W_h2h forward, dz W_h2h
+        # backward); the hoisted GEMMs = input projections / embedding part / projector (forward, d(input), d(weight)) plus the weight
+        # gradients of every matrix the two step chains use; the decoder chains themselves (forward = backward in FLOPs)
+        alg = {"conv_fwd": fl["convs"], "conv_dgrad": fl["convs"], "conv_wgrad": fl["convs"], "encoder_seq": 2 * fl["enc_rec"],
+               "rnn_gemm": 3 * (fl["enc_in"] + fl["dec_emb"] + fl["proj"]) + fl["enc_rec"] + fl["dec_chain"],
+               "decoder_fwd": fl["dec_chain"], "decoder_bwd": fl["dec_chain"]}
+        families = {}
+        for k, ms in fam.items():
+            if ms <= 0:
+                continue
+            e = {"ms_per_step": ms}
+            if k in alg:
+                tf = alg[k] * B / (ms * 1e-3) / 1e12
+                e.update({"algorithmic_gflop": alg[k] * B / 1e9, "tflops": tf, "frac_of_mfma_peak": tf / peak})
+            families[k] = e
+        families["_sum_ms"] = float(sum(fam.values()))
+
+    # ---- decode throughput (greedy, max_decoder_l = 50 steps + gold pass = the reference's -phase test step), no exchange across ranks
     dec = None; dec_dict = None
     if args.decode_steps > 0:
         m.decode_device(images, targets, targets_eval, 1); sync()
@@ -153,26 +237,44 @@ def main():
         for _ in range(args.decode_steps):
             m.decode_device(images, targets, targets_eval, 1)
         sync()
-        eld = time.perf_counter() - t0
-        dec = world * B * 50 * args.decode_steps / eld
-        # the same step under -use_dictionary: a synthetic 90 k-word lexicon as a device-resident flat trie,
-        # admissibility tested inside the selection kernel (the reference walks Lua tables per image, beam and candidate)
-        rng = np.random.default_rng(1234)
-        lens = rng.integers(3, 11, size=90000)
-        letters = rng.integers(0, 26, size=int(lens.sum())).astype(np.uint8) + 97
-        words, o = [], 0
-        for n in lens:
-            words.append(letters[o:o + n].tobytes().decode()); o += int(n)
-        trie = aocr.build_trie(words).to(dev)
-        m.decode_device(images, targets, targets_eval, 1, trie); sync()
-        t0 = time.perf_counter()
-        for _ in range(args.decode_steps):
-            m.decode_device(images, targets, targets_eval, 1, trie)
-        sync()
-        dec_dict = {"chars_per_s": world * B * 50 * args.decode_steps / (time.perf_counter() - t0), "words": len(words),
-                    "trie_nodes": trie.n_nodes, "trie_bytes": int(trie.mask.nbytes + trie.base.nbytes + trie.child.nbytes)}
+        eld = (time.perf_counter() - t0) / args.decode_steps
+        Hd, T = 2 * wl["He"], W // 4 - 1
+        dec = {"chars_per_s": world * B * 50 / eld, "what": "decoder steps/s: B*50 per call, beam pass + gold pass (model.lua:376-627)",
+               "emitted_chars_per_s": world * nnz / eld, "ms_per_call": 1e3 * eld}
+        if rank == 0:
+            fam = m.profile_families(lambda: m.decode_device(images, targets, targets_eval, 1), repeats=2)
+            chain = fam["decode_chain"]; gold = fam["decoder_fwd"] + fam["rnn_gemm"]
+            wbytes = 2 * (sum((Hd + Hd) * 4 * Hd for _ in range(wl["Ld"])) + Hd * Hd + 2 * Hd * Hd) + 4 * 39 * Hd   # bf16 recurrent weights + fp32 projector
+            sbytes = B * T * Hd * 2 + B * Hd * 4 * (4 * wl["Ld"] + 6)                                                # context (bf16) + state rows
+            if wl["compute"] != "bf16":
+                wbytes *= 2; sbytes = B * T * Hd * 4 + B * Hd * 4 * (4 * wl["Ld"] + 6)
+            dec.update({"beam_only_chars_per_s": B * 50 / (chain * 1e-3) if chain > 0 else None, "beam_ms": chain, "gold_pass_ms": gold,
+                        "cnn_encoder_ms": sum(fam[k] for k in ("conv_fwd", "bn", "pool_conv1", "encoder_seq", "other"))})
+            dec["decode_roofline"] = {
+                "bound": "hbm", "unit": "GB/s", "launches_per_step": 6, "algorithmic_bytes_per_step": wbytes + sbytes,
+                "achieved": (wbytes + sbytes) / (chain / 50 * 1e-3) / 1e9 if chain > 0 else None, "peak": HBM_PEAK_GBPS,
+                "frac": (wbytes + sbytes) / (chain / 50 * 1e-3) / 1e9 / HBM_PEAK_GBPS if chain > 0 else None,
+                "us_per_step": 1e3 * chain / 50,
+                "note": "one decoder step streams every recurrent weight once and the batch's context once; the chain is bound by the "
+                        "latency of its dependent launches, not by these bytes"}
+        # the same step under -use_dictionary: a synthetic 90 k-word lexicon as a device-resident flat trie
+        if not args.no_secondary:
+            rng = np.random.default_rng(1234)
+            lens = rng.integers(3, 11, size=90000)
+            letters = rng.integers(0, 26, size=int(lens.sum())).astype(np.uint8) + 97
+            words, o = [], 0
+            for n in lens:
+                words.append(letters[o:o + n].tobytes().decode()); o += int(n)
+            trie = aocr.build_trie(words).to(dev)
+            m.decode_device(images, targets, targets_eval, 1, trie); sync()
+            t0 = time.perf_counter()
+            for _ in range(args.decode_steps):
+                m.decode_device(images, targets, targets_eval, 1, trie)
+            sync()
+            dec_dict = {"chars_per_s": world * B * 50 * args.decode_steps / (time.perf_counter() - t0), "words": len(words),
+                        "trie_nodes": trie.n_nodes, "trie_bytes": int(trie.mask.nbytes + trie.base.nbytes + trie.child.nbytes)}
 
-    # secondary line (N = 1 only): BASELINE.json configs[1] = C2 in exact-fp32 MFMA mode (the 1e-4 logit-parity configuration)
+    # ---- secondary line (N = 1 only): BASELINE.json configs[1] = C2 in exact-fp32 MFMA mode (the 1e-4 logit-parity configuration)
     c2 = None
     if world == 1 and args.workload == "c3" and not args.no_secondary:
         w2 = WORKLOADS["c2"]
@@ -187,15 +289,14 @@ def main():
         for _ in range(10):
             m2.train_step_device(i2, t2, e2)
         torch.cuda.synchronize(); e = time.perf_counter() - t0
+        f2 = flops(w2["W"], w2["He"], w2["Le"], w2["Ld"], w2["L"])["total"]
         c2 = {"workload": "c2: " + w2["name"], "dtype": "f32", "steps": 10, "ms_per_step": 1e3 * e / 10, "value": w2["B"] * 10 / e,
-              "unit": "image-lines/s"}
+              "unit": "image-lines/s", "step_mfma_frac": 3 * f2 * w2["B"] * 10 / e / 1e12 / PEAK["f32"]}
         m2.shutdown()
 
-    # data path: 255*rgb2y + image.scale of one C3 batch of decoded 48x384 RGB line images to 32x256,
-    # inputs resident in HBM; HBM-bound, reported against the 8 TB/s peak (algorithmic bytes = uint8 source + fp32 output)
+    # ---- data path, HBM-bound
     dp = None
     if world == 1 and not args.no_secondary:
-        import ctypes as C
         from aocr.data import ImageDesc
         n, sh, sw, ow = B, 48, 384, W
         src = torch.randint(0, 256, (n * sh * sw * 3,), dtype=torch.uint8, device=dev)
@@ -214,32 +315,38 @@ def main():
         msd = e0.elapsed_time(e1) / 20
         byts = n * (sh * sw * 3 + 32 * ow * 4)
         dp = {"kernel": "aocr_preprocess_lines (rgb2y + image.scale 48x384x3 -> 32x%d)" % ow, "images_per_s": n / (msd * 1e-3),
-              "ms_per_batch": msd, "bound": "hbm", "achieved_GBps": byts / (msd * 1e-3) / 1e9, "peak_GBps": 8000.0,
-              "frac": byts / (msd * 1e-3) / 1e9 / 8000.0}
+              "ms_per_batch": msd, "bound": "hbm", "achieved_GBps": byts / (msd * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBPS,
+              "frac": byts / (msd * 1e-3) / 1e9 / HBM_PEAK_GBPS}
 
     out = None
     if rank == 0:
         bf16 = wl["compute"] == "bf16"
-        ms, fl = m.profile_kernel(0, 20)
-        peak = 2500.0 if bf16 else 157.3
-        ach = fl / (ms * 1e-3) / 1e12
-        fpi = flops_per_image(W, wl["He"], wl["Le"], wl["Ld"], L)
-        traffic = None                                   # PMC passes cannot run inside this process: value measured with
-        pmc = os.path.join(ROOT, "profiles", "r01_conv6_fwd_pmc.json")       # rocprofv3 --pmc (tools/pmc_traffic.py), C3 bf16 only
-        if bf16 and args.workload == "c3" and os.path.exists(pmc):
+        ms, kfl = m.profile_kernel(0, 20)                # conv6 forward, HIP events on the model's stream
+        ach = kfl / (ms * 1e-3) / 1e12
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_conv6_fwd_pmc.json")
+        if bf16 and args.workload == "c3" and world == 1 and args.scaling == "weak" and os.path.exists(pmc):
             traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
+            traffic_source = ("profiles/r01_conv6_fwd_pmc.json: rocprofv3 --pmc passes of this command (tools/pmc_traffic.py); PMC counters cannot "
+                              "be read from inside the timed process, so this field is NOT measured in this run")
         out = {
             "metric": "image-lines/sec (train step)", "value": lines_per_s, "unit": "image-lines/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {wl['name']}", "global_batch": world * B, "img": f"32x{W}",
+            "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {wl['name']}", "global_batch": global_B, "per_gpu_batch": B, "img": f"32x{W}",
                        "decoder_steps": L, "parallelism": f"dp{world}", "input_feed": True},
-            "train_gflop_per_image": 3 * fpi / 1e9, "step_tflops": 3 * fpi * lines_per_s / 1e12,
-            "step_mfma_frac": 3 * fpi * lines_per_s / 1e12 / (peak * world),
-            "decode_chars_per_s": dec, "decode_dict": dec_dict, "replica_drift": replica_drift, "loss": loss_val, "secondary": c2, "data_path": dp,
+            "scaling_measured": world > 1, "rccl_ranks": rccl_ranks,
+            "step_ms_events": {"median": float(np.median(per_step)), "p10": float(np.percentile(per_step, 10)),
+                               "p90": float(np.percentile(per_step, 90)), "n": int(args.steps)},
+            "sustained": sustained,
+            "train_gflop_per_image": 3 * fl["total"] / 1e9, "step_tflops": 3 * fl["total"] * lines_per_s / 1e12,
+            "step_mfma_frac": 3 * fl["total"] * lines_per_s / 1e12 / (peak * world),
+            "families": families,
+            "decode_chars_per_s": dec["chars_per_s"] if dec else None, "decode": dec, "decode_dict": dec_dict,
+            "replica_drift": replica_drift, "loss": loss_val, "secondary": c2, "data_path": dp,
             "roofline": {"bound": "mfma", "kernel": "conv6 forward implicit GEMM (512->512 3x3 + ReLU + pool)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                         "ms_per_launch": ms},
+                         "traffic_source": traffic_source, "ms_per_launch": ms},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl)

@@ -102,6 +102,24 @@ int aocr_train_forward_backward(aocr_model* m, const float* images_dev, const in
 int aocr_grad_buckets(const aocr_config* cfg, int64_t begin[AOCR_GRAD_BUCKETS], int64_t end[AOCR_GRAD_BUCKETS]);
 int aocr_stream_wait_grads(aocr_model* m, int32_t bucket, void* stream);
 
+/* ---- data parallelism inside the library: one process per GPU, ONE exchange step -- the sum over ranks of the flat
+ * gradient vector between feval and the per-group clip (optim_sgd.lua:38 -> :40) -- plus, with sync_bn, the per-channel BatchNorm
+ * sums of the three BatchNorm layers (cnn.lua:23,32,41) in the forward and the backward pass, so that N ranks on slices of a batch
+ * compute what one GPU computes on the whole batch (training-mode statistics included; running statistics stay identical on all ranks).
+ * Provider 1: RCCL over xGMI.  rank 0 calls aocr_comm_unique_id, the host hands the 128 bytes to the other ranks (file, socket, MPI:
+ * its choice), every rank calls aocr_comm_init_rank (collective, like ncclCommInitRank).  librccl.so is bound at run time.
+ * Provider 2: a host callback that sums `count` elements (dtype 0 = fp32, 1 = fp64) of a device buffer over the ranks in place,
+ * enqueued on `stream` (the Python mirror routes torch.distributed through it; the tests use gloo).
+ * aocr_allreduce_grads: after aocr_train_forward_backward and before aocr_sgd_step; the buckets of aocr_grad_buckets are summed on a
+ * second stream as the backward pass completes them (overlap), loss_dev (optional, 1 float) is summed too, and the model's stream
+ * waits for the last bucket.  Pass grad_scale = 1 / GLOBAL batch to aocr_train_forward_backward. */
+typedef int (*aocr_allreduce_fn)(void* user, void* buf_dev, int64_t count, int32_t dtype, void* stream);
+int aocr_comm_unique_id(char id[128]);
+int aocr_comm_init_rank(aocr_model* m, const char id[128], int32_t nranks, int32_t rank, int32_t sync_bn);
+int aocr_comm_set_callback(aocr_model* m, aocr_allreduce_fn fn, void* user, int32_t nranks, int32_t sync_bn);
+int aocr_allreduce_grads(aocr_model* m, float* loss_dev);
+int aocr_comm_destroy(aocr_model* m);
+
 /* optim.sgd_list, src/optim/optim_sgd.lua:38-95 with the options the reference
  * leaves at 0: per group, if ||g||_2 > clip then g *= clip/||g||_2; w -= lr*g.
  * norms_dev (optional, 2*5 floats): {param norm, grad norm} per group, as printed
@@ -161,6 +179,26 @@ int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32
  * on the model's stream; which: 0 = conv6 forward implicit GEMM (largest layer).
  * ms_per_launch and flops_per_launch are host outputs (this call synchronises). */
 int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_per_launch, double* flops_per_launch);
+
+/* Per-family timing of the fused step with HIP events on the model's stream (measurement only).  After
+ * aocr_profile_enable(m, 1) every fused entry point records an event wherever the work changes family; aocr_profile_read
+ * synchronises the stream, returns the milliseconds accumulated per family since the last read (ms[AOCR_PROF_FAMILIES]) and the
+ * number of marks, and clears the record.  Families: */
+#define AOCR_PROF_OTHER 0        /* weight shadows, zero fills, copies, loss, embedding */
+#define AOCR_PROF_CONV_FWD 1     /* conv2..conv7 forward implicit GEMMs (cnn.lua:17-41) */
+#define AOCR_PROF_CONV_DGRAD 2   /* their data gradients */
+#define AOCR_PROF_CONV_WGRAD 3   /* their filter gradients */
+#define AOCR_PROF_BN 4           /* BatchNorm(+ReLU) forward and backward (cnn.lua:23,32,41) */
+#define AOCR_PROF_POOL_CONV1 5   /* conv1 forward / backward and the un-pool passes */
+#define AOCR_PROF_ENC_SEQ 6      /* the encoder recurrences, forward and BPTT (model.lua:294-316, 664-690) */
+#define AOCR_PROF_RNN_GEMM 7     /* hoisted input projections, projector, every LSTM / attention weight gradient */
+#define AOCR_PROF_DEC_FWD 8      /* decoder step chain forward (model.lua:553-568) */
+#define AOCR_PROF_DEC_BWD 9      /* decoder step chain BPTT (model.lua:643-661) */
+#define AOCR_PROF_SGD 10         /* clip + update (optim_sgd.lua:38-95) */
+#define AOCR_PROF_DECODE 11      /* beam / greedy decode chain (model.lua:376-536) */
+#define AOCR_PROF_FAMILIES 12
+int aocr_profile_enable(aocr_model* m, int32_t on);
+int aocr_profile_read(aocr_model* m, float ms[AOCR_PROF_FAMILIES], int32_t* marks);
 
 /* ---- module-level entry points (the nn.Module surface of the files under src/model) ---- */
 

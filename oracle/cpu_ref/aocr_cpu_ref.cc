@@ -36,6 +36,14 @@ constexpr int PAD = 1, EOS = 3;      // train.lua:53 (1-based ids)
 
 struct Cfg { int32_t img_h, enc_hidden, enc_layers, dec_layers, vocab, emb, input_feed; };
 
+int nthreads() {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------ GEMM
 // C[M,N] (ldc) (+)= sum_k a(i,k) * B[k*ldb + j],  a(i,k) = A[i*sai + k*sak]; B and C have unit stride along j.
 // 6 x (2 vectors of 64 bytes) register tile, k blocked by 256; `par` spreads (row block, column tile) tasks over the OpenMP team.
@@ -132,7 +140,8 @@ void gemm(int M, int N, int K, const T* A, long sai, long sak, const T* B, long 
   const int ib = (M + Q::IB - 1) / Q::IB, jb = (N + Q::JB - 1) / Q::JB;
   const long tasks = (long)ib * jb;
   if (par && tasks > 1) {
-#pragma omp parallel
+    const int team = (int)std::min<long>(tasks, nthreads());
+#pragma omp parallel num_threads(team)
     {
       std::vector<T> bpack((size_t)Q::KC * Q::NR + 16), apack((size_t)Q::IT * Q::KC * Q::MR + 16);
 #pragma omp for schedule(dynamic)
@@ -144,13 +153,6 @@ void gemm(int M, int N, int K, const T* A, long sai, long sak, const T* B, long 
   }
 }
 
-int nthreads() {
-#ifdef _OPENMP
-  return omp_get_max_threads();
-#else
-  return 1;
-#endif
-}
 
 // nn.Linear forward: Y[M,N] = X[M,K] W[N,K]^T (+ b) -- addmm against the transposed weight (transposed once per call)
 template <class T> struct Linear {
@@ -264,8 +266,8 @@ template <class T> void col2im_add(const T* cols, int C, int H, int W, int k, in
 template <class T> void conv_forward(const Map<T>& x, int B, const ConvSpec& s, const T* W, const T* bias, Map<T>& y) {
   const int Ho = x.H + 2 * s.pad - s.k + 1, Wo = x.W + 2 * s.pad - s.k + 1, CK = s.cin * s.k * s.k, HW = Ho * Wo;
   y.C = s.cout; y.H = Ho; y.W = Wo; y.v.resize((size_t)B * s.cout * HW);
-  const bool over_images = B >= nthreads();
-#pragma omp parallel if (over_images)
+  const bool over_images = B >= 4;                         // images are independent: one image per thread, serial GEMM inside
+#pragma omp parallel if (over_images) num_threads(std::min(B, nthreads()))
   {
     std::vector<T> cols((size_t)CK * HW);
 #pragma omp for schedule(dynamic)
@@ -280,10 +282,10 @@ template <class T> void conv_forward(const Map<T>& x, int B, const ConvSpec& s, 
 // gradInput (may be null), gradWeight +=, gradBias +=
 template <class T> void conv_backward(const Map<T>& x, int B, const ConvSpec& s, const T* W, const std::vector<T>& dy, T* dW, T* db, std::vector<T>* dx) {
   const int Ho = x.H + 2 * s.pad - s.k + 1, Wo = x.W + 2 * s.pad - s.k + 1, CK = s.cin * s.k * s.k, HW = Ho * Wo;
+  const bool over_images = B >= 4;
   if (dx) {
     dx->assign((size_t)B * x.img(), T(0));
-    const bool over_images = B >= nthreads();
-#pragma omp parallel if (over_images)
+#pragma omp parallel if (over_images) num_threads(std::min(B, nthreads()))
     {
       std::vector<T> dcols((size_t)CK * HW);
 #pragma omp for schedule(dynamic)
@@ -293,13 +295,31 @@ template <class T> void conv_backward(const Map<T>& x, int B, const ConvSpec& s,
       }
     }
   }
-  std::vector<T> rows((size_t)HW * CK);
-  for (int b = 0; b < B; ++b) {                           // accGradParameters, image by image
-    im2row(x.v.data() + (size_t)b * x.img(), s.cin, x.H, x.W, s.k, s.pad, Ho, Wo, rows.data(), true);
-    const T* dyb = dy.data() + (size_t)b * s.cout * HW;
-    gemm(s.cout, CK, HW, dyb, HW, 1, rows.data(), CK, dW, CK, true, true);
-    for (int co = 0; co < s.cout; ++co) { T sacc = 0; for (int p = 0; p < HW; ++p) sacc += dyb[(size_t)co * HW + p]; db[co] += sacc; }
+  // accGradParameters, image by image.  With several images each thread sums its images into a private gradWeight and the
+  // threads' sums are added up afterwards (the reference's order is image 1..B into one buffer; fp addition order differs only here).
+  const int team = over_images ? std::min(std::min(B, nthreads()), 16) : 1;
+  std::vector<std::vector<T>> acc(team);
+#pragma omp parallel num_threads(team) if (team > 1)
+  {
+#ifdef _OPENMP
+    const int tid = team > 1 ? omp_get_thread_num() : 0;
+#else
+    const int tid = 0;
+#endif
+    std::vector<T> rows((size_t)HW * CK);
+    std::vector<T>& a = acc[tid]; a.assign((size_t)s.cout * CK + s.cout, T(0));
+#pragma omp for schedule(static)
+    for (int b = 0; b < B; ++b) {
+      im2row(x.v.data() + (size_t)b * x.img(), s.cin, x.H, x.W, s.k, s.pad, Ho, Wo, rows.data(), team == 1);
+      const T* dyb = dy.data() + (size_t)b * s.cout * HW;
+      gemm(s.cout, CK, HW, dyb, HW, 1, rows.data(), CK, a.data(), CK, true, team == 1);
+      for (int co = 0; co < s.cout; ++co) { T sacc = 0; for (int p = 0; p < HW; ++p) sacc += dyb[(size_t)co * HW + p]; a[(size_t)s.cout * CK + co] += sacc; }
+    }
   }
+  const size_t nW = (size_t)s.cout * CK;
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < nW; ++i) { T v = 0; for (int t = 0; t < team; ++t) v += acc[t][i]; dW[i] += v; }
+  for (int co = 0; co < s.cout; ++co) { T v = 0; for (int t = 0; t < team; ++t) v += acc[t][nW + co]; db[co] += v; }
 }
 
 template <class T> void relu_inplace(std::vector<T>& v) {

@@ -1,0 +1,108 @@
+"""Data parallelism inside the library (include/aocr.h: aocr_comm_*, aocr_allreduce_grads, synchronised BatchNorm).
+
+* DP-2 == 1 GPU in TRAINING mode: two processes (gloo, both on the one GPU of the box -- RCCL refuses two ranks on one device), each
+  with half of a batch, exchange through the library's callback provider with synchronised BatchNorm; loss, every gradient, the
+  updated parameters and the running statistics must equal the single-process step on the whole batch.
+* The RCCL provider itself (librccl bound by the library with dlopen): a 1-rank communicator on the one GPU -- ncclCommInitRank,
+  ncclAllReduce on the library's second stream behind the gradient-ready events -- must leave the step unchanged."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = dict(enc_hidden=32, enc_layers=1, dec_layers=2, input_feed=True)
+
+
+def _build(B, W, compute="f32"):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_step_gpu import make
+    return make(CFG, B=B, W=W, maxlen=6, compute=compute, max_decoder_l=8, max_beam=1)
+
+
+def _worker(rank, world, port, q, sync_bn):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for p in (os.path.join(ROOT, "torch-attention-ocr_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if not sync_bn:
+        os.environ["AOCR_NO_SYNC_BN"] = "1"
+    m, O, ocfg, P, st, batch = _build(8, 40)                      # the GLOBAL batch: every rank generates it, then keeps its slice
+    half = 8 // world
+    sl = slice(rank * half, (rank + 1) * half)
+    local = [np.asarray(batch[0])[sl], np.asarray(batch[1])[sl], np.asarray(batch[2])[sl], batch[3], None]
+    loss, _ = m.step(local, False)                                  # feval + exchange + clip + update, through Model.step
+    grads = {k: v.numpy() for k, v in m.get_gradients().items()}
+    params = {k: v.numpy() for k, v in m.get_parameters().items()}
+    bn = {k: v.numpy() for k, v in m.get_bn_state().items()}
+    q.put((rank, loss, grads, params, bn))
+    dist.barrier()
+    m.shutdown()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sync_bn", [True, False])
+def test_dp2_equals_single_gpu_in_training_mode(cuda, sync_bn):
+    m, O, ocfg, P, st, batch = _build(8, 40)
+    loss1, _ = m.step(batch, False)
+    g1 = {k: v.numpy() for k, v in m.get_gradients().items()}
+    p1 = {k: v.numpy() for k, v in m.get_parameters().items()}
+    b1 = {k: v.numpy() for k, v in m.get_bn_state().items()}
+    m.shutdown()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300 + (7 if sync_bn else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sync_bn)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, l0, g0, p0, bn0), (_, l1, gr1, pr1, bnr1) = res
+    for k in g0:                                   # both ranks hold the same summed gradients and the same updated parameters
+        assert np.array_equal(g0[k], gr1[k]) and np.array_equal(p0[k], pr1[k]), k
+    assert l0 == pytest.approx(l1)
+    noisy = ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b")
+
+    def rel(a, b):
+        return float(np.abs(a.astype(np.float64) - b).max() / (np.abs(b).max() + 1e-12))
+    worst = max(rel(g0[k], g1[k]) for k in g1 if k not in noisy)
+    worst_p = max(float(np.abs(p0[k] - p1[k]).max()) for k in p1)
+    worst_bn = max(float(np.abs(bn0[k] - b1[k]).max()) for k in b1)
+    print(f"[dp] sync_bn={sync_bn}: loss {l0:.5f} vs single {loss1:.5f}; worst gradient rel {worst:.2e}, parameter max-abs {worst_p:.2e}, running stats {worst_bn:.2e}")
+    if sync_bn:                                    # DP-2 == 1 GPU on the concatenated batch, training-mode BatchNorm included
+        assert l0 == pytest.approx(loss1, rel=1e-5)
+        assert worst < 2e-4 and worst_p < 1e-5 and worst_bn < 1e-5
+    else:                                          # per-rank statistics: a different (documented) computation -- must NOT coincide
+        assert worst > 1e-3
+
+
+def test_rccl_provider_single_rank(cuda):
+    """librccl through the library's own binding (ncclGetUniqueId / ncclCommInitRank / ncclAllReduce on the second stream)."""
+    import ctypes as C
+    import aocr
+    from aocr import check, lib, ptr
+    from aocr import dist as adist
+    m, O, ocfg, P, st, batch = _build(8, 40, compute="bf16")
+    loss0 = m.train_forward_backward(batch)
+    g0 = m.grad_params.clone()
+    adist.attach_rccl(m, sync_bn=True)              # world of 1: every all-reduce is the identity, but goes through RCCL
+    images, targets, targets_eval = m._upload(batch)
+    B, _, _, W = images.shape
+    loss = torch.zeros(1, device=cuda)
+    for _ in range(3):
+        check(lib.aocr_train_forward_backward(m._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, targets.shape[1], 1.0 / B, ptr(loss)))
+        check(lib.aocr_allreduce_grads(m._h, ptr(loss)), "aocr_allreduce_grads")
+        g = m.grad_params.clone()                   # on the model's stream, which has joined the exchange stream
+        torch.cuda.synchronize()
+        assert (g - g0).abs().max().item() <= 1e-4 * g0.abs().max().item()
+        assert loss.item() == pytest.approx(loss0, rel=1e-5)
+    check(lib.aocr_comm_destroy(m._h))
+    m.shutdown()

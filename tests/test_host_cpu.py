@@ -38,8 +38,8 @@ def test_bench_flop_model_matches_survey():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
     b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
-    assert abs(b.flops_per_image(100, 256, 1, 2, 24) / 1e9 - 1.5524) < 1e-3      # SURVEY.md 8(d) C2 forward
-    assert abs(b.flops_per_image(256, 256, 1, 2, 24) / 1e9 - 3.6048) < 1e-3      # C3 forward
+    assert abs(b.flops(100, 256, 1, 2, 24)["total"] / 1e9 - 1.5524) < 1e-3      # SURVEY.md 8(d) C2 forward
+    assert abs(b.flops(256, 256, 1, 2, 24)["total"] / 1e9 - 3.6048) < 1e-3      # C3 forward
 
 
 def _dp_worker(rank, world, port, q):

@@ -17,6 +17,8 @@ LIB_PATH = os.path.join(_HERE, "libaocr.so")
 
 NUM_GROUPS = 5
 COMPUTE_F32, COMPUTE_BF16 = 0, 1
+PROF_FAMILIES = ["other", "conv_fwd", "conv_dgrad", "conv_wgrad", "bn", "pool_conv1", "encoder_seq", "rnn_gemm", "decoder_fwd",
+                 "decoder_bwd", "sgd", "decode_chain"]          # AOCR_PROF_* of include/aocr.h
 
 
 class AocrError(RuntimeError):
@@ -45,6 +47,7 @@ lib = C.CDLL(LIB_PATH)
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 _cfgp = C.POINTER(Config)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _i64, _i32, _vp)     # aocr_allreduce_fn of include/aocr.h
 
 # name -> (restype, argtypes); every symbol declared in include/aocr.h
 SIGNATURES = {
@@ -60,6 +63,11 @@ SIGNATURES = {
     "aocr_train_forward_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "aocr_grad_buckets": (C.c_int, [_cfgp, C.POINTER(_i64), C.POINTER(_i64)]),
     "aocr_stream_wait_grads": (C.c_int, [_vp, _i32, _vp]),
+    "aocr_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "aocr_comm_init_rank": (C.c_int, [_vp, C.c_char_p, _i32, _i32, _i32]),
+    "aocr_comm_set_callback": (C.c_int, [_vp, _vp, _vp, _i32, _i32]),
+    "aocr_allreduce_grads": (C.c_int, [_vp, _vp]),
+    "aocr_comm_destroy": (C.c_int, [_vp]),
     "aocr_sgd_step": (C.c_int, [_vp, _f32, _f32, _vp]),
     "aocr_adadelta_step": (C.c_int, [_vp, _f32, _f32, _f32, _vp]),
     "aocr_forward_logits": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -67,6 +75,8 @@ SIGNATURES = {
     "aocr_decode_dict": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "aocr_get_tensor": (C.c_int, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i64)]),
     "aocr_profile_kernel": (C.c_int, [_vp, _i32, _i32, C.POINTER(_f32), C.POINTER(C.c_double)]),
+    "aocr_profile_enable": (C.c_int, [_vp, _i32]),
+    "aocr_profile_read": (C.c_int, [_vp, C.POINTER(_f32), C.POINTER(_i32)]),
     "aocr_gemm": (C.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _i32]),
     "aocr_conv2d_forward": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 9),
     "aocr_conv2d_backward_data": (C.c_int, [_vp, _i32, _vp, _vp, _vp] + [_i32] * 7),

@@ -14,6 +14,8 @@ about a millisecond at 8 GPUs -- only the last 3.8 MB bucket (conv1..conv4) is e
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
 
@@ -64,3 +66,54 @@ def exchange_overlapped(flat_grads: torch.Tensor, loss: torch.Tensor, ranges, wa
             if k == 0:
                 d.all_reduce(loss)                   # the loss is final before the backward pass starts
     main.wait_stream(comm_stream)                    # the clip + update need every bucket
+
+
+# ------------------------------------------------------------------------------------------------ the exchange inside the library
+def attach(model, sync_bn: bool = True) -> None:
+    """Hands torch.distributed to the library as its all-reduce provider (`aocr_comm_set_callback`, include/aocr.h): from then on
+    `aocr_allreduce_grads` sums the gradient buckets on the library's own second stream beside the backward pass, and -- with
+    sync_bn -- the three BatchNorm layers normalise with the statistics of the GLOBAL batch, so that N ranks on slices of a batch
+    compute what one GPU computes on the whole batch.  A Lua / C host uses `aocr_comm_init_rank` (RCCL bound by the library) instead."""
+    from ._lib import ALLREDUCE_FN, check, lib
+    if world_size() <= 1 or getattr(model, "_comm_cb", None) is not None:
+        return
+    d = torch.distributed
+
+    def view(ptr, count, dtype):
+        nbytes = count * (8 if dtype else 4)
+        for t in (model.grad_params, model.workspace, model._scal):
+            base = t.data_ptr()
+            if base <= ptr and ptr + nbytes <= base + t.numel() * t.element_size():
+                off = ptr - base
+                flat = t.view(torch.uint8).reshape(-1)[off:off + nbytes]
+                return flat.view(torch.float64 if dtype else torch.float32)
+        raise RuntimeError("all-reduce of a buffer outside the model's tensors")
+
+    def cb(user, buf, count, dtype, stream):
+        try:
+            v = view(buf, count, dtype)
+            ext = torch.cuda.ExternalStream(stream, device=model.device) if stream else torch.cuda.default_stream(model.device)
+            with torch.cuda.stream(ext):
+                d.all_reduce(v)
+            return 0
+        except Exception as e:                       # never let an exception cross the C boundary
+            print(f"[aocr.dist] all-reduce callback failed: {e!r}", flush=True)
+            return 1
+    model._comm_cb = ALLREDUCE_FN(cb)                # keep the trampoline alive as long as the model
+    check(lib.aocr_comm_set_callback(model._h, C.cast(model._comm_cb, C.c_void_p), None, world_size(), int(sync_bn)), "aocr_comm_set_callback")
+
+
+def attach_rccl(model, sync_bn: bool = True) -> None:
+    """The library's own RCCL provider (what a non-Python host uses): rank 0's unique id travels through torch.distributed's store."""
+    from ._lib import check, lib
+    d = torch.distributed
+    n, r = (d.get_world_size(), d.get_rank()) if (d.is_available() and d.is_initialized()) else (1, 0)
+    buf = C.create_string_buffer(128)
+    if r == 0:
+        check(lib.aocr_comm_unique_id(buf), "aocr_comm_unique_id")
+    if n > 1:
+        ids = [bytes(buf.raw)]
+        d.broadcast_object_list(ids, 0)
+        buf = C.create_string_buffer(ids[0], 128)
+    check(lib.aocr_comm_init_rank(model._h, buf, n, r, int(sync_bn)), "aocr_comm_init_rank")
+    model._comm_rccl = True

@@ -117,7 +117,7 @@ class Model:
             magic = f.read(4)
         if magic[:2] != b"PK":                       # not a torch.save zip: a Torch7 file (the reference's checkpoint or our flat export)
             return self._load_t7(model_path, config)
-        ck = torch.load(model_path, map_location="cpu", weights_only=False)
+        ck = torch.load(model_path, map_location="cpu", weights_only=True)        # tensors + plain containers only: no pickle execution
         self._set_structure(ck["config"])
         merged = dict(ck["config"])
         for k in ("max_encoder_l", "max_decoder_l", "batch_size", "prealloc", "img_h", "max_img_w", "max_beam", "compute"):
@@ -127,6 +127,7 @@ class Model:
         self._set_runtime(merged)
         self.global_step = ck["global_step"]
         self.optim_state = dict(ck["optim_state"])
+        self.optim_state.setdefault("learningRate", float(merged.get("learning_rate", _DEFAULTS["learning_rate"])))   # train.lua:87
         self._build()
         self.params.copy_(ck["params"].to(self.params.device))
         self.bn_state.copy_(ck["bn_state"].to(self.params.device))
@@ -144,7 +145,8 @@ class Model:
                 merged[k] = v
         self._set_runtime(merged)
         self.global_step = ck["global_step"]
-        self.optim_state = dict(ck["optim_state"]) or {"learningRate": float(merged["learning_rate"])}
+        self.optim_state = dict(ck["optim_state"] or {})
+        self.optim_state.setdefault("learningRate", float(merged["learning_rate"]))                                  # train.lua:87
         self._build()
         self.set_parameters({k: torch.from_numpy(v) for k, v in ck["params"].items()},
                             {k: torch.from_numpy(v) for k, v in ck["bn_state"].items()})
@@ -289,20 +291,26 @@ class Model:
         assert images.dim() == 4 and images.shape[1] == 1 and images.shape[2] == self.img_h
         return images, targets, targets_eval
 
-    def train_step_device(self, images, targets, targets_eval):
+    def train_step_device(self, images, targets, targets_eval, global_batch=None):
         """One optimisation step on inputs already resident in HBM; enqueues only (no host sync) and returns
-        the device scalar holding the step's NLL sum (summed over ranks under data parallelism)."""
+        the device scalar holding the step's NLL sum (summed over ranks under data parallelism).
+        global_batch: rows of the step over ALL ranks (default: this rank's rows x world size, i.e. equal slices)."""
         B, _, _, W = images.shape
         target_l = targets.shape[1]
         assert target_l <= self.max_decoder_l, f"max_decoder_l ({self.max_decoder_l}) < target_l ({target_l})!"
         check(lib.aocr_model_set_stream(self._h, self._stream()))
         loss_dev = self._scal[0:1]
+        if dist.world_size() > 1 and not os.environ.get("AOCR_PY_EXCHANGE"):
+            dist.attach(self, sync_bn=not os.environ.get("AOCR_NO_SYNC_BN"))       # once: torch.distributed becomes the library's provider
         # d(loss) / (global batch): model.lua:645-647 divides by the step's batch size
+        scale = dist.grad_scale(B) if global_batch is None else 1.0 / float(global_batch)
         check(lib.aocr_train_forward_backward(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, target_l,
-                                              dist.grad_scale(B), ptr(loss_dev)), "aocr_train_forward_backward")
+                                              scale, ptr(loss_dev)), "aocr_train_forward_backward")
         # the one exchange step of data parallelism (RCCL over xGMI), between feval and the per-group clip; bucketed in the order
         # the backward pass completes the gradient vector and run on a second stream beside it
-        if dist.world_size() > 1 and os.environ.get("AOCR_NO_OVERLAP"):
+        if getattr(self, "_comm_cb", None) is not None or getattr(self, "_comm_rccl", False):
+            check(lib.aocr_allreduce_grads(self._h, ptr(loss_dev)), "aocr_allreduce_grads")   # inside the library (include/aocr.h)
+        elif dist.world_size() > 1 and os.environ.get("AOCR_NO_OVERLAP"):
             dist.exchange(self.grad_params, loss_dev)             # one all-reduce after the backward pass (A/B against the overlap)
         elif dist.world_size() > 1:
             if self._comm_stream is None:
@@ -343,6 +351,21 @@ class Model:
         check(lib.aocr_profile_kernel(self._h, which, iters, C.byref(ms), C.byref(fl)), "aocr_profile_kernel")
         return ms.value, fl.value
 
+    def profile_families(self, fn, repeats=3):
+        """Per-family HIP-event timing (include/aocr.h AOCR_PROF_*): runs fn() `repeats` times with the library's marks on and
+        returns {family: ms per call}."""
+        check(lib.aocr_profile_enable(self._h, 1), "aocr_profile_enable")
+        try:
+            tot = np.zeros(len(_lib.PROF_FAMILIES))
+            for _ in range(repeats):
+                fn()
+                ms, marks = (C.c_float * len(_lib.PROF_FAMILIES))(), C.c_int32()
+                check(lib.aocr_profile_read(self._h, ms, C.byref(marks)), "aocr_profile_read")
+                tot += np.array(list(ms))
+        finally:
+            check(lib.aocr_profile_enable(self._h, 0), "aocr_profile_enable")
+        return {k: float(v / repeats) for k, v in zip(_lib.PROF_FAMILIES, tot)}
+
     def step(self, batch, forward_only, beam_size=None, trie=None):
         """Returns (loss*batch_size, [num_nonzeros, num_correct]) exactly like model:step (model.lua:695-705)."""
         images, targets, targets_eval = self._upload(batch)
@@ -355,7 +378,14 @@ class Model:
         check(lib.aocr_model_set_stream(self._h, self._stream()))
         loss_dev = self._scal[0:1]
         if not forward_only:
-            loss_dev = self.train_step_device(images, targets, targets_eval)
+            global_batch = None
+            if dist.world_size() > 1:
+                # tail batches differ between ranks (data_gen.lua:123-153): the rows and label counts of the step are summed first, so
+                # that d(loss) is scaled by 1 / (global rows) and train.lua:103,120 divides the summed loss by the summed count
+                cnt = torch.tensor([float(B), float(num_nonzeros)], dtype=torch.float64, device=self.device)
+                torch.distributed.all_reduce(cnt)
+                global_batch, num_nonzeros = int(cnt[0].item()), int(cnt[1].item())
+            loss_dev = self.train_step_device(images, targets, targets_eval, global_batch)
             return float(loss_dev.item()), [num_nonzeros, 0.0]
         # forward only: beam search + gold pass
         beam_size = beam_size or 1
@@ -439,7 +469,13 @@ class Model:
 
     def save(self, model_path):
         """model:save, model.lua:720-725 ({nets, config, global_step, optim_state}); nets = the flat parameter vector.
-        A path ending in .t7 is written in Torch7 serialization instead (aocr.checkpoint.write_flat_checkpoint)."""
+        A path ending in .t7 is written in Torch7 serialization instead (aocr.checkpoint.write_flat_checkpoint).
+        NOT readable by the reference's model:load (which expects the five serialized nn modules): the reference-format writer is
+        the Lua side of the boundary (lua/model.lua model:save, which keeps the reference's own nets as parameter containers).
+        Under data parallelism without synchronised BatchNorm the running statistics are rank-local; they are averaged over the ranks
+        here so that a rank-0 checkpoint does not carry one rank's statistics."""
+        if dist.world_size() > 1 and getattr(self, "_comm_cb", None) is None:
+            torch.distributed.all_reduce(self.bn_state); self.bn_state.div_(dist.world_size())
         if str(model_path).endswith(".t7"):
             from .checkpoint import write_flat_checkpoint
             write_flat_checkpoint(model_path, {k: v.numpy() for k, v in self.get_parameters().items()},

@@ -147,7 +147,50 @@ int aocr_model_create(const aocr_config* cfg, float* params_dev, float* grads_de
 }
 int aocr_model_destroy(aocr_model* m) {
   if (m) for (int i = 0; i < 4; ++i) if (m->grad_ev[i]) hipEventDestroy(m->grad_ev[i]);
+  if (m) for (hipEvent_t e : m->prof_ev) hipEventDestroy(e);
+  if (m) comm_destroy(m);
   delete m; return 0;
+}
+int aocr_comm_unique_id(char id[128]) {
+  REQUIRE(id, "NULL argument");
+  if (const char* e = comm_unique_id(id)) return fail("%s", e);
+  return 0;
+}
+int aocr_comm_init_rank(aocr_model* m, const char id[128], int32_t nranks, int32_t rank, int32_t sync_bn) {
+  REQUIRE(m && id && nranks >= 1 && rank >= 0 && rank < nranks, "bad arguments");
+  REQUIRE(m->comm.provider == 0, "a communicator is already attached (aocr_comm_destroy first)");
+  if (const char* e = comm_init_rccl(m, id, nranks, rank, sync_bn)) return fail("%s", e);
+  return 0;
+}
+int aocr_comm_set_callback(aocr_model* m, aocr_allreduce_fn fn, void* user, int32_t nranks, int32_t sync_bn) {
+  REQUIRE(m && fn && nranks >= 1, "bad arguments");
+  REQUIRE(m->comm.provider == 0, "a communicator is already attached (aocr_comm_destroy first)");
+  if (const char* e = comm_init_callback(m, fn, user, nranks, sync_bn)) return fail("%s", e);
+  return 0;
+}
+int aocr_allreduce_grads(aocr_model* m, float* loss_dev) {
+  REQUIRE(m, "NULL model");
+  REQUIRE(m->comm.provider != 0, "no communicator attached (aocr_comm_init_rank / aocr_comm_set_callback)");
+  REQUIRE(m->last_valid, "no train step has been enqueued yet");
+  const int rc = comm_allreduce_grads(m, loss_dev);
+  REQUIRE(rc == 0, rc == 2 ? "the all-reduce provider reported an error" : "stream / event error in the gradient exchange");
+  return 0;
+}
+int aocr_comm_destroy(aocr_model* m) { REQUIRE(m, "NULL model"); comm_destroy(m); return 0; }
+int aocr_profile_enable(aocr_model* m, int32_t on) { REQUIRE(m, "NULL model"); m->prof_on = on != 0; m->prof_n = 0; return 0; }
+int aocr_profile_read(aocr_model* m, float ms[AOCR_PROF_FAMILIES], int32_t* marks) {
+  REQUIRE(m && ms, "NULL argument");
+  for (int i = 0; i < AOCR_PROF_FAMILIES; ++i) ms[i] = 0.f;
+  if (marks) *marks = (int32_t)m->prof_n;
+  if (m->prof_n < 2) { m->prof_n = 0; return 0; }
+  if (hipEventSynchronize(m->prof_ev[m->prof_n - 1]) != hipSuccess) return fail("hipEventSynchronize failed");
+  for (size_t i = 0; i + 1 < m->prof_n; ++i) {
+    const int tag = m->prof_tag[i];
+    if (tag < 0) continue;                               // a closing mark: the gap to the next entry point is not kernel time
+    float t = 0.f; if (hipEventElapsedTime(&t, m->prof_ev[i], m->prof_ev[i + 1]) == hipSuccess) ms[tag] += t;
+  }
+  m->prof_n = 0;
+  return 0;
 }
 int aocr_model_set_stream(aocr_model* m, void* stream) { REQUIRE(m, "NULL model"); m->s = (hipStream_t)stream; return 0; }
 
@@ -164,12 +207,14 @@ int aocr_train_forward_backward(aocr_model* m, const float* images_dev, const in
                                 int32_t B, int32_t W, int32_t L, float grad_scale, float* loss_dev) {
   Dims d; if (step_dims(m, B, W, L, d)) return 1;
   REQUIRE(images_dev && targets_dev && targets_eval_dev, "NULL input");
+  prof_mark(m, AOCR_PROF_OTHER);
   hipMemsetAsync(m->grads, 0, (size_t)m->layout.group_off[AOCR_NUM_GROUPS] * sizeof(float), m->s);      // model.lua:637-639
   cnn_forward(m, images_dev, d, 1, 1);
   encoder_forward(m, d);
   decoder_tf_forward(m, d, targets_dev, 1, L, true);
   loss_and_dlogits(m, d, targets_eval_dev, 1, L, grad_scale, true, loss_dev);
   backward_all(m, images_dev, targets_dev, d);
+  prof_mark(m, -1);
   m->last = d; m->last_valid = 1;
   return check_launch("aocr_train_forward_backward");
 }
@@ -199,7 +244,9 @@ int aocr_stream_wait_grads(aocr_model* m, int32_t bucket, void* stream) {
 
 int aocr_sgd_step(aocr_model* m, float lr, float clip, float* norms_dev) {
   REQUIRE(m, "NULL model");
+  prof_mark(m, AOCR_PROF_SGD);
   sgd_clip_update(m->s, m->params, m->grads, m->layout.group_off, lr, clip, norms_dev, m->sgd_scratch);
+  prof_mark(m, -1);
   return check_launch("aocr_sgd_step");
 }
 
@@ -254,13 +301,17 @@ int aocr_decode_dict(aocr_model* m, const float* images_dev, const int32_t* targ
   hipLaunchKernelGGL(pad_targets_kernel, dim3(cdiv((int64_t)B * Lt, 256)), dim3(256), 0, m->s, targets_dev, m->tgt_pad, B, L, Lt);
   hipLaunchKernelGGL(pad_targets_kernel, dim3(cdiv((int64_t)B * Lt, 256)), dim3(256), 0, m->s, targets_eval_dev, m->tge_pad, B, L, Lt);
   d.L = Lt;
+  prof_mark(m, AOCR_PROF_OTHER);
   cnn_forward(m, images_dev, d, 0, 0);                                    // model.lua:280-281: evaluate()
   encoder_forward(m, d);
+  prof_mark(m, AOCR_PROF_DECODE);
   decode_beam(m, d, m->tgt_pad, beam, labels_dev, scores_dev, trie);
   // gold pass, model.lua:589-627
   decoder_tf_forward(m, d, m->tgt_pad, 1, Lt, false);
+  prof_mark(m, AOCR_PROF_OTHER);
   loss_and_dlogits(m, d, m->tge_pad, 1, Lt, 0.f, false, loss_dev);
   if (gold_scores_dev) gold_scores(m->s, m->nll_rows, gold_scores_dev, Lt, B);
+  prof_mark(m, -1);
   m->last = d; m->last_valid = 1;
   return check_launch(trie ? "aocr_decode_dict" : "aocr_decode");
 }

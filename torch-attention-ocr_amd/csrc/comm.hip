@@ -1,0 +1,98 @@
+// comm.hip -- the ONE exchange step of the data-parallel path inside the library: the sum over ranks of the flat
+// gradient vector between feval and the per-group clip (optim_sgd.lua:38 -> :40), plus the per-channel BatchNorm sums when
+// synchronised BatchNorm is on (cnn.lua:23,32,41: the reference's batch statistics are those of the WHOLE batch).
+//
+// Two providers behind one call: RCCL (ncclAllReduce over xGMI; librccl is bound with dlopen, so a single-GPU host never needs it)
+// or a host callback (the Python mirror passes torch.distributed through it: gloo in the tests, nccl = RCCL otherwise).
+#include "model.h"
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstring>
+
+namespace aocr {
+
+namespace {
+struct NcclId { char internal[128]; };
+typedef int (*GetUniqueIdFn)(NcclId*);
+typedef int (*CommInitRankFn)(void**, int, NcclId, int);
+typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*CommDestroyFn)(void*);
+typedef const char* (*GetErrorStringFn)(int);
+struct Rccl { void* h = nullptr; GetUniqueIdFn uid; CommInitRankFn init; AllReduceFn allreduce; CommDestroyFn destroy; GetErrorStringFn errstr; };
+Rccl g_rccl;
+const char* load_rccl() {
+  if (g_rccl.h) return nullptr;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; }        // the copy the process already has, if any
+  for (int i = 0; i < 3 && !h; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+  if (!h) return "librccl.so not found";
+  g_rccl.uid = (GetUniqueIdFn)dlsym(h, "ncclGetUniqueId"); g_rccl.init = (CommInitRankFn)dlsym(h, "ncclCommInitRank");
+  g_rccl.allreduce = (AllReduceFn)dlsym(h, "ncclAllReduce"); g_rccl.destroy = (CommDestroyFn)dlsym(h, "ncclCommDestroy");
+  g_rccl.errstr = (GetErrorStringFn)dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.uid || !g_rccl.init || !g_rccl.allreduce || !g_rccl.destroy) return "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
+  g_rccl.h = h;
+  return nullptr;
+}
+constexpr int NCCL_SUM = 0, NCCL_F32 = 7, NCCL_F64 = 8;
+}  // namespace
+
+const char* comm_unique_id(char id[128]) {
+  if (const char* e = load_rccl()) return e;
+  NcclId u; if (g_rccl.uid(&u) != 0) return "ncclGetUniqueId failed";
+  memcpy(id, u.internal, 128);
+  return nullptr;
+}
+
+static const char* comm_common_init(aocr_model* m, int nranks, int sync_bn) {
+  m->comm.nranks = nranks; m->comm.sync_bn = sync_bn != 0;
+  if (!m->comm.stream && hipStreamCreateWithFlags(&m->comm.stream, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
+  if (!m->comm.done && hipEventCreateWithFlags(&m->comm.done, hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
+  return nullptr;
+}
+const char* comm_init_rccl(aocr_model* m, const char id[128], int nranks, int rank, int sync_bn) {
+  if (const char* e = load_rccl()) return e;
+  NcclId u; memcpy(u.internal, id, 128);
+  void* c = nullptr;
+  const int rc = g_rccl.init(&c, nranks, u, rank);
+  if (rc != 0) { static thread_local char buf[160]; snprintf(buf, sizeof buf, "ncclCommInitRank: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "error"); return buf; }
+  m->comm.rccl = c; m->comm.provider = 1;
+  return comm_common_init(m, nranks, sync_bn);
+}
+const char* comm_init_callback(aocr_model* m, aocr_allreduce_fn fn, void* user, int nranks, int sync_bn) {
+  m->comm.fn = fn; m->comm.user = user; m->comm.provider = 2;
+  return comm_common_init(m, nranks, sync_bn);
+}
+void comm_destroy(aocr_model* m) {
+  if (m->comm.provider == 1 && m->comm.rccl && g_rccl.h) g_rccl.destroy(m->comm.rccl);
+  if (m->comm.stream) hipStreamDestroy(m->comm.stream);
+  if (m->comm.done) hipEventDestroy(m->comm.done);
+  m->comm = CommState{};
+}
+
+// in-place sum over ranks of `count` elements (dtype 0 = fp32, 1 = fp64) enqueued on `stream`
+int comm_allreduce(aocr_model* m, void* buf, int64_t count, int dtype, hipStream_t stream) {
+  if (m->comm.nranks <= 1 && m->comm.provider != 1) return 0;
+  if (m->comm.provider == 1) return g_rccl.allreduce(buf, buf, (size_t)count, dtype ? NCCL_F64 : NCCL_F32, NCCL_SUM, m->comm.rccl, stream);
+  if (m->comm.provider == 2) return m->comm.fn(m->comm.user, buf, count, dtype, (void*)stream);
+  return 0;
+}
+
+// Bucketed sum of the gradient vector on the library's second stream: every bucket waits for the event the backward pass recorded
+// when that part of the vector was complete (backward_all), so the exchange of the decoder / encoder / upper-CNN buckets runs beside
+// the rest of the backward pass; the model's stream joins at the end (the clip needs every bucket).
+int comm_allreduce_grads(aocr_model* m, float* loss_dev) {
+  if (m->comm.provider == 0) return 0;
+  hipStream_t cs = m->comm.stream;
+  int64_t b[AOCR_GRAD_BUCKETS], e[AOCR_GRAD_BUCKETS];
+  aocr_grad_buckets(&m->cfg, b, e);
+  for (int k = 0; k < AOCR_GRAD_BUCKETS; ++k) {
+    if (hipStreamWaitEvent(cs, m->grad_ev[k], 0) != hipSuccess) return 1;
+    if (comm_allreduce(m, m->grads + b[k], e[k] - b[k], 0, cs) != 0) return 2;
+    if (k == 0 && loss_dev && comm_allreduce(m, loss_dev, 1, 0, cs) != 0) return 2;      // the loss is final before the backward pass starts
+  }
+  if (hipEventRecord(m->comm.done, cs) != hipSuccess || hipStreamWaitEvent(m->s, m->comm.done, 0) != hipSuccess) return 1;
+  return 0;
+}
+
+}  // namespace aocr

@@ -30,6 +30,13 @@ struct Arena {
   }
 };
 
+// data-parallel exchange state (comm.hip): provider 0 = none, 1 = RCCL, 2 = host callback
+struct CommState {
+  int nranks = 1; bool sync_bn = false; int provider = 0;
+  void* rccl = nullptr; aocr_allreduce_fn fn = nullptr; void* user = nullptr;
+  hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+};
+
 struct Dims {                     // geometry of one step
   int B, H, W, L, T;
   int H1, W1, H2, W2, H4, H6, Ho7, Wo7;
@@ -86,9 +93,22 @@ struct aocr_model {
   int64_t conv5_off;              // offset of cnn.conv5.w in the flat vectors: the CNN group is split there
   aocr::Dims last;                // dims of the last step (for the parity taps)
   int last_valid;
+  aocr::CommState comm;
+  // per-family HIP-event profile (aocr_profile_enable): a mark = "family `tag` runs from here to the next mark"
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev; std::vector<int> prof_tag; size_t prof_n = 0;
 };
 
 namespace aocr {
+const char* comm_unique_id(char id[128]);
+const char* comm_init_rccl(aocr_model* m, const char id[128], int nranks, int rank, int sync_bn);
+const char* comm_init_callback(aocr_model* m, aocr_allreduce_fn fn, void* user, int nranks, int sync_bn);
+void comm_destroy(aocr_model* m);
+int comm_allreduce(aocr_model* m, void* buf, int64_t count, int dtype, hipStream_t stream);
+int comm_allreduce_grads(aocr_model* m, float* loss_dev);
+inline bool sync_bn_on(const aocr_model* m) { return m->comm.provider != 0 && m->comm.sync_bn; }
+void prof_mark_slow(aocr_model* m, int tag);
+inline void prof_mark(aocr_model* m, int tag) { if (m->prof_on) prof_mark_slow(m, tag); }
 void build_shadow_jobs(aocr_model* m);                              // after bind_params + model_carve
 int model_carve(aocr_model* m, void* base, size_t bytes);          // returns 0 / -1 (too small); base==nullptr: size only
 void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training, int update_running);

@@ -67,6 +67,15 @@ bool make_dims(const aocr_config& c, int B, int W, int L, Dims& d) {
   return B >= 1 && d.Ho7 >= 1 && d.Wo7 >= 1 && L >= 1;
 }
 
+// per-family profile marks (aocr_profile_enable): one timing event per change of family
+void prof_mark_slow(aocr_model* m, int tag) {
+  if (m->prof_n > 0 && m->prof_tag[m->prof_n - 1] == tag) return;          // same family continues
+  if (m->prof_n == m->prof_ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; m->prof_ev.push_back(e); m->prof_tag.push_back(0); }
+  m->prof_tag[m->prof_n] = tag;
+  hipEventRecord(m->prof_ev[m->prof_n], m->s);
+  ++m->prof_n;
+}
+
 // ------------------------------------------------------------------------------------------------
 // workspace
 // ------------------------------------------------------------------------------------------------
@@ -278,8 +287,11 @@ static void run_gates_bwd(aocr_model* m, int nz, const LoadK* a, const ShW* cons
 // ------------------------------------------------------------------------------------------------
 // CNN forward, cnn.lua:9-45.  Output X is time-major (T,B,512) (= cnn_output:transpose(1,2), model.lua:288).
 // ------------------------------------------------------------------------------------------------
+static int bn_sync_allreduce(void* ctx, void* buf, int64_t count, int dtype, hipStream_t s) { return comm_allreduce((aocr_model*)ctx, buf, count, dtype, s); }
+
 void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training, int update_running) {
   hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
+  const BnSync bsync_v{bn_sync_allreduce, m}; const BnSync* bsync = (training && sync_bn_on(m)) ? &bsync_v : nullptr;
   if (bf && !m->shadow_host.empty()) {                          // every bf16 shadow of the step in one launch
     shadow_jobs(s, m->shadow_dev, (int)m->shadow_host.size(), m->shadow_tiles);
   } else {
@@ -291,54 +303,55 @@ void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training
   }
   // bf16 mode: the pooled conv outputs exist only as bf16 shadows (every consumer -- next conv, filter gradient, ReLU mask of the
   // un-pool -- reads the shadow; aocr_get_tensor materialises fp32 on demand)
-  conv1_forward(s, images, m->conv[1].w, m->conv[1].b, bf ? nullptr : m->A1, B, d.H, d.W, m->A1b);
-  conv_forward(s, bf, m->A1, m->conv[2].w, m->conv[2].b, bf ? nullptr : m->A2, m->idx2, B, d.H1, d.W1, 64, 128, 3, 1, 1, 1, m->A1b, m->wb[2], m->A2b);
-  conv_forward(s, bf, m->A2, m->conv[3].w, m->conv[3].b, m->Y3, nullptr, B, d.H2, d.W2, 128, 256, 3, 1, 0, 0, m->A2b, m->wb[3], nullptr);
-  bn_relu_forward(s, m->Y3, bf ? nullptr : m->A3, m->bn[3].w, m->bn[3].b, m->bn[3].rm, m->bn[3].rv, m->bn[3].save, m->bn_scratch,
-                  (int64_t)B * d.H2 * d.W2, 256, training, update_running, 0, m->A3b);
-  conv_forward(s, bf, m->A3, m->conv[4].w, m->conv[4].b, bf ? nullptr : m->A4, m->idx4, B, d.H2, d.W2, 256, 256, 3, 1, 1, 2, m->A3b, m->wb[4], m->A4b);
-  conv_forward(s, bf, m->A4, m->conv[5].w, m->conv[5].b, m->Y5, nullptr, B, d.H4, d.W2, 256, 512, 3, 1, 0, 0, m->A4b, m->wb[5], nullptr);
-  bn_relu_forward(s, m->Y5, bf ? nullptr : m->A5, m->bn[5].w, m->bn[5].b, m->bn[5].rm, m->bn[5].rv, m->bn[5].save, m->bn_scratch,
-                  (int64_t)B * d.H4 * d.W2, 512, training, update_running, 0, m->A5b);
-  conv_forward(s, bf, m->A5, m->conv[6].w, m->conv[6].b, bf ? nullptr : m->A6, m->idx6, B, d.H4, d.W2, 512, 512, 3, 1, 1, 2, m->A5b, m->wb[6], m->A6b);
-  conv_forward(s, bf, m->A6, m->conv[7].w, m->conv[7].b, m->Y7, nullptr, B, d.H6, d.W2, 512, 512, 2, 0, 0, 0, m->A6b, m->wb[7], nullptr);
-  bn_relu_forward(s, m->Y7, m->X, m->bn[7].w, m->bn[7].b, m->bn[7].rm, m->bn[7].rv, m->bn[7].save, m->bn_scratch,
-                  (int64_t)B * d.T, 512, training, update_running, B, m->Xb);
+  prof_mark(m, AOCR_PROF_POOL_CONV1); conv1_forward(s, images, m->conv[1].w, m->conv[1].b, bf ? nullptr : m->A1, B, d.H, d.W, m->A1b);
+  prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A1, m->conv[2].w, m->conv[2].b, bf ? nullptr : m->A2, m->idx2, B, d.H1, d.W1, 64, 128, 3, 1, 1, 1, m->A1b, m->wb[2], m->A2b);
+  prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A2, m->conv[3].w, m->conv[3].b, m->Y3, nullptr, B, d.H2, d.W2, 128, 256, 3, 1, 0, 0, m->A2b, m->wb[3], nullptr);
+  prof_mark(m, AOCR_PROF_BN); bn_relu_forward(s, m->Y3, bf ? nullptr : m->A3, m->bn[3].w, m->bn[3].b, m->bn[3].rm, m->bn[3].rv, m->bn[3].save, m->bn_scratch,
+                  (int64_t)B * d.H2 * d.W2, 256, training, update_running, 0, m->A3b, bsync);
+  prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A3, m->conv[4].w, m->conv[4].b, bf ? nullptr : m->A4, m->idx4, B, d.H2, d.W2, 256, 256, 3, 1, 1, 2, m->A3b, m->wb[4], m->A4b);
+  prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A4, m->conv[5].w, m->conv[5].b, m->Y5, nullptr, B, d.H4, d.W2, 256, 512, 3, 1, 0, 0, m->A4b, m->wb[5], nullptr);
+  prof_mark(m, AOCR_PROF_BN); bn_relu_forward(s, m->Y5, bf ? nullptr : m->A5, m->bn[5].w, m->bn[5].b, m->bn[5].rm, m->bn[5].rv, m->bn[5].save, m->bn_scratch,
+                  (int64_t)B * d.H4 * d.W2, 512, training, update_running, 0, m->A5b, bsync);
+  prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A5, m->conv[6].w, m->conv[6].b, bf ? nullptr : m->A6, m->idx6, B, d.H4, d.W2, 512, 512, 3, 1, 1, 2, m->A5b, m->wb[6], m->A6b);
+  prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A6, m->conv[7].w, m->conv[7].b, m->Y7, nullptr, B, d.H6, d.W2, 512, 512, 2, 0, 0, 0, m->A6b, m->wb[7], nullptr);
+  prof_mark(m, AOCR_PROF_BN); bn_relu_forward(s, m->Y7, m->X, m->bn[7].w, m->bn[7].b, m->bn[7].rm, m->bn[7].rv, m->bn[7].save, m->bn_scratch,
+                  (int64_t)B * d.T, 512, training, update_running, B, m->Xb, bsync);
 }
 
 static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
+  const BnSync bsync_v{bn_sync_allreduce, m}; const BnSync* bsync = sync_bn_on(m) ? &bsync_v : nullptr;
   float *G0 = m->G0, *G1 = m->G1; bf16_t* G0b = m->G0b;
   // bn7 + relu (dX is time-major, Y7 batch-major)
   // bf16 mode: the BatchNorm backward writes only the bf16 shadow of its gradient, takes the ReLU mask from the bf16 output
   // shadow and accumulates the preceding conv's bias gradient (fp32 G0 is free there: partial slab)
-  bn_relu_backward(s, m->Y7, m->X, m->dX, m->bn[7].w, m->bn[7].save, bf ? nullptr : G0, m->bn[7].dw, m->bn[7].db, m->bn_scratch,
-                   (int64_t)B * d.T, 512, B, G0b, bf ? m->Xb : nullptr, bf ? m->conv[7].db : nullptr, bf ? G0 : nullptr);
+  prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y7, m->X, m->dX, m->bn[7].w, m->bn[7].save, bf ? nullptr : G0, m->bn[7].dw, m->bn[7].db, m->bn_scratch,
+                   (int64_t)B * d.T, 512, B, G0b, bf ? m->Xb : nullptr, bf ? m->conv[7].db : nullptr, bf ? G0 : nullptr, bsync);
   const char* dbg_stop = getenv("AOCR_DBG_STOP");          // debugging aid: leave the gradient map of a stage in place (tap "g0")
   const int stop = dbg_stop ? atoi(dbg_stop) : 0;
   if (stop == 1) return;
-  conv_backward_filter(s, bf, m->A6, G0, m->conv[7].dw, bf ? nullptr : m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0, m->A6b, G0b);
-  conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0, G0b, m->wtb[7], m->wtf[7]);
-  unpool_relu_backward(s, G1, m->A6, m->idx6, bf ? nullptr : G0, B, d.H4, d.W2, 512, 2, G0b, bf ? m->conv[6].db : nullptr, bf ? G0 : nullptr, bf ? m->A6b : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
+  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A6, G0, m->conv[7].dw, bf ? nullptr : m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0, m->A6b, G0b);
+  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0, G0b, m->wtb[7], m->wtf[7]);
+  prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A6, m->idx6, bf ? nullptr : G0, B, d.H4, d.W2, 512, 2, G0b, bf ? m->conv[6].db : nullptr, bf ? G0 : nullptr, bf ? m->A6b : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
   if (stop == 2) return;
-  conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, bf ? nullptr : m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, G0b);
-  conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, G0b, m->wtb[6], m->wtf[6]);
-  bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, bf ? nullptr : G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
-                   (int64_t)B * d.H4 * d.W2, 512, 0, G0b, bf ? m->A5b : nullptr, bf ? m->conv[5].db : nullptr, bf ? G0 : nullptr);
-  conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, bf ? nullptr : m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, G0b);
+  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, bf ? nullptr : m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, G0b);
+  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, G0b, m->wtb[6], m->wtf[6]);
+  prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, bf ? nullptr : G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
+                   (int64_t)B * d.H4 * d.W2, 512, 0, G0b, bf ? m->A5b : nullptr, bf ? m->conv[5].db : nullptr, bf ? G0 : nullptr, bsync);
+  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, bf ? nullptr : m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, G0b);
   hipEventRecord(m->grad_ev[2], s);                             // every CNN gradient from conv5.w upwards is complete
-  conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1, G0b, m->wtb[5], m->wtf[5]);
-  unpool_relu_backward(s, G1, m->A4, m->idx4, bf ? nullptr : G0, B, d.H2, d.W2, 256, 2, G0b, bf ? m->conv[4].db : nullptr, bf ? G0 : nullptr, bf ? m->A4b : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
-  conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, bf ? nullptr : m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, G0b);
-  conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, G0b, m->wtb[4], m->wtf[4]);
-  bn_relu_backward(s, m->Y3, m->A3, G1, m->bn[3].w, m->bn[3].save, bf ? nullptr : G0, m->bn[3].dw, m->bn[3].db, m->bn_scratch,
-                   (int64_t)B * d.H2 * d.W2, 256, 0, G0b, bf ? m->A3b : nullptr, bf ? m->conv[3].db : nullptr, bf ? G0 : nullptr);
-  conv_backward_filter(s, bf, m->A2, G0, m->conv[3].dw, bf ? nullptr : m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, G0b);
-  conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1, G0b, m->wtb[3], m->wtf[3]);
-  unpool_relu_backward(s, G1, m->A2, m->idx2, bf ? nullptr : G0, B, d.H1, d.W1, 128, 1, G0b, bf ? m->conv[2].db : nullptr, bf ? G0 : nullptr, bf ? m->A2b : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
-  conv_backward_filter(s, bf, m->A1, G0, m->conv[2].dw, bf ? nullptr : m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1, m->A1b, G0b);
-  conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1, G0b, m->wtb[2], m->wtf[2]);
-  conv1_backward(s, images, m->conv[1].w, m->conv[1].b, G1, m->conv[1].dw, m->conv[1].db, B, d.H, d.W,
+  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1, G0b, m->wtb[5], m->wtf[5]);
+  prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A4, m->idx4, bf ? nullptr : G0, B, d.H2, d.W2, 256, 2, G0b, bf ? m->conv[4].db : nullptr, bf ? G0 : nullptr, bf ? m->A4b : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
+  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, bf ? nullptr : m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, G0b);
+  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, G0b, m->wtb[4], m->wtf[4]);
+  prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y3, m->A3, G1, m->bn[3].w, m->bn[3].save, bf ? nullptr : G0, m->bn[3].dw, m->bn[3].db, m->bn_scratch,
+                   (int64_t)B * d.H2 * d.W2, 256, 0, G0b, bf ? m->A3b : nullptr, bf ? m->conv[3].db : nullptr, bf ? G0 : nullptr, bsync);
+  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A2, G0, m->conv[3].dw, bf ? nullptr : m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, G0b);
+  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1, G0b, m->wtb[3], m->wtf[3]);
+  prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A2, m->idx2, bf ? nullptr : G0, B, d.H1, d.W1, 128, 1, G0b, bf ? m->conv[2].db : nullptr, bf ? G0 : nullptr, bf ? m->A2b : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
+  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A1, G0, m->conv[2].dw, bf ? nullptr : m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1, m->A1b, G0b);
+  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1, G0b, m->wtb[2], m->wtf[2]);
+  prof_mark(m, AOCR_PROF_POOL_CONV1); conv1_backward(s, images, m->conv[1].w, m->conv[1].b, G1, m->conv[1].dw, m->conv[1].db, B, d.H, d.W,
                  (size_t)B * d.H1 * d.W1 * 128 >= (size_t)4096 * 640 ? G0 : nullptr);      // G0 is free here: use it as the partial slab
 }
 
@@ -366,6 +379,7 @@ void encoder_forward(aocr_model* m, const Dims& d) {
       const LstmP& p = m->enc[dir][l];
       const float* xin = l == 0 ? m->X : m->ehs[dir][l - 1] + slot;        // Dropout(0) = identity (S6)
       const bf16_t* xinb = l == 0 ? m->Xb : (m->ehs_b[dir][l - 1] ? m->ehs_b[dir][l - 1] + slot : nullptr);
+      prof_mark(m, AOCR_PROF_RNN_GEMM);
       if (bf && xinb && p.swi.wb && p.in % 32 == 0)
         gemm_hh(s, xinb, p.in, p.swi.wb, p.in, m->ezx[dir][l], 4 * He, T * B, 4 * He, p.in, p.bi, p.bh, 0);
       else
@@ -377,7 +391,9 @@ void encoder_forward(aocr_model* m, const Dims& d) {
         zl.add(m->ehs_b[dir][l], slot * sizeof(bf16_t)); zl.add(m->ehs_b[dir][l] + (size_t)(T + 1) * slot, slot * sizeof(bf16_t));
       }
     }
+    prof_mark(m, AOCR_PROF_OTHER);
     zero_many(s, zl);
+    prof_mark(m, AOCR_PROF_ENC_SEQ);
     const bool top = l == m->Le - 1;
     if (getenv("AOCR_TRACE")) fprintf(stderr, "[aocr] encoder layer %d forward: %s kernels\n", l, seq_kernels_ok(m, B) ? "whole-sequence" : "per-step");
     if (seq_kernels_ok(m, B)) {                         // whole-sequence kernel: one launch for all T steps of both directions
@@ -412,6 +428,7 @@ void encoder_forward(aocr_model* m, const Dims& d) {
     }
   }
   // bf16 mode: the attention kernels of the decoder (2 x L launches per step) read the context from a bf16 shadow
+  prof_mark(m, AOCR_PROF_OTHER);
   if (m->context_b) copy2d_bf16(s, m->context, Hd, m->context_b, Hd, B * T, Hd);
 }
 
@@ -423,6 +440,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
   const size_t slot = (size_t)B * He;
   for (int l = m->Le - 1; l >= 0; --l) {
     const bool top = l == m->Le - 1;
+    prof_mark(m, AOCR_PROF_ENC_SEQ);
     for (int dir = 0; dir < 2; ++dir) {
       if (top) copy2d(s, m->dc_st[0] + dir * He, Hd, m->edc[dir], He, B, He);        // model.lua:666,680
       else hipMemsetAsync(m->edc[dir], 0, slot * sizeof(float), s);
@@ -465,6 +483,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       }
       run_gates_bwd(m, 2, la, ww, ee, B, He, lah);
     }
+    prof_mark(m, AOCR_PROF_RNN_GEMM);
     WGradProblem wg[4]; int nwg = 0;
     for (int dir = 0; dir < 2; ++dir) {
       const LstmP& p = m->enc[dir][l];
@@ -574,12 +593,14 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
   hipStream_t s = m->s; const bool bf = m->bf16;
   const int B = d.B, T = d.T, L = d.L, Hd = m->Hd, E = m->E;
   const size_t slot = (size_t)B * Hd;
+  prof_mark(m, AOCR_PROF_RNN_GEMM);
   embedding_gather(s, m->lookup, tgt, st, sb, m->emb_all, L, B, E);
   const LstmP& p1 = m->dec[0];
   gemm(s, bf, m->emb_all, E, true, p1.wi, p1.in, true, m->zx1_all, 4 * Hd, L * B, 4 * Hd, E, p1.bi, p1.bh, 0);
   float* c0[MAXL]; float* h0[MAXL];
   for (int l = 0; l < m->Ld; ++l) { c0[l] = m->dcs[l]; h0[l] = m->dhs[l]; }
   const bool sh = m->bf16 && m->out_b != nullptr;
+  prof_mark(m, AOCR_PROF_DEC_FWD);
   dec_init_state(m, d, c0, h0, m->out_all, B, sh);
   for (int t = 0; t < L; ++t) {
     DecStepIO io; io.R = B; io.ctx_div = 1;
@@ -597,12 +618,14 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
     }
     dec_step_forward(m, io, T);
   }
+  prof_mark(m, AOCR_PROF_RNN_GEMM);
   gemm(s, bf, m->out_all + slot, Hd, true, m->wo, Hd, true, m->logits, LOGIT_LD, L * B, m->V, Hd, m->bo, nullptr, 0);
 }
 
 void loss_and_dlogits(aocr_model* m, const Dims& d, const int32_t* tge, int64_t st, int64_t sb, float grad_scale, bool want_grad,
                       float* loss_dev) {
   const int64_t rows = (int64_t)d.L * d.B;
+  prof_mark(m, AOCR_PROF_OTHER);
   logsoftmax_nll(m->s, m->logits, LOGIT_LD, tge, st, sb, d.B, nullptr, want_grad ? m->dlogits : nullptr, m->nll_rows, rows, m->V,
                  grad_scale);
   if (loss_dev) sum_to_scalar(m->s, m->nll_rows, rows, loss_dev);
@@ -615,9 +638,11 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   const size_t slot = (size_t)B * Hd;
   const int rows = L * B;
   // projector backward for all steps at once (model.lua:648): d(out) part, gradWeight, gradBias
+  prof_mark(m, AOCR_PROF_RNN_GEMM);
   gemm(s, bf, m->dlogits, LOGIT_LD, true, m->wo, Hd, false, m->dout_proj, Hd, rows, Hd, V, nullptr, nullptr, 0);
   gemm(s, bf, m->dlogits, LOGIT_LD, false, m->out_all + slot, Hd, false, m->dwo, Hd, V, Hd, rows, nullptr, nullptr, EP_ATOMIC);
   colsum_accum(s, m->dlogits, LOGIT_LD, rows, V, m->dbo);
+  prof_mark(m, AOCR_PROF_DEC_BWD);
   { ZeroList zl; for (int l = 0; l < Ld; ++l) { zl.add(m->dh_rec[l], slot * sizeof(float)); zl.add(m->dc_st[l], slot * sizeof(float)); } zero_many(s, zl); }
   const bool feed_fused = m->cfg.input_feed && Ld <= 2;  // the feed product joins the grouped launch and carries the tanh backward
   for (int t = L - 1; t >= 0; --t) {
@@ -689,6 +714,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
     }
   }
   // ---- hoisted parameter gradients (accGradParameters of every clone summed over time)
+  prof_mark(m, AOCR_PROF_RNN_GEMM);
   const float* h_top_all = m->dhs[Ld - 1] + slot;
   WGradProblem wg[16]; int nwg = 0;
   const bool sh = m->bf16 && m->dpre_b != nullptr;

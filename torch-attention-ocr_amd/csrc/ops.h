@@ -114,12 +114,14 @@ void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pool
 // dbias + partial (>= 2048*C floats scratch): fused bias gradient, dy may then be null; pooledb: bf16 shadow of pooled (mask source)
 void bf16_to_f32(hipStream_t s, const bf16_t* src, float* dst, int64_t n);
 size_t bn_scratch_bytes(int C);
+// synchronised BatchNorm: sums `count` elements (dtype 1 = fp64) of a device buffer over the data-parallel ranks, on stream s
+struct BnSync { int (*allreduce)(void* ctx, void* buf, int64_t count, int dtype, hipStream_t s); void* ctx; };
 void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, const float* b, float* rm, float* rv,
                      float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows,
-                     bf16_t* yb = nullptr);
+                     bf16_t* yb = nullptr, const BnSync* sync = nullptr);
 void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
                       float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb = nullptr,
-                      const bf16_t* yb = nullptr, float* conv_dbias = nullptr, float* partial = nullptr);
+                      const bf16_t* yb = nullptr, float* conv_dbias = nullptr, float* partial = nullptr, const BnSync* sync = nullptr);
 // yb: bf16 shadow of y (ReLU mask source); conv_dbias + partial (>= 4096*256 floats): fused bias gradient of the preceding conv, dx may then be null
 // ctx_div: rows r share context row r / ctx_div (beam search keeps one context per image, model.lua:373)
 void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a, float* c, int64_t ldc, int B, int T, int Hd,

@@ -358,7 +358,7 @@ void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pool
 // scratch layout: double part[BN_CHUNKS][C][2], then double fin[C][2].
 // =============================================================================================
 static const int BN_CHUNKS = 512;
-size_t bn_scratch_bytes(int C) { return (size_t)(BN_CHUNKS + 1) * C * 2 * sizeof(double); }
+size_t bn_scratch_bytes(int C) { return (size_t)(BN_CHUNKS + 1) * C * 2 * sizeof(double) + 64; }   // + the row count that travels with the synchronised sums
 
 // mode 0: (sum x, sum x^2);  mode 1: (sum dy, sum dy*xhat) with dy = dA*(y>0), xhat = (x-mean)*invstd
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
@@ -434,6 +434,32 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const double* __re
     rv[c] = (float)(0.1 * unb + 0.9 * (double)rv[c]);
   }
 }
+// ---- synchronised BatchNorm (data parallelism): the per-channel sums leave the reduction un-normalised, travel through ONE
+// all-reduce together with the row count (fin[2C]), and are normalised by the global count afterwards.
+__global__ __launch_bounds__(256) void bn_sums_kernel(const double* __restrict__ part, int nchunk, int64_t rows, int C, double* fin, float* dw,
+                                                      float* db) {
+  int c; double s, ss;
+  if (blockIdx.x == 0 && threadIdx.x == 0) fin[2 * C] = (double)rows;
+  if (!bn_reduce_partials(part, nchunk, C, c, s, ss)) return;
+  fin[c * 2] = s; fin[c * 2 + 1] = ss;
+  if (dw) { dw[c] += (float)ss; db[c] += (float)s; }                       // backward: the LOCAL sums (the gradient exchange adds the ranks up)
+}
+__global__ void bn_fwd_stats_kernel(const double* __restrict__ fin, int C, float* save, float* rm, float* rv, int update_running) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double n = fin[2 * C], mean = fin[c * 2] / n; double var = fin[c * 2 + 1] / n - mean * mean;
+  if (var < 0) var = 0;
+  save[c] = (float)mean; save[C + c] = (float)(1.0 / sqrt(var + 1e-5));
+  if (update_running) {
+    const double unb = n > 1 ? var * n / (n - 1.0) : var;
+    rm[c] = (float)(0.1 * mean + 0.9 * (double)rm[c]);
+    rv[c] = (float)(0.1 * unb + 0.9 * (double)rv[c]);
+  }
+}
+__global__ void bn_bwd_scale_kernel(double* fin, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * C) fin[i] = fin[i] / fin[2 * C];
+}
 __global__ void bn_eval_prepare_kernel(const float* rm, const float* rv, float* save, int C) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) { save[c] = rm[c]; save[C + c] = (float)(1.0 / sqrt((double)rv[c] + 1e-5)); }
@@ -504,13 +530,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, const float* b, float* rm, float* rv,
-                     float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows, bf16_t* yb) {
+                     float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows, bf16_t* yb,
+                     const BnSync* sync) {
   int T = tb_rows > 0 ? (int)(rows / tb_rows) : 0;
   if (training) {
     double* part = (double*)scratch;
     int nchunk = (int)std::min<int64_t>(BN_CHUNKS, (rows + 63) / 64);
     hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, x, nullptr, nullptr, nullptr, part, rows,
                        C, 0, 0, 0, nullptr);
+    if (sync) {                                           // statistics of the GLOBAL batch: (sum x, sum x^2, rows) summed over the ranks
+      double* fin = part + (size_t)BN_CHUNKS * C * 2;
+      hipLaunchKernelGGL(bn_sums_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, part, nchunk, rows, C, fin, nullptr, nullptr);
+      sync->allreduce(sync->ctx, fin, 2 * C + 1, 1, s);
+      hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, fin, C, save, rm, rv, update_running);
+    } else
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, part, nchunk, rows, C, save, rm, rv,
                        update_running);
   } else {
@@ -522,12 +555,17 @@ void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, co
 }
 void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
                       float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb,
-                      const bf16_t* yb, float* conv_dbias, float* partial) {
+                      const bf16_t* yb, float* conv_dbias, float* partial, const BnSync* sync) {
   int T = tb_rows > 0 ? (int)(rows / tb_rows) : 0;
   double* part = (double*)scratch;
   double* fin = part + (size_t)BN_CHUNKS * C * 2;
   int nchunk = (int)std::min<int64_t>(BN_CHUNKS, (rows + 63) / 64);
   hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, x, y, dA, save, part, rows, C, 1, tb_rows, T, yb);
+  if (sync) {                                             // mean(dy), mean(dy * xhat) over the GLOBAL batch
+    hipLaunchKernelGGL(bn_sums_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, part, nchunk, rows, C, fin, dw, db);
+    sync->allreduce(sync->ctx, fin, 2 * C + 1, 1, s);
+    hipLaunchKernelGGL(bn_bwd_scale_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, fin, C);
+  } else
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, part, nchunk, rows, C, save, fin, dw, db);
   const int C4 = C / 4;
   int64_t total = rows * C4;
