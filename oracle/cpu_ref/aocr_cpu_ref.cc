@@ -44,6 +44,8 @@ int nthreads() {
 #endif
 }
 
+inline int small_team(long items) { return (int)std::max<long>(1, std::min<long>(std::min<long>(items, nthreads()), 16)); }   // per-timestep element-wise loops
+
 // ------------------------------------------------------------------------------------------------ GEMM
 // C[M,N] (ldc) (+)= sum_k a(i,k) * B[k*ldb + j],  a(i,k) = A[i*sai + k*sak]; B and C have unit stride along j.
 // 6 x (2 vectors of 64 bytes) register tile, k blocked by 256; `par` spreads (row block, column tile) tasks over the OpenMP team.
@@ -140,7 +142,9 @@ void gemm(int M, int N, int K, const T* A, long sai, long sak, const T* B, long 
   const int ib = (M + Q::IB - 1) / Q::IB, jb = (N + Q::JB - 1) / Q::JB;
   const long tasks = (long)ib * jb;
   if (par && tasks > 1) {
-    const int team = (int)std::min<long>(tasks, nthreads());
+    // team size by the amount of work: a 128-thread team costs more in fork / barrier time than a per-timestep GEMM takes
+    const double mflop = 2.0 * M * N * (double)K / 1e6;
+    const int team = (int)std::max<long>(1, std::min<long>(std::min<long>(tasks, nthreads()), std::min<long>(32, (long)(mflop / 2.0))));
 #pragma omp parallel num_threads(team)
     {
       std::vector<T> bpack((size_t)Q::KC * Q::NR + 16), apack((size_t)Q::IT * Q::KC * Q::MR + 16);
@@ -435,7 +439,7 @@ template <class T> void cell_forward(const LstmW<T>& w, const Linear<T>& li, con
   cc.x.resize((size_t)B * w.in); for (int b = 0; b < B; ++b) std::copy(x + (size_t)b * ldx, x + (size_t)b * ldx + w.in, cc.x.begin() + (size_t)b * w.in);
   cc.c_prev.assign(c_prev, c_prev + (size_t)B * H); cc.h_prev.assign(h_prev, h_prev + (size_t)B * H);
   cc.gates.resize((size_t)B * 4 * H); cc.c.resize((size_t)B * H); cc.h.resize((size_t)B * H);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(small_team(B))
   for (int b = 0; b < B; ++b) for (int j = 0; j < H; ++j) {
     const size_t o = (size_t)b * 4 * H;
     const T ig = sigm(z[o + j] + z2[o + j]), fg = sigm(z[o + H + j] + z2[o + H + j]), og = sigm(z[o + 2 * H + j] + z2[o + 2 * H + j]);
@@ -448,7 +452,7 @@ template <class T> void cell_forward(const LstmW<T>& w, const Linear<T>& li, con
 // dc/dh in: gradient wrt (c_out, h_out); out: dz (B,4H), dc_prev in place of dc
 template <class T> void cell_backward_gates(const CellCache<T>& cc, int B, int H, std::vector<T>& dc, const std::vector<T>& dh, std::vector<T>& dz) {
   dz.resize((size_t)B * 4 * H);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(small_team(B))
   for (int b = 0; b < B; ++b) for (int j = 0; j < H; ++j) {
     const size_t o = (size_t)b * 4 * H, s = (size_t)b * H + j;
     const T ig = cc.gates[o + j], fg = cc.gates[o + H + j], og = cc.gates[o + 2 * H + j], gg = cc.gates[o + 3 * H + j];
@@ -467,7 +471,7 @@ template <class T> struct AttnCache { std::vector<T> q, a, cat, out; };
 template <class T> void attn_forward(const Linear<T>& la, const Linear<T>& lc, const T* h_top, const T* ctx, int R, int ctx_div, int Tn, int Hd, AttnCache<T>& ac) {
   ac.q.resize((size_t)R * Hd); ac.a.resize((size_t)R * Tn); ac.cat.resize((size_t)R * 2 * Hd); ac.out.resize((size_t)R * Hd);
   la.fwd(h_top, Hd, R, ac.q.data(), Hd, false);                                                              // LinearNoBias, :131
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(small_team(R))
   for (int r = 0; r < R; ++r) {
     const T* cx = ctx + (size_t)(r / ctx_div) * Tn * Hd; T* a = ac.a.data() + (size_t)r * Tn; const T* q = ac.q.data() + (size_t)r * Hd;
     T mx = -INFINITY;
@@ -615,7 +619,7 @@ int train_step(const Cfg& cfg, T* params, T* bn_state, const T* images, const in
     for (size_t i = 0; i < dpre.size(); ++i) dpre[i] = dout[i] * (T(1) - st.at.out[i] * st.at.out[i]);
     linear_bwd_weight(dpre.data(), Hd, st.at.cat.data(), 2 * Hd, B, Hd, 2 * Hd, G.wc);
     linear_bwd_input(dpre.data(), Hd, M.P.wc, B, Hd, 2 * Hd, dcat.data(), 2 * Hd, false);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(small_team(B))
     for (int b = 0; b < B; ++b) {
       const T* cx = M.context.data() + (size_t)b * Tn * Hd; T* dcx = dctx.data() + (size_t)b * Tn * Hd;
       const T* a = st.at.a.data() + (size_t)b * Tn; const T* dcv = dcat.data() + (size_t)b * 2 * Hd; const T* q = st.at.q.data() + (size_t)b * Hd;

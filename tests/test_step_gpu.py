@@ -190,34 +190,75 @@ def test_dma_conv_kernel_matches_tiled_kernel(cuda, monkeypatch, B, W):
 
 
 @pytest.mark.parametrize("He,B,W,Le", [(64, 16, 40, 1), (256, 32, 72, 1), (128, 16, 36, 1), (64, 16, 44, 2), (256, 16, 36, 2),
-                                        (64, 16, 800, 1)])          # W = 800: T = 199 steps (BASELINE C4 upper width)
+                                        (64, 16, 800, 1),           # W = 800: T = 199 steps (BASELINE C4 upper width)
+                                        (512, 16, 100, 1), (512, 40, 52, 2), (256, 21, 60, 1), (128, 70, 36, 1)])   # He = 512; ragged batches
 def test_seq_encoder_kernels_match_step_kernels(cuda, monkeypatch, He, B, W, Le):
-    """Whole-sequence BiLSTM encoder kernels (one workgroup owns 16 batch rows for all T steps, weights re-streamed by
-    LDS-DMA) against the per-step kernels on the same bf16 operands: only fp32 summation order differs.
-    AOCR_NO_SEQ=1 forces the per-step path."""
+    """The whole-sequence BiLSTM encoder kernels against the per-step kernels on the same bf16 operands (only fp32 summation order
+    differs).  Two families: CLUSTER kernels (rnn_cluster.hip: He/64 CUs share 16 rows, recurrent weights resident in registers,
+    h(t) / partial d h exchanged as tagged granules; any batch size, He up to 512) and the one-workgroup-per-16-rows kernels
+    (rnn_seq.hip, B % 16 == 0, He <= 256; AOCR_NO_CLUSTER=1).  AOCR_NO_SEQ=1 forces the per-step path."""
     cfg = dict(enc_hidden=He, enc_layers=Le, dec_layers=2, input_feed=True)      # Le = 2: the lower layer takes its d h from the layer above
     out = {}
-    for no_seq in ("0", "1"):          # whole-sequence path first: it must not be able to inherit the other run's buffers
-        monkeypatch.setenv("AOCR_NO_SEQ", no_seq)
+    variants = {"cluster": {}, "step": {"AOCR_NO_SEQ": "1"}}
+    if B % 16 == 0 and He <= 256:
+        variants["seq"] = {"AOCR_NO_CLUSTER": "1"}
+    for name, env in variants.items():          # the new paths first: they must not be able to inherit another run's buffers
+        monkeypatch.delenv("AOCR_NO_SEQ", raising=False); monkeypatch.delenv("AOCR_NO_CLUSTER", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=6, compute="bf16")
         loss = m.train_forward_backward(batch)
-        out[no_seq] = dict(loss=loss, context=m.get_tensor("context").clone(), logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(),
-                           dfeats=m.get_tensor("dfeats").clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        loss2 = m.train_forward_backward(batch)                 # a second step on the same model: the exchange tags move on with the launch epoch
+        assert loss2 == pytest.approx(loss, rel=1e-5)
+        if name == "cluster":
+            assert int(m.get_tensor("cl_err").view(torch.int32)[0]) == 0, "a cluster kernel timed out waiting for its group"
+        out[name] = dict(loss=loss, context=m.get_tensor("context").clone(), logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(),
+                         dfeats=m.get_tensor("dfeats").clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.shutdown()
+    a = out["step"]
+    for name in variants:
+        if name == "step":
+            continue
+        b = out[name]
+        for k in ("context", "logits"):
+            e = (a[k].double() - b[k].double()).abs().max().item()
+            print(f"[parity] {name}-vs-step He={He} B={B} {k} max-abs {e:.3e}")
+            assert e < 5e-3, (name, k)  # bf16 re-rounding of h(t) after a different fp32 summation order, compounded over T steps
+        assert abs(a["loss"] - b["loss"]) < 2e-3 * max(1.0, abs(a["loss"]))
+        e = relerr(b["dfeats"], a["dfeats"]); print(f"[parity] {name}-vs-step dfeats rel {e:.3e}"); assert e < 3e-2
+        worst = 0.0
+        for k in a["grads"]:
+            if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):      # bias in front of a BatchNorm: exact gradient 0, only rounding noise
+                continue
+            e = relerr(b["grads"][k], a["grads"][k]); worst = max(worst, e)
+            assert e < 3e-2, (name, k, e)
+        print(f"[parity] {name}-vs-step worst gradient rel {worst:.3e}")
+
+
+@pytest.mark.parametrize("He,B,W", [(256, 8, 416), (256, 8, 800), (256, 4, 1100), (512, 8, 100), (512, 8, 420), (512, 4, 600)])
+def test_attention_bf16_general_T_matches_generic(cuda, monkeypatch, He, B, W):
+    """attn_bf16_kernel (bf16 context shadow; register-resident slice for T <= 256 at Hd = 512 / T <= 128 at Hd = 1024, two streamed
+    passes beyond) against the generic fp32-context kernel (AOCR_NO_ATTN_BF16=1) inside the whole train step: T = 103, 199, 274 at
+    Hd = 512; T = 24, 104, 149 at Hd = 1024.  The two differ by the bf16 rounding of the context only."""
+    cfg = dict(enc_hidden=He, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for knob in ("0", "1"):
+        if knob == "1":
+            monkeypatch.setenv("AOCR_NO_ATTN_BF16", "1")
+        else:
+            monkeypatch.delenv("AOCR_NO_ATTN_BF16", raising=False)
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=6, compute="bf16")
+        loss = m.train_forward_backward(batch)
+        out[knob] = dict(loss=loss, logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), dctx=m.get_tensor("dcontext").clone(),
+                         grads={k: v.clone() for k, v in m.get_gradients().items()})
         m.shutdown()
     a, b = out["1"], out["0"]
-    for k in ("context", "logits"):
-        e = (a[k].double() - b[k].double()).abs().max().item()
-        print(f"[parity] seq-vs-step He={He} {k} max-abs {e:.3e}")
-        assert e < 5e-3, k        # bf16 re-rounding of h(t) after a different fp32 summation order, compounded over T steps
-    assert abs(a["loss"] - b["loss"]) < 2e-3 * max(1.0, abs(a["loss"]))
-    e = relerr(b["dfeats"], a["dfeats"]); print(f"[parity] seq-vs-step dfeats rel {e:.3e}"); assert e < 3e-2
-    worst = 0.0
-    for k in a["grads"]:
-        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):      # bias in front of a BatchNorm: exact gradient 0, only rounding noise
-            continue
-        e = relerr(b["grads"][k], a["grads"][k]); worst = max(worst, e)
-        assert e < 3e-2, (k, e)
-    print(f"[parity] seq-vs-step worst gradient rel {worst:.3e}")
+    e = (a["logits"].double() - b["logits"].double()).abs().max().item()
+    r = relerr(b["dctx"], a["dctx"])
+    print(f"[parity] attention bf16 general-T He={He} W={W}: logits max-abs {e:.3e}, d(context) rel {r:.3e}, loss {b['loss']:.4f} vs {a['loss']:.4f}")
+    assert e < 5e-3 and r < 3e-2
+    for k in ("dec.attn.wa", "dec.attn.wc", "dec.l2.h2h.w", "enc_fw.l1.h2h.w"):
+        assert relerr(b["grads"][k], a["grads"][k]) < 3e-2, k
 
 
 def test_c3_full_size_kernel_paths_agree(cuda, monkeypatch):

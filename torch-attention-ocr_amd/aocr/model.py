@@ -395,9 +395,9 @@ class Model:
         # word scoring on device (evalWordErrRate, utils.lua:136-175): one Levenshtein distance per row, a word is right iff it is 0
         tge_dev = torch.full((B, Lt), PAD, dtype=torch.int32, device=self.device)
         tge_dev[:, :target_l] = targets_eval
-        dist, tlen = edit_distance_device(labels, tge_dev, self._stream())
+        edist, tlen = edit_distance_device(labels, tge_dev, self._stream())
         labels_h = labels.cpu().numpy()
-        dist_h, tlen_h = dist.cpu().numpy(), tlen.cpu().numpy()
+        dist_h, tlen_h = edist.cpu().numpy(), tlen.cpu().numpy()
         word_err = float((dist_h != 0).sum())
         labels_pred, labels_gold = [], []
         if self.visualize:

@@ -159,6 +159,11 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
   m->tgt_pad = a.get<int32_t>(B * L); m->tge_pad = a.get<int32_t>(B * L);
   m->trie_loc[0] = a.get<int32_t>(R); m->trie_loc[1] = a.get<int32_t>(R);
   m->sgd_scratch = a.get<char>(sgd_scratch_bytes());
+  if (m->bf16 && He % 64 == 0 && He <= 512) {                    // exchange buffers of the cluster encoder kernels
+    m->cl_xbytes = enc_cluster_xbuf_bytes((int)B, (int)He); m->cl_pbytes = enc_cluster_pbuf_bytes((int)B, (int)He);
+    m->cl_xbuf = a.get<unsigned long long>(m->cl_xbytes / 8); m->cl_pbuf = a.get<unsigned long long>(m->cl_pbytes / 8);
+    m->cl_err = a.get<int>(16);
+  }
   m->shadow_dev = m->bf16 ? a.get<ShadowJob>(128) : nullptr;
   m->ws_bytes = a.off + 256;
   if (base && a.off > bytes) return -1;
@@ -369,6 +374,24 @@ static bool seq_kernels_ok(const aocr_model* m, int B) {
   return enc_seq_supported(B, m->He, cus);
 }
 
+// The cluster kernels (rnn_cluster.hip) need bf16 shadows and He in {64,128,256,512}; any batch size.  AOCR_NO_CLUSTER=1 falls back to
+// the one-workgroup-per-16-rows kernels / the per-step kernels (parity tests compare the paths).
+static bool cluster_ok(const aocr_model* m, int B, int T, int& G, int& RT, int& groups) {
+  if (!m->bf16 || !m->cl_xbuf || !m->ehs_b[0][0] || !m->enc[0][0].swh.wb || !m->edz_b[0][0]) return false;
+  const char* e = getenv("AOCR_NO_CLUSTER");
+  if (e && e[0] == '1') return false;
+  e = getenv("AOCR_NO_SEQ");                              // "no whole-sequence kernels at all": the per-step launch chain
+  if (e && e[0] == '1') return false;
+  static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  return enc_cluster_plan(B, m->He, T, cus, G, RT, groups);
+}
+static unsigned next_epoch(aocr_model* m) {
+  if (++m->cl_epoch >= (1u << 20)) {                              // tags would repeat: clear the buffers and start over
+    hipMemsetAsync(m->cl_xbuf, 0, m->cl_xbytes, m->s); hipMemsetAsync(m->cl_pbuf, 0, m->cl_pbytes, m->s); m->cl_epoch = 1;
+  }
+  return m->cl_epoch;
+}
+
 void encoder_forward(aocr_model* m, const Dims& d) {
   hipStream_t s = m->s; const bool bf = m->bf16;
   const int B = d.B, T = d.T, He = m->He, Hd = m->Hd;
@@ -395,7 +418,19 @@ void encoder_forward(aocr_model* m, const Dims& d) {
     zero_many(s, zl);
     prof_mark(m, AOCR_PROF_ENC_SEQ);
     const bool top = l == m->Le - 1;
-    if (getenv("AOCR_TRACE")) fprintf(stderr, "[aocr] encoder layer %d forward: %s kernels\n", l, seq_kernels_ok(m, B) ? "whole-sequence" : "per-step");
+    int clG = 0, clRT = 0, clGroups = 0;
+    const bool cluster = cluster_ok(m, B, T, clG, clRT, clGroups);
+    if (getenv("AOCR_TRACE")) fprintf(stderr, "[aocr] encoder layer %d forward: %s kernels\n", l, cluster ? "cluster" : seq_kernels_ok(m, B) ? "whole-sequence" : "per-step");
+    if (cluster) {                                        // groups of He/64 CUs, recurrent weights resident in registers
+      EncClFwdArgs a; a.B = B; a.T = T; a.He = He; a.Hd = Hd; a.groups = clGroups; a.epoch = next_epoch(m); a.xbuf = m->cl_xbuf; a.err = m->cl_err;
+      for (int dir = 0; dir < 2; ++dir) {
+        EncSeqDir& e = a.d[dir];
+        e.w = m->enc[dir][l].swh.wb; e.zx = m->ezx[dir][l]; e.hs = m->ehs[dir][l]; e.cs = m->ecs[dir][l]; e.hsb = m->ehs_b[dir][l];
+        e.gates = m->egates[dir][l]; e.ctx = top ? m->context + dir * He : nullptr; e.reverse = dir;
+      }
+      enc_cluster_forward(s, a, clG, clRT);
+      continue;
+    }
     if (seq_kernels_ok(m, B)) {                         // whole-sequence kernel: one launch for all T steps of both directions
       EncSeqFwdArgs a; a.B = B; a.T = T; a.He = He; a.Hd = Hd;
       for (int dir = 0; dir < 2; ++dir) {
@@ -445,9 +480,23 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       if (top) copy2d(s, m->dc_st[0] + dir * He, Hd, m->edc[dir], He, B, He);        // model.lua:666,680
       else hipMemsetAsync(m->edc[dir], 0, slot * sizeof(float), s);
     }
-    const bool seq = seq_kernels_ok(m, B) && m->edz_b[0][l] && m->enc[0][l].swh.wtb;
-    if (getenv("AOCR_TRACE")) fprintf(stderr, "[aocr] encoder layer %d backward: %s kernels\n", l, seq ? "whole-sequence" : "per-step");
-    if (seq) {
+    int clG = 0, clRT = 0, clGroups = 0;
+    const bool cluster = cluster_ok(m, B, T, clG, clRT, clGroups) && m->edz_b[0][l] && m->enc[0][l].swh.wtb;
+    const bool seq = cluster || (seq_kernels_ok(m, B) && m->edz_b[0][l] && m->enc[0][l].swh.wtb);
+    if (getenv("AOCR_TRACE")) fprintf(stderr, "[aocr] encoder layer %d backward: %s kernels\n", l, cluster ? "cluster" : seq ? "whole-sequence" : "per-step");
+    if (cluster) {
+      EncClBwdArgs a; a.B = B; a.T = T; a.He = He; a.groups = clGroups; a.epoch = next_epoch(m); a.pbuf = m->cl_pbuf; a.err = m->cl_err;
+      for (int dir = 0; dir < 2; ++dir) {
+        EncSeqBwdDir& e = a.d[dir];
+        e.wt = m->enc[dir][l].swh.wtb;
+        if (top) { e.dh1 = m->dctx + dir * He; e.dh1_row = (int64_t)T * Hd; e.dh1_t = Hd; }      // model.lua:670,684
+        else { e.dh1 = m->edxl[dir]; e.dh1_row = He; e.dh1_t = (int64_t)slot; }
+        e.dh2 = top ? m->dh_rec[0] + dir * He : nullptr; e.dh2_row = Hd;                            // model.lua:667,681
+        e.dc = m->edc[dir]; e.gates = m->egates[dir][l]; e.cs = m->ecs[dir][l];
+        e.dz = m->edz[dir][l]; e.dzb = m->edz_b[dir][l]; e.forward_dir = dir == 0;
+      }
+      enc_cluster_backward(s, a, clG, clRT);
+    } else if (seq) {
       EncSeqBwdArgs a; a.B = B; a.T = T; a.He = He;
       for (int dir = 0; dir < 2; ++dir) {
         EncSeqBwdDir& e = a.d[dir];

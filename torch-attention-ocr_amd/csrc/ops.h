@@ -200,6 +200,14 @@ struct EncSeqBwdDir {
 };
 struct EncSeqBwdArgs { EncSeqBwdDir d[2]; int B, T, He; };
 bool enc_seq_supported(int B, int He, int blocks_limit);
+// ---- the same recurrences on clusters of CUs with register-resident weights (rnn_cluster.hip)
+struct EncClFwdArgs { EncSeqDir d[2]; int B, T, He, Hd, groups; unsigned epoch; unsigned long long* xbuf; int* err; int gid0 = 0, ngid = 0; };
+struct EncClBwdArgs { EncSeqBwdDir d[2]; int B, T, He, groups; unsigned epoch; unsigned long long* pbuf; int* err; int gid0 = 0, ngid = 0; };
+bool enc_cluster_plan(int B, int He, int T, int cus, int& G, int& RT, int& groups);
+size_t enc_cluster_xbuf_bytes(int B, int He);
+size_t enc_cluster_pbuf_bytes(int B, int He);
+void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a, int G, int RT);
+void enc_cluster_backward(hipStream_t s, const EncClBwdArgs& a, int G, int RT);
 void enc_seq_backward(hipStream_t s, const EncSeqBwdArgs& a);
 void enc_seq_forward(hipStream_t s, const EncSeqFwdArgs& a);
 // data path (data.hip): 255*rgb2y + image.scale to (out_h, out_w) for n images sharing out_w

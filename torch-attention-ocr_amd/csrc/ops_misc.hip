@@ -807,12 +807,128 @@ __global__ __launch_bounds__(64 * NW) void attn_reg_h512_kernel(const bf16_t* __
   }
 }
 
+// General-T form of the bf16-context kernel, Hd = 512 * NC (He = 256: BASELINE C3/C4; He = 512: the reference default and C5).
+// 16 waves per batch row, wave w owns context rows t = w, w+16, ...  STREAM = false: the row's whole (T <= 16 RW, Hd) slice sits in
+// registers (RW x NC 16-byte fragments per lane) and serves the score pass and the weighted-sum pass -- one read of the context, as in
+// attn_reg_h512_kernel, for T up to 256 (C4's widest bucket is T = 199).  STREAM = true: any T (C5: T = 1785), two passes over the
+// bf16 shadow in chunks of 16 RW rows, scores parked in LDS in between.  Softmax / its backward over T by wave 0.
+template <bool BWD, int NC, int RW, bool STREAM>
+__global__ __launch_bounds__(1024) void attn_bf16_kernel(const bf16_t* __restrict__ ctx, const float* __restrict__ u, int64_t ldu,
+                                                         const float* __restrict__ a_in, float* __restrict__ p_out,
+                                                         float* __restrict__ o, int64_t ldo, int T, int ctx_div,
+                                                         bf16_t* __restrict__ ob, int64_t ldob) {
+  constexpr int NW = 16, Hd = 512 * NC;
+  extern __shared__ float sc[];                                 // T scores / probabilities
+  __shared__ __attribute__((aligned(16))) float red[NW][Hd];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bf16_t* cb = ctx + (int64_t)(b / ctx_div) * T * Hd + lane * 8;
+  const float* ub = u + (int64_t)b * ldu + lane * 8;
+  float uu[NC][8];
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) {
+    const float4 u0 = *reinterpret_cast<const float4*>(ub + cc * 512), u1 = *reinterpret_cast<const float4*>(ub + cc * 512 + 4);
+    uu[cc][0] = u0.x; uu[cc][1] = u0.y; uu[cc][2] = u0.z; uu[cc][3] = u0.w; uu[cc][4] = u1.x; uu[cc][5] = u1.y; uu[cc][6] = u1.z; uu[cc][7] = u1.w;
+  }
+  bf16x8 c[RW][NC];
+  auto load_rows = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int t = t0 + wave + NW * i;
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) {
+        if (t < T) c[i][cc] = *reinterpret_cast<const bf16x8*>(cb + (int64_t)t * Hd + cc * 512);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) c[i][cc][e] = (bf16_t)0.f;
+        }
+      }
+    }
+  };
+  auto scores = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf((float)c[i][cc][e], uu[cc][e], s);
+      s = wave_sum(s);
+      const int t = t0 + wave + NW * i;
+      if (lane == 0 && t < T) sc[t] = s;
+    }
+  };
+  if (!STREAM) { load_rows(0); scores(0); }
+  else for (int t0 = 0; t0 < T; t0 += NW * RW) { load_rows(t0); scores(t0); }
+  __syncthreads();
+  if (wave == 0) {                                              // softmax (forward) / softmax backward over T
+    if (!BWD) {
+      float m = -INFINITY;
+      for (int t = lane; t < T; t += 64) m = fmaxf(m, sc[t]);
+      m = wave_max(m);
+      float sum = 0.f;
+      for (int t = lane; t < T; t += 64) { const float e = expf(sc[t] - m); sc[t] = e; sum += e; }
+      sum = wave_sum(sum);
+      const float inv = 1.f / sum;
+      for (int t = lane; t < T; t += 64) { const float p = sc[t] * inv; sc[t] = p; p_out[(int64_t)b * T + t] = p; }
+    } else {
+      float dot = 0.f;
+      for (int t = lane; t < T; t += 64) dot += a_in[(int64_t)b * T + t] * sc[t];
+      dot = wave_sum(dot);
+      for (int t = lane; t < T; t += 64) { const float p = a_in[(int64_t)b * T + t] * (sc[t] - dot); sc[t] = p; p_out[(int64_t)b * T + t] = p; }
+    }
+  }
+  __syncthreads();
+  float acc[NC][8];
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[cc][e] = 0.f;
+  auto accumulate = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int t = t0 + wave + NW * i;
+      const float p = t < T ? sc[t] : 0.f;
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[cc][e] = fmaf(p, (float)c[i][cc][e], acc[cc][e]);
+    }
+  };
+  if (!STREAM) accumulate(0);
+  else for (int t0 = 0; t0 < T; t0 += NW * RW) { load_rows(t0); accumulate(t0); }
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) {
+    *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8]) = make_float4(acc[cc][0], acc[cc][1], acc[cc][2], acc[cc][3]);
+    *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8 + 4]) = make_float4(acc[cc][4], acc[cc][5], acc[cc][6], acc[cc][7]);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < Hd; j += 64 * NW) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; q += 4) v += (red[q][j] + red[q + 1][j]) + (red[q + 2][j] + red[q + 3][j]);
+    o[(int64_t)b * ldo + j] = v;
+    if (ob) ob[(int64_t)b * ldob + j] = (bf16_t)v;
+  }
+}
+
 constexpr int ATTN_NW = 16;
 template <bool BWD>
 static void attn_launch(hipStream_t s, const float* ctx, const float* u, int64_t ldu, const float* a_in, float* p_out, float* o,
                         int64_t ldo, int B, int T, int Hd, int ctx_div, bf16_t* ob, int64_t ldob, const bf16_t* ctxb) {
+#define AOCR_ATTN_BF16(NC, RW, STREAM) do {                                                                                   \
+    if (64 * 1024 + (size_t)T * 4 > 64 * 1024)                                                                                  \
+      (void)hipFuncSetAttribute((const void*)attn_bf16_kernel<BWD, NC, RW, STREAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)T * 4)); \
+    hipLaunchKernelGGL((attn_bf16_kernel<BWD, NC, RW, STREAM>), dim3(B), dim3(1024), (size_t)T * sizeof(float), s, ctxb, u, ldu, a_in, p_out, o, \
+                       ldo, T, ctx_div, ob, ldob); } while (0)
+  const bool bf_ok = ctxb && ldu % 4 == 0 && !getenv("AOCR_NO_ATTN_BF16");
   if (T <= 64 && Hd == 512 && ctxb && ldu % 4 == 0)
     hipLaunchKernelGGL((attn_reg_h512_kernel<BWD, ATTN_NW>), dim3(B), dim3(64 * ATTN_NW), 0, s, ctxb, u, ldu, a_in, p_out, o, ldo, T, ctx_div, ob, ldob);
+  else if (bf_ok && Hd == 512 && T <= 128) AOCR_ATTN_BF16(1, 8, false);
+  else if (bf_ok && Hd == 512 && T <= 256) AOCR_ATTN_BF16(1, 16, false);
+  else if (bf_ok && Hd == 512) AOCR_ATTN_BF16(1, 4, true);
+  else if (bf_ok && Hd == 1024 && T <= 64) AOCR_ATTN_BF16(2, 4, false);
+  else if (bf_ok && Hd == 1024 && T <= 128) AOCR_ATTN_BF16(2, 8, false);
+  else if (bf_ok && Hd == 1024) AOCR_ATTN_BF16(2, 4, true);
   else if (T <= 64 && Hd == 512)
     hipLaunchKernelGGL((attn_reg_kernel<2, BWD, float>), dim3(B), dim3(256), 0, s, ctx, u, ldu, a_in, p_out, o, ldo, T, ctx_div, ob, ldob);
   else if (T <= 64 && Hd == 256)
@@ -1227,10 +1343,10 @@ __global__ __launch_bounds__(64) void beam_select_kernel(const float* __restrict
       float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
       if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
-    if (tv.mask) {                                              // fewer admissible candidates than beams: repeat the best one,
-      if (bi == 0x7fffffff) { best = first_best; bi = first_bi; }   // model.lua:419-433 (and the intent of :477-497, S11)
-      if (k == 0) { first_best = best; first_bi = bi; }
-    }
+    // fewer admissible candidates than beams: repeat the best one, model.lua:419-433 (and the intent of :477-497, S11).  The same
+    // fallback guards a row of NaN / -inf scores without a dictionary (a diverged model): the index must stay inside the row.
+    if (bi == 0x7fffffff) { best = first_best; bi = first_bi; }
+    if (k == 0) { first_best = best; first_bi = bi; }
     if (lane == 0) {
       cand[bi] = -INFINITY;
       tokens[b * kout + k] = bi % V + 1;                        // model.lua:456-458
@@ -1293,10 +1409,9 @@ __global__ __launch_bounds__(64 * PS_NW) void project_select_kernel(const float*
         float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
       }
-      if (tv.mask) {                                            // model.lua:419-433: repeat the best admissible candidate
-        if (bi == 0x7fffffff) { best = first_best; bi = first_bi; }
-        if (k == 0) { first_best = best; first_bi = bi; }
-      }
+      // model.lua:419-433: repeat the best admissible candidate; also the guard for NaN / -inf rows (see beam_select_kernel)
+      if (bi == 0x7fffffff) { best = first_best; bi = first_bi; }
+      if (k == 0) { first_best = best; first_bi = bi; }
       if (lane == 0) {
         cand[bi] = -INFINITY; cand[n + k] = best;
         tokens[b * kout + k] = bi % V + 1;
@@ -1400,6 +1515,8 @@ __global__ __launch_bounds__(64) void edit_distance_kernel(const int32_t* __rest
   if (target_len) target_len[b] = lg;
 }
 void edit_distance(hipStream_t s, const int32_t* labels, const int32_t* targets, int B, int L, int32_t* dist, int32_t* target_len) {
+  const size_t lds = (size_t)(L + 1) * 64 * sizeof(int32_t);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)edit_distance_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // L > 255: above the default dynamic-LDS limit
   hipLaunchKernelGGL(edit_distance_kernel, dim3(cdiv(B, 64)), dim3(64), (size_t)(L + 1) * 64 * sizeof(int32_t), s, labels, targets, B, L,
                      dist, target_len);
 }
