@@ -139,6 +139,7 @@ int aocr_model_create(const aocr_config* cfg, float* params_dev, float* grads_de
   }
   if (m->cl_xbuf) {                                     // tags start at epoch 1: the exchange buffers must not hold a stale match
     hipMemsetAsync(m->cl_xbuf, 0, m->cl_xbytes, m->s); hipMemsetAsync(m->cl_pbuf, 0, m->cl_pbytes, m->s); hipMemsetAsync(m->cl_err, 0, 64, m->s);
+    hipMemsetAsync(m->cl_xtab, 0, ((size_t)2 * ((cfg->batch_size + 15) / 16) * 8 + 64) * 8, m->s);
   }
   for (int i = 0; i < 4; ++i)
   {
@@ -333,7 +334,15 @@ int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32
   else if (n == "conv1") { if (m->bf16) bf16_to_f32(m->s, m->A1b, m->A1, (int64_t)d.B * d.H1 * d.W1 * 64); *ptr_dev = m->A1; *ndim = 4; shape[0] = d.B; shape[1] = d.H1; shape[2] = d.W1; shape[3] = 64; }
   else if (n == "conv2") { if (m->bf16) bf16_to_f32(m->s, m->A2b, m->A2, (int64_t)d.B * d.H2 * d.W2 * 128); *ptr_dev = m->A2; *ndim = 4; shape[0] = d.B; shape[1] = d.H2; shape[2] = d.W2; shape[3] = 128; }
   else if (n == "conv6") { if (m->bf16) bf16_to_f32(m->s, m->A6b, m->A6, (int64_t)d.B * d.H6 * d.W2 * 512); *ptr_dev = m->A6; *ndim = 4; shape[0] = d.B; shape[1] = d.H6; shape[2] = d.W2; shape[3] = 512; }
-  else if (n == "cl_err") { *ptr_dev = m->cl_err; *ndim = 1; shape[0] = 1; REQUIRE(m->cl_err, "no cluster kernels in this configuration"); }
+  else if (n == "enc_dz0" || n == "enc_dz1") {           // debugging aid: bf16 d z of the top encoder layer, direction 0 / 1
+    const int dir = n == "enc_dz1"; const int64_t cnt = (int64_t)d.T * d.B * 4 * m->He;
+    REQUIRE(m->edz_b[dir][m->Le - 1], "no bf16 d z in this mode");
+    bf16_to_f32(m->s, m->edz_b[dir][m->Le - 1], m->G0, cnt);
+    *ptr_dev = m->G0; *ndim = 3; shape[0] = d.T; shape[1] = d.B; shape[2] = 4 * m->He;
+  }
+  else if (n == "enc_cs0") { *ptr_dev = m->ecs[0][m->Le - 1]; *ndim = 3; shape[0] = d.T + 2; shape[1] = d.B; shape[2] = m->He; }
+  else if (n == "enc_gates0") { *ptr_dev = m->egates[0][m->Le - 1]; *ndim = 3; shape[0] = d.T; shape[1] = d.B; shape[2] = 4 * m->He; }
+  else if (n == "cl_err") { *ptr_dev = m->cl_err; *ndim = 1; shape[0] = 8; REQUIRE(m->cl_err, "no cluster kernels in this configuration"); }
   else if (n == "g0") {                                   // debugging aid (AOCR_DBG_STOP=1|2): the gradient map the CNN backward pass stopped at
     const char* e = getenv("AOCR_DBG_STOP"); const int stop = e ? atoi(e) : 0;
     const int64_t cnt = stop == 1 ? (int64_t)d.B * d.T * 512 : (int64_t)d.B * d.H4 * d.W2 * 512;

@@ -94,7 +94,7 @@ struct aocr_model {
   aocr::Dims last;                // dims of the last step (for the parity taps)
   int last_valid;
   // cluster encoder kernels (rnn_cluster.hip): exchange buffers, error flag, launch epoch (tags = epoch * 4096 + step)
-  unsigned long long *cl_xbuf = nullptr, *cl_pbuf = nullptr; int* cl_err = nullptr; size_t cl_xbytes = 0, cl_pbytes = 0; unsigned cl_epoch = 0;
+  unsigned long long *cl_xbuf = nullptr, *cl_pbuf = nullptr, *cl_xtab = nullptr; int* cl_err = nullptr; size_t cl_xbytes = 0, cl_pbytes = 0; unsigned cl_epoch = 0;
   aocr::CommState comm;
   // per-family HIP-event profile (aocr_profile_enable): a mark = "family `tag` runs from here to the next mark"
   bool prof_on = false;

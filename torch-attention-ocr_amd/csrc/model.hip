@@ -162,7 +162,8 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
   if (m->bf16 && He % 64 == 0 && He <= 512) {                    // exchange buffers of the cluster encoder kernels
     m->cl_xbytes = enc_cluster_xbuf_bytes((int)B, (int)He); m->cl_pbytes = enc_cluster_pbuf_bytes((int)B, (int)He);
     m->cl_xbuf = a.get<unsigned long long>(m->cl_xbytes / 8); m->cl_pbuf = a.get<unsigned long long>(m->cl_pbytes / 8);
-    m->cl_err = a.get<int>(16);
+    m->cl_xtab = a.get<unsigned long long>((size_t)2 * ((B + 15) / 16) * 8 + 64);      // XCC ids of the members of every group
+    m->cl_err = a.get<int>(16 + 256 * 8);                        // error flag + the trash slots rows >= B store to
   }
   m->shadow_dev = m->bf16 ? a.get<ShadowJob>(128) : nullptr;
   m->ws_bytes = a.off + 256;
@@ -388,6 +389,7 @@ static bool cluster_ok(const aocr_model* m, int B, int T, int& G, int& RT, int& 
 static unsigned next_epoch(aocr_model* m) {
   if (++m->cl_epoch >= (1u << 20)) {                              // tags would repeat: clear the buffers and start over
     hipMemsetAsync(m->cl_xbuf, 0, m->cl_xbytes, m->s); hipMemsetAsync(m->cl_pbuf, 0, m->cl_pbytes, m->s); m->cl_epoch = 1;
+    hipMemsetAsync(m->cl_xtab, 0, ((size_t)2 * ((m->cfg.batch_size + 15) / 16) * 8 + 64) * 8, m->s);
   }
   return m->cl_epoch;
 }
@@ -422,7 +424,7 @@ void encoder_forward(aocr_model* m, const Dims& d) {
     const bool cluster = cluster_ok(m, B, T, clG, clRT, clGroups);
     if (getenv("AOCR_TRACE")) fprintf(stderr, "[aocr] encoder layer %d forward: %s kernels\n", l, cluster ? "cluster" : seq_kernels_ok(m, B) ? "whole-sequence" : "per-step");
     if (cluster) {                                        // groups of He/64 CUs, recurrent weights resident in registers
-      EncClFwdArgs a; a.B = B; a.T = T; a.He = He; a.Hd = Hd; a.groups = clGroups; a.epoch = next_epoch(m); a.xbuf = m->cl_xbuf; a.err = m->cl_err;
+      EncClFwdArgs a; a.B = B; a.T = T; a.He = He; a.Hd = Hd; a.groups = clGroups; a.epoch = next_epoch(m); a.xbuf = m->cl_xbuf; a.err = m->cl_err; a.xtab = m->cl_xtab;
       for (int dir = 0; dir < 2; ++dir) {
         EncSeqDir& e = a.d[dir];
         e.w = m->enc[dir][l].swh.wb; e.zx = m->ezx[dir][l]; e.hs = m->ehs[dir][l]; e.cs = m->ecs[dir][l]; e.hsb = m->ehs_b[dir][l];
@@ -485,7 +487,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
     const bool seq = cluster || (seq_kernels_ok(m, B) && m->edz_b[0][l] && m->enc[0][l].swh.wtb);
     if (getenv("AOCR_TRACE")) fprintf(stderr, "[aocr] encoder layer %d backward: %s kernels\n", l, cluster ? "cluster" : seq ? "whole-sequence" : "per-step");
     if (cluster) {
-      EncClBwdArgs a; a.B = B; a.T = T; a.He = He; a.groups = clGroups; a.epoch = next_epoch(m); a.pbuf = m->cl_pbuf; a.err = m->cl_err;
+      EncClBwdArgs a; a.B = B; a.T = T; a.He = He; a.groups = clGroups; a.epoch = next_epoch(m); a.pbuf = m->cl_pbuf; a.err = m->cl_err; a.xtab = m->cl_xtab;
       for (int dir = 0; dir < 2; ++dir) {
         EncSeqBwdDir& e = a.d[dir];
         e.wt = m->enc[dir][l].swh.wtb;
@@ -494,6 +496,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
         e.dh2 = top ? m->dh_rec[0] + dir * He : nullptr; e.dh2_row = Hd;                            // model.lua:667,681
         e.dc = m->edc[dir]; e.gates = m->egates[dir][l]; e.cs = m->ecs[dir][l];
         e.dz = m->edz[dir][l]; e.dzb = m->edz_b[dir][l]; e.forward_dir = dir == 0;
+        e.dbi = m->enc[dir][l].dbi; e.dbh = m->enc[dir][l].dbh;
       }
       enc_cluster_backward(s, a, clG, clRT);
     } else if (seq) {
@@ -544,7 +547,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       const bf16_t* hprevb = m->ehs_b[dir][l] ? m->ehs_b[dir][l] + (dir == 0 ? 0 : 2 * slot) : nullptr;
       wg[nwg++] = WGradProblem{dz, 4 * He, xin, p.in, p.dwi, p.in, 4 * He, p.in, T * B, dzb, xinb};
       wg[nwg++] = WGradProblem{dz, 4 * He, hprev, He, p.dwh, He, 4 * He, He, T * B, dzb, hprevb};
-      colsum_accum(s, dz, 4 * He, (int64_t)T * B, 4 * He, p.dbi, p.dbh);        // both biases see the same d z (LSTM.lua:79-88)
+      if (!cluster) colsum_accum(s, dz, 4 * He, (int64_t)T * B, 4 * He, p.dbi, p.dbh);        // both biases see the same d z (LSTM.lua:79-88); the cluster kernel sums them itself
       float* dxo = l == 0 ? m->dX : m->edxl[dir];
       const int dxf = (l == 0 && dir == 1) ? EP_ACCUM : 0;                          // model.lua:675 copy, :689 add
       if (bf && dzb && p.swi.wtb) gemm_hh(s, dzb, 4 * He, p.swi.wtb, 4 * He, dxo, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dxf);

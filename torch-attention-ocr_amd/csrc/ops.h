@@ -196,13 +196,14 @@ struct EncSeqBwdDir {
   const float* gates;      // saved gates [T][B][4He]
   const float* cs;         // cell-state slots [(T+2)][B][He]
   float* dz; bf16_t* dzb;  // out: d z [T][B][4He], fp32 and bf16
+  float* dbi = nullptr; float* dbh = nullptr;   // cluster kernels only: both bias gradients (+= sum of d z over rows and steps; no fp32 d z is written)
   int forward_dir;         // 1: the direction whose forward pass walked t = 0..T-1 (its BPTT walks T-1..0, c_prev = slot t)
 };
 struct EncSeqBwdArgs { EncSeqBwdDir d[2]; int B, T, He; };
 bool enc_seq_supported(int B, int He, int blocks_limit);
 // ---- the same recurrences on clusters of CUs with register-resident weights (rnn_cluster.hip)
-struct EncClFwdArgs { EncSeqDir d[2]; int B, T, He, Hd, groups; unsigned epoch; unsigned long long* xbuf; int* err; int gid0 = 0, ngid = 0; };
-struct EncClBwdArgs { EncSeqBwdDir d[2]; int B, T, He, groups; unsigned epoch; unsigned long long* pbuf; int* err; int gid0 = 0, ngid = 0; };
+struct EncClFwdArgs { EncSeqDir d[2]; int B, T, He, Hd, groups; unsigned epoch; unsigned long long* xbuf; int* err; int gid0 = 0, ngid = 0; unsigned long long* xtab = nullptr; int force_remote = 0; };
+struct EncClBwdArgs { EncSeqBwdDir d[2]; int B, T, He, groups; unsigned epoch; unsigned long long* pbuf; int* err; int gid0 = 0, ngid = 0; unsigned long long* xtab = nullptr; int force_remote = 0; };
 bool enc_cluster_plan(int B, int He, int T, int cus, int& G, int& RT, int& groups);
 size_t enc_cluster_xbuf_bytes(int B, int He);
 size_t enc_cluster_pbuf_bytes(int B, int He);

@@ -35,11 +35,78 @@ __device__ __forceinline__ unsigned quad_swap(unsigned v) { return (unsigned)__b
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-// forward
+// VMEM discipline.  The group's critical path is  granule store -> L2 -> poll.  Everything else a step moves (state slots, saved
+// gates, the next step's inputs) is bulk traffic whose completion must NOT be waited for on that path: vmcnt counts in issue order, so
+// the polls are issued FIRST, the bulk stores / prefetch loads of the neighbouring steps BEHIND them, and the wait for the polls is
+// an explicit s_waitcnt vmcnt(N) with N = the number of bulk instructions issued in between.  That count must be static: the polls are
+// inline asm (the compiler's own wait insertion would drain the queue), invalid rows store to a trash slot instead of branching.
 // ---------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void poll16(u32x4& v, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory"); }
+__device__ __forceinline__ void pin(u32x4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+// bulk traffic as inline asm too: its instruction count between a batch of polls and their wait must be exact, and the compiler must not
+// insert a wait of its own in front of a use of a prefetched value (it would drain the stores issued since)
+__device__ __forceinline__ void ld4(float& v, const float* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void ld16(f32x4& v, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void st4(float* p, float v) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st2(bf16_t* p, unsigned bits) { asm volatile("global_store_short %0, %1, off" ::"v"(p), "v"(bits) : "memory"); }
+// NOTE the trailing s_nop: a store of more than 8 bytes reads its data registers for a few cycles after issue, and the compiler's hazard
+// recognizer does not look inside inline asm -- without the wait states the next VALU write to one of those registers (the register
+// allocator reuses them at once) corrupts the data of the later lanes (seen: rows 12-15 of a tile).
+__device__ __forceinline__ void st16(void* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st8(void* p, unsigned a, unsigned b) { typedef unsigned u32x2 __attribute__((ext_vector_type(2))); const u32x2 v = {a, b}; asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st16_sc1(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+// Prefetch WITHOUT a register destination (LDS-DMA): lane l of the wave gets its 16 bytes at lds_base + 16 l.  An inline-asm load whose
+// result must stay untouched in a VGPR across an MFMA phase is not safe -- under register pressure the allocator splits the live range
+// (copies the not-yet-landed register to an AGPR) -- so everything prefetched across a phase goes through LDS and is read back behind
+// the wait that covers it (vmcnt counts LDS-DMA like any other load).
+__device__ __forceinline__ void cl_dma16(const void* g, unsigned char* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+// Two granules to a consumer.  `local` (wave-uniform): every member of the group runs on ONE XCD (checked at kernel start), so a plain
+// store -- which stays in that XCD's L2 -- is visible to the members' sc1 (L1-bypassing) polls without the trip through the fabric that
+// a write-through store costs (MI355X_MICROARCH.md: plain stores KEEP the line in the XCD's L2, sc1 stores DROP it).
+__device__ __forceinline__ void st_granules(void* p, u32x4 v, bool local) {
+  if (local) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else st16_sc1(p, v);
+}
+// Are all G members of this group on one XCD?  Each member publishes its XCC id (tagged with the launch epoch), reads the others'.
+template <int G> __device__ __forceinline__ bool group_is_local(u64* tab, int member, unsigned epoch, int* err) {
+  __shared__ int s_local;
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15u;
+    st_granule(tab + member, ((u64)epoch << 32) | (u64)(xcc + 1u));
+    int same = 1;
+    for (int m = 0; m < G; ++m) {
+      u64 v; int spins = 0;
+      while ((unsigned)((v = ld_granule(tab + m)) >> 32) != epoch) { if (++spins > CL_SPIN_LIMIT) { atomicExch(err, 3); same = 0; break; } __builtin_amdgcn_s_sleep(2); }
+      if ((unsigned)v != xcc + 1u) same = 0;
+    }
+    s_local = same;
+  }
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane(s_local) != 0;
+}   // two granules, write-through
+
+// Both kernels compute the TRANSPOSED products (weights as the A operand, the state as B): an accumulator then holds FOUR CONSECUTIVE
+// UNITS of ONE batch row per lane, so every global access of the epilogue is 8 or 16 contiguous bytes per lane (7 stores and 4 loads
+// per 16-row tile and step instead of 16 + 16) and a lane's h values are one 16-byte pair of granules.  With the polls that is ~28
+// vector-memory instructions per wave and step; the first layout issued 56, and the wave (at most 63 in flight) stalled on its
+// own store acknowledgements.
+//
+// forward.  Saved gates layout of the cluster kernels: [T][B][He][4] (16 bytes per cell).
 template <int G, int RT, bool CTX>
 __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
   constexpr int He = 64 * G, KS = 2 * G, R = 16 * RT;
+  constexpr int NPW = (2 * G + 3) / 4;                           // (member, k-step) pieces polled per wave
+  constexpr int HP = He * 2 + 16;                                // LDS pitch of the gathered h(t-1): [R][He] bf16, padded
+  constexpr int NBULK = RT * (CTX ? 7 : 6);                      // store instructions issued behind the polls (inline asm: exact)
+  extern __shared__ __attribute__((aligned(16))) unsigned char hbuf[];        // [2][R][HP], then the zx staging [4 waves][RT * 4 pieces][1 KiB]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c16 = lane & 15, q = lane >> 4;
   const int wid = blockIdx.x, xcd = wid & 7, i8 = wid >> 3;
@@ -49,126 +116,179 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
   const int dir = gid / p.groups, group = gid - dir * p.groups;
   const EncSeqDir& d = p.d[dir];
   const int B = p.B, T = p.T, row0 = group * R;
-  const int ucol = 64 * member + 16 * wave + c16;               // this lane's hidden unit (all four gates)
+  const int u0 = 64 * member + 16 * wave + 4 * q;               // this lane's four hidden units u0 .. u0+3 (epilogue), batch row c16
+  unsigned char* const zxl = hbuf + 2 * R * HP + wave * (RT * 4 * 1024);
 
-  bf16x8 wres[4][KS];                                            // resident B fragments: gate g, k-step s
+  bf16x8 wres[4][KS];                                            // resident A fragments: gate g, k-step s; A row = unit 16 wave + c16
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) wres[g][s] = *reinterpret_cast<const bf16x8*>(d.w + (size_t)(g * He + ucol) * He + 32 * s + 8 * q);
+    for (int s = 0; s < KS; ++s)
+      wres[g][s] = *reinterpret_cast<const bf16x8*>(d.w + (size_t)(g * He + 64 * member + 16 * wave + c16) * He + 32 * s + 8 * q);
 
-  float cst[RT][4];
+  f32x4 cst[RT];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) cst[rt][i] = 0.f;
+  for (int rt = 0; rt < RT; ++rt) cst[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
   u64* const xg = p.xbuf + (size_t)gid * 2 * G * R * 32;         // [parity][member][row][32 granules]
+  float* const trash = reinterpret_cast<float*>(p.err + 16) + (threadIdx.x & 255) * 4;   // rows >= B store here
+  const bool local = group_is_local<G>(p.xtab + (size_t)gid * 8, member, p.epoch, p.err) && !p.force_remote;
 
-  float zx[RT][4][4];
-  auto load_zx = [&](int t) {
-    const float* z = d.zx + (size_t)t * B * 4 * He + ucol;
+  auto dma_zx = [&](int t) {                                     // RT * 4 LDS-DMA loads: the input part of step t for this lane's cells
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < RT; ++rt) {
+      const int row = min(row0 + 16 * rt + c16, B - 1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = min(row0 + 16 * rt + 4 * q + i, B - 1);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) zx[rt][g][i] = z[(size_t)row * 4 * He + g * He];
-      }
+      for (int g = 0; g < 4; ++g) cl_dma16(d.zx + ((size_t)t * B + row) * 4 * He + g * He + u0, zxl + (rt * 4 + g) * 1024);
+    }
   };
-  load_zx(d.reverse ? T - 1 : 0);
+  dma_zx(d.reverse ? T - 1 : 0);
+  wait_vm<0>();
+  __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0) the compiler can see: no wait of its own for the prologue loads inside the loop
+  f32x4 gat[RT][4], hh[RT], cc[RT];                              // outputs of the step before ([unit i] = {in, forget, out, g}), stored one step late
+  auto store_outputs = [&](int t) {                              // RT * (6 or 7) store instructions, none conditional
+    const size_t so = (size_t)(t + 1) * B * He;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int row = row0 + 16 * rt + c16;
+      const bool ok = row < B;
+      const size_t o = so + (size_t)row * He + u0;
+      st16(ok ? d.cs + o : trash, cc[rt]);
+      const unsigned h01 = bf16_bits(hh[rt][0]) | (bf16_bits(hh[rt][1]) << 16), h23 = bf16_bits(hh[rt][2]) | (bf16_bits(hh[rt][3]) << 16);
+      st8(ok ? reinterpret_cast<void*>(d.hsb + o) : reinterpret_cast<void*>(trash), h01, h23);
+      if (CTX) st16(ok ? d.ctx + ((size_t)row * T + t) * p.Hd + u0 : trash, hh[rt]);
+      float* gp = ok ? d.gates + (((size_t)t * B + row) * He + u0) * 4 : trash;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) st16(ok ? gp + 4 * i : trash, gat[rt][i]);
+    }
+  };
   bool dead = false;
 
   for (int it = 0; it < T && !dead; ++it) {
     const int t = d.reverse ? T - 1 - it : it;
+    const int tprev = d.reverse ? t + 1 : t - 1;
     f32x4 acc[RT][4];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[rt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned tag = p.epoch * 4096u + (unsigned)it;
+    const u64* xp = xg + (size_t)((it - 1) & 1) * G * R * 32 + c16 * 32 + 4 * q;
     if (it > 0) {
-      const unsigned tag = p.epoch * 4096u + (unsigned)it;
-      const u64* xp = xg + (size_t)((it - 1) & 1) * G * R * 32;
+      // ---- all-gather of h(t-1), shared by the four waves: the 2G (member, k-step) pieces are dealt to the waves (piece x = wave + 4 j),
+      // each wave polls its pieces (2 RT loads of 16 bytes per lane and piece), drops the bf16 payload into LDS as the B operand
+      // [row][k], and after ONE barrier every wave reads its fragments for all of K.  LDS alternates with the step parity.
+      unsigned char* const hb = hbuf + (size_t)(it & 1) * R * HP;
+      u32x4 gr[NPW][RT][2];
+      auto issue = [&]() {
 #pragma unroll
-      for (int m = 0; m < G; ++m) {                              // h(t-1) slice of member m: units 64m .. 64m+63 = k-steps 2m, 2m+1
-        const u64* xm = xp + (size_t)m * R * 32 + c16 * 32 + 4 * q;
-        u64 gr[RT][2][4];
-        int spins = 0;
-        while (true) {
-          bool ok = true;
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) gr[rt][ks][j] = ld_granule(xm + rt * 16 * 32 + ks * 16 + j);
+        for (int j = 0; j < NPW; ++j) {
+          const int x = (wave + 4 * j) % (2 * G);                // straight-line on purpose (G = 1: waves 2, 3 repeat pieces 0, 1): a branch
+                                                                 // around an asm load makes the compiler copy its not-yet-landed result
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) ok = ok && (unsigned)(gr[rt][ks][j] >> 32) == tag;
-          if (__all(ok)) break;
-          if (++spins > CL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicExch(p.err, 1); break; }
-          __builtin_amdgcn_s_sleep(1);
+            for (int hf = 0; hf < 2; ++hf) poll16(gr[j][rt][hf], xp + (size_t)(x >> 1) * R * 32 + rt * 16 * 32 + (x & 1) * 16 + hf * 2);
         }
-        if (dead) break;
+      };
+      auto settle = [&]() {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int j = 0; j < NPW; ++j)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 raw = {(unsigned)gr[rt][ks][0], (unsigned)gr[rt][ks][1], (unsigned)gr[rt][ks][2], (unsigned)gr[rt][ks][3]};
-            bf16x8 a; __builtin_memcpy(&a, &raw, 16);
+          for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[rt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wres[g][2 * m + ks], acc[rt][g], 0, 0, 0);
-          }
+            for (int hf = 0; hf < 2; ++hf) pin(gr[j][rt][hf]);
+      };
+      issue();
+      store_outputs(tprev);                                      // behind the polls: the outputs of the step before (NBULK store instructions)
+      wait_vm<NBULK>();                                          // the polls and everything older (this step's zx in LDS) have landed
+      settle();
+      int spins = 0;
+      while (true) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < NPW; ++j)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) ok = ok && gr[j][rt][hf][1] == tag && gr[j][rt][hf][3] == tag;
+        if (__all(ok)) break;
+        if (++spins > CL_SPIN_LIMIT) {
+          dead = true;
+          if (lane == 0 && atomicExch(p.err, 1) == 0) { p.err[1] = it; p.err[2] = wave; p.err[3] = member; p.err[4] = gid; }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        issue(); wait_vm<0>(); settle();
       }
+#pragma unroll
+      for (int j = 0; j < NPW; ++j) {
+        const int x = (wave + 4 * j) % (2 * G);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const u32x4 raw = {gr[j][rt][0][0], gr[j][rt][0][2], gr[j][rt][1][0], gr[j][rt][1][2]};       // units 32 x + 8 q .. +7 of batch row c16
+          *reinterpret_cast<u32x4*>(hb + (size_t)(16 * rt + c16) * HP + (32 * x + 8 * q) * 2) = raw;
+        }
+      }
+      __syncthreads();
+      dead = __syncthreads_or(dead);                             // a timeout anywhere in the workgroup stops all of it
       if (dead) break;
-    }
-    // ---- gate math; the exchange stores go first (they are the group's critical path)
-    const unsigned tagn = p.epoch * 4096u + (unsigned)(it + 1);
-    u64* const xw = xg + ((size_t)(it & 1) * G + member) * R * 32 + (16 * wave + c16) / 2;
-    float ig[RT][4], fg[RT][4], og[RT][4], gg[RT][4], hh[RT][4];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ig[rt][i] = sigmoidf_(acc[rt][0][i] + zx[rt][0][i]); fg[rt][i] = sigmoidf_(acc[rt][1][i] + zx[rt][1][i]);
-        og[rt][i] = sigmoidf_(acc[rt][2][i] + zx[rt][2][i]); gg[rt][i] = tanhf_(acc[rt][3][i] + zx[rt][3][i]);
-        const float cn = fg[rt][i] * cst[rt][i] + ig[rt][i] * gg[rt][i];
-        cst[rt][i] = cn; hh[rt][i] = og[rt][i] * tanhf_(cn);
-        const unsigned hb = bf16_bits(hh[rt][i]), ot = quad_swap(hb);
-        if (!(c16 & 1) && it + 1 < T) st_granule(xw + (size_t)(16 * rt + 4 * q + i) * 32, ((u64)tagn << 32) | (u64)(hb | (ot << 16)));
-      }
-    // ---- what the rest of the step needs in HBM: state slots, saved gates, bf16 shadow, context slice (EpGatesFwd's outputs)
-    const size_t so = (size_t)(t + 1) * B * He;
+        for (int s2 = 0; s2 < KS; ++s2) {
+          const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hb + (size_t)(16 * rt + c16) * HP + (32 * s2 + 8 * q) * 2);   // B operand: column = batch row c16
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = row0 + 16 * rt + 4 * q + i;
-        if (row < B) {
-          const size_t o = so + (size_t)row * He + ucol;
-          d.cs[o] = cst[rt][i]; d.hs[o] = hh[rt][i]; d.hsb[o] = (bf16_t)hh[rt][i];
-          if (CTX) d.ctx[((size_t)row * T + t) * p.Hd + ucol] = hh[rt][i];
-          float* gp = d.gates + ((size_t)t * B + row) * 4 * He + ucol;
-          gp[0] = ig[rt][i]; gp[He] = fg[rt][i]; gp[2 * He] = og[rt][i]; gp[3 * He] = gg[rt][i];
+          for (int g = 0; g < 4; ++g) acc[rt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres[g][s2], hv, acc[rt][g], 0, 0, 0);
         }
+    }
+    if (dead) break;
+    f32x4 zx[RT][4];                                             // this step's input part, prefetched into LDS one step ago
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) zx[rt][g] = *reinterpret_cast<const f32x4*>(zxl + (rt * 4 + g) * 1024 + lane * 16);
+    // ---- gate math (acc[rt][g][i]: unit u0 + i, batch row c16) and the exchange store: one 16-byte pair of granules per lane and tile
+    const unsigned tagn = p.epoch * 4096u + (unsigned)(it + 1);
+    u64* const xw = xg + ((size_t)(it & 1) * G + member) * R * 32 + 8 * wave + 2 * q;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float ig = sigmoidf_(acc[rt][0][i] + zx[rt][0][i]), fg = sigmoidf_(acc[rt][1][i] + zx[rt][1][i]);
+        const float og = sigmoidf_(acc[rt][2][i] + zx[rt][2][i]), gg = tanhf_(acc[rt][3][i] + zx[rt][3][i]);
+        const float cn = fg * cst[rt][i] + ig * gg;
+        cst[rt][i] = cn; cc[rt][i] = cn; hh[rt][i] = og * tanhf_(cn); gat[rt][i] = f32x4{ig, fg, og, gg};
       }
-    if (it + 1 < T) load_zx(d.reverse ? t - 1 : t + 1);
+      if (it + 1 < T) {
+        const u32x4 gv = {bf16_bits(hh[rt][0]) | (bf16_bits(hh[rt][1]) << 16), tagn, bf16_bits(hh[rt][2]) | (bf16_bits(hh[rt][3]) << 16), tagn};
+        st_granules(xw + (size_t)(16 * rt + c16) * 32, gv, local);
+      }
+    }
+    dma_zx(it + 1 < T ? (d.reverse ? t - 1 : t + 1) : t);        // the next step's input part: issued behind the granules, older than the next polls
+  }
+  wait_vm<0>();
+  if (!dead) {                                                   // the last step's outputs + its fp32 h (the decoder's initial state reads it)
+    const int tl = d.reverse ? 0 : T - 1;
+    store_outputs(tl);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) { const int row = row0 + 16 * rt + c16; if (row < B) *reinterpret_cast<f32x4*>(d.hs + ((size_t)(tl + 1) * B + row) * He + u0) = hh[rt]; }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward (BPTT) of one layer
+// backward (BPTT) of one layer.  Per step: MFMA on the own d z of the step before (LDS) -> partial tiles sent (granules) / kept (LDS)
+// -> barrier -> polls issued, behind them the bf16 d z stores of the step before -> partial sums -> EpGatesBwd -> d z(t) to LDS ->
+// barrier.  The bias gradient (sum of d z over rows and steps) is kept in registers and added to both bias gradients at the end: no
+// fp32 d z leaves the kernel.  Transposed tiles as in the forward kernel: lane = batch row c16, units u0 .. u0+3.
 // ---------------------------------------------------------------------------------------------
 template <int G, int RT>
 __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
-  constexpr int He = 64 * G, KG = 4 * He, R = 16 * RT, AP = 256 * 2 + 16;     // A operand: [R][256 own gate columns] bf16, padded pitch
+  constexpr int He = 64 * G, KG = 4 * He, R = 16 * RT, AP = 256 * 2 + 16;     // B operand: [R][256 own gate columns] bf16, padded pitch
+  constexpr int NBULK = RT * 4;                                 // store instructions issued behind the first batch of polls (4 x 8 bytes of bf16 d z per tile)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const abuf = lds;                                            // [2][R][AP]
   f32x4* const own = reinterpret_cast<f32x4*>(lds + 2 * R * AP);              // [4 tiles][RT][64 lanes]
+  unsigned char* const prel = lds + 2 * R * AP + 4 * RT * 64 * 16 + (threadIdx.x >> 6) * (RT * 7 * 1024);   // epilogue-input staging [4 waves][RT * 7 pieces][1 KiB]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
   const int wid = blockIdx.x, xcd = wid & 7, i8 = wid >> 3;
@@ -178,9 +298,10 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
   const int dir = gid / p.groups, group = gid - dir * p.groups;
   const EncSeqBwdDir& d = p.d[dir];
   const int B = p.B, T = p.T, row0 = group * R;
-  const int ucol = 64 * member + 16 * wave + c16;               // epilogue: this lane's hidden unit
+  const int ul = 16 * wave + 4 * q, u0 = 64 * member + ul;      // epilogue: this lane's four hidden units (local / global), batch row c16
+  float* const trash = reinterpret_cast<float*>(p.err + 16) + (threadIdx.x & 255) * 4;
 
-  // resident B fragments: this wave's G output tiles (units 16 (wave G + j) ..), K = the workgroup's own 256 gate columns
+  // resident A fragments: this wave's G output tiles (A row = unit 16 (wave G + j) + c16), K = the workgroup's own 256 gate columns
   // k = gate * 64 + local unit  <->  column gate * He + 64 member + local unit of W^T [He][4He]
   bf16x8 wres[G][8];
 #pragma unroll
@@ -189,44 +310,68 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
     for (int s = 0; s < 8; ++s)
       wres[j][s] = *reinterpret_cast<const bf16x8*>(d.wt + (size_t)(16 * (wave * G + j) + c16) * KG + (s >> 1) * He + 64 * member + 32 * (s & 1) + 8 * q);
 
-  float dcr[RT][4];
+  f32x4 dcr[RT]; float dbs[4][4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dbs[g][i] = 0.f;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) { const int row = min(row0 + 16 * rt + c16, B - 1); dcr[rt] = *reinterpret_cast<const f32x4*>(d.dc + (size_t)row * He + u0); }
+
+  struct Pre { f32x4 g[RT][4], cc[RT], cp[RT], dh[RT]; };
+  auto prefetch = [&](int it) {                                  // RT * 7 LDS-DMA loads: saved gates, c(t), c(t-1), d h from above
+    const int t = d.forward_dir ? T - 1 - it : it, prev = d.forward_dir ? t : t + 2;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int row = min(row0 + 16 * rt + c16, B - 1);
+      unsigned char* pl = prel + rt * 7 * 1024;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cl_dma16(d.gates + (((size_t)t * B + row) * He + u0 + i) * 4, pl + i * 1024);
+      cl_dma16(d.cs + ((size_t)(t + 1) * B + row) * He + u0, pl + 4 * 1024);
+      cl_dma16(d.cs + ((size_t)prev * B + row) * He + u0, pl + 5 * 1024);
+      cl_dma16(d.dh1 + (size_t)row * d.dh1_row + (size_t)t * d.dh1_t + u0, pl + 6 * 1024);
+    }
+  };
+  auto read_pre = [&](Pre& x) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const unsigned char* pl = prel + rt * 7 * 1024 + lane * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x.g[rt][i] = *reinterpret_cast<const f32x4*>(pl + i * 1024);
+      x.cc[rt] = *reinterpret_cast<const f32x4*>(pl + 4 * 1024); x.cp[rt] = *reinterpret_cast<const f32x4*>(pl + 5 * 1024);
+      x.dh[rt] = *reinterpret_cast<const f32x4*>(pl + 6 * 1024);
+    }
+  };
+  u64* const pb = p.pbuf + (size_t)gid * 2 * G * G * 4 * RT * 256;            // [parity][dest][src][tile][rt][lane][4 granules]
+  const bool local = group_is_local<G>(p.xtab + (size_t)gid * 8, member, p.epoch, p.err) && !p.force_remote;
+  f32x4 zprev[RT][4];                                            // d z of the step before ([gate][unit i]): stored to HBM one step late
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int row = min(row0 + 16 * rt + 4 * q + i, B - 1); dcr[rt][i] = d.dc[(size_t)row * He + ucol]; }
-
-  float pg[RT][4][4], pcc[RT][4], pcp[RT][4], pdh[RT][4];        // the next step's epilogue inputs
-  auto prefetch = [&](int it) {
-    const int t = d.forward_dir ? T - 1 - it : it, prev = d.forward_dir ? t : t + 2;
+    for (int g = 0; g < 4; ++g) zprev[rt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto store_dz = [&](int t) {                                   // RT * 4 store instructions, none conditional
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < RT; ++rt) {
+      const int row = row0 + 16 * rt + c16;
+      const bool ok = row < B;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = min(row0 + 16 * rt + 4 * q + i, B - 1);
-        const float* g_t = d.gates + ((size_t)t * B + row) * KG + ucol;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pg[rt][g][i] = g_t[g * He];
-        pcc[rt][i] = d.cs[((size_t)(t + 1) * B + row) * He + ucol];
-        pcp[rt][i] = d.cs[((size_t)prev * B + row) * He + ucol];
-        pdh[rt][i] = d.dh1[(size_t)row * d.dh1_row + (size_t)t * d.dh1_t + ucol];
+      for (int g = 0; g < 4; ++g) {
+        const unsigned z01 = bf16_bits(zprev[rt][g][0]) | (bf16_bits(zprev[rt][g][1]) << 16), z23 = bf16_bits(zprev[rt][g][2]) | (bf16_bits(zprev[rt][g][3]) << 16);
+        st8(ok ? reinterpret_cast<void*>(d.dzb + ((size_t)t * B + row) * KG + g * He + u0) : reinterpret_cast<void*>(trash), z01, z23);
       }
+    }
   };
-  prefetch(0);
-  if (d.dh2) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { const int row = min(row0 + 16 * rt + 4 * q + i, B - 1); pdh[rt][i] += d.dh2[(size_t)row * d.dh2_row + ucol]; }
-  }
-  u64* const pb = p.pbuf + (size_t)gid * 2 * G * G * 4 * RT * 256;            // [parity][dest][src][tile][rt][lane][4 granules]
   bool dead = false;
+  __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0) the compiler can see: no wait of its own for the prologue loads inside the loop
 
   for (int it = 0; it < T; ++it) {
     const int t = d.forward_dir ? T - 1 - it : it;
+    const int tprev = d.forward_dir ? t + 1 : t - 1;
     const unsigned tag = p.epoch * 4096u + (unsigned)it;
     const int par = it & 1;
+    prefetch(it);                                                // this step's epilogue inputs -> LDS: older than the polls, landed when they have
     if (it > 0 && !dead) {
-      // ---- partial d h for ALL units from this workgroup's own d z of the step before
+      // ---- partial d h (transposed: units x rows) for ALL units from this workgroup's own d z of the step before
       f32x4 acc[RT][G];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -237,9 +382,9 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(ab + (size_t)(16 * rt + c16) * AP + (32 * s + 8 * q) * 2);
+          const bf16x8 zb = *reinterpret_cast<const bf16x8*>(ab + (size_t)(16 * rt + c16) * AP + (32 * s + 8 * q) * 2);   // column = batch row c16
 #pragma unroll
-          for (int j = 0; j < G; ++j) acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wres[j][s], acc[rt][j], 0, 0, 0);
+          for (int j = 0; j < G; ++j) acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres[j][s], zb, acc[rt][j], 0, 0, 0);
         }
       // ---- reduce-scatter: tile (wave G + j) belongs to member (wave G + j) / 4
 #pragma unroll
@@ -250,81 +395,128 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
           if (dm == member) own[(e * RT + rt) * 64 + lane] = acc[rt][j];
           else {
             u64* dst = pb + ((((size_t)(par * G + dm) * G + member) * 4 + e) * RT + rt) * 256 + lane * 4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) st_granule(dst + i, ((u64)tag << 32) | (u64)__float_as_uint(acc[rt][j][i]));
+            const u32x4 g0 = {__float_as_uint(acc[rt][j][0]), tag, __float_as_uint(acc[rt][j][1]), tag};
+            const u32x4 g1 = {__float_as_uint(acc[rt][j][2]), tag, __float_as_uint(acc[rt][j][3]), tag};
+            st_granules(dst, g0, local); st_granules(dst + 2, g1, local);
           }
         }
       }
     }
     __syncthreads();                                             // own partials are in LDS; everyone is done with abuf[(it-1)&1]
-    float dh[RT][4];
+    // ---- polls first (the other members' partial tiles, in batches of <= PB members), bulk stores behind the first batch
+    constexpr int NO = G - 1, PB = (NO > 4 || (RT > 1 && NO > 2)) ? (RT > 1 ? 2 : 4) : (NO > 0 ? NO : 1);
+    const bool live = it > 0 && !dead;
+    Pre cur;
+    if (NO == 0 || !live) { if (it > 0) store_dz(tprev); else store_dz(t); wait_vm<NBULK>(); read_pre(cur); }
+    f32x4 dh[RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int k0 = 0; k0 < NO; k0 += PB) {
+      u32x4 gr[PB][RT][2];
+      auto issue = [&]() {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dh[rt][i] = pdh[rt][i];
-    if (it > 0 && !dead) {
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const f32x4 o = own[(wave * RT + rt) * 64 + lane];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dh[rt][i] += o[i];
-      }
-#pragma unroll
-      for (int sm = 0; sm < G; ++sm) {
-        if (sm == member) continue;
-        const u64* src = pb + ((((size_t)(par * G + member) * G + sm) * 4 + wave) * RT) * 256 + lane * 4;
-        u64 gr[RT][4];
-        int spins = 0;
-        while (true) {
-          bool ok = true;
+        for (int kk = 0; kk < PB; ++kk) {
+          const int k = (k0 + kk) % (NO > 0 ? NO : 1), sm = k + (k >= member ? 1 : 0);   // the G-1 other members (straight-line: a tail batch repeats)
+          const u64* src = pb + ((((size_t)(par * G + member) * G + sm) * 4 + wave) * RT) * 256 + lane * 4;
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gr[rt][i] = ld_granule(src + rt * 256 + i);
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ok = ok && (unsigned)(gr[rt][i] >> 32) == tag;
-          if (__all(ok)) break;
-          if (++spins > CL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicExch(p.err, 2); break; }
-          __builtin_amdgcn_s_sleep(1);
+            for (int hf = 0; hf < 2; ++hf) poll16(gr[kk][rt][hf], src + rt * 256 + hf * 2);
         }
-        if (dead) break;
+      };
+      auto settle = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < PB; ++kk)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) pin(gr[kk][rt][hf]);
+      };
+      if (!live) break;
+      issue();
+      if (k0 == 0) { store_dz(tprev); wait_vm<NBULK>(); read_pre(cur); }   // (step 0 stores zeros to the slot it rewrites one step later: handled above)
+      else wait_vm<0>();
+      settle();
+      if (k0 == 0) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) dh[rt] = cur.dh[rt];
+      }
+      int spins = 0;
+      while (true) {
+        bool ok = true;
+#pragma unroll
+        for (int kk = 0; kk < PB; ++kk)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) ok = ok && gr[kk][rt][hf][1] == tag && gr[kk][rt][hf][3] == tag;
+        if (__all(ok)) break;
+        if (++spins > CL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicExch(p.err, 2); break; }
+        __builtin_amdgcn_s_sleep(1);
+        issue(); wait_vm<0>(); settle();
+      }
+      if (dead) break;
+#pragma unroll
+      for (int kk = 0; kk < PB; ++kk) {
+        if (k0 + kk >= NO) continue;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) dh[rt][i] += __uint_as_float((unsigned)gr[rt][i]);
+          for (int hf = 0; hf < 2; ++hf) { dh[rt][2 * hf] += __uint_as_float(gr[kk][rt][hf][0]); dh[rt][2 * hf + 1] += __uint_as_float(gr[kk][rt][hf][2]); }
       }
     }
-    // ---- EpGatesBwd for this lane's cells: d z(t) to HBM (fp32 + bf16: operands of the hoisted gradients) and, as bf16, to LDS
+    if (NO == 0 || !live) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) dh[rt] = cur.dh[rt];
+    }
+    if (it == 0 && d.dh2) {                                      // model.lua:667,681: d h of the decoder's initial state joins the first processed step
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int row = min(row0 + 16 * rt + c16, B - 1);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(d.dh2 + (size_t)row * d.dh2_row + u0);
+        dh[rt] += v;
+      }
+    }
+    if (live && !dead) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) dh[rt] += own[(wave * RT + rt) * 64 + lane];
+    }
+    // ---- EpGatesBwd for this lane's cells: d z(t) as bf16 to LDS (next step's B operand); the HBM copies go out one step late
     unsigned char* an = abuf + (size_t)par * R * AP;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < RT; ++rt) {
+      const bool ok = row0 + 16 * rt + c16 < B;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int rl = 16 * rt + 4 * q + i, row = row0 + rl;
-        const float ig = pg[rt][0][i], fg = pg[rt][1][i], og = pg[rt][2][i], gg = pg[rt][3][i];
-        const float tc = tanhf_(pcc[rt][i]);
+        const float ig = cur.g[rt][i][0], fg = cur.g[rt][i][1], og = cur.g[rt][i][2], gg = cur.g[rt][i][3];
+        const float tc = tanhf_(cur.cc[rt][i]);
         const float dc = dh[rt][i] * og * (1.f - tc * tc) + dcr[rt][i];
         const float d_o = dh[rt][i] * tc;
-        const float z[4] = {dc * gg * ig * (1.f - ig), dc * pcp[rt][i] * fg * (1.f - fg), d_o * og * (1.f - og), dc * ig * (1.f - gg * gg)};
+        const float z[4] = {dc * gg * ig * (1.f - ig), dc * cur.cp[rt][i] * fg * (1.f - fg), d_o * og * (1.f - og), dc * ig * (1.f - gg * gg)};
         dcr[rt][i] = dc * fg;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          *reinterpret_cast<bf16_t*>(an + (size_t)rl * AP + (g * 64 + 16 * wave + c16) * 2) = (bf16_t)z[g];
-          if (row < B) {
-            const size_t o = ((size_t)t * B + row) * KG + g * He + ucol;
-            d.dz[o] = z[g]; d.dzb[o] = (bf16_t)z[g];
-          }
-        }
+        for (int g = 0; g < 4; ++g) { zprev[rt][g][i] = z[g]; if (ok) dbs[g][i] += z[g]; }
       }
-    if (it + 1 < T) prefetch(it + 1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 zz = {bf16_bits(zprev[rt][g][0]) | (bf16_bits(zprev[rt][g][1]) << 16), bf16_bits(zprev[rt][g][2]) | (bf16_bits(zprev[rt][g][3]) << 16)};
+        *reinterpret_cast<u32x2*>(an + (size_t)(16 * rt + c16) * AP + (g * 64 + ul) * 2) = zz;
+      }
+    }
     __syncthreads();                                             // d z(t) complete in LDS
   }
+  store_dz(d.forward_dir ? 0 : T - 1);
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+  for (int rt = 0; rt < RT; ++rt) { const int row = row0 + 16 * rt + c16; if (row < B) *reinterpret_cast<f32x4*>(d.dc + (size_t)row * He + u0) = dcr[rt]; }
+  // bias gradients: both Linear layers see the same d z (LSTM.lua:79-88); sum over this lane's steps, then over the 16 rows of the tile
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int row = row0 + 16 * rt + 4 * q + i; if (row < B) d.dc[(size_t)row * He + ucol] = dcr[rt][i]; }
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = dbs[g][i];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      if (c16 == 0) { atomicAdd(d.dbi + g * He + u0 + i, v); atomicAdd(d.dbh + g * He + u0 + i, v); }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -351,18 +543,21 @@ size_t enc_cluster_pbuf_bytes(int B, int He) {
 }
 
 template <int G, int RT> static void launch_fwd(hipStream_t s, const EncClFwdArgs& a, int grid) {
-  if (a.d[0].ctx) hipLaunchKernelGGL((enc_cl_fwd_kernel<G, RT, true>), dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((enc_cl_fwd_kernel<G, RT, false>), dim3(grid), dim3(256), 0, s, a);
+  const size_t lds = (size_t)2 * 16 * RT * (64 * G * 2 + 16) + (size_t)4 * RT * 4 * 1024;
+  if (a.d[0].ctx) hipLaunchKernelGGL((enc_cl_fwd_kernel<G, RT, true>), dim3(grid), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((enc_cl_fwd_kernel<G, RT, false>), dim3(grid), dim3(256), lds, s, a);
 }
 template <int G, int RT> static void launch_bwd(hipStream_t s, const EncClBwdArgs& a, int grid) {
-  const size_t lds = (size_t)2 * 16 * RT * (256 * 2 + 16) + (size_t)4 * RT * 64 * 16;
+  const size_t lds = (size_t)2 * 16 * RT * (256 * 2 + 16) + (size_t)4 * RT * 64 * 16 + (size_t)4 * RT * 7 * 1024;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)enc_cl_bwd_kernel<G, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((enc_cl_bwd_kernel<G, RT>), dim3(grid), dim3(256), lds, s, a);
 }
 static int cluster_cus() {
   static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
   return cus;
 }
-void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a0, int G, int RT) {
+void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a00, int G, int RT) {
+  EncClFwdArgs a0 = a00; a0.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;    // testing aid: write-through granules even inside one XCD
   const int per_pass = std::max(8, cluster_cus() / (8 * G) * 8);          // groups (gids) one launch can keep resident
   for (int g0 = 0; g0 < 2 * a0.groups; g0 += per_pass) {
     EncClFwdArgs a = a0; a.gid0 = g0; a.ngid = std::min(per_pass, 2 * a0.groups - g0);
@@ -372,7 +567,8 @@ void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a0, int G, int RT) {
 #undef AOCR_CL
   }
 }
-void enc_cluster_backward(hipStream_t s, const EncClBwdArgs& a0, int G, int RT) {
+void enc_cluster_backward(hipStream_t s, const EncClBwdArgs& a00, int G, int RT) {
+  EncClBwdArgs a0 = a00; a0.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;
   const int per_pass = std::max(8, cluster_cus() / (8 * G) * 8);
   for (int g0 = 0; g0 < 2 * a0.groups; g0 += per_pass) {
     EncClBwdArgs a = a0; a.gid0 = g0; a.ngid = std::min(per_pass, 2 * a0.groups - g0);
