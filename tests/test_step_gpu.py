@@ -261,6 +261,47 @@ def test_attention_bf16_general_T_matches_generic(cuda, monkeypatch, He, B, W):
         assert relerr(b["grads"][k], a["grads"][k]) < 3e-2, k
 
 
+@pytest.mark.parametrize("B,W,maxlen", [(32, 72, 6), (16, 100, 9), (45, 52, 5), (256, 256, 23), (70, 416, 12), (8, 800, 4)])
+def test_decoder_cluster_kernel_matches_launch_chain(cuda, monkeypatch, B, W, maxlen):
+    """The teacher-forced decoder loop as ONE launch (dec_cluster.hip: 32 CUs share 32 rows, W1 / W2 / W_c resident in registers,
+    out / h1 / h2 / attention context exchanged as tagged granules, scores against the pre-multiplied context ctx . W_a) against
+    the per-step launch chain (AOCR_NO_DEC_CLUSTER=1) on the same bf16 operands: Hd = 512, two layers, input feed; ragged
+    batches, T up to 199, the C3 shape.  Also the gold-pass decode (the same loop without the saved gates)."""
+    cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for knob in ("0", "1"):
+        if knob == "1":
+            monkeypatch.setenv("AOCR_NO_DEC_CLUSTER", "1")
+        else:
+            monkeypatch.delenv("AOCR_NO_DEC_CLUSTER", raising=False)
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=maxlen, compute="bf16", max_decoder_l=maxlen + 1, max_beam=1)
+        loss = m.train_forward_backward(batch)
+        loss2 = m.train_forward_backward(batch)
+        assert loss2 == pytest.approx(loss, rel=1e-5)
+        assert int(m.get_tensor("cl_err").view(torch.int32)[0]) == 0, "a cluster kernel timed out waiting for its group"
+        out[knob] = dict(loss=loss, logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), dctx=m.get_tensor("dcontext").clone(),
+                         grads={k: v.clone() for k, v in m.get_gradients().items()})
+        dloss, _ = m.step(batch, True, 1)                       # forward_only: the gold pass runs the same loop without saved gates
+        out[knob]["gold"] = [float(x) for x in m._dec_out.gold_scores] + [float(dloss)]
+        m.shutdown()
+    a, b = out["1"], out["0"]
+    e = (a["logits"].double() - b["logits"].double()).abs().max().item()
+    r = relerr(b["dctx"], a["dctx"])
+    print(f"[parity] decoder cluster B={B} W={W} L={maxlen + 1}: logits max-abs {e:.3e}, d(context) rel {r:.3e}, loss {b['loss']:.5f} vs {a['loss']:.5f}")
+    assert e < 1e-2 and r < 3e-2
+    assert abs(a["loss"] - b["loss"]) < 2e-3 * max(1.0, abs(a["loss"]))
+    worst = ("", 0.0)
+    for k in a["grads"]:
+        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):
+            continue
+        x = relerr(b["grads"][k], a["grads"][k])
+        if x > worst[1]: worst = (k, x)
+        assert x < 3e-2, (k, x)
+    print(f"[parity] decoder cluster worst gradient rel {worst[1]:.3e} ({worst[0]})")
+    for x, y in zip(a["gold"], b["gold"]):
+        assert abs(x - y) < 2e-2 * max(1.0, abs(x)), (x, y)
+
+
 def test_c3_full_size_kernel_paths_agree(cuda, monkeypatch):
     """BASELINE config C3 at full size (32x256, B=256, He=256, L=24, bf16): the production dispatch (256x256 LDS-DMA conv /
     filter-gradient kernels, whole-sequence encoder kernels -- chosen by shape, no forcing) against the 128x128 and

@@ -164,6 +164,11 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     m->cl_xbuf = a.get<unsigned long long>(m->cl_xbytes / 8); m->cl_pbuf = a.get<unsigned long long>(m->cl_pbytes / 8);
     m->cl_xtab = a.get<unsigned long long>((size_t)2 * ((B + 15) / 16) * 8 + 64);      // XCC ids of the members of every group
     m->cl_err = a.get<int>(16 + 256 * 8);                        // error flag + the trash slots rows >= B store to
+    if (Hd == 512 && m->Ld == 2 && m->cfg.input_feed) {          // the decoder loop as one launch (dec_cluster.hip)
+      m->dc_xbytes = dec_cluster_xbuf_bytes((int)B); m->dc_tbytes = dec_cluster_xtab_bytes((int)B);
+      m->dc_xbuf = a.get<unsigned long long>(m->dc_xbytes / 8); m->dc_xtab = a.get<unsigned long long>(m->dc_tbytes / 8);
+      m->ctxa_b = a.get<bf16_t>(B * T * Hd);
+    }
   }
   m->shadow_dev = m->bf16 ? a.get<ShadowJob>(128) : nullptr;
   m->ws_bytes = a.off + 256;
@@ -390,6 +395,7 @@ static unsigned next_epoch(aocr_model* m) {
   if (++m->cl_epoch >= (1u << 20)) {                              // tags would repeat: clear the buffers and start over
     hipMemsetAsync(m->cl_xbuf, 0, m->cl_xbytes, m->s); hipMemsetAsync(m->cl_pbuf, 0, m->cl_pbytes, m->s); m->cl_epoch = 1;
     hipMemsetAsync(m->cl_xtab, 0, ((size_t)2 * ((m->cfg.batch_size + 15) / 16) * 8 + 64) * 8, m->s);
+    if (m->dc_xbuf) { hipMemsetAsync(m->dc_xbuf, 0, m->dc_xbytes, m->s); hipMemsetAsync(m->dc_xtab, 0, m->dc_tbytes, m->s); }
   }
   return m->cl_epoch;
 }
@@ -639,6 +645,16 @@ static void dec_init_state(aocr_model* m, const Dims& d, float* const* c0, float
   }
 }
 
+// The decoder cluster kernel (dec_cluster.hip): bf16 mode, Hd = 512, two layers, input feed (the reference's defaults at
+// He = 256); AOCR_NO_DEC_CLUSTER=1 keeps the per-step launch chain (parity tests compare the two).
+static bool dec_cluster_ok(const aocr_model* m, int T, int L) {
+  if (!m->bf16 || !m->dc_xbuf || !m->ctxa_b || !m->dec[0].swi.wb || !m->swa.wtb || !m->swc.wb) return false;
+  const char* e = getenv("AOCR_NO_DEC_CLUSTER");
+  if (e && e[0] == '1') return false;
+  static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  return dec_cluster_supported(m->Hd, m->Ld, m->cfg.input_feed, T, L, cus);
+}
+
 // teacher-forced decoder loop, model.lua:553-568 (train) / :604-627 (gold pass); the projector (model.lua:560)
 // is hoisted out of the loop: logits for all L steps in one contraction.
 void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_t st, int64_t sb, bool keep_gates) {
@@ -654,6 +670,19 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
   const bool sh = m->bf16 && m->out_b != nullptr;
   prof_mark(m, AOCR_PROF_DEC_FWD);
   dec_init_state(m, d, c0, h0, m->out_all, B, sh);
+  if (sh && dec_cluster_ok(m, T, L)) {
+    // scores against the pre-multiplied context: ctx[t] . (W_a h) = (ctx W_a)[t] . h, LSTM.lua:131-137
+    gemm_hh_shadow(s, m->context_b, Hd, m->swa.wtb, Hd, m->dctx, Hd, m->ctxa_b, Hd, B * T, Hd, Hd);
+    DecClFwdArgs a; a.B = B; a.T = T; a.L = L; a.epoch = next_epoch(m);
+    a.w1i = m->dec[0].swi.wb; a.w1h = m->dec[0].swh.wb; a.w2i = m->dec[1].swi.wb; a.w2h = m->dec[1].swh.wb; a.wc = m->swc.wb;
+    a.b2i = m->dec[1].bi; a.b2h = m->dec[1].bh; a.zx1 = m->zx1_all; a.ctxb = m->context_b; a.ctxa = m->ctxa_b;
+    for (int l = 0; l < 2; ++l) { a.cs[l] = m->dcs[l]; a.hs[l] = m->dhs[l]; a.hsb[l] = m->dhs_b[l]; a.gates[l] = keep_gates ? m->dgates[l] : nullptr; }
+    a.a_all = m->a_all; a.cat = m->cat_all; a.out = m->out_all; a.cat_b = m->cat_b; a.out_b = m->out_b;
+    a.xbuf = m->dc_xbuf; a.xtab = m->dc_xtab; a.err = m->cl_err;
+    dec_cluster_forward(s, a);
+    if (keep_gates)                                                // q = W_a h_top for all L steps: only the backward pass reads it
+      gemm_hh(s, m->dhs_b[1] + slot, Hd, m->swa.wb, Hd, m->q_all, Hd, L * B, Hd, Hd, nullptr, nullptr, 0);
+  } else
   for (int t = 0; t < L; ++t) {
     DecStepIO io; io.R = B; io.ctx_div = 1;
     io.zx1 = m->zx1_all + (size_t)t * B * 4 * Hd; io.feed = m->out_all + (size_t)t * slot;

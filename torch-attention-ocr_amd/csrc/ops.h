@@ -89,6 +89,9 @@ void grouped_wgrad(hipStream_t s, bool bf16, const WGradProblem* p, int n);
 // C = A B^T (+bias) with both operands read from K-contiguous bf16 shadows (A [M][K], B [N][K])
 void gemm_hh(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
              const float* bias, const float* bias2, int flags);
+// the same with a bf16 copy of C written beside it (plain stores)
+void gemm_hh_shadow(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, bf16_t* Cb, int64_t ldcb,
+                    int M, int N, int K);
 
 // ---- convolution layers (ops_gemm.hip)
 // xb/wb/dyb/wtb: optional bf16 shadows of the operands (both of a contraction's operands must be given to take the
@@ -209,6 +212,22 @@ size_t enc_cluster_xbuf_bytes(int B, int He);
 size_t enc_cluster_pbuf_bytes(int B, int He);
 void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a, int G, int RT);
 void enc_cluster_backward(hipStream_t s, const EncClBwdArgs& a, int G, int RT);
+// teacher-forced decoder loop in one launch (dec_cluster.hip): Hd = 512, two layers, input feed, bf16 mode
+struct DecClFwdArgs {
+  int B, T, L; unsigned epoch; int group0 = 0, ngroups = 0, force_remote = 0;
+  const bf16_t *w1i, *w1h, *w2i, *w2h, *wc;           // bf16 shadows: [4 Hd][Hd] x 4, W_c [Hd][2 Hd]
+  const float *b2i, *b2h;                              // layer-2 biases (layer 1's are inside zx1)
+  const float* zx1;                                    // [L][B][4 Hd]: embedding part of layer 1 + both biases
+  const bf16_t *ctxb, *ctxa;                           // [B][T][Hd]: encoder context and context . W_a
+  float* cs[2]; float* hs[2]; bf16_t* hsb[2];          // [L + 1][B][Hd], slot 0 = initial state
+  float* gates[2];                                     // [L][B][4 Hd] post-activation, or nullptr
+  float *a_all, *cat, *out; bf16_t *cat_b, *out_b;
+  unsigned long long *xbuf, *xtab; int* err;
+};
+bool dec_cluster_supported(int Hd, int Ld, int input_feed, int T, int L, int cus);
+size_t dec_cluster_xbuf_bytes(int B);
+size_t dec_cluster_xtab_bytes(int B);
+void dec_cluster_forward(hipStream_t s, const DecClFwdArgs& a);
 void enc_seq_backward(hipStream_t s, const EncSeqBwdArgs& a);
 void enc_seq_forward(hipStream_t s, const EncSeqFwdArgs& a);
 // data path (data.hip): 255*rgb2y + image.scale to (out_h, out_w) for n images sharing out_w

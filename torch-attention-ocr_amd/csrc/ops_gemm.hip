@@ -242,6 +242,14 @@ void gemm_hh(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64
   launch_lds(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K, 1);
 }
 
+void gemm_hh_shadow(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, bf16_t* Cb, int64_t ldcb,
+                    int M, int N, int K) {
+  LoadKh a; a.p = A; a.ld = lda; a.rows = M; a.K = K;
+  LoadKh b; b.p = B; b.ld = ldb; b.rows = N; b.K = K;
+  EpStore e = make_store(C, ldc, M, N, nullptr, nullptr, 0); e.Cb = Cb; e.ldcb = ldcb;
+  launch_lds(s, a, b, e, M, N, K, 1);
+}
+
 template <class LD, class KERNEL>
 static void grouped_launch(hipStream_t s, const WGradProblem* const* q, int cnt, int slots, bool shadows, KERNEL kernel) {
   int64_t tiles = 0;
