@@ -1,0 +1,23 @@
+"""Debugging aid: cycles per phase of the decoder cluster kernel (AOCR_DC_STAMPS=1), workgroup 0, summed over the L steps."""
+import os, sys
+os.environ["AOCR_DC_STAMPS"] = "1"
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "torch-attention-ocr_amd"))
+import torch
+from test_step_gpu import make
+B, W, L = 256, 256, 24
+m, O, ocfg, P, st, batch = make(dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True), B=B, W=W, maxlen=L - 1, compute="bf16", max_decoder_l=L, max_beam=1)
+for _ in range(3):
+    m.train_forward_backward(batch)
+torch.cuda.synchronize()
+s = m.get_tensor("dc_stamps").view(torch.int64).cpu().tolist()
+names = ["gather out", "layer 1 rest", "gather h1", "layer 2", "gather h2", "attn publish", "gather c", "out", "(gathers: first poll round)", "(gathers: retries)", "attn scores", "attn softmax", "attn context", "(gathers: LDS write + barrier)", "-", "group in one XCD"]
+tot = sum(s)
+raw = {14, 15}
+tot = sum(v for i, v in enumerate(s) if i not in {8, 9, 13, 14, 15})
+for i, (n, v) in enumerate(zip(names, s)):
+    if i in raw:
+        print(f"{n:30s} {v:9d} (total over {L} steps)")
+    else:
+        print(f"{n:30s} {v / L:9.0f} cycles/step  {100.0 * v / tot:5.1f} %")
+print("total cycles/step", tot / L)

@@ -1,7 +1,7 @@
 // dec_cluster.hip -- the teacher-forced decoder loop (model.lua:553-568 train, :604-627 gold pass; cell LSTM.lua:18-122, attention
 // LSTM.lua:124-162) as ONE launch for all L steps: a GROUP of 32 compute units (one XCD under round-robin dispatch) owns 32 batch
 // rows, and every recurrent weight the loop needs -- W1 = [W1_i2h(feed part) | W1_h2h], W2 = [W2_i2h | W2_h2h], W_a, W_c: 10 MB in bf16
-// at Hd = 512 -- is RESIDENT IN THE REGISTERS of the group (288 VGPRs per lane: member m owns hidden units 16m .. 16m+15 of both
+// at Hd = 512 -- is RESIDENT IN THE REGISTERS of the group (192 VGPRs per lane; half of W2 and W_c stream from L2 beside the polls of their phase: member m owns hidden units 16m .. 16m+15 of both
 // layers and output columns 16m .. 16m+15 of W_a / W_c).  The launch chain this replaces runs 5 dependent kernels per step, each of
 // which re-streams its weights through L2 and pays a launch + drain (~8 us each at C3: 0.94 ms for 24 steps).
 //
@@ -30,53 +30,113 @@ typedef unsigned long long u64;
 namespace {
 constexpr int DC_SPIN_LIMIT = 1 << 18;
 constexpr int HD = 512, NM = 32, R = 32, PA = HD * 2 + 16;      // hidden size, members per group, rows per group, LDS operand pitch
+constexpr int LDS_BYTES = 3 * R * PA + 32768;                    // three operand buffers + the reduction scratch
 
-__device__ __forceinline__ void dpoll16(u32x4& v, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory"); }
-__device__ __forceinline__ void dwait0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// ---- VMEM in program order: polls first, the previous phase's output stores behind them, then `s_waitcnt vmcnt(#stores)` -- the
+// polls are waited for, the stores are not (vmcnt counts loads and stores in issue order on gfx9).  Every store below is ONE
+// instruction whatever the lane's predicate (invalid lanes point at a trash slot), so the counts are exact.
+// poll j of a gather: scalar base + one 32-bit lane offset shared by all 16 polls + an immediate (the polls of a thread are a constant stride apart)
+template <int IMM> __device__ __forceinline__ void dpoll16(u32x4& v, unsigned voff, const void* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 sc1" : "=v"(v) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+template <int RS, int J> __device__ __forceinline__ void dpoll_j(u32x4& v, unsigned voff, const unsigned char* sbase) {
+  constexpr int STEP = 2 * RS * 8;                                 // bytes between the rows idx >> 7 of polls j and j + 1
+  if constexpr (STEP * 15 < 4096) dpoll16<STEP * J>(v, voff, sbase);
+  else dpoll16<0>(v, voff, sbase + (size_t)STEP * J);
+}
+template <int RS, int J = 0> __device__ __forceinline__ void dpoll_all(u32x4 (&gr)[16], unsigned voff, const unsigned char* sbase) {
+  if constexpr (J < 16) { dpoll_j<RS, J>(gr[J], voff, sbase); dpoll_all<RS, J + 1>(gr, voff, sbase); }
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void dpin(u32x4& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void dst_granules(void* p, u32x4 v, bool local) {
-  if (local) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+__device__ __forceinline__ void st4(void* p, unsigned v) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st4f(void* p, float v) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st8(void* p, u32x2 v) { asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st16f(void* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+// granule stores: plain inside one XCD (they stay in its L2, which the polls read), write-through otherwise
+__device__ __forceinline__ void st_gr16(void* p, u32x4 v, int mode) {
+  if (mode == 1) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else if (mode == 3) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else if (mode == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
   else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
+__device__ __forceinline__ void st_gr8(void* p, u32x2 v, int mode) {
+  if (mode == 1) asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+  else if (mode == 2) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+  else if (mode == 3) asm volatile("global_store_dwordx2 %0, %1, off nt\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+  else if (mode == 4) asm volatile("global_store_dwordx2 %0, %1, off sc0\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+}
+// workgroup barrier that orders LDS only: global loads / stores stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 __device__ __forceinline__ unsigned bfbits(float x) { bf16_t h = (bf16_t)x; unsigned short u; __builtin_memcpy(&u, &h, 2); return u; }
+__device__ __forceinline__ unsigned bfpair(float a, float b) { return bfbits(a) | (bfbits(b) << 16); }
 __device__ __forceinline__ u64 ldg64(const u64* p) { return __hip_atomic_load(const_cast<u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stg64(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ddma4(const void* g, unsigned char* lds_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
+
+// wave-wide reductions on the DPP network (no LDS round trips): butterflies inside a row of 16, then row_bcast15 / row_bcast31
+template <int CTRL, int ROWS> __device__ __forceinline__ float dppf(float ident, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), CTRL, ROWS, 0xF, false));
+}
+template <class OP> __device__ __forceinline__ float wave_reduce(float v, float ident, OP op) {
+  v = op(v, dppf<0xB1, 0xF>(ident, v));          // quad_perm [1,0,3,2]
+  v = op(v, dppf<0x4E, 0xF>(ident, v));          // quad_perm [2,3,0,1]
+  v = op(v, dppf<0x141, 0xF>(ident, v));         // row_half_mirror
+  v = op(v, dppf<0x140, 0xF>(ident, v));         // row_mirror: every lane of a row holds the row's result
+  v = op(v, dppf<0x142, 0xA>(ident, v));         // row_bcast15 into rows 1, 3
+  v = op(v, dppf<0x143, 0xC>(ident, v));         // row_bcast31 into rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // all-gather of one 32 x 512 bf16 operand into an LDS buffer: element (row, 4-unit chunk c) is the pair of granules at
-// src + row * RS + (c >> 2) * MS + 2 * (c & 3); 16 polls of 16 bytes per thread.  Returns false after a timeout.
-template <int RS, int MS>
-__device__ __forceinline__ bool gather(const u64* src, unsigned tag, unsigned char* dst, int tid, int* err, int code) {
-  bool dead = false;
-  __syncthreads();                              // every wave of this workgroup is past its reads of the previous contents of dst
+// src + row * RS + (c >> 2) * MS + 2 * (c & 3); 16 polls of 16 bytes per thread.  pre(): loads the caller wants in flight beside the
+// polls (older: landed when the polls have); deferred(): exactly NST one-instruction stores.  Ends with the operand complete in
+// LDS for every wave; *dead_flag is set (for all waves) after a timeout.
+template <int RS, int MS, int NPUB, int NST, class PRE, class PUB, class DEF>
+__device__ __forceinline__ void gather(const u64* src, unsigned tag, unsigned char* dst, int tid, int* err, int code, int* dead_flag, PRE&& pre, PUB&& publish,
+                                       DEF&& deferred, u64 (&gs)[3], bool stamps) {
+  u32x4 gr[16];
+  pre();
+  const unsigned voff = (unsigned)(((tid >> 7) * RS + ((tid & 127) >> 2) * MS + 2 * (tid & 3)) * 8);     // poll j: idx = tid + 256 j -> row (tid >> 7) + 2 j, the same chunk
+  const unsigned char* const sbase = reinterpret_cast<const unsigned char*>(src);                          // (wave-uniform)
+  dpoll_all<RS>(gr, voff, sbase);
+  publish();                                    // exactly NPUB granule stores: this workgroup's own part, behind the polls so that the polls do not wait for its write acknowledgements
+  deferred();
+  u64 t0 = stamps ? __builtin_readcyclecounter() : 0;
+  lds_barrier();                                // every wave of this workgroup is past its reads of the previous contents of dst
+  wait_vm<NPUB + NST>();
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    u32x4 gr[8];
-    auto issue = [&]() {
+  for (int j = 0; j < 16; ++j) dpin(gr[j]);
+  if (stamps) { const u64 t1 = __builtin_readcyclecounter(); gs[0] += t1 - t0; t0 = t1; }
+  auto landed = [&]() {
+    bool ok = true;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const int idx = tid + 256 * (8 * half + j), row = idx >> 7, ch = idx & 127; dpoll16(gr[j], src + (size_t)row * RS + (ch >> 2) * MS + 2 * (ch & 3)); }
-    };
-    issue(); dwait0();
+    for (int j = 0; j < 16; ++j) ok = ok && gr[j][1] == tag && gr[j][3] == tag;
+    return (bool)__all(ok);
+  };
+  int spins = 0;
+  bool ok = landed();
+#pragma nounroll
+  while (!ok) {
+    asm volatile("" : "+s"(spins));                 // keeps the compiler from reasoning about (and unrolling over) the trip count
+    if (++spins > DC_SPIN_LIMIT) { if ((tid & 63) == 0) { atomicExch(err, code); *dead_flag = 1; } break; }
+    __builtin_amdgcn_s_sleep(1);
+    dpoll_all<RS>(gr, voff, sbase);
+    wait_vm<0>();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dpin(gr[j]);
-    int spins = 0;
-    while (!dead) {
-      bool ok = true;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ok = ok && gr[j][1] == tag && gr[j][3] == tag;
-      if (__all(ok)) break;
-      if (++spins > DC_SPIN_LIMIT) { dead = true; if ((tid & 63) == 0) atomicExch(err, code); break; }
-      __builtin_amdgcn_s_sleep(1);
-      issue(); dwait0();
-#pragma unroll
-      for (int j = 0; j < 8; ++j) dpin(gr[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const int idx = tid + 256 * (8 * half + j), row = idx >> 7, ch = idx & 127; *reinterpret_cast<u32x2*>(dst + (size_t)row * PA + ch * 8) = u32x2{gr[j][0], gr[j][2]}; }
+    for (int j = 0; j < 16; ++j) dpin(gr[j]);
+    ok = landed();
   }
-  return !dead;
+  if (stamps) { const u64 t1 = __builtin_readcyclecounter(); gs[1] += t1 - t0; t0 = t1; }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { const int idx = tid + 256 * j, row = idx >> 7, ch = idx & 127; *reinterpret_cast<u32x2*>(dst + (size_t)row * PA + ch * 8) = u32x2{gr[j][0], gr[j][2]}; }
+  lds_barrier();
+  if (stamps) { const u64 t1 = __builtin_readcyclecounter(); gs[2] += t1 - t0; }
 }
 // the same operand from a plain bf16 array [B][512] (step 0: the initial states)
 __device__ __forceinline__ void load_rows(const bf16_t* src, int row0, int B, unsigned char* dst, int tid) {
@@ -89,14 +149,16 @@ __device__ __forceinline__ void load_rows(const bf16_t* src, int row0, int B, un
 }
 }  // namespace
 
+#define DC_STAMP(k) do { if (p.stamps) { const u64 now_ = __builtin_readcyclecounter(); stamp[k] += now_ - tprev; tprev = now_; } } while (0)
+
 __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const F = lds;                        // feed (out(t-1)), later c(t)
   unsigned char* const H1 = lds + R * PA;              // h1(t-1), later h1(t)
   unsigned char* const H2 = lds + 2 * R * PA;          // h2(t-1), later h2(t)
-  unsigned char* const zxs = lds + 3 * R * PA;         // [4 waves][2 rt][4 gates][256 B]: zx1 staging (LDS-DMA)
-  float* const red = reinterpret_cast<float*>(lds + 3 * R * PA + 8192);     // [4 waves][2][64][4] partial tiles / attention scratch (8 KB)
-  float* const sc = red + 2048;                        // [<= 256] attention scores / probabilities, then [4][512] partial context (8 KB + 1 KB)
+  float* const red = reinterpret_cast<float*>(lds + 3 * R * PA);     // [4 waves][4 tiles][2][64 lanes][4]: K-split partial tiles (32 KB);
+  float* const part = red;                                            // attention: [4 waves][512] partial context,
+  float* const sc = red + 2048;                                       //            [256] scores
   __shared__ int s_local, s_dead;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
@@ -106,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
   const int group = p.group0 + gl;
   const int B = p.B, T = p.T, L = p.L, row0 = group * R;
   const int unit = 16 * member + 4 * wave + q;                   // gate epilogues: this lane's hidden unit (lane = (batch row c16, unit))
-  const int arow_u = 16 * member + 4 * wave + (c16 >> 2), arow_g = c16 & 3;      // A fragment row: tile row c16 = 4 * unit + gate
+  const size_t slot = (size_t)B * HD;
 
   // ---- co-location check (rnn_cluster.hip): plain granule stores are only visible to the group's polls inside one XCD
   u64* const xt = p.xtab + (size_t)group * NM;
@@ -116,231 +178,299 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
     int same = 1;
     for (int m = 0; m < NM; ++m) {
       u64 v; int spins = 0;
-      while ((unsigned)((v = ldg64(xt + m)) >> 32) != p.epoch) { if (++spins > DC_SPIN_LIMIT) { atomicExch(p.err, 13); same = 0; break; } __builtin_amdgcn_s_sleep(2); }
+      while ((unsigned)((v = ldg64(xt + m)) >> 32) != p.epoch) { if (++spins > DC_SPIN_LIMIT) { atomicExch(p.err, 15); same = 0; break; } __builtin_amdgcn_s_sleep(2); }
       if ((unsigned)v != xcc + 1u) same = 0;
     }
     s_local = same && !p.force_remote; s_dead = 0;
   }
   __syncthreads();
-  const bool local = __builtin_amdgcn_readfirstlane(s_local) != 0;
+  const int local = __builtin_amdgcn_readfirstlane(s_local) != 0 ? (p.exp >> 4 ? p.exp >> 4 : 1) : 0;     // store mode of the granules (AOCR_DC_EXP >> 4: experiments)
 
-  // ---- resident weights (A fragments)
-  bf16x8 w1[32], w2[32], wcr[8];
+  // ---- resident weights: MFMA A fragments.  The four waves split K (wave w: columns 256 w .. 256 w + 255 of the concatenated
+  // operand) and each holds all 64 gate rows of the member (4 tiles of [unit][gate] rows), so an operand fragment read from LDS
+  // feeds four products; the partial tiles meet in LDS, wave w finishes tile w (units 4w .. 4w+3).
+  // Resident: W1 and tiles 0, 1 of W2 (192 VGPRs); tiles 2, 3 of W2 and W_c stream from L2 beside the polls of their phase.
+  bf16x8 w1a[16], w1b[16], w2a[16];
+  const size_t xwf = (p.exp & 2) ? 0 : 1;
+  auto wfrag = [&](const bf16_t* wi, const bf16_t* wh, int c16_, int q_, int j, int s) {
+    return *reinterpret_cast<const bf16x8*>((wave < 2 ? wi : wh) + xwf * ((size_t)((c16_ & 3) * HD + 16 * member + 4 * j + (c16_ >> 2)) * HD + 256 * (wave & 1) + 32 * s + 8 * q_));
+  };
 #pragma unroll
-  for (int s = 0; s < 32; ++s) {
-    const size_t ro = (size_t)(arow_g * HD + arow_u) * HD + 32 * (s & 15) + 8 * q;
-    w1[s] = *reinterpret_cast<const bf16x8*>((s < 16 ? p.w1i : p.w1h) + ro);
-    w2[s] = *reinterpret_cast<const bf16x8*>((s < 16 ? p.w2i : p.w2h) + ro);
-  }
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-  for (int s = 0; s < 8; ++s) wcr[s] = *reinterpret_cast<const bf16x8*>(p.wc + (size_t)(16 * member + c16) * 2 * HD + 256 * wave + 32 * s + 8 * q);
+    for (int s = 0; s < 8; ++s) {
+      w1a[j * 8 + s] = wfrag(p.w1i, p.w1h, c16, q, j, s); w1b[j * 8 + s] = wfrag(p.w1i, p.w1h, c16, q, j + 2, s);
+      w2a[j * 8 + s] = wfrag(p.w2i, p.w2h, c16, q, j, s);
+    }
   float b2[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) b2[i] = p.b2i[i * HD + unit] + p.b2h[i * HD + unit];
-  float c1[2], c2[2];
+  float c1[2], c2[2], zxr[2][4];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) { const int row = min(row0 + 16 * rt + c16, B - 1); c1[rt] = p.cs[0][(size_t)row * HD + unit]; c2[rt] = p.cs[1][(size_t)row * HD + unit]; }
-
+  for (int rt = 0; rt < 2; ++rt) {
+    const int row = min(row0 + 16 * rt + c16, B - 1);
+    c1[rt] = p.cs[0][(size_t)row * HD + unit]; c2[rt] = p.cs[1][(size_t)row * HD + unit];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) zxr[rt][i] = p.zx1[(size_t)row * 4 * HD + i * HD + unit];
+  }
   u64* const xg = p.xbuf + (size_t)group * 4 * 2 * 8192;          // [kind: out, h1, h2, c][parity][8192 granules]
-  auto dma_zx = [&](int t) {
+  load_rows(p.out_b, row0, B, F, tid); load_rows(p.hsb[0], row0, B, H1, tid); load_rows(p.hsb[1], row0, B, H2, tid);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): nothing of the prologue is in flight inside the loop
+  __syncthreads();
+  u64 stamp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, gs[3] = {0, 0, 0}, tprev = __builtin_readcyclecounter();
+
+  // the row of the group whose attention this workgroup computes
+  const int arow = row0 + member; const bool rvalid = arow < B;
+  const bf16_t* const ca = p.ctxa + (size_t)min(arow, B - 1) * T * HD;
+  const bf16_t* const cx = p.ctxb + (size_t)min(arow, B - 1) * T * HD;
+  const size_t xa = (p.exp & 1) ? 0 : 1, xw = (p.exp & 2) ? 0 : 1;      // perf experiments (AOCR_DC_EXP): collapse the streamed addresses
+  const int ntile = (T + 15) >> 4;
+
+  // one K-split product: acc tiles -> LDS -> this wave's tile (both row tiles) summed over the four waves
+  auto product = [&](const bf16x8 (&wa)[16], const bf16x8 (&wb)[16], const unsigned char* x0, const unsigned char* x1, f32x4 (&v)[2]) {
+    const unsigned char* src = (wave < 2 ? x0 : x1) + (256 * (wave & 1) + 8 * q) * 2;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt + c16) * PA + 64 * s);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(j < 2 ? wa[j * 8 + s] : wb[(j - 2) * 8 + s], bv, acc[j][rt], 0, 0, 0);
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) *reinterpret_cast<f32x4*>(red + ((size_t)((wave * 4 + j) * 2 + rt) * 64 + lane) * 4) = acc[j][rt];
+    lds_barrier();
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-      const int row = min(row0 + 16 * rt + c16, B - 1);
+      v[rt] = *reinterpret_cast<const f32x4*>(red + ((size_t)((0 * 4 + wave) * 2 + rt) * 64 + lane) * 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ddma4(p.zx1 + ((size_t)t * B + row) * 4 * HD + i * HD + unit, zxs + wave * 2048 + (rt * 4 + i) * 256);
+      for (int w2_ = 1; w2_ < 4; ++w2_) v[rt] += *reinterpret_cast<const f32x4*>(red + ((size_t)((w2_ * 4 + wave) * 2 + rt) * 64 + lane) * 4);
     }
   };
-  dma_zx(0);
-  load_rows(p.out_b, row0, B, F, tid); load_rows(p.hsb[0], row0, B, H1, tid); load_rows(p.hsb[1], row0, B, H2, tid);
-  dwait0();
-  __syncthreads();
-  bool dead = false;
+  // LSTM cell on this lane's (unit, row) pairs; returns the packed h of the four units of (row, wave) in lanes q == 0
+  auto cell = [&](const f32x4 (&z)[2], float (&c)[2], f32x4 (&g)[2], u32x2 (&hp)[2]) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const float ig = sigmoidf_(z[rt][0]), fg = sigmoidf_(z[rt][1]), og = sigmoidf_(z[rt][2]), gg = tanhf_(z[rt][3]);
+      const float cn = fg * c[rt] + ig * gg, hn = og * tanhf_(cn);
+      c[rt] = cn; g[rt] = f32x4{ig, fg, og, gg};
+      const unsigned hb = bfbits(hn);
+      const unsigned h1v = __shfl(hb, lane + 16, 64), h2v = __shfl(hb, lane + 32, 64), h3v = __shfl(hb, lane + 48, 64);
+      hp[rt] = u32x2{hb | (h1v << 16), h2v | (h3v << 16)};
+    }
+  };
+  // deferred stores of one LSTM layer (6 instructions; 8 with the [c ; h] shadow of the top layer)
+  // (ot: the thread id through an opaque per-step copy, so that the address arithmetic stays inside the step instead of being hoisted
+  // out of the loop into ~200 live registers)
+  auto store_layer = [&](int ot, int l, int t, const f32x4 (&g)[2], const float (&c)[2], const u32x2 (&hp)[2], bool top) {
+    const int c16 = ot & 15, q = (ot >> 4) & 3, unit = 16 * member + 4 * wave + q;
+    unsigned char* const trash = reinterpret_cast<unsigned char*>(p.err + 16) + ot * 16;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row = row0 + 16 * rt + c16; const bool ok = row < B;
+      st16f(ok && p.gates[l] ? (void*)(p.gates[l] + (((size_t)t * B + row) * HD + unit) * 4) : (void*)trash, g[rt]);
+      st4f(ok ? (void*)(p.cs[l] + (size_t)(t + 1) * slot + (size_t)row * HD + unit) : (void*)trash, c[rt]);
+      const bool okh = ok && q == 0;
+      st8(okh ? (void*)(p.hsb[l] + (size_t)(t + 1) * slot + (size_t)row * HD + 16 * member + 4 * wave) : (void*)trash, hp[rt]);
+      if (top) st8(okh ? (void*)(p.cat_b + ((size_t)t * B + row) * 2 * HD + HD + 16 * member + 4 * wave) : (void*)trash, hp[rt]);   // JoinTable [c ; h_top], LSTM.lua:153
+    }
+  };
+  f32x4 ov = f32x4{0.f, 0.f, 0.f, 0.f}; u32x2 ovb = u32x2{0u, 0u};       // out(t) of this lane (waves 0, 1), stored one phase late
+  auto store_out = [&](int ot, int t) {                                  // 2 instructions
+    const int c16 = ot & 15, q = (ot >> 4) & 3;
+    unsigned char* const trash = reinterpret_cast<unsigned char*>(p.err + 16) + ot * 16;
+    const int row = row0 + 16 * wave + c16; const bool ok = wave < 2 && row < B;
+    const size_t o = (size_t)(t + 1) * slot + (size_t)row * HD + 16 * member + 4 * q;
+    st16f(ok ? (void*)(p.out + o) : (void*)trash, ov);
+    st8(ok ? (void*)(p.out_b + o) : (void*)trash, ovb);
+  };
 
-  for (int t = 0; t < L && !dead; ++t) {
+  for (int t = 0; t < L; ++t) {
     const unsigned tagc = p.epoch * 4096u + (unsigned)(t + 1);    // tag of everything produced in step t
     const int par = t & 1;
-    const size_t slot = (size_t)B * HD;
+    int ot = tid; asm volatile("" : "+v"(ot));                     // opaque copy of the thread id (see store_layer)
+    const int olane = ot & 63, oc16 = ot & 15, oq = (ot >> 4) & 3, ounit = 16 * member + 4 * wave + oq;
+    unsigned char* const otrash = reinterpret_cast<unsigned char*>(p.err + 16) + ot * 16;
     // =================== layer 1: z1 = [feed ; h1(t-1)] W1^T + zx1(t)
     if (t > 0) {
-      const bool okg = gather<8, 256>(xg + (size_t)(0 * 2 + ((t - 1) & 1)) * 8192, p.epoch * 4096u + (unsigned)t, F, tid, p.err, 11);
-      if (!okg) s_dead = 1;
-      __syncthreads();
-      if (s_dead) { dead = true; break; }
+      gather<8, 256, 1, 2>(xg + (size_t)(0 * 2 + ((t - 1) & 1)) * 8192, p.epoch * 4096u + (unsigned)t, F, ot, p.err, 11, &s_dead, [] {},
+                           [&] {                                    // out(t-1) of this member's 16 units (waves 0, 1: one row tile each)
+                             st_gr16(wave < 2 ? (void*)(xg + (size_t)(0 * 2 + ((t - 1) & 1)) * 8192 + ((size_t)(member * 32 + 16 * wave + oc16) * 8 + 2 * oq)) : (void*)otrash,
+                                     u32x4{ovb[0], p.epoch * 4096u + (unsigned)t, ovb[1], p.epoch * 4096u + (unsigned)t}, local);
+                           },
+                           [&] { store_out(ot, t - 1); }, gs, p.stamps != nullptr);
+      if (s_dead) break;
     }
+    DC_STAMP(0);
+    f32x4 g1[2]; u32x2 hp1[2];
     {
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 z[2];
+      product(w1a, w1b, F, H1, z);
 #pragma unroll
-      for (int s = 0; s < 32; ++s) {
-        const unsigned char* src = s < 16 ? F : H1;
+      for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          const bf16x8 bv = *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt + c16) * PA + ((s & 15) * 32 + 8 * q) * 2);
-          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[s], bv, acc[rt], 0, 0, 0);
-        }
-      }
-      unsigned hb[2];
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const int row = row0 + 16 * rt + c16;
-        float z[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) z[i] = acc[rt][i] + *reinterpret_cast<const float*>(zxs + wave * 2048 + (rt * 4 + i) * 256 + lane * 4);
-        const float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), og = sigmoidf_(z[2]), gg = tanhf_(z[3]);
-        const float cn = fg * c1[rt] + ig * gg, hn = og * tanhf_(cn);
-        c1[rt] = cn; hb[rt] = bfbits(hn);
-        if (row < B) {
-          if (p.gates[0]) { float* gp = p.gates[0] + ((size_t)t * B + row) * 4 * HD + unit; gp[0] = ig; gp[HD] = fg; gp[2 * HD] = og; gp[3 * HD] = gg; }
-          const size_t o = (size_t)(t + 1) * slot + (size_t)row * HD + unit;
-          p.cs[0][o] = cn; p.hs[0][o] = hn; p.hsb[0][o] = (bf16_t)hn;
-        }
-      }
-      // publish h1(t): the four units of (row, wave) are in lanes q = 0..3 of column c16 -> lane q = 0 packs them
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const unsigned h1v = __shfl(hb[rt], lane + 16, 64), h2v = __shfl(hb[rt], lane + 32, 64), h3v = __shfl(hb[rt], lane + 48, 64);
-        if (q == 0) dst_granules(xg + (size_t)(1 * 2 + par) * 8192 + ((size_t)(member * 32 + 16 * rt + c16) * 8 + 2 * wave), u32x4{hb[rt] | (h1v << 16), tagc, h2v | (h3v << 16), tagc}, local);
-      }
+        for (int i = 0; i < 4; ++i) z[rt][i] += zxr[rt][i];
+      cell(z, c1, g1, hp1);
     }
+    DC_STAMP(1);
     // =================== layer 2: z2 = [h1(t) ; h2(t-1)] W2^T + b
+    bf16x8 w2b[16];
+    auto publish_h = [&](int kind, const u32x2 (&hp)[2]) {       // h(t) of (row, wave): lanes q == 0 hold the four units packed
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+        st_gr16(oq == 0 ? (void*)(xg + (size_t)(kind * 2 + par) * 8192 + ((size_t)(member * 32 + 16 * rt + oc16) * 8 + 2 * wave)) : (void*)otrash, u32x4{hp[rt][0], tagc, hp[rt][1], tagc}, local);
+    };
+    gather<8, 256, 2, 6>(xg + (size_t)(1 * 2 + par) * 8192, tagc, H1, ot, p.err, 12, &s_dead,
+                      [&] {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                          for (int s = 0; s < 8; ++s) w2b[j * 8 + s] = wfrag(p.w2i, p.w2h, oc16, oq, j + 2, s);
+                      },
+                      [&] { publish_h(1, hp1); }, [&] { store_layer(ot, 0, t, g1, c1, hp1, false); }, gs, p.stamps != nullptr);
+    if (s_dead) break;
+    DC_STAMP(2);
+    f32x4 g2[2]; u32x2 hp2[2];
     {
-      const bool okg = gather<8, 256>(xg + (size_t)(1 * 2 + par) * 8192, tagc, H1, tid, p.err, 12);
-      if (!okg) s_dead = 1;
-      __syncthreads();
-      if (s_dead) { dead = true; break; }
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 z[2];
+      product(w2a, w2b, H1, H2, z);
 #pragma unroll
-      for (int s = 0; s < 32; ++s) {
-        const unsigned char* src = s < 16 ? H1 : H2;
+      for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          const bf16x8 bv = *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt + c16) * PA + ((s & 15) * 32 + 8 * q) * 2);
-          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[s], bv, acc[rt], 0, 0, 0);
-        }
-      }
-      unsigned hb[2];
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const int row = row0 + 16 * rt + c16;
-        const float ig = sigmoidf_(acc[rt][0] + b2[0]), fg = sigmoidf_(acc[rt][1] + b2[1]), og = sigmoidf_(acc[rt][2] + b2[2]), gg = tanhf_(acc[rt][3] + b2[3]);
-        const float cn = fg * c2[rt] + ig * gg, hn = og * tanhf_(cn);
-        c2[rt] = cn; hb[rt] = bfbits(hn);
-        if (row < B) {
-          if (p.gates[1]) { float* gp = p.gates[1] + ((size_t)t * B + row) * 4 * HD + unit; gp[0] = ig; gp[HD] = fg; gp[2 * HD] = og; gp[3 * HD] = gg; }
-          const size_t o = (size_t)(t + 1) * slot + (size_t)row * HD + unit;
-          p.cs[1][o] = cn; p.hs[1][o] = hn; p.hsb[1][o] = (bf16_t)hn;
-          const size_t oc = ((size_t)t * B + row) * 2 * HD + HD + unit;                      // JoinTable [c ; h_top], LSTM.lua:153
-          p.cat[oc] = hn; p.cat_b[oc] = (bf16_t)hn;
-        }
-      }
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const unsigned h1v = __shfl(hb[rt], lane + 16, 64), h2v = __shfl(hb[rt], lane + 32, 64), h3v = __shfl(hb[rt], lane + 48, 64);
-        if (q == 0) dst_granules(xg + (size_t)(2 * 2 + par) * 8192 + ((size_t)(member * 32 + 16 * rt + c16) * 8 + 2 * wave), u32x4{hb[rt] | (h1v << 16), tagc, h2v | (h3v << 16), tagc}, local);
-      }
+        for (int i = 0; i < 4; ++i) z[rt][i] += b2[i];
+      cell(z, c2, g2, hp2);
     }
-    // =================== attention of row `member` of the group
+    DC_STAMP(3);
+    // =================== attention of row `member` of the group: scores on MFMA (A = a 16-step tile of ctx . W_a, B = h2 broadcast)
+    float av; unsigned cb;
     {
-      const bool okg = gather<8, 256>(xg + (size_t)(2 * 2 + par) * 8192, tagc, H2, tid, p.err, 13);
-      if (!okg) s_dead = 1;
-      __syncthreads();
-      if (s_dead) { dead = true; break; }
-      // scores of this member's row against the pre-multiplied context: s[tt] = ctxA[row][tt] . h2[row]
-      const int arow = row0 + member;                              // the batch row whose attention this workgroup computes
-      const bool rvalid = arow < B;
-      float h2v[8];
+      bf16x8 cav[16];                                              // tile `wave` of the pre-multiplied context: in flight beside the polls
+      const bf16_t* carow = ca + xa * ((size_t)min(16 * wave + oc16, T - 1) * HD + 8 * oq);
+      gather<8, 256, 2, 8>(xg + (size_t)(2 * 2 + par) * 8192, tagc, H2, ot, p.err, 13, &s_dead,
+                        [&] {
+#pragma unroll
+                          for (int s = 0; s < 8; ++s) cav[s] = *reinterpret_cast<const bf16x8*>(carow + xa * 32 * s);
+                        },
+                        [&] { publish_h(2, hp2); }, [&] { store_layer(ot, 1, t, g2, c2, hp2, true); }, gs, p.stamps != nullptr);
+      if (s_dead) break;
+      DC_STAMP(4);
+#pragma unroll
+      for (int s = 8; s < 16; ++s) cav[s] = *reinterpret_cast<const bf16x8*>(carow + xa * 32 * s);
+      const unsigned char* hrow = H2 + (size_t)member * PA + 16 * q;
+      for (int tile = wave; tile < ntile; tile += 4) {
+        if (tile != wave) {
+          const bf16_t* r2 = ca + (size_t)min(16 * tile + oc16, T - 1) * HD + 8 * oq;
+#pragma unroll
+          for (int s = 0; s < 16; ++s) cav[s] = *reinterpret_cast<const bf16x8*>(r2 + 32 * s);
+        }
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cav[s], *reinterpret_cast<const bf16x8*>(hrow + 64 * s), acc, 0, 0, 0);
+        if (c16 == 0) *reinterpret_cast<f32x4*>(sc + 16 * tile + 4 * q) = acc;       // rows 4q .. 4q+3 of the tile; every column holds the same value
+      }
+      // context rows of this wave: tt = 64 c + 4 i + wave; the first chunk is loaded while the softmax runs
+      bf16x8 cv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cv[i] = *reinterpret_cast<const bf16x8*>(cx + xa * ((size_t)min(4 * i + wave, T - 1) * HD + 8 * olane));
+      lds_barrier();
+      DC_STAMP(10);
+      // softmax over T (LSTM.lua:139), redundantly in every wave: lane holds steps lane + 64 j
+      float aj[4];
       {
-        const bf16x8 hv = *reinterpret_cast<const bf16x8*>(H2 + (size_t)member * PA + lane * 16);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) h2v[e] = (float)hv[e];
-      }
-      const bf16_t* ca = p.ctxa + ((size_t)min(arow, B - 1) * T) * HD + lane * 8;
-      const bf16_t* cx = p.ctxb + ((size_t)min(arow, B - 1) * T) * HD + lane * 8;
-      for (int tt = wave; tt < T; tt += 4) {
-        const bf16x8 cv = *reinterpret_cast<const bf16x8*>(ca + (size_t)tt * HD);
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s = fmaf((float)cv[e], h2v[e], s);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (lane == 0) sc[tt] = s;
-      }
-      __syncthreads();
-      if (wave == 0) {                                             // softmax over T (LSTM.lua:139)
         float m = -INFINITY;
-        for (int tt = lane; tt < T; tt += 64) m = fmaxf(m, sc[tt]);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        for (int j = 0; j < 4; ++j) { aj[j] = lane + 64 * j < T ? sc[lane + 64 * j] : -INFINITY; m = fmaxf(m, aj[j]); }
+        m = wave_reduce(m, -INFINITY, [](float a, float b) { return fmaxf(a, b); });
         float sum = 0.f;
-        for (int tt = lane; tt < T; tt += 64) { const float e = expf(sc[tt] - m); sc[tt] = e; sum += e; }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        for (int j = 0; j < 4; ++j) { aj[j] = lane + 64 * j < T ? expf(aj[j] - m) : 0.f; sum += aj[j]; }
+        sum = wave_reduce(sum, 0.f, [](float a, float b) { return a + b; });
         const float inv = 1.f / sum;
-        for (int tt = lane; tt < T; tt += 64) { const float a = sc[tt] * inv; sc[tt] = a; if (rvalid) p.a_all[((size_t)t * B + arow) * T + tt] = a; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aj[j] *= inv;
       }
-      __syncthreads();
+      av = wave == 0 ? aj[0] : wave == 1 ? aj[1] : wave == 2 ? aj[2] : aj[3];      // a[tid]
+      DC_STAMP(11);
       float cacc[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) cacc[e] = 0.f;
-      for (int tt = wave; tt < T; tt += 4) {
-        const bf16x8 cv = *reinterpret_cast<const bf16x8*>(cx + (size_t)tt * HD);
-        const float a = sc[tt];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) cacc[e] = fmaf(a, (float)cv[e], cacc[e]);
-      }
-      float* part = sc + 256;                                      // [4 waves][512]
-      *reinterpret_cast<f32x4*>(part + wave * HD + lane * 8) = f32x4{cacc[0], cacc[1], cacc[2], cacc[3]};
-      *reinterpret_cast<f32x4*>(part + wave * HD + lane * 8 + 4) = f32x4{cacc[4], cacc[5], cacc[6], cacc[7]};
-      __syncthreads();
-      if (tid < 128) {                                             // c[4 tid .. 4 tid + 3]: sum over the waves, publish + keep for the backward pass
-        f32x4 v = *reinterpret_cast<const f32x4*>(part + tid * 4);
+      for (int c = 0; c < 4; ++c) {
+        if (64 * c >= T) break;
+        if (c > 0) {
 #pragma unroll
-        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(part + w * HD + tid * 4);
-        dst_granules(xg + (size_t)(3 * 2 + par) * 8192 + ((size_t)member * 256 + 2 * tid), u32x4{bfbits(v[0]) | (bfbits(v[1]) << 16), tagc, bfbits(v[2]) | (bfbits(v[3]) << 16), tagc}, local);
-        if (rvalid) {
-          const size_t oc = ((size_t)t * B + arow) * 2 * HD + 4 * tid;
-          *reinterpret_cast<f32x4*>(p.cat + oc) = v;
-          *reinterpret_cast<u32x2*>(p.cat_b + oc) = u32x2{bfbits(v[0]) | (bfbits(v[1]) << 16), bfbits(v[2]) | (bfbits(v[3]) << 16)};
+          for (int i = 0; i < 16; ++i) cv[i] = *reinterpret_cast<const bf16x8*>(cx + (size_t)min(64 * c + 4 * i + wave, T - 1) * HD + 8 * olane);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, aj[c]), 4 * i + wave));     // 0 beyond T
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cacc[e] = fmaf(a, (float)cv[i][e], cacc[e]);
         }
       }
+      *reinterpret_cast<f32x4*>(part + wave * HD + lane * 8) = f32x4{cacc[0], cacc[1], cacc[2], cacc[3]};
+      *reinterpret_cast<f32x4*>(part + wave * HD + lane * 8 + 4) = f32x4{cacc[4], cacc[5], cacc[6], cacc[7]};
+      lds_barrier();
+      DC_STAMP(12);
+      {                                                            // c[2 tid], c[2 tid + 1]: sum over the waves, publish one granule
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { v0 += part[w * HD + 2 * tid]; v1 += part[w * HD + 2 * tid + 1]; }
+        cb = bfpair(v0, v1);
+      }
     }
+    DC_STAMP(5);
     // =================== out = tanh(W_c [c ; h2]), LSTM.lua:153-157
     {
-      const bool okg = gather<256, 8>(xg + (size_t)(3 * 2 + par) * 8192, tagc, F, tid, p.err, 14);
-      if (!okg) s_dead = 1;
-      __syncthreads();
-      if (s_dead) { dead = true; break; }
+      const int tn = min(t + 1, L - 1);
+      bf16x8 wcr[8];                                               // this wave's K quarter of W_c rows 16 member .. +15: streamed from L2 beside the polls
+      gather<256, 8, 1, 2>(xg + (size_t)(3 * 2 + par) * 8192, tagc, F, ot, p.err, 14, &s_dead,
+                        [&] {                                      // zx1 of the next step: landed with the polls
+#pragma unroll
+                          for (int s = 0; s < 8; ++s) wcr[s] = *reinterpret_cast<const bf16x8*>(p.wc + xw * ((size_t)(16 * member + oc16) * 2 * HD + 256 * wave + 32 * s + 8 * oq));
+#pragma unroll
+                          for (int rt = 0; rt < 2; ++rt) {
+                            const int row = min(row0 + 16 * rt + oc16, B - 1);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) zxr[rt][i] = p.zx1[((size_t)tn * B + row) * 4 * HD + i * HD + ounit];
+                          }
+                        },
+                        [&] { st_gr8(xg + (size_t)(3 * 2 + par) * 8192 + ((size_t)member * 256 + ot), u32x2{cb, tagc}, local); },
+                        [&] {
+                          st4f(rvalid && ot < T ? (void*)(p.a_all + ((size_t)t * B + arow) * T + ot) : (void*)otrash, av);
+                          st4(rvalid ? (void*)(p.cat_b + ((size_t)t * B + arow) * 2 * HD + 2 * ot) : (void*)otrash, cb);
+                        }, gs, p.stamps != nullptr);
+      if (s_dead) break;
+      DC_STAMP(6);
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-      const unsigned char* src = wave < 2 ? F : H2;                // k = 256 wave + 32 s: waves 0, 1 read c, waves 2, 3 read h2
+      const unsigned char* src = (wave < 2 ? F : H2) + (256 * (wave & 1) + 8 * q) * 2;   // k = 256 wave + 32 s: waves 0, 1 read c, waves 2, 3 read h2
 #pragma unroll
       for (int s = 0; s < 8; ++s)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          const bf16x8 bv = *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt + c16) * PA + (256 * (wave & 1) + 32 * s + 8 * q) * 2);
-          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcr[s], bv, acc[rt], 0, 0, 0);
-        }
+        for (int rt = 0; rt < 2; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcr[s], *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt + c16) * PA + 64 * s), acc[rt], 0, 0, 0);
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) *reinterpret_cast<f32x4*>(red + ((wave * 2 + rt) * 64 + lane) * 4) = acc[rt];
-      __syncthreads();
-      if (wave < 2) {
-        const int rt = wave;
-        f32x4 v = *reinterpret_cast<const f32x4*>(red + ((0 * 2 + rt) * 64 + lane) * 4);
+      lds_barrier();
+      if (wave < 2) {                                              // wave = row tile
+        f32x4 v = *reinterpret_cast<const f32x4*>(red + ((0 * 2 + wave) * 64 + lane) * 4);
 #pragma unroll
-        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(red + ((w * 2 + rt) * 64 + lane) * 4);
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(red + ((w * 2 + wave) * 64 + lane) * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = tanhf_(v[i]);
-        const int row = row0 + 16 * rt + c16;
-        if (t + 1 < L) dst_granules(xg + (size_t)(0 * 2 + par) * 8192 + ((size_t)(member * 32 + 16 * rt + c16) * 8 + 2 * q), u32x4{bfbits(v[0]) | (bfbits(v[1]) << 16), tagc, bfbits(v[2]) | (bfbits(v[3]) << 16), tagc}, local);
-        if (row < B) {
-          const size_t o = (size_t)(t + 1) * slot + (size_t)row * HD + 16 * member + 4 * q;
-          *reinterpret_cast<f32x4*>(p.out + o) = v;
-          *reinterpret_cast<u32x2*>(p.out_b + o) = u32x2{bfbits(v[0]) | (bfbits(v[1]) << 16), bfbits(v[2]) | (bfbits(v[3]) << 16)};
-        }
+        ov = v; ovb = u32x2{bfpair(v[0], v[1]), bfpair(v[2], v[3])};         // published behind the polls of the next step's first gather
       }
-      if (t + 1 < L) dma_zx(t + 1);
-      __syncthreads();                                             // red / sc are reused by the next step
     }
+    DC_STAMP(7);
   }
-  dwait0();
+  if (!s_dead) store_out(tid, L - 1);
+  wait_vm<0>();
+  if (p.stamps && wid == 0 && tid == 0)
+    { stamp[8] = gs[0]; stamp[9] = gs[1]; stamp[13] = gs[2]; stamp[15] = local ? 1 : 0; for (int k = 0; k < 16; ++k) p.stamps[k] = stamp[k]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -351,10 +481,12 @@ bool dec_cluster_supported(int Hd, int Ld, int input_feed, int T, int L, int cus
 void dec_cluster_forward(hipStream_t s, const DecClFwdArgs& a0) {
   static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
   const int groups = (a0.B + R - 1) / R, per_pass = std::max(8, cus / (8 * NM) * 8);
-  const size_t lds = (size_t)3 * R * PA + 8192 + 8192 + 1024 + 8192;
+  const size_t lds = LDS_BYTES;
   (void)hipFuncSetAttribute((const void*)dec_cl_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   for (int g0 = 0; g0 < groups; g0 += per_pass) {
     DecClFwdArgs a = a0; a.group0 = g0; a.ngroups = std::min(per_pass, groups - g0); a.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;
+    a.exp = getenv("AOCR_DC_EXP") ? atoi(getenv("AOCR_DC_EXP")) : 0;
+    a.stamps = getenv("AOCR_DC_STAMPS") ? a.xtab + (size_t)groups * NM : nullptr;   // debugging aid: cycles per phase of workgroup 0
     hipLaunchKernelGGL(dec_cl_fwd_kernel, dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), lds, s, a);
   }
 }

@@ -215,6 +215,7 @@ struct EpGatesBwd {
   float* dc_out; int64_t lddco;           // d(c_prev)
   int M, H;
   bf16_t* dzb = nullptr; int64_t lddzb = 0; // optional bf16 shadow of dz
+  bool gil = false;                         // gates stored [m][j][4] (interleaved per unit: the decoder cluster kernel) instead of [m][g*H+j]
   template <int NT> __device__ __forceinline__ void quad(int m, int j, int, const float (&v)[NT][4]) const {
     static_assert(NT == 1, "gate backward epilogue is single-tile");
     if (j >= H) return;
@@ -225,8 +226,9 @@ struct EpGatesBwd {
       float dh = v[0][i];
       if (dh1) dh += dh1[(int64_t)row * ld1 + j];
       if (dh2) dh += dh2[(int64_t)row * ld2 + j];
-      const float* gp = gates + (int64_t)row * ldg + j;
-      float ig = gp[0], fg = gp[H], og = gp[2 * H], gg = gp[3 * H];
+      float ig, fg, og, gg;
+      if (gil) { const float4 g4 = *reinterpret_cast<const float4*>(gates + (int64_t)row * ldg + 4 * j); ig = g4.x; fg = g4.y; og = g4.z; gg = g4.w; }
+      else { const float* gp = gates + (int64_t)row * ldg + j; ig = gp[0]; fg = gp[H]; og = gp[2 * H]; gg = gp[3 * H]; }
       float tc = tanhf_(c[(int64_t)row * ldcc + j]);
       float dc = dh * og * (1.f - tc * tc);
       if (dc_in) dc += dc_in[(int64_t)row * lddc + j];
@@ -249,8 +251,8 @@ struct EpGatesBwd {
     if (dh1) p.dh = dh1[(int64_t)row * ld1 + j];
     if (dh2) p.dh += dh2[(int64_t)row * ld2 + j];
     if (dc_in) p.dc = dc_in[(int64_t)row * lddc + j];
-    const float* gp = gates + (int64_t)row * ldg + j;
-    p.ig = gp[0]; p.fg = gp[H]; p.og = gp[2 * H]; p.gg = gp[3 * H];
+    if (gil) { const float4 g4 = *reinterpret_cast<const float4*>(gates + (int64_t)row * ldg + 4 * j); p.ig = g4.x; p.fg = g4.y; p.og = g4.z; p.gg = g4.w; }
+    else { const float* gp = gates + (int64_t)row * ldg + j; p.ig = gp[0]; p.fg = gp[H]; p.og = gp[2 * H]; p.gg = gp[3 * H]; }
     p.c = c[(int64_t)row * ldcc + j]; p.cp = c_prev[(int64_t)row * ldcp + j];
     return p;
   }

@@ -670,16 +670,18 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
   const bool sh = m->bf16 && m->out_b != nullptr;
   prof_mark(m, AOCR_PROF_DEC_FWD);
   dec_init_state(m, d, c0, h0, m->out_all, B, sh);
+  m->dgates_il = false;
   if (sh && dec_cluster_ok(m, T, L)) {
     // scores against the pre-multiplied context: ctx[t] . (W_a h) = (ctx W_a)[t] . h, LSTM.lua:131-137
     gemm_hh_shadow(s, m->context_b, Hd, m->swa.wtb, Hd, m->dctx, Hd, m->ctxa_b, Hd, B * T, Hd, Hd);
     DecClFwdArgs a; a.B = B; a.T = T; a.L = L; a.epoch = next_epoch(m);
     a.w1i = m->dec[0].swi.wb; a.w1h = m->dec[0].swh.wb; a.w2i = m->dec[1].swi.wb; a.w2h = m->dec[1].swh.wb; a.wc = m->swc.wb;
     a.b2i = m->dec[1].bi; a.b2h = m->dec[1].bh; a.zx1 = m->zx1_all; a.ctxb = m->context_b; a.ctxa = m->ctxa_b;
-    for (int l = 0; l < 2; ++l) { a.cs[l] = m->dcs[l]; a.hs[l] = m->dhs[l]; a.hsb[l] = m->dhs_b[l]; a.gates[l] = keep_gates ? m->dgates[l] : nullptr; }
-    a.a_all = m->a_all; a.cat = m->cat_all; a.out = m->out_all; a.cat_b = m->cat_b; a.out_b = m->out_b;
+    for (int l = 0; l < 2; ++l) { a.cs[l] = m->dcs[l]; a.hsb[l] = m->dhs_b[l]; a.gates[l] = keep_gates ? m->dgates[l] : nullptr; }
+    a.a_all = m->a_all; a.out = m->out_all; a.cat_b = m->cat_b; a.out_b = m->out_b;
     a.xbuf = m->dc_xbuf; a.xtab = m->dc_xtab; a.err = m->cl_err;
     dec_cluster_forward(s, a);
+    m->dgates_il = true;
     if (keep_gates)                                                // q = W_a h_top for all L steps: only the backward pass reads it
       gemm_hh(s, m->dhs_b[1] + slot, Hd, m->swa.wb, Hd, m->q_all, Hd, L * B, Hd, Hd, nullptr, nullptr, 0);
   } else
@@ -755,7 +757,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
       }
       e.dh2 = m->dh_rec[l]; e.ld2 = Hd;
       e.dc_in = m->dc_st[l]; e.lddc = Hd;
-      e.gates = m->dgates[l] + (size_t)t * B * 4 * Hd; e.ldg = 4 * Hd;
+      e.gates = m->dgates[l] + (size_t)t * B * 4 * Hd; e.ldg = 4 * Hd; e.gil = m->dgates_il;
       e.c_prev = m->dcs[l] + (size_t)t * slot; e.ldcp = Hd; e.c = m->dcs[l] + (size_t)(t + 1) * slot; e.ldcc = Hd;
       e.dz = m->ddz[l] + (size_t)t * B * 4 * Hd; e.lddz = 4 * Hd; e.dc_out = m->dc_st[l]; e.lddco = Hd; e.M = B; e.H = Hd;
       if (sh) { e.dzb = m->ddz_b[l] + (size_t)t * B * 4 * Hd; e.lddzb = 4 * Hd; }

@@ -219,10 +219,10 @@ struct DecClFwdArgs {
   const float *b2i, *b2h;                              // layer-2 biases (layer 1's are inside zx1)
   const float* zx1;                                    // [L][B][4 Hd]: embedding part of layer 1 + both biases
   const bf16_t *ctxb, *ctxa;                           // [B][T][Hd]: encoder context and context . W_a
-  float* cs[2]; float* hs[2]; bf16_t* hsb[2];          // [L + 1][B][Hd], slot 0 = initial state
-  float* gates[2];                                     // [L][B][4 Hd] post-activation, or nullptr
-  float *a_all, *cat, *out; bf16_t *cat_b, *out_b;
-  unsigned long long *xbuf, *xtab; int* err;
+  float* cs[2]; bf16_t* hsb[2];                        // [L + 1][B][Hd], slot 0 = initial state (the fp32 h is not written: every reader takes the bf16 copy)
+  float* gates[2];                                     // [L][B][Hd][4] post-activation (i, f, o, g INTERLEAVED per unit), or nullptr
+  float *a_all, *out; bf16_t *cat_b, *out_b;           // [c ; h_top] only as its bf16 copy
+  unsigned long long *xbuf, *xtab; int* err; unsigned long long* stamps = nullptr; int exp = 0;
 };
 bool dec_cluster_supported(int Hd, int Ld, int input_feed, int T, int L, int cus);
 size_t dec_cluster_xbuf_bytes(int B);
