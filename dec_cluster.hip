@@ -85,29 +85,22 @@ template <class OP> __device__ __forceinline__ float wave_reduce(float v, float 
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-#ifdef DC_DEBUG_STAMPS
-#define DC_TL(cond, k) do { if (tl && (cond)) tl[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define DC_GS(k) do { if (stamps) { const u64 t1_ = __builtin_readcyclecounter(); gs[k] += t1_ - t0; t0 = t1_; } } while (0)
-#else
-#define DC_TL(cond, k) do { } while (0)
-#define DC_GS(k) do { } while (0)
-#endif
 // All-gather of one 32 x 512 bf16 operand into an LDS buffer.  The payload is the real output tensor (h, [c ; h] or out as bf16): every
 // wave of every member stores its piece, waits for the write acknowledgement, then raises its flag (128 flags of 4 bytes per
 // operand); a reader polls the flags -- 512 bytes per round instead of the operand -- and loads the 32 KB once.
 //   payload():  this wave's piece (any number of stores);   deferred(): exactly NST one-instruction stores of older outputs, issued
-//   behind the operand loads (the flag polls wait for everything older than them).
-template <int NST, class PAY, class DEF>
+//   while the piece's acknowledgement is awaited;   pre(): loads the caller wants in flight beside the polls.
+template <int NST, class PAY, class DEF, class PRE>
 __device__ __forceinline__ void gather(unsigned* flags, unsigned tag, const bf16_t* src, int stride_bytes, int row0, int B, unsigned char* dst, int tid, int wave,
-                                       int member, bool local, int* err, int code, int* dead_flag, PAY&& payload, DEF&& deferred, u64 (&gs)[3], bool stamps, [[maybe_unused]] u64* tl) {
-  [[maybe_unused]] u64 t0 = stamps ? __builtin_readcyclecounter() : 0;
+                                       int member, bool local, int* err, int code, int* dead_flag, PAY&& payload, DEF&& deferred, PRE&& pre, u64 (&gs)[3], bool stamps) {
+  u64 t0 = stamps ? __builtin_readcyclecounter() : 0;
   payload();
-  __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the piece is in L2.  (The builtin, not asm: the compiler's own count of outstanding loads restarts here,
-                                                //  so it inserts no waits of its own between the asm loads below.)
-  if ((tid & 63) < NM) pst4(flags + (size_t)(tid & 63) * 128 + member * 4 + wave, tag, local);      // one copy per reader: polls of different members never meet in one line
-  DC_TL((tid & 63) == 0, wave);
-  DC_GS(0);
-  const unsigned foff = (unsigned)(member * 128 + (tid & 63)) * 4;
+  deferred();
+  wait_vm<NST>();                               // the piece is in L2
+  if ((tid & 63) == 0) pst4(flags + member * 4 + wave, tag, local);
+  pre();
+  if (stamps) { const u64 t1 = __builtin_readcyclecounter(); gs[0] += t1 - t0; t0 = t1; }
+  const unsigned foff = (unsigned)(tid & 63) * 4;
   unsigned f0, f1; int spins = 0;
 #pragma nounroll
   while (true) {
@@ -119,24 +112,18 @@ __device__ __forceinline__ void gather(unsigned* flags, unsigned tag, const bf16
     if (++spins > DC_SPIN_LIMIT) { if ((tid & 63) == 0) { atomicExch(err, code); *dead_flag = 1; } break; }
     __builtin_amdgcn_s_sleep(1);
   }
-  DC_GS(1);
-  DC_TL((tid & 63) == 0, 4 + wave);
+  if (stamps) { const u64 t1 = __builtin_readcyclecounter(); gs[1] += t1 - t0; t0 = t1; }
   u32x4 gr[8];                                  // 32 rows x 64 chunks of 16 bytes: thread -> chunk tid & 63 of rows (tid >> 6) + 4 j
 #pragma unroll
-  for (int j = 0; j < 8; ++j) ld16_sc1(gr[j], (unsigned)(min(row0 + (((tid >> 6) + 4 * j + member) & 31), B - 1) * stride_bytes + (tid & 63) * 16), src, local);   // (members start at different rows)
-  deferred();                                   // behind the loads: nothing on the exchange path waits for their acknowledgements
-  DC_TL((tid & 63) == 0, 8 + wave);
+  for (int j = 0; j < 8; ++j) ld16_sc1(gr[j], (unsigned)(min(row0 + (tid >> 6) + 4 * j, B - 1) * stride_bytes + (tid & 63) * 16), src, local);
   lds_barrier();                                // every wave of this workgroup is past its reads of the previous contents of dst
-  DC_TL(tid == 0, 12);
-  wait_vm<NST>();
-  DC_TL(tid == 0, 13);
+  wait_vm<0>();
 #pragma unroll
   for (int j = 0; j < 8; ++j) dpin(gr[j]);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(dst + (size_t)(((tid >> 6) + 4 * j + member) & 31) * PA + (tid & 63) * 16) = gr[j];
+  for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(dst + (size_t)((tid >> 6) + 4 * j) * PA + (tid & 63) * 16) = gr[j];
   lds_barrier();
-  DC_TL(tid == 0, 14);
-  DC_GS(2);
+  if (stamps) { const u64 t1 = __builtin_readcyclecounter(); gs[2] += t1 - t0; }
 }
 // the same operand from a plain bf16 array [B][512] (step 0: the initial states)
 __device__ __forceinline__ void load_rows(const bf16_t* src, int row0, int B, unsigned char* dst, int tid) {
@@ -149,13 +136,7 @@ __device__ __forceinline__ void load_rows(const bf16_t* src, int row0, int B, un
 }
 }  // namespace
 
-// Debugging aids, compiled in with -DDC_DEBUG_STAMPS only (their global stores make the compiler insert vmcnt waits between the asm loads):
-// cycles per phase of workgroup 0 and a real-time timeline of one step of group 0 (tools/dc_stamp.py).
-#ifdef DC_DEBUG_STAMPS
 #define DC_STAMP(k) do { if (p.stamps) { const u64 now_ = __builtin_readcyclecounter(); stamp[k] += now_ - tprev; tprev = now_; } } while (0)
-#else
-#define DC_STAMP(k) do { } while (0)
-#endif
 
 __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -196,8 +177,11 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
   // operand) and each holds all 64 gate rows of the member (4 tiles of [unit][gate] rows), so an operand fragment read from LDS
   // feeds four products; the partial tiles meet in LDS, wave w finishes tile w (units 4w .. 4w+3).
   bf16x8 w1a[16], w1b[16], w2a[16], w2b[16], wcr[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) wcr[s] = *reinterpret_cast<const bf16x8*>(p.wc + (size_t)(16 * member + c16) * 2 * HD + 256 * wave + 32 * s + 8 * q);
+  const size_t xwf = (p.exp & 2) ? 0 : 1;
   auto wfrag = [&](const bf16_t* wi, const bf16_t* wh, int c16_, int q_, int j, int s) {
-    return *reinterpret_cast<const bf16x8*>((wave < 2 ? wi : wh) + (size_t)((c16_ & 3) * HD + 16 * member + 4 * j + (c16_ >> 2)) * HD + 256 * (wave & 1) + 32 * s + 8 * q_);
+    return *reinterpret_cast<const bf16x8*>((wave < 2 ? wi : wh) + xwf * ((size_t)((c16_ & 3) * HD + 16 * member + 4 * j + (c16_ >> 2)) * HD + 256 * (wave & 1) + 32 * s + 8 * q_));
   };
 #pragma unroll
   for (int j = 0; j < 2; ++j)
@@ -206,8 +190,6 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
       w1a[j * 8 + s] = wfrag(p.w1i, p.w1h, c16, q, j, s); w1b[j * 8 + s] = wfrag(p.w1i, p.w1h, c16, q, j + 2, s);
       w2a[j * 8 + s] = wfrag(p.w2i, p.w2h, c16, q, j, s); w2b[j * 8 + s] = wfrag(p.w2i, p.w2h, c16, q, j + 2, s);
     }
-#pragma unroll
-  for (int s = 0; s < 8; ++s) wcr[s] = *reinterpret_cast<const bf16x8*>(p.wc + (size_t)(16 * member + c16) * 2 * HD + 256 * wave + 32 * s + 8 * q);
   float b2[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) b2[i] = p.b2i[i * HD + unit] + p.b2h[i * HD + unit];
@@ -219,7 +201,7 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) zxr[rt][i] = p.zx1[(size_t)row * 4 * HD + i * HD + unit];
   }
-  unsigned* const xg = reinterpret_cast<unsigned*>(p.xbuf) + (size_t)group * 4 * NM * 128;      // flags [kind: out, h1, h2, c][reader][member][wave]
+  unsigned* const xg = reinterpret_cast<unsigned*>(p.xbuf) + (size_t)group * 4 * 128;      // flags [kind: out, h1, h2, c][member][wave]
   load_rows(p.out_b, row0, B, F, tid); load_rows(p.hsb[0], row0, B, H1, tid); load_rows(p.hsb[1], row0, B, H2, tid);
   __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): nothing of the prologue is in flight inside the loop
   __syncthreads();
@@ -229,6 +211,7 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
   const int arow = row0 + member; const bool rvalid = arow < B;
   const bf16_t* const ca = p.ctxa + (size_t)min(arow, B - 1) * T * HD;
   const bf16_t* const cx = p.ctxb + (size_t)min(arow, B - 1) * T * HD;
+  const size_t xa = (p.exp & 1) ? 0 : 1, xw = (p.exp & 2) ? 0 : 1;      // perf experiments (AOCR_DC_EXP): collapse the streamed addresses
   const int ntile = (T + 15) >> 4;
 
   // one K-split product: acc tiles -> LDS -> this wave's tile (both row tiles) summed over the four waves
@@ -296,18 +279,17 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
   for (int t = 0; t < L; ++t) {
     const unsigned tagc = p.epoch * 4096u + (unsigned)(t + 1);    // flags of step t: + kind * 1024
 
-    u64* const tl0 = (p.stamps && group == 0 && t == 10) ? reinterpret_cast<u64*>(p.err + 16 + 2048) + member * 64 : nullptr;   // timeline of one step (debugging aid)
     int ot = tid; asm volatile("" : "+v"(ot));                     // opaque copy of the thread id (see store_layer)
     const int olane = ot & 63, oc16 = ot & 15, oq = (ot >> 4) & 3, ounit = 16 * member + 4 * wave + oq;
     unsigned char* const otrash = reinterpret_cast<unsigned char*>(p.err + 16) + ot * 16;
     // =================== layer 1: z1 = [feed ; h1(t-1)] W1^T + zx1(t)
     if (t > 0) {
-      gather<1>(xg + 0 * NM * 128, tagc - 1u, p.out_b + (size_t)t * slot, HD * 2, row0, B, F, ot, wave, member, local, p.err, 11, &s_dead,
+      gather<1>(xg + 0 * 128, tagc - 1u, p.out_b + (size_t)t * slot, HD * 2, row0, B, F, ot, wave, member, local, p.err, 11, &s_dead,
                 [&] {                                               // out(t-1) of this member's 16 units (waves 0, 1: one row tile each)
                   const int row = row0 + 16 * wave + oc16;
                   pst8(wave < 2 && row < B ? (void*)(p.out_b + (size_t)t * slot + (size_t)row * HD + 16 * member + 4 * oq) : (void*)otrash, ovb, local);
                 },
-                [&] { store_out(ot, t - 1); }, gs, p.stamps != nullptr, tl0);
+                [&] { store_out(ot, t - 1); }, [] {}, gs, p.stamps != nullptr);
       if (s_dead) break;
     }
     DC_STAMP(0);
@@ -330,17 +312,12 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
         pst8(oq == 0 && row < B ? (void*)(p.hsb[l] + (size_t)(t + 1) * slot + (size_t)row * HD + 16 * member + 4 * wave) : (void*)otrash, hp[rt], local);
       }
     };
-    gather<4>(xg + 1 * NM * 128, tagc + 1024u, p.hsb[0] + (size_t)(t + 1) * slot, HD * 2, row0, B, H1, ot, wave, member, local, p.err, 12, &s_dead,
-              [&] { publish_h(0, hp1); }, [&] { store_layer(ot, 0, t, g1, c1, hp1, false); }, gs, p.stamps != nullptr, tl0 ? tl0 + 16 : nullptr);
+    gather<4>(xg + 1 * 128, tagc + 1024u, p.hsb[0] + (size_t)(t + 1) * slot, HD * 2, row0, B, H1, ot, wave, member, local, p.err, 12, &s_dead,
+              [&] { publish_h(0, hp1); }, [&] { store_layer(ot, 0, t, g1, c1, hp1, false); },
+              [] {}, gs, p.stamps != nullptr);
     if (s_dead) break;
     DC_STAMP(2);
     f32x4 g2[2]; u32x2 hp2[2];
-    bf16x8 cav[16];                                                // tile `wave` of the pre-multiplied context of this member's row: lands while layer 2 runs
-    {
-      const bf16_t* carow = ca + (size_t)min(16 * wave + oc16, T - 1) * HD + 8 * oq;
-#pragma unroll
-      for (int s = 0; s < 16; ++s) cav[s] = *reinterpret_cast<const bf16x8*>(carow + 32 * s);
-    }
     {
       f32x4 z[2];
       product(w2a, w2b, H1, H2, z);
@@ -354,19 +331,16 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
     // =================== attention of row `member` of the group: scores on MFMA (A = a 16-step tile of ctx . W_a, B = h2 broadcast)
     float av; unsigned cb;
     {
-      gather<6>(xg + 2 * NM * 128, tagc + 2048u, p.hsb[1] + (size_t)(t + 1) * slot, HD * 2, row0, B, H2, ot, wave, member, local, p.err, 13, &s_dead,
-                [&] { publish_h(1, hp2); }, [&] { store_layer(ot, 1, t, g2, c2, hp2, true); }, gs, p.stamps != nullptr, tl0 ? tl0 + 32 : nullptr);
+      bf16x8 cav[16];                                              // tile `wave` of the pre-multiplied context: in flight beside the polls
+      const bf16_t* carow = ca + xa * ((size_t)min(16 * wave + oc16, T - 1) * HD + 8 * oq);
+      gather<6>(xg + 2 * 128, tagc + 2048u, p.hsb[1] + (size_t)(t + 1) * slot, HD * 2, row0, B, H2, ot, wave, member, local, p.err, 13, &s_dead,
+                [&] { publish_h(1, hp2); }, [&] { store_layer(ot, 1, t, g2, c2, hp2, true); },
+                [&] {
+#pragma unroll
+                  for (int s = 0; s < 16; ++s) cav[s] = *reinterpret_cast<const bf16x8*>(carow + xa * 32 * s);
+                }, gs, p.stamps != nullptr);
       if (s_dead) break;
       DC_STAMP(4);
-      {                                                            // zx1 of the next step: lands while the attention runs
-        const int tn = min(t + 1, L - 1);
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          const int row = min(row0 + 16 * rt + oc16, B - 1);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) zxr[rt][i] = p.zx1[((size_t)tn * B + row) * 4 * HD + i * HD + ounit];
-        }
-      }
       const unsigned char* hrow = H2 + (size_t)member * PA + 16 * q;
       for (int tile = wave; tile < ntile; tile += 4) {
         if (tile != wave) {
@@ -382,7 +356,7 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
       // context rows of this wave: tt = 64 c + 4 i + wave; the first chunk is loaded while the softmax runs
       bf16x8 cv[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) cv[i] = *reinterpret_cast<const bf16x8*>(cx + (size_t)min(4 * i + wave, T - 1) * HD + 8 * olane);
+      for (int i = 0; i < 16; ++i) cv[i] = *reinterpret_cast<const bf16x8*>(cx + xa * ((size_t)min(4 * i + wave, T - 1) * HD + 8 * olane));
       lds_barrier();
       DC_STAMP(10);
       // softmax over T (LSTM.lua:139), redundantly in every wave: lane holds steps lane + 64 j
@@ -433,9 +407,18 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
     DC_STAMP(5);
     // =================== out = tanh(W_c [c ; h2]), LSTM.lua:153-157
     {
-      gather<1>(xg + 3 * NM * 128, tagc + 3072u, p.cat_b + (size_t)t * B * 2 * HD, HD * 4, row0, B, F, ot, wave, member, local, p.err, 14, &s_dead,
+      const int tn = min(t + 1, L - 1);
+      gather<1>(xg + 3 * 128, tagc + 3072u, p.cat_b + (size_t)t * B * 2 * HD, HD * 4, row0, B, F, ot, wave, member, local, p.err, 14, &s_dead,
                 [&] { pst4(rvalid ? (void*)(p.cat_b + ((size_t)t * B + arow) * 2 * HD + 2 * ot) : (void*)otrash, cb, local); },      // c of row `member`: units 2 tid, 2 tid + 1
-                [&] { st4f(rvalid && ot < T ? (void*)(p.a_all + ((size_t)t * B + arow) * T + ot) : (void*)otrash, av); }, gs, p.stamps != nullptr, tl0 ? tl0 + 48 : nullptr);
+                [&] { st4f(rvalid && ot < T ? (void*)(p.a_all + ((size_t)t * B + arow) * T + ot) : (void*)otrash, av); },
+                [&] {                                              // zx1 of the next step: landed with the polls
+#pragma unroll
+                  for (int rt = 0; rt < 2; ++rt) {
+                    const int row = min(row0 + 16 * rt + oc16, B - 1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) zxr[rt][i] = p.zx1[((size_t)tn * B + row) * 4 * HD + i * HD + ounit];
+                  }
+                }, gs, p.stamps != nullptr);
       if (s_dead) break;
       DC_STAMP(6);
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -469,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-size_t dec_cluster_xbuf_bytes(int B) { return (size_t)((B + R - 1) / R) * 4 * NM * 128 * sizeof(unsigned) + 256; }
+size_t dec_cluster_xbuf_bytes(int B) { return (size_t)((B + R - 1) / R) * 4 * 128 * sizeof(unsigned) + 256; }
 size_t dec_cluster_xtab_bytes(int B) { return (size_t)((B + R - 1) / R) * NM * sizeof(u64) + 256; }
 bool dec_cluster_supported(int Hd, int Ld, int input_feed, int T, int L, int cus) { return Hd == HD && Ld == 2 && input_feed && T >= 1 && T <= 256 && L + 2 < 1024 && cus >= 8 * NM; }
 
@@ -480,6 +463,7 @@ void dec_cluster_forward(hipStream_t s, const DecClFwdArgs& a0) {
   (void)hipFuncSetAttribute((const void*)dec_cl_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   for (int g0 = 0; g0 < groups; g0 += per_pass) {
     DecClFwdArgs a = a0; a.group0 = g0; a.ngroups = std::min(per_pass, groups - g0); a.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;
+    a.exp = getenv("AOCR_DC_EXP") ? atoi(getenv("AOCR_DC_EXP")) : 0;
     a.stamps = getenv("AOCR_DC_STAMPS") ? a.xtab + (size_t)groups * NM : nullptr;   // debugging aid: cycles per phase of workgroup 0
     hipLaunchKernelGGL(dec_cl_fwd_kernel, dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), lds, s, a);
   }

@@ -21,3 +21,11 @@ for i, (n, v) in enumerate(zip(names, s)):
     else:
         print(f"{n:30s} {v / L:9.0f} cycles/step  {100.0 * v / tot:5.1f} %")
 print("total cycles/step", tot / L)
+tm = m.get_tensor("dc_times").view(torch.int64).cpu().view(32, 4, 16)
+t0 = int(tm[:, 0, 0:4].min())
+print("timeline of step 10, group 0 (ns from the first 'out' flag), min .. max over the 32 members (and the 4 waves where per wave)")
+for k, name in enumerate(["out", "h1", "h2", "c"]):
+    r = lambda x: f"{int(((x - t0) * 10).min()):6d} .. {int(((x - t0) * 10).max()):6d}"
+    print(f"  {name:4s} flag raised {r(tm[:, k, 0:4])} | all seen {r(tm[:, k, 4:8])} | loads + stores issued {r(tm[:, k, 8:12])} | barrier {r(tm[:, k, 12])} | landed {r(tm[:, k, 13])} | in LDS {r(tm[:, k, 14])}")
+    w = [int(((tm[:, k, 8 + i] - tm[:, k, 4 + i]) * 10).float().mean()) for i in range(4)]
+    print(f"       seen -> issued, mean per wave: {w}")

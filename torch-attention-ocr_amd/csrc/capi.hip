@@ -345,6 +345,7 @@ int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32
   else if (n == "enc_gates0") { *ptr_dev = m->egates[0][m->Le - 1]; *ndim = 3; shape[0] = d.T; shape[1] = d.B; shape[2] = 4 * m->He; }
   else if (n == "cl_err") { *ptr_dev = m->cl_err; *ndim = 1; shape[0] = 8; REQUIRE(m->cl_err, "no cluster kernels in this configuration"); }
   else if (n == "dc_stamps") { REQUIRE(m->dc_xtab, "no decoder cluster kernel in this configuration"); *ptr_dev = m->dc_xtab + (size_t)((d.B + 31) / 32) * 32; *ndim = 1; shape[0] = 32; }   // 16 x u64 cycle counters (AOCR_DC_STAMPS=1) viewed as 16 floats
+  else if (n == "dc_times") { REQUIRE(m->cl_err, "no cluster kernels in this configuration"); *ptr_dev = m->cl_err + 16 + 2048; *ndim = 1; shape[0] = 32 * 4 * 16 * 2; }   // 32 members x 4 gathers x 16 x u64 (10 ns ticks)
   else if (n == "g0") {                                   // debugging aid (AOCR_DBG_STOP=1|2): the gradient map the CNN backward pass stopped at
     const char* e = getenv("AOCR_DBG_STOP"); const int stop = e ? atoi(e) : 0;
     const int64_t cnt = stop == 1 ? (int64_t)d.B * d.T * 512 : (int64_t)d.B * d.H4 * d.W2 * 512;

@@ -163,7 +163,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     m->cl_xbytes = enc_cluster_xbuf_bytes((int)B, (int)He); m->cl_pbytes = enc_cluster_pbuf_bytes((int)B, (int)He);
     m->cl_xbuf = a.get<unsigned long long>(m->cl_xbytes / 8); m->cl_pbuf = a.get<unsigned long long>(m->cl_pbytes / 8);
     m->cl_xtab = a.get<unsigned long long>((size_t)2 * ((B + 15) / 16) * 8 + 64);      // XCC ids of the members of every group
-    m->cl_err = a.get<int>(16 + 256 * 8);                        // error flag + the trash slots rows >= B store to
+    m->cl_err = a.get<int>(16 + 256 * 8 + 4096);                 // error flag + the trash slots rows >= B store to + a debugging timeline
     if (Hd == 512 && m->Ld == 2 && m->cfg.input_feed) {          // the decoder loop as one launch (dec_cluster.hip)
       m->dc_xbytes = dec_cluster_xbuf_bytes((int)B); m->dc_tbytes = dec_cluster_xtab_bytes((int)B);
       m->dc_xbuf = a.get<unsigned long long>(m->dc_xbytes / 8); m->dc_xtab = a.get<unsigned long long>(m->dc_tbytes / 8);

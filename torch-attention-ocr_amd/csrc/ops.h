@@ -222,7 +222,7 @@ struct DecClFwdArgs {
   float* cs[2]; bf16_t* hsb[2];                        // [L + 1][B][Hd], slot 0 = initial state (the fp32 h is not written: every reader takes the bf16 copy)
   float* gates[2];                                     // [L][B][Hd][4] post-activation (i, f, o, g INTERLEAVED per unit), or nullptr
   float *a_all, *out; bf16_t *cat_b, *out_b;           // [c ; h_top] only as its bf16 copy
-  unsigned long long *xbuf, *xtab; int* err; unsigned long long* stamps = nullptr; int exp = 0;
+  unsigned long long *xbuf, *xtab; int* err; unsigned long long* stamps = nullptr;
 };
 bool dec_cluster_supported(int Hd, int Ld, int input_feed, int T, int L, int cus);
 size_t dec_cluster_xbuf_bytes(int B);
