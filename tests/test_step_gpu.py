@@ -269,11 +269,12 @@ def test_decoder_cluster_kernel_matches_launch_chain(cuda, monkeypatch, B, W, ma
     batches, T up to 199, the C3 shape.  Also the gold-pass decode (the same loop without the saved gates)."""
     cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
     out = {}
-    for knob in ("0", "1"):
+    for knob in ("0", "fwd", "1"):                               # both cluster kernels | forward only (BPTT through the launch chain) | launch chain
+        monkeypatch.delenv("AOCR_NO_DEC_CLUSTER", raising=False); monkeypatch.delenv("AOCR_NO_DEC_CLUSTER_BWD", raising=False)
         if knob == "1":
             monkeypatch.setenv("AOCR_NO_DEC_CLUSTER", "1")
-        else:
-            monkeypatch.delenv("AOCR_NO_DEC_CLUSTER", raising=False)
+        elif knob == "fwd":
+            monkeypatch.setenv("AOCR_NO_DEC_CLUSTER_BWD", "1")
         m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=maxlen, compute="bf16", max_decoder_l=maxlen + 1, max_beam=1)
         loss = m.train_forward_backward(batch)
         loss2 = m.train_forward_backward(batch)
@@ -284,20 +285,23 @@ def test_decoder_cluster_kernel_matches_launch_chain(cuda, monkeypatch, B, W, ma
         dloss, _ = m.step(batch, True, 1)                       # forward_only: the gold pass runs the same loop without saved gates
         out[knob]["gold"] = [float(x) for x in m._dec_out.gold_scores] + [float(dloss)]
         m.shutdown()
-    a, b = out["1"], out["0"]
-    e = (a["logits"].double() - b["logits"].double()).abs().max().item()
-    r = relerr(b["dctx"], a["dctx"])
-    print(f"[parity] decoder cluster B={B} W={W} L={maxlen + 1}: logits max-abs {e:.3e}, d(context) rel {r:.3e}, loss {b['loss']:.5f} vs {a['loss']:.5f}")
-    assert e < 1e-2 and r < 3e-2
-    assert abs(a["loss"] - b["loss"]) < 2e-3 * max(1.0, abs(a["loss"]))
-    worst = ("", 0.0)
-    for k in a["grads"]:
-        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):
-            continue
-        x = relerr(b["grads"][k], a["grads"][k])
-        if x > worst[1]: worst = (k, x)
-        assert x < 3e-2, (k, x)
-    print(f"[parity] decoder cluster worst gradient rel {worst[1]:.3e} ({worst[0]})")
+    a = out["1"]
+    for name in ("fwd", "0"):
+        b = out[name]
+        e = (a["logits"].double() - b["logits"].double()).abs().max().item()
+        r = relerr(b["dctx"], a["dctx"])
+        print(f"[parity] decoder cluster ({name}) B={B} W={W} L={maxlen + 1}: logits max-abs {e:.3e}, d(context) rel {r:.3e}, loss {b['loss']:.5f} vs {a['loss']:.5f}")
+        assert e < 1e-2 and r < 3e-2
+        assert abs(a["loss"] - b["loss"]) < 2e-3 * max(1.0, abs(a["loss"]))
+        worst = ("", 0.0)
+        for k in a["grads"]:
+            if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):
+                continue
+            x = relerr(b["grads"][k], a["grads"][k])
+            if x > worst[1]: worst = (k, x)
+            assert x < 3e-2, (name, k, x)
+        print(f"[parity] decoder cluster ({name}) worst gradient rel {worst[1]:.3e} ({worst[0]})")
+    b = out["0"]
     for x, y in zip(a["gold"], b["gold"]):
         assert abs(x - y) < 2e-2 * max(1.0, abs(x)), (x, y)
 

@@ -140,7 +140,7 @@ int aocr_model_create(const aocr_config* cfg, float* params_dev, float* grads_de
   if (m->cl_xbuf) {                                     // tags start at epoch 1: the exchange buffers must not hold a stale match
     hipMemsetAsync(m->cl_xbuf, 0, m->cl_xbytes, m->s); hipMemsetAsync(m->cl_pbuf, 0, m->cl_pbytes, m->s); hipMemsetAsync(m->cl_err, 0, 64, m->s);
     hipMemsetAsync(m->cl_xtab, 0, ((size_t)2 * ((cfg->batch_size + 15) / 16) * 8 + 64) * 8, m->s);
-    if (m->dc_xbuf) { hipMemsetAsync(m->dc_xbuf, 0, m->dc_xbytes, m->s); hipMemsetAsync(m->dc_xtab, 0, m->dc_tbytes, m->s); }
+    if (m->dc_xbuf) { hipMemsetAsync(m->dc_xbuf, 0, m->dc_xbytes, m->s); hipMemsetAsync(m->dc_xtab, 0, m->dc_tbytes, m->s); hipMemsetAsync(m->dc_bxbuf, 0, m->dc_bxbytes, m->s); }
   }
   for (int i = 0; i < 4; ++i)
   {
@@ -345,6 +345,10 @@ int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32
   else if (n == "enc_gates0") { *ptr_dev = m->egates[0][m->Le - 1]; *ndim = 3; shape[0] = d.T; shape[1] = d.B; shape[2] = 4 * m->He; }
   else if (n == "cl_err") { *ptr_dev = m->cl_err; *ndim = 1; shape[0] = 8; REQUIRE(m->cl_err, "no cluster kernels in this configuration"); }
   else if (n == "dc_stamps") { REQUIRE(m->dc_xtab, "no decoder cluster kernel in this configuration"); *ptr_dev = m->dc_xtab + (size_t)((d.B + 31) / 32) * 32; *ndim = 1; shape[0] = 32; }   // 16 x u64 cycle counters (AOCR_DC_STAMPS=1) viewed as 16 floats
+  else if (n == "ds_all") { *ptr_dev = m->ds_all; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = d.T; }          // debugging aids: decoder BPTT intermediates
+  else if (n == "dq_all") { *ptr_dev = m->dq_all; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = m->Hd; }
+  else if (n == "dcat_all") { *ptr_dev = m->dcat_all; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = 2 * m->Hd; }
+  else if (n == "dpre_all") { *ptr_dev = m->dpre_all; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = m->Hd; }
   else if (n == "dc_times") { REQUIRE(m->cl_err, "no cluster kernels in this configuration"); *ptr_dev = m->cl_err + 16 + 2048; *ndim = 1; shape[0] = 32 * 4 * 16 * 2; }   // 32 members x 4 gathers x 16 x u64 (10 ns ticks)
   else if (n == "g0") {                                   // debugging aid (AOCR_DBG_STOP=1|2): the gradient map the CNN backward pass stopped at
     const char* e = getenv("AOCR_DBG_STOP"); const int stop = e ? atoi(e) : 0;

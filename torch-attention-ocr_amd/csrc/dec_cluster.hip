@@ -25,6 +25,7 @@ namespace aocr {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 
 namespace {
@@ -468,10 +469,359 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
     { stamp[8] = gs[0]; stamp[9] = gs[1]; stamp[13] = gs[2]; stamp[15] = local ? 1 : 0; for (int k = 0; k < 16; ++k) p.stamps[k] = stamp[k]; }
 }
 
+// =============================================================================================================================
+// Decoder BPTT (model.lua:643-661, t = L..1; cell backward LSTM.lua:79-105 through nngraph, attention LSTM.lua:124-162) in ONE launch,
+// same groups as the forward kernel: member m owns units 16m .. 16m+15 of every 512-wide vector of its 32 rows.  Per step, five
+// exchanges inside the group (flags + the real output tensors as payload, as in the forward kernel):
+//   d pre = (d out_proj(t) + d feed) (1 - out^2)                         own units                      -> all-gather (bf16)
+//   [d c ; d h2a] = d pre W_c                                            own columns                    -> row r's d c to member r (fp32)
+//   member r: d a = ctx d c, d s = a (d a - a . d a), d q = d s ctx       the row's attention backward   -> all-gather d q (bf16)
+//   d h2 = d q W_a + d h2a + d h2rec;  cell backward of layer 2          own units: d z2 (4 gates)      -> all-gather d z2 (bf16, 4 KB rows)
+//   d h1 = d z2 W2_i2h + d h1rec;      cell backward of layer 1          own units: d z1                -> all-gather d z1
+//   d h2rec = d z2 W2_h2h,  d h1rec = d z1 W1_h2h,  d feed = d z1 W1_i2h[:, E:]                           own units, for step t-1
+// The four K = 2048 weight slices (rows 16m .. 16m+15 of the TRANSPOSED matrices, K split over the four waves) stay in registers:
+// 256 VGPRs per lane; W_c^T / W_a^T slices (48) too.  Everything the hoisted weight-gradient GEMMs and attention_dctx read is
+// written in the launch chain's layouts: d pre, d c (in d cat), d s, d q, d z (fp32 + bf16), plus the final d c / d h of both layers.
+template <int CH, int NST, class DEF>
+__device__ __forceinline__ void fetch_rows(const bf16_t* src, int stride_bytes, int row0, int B, unsigned char* dst, int pitch, int tid, int member, bool local, DEF&& deferred) {
+  // 32 rows x CH KB into LDS (row pitch `pitch`), CH passes of 8 loads per thread; deferred(): exactly NST stores behind the first pass
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    u32x4 gr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ld16_sc1(gr[j], (unsigned)(min(row0 + (((tid >> 6) + 4 * j + member) & 31), B - 1) * stride_bytes + c * 1024 + (tid & 63) * 16), src, local);
+    if (c == 0) { deferred(); lds_barrier(); wait_vm<NST>(); } else wait_vm<0>();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dpin(gr[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(dst + (size_t)(((tid >> 6) + 4 * j + member) & 31) * pitch + c * 1024 + (tid & 63) * 16) = gr[j];
+  }
+  lds_barrier();
+}
+// payload(): this wave's piece; then the acknowledgement, the flag (one copy per reader) and the wait for all 128 flags of the group
+template <class PAY>
+__device__ __forceinline__ void raise_and_wait(unsigned* flags, unsigned tag, int tid, int wave, int member, bool local, int* err, int code, int* dead_flag, PAY&& payload) {
+  payload();
+  __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the piece is in L2 (and the compiler's own count restarts: see gather)
+  if ((tid & 63) < NM) pst4(flags + (size_t)(tid & 63) * 128 + member * 4 + wave, tag, local);
+  const unsigned foff = (unsigned)(member * 128 + (tid & 63)) * 4;
+  unsigned f0, f1; int spins = 0;
+#pragma nounroll
+  while (true) {
+    ld4_sc1(f0, foff, flags, local); ld4_sc1(f1, foff + 256, flags, local);
+    wait_vm<0>();
+    asm volatile("" : "+v"(f0), "+v"(f1));
+    if (__all(f0 == tag && f1 == tag)) break;
+    asm volatile("" : "+s"(spins));
+    if (++spins > DC_SPIN_LIMIT) { if ((tid & 63) == 0) { atomicExch(err, code); *dead_flag = 1; } break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+constexpr int PZ = 4096 + 16;                                      // LDS pitch of a d z operand row (2048 bf16)
+constexpr int BWD_LDS_BYTES = R * PZ + 16384 + 4096;               // operand (d pre / d q alias its start) + partial tiles + attention scratch
+
+__global__ __launch_bounds__(256, 1) void dec_cl_bwd_kernel(DecClBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* const X = lds;                                     // [32][PA]: d pre, later d q;  [32][PZ]: d z2, later d z1
+  float* const red = reinterpret_cast<float*>(lds + R * PZ);        // [4 waves][2 tiles][2 rt][64 lanes][4]: K-split partial tiles (16 KB)
+  float* const part = red;                                          // attention: [4 waves][512] partial d q
+  float* const da = reinterpret_cast<float*>(lds + R * PZ + 16384); // [256] d a
+  bf16_t* const dchl = reinterpret_cast<bf16_t*>(lds + R * PZ + 16384 + 1024);   // [2][512]: the row's d c as hi + lo bf16 (B operands)
+  __shared__ int s_local, s_dead;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q = lane >> 4;
+  const int wid = blockIdx.x, xcd = wid & 7, i8 = wid >> 3;
+  const int member = i8 % NM, gl = (i8 / NM) * 8 + xcd;
+  if (gl >= p.ngroups) return;
+  const int group = p.group0 + gl;
+  const int B = p.B, T = p.T, L = p.L, row0 = group * R;
+  const size_t slot = (size_t)B * HD;
+
+  u64* const xt = p.xtab + (size_t)group * NM;
+  if (tid == 0) {
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); xcc &= 15u;
+    stg64(xt + member, ((u64)p.epoch << 32) | (u64)(xcc + 1u));
+    int same = 1;
+    for (int m = 0; m < NM; ++m) {
+      u64 v; int spins = 0;
+      while ((unsigned)((v = ldg64(xt + m)) >> 32) != p.epoch) { if (++spins > DC_SPIN_LIMIT) { atomicExch(p.err, 25); same = 0; break; } __builtin_amdgcn_s_sleep(2); }
+      if ((unsigned)v != xcc + 1u) same = 0;
+    }
+    s_local = same && !p.force_remote; s_dead = 0;
+  }
+  __syncthreads();
+  const bool local = __builtin_amdgcn_readfirstlane(s_local) != 0;
+
+  // ---- resident weights: rows 16m + c16 of the transposed matrices (A fragments), this wave's quarter of K
+  bf16x8 wz[4][16], wct[2][4], wat[4];
+  {
+    const bf16_t* wsrc[4] = {p.w2i_t, p.w2h_t, p.w1h_t, p.w1f_t};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) wz[k][s] = *reinterpret_cast<const bf16x8*>(wsrc[k] + (size_t)(16 * member + c16) * 4 * HD + 512 * wave + 32 * s + 8 * q);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      wct[0][s] = *reinterpret_cast<const bf16x8*>(p.wc_t + (size_t)(16 * member + c16) * HD + 128 * wave + 32 * s + 8 * q);          // d c columns
+      wct[1][s] = *reinterpret_cast<const bf16x8*>(p.wc_t + (size_t)(HD + 16 * member + c16) * HD + 128 * wave + 32 * s + 8 * q);     // d h_top columns
+      wat[s] = *reinterpret_cast<const bf16x8*>(p.wa_t + (size_t)(16 * member + c16) * HD + 128 * wave + 32 * s + 8 * q);
+    }
+  }
+  unsigned* const xg = reinterpret_cast<unsigned*>(p.xbuf) + (size_t)group * 5 * NM * 128;      // flags [kind][reader][member][wave]
+  const int arow = row0 + member; const bool rvalid = arow < B;
+  const bf16_t* const cx = p.ctxb + (size_t)min(arow, B - 1) * T * HD;
+  const int ntile = (T + 15) >> 4;
+  // elementwise layout (waves 0, 1 = row tile): lane -> row 16 wave + c16, units 16 member + 4q .. + 3
+  f32x4 dc1 = {0.f, 0.f, 0.f, 0.f}, dc2 = dc1, dh1rec = dc1, dh2rec = dc1, dfeed = dc1;
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+
+  // K-split product of NT tiles: partial tiles -> LDS -> waves 0, 1 hold (row tile = wave) the sums
+  auto reduce_tiles = [&](auto& acc, auto& v) {
+    constexpr int NT = sizeof(v) / sizeof(v[0]);
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) *reinterpret_cast<f32x4*>(red + ((size_t)((wave * 2 + n) * 2 + rt) * 64 + lane) * 4) = acc[n][rt];
+    lds_barrier();
+    if (wave < 2) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        v[n] = *reinterpret_cast<const f32x4*>(red + ((size_t)((0 * 2 + n) * 2 + wave) * 64 + lane) * 4);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v[n] += *reinterpret_cast<const f32x4*>(red + ((size_t)((w * 2 + n) * 2 + wave) * 64 + lane) * 4);
+      }
+    }
+  };
+  // cell backward of one layer on this lane's 4 units (EpGatesBwd): d h -> d z (4 gates x 4 units), d c state update
+  auto cell_bwd = [&](int ot, int l, int t, const f32x4& dh, f32x4& dcs, f32x4 (&dz)[4]) {
+    const int c16_ = ot & 15, q_ = (ot >> 4) & 3;
+    const int row = min(row0 + 16 * wave + c16_, B - 1), u0 = 16 * member + 4 * q_;
+    const f32x4 cn = *reinterpret_cast<const f32x4*>(p.cs[l] + (size_t)(t + 1) * slot + (size_t)row * HD + u0);
+    const f32x4 cp = *reinterpret_cast<const f32x4*>(p.cs[l] + (size_t)t * slot + (size_t)row * HD + u0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.gates[l] + (((size_t)t * B + row) * HD + u0 + i) * 4);
+      const float ig = g[0], fg = g[1], og = g[2], gg = g[3];
+      const float tc = tanhf_(cn[i]);
+      const float dcv = dh[i] * og * (1.f - tc * tc) + dcs[i];
+      const float d_o = dh[i] * tc, di = dcv * gg, dg = dcv * ig, df = dcv * cp[i];
+      dz[0][i] = di * ig * (1.f - ig); dz[1][i] = df * fg * (1.f - fg); dz[2][i] = d_o * og * (1.f - og); dz[3][i] = dg * (1.f - gg * gg);
+      dcs[i] = dcv * fg;
+    }
+  };
+
+  for (int t = L - 1; t >= 0; --t) {
+    const unsigned tagc = p.epoch * 4096u + (unsigned)(t + 1);     // flags of step t: + kind * 512
+    int ot = tid; asm volatile("" : "+v"(ot));                      // opaque per-step copy of the thread id (see the forward kernel)
+    const int olane = ot & 63, oc16 = ot & 15, oq = (ot >> 4) & 3;
+    unsigned char* const otrash = reinterpret_cast<unsigned char*>(p.err + 16) + ot * 16;
+    const int erow = row0 + 16 * wave + oc16;                        // elementwise layout (waves 0, 1)
+    const bool eok = wave < 2 && erow < B;
+    const size_t eoff = (size_t)min(erow, B - 1) * HD + 16 * member + 4 * oq;
+    // attention prefetches of this member's row (independent of the step's gradients): a(t), the d a tile of ctx
+    float aj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) aj[j] = (olane + 64 * j < T) ? p.a_all[((size_t)t * B + min(arow, B - 1)) * T + olane + 64 * j] : 0.f;
+    // the tile of ctx for d a (rows 16 wave + c16): loaded two exchanges ahead of its use
+    bf16x8 cxv[16];
+    {
+      const bf16_t* r1 = cx + (size_t)min(16 * wave + oc16, T - 1) * HD + 8 * oq;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) cxv[s] = *reinterpret_cast<const bf16x8*>(r1 + 32 * s);
+    }
+    // =================== d pre
+    f32x4 dpre = {0.f, 0.f, 0.f, 0.f};
+    if (wave < 2) {
+      const f32x4 dp = *reinterpret_cast<const f32x4*>(p.dout_proj + (size_t)t * slot + eoff);
+      const f32x4 o = *reinterpret_cast<const f32x4*>(p.out + (size_t)(t + 1) * slot + eoff);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dpre[i] = (dp[i] + dfeed[i]) * (1.f - o[i] * o[i]);
+    }
+    raise_and_wait(xg + 0 * NM * 128, tagc, ot, wave, member, local, p.err, 21, &s_dead,
+                   [&] { pst8(eok ? (void*)(p.dpre_b + (size_t)t * slot + eoff) : (void*)otrash, u32x2{bfpair(dpre[0], dpre[1]), bfpair(dpre[2], dpre[3])}, local); });
+    fetch_rows<1, 1>(p.dpre_b + (size_t)t * slot, HD * 2, row0, B, X, PA, ot, member, local,
+                     [&] { st16f(eok ? (void*)(p.dpre + (size_t)t * slot + eoff) : (void*)otrash, dpre); });
+    if (s_dead) break;
+    // =================== [d c ; d h2a] = d pre W_c  (two tiles of 16 columns)
+    f32x4 dcat[2];
+    {
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) { acc[n][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[n][1] = acc[n][0]; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const bf16x8 bv = *reinterpret_cast<const bf16x8*>(X + (size_t)(16 * rt + c16) * PA + (128 * wave + 32 * s + 8 * q) * 2);
+          acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wct[0][s], bv, acc[0][rt], 0, 0, 0);
+          acc[1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wct[1][s], bv, acc[1][rt], 0, 0, 0);
+        }
+      reduce_tiles(acc, dcat);
+    }
+    // d c of all rows -> the rows' owners (payload: the c half of d cat, fp32; attention_dctx reads it after the loop)
+    raise_and_wait(xg + 1 * NM * 128, tagc + 512u, ot, wave, member, local, p.err, 22, &s_dead,
+                   [&] { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(eok ? (void*)(p.dcat + ((size_t)t * B + min(erow, B - 1)) * 2 * HD + 16 * member + 4 * oq) : (void*)otrash), "v"(dcat[0]) : "memory"); });
+    if (s_dead) break;
+    {                                                                // this member's row: 512 floats -> hi + lo bf16 in LDS
+      unsigned lo, hi;
+      u64 v; asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(v) : "v"((unsigned)(ot * 8)), "s"(p.dcat + ((size_t)t * B + min(arow, B - 1)) * 2 * HD) : "memory");
+      wait_vm<0>();
+      asm volatile("" : "+v"(v));
+      const float x0 = __builtin_bit_cast(float, (unsigned)v), x1 = __builtin_bit_cast(float, (unsigned)(v >> 32));
+      const float h0 = (float)(bf16_t)x0, h1 = (float)(bf16_t)x1;
+      hi = bfpair(h0, h1); lo = bfpair(x0 - h0, x1 - h1);
+      reinterpret_cast<unsigned*>(dchl)[ot] = hi; reinterpret_cast<unsigned*>(dchl + HD)[ot] = lo;
+      lds_barrier();
+    }
+    // =================== attention backward of row `member`
+    unsigned dqb; float dsv_own; f32x2 dqv;
+    {
+      const unsigned char* hrow = reinterpret_cast<const unsigned char*>(dchl) + 16 * q;
+      for (int tile = wave; tile < ntile; tile += 4) {
+        if (tile != wave) {
+          const bf16_t* r2 = cx + (size_t)min(16 * tile + oc16, T - 1) * HD + 8 * oq;
+#pragma unroll
+          for (int s = 0; s < 16; ++s) cxv[s] = *reinterpret_cast<const bf16x8*>(r2 + 32 * s);
+        }
+        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cxv[s], *reinterpret_cast<const bf16x8*>(hrow + 64 * s), a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cxv[s], *reinterpret_cast<const bf16x8*>(hrow + HD * 2 + 64 * s), a1, 0, 0, 0);
+        }
+        if (c16 == 0) *reinterpret_cast<f32x4*>(da + 16 * tile + 4 * q) = a0 + a1;
+      }
+      bf16x8 cv[16];                                               // second pass over ctx (d q): in flight across the d s arithmetic
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cv[i] = *reinterpret_cast<const bf16x8*>(cx + (size_t)min(4 * i + wave, T - 1) * HD + 8 * olane);
+      lds_barrier();
+      float dsj[4];
+      {
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dsj[j] = lane + 64 * j < T ? da[lane + 64 * j] : 0.f; dot += aj[j] * dsj[j]; }
+        dot = wave_reduce(dot, 0.f, [](float a, float b) { return a + b; });
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dsj[j] = aj[j] * (dsj[j] - dot);          // SoftMax backward (LSTM.lua:139)
+      }
+      dsv_own = wave == 0 ? dsj[0] : wave == 1 ? dsj[1] : wave == 2 ? dsj[2] : dsj[3];      // d s[tid]
+      float cacc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cacc[e] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (64 * c >= T) break;
+        if (c > 0) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) cv[i] = *reinterpret_cast<const bf16x8*>(cx + (size_t)min(64 * c + 4 * i + wave, T - 1) * HD + 8 * olane);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dsj[c]), 4 * i + wave));     // 0 beyond T
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cacc[e] = fmaf(d, (float)cv[i][e], cacc[e]);
+        }
+      }
+      *reinterpret_cast<f32x4*>(part + wave * HD + lane * 8) = f32x4{cacc[0], cacc[1], cacc[2], cacc[3]};
+      *reinterpret_cast<f32x4*>(part + wave * HD + lane * 8 + 4) = f32x4{cacc[4], cacc[5], cacc[6], cacc[7]};
+      lds_barrier();
+      float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { v0 += part[w * HD + 2 * tid]; v1 += part[w * HD + 2 * tid + 1]; }
+      dqv = f32x2{v0, v1}; dqb = bfpair(v0, v1);
+    }
+    raise_and_wait(xg + 2 * NM * 128, tagc + 1024u, ot, wave, member, local, p.err, 23, &s_dead,
+                   [&] { pst4(rvalid ? (void*)(p.dq_b + (size_t)t * slot + (size_t)arow * HD + 2 * ot) : (void*)otrash, dqb, local); });
+    fetch_rows<1, 2>(p.dq_b + (size_t)t * slot, HD * 2, row0, B, X, PA, ot, member, local,
+                     [&] {
+                       st4f(rvalid && ot < T ? (void*)(p.ds_all + ((size_t)t * B + arow) * T + ot) : (void*)otrash, dsv_own);
+                       asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" ::"v"(rvalid ? (void*)(p.dq + (size_t)t * slot + (size_t)arow * HD + 2 * ot) : (void*)otrash), "v"(dqv) : "memory");
+                     });
+    if (s_dead) break;
+    // =================== d h2 = d q W_a + d h2a + d h2rec;  cell backward of layer 2
+    f32x4 dz[4];
+    {
+      f32x4 acc[1][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}}, v[1];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+          acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wat[s], *reinterpret_cast<const bf16x8*>(X + (size_t)(16 * rt + c16) * PA + (128 * wave + 32 * s + 8 * q) * 2), acc[0][rt], 0, 0, 0);
+      reduce_tiles(acc, v);
+      if (wave < 2) { const f32x4 dh2 = v[0] + dcat[1] + dh2rec; cell_bwd(ot, 1, t, dh2, dc2, dz); }
+    }
+    auto dz_payload = [&](int l) {                                   // d z of (row, 4 units) x 4 gates, bf16, [row][gate * 512 + unit]
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        pst8(eok ? (void*)(p.dzb[l] + ((size_t)t * B + min(erow, B - 1)) * 4 * HD + g * HD + 16 * member + 4 * oq) : (void*)otrash, u32x2{bfpair(dz[g][0], dz[g][1]), bfpair(dz[g][2], dz[g][3])}, local);
+    };
+    auto dz_deferred = [&](int l) {                                  // the fp32 copy: 4 stores
+#pragma unroll
+      for (int g = 0; g < 4; ++g) st16f(eok ? (void*)(p.dz[l] + ((size_t)t * B + min(erow, B - 1)) * 4 * HD + g * HD + 16 * member + 4 * oq) : (void*)otrash, dz[g]);
+    };
+    // K = 2048 products against the gathered d z: two tiles (matrices ka, kb), this wave's quarter of K
+    auto zprod = [&](const bf16x8 (&wa_)[16], const bf16x8 (&wb_)[16], f32x4 (&v)[2]) {
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) { acc[n][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[n][1] = acc[n][0]; }
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const bf16x8 bv = *reinterpret_cast<const bf16x8*>(X + (size_t)(16 * rt + c16) * PZ + (512 * wave + 32 * s + 8 * q) * 2);
+          acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa_[s], bv, acc[0][rt], 0, 0, 0);
+          acc[1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb_[s], bv, acc[1][rt], 0, 0, 0);
+        }
+      reduce_tiles(acc, v);
+    };
+    raise_and_wait(xg + 3 * NM * 128, tagc + 1536u, ot, wave, member, local, p.err, 24, &s_dead, [&] { dz_payload(1); });
+    fetch_rows<4, 4>(p.dzb[1] + (size_t)t * B * 4 * HD, HD * 8, row0, B, X, PZ, ot, member, local, [&] { dz_deferred(1); });
+    if (s_dead) break;
+    {
+      f32x4 v[2];
+      zprod(wz[0], wz[1], v);                                               // d z2 W2_i2h (-> d h1), d z2 W2_h2h (-> d h2rec of step t-1)
+      if (wave < 2) { dh2rec = v[1]; const f32x4 dh1 = v[0] + dh1rec; cell_bwd(ot, 0, t, dh1, dc1, dz); }
+    }
+    raise_and_wait(xg + 4 * NM * 128, tagc + 2048u, ot, wave, member, local, p.err, 26, &s_dead, [&] { dz_payload(0); });
+    fetch_rows<4, 4>(p.dzb[0] + (size_t)t * B * 4 * HD, HD * 8, row0, B, X, PZ, ot, member, local, [&] { dz_deferred(0); });
+    if (s_dead) break;
+    {
+      f32x4 v[2];
+      zprod(wz[2], wz[3], v);                                               // d z1 W1_h2h (-> d h1rec), d z1 W1_i2h[:, E:] (-> d feed)
+      if (wave < 2) { dh1rec = v[0]; dfeed = v[1]; }
+    }
+    lds_barrier();                                                  // the d z operand is dead: the next step overwrites its start
+  }
+  // d c / d h of the initial decoder state, for the encoder's backward pass (model.lua:662-690)
+  if (!s_dead && wave < 2) {
+    const int erow = row0 + 16 * wave + c16;
+    if (erow < B) {
+      const size_t o = (size_t)erow * HD + 16 * member + 4 * q;
+      *reinterpret_cast<f32x4*>(p.dc_st[0] + o) = dc1; *reinterpret_cast<f32x4*>(p.dc_st[1] + o) = dc2;
+      *reinterpret_cast<f32x4*>(p.dh_rec[0] + o) = dh1rec; *reinterpret_cast<f32x4*>(p.dh_rec[1] + o) = dh2rec;
+      *reinterpret_cast<f32x4*>(p.dfeed + o) = dfeed;
+    }
+  }
+  wait_vm<0>();
+}
+
 // ---------------------------------------------------------------------------------------------
 size_t dec_cluster_xbuf_bytes(int B) { return (size_t)((B + R - 1) / R) * 4 * NM * 128 * sizeof(unsigned) + 256; }
 size_t dec_cluster_xtab_bytes(int B) { return (size_t)((B + R - 1) / R) * NM * sizeof(u64) + 256; }
 bool dec_cluster_supported(int Hd, int Ld, int input_feed, int T, int L, int cus) { return Hd == HD && Ld == 2 && input_feed && T >= 1 && T <= 256 && L + 2 < 1024 && cus >= 8 * NM; }
+
+size_t dec_cluster_bwd_xbuf_bytes(int B) { return (size_t)((B + R - 1) / R) * 5 * NM * 128 * sizeof(unsigned) + 256; }
+bool dec_cluster_bwd_supported(int Hd, int Ld, int input_feed, int T, int L, int cus) { return dec_cluster_supported(Hd, Ld, input_feed, T, L, cus) && L + 2 < 512; }
+void dec_cluster_backward(hipStream_t s, const DecClBwdArgs& a0) {
+  static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int groups = (a0.B + R - 1) / R, per_pass = std::max(8, cus / (8 * NM) * 8);
+  (void)hipFuncSetAttribute((const void*)dec_cl_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES);
+  for (int g0 = 0; g0 < groups; g0 += per_pass) {
+    DecClBwdArgs a = a0; a.group0 = g0; a.ngroups = std::min(per_pass, groups - g0); a.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;
+    hipLaunchKernelGGL(dec_cl_bwd_kernel, dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), (size_t)BWD_LDS_BYTES, s, a);
+  }
+}
 
 void dec_cluster_forward(hipStream_t s, const DecClFwdArgs& a0) {
   static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();

@@ -168,6 +168,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
       m->dc_xbytes = dec_cluster_xbuf_bytes((int)B); m->dc_tbytes = dec_cluster_xtab_bytes((int)B);
       m->dc_xbuf = a.get<unsigned long long>(m->dc_xbytes / 8); m->dc_xtab = a.get<unsigned long long>(m->dc_tbytes / 8);
       m->ctxa_b = a.get<bf16_t>(B * T * Hd);
+      m->dc_bxbytes = dec_cluster_bwd_xbuf_bytes((int)B); m->dc_bxbuf = a.get<unsigned long long>(m->dc_bxbytes / 8);
     }
   }
   m->shadow_dev = m->bf16 ? a.get<ShadowJob>(128) : nullptr;
@@ -395,7 +396,7 @@ static unsigned next_epoch(aocr_model* m) {
   if (++m->cl_epoch >= (1u << 20)) {                              // tags would repeat: clear the buffers and start over
     hipMemsetAsync(m->cl_xbuf, 0, m->cl_xbytes, m->s); hipMemsetAsync(m->cl_pbuf, 0, m->cl_pbytes, m->s); m->cl_epoch = 1;
     hipMemsetAsync(m->cl_xtab, 0, ((size_t)2 * ((m->cfg.batch_size + 15) / 16) * 8 + 64) * 8, m->s);
-    if (m->dc_xbuf) { hipMemsetAsync(m->dc_xbuf, 0, m->dc_xbytes, m->s); hipMemsetAsync(m->dc_xtab, 0, m->dc_tbytes, m->s); }
+    if (m->dc_xbuf) { hipMemsetAsync(m->dc_xbuf, 0, m->dc_xbytes, m->s); hipMemsetAsync(m->dc_xtab, 0, m->dc_tbytes, m->s); hipMemsetAsync(m->dc_bxbuf, 0, m->dc_bxbytes, m->s); }
   }
   return m->cl_epoch;
 }
@@ -655,6 +656,14 @@ static bool dec_cluster_ok(const aocr_model* m, int T, int L) {
   return dec_cluster_supported(m->Hd, m->Ld, m->cfg.input_feed, T, L, cus);
 }
 
+static bool dec_cluster_bwd_ok(const aocr_model* m, int T, int L) {
+  if (!m->dc_bxbuf || !m->dpre_b || !m->dq_b || !m->ddz_b[0] || !m->dec[0].swi.wtb || !m->swc.wtb) return false;
+  const char* e = getenv("AOCR_NO_DEC_CLUSTER_BWD");
+  if (e && e[0] == '1') return false;
+  static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  return dec_cluster_bwd_supported(m->Hd, m->Ld, m->cfg.input_feed, T, L, cus);
+}
+
 // teacher-forced decoder loop, model.lua:553-568 (train) / :604-627 (gold pass); the projector (model.lua:560)
 // is hoisted out of the loop: logits for all L steps in one contraction.
 void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_t st, int64_t sb, bool keep_gates) {
@@ -728,6 +737,15 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   prof_mark(m, AOCR_PROF_DEC_BWD);
   { ZeroList zl; for (int l = 0; l < Ld; ++l) { zl.add(m->dh_rec[l], slot * sizeof(float)); zl.add(m->dc_st[l], slot * sizeof(float)); } zero_many(s, zl); }
   const bool feed_fused = m->cfg.input_feed && Ld <= 2;  // the feed product joins the grouped launch and carries the tanh backward
+  if (m->dgates_il && dec_cluster_bwd_ok(m, T, L)) {     // the whole loop as one launch (dec_cluster.hip); needs the forward cluster kernel's saved state
+    DecClBwdArgs a; a.B = B; a.T = T; a.L = L; a.epoch = next_epoch(m);
+    a.w2i_t = m->dec[1].swi.wtb; a.w2h_t = m->dec[1].swh.wtb; a.w1h_t = m->dec[0].swh.wtb; a.w1f_t = m->dec[0].swi.wtb;
+    a.wc_t = m->swc.wtb; a.wa_t = m->swa.wtb; a.dout_proj = m->dout_proj; a.out = m->out_all; a.a_all = m->a_all; a.ctxb = m->context_b;
+    for (int l = 0; l < 2; ++l) { a.cs[l] = m->dcs[l]; a.gates[l] = m->dgates[l]; a.dz[l] = m->ddz[l]; a.dzb[l] = m->ddz_b[l]; a.dc_st[l] = m->dc_st[l]; a.dh_rec[l] = m->dh_rec[l]; }
+    a.dpre = m->dpre_all; a.dpre_b = m->dpre_b; a.dcat = m->dcat_all; a.ds_all = m->ds_all; a.dq = m->dq_all; a.dq_b = m->dq_b; a.dfeed = m->dfeed;
+    a.xbuf = m->dc_bxbuf; a.xtab = m->dc_xtab; a.err = m->cl_err;
+    dec_cluster_backward(s, a);
+  } else
   for (int t = L - 1; t >= 0; --t) {
     const bool last = t == L - 1;
     const float* out_t = m->out_all + (size_t)(t + 1) * slot;

@@ -224,7 +224,25 @@ struct DecClFwdArgs {
   float *a_all, *out; bf16_t *cat_b, *out_b;           // [c ; h_top] only as its bf16 copy
   unsigned long long *xbuf, *xtab; int* err; unsigned long long* stamps = nullptr;
 };
+// decoder BPTT in one launch (dec_cluster.hip); reads what the forward cluster kernel saved (interleaved gates)
+struct DecClBwdArgs {
+  int B, T, L; unsigned epoch; int group0 = 0, ngroups = 0, force_remote = 0;
+  const bf16_t *w2i_t, *w2h_t, *w1h_t, *w1f_t;          // transposed bf16 shadows [Hd][4 Hd]: W2_i2h, W2_h2h, W1_h2h, W1_i2h[:, E:]
+  const bf16_t *wc_t, *wa_t;                           // [2 Hd][Hd], [Hd][Hd]
+  const float *dout_proj, *out;                        // [L][B][Hd] projector gradient; [L + 1][B][Hd] attention outputs
+  const float* a_all; const bf16_t* ctxb;              // [L][B][T]; [B][T][Hd]
+  const float* cs[2]; const float* gates[2];           // [L + 1][B][Hd]; [L][B][Hd][4] (interleaved)
+  float* dpre; bf16_t* dpre_b;                         // [L][B][Hd]
+  float* dcat;                                         // [L][B][2 Hd]: only the c half is written
+  float* ds_all; float* dq; bf16_t* dq_b;              // [L][B][T]; [L][B][Hd]
+  float* dz[2]; bf16_t* dzb[2];                        // [L][B][4 Hd]
+  float* dc_st[2]; float* dh_rec[2]; float* dfeed;     // [B][Hd]: gradients of the initial state
+  unsigned long long *xbuf, *xtab; int* err;
+};
 bool dec_cluster_supported(int Hd, int Ld, int input_feed, int T, int L, int cus);
+bool dec_cluster_bwd_supported(int Hd, int Ld, int input_feed, int T, int L, int cus);
+size_t dec_cluster_bwd_xbuf_bytes(int B);
+void dec_cluster_backward(hipStream_t s, const DecClBwdArgs& a);
 size_t dec_cluster_xbuf_bytes(int B);
 size_t dec_cluster_xtab_bytes(int B);
 void dec_cluster_forward(hipStream_t s, const DecClFwdArgs& a);
