@@ -29,3 +29,10 @@ for k, name in enumerate(["out", "h1", "h2", "c"]):
     print(f"  {name:4s} flag raised {r(tm[:, k, 0:4])} | all seen {r(tm[:, k, 4:8])} | loads + stores issued {r(tm[:, k, 8:12])} | barrier {r(tm[:, k, 12])} | landed {r(tm[:, k, 13])} | in LDS {r(tm[:, k, 14])}")
     w = [int(((tm[:, k, 8 + i] - tm[:, k, 4 + i]) * 10).float().mean()) for i in range(4)]
     print(f"       seen -> issued, mean per wave: {w}")
+sb = m.get_tensor("dc_bstamps").view(torch.int64).cpu().tolist()
+bn = ["dpre + raise/wait", "fetch dpre", "dcat product", "dc raise/wait", "attention bwd", "dq raise/wait", "fetch dq", "dh2 product + cell 2", "dz2 raise/wait", "fetch dz2", "dz2 products + cell 1", "dz1 raise/wait", "fetch dz1", "dz1 products"]
+tb = sum(sb[:14])
+print("backward kernel, workgroup 0:")
+for n, v in zip(bn, sb):
+    print(f"  {n:24s} {v / L:9.0f} cycles/step  {100.0 * v / max(tb, 1):5.1f} %")
+print("  total cycles/step", tb / L)

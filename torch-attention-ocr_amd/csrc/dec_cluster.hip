@@ -484,17 +484,33 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
 // written in the launch chain's layouts: d pre, d c (in d cat), d s, d q, d z (fp32 + bf16), plus the final d c / d h of both layers.
 template <int CH, int NST, class DEF>
 __device__ __forceinline__ void fetch_rows(const bf16_t* src, int stride_bytes, int row0, int B, unsigned char* dst, int pitch, int tid, int member, bool local, DEF&& deferred) {
-  // 32 rows x CH KB into LDS (row pitch `pitch`), CH passes of 8 loads per thread; deferred(): exactly NST stores behind the first pass
+  // 32 rows x CH KB into LDS (row pitch `pitch`), CH passes of 8 loads per thread, two passes in flight; deferred(): exactly NST stores
+  // behind the first pass
+  u32x4 g0[8], g1[8];
+  auto issue = [&](u32x4 (&g)[8], int c) {
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    u32x4 gr[8];
+    for (int j = 0; j < 8; ++j) ld16_sc1(g[j], (unsigned)(min(row0 + (((tid >> 6) + 4 * j + member) & 31), B - 1) * stride_bytes + c * 1024 + (tid & 63) * 16), src, local);
+  };
+  auto land = [&](u32x4 (&g)[8], int c) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ld16_sc1(gr[j], (unsigned)(min(row0 + (((tid >> 6) + 4 * j + member) & 31), B - 1) * stride_bytes + c * 1024 + (tid & 63) * 16), src, local);
-    if (c == 0) { deferred(); lds_barrier(); wait_vm<NST>(); } else wait_vm<0>();
+    for (int j = 0; j < 8; ++j) dpin(g[j]);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dpin(gr[j]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(dst + (size_t)(((tid >> 6) + 4 * j + member) & 31) * pitch + c * 1024 + (tid & 63) * 16) = gr[j];
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(dst + (size_t)(((tid >> 6) + 4 * j + member) & 31) * pitch + c * 1024 + (tid & 63) * 16) = g[j];
+  };
+  issue(g0, 0);
+  if constexpr (CH == 1) {
+    deferred();
+    lds_barrier();                              // every wave of this workgroup is past its reads of the previous contents of dst
+    wait_vm<NST>(); land(g0, 0);
+  } else {
+    static_assert(CH == 4, "1 or 4 KB rows");
+    issue(g1, 1);
+    lds_barrier();
+    wait_vm<8>(); land(g0, 0);
+    issue(g0, 2); wait_vm<8>(); land(g1, 1);
+    issue(g1, 3); wait_vm<8>(); land(g0, 2);
+    deferred();                                 // behind the last pass: no load waits for these acknowledgements
+    wait_vm<NST>(); land(g1, 3);
   }
   lds_barrier();
 }
@@ -575,6 +591,7 @@ __global__ __launch_bounds__(256, 1) void dec_cl_bwd_kernel(DecClBwdArgs p) {
   // elementwise layout (waves 0, 1 = row tile): lane -> row 16 wave + c16, units 16 member + 4q .. + 3
   f32x4 dc1 = {0.f, 0.f, 0.f, 0.f}, dc2 = dc1, dh1rec = dc1, dh2rec = dc1, dfeed = dc1;
   __builtin_amdgcn_s_waitcnt(0x0F70);
+  [[maybe_unused]] u64 stamp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 
   // K-split product of NT tiles: partial tiles -> LDS -> waves 0, 1 hold (row tile = wave) the sums
   auto reduce_tiles = [&](auto& acc, auto& v) {
@@ -593,24 +610,40 @@ __global__ __launch_bounds__(256, 1) void dec_cl_bwd_kernel(DecClBwdArgs p) {
       }
     }
   };
-  // cell backward of one layer on this lane's 4 units (EpGatesBwd): d h -> d z (4 gates x 4 units), d c state update
-  auto cell_bwd = [&](int ot, int l, int t, const f32x4& dh, f32x4& dcs, f32x4 (&dz)[4]) {
-    const int c16_ = ot & 15, q_ = (ot >> 4) & 3;
-    const int row = min(row0 + 16 * wave + c16_, B - 1), u0 = 16 * member + 4 * q_;
-    const f32x4 cn = *reinterpret_cast<const f32x4*>(p.cs[l] + (size_t)(t + 1) * slot + (size_t)row * HD + u0);
-    const f32x4 cp = *reinterpret_cast<const f32x4*>(p.cs[l] + (size_t)t * slot + (size_t)row * HD + u0);
+  // cell backward of one layer on this lane's 4 units (EpGatesBwd): d h -> d z (4 gates x 4 units), d c state update (waves 0, 1).
+  // (Loading the saved gates / cell states a phase ahead was measured slower: 24 more live registers spill.)
+  struct CellIn { f32x4 cn, cp, g[4]; };
+  auto cell_load = [&](int ot, int l, int t, CellIn& ci) {
+    if (wave < 2) {
+      const int c16_ = ot & 15, q_ = (ot >> 4) & 3;
+      const int row = min(row0 + 16 * wave + c16_, B - 1), u0 = 16 * member + 4 * q_;
+      ci.cn = *reinterpret_cast<const f32x4*>(p.cs[l] + (size_t)(t + 1) * slot + (size_t)row * HD + u0);
+      ci.cp = *reinterpret_cast<const f32x4*>(p.cs[l] + (size_t)t * slot + (size_t)row * HD + u0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ci.g[i] = *reinterpret_cast<const f32x4*>(p.gates[l] + (((size_t)t * B + row) * HD + u0 + i) * 4);
+    }
+  };
+  auto cell_bwd = [&](const CellIn& ci, const f32x4& dh, f32x4& dcs, f32x4 (&dz)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const f32x4 g = *reinterpret_cast<const f32x4*>(p.gates[l] + (((size_t)t * B + row) * HD + u0 + i) * 4);
-      const float ig = g[0], fg = g[1], og = g[2], gg = g[3];
-      const float tc = tanhf_(cn[i]);
+      const float ig = ci.g[i][0], fg = ci.g[i][1], og = ci.g[i][2], gg = ci.g[i][3];
+      const float tc = tanhf_(ci.cn[i]);
       const float dcv = dh[i] * og * (1.f - tc * tc) + dcs[i];
-      const float d_o = dh[i] * tc, di = dcv * gg, dg = dcv * ig, df = dcv * cp[i];
+      const float d_o = dh[i] * tc, di = dcv * gg, dg = dcv * ig, df = dcv * ci.cp[i];
       dz[0][i] = di * ig * (1.f - ig); dz[1][i] = df * fg * (1.f - fg); dz[2][i] = d_o * og * (1.f - og); dz[3][i] = dg * (1.f - gg * gg);
       dcs[i] = dcv * fg;
     }
   };
-
+  // d out_proj(t) and out(t) of this lane's units: loaded one step ahead
+  f32x4 dpn = {0.f, 0.f, 0.f, 0.f}, on = dpn;
+  auto load_step_inputs = [&](int ot, int t) {
+    if (wave < 2) {
+      const size_t eo = (size_t)min(row0 + 16 * wave + (ot & 15), B - 1) * HD + 16 * member + 4 * ((ot >> 4) & 3);
+      dpn = *reinterpret_cast<const f32x4*>(p.dout_proj + (size_t)t * slot + eo);
+      on = *reinterpret_cast<const f32x4*>(p.out + (size_t)(t + 1) * slot + eo);
+    }
+  };
+  load_step_inputs(tid, L - 1);
   for (int t = L - 1; t >= 0; --t) {
     const unsigned tagc = p.epoch * 4096u + (unsigned)(t + 1);     // flags of step t: + kind * 512
     int ot = tid; asm volatile("" : "+v"(ot));                      // opaque per-step copy of the thread id (see the forward kernel)
@@ -619,29 +652,29 @@ __global__ __launch_bounds__(256, 1) void dec_cl_bwd_kernel(DecClBwdArgs p) {
     const int erow = row0 + 16 * wave + oc16;                        // elementwise layout (waves 0, 1)
     const bool eok = wave < 2 && erow < B;
     const size_t eoff = (size_t)min(erow, B - 1) * HD + 16 * member + 4 * oq;
+    // =================== d pre
+    f32x4 dpre = {0.f, 0.f, 0.f, 0.f};
+    if (wave < 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dpre[i] = (dpn[i] + dfeed[i]) * (1.f - on[i] * on[i]);
+    }
+    raise_and_wait(xg + 0 * NM * 128, tagc, ot, wave, member, local, p.err, 21, &s_dead,
+                   [&] { pst8(eok ? (void*)(p.dpre_b + (size_t)t * slot + eoff) : (void*)otrash, u32x2{bfpair(dpre[0], dpre[1]), bfpair(dpre[2], dpre[3])}, local); });
+    DC_STAMP(0);
+    fetch_rows<1, 1>(p.dpre_b + (size_t)t * slot, HD * 2, row0, B, X, PA, ot, member, local,
+                     [&] { st16f(eok ? (void*)(p.dpre + (size_t)t * slot + eoff) : (void*)otrash, dpre); });
+    DC_STAMP(1);
     // attention prefetches of this member's row (independent of the step's gradients): a(t), the d a tile of ctx
     float aj[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) aj[j] = (olane + 64 * j < T) ? p.a_all[((size_t)t * B + min(arow, B - 1)) * T + olane + 64 * j] : 0.f;
-    // the tile of ctx for d a (rows 16 wave + c16): loaded two exchanges ahead of its use
+    // the tile of ctx for d a (rows 16 wave + c16): in flight across the d cat product and the d c exchange
     bf16x8 cxv[16];
     {
       const bf16_t* r1 = cx + (size_t)min(16 * wave + oc16, T - 1) * HD + 8 * oq;
 #pragma unroll
       for (int s = 0; s < 16; ++s) cxv[s] = *reinterpret_cast<const bf16x8*>(r1 + 32 * s);
     }
-    // =================== d pre
-    f32x4 dpre = {0.f, 0.f, 0.f, 0.f};
-    if (wave < 2) {
-      const f32x4 dp = *reinterpret_cast<const f32x4*>(p.dout_proj + (size_t)t * slot + eoff);
-      const f32x4 o = *reinterpret_cast<const f32x4*>(p.out + (size_t)(t + 1) * slot + eoff);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dpre[i] = (dp[i] + dfeed[i]) * (1.f - o[i] * o[i]);
-    }
-    raise_and_wait(xg + 0 * NM * 128, tagc, ot, wave, member, local, p.err, 21, &s_dead,
-                   [&] { pst8(eok ? (void*)(p.dpre_b + (size_t)t * slot + eoff) : (void*)otrash, u32x2{bfpair(dpre[0], dpre[1]), bfpair(dpre[2], dpre[3])}, local); });
-    fetch_rows<1, 1>(p.dpre_b + (size_t)t * slot, HD * 2, row0, B, X, PA, ot, member, local,
-                     [&] { st16f(eok ? (void*)(p.dpre + (size_t)t * slot + eoff) : (void*)otrash, dpre); });
     if (s_dead) break;
     // =================== [d c ; d h2a] = d pre W_c  (two tiles of 16 columns)
     f32x4 dcat[2];
@@ -659,9 +692,11 @@ __global__ __launch_bounds__(256, 1) void dec_cl_bwd_kernel(DecClBwdArgs p) {
         }
       reduce_tiles(acc, dcat);
     }
+    DC_STAMP(2);
     // d c of all rows -> the rows' owners (payload: the c half of d cat, fp32; attention_dctx reads it after the loop)
     raise_and_wait(xg + 1 * NM * 128, tagc + 512u, ot, wave, member, local, p.err, 22, &s_dead,
                    [&] { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(eok ? (void*)(p.dcat + ((size_t)t * B + min(erow, B - 1)) * 2 * HD + 16 * member + 4 * oq) : (void*)otrash), "v"(dcat[0]) : "memory"); });
+    DC_STAMP(3);
     if (s_dead) break;
     {                                                                // this member's row: 512 floats -> hi + lo bf16 in LDS
       unsigned lo, hi;
@@ -731,14 +766,17 @@ __global__ __launch_bounds__(256, 1) void dec_cl_bwd_kernel(DecClBwdArgs p) {
       for (int w = 0; w < 4; ++w) { v0 += part[w * HD + 2 * tid]; v1 += part[w * HD + 2 * tid + 1]; }
       dqv = f32x2{v0, v1}; dqb = bfpair(v0, v1);
     }
+    DC_STAMP(4);
     raise_and_wait(xg + 2 * NM * 128, tagc + 1024u, ot, wave, member, local, p.err, 23, &s_dead,
                    [&] { pst4(rvalid ? (void*)(p.dq_b + (size_t)t * slot + (size_t)arow * HD + 2 * ot) : (void*)otrash, dqb, local); });
+    DC_STAMP(5);
     fetch_rows<1, 2>(p.dq_b + (size_t)t * slot, HD * 2, row0, B, X, PA, ot, member, local,
                      [&] {
                        st4f(rvalid && ot < T ? (void*)(p.ds_all + ((size_t)t * B + arow) * T + ot) : (void*)otrash, dsv_own);
                        asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" ::"v"(rvalid ? (void*)(p.dq + (size_t)t * slot + (size_t)arow * HD + 2 * ot) : (void*)otrash), "v"(dqv) : "memory");
                      });
     if (s_dead) break;
+    DC_STAMP(6);
     // =================== d h2 = d q W_a + d h2a + d h2rec;  cell backward of layer 2
     f32x4 dz[4];
     {
@@ -749,7 +787,7 @@ __global__ __launch_bounds__(256, 1) void dec_cl_bwd_kernel(DecClBwdArgs p) {
         for (int rt = 0; rt < 2; ++rt)
           acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wat[s], *reinterpret_cast<const bf16x8*>(X + (size_t)(16 * rt + c16) * PA + (128 * wave + 32 * s + 8 * q) * 2), acc[0][rt], 0, 0, 0);
       reduce_tiles(acc, v);
-      if (wave < 2) { const f32x4 dh2 = v[0] + dcat[1] + dh2rec; cell_bwd(ot, 1, t, dh2, dc2, dz); }
+      if (wave < 2) { const f32x4 dh2 = v[0] + dcat[1] + dh2rec; CellIn ci; cell_load(ot, 1, t, ci); cell_bwd(ci, dh2, dc2, dz); }
     }
     auto dz_payload = [&](int l) {                                   // d z of (row, 4 units) x 4 gates, bf16, [row][gate * 512 + unit]
 #pragma unroll
@@ -775,23 +813,31 @@ __global__ __launch_bounds__(256, 1) void dec_cl_bwd_kernel(DecClBwdArgs p) {
         }
       reduce_tiles(acc, v);
     };
+    DC_STAMP(7);
     raise_and_wait(xg + 3 * NM * 128, tagc + 1536u, ot, wave, member, local, p.err, 24, &s_dead, [&] { dz_payload(1); });
+    DC_STAMP(8);
     fetch_rows<4, 4>(p.dzb[1] + (size_t)t * B * 4 * HD, HD * 8, row0, B, X, PZ, ot, member, local, [&] { dz_deferred(1); });
     if (s_dead) break;
+    DC_STAMP(9);
     {
       f32x4 v[2];
       zprod(wz[0], wz[1], v);                                               // d z2 W2_i2h (-> d h1), d z2 W2_h2h (-> d h2rec of step t-1)
-      if (wave < 2) { dh2rec = v[1]; const f32x4 dh1 = v[0] + dh1rec; cell_bwd(ot, 0, t, dh1, dc1, dz); }
+      if (wave < 2) { dh2rec = v[1]; const f32x4 dh1 = v[0] + dh1rec; CellIn ci; cell_load(ot, 0, t, ci); cell_bwd(ci, dh1, dc1, dz); }
     }
+    DC_STAMP(10);
     raise_and_wait(xg + 4 * NM * 128, tagc + 2048u, ot, wave, member, local, p.err, 26, &s_dead, [&] { dz_payload(0); });
+    DC_STAMP(11);
     fetch_rows<4, 4>(p.dzb[0] + (size_t)t * B * 4 * HD, HD * 8, row0, B, X, PZ, ot, member, local, [&] { dz_deferred(0); });
     if (s_dead) break;
+    DC_STAMP(12);
+    if (t > 0) load_step_inputs(ot, t - 1);
     {
       f32x4 v[2];
       zprod(wz[2], wz[3], v);                                               // d z1 W1_h2h (-> d h1rec), d z1 W1_i2h[:, E:] (-> d feed)
       if (wave < 2) { dh1rec = v[0]; dfeed = v[1]; }
     }
     lds_barrier();                                                  // the d z operand is dead: the next step overwrites its start
+    DC_STAMP(13);
   }
   // d c / d h of the initial decoder state, for the encoder's backward pass (model.lua:662-690)
   if (!s_dead && wave < 2) {
@@ -804,11 +850,15 @@ __global__ __launch_bounds__(256, 1) void dec_cl_bwd_kernel(DecClBwdArgs p) {
     }
   }
   wait_vm<0>();
+#ifdef DC_DEBUG_STAMPS
+  if (p.stamps && wid == 0 && tid == 0)
+    for (int k = 0; k < 16; ++k) p.stamps[k] = stamp[k];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
 size_t dec_cluster_xbuf_bytes(int B) { return (size_t)((B + R - 1) / R) * 4 * NM * 128 * sizeof(unsigned) + 256; }
-size_t dec_cluster_xtab_bytes(int B) { return (size_t)((B + R - 1) / R) * NM * sizeof(u64) + 256; }
+size_t dec_cluster_xtab_bytes(int B) { return (size_t)((B + R - 1) / R) * NM * sizeof(u64) + 512; }   // + two debugging stamp areas
 bool dec_cluster_supported(int Hd, int Ld, int input_feed, int T, int L, int cus) { return Hd == HD && Ld == 2 && input_feed && T >= 1 && T <= 256 && L + 2 < 1024 && cus >= 8 * NM; }
 
 size_t dec_cluster_bwd_xbuf_bytes(int B) { return (size_t)((B + R - 1) / R) * 5 * NM * 128 * sizeof(unsigned) + 256; }
@@ -819,6 +869,7 @@ void dec_cluster_backward(hipStream_t s, const DecClBwdArgs& a0) {
   (void)hipFuncSetAttribute((const void*)dec_cl_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES);
   for (int g0 = 0; g0 < groups; g0 += per_pass) {
     DecClBwdArgs a = a0; a.group0 = g0; a.ngroups = std::min(per_pass, groups - g0); a.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;
+    a.stamps = getenv("AOCR_DC_STAMPS") ? a.xtab + (size_t)groups * NM + 16 : nullptr;   // debugging aid (-DDC_DEBUG_STAMPS): cycles per phase of workgroup 0
     hipLaunchKernelGGL(dec_cl_bwd_kernel, dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), (size_t)BWD_LDS_BYTES, s, a);
   }
 }

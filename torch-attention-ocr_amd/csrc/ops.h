@@ -237,7 +237,7 @@ struct DecClBwdArgs {
   float* ds_all; float* dq; bf16_t* dq_b;              // [L][B][T]; [L][B][Hd]
   float* dz[2]; bf16_t* dzb[2];                        // [L][B][4 Hd]
   float* dc_st[2]; float* dh_rec[2]; float* dfeed;     // [B][Hd]: gradients of the initial state
-  unsigned long long *xbuf, *xtab; int* err;
+  unsigned long long *xbuf, *xtab; int* err; unsigned long long* stamps = nullptr;
 };
 bool dec_cluster_supported(int Hd, int Ld, int input_feed, int T, int L, int cus);
 bool dec_cluster_bwd_supported(int Hd, int Ld, int input_feed, int T, int L, int cus);
