@@ -324,10 +324,10 @@ def main():
         ms, kfl = m.profile_kernel(0, 20)                # conv6 forward, HIP events on the model's stream
         ach = kfl / (ms * 1e-3) / 1e12
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_conv6_fwd_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r02_conv6_fwd_pmc.json")
         if bf16 and args.workload == "c3" and world == 1 and args.scaling == "weak" and os.path.exists(pmc):
             traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
-            traffic_source = ("profiles/r01_conv6_fwd_pmc.json: rocprofv3 --pmc passes of this command (tools/pmc_traffic.py); PMC counters cannot "
+            traffic_source = ("profiles/r02_conv6_fwd_pmc.json: rocprofv3 --pmc passes of this command (tools/pmc_traffic.py); PMC counters cannot "
                               "be read from inside the timed process, so this field is NOT measured in this run")
         out = {
             "metric": "image-lines/sec (train step)", "value": lines_per_s, "unit": "image-lines/s", "n_gpus": world,
