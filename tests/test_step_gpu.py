@@ -306,6 +306,36 @@ def test_decoder_cluster_kernel_matches_launch_chain(cuda, monkeypatch, B, W, ma
         assert abs(x - y) < 2e-2 * max(1.0, abs(x)), (x, y)
 
 
+@pytest.mark.parametrize("B,W,maxdec", [(32, 72, 10), (45, 100, 12), (256, 256, 50), (8, 800, 6)])
+def test_greedy_decode_cluster_kernel_matches_launch_chain(cuda, monkeypatch, B, W, maxdec):
+    """Greedy decode (model.lua:376-536 at beam 1) through the decoder cluster kernel's DEC variant -- cell, attention, projector on fp32
+    out, LogSoftMax, selection and the PAD-after-EOS rule inside one launch -- against the launch chain + project_select_kernel.
+    Labels must agree except where the two paths' logits tie to within bf16 noise (random weights: near-uniform log-probabilities)."""
+    cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for knob in ("0", "1"):
+        if knob == "1":
+            monkeypatch.setenv("AOCR_NO_DEC_CLUSTER", "1")
+        else:
+            monkeypatch.delenv("AOCR_NO_DEC_CLUSTER", raising=False)
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=min(5, maxdec - 1), compute="bf16", max_decoder_l=maxdec, max_beam=1)
+        # sharpen the output distribution so that the arg-max is not a coin toss between 39 near-equal classes
+        P2 = dict(P); P2["proj.w"] = P["proj.w"] * 40.0; m.set_parameters(P2, st)
+        loss, stats = m.step(batch, True, 1)
+        assert int(m.get_tensor("cl_err").view(torch.int32)[0]) == 0
+        o = m._dec_out
+        out[knob] = dict(labels=np.array(o.labels), scores=np.array(o.scores), gold=np.array(o.gold_scores), loss=loss)
+        m.shutdown()
+    a, b = out["1"], out["0"]
+    same_rows = (a["labels"] == b["labels"]).all(axis=1)
+    agree = (a["labels"] == b["labels"]).mean()
+    print(f"[parity] greedy decode cluster B={B} W={W} Lt={maxdec}: label agreement {agree:.4f}, identical rows {same_rows.mean():.3f}, "
+          f"score max-abs on identical rows {np.abs(a['scores'] - b['scores'])[same_rows].max() if same_rows.any() else float('nan'):.3e}")
+    assert agree >= 0.97 and same_rows.mean() >= 0.85
+    assert np.abs(a["scores"] - b["scores"])[same_rows].max() < 2e-2 * max(1.0, np.abs(a["scores"]).max())
+    assert np.abs(a["gold"] - b["gold"]).max() < 2e-2 * max(1.0, np.abs(a["gold"]).max())
+
+
 def test_c3_full_size_kernel_paths_agree(cuda, monkeypatch):
     """BASELINE config C3 at full size (32x256, B=256, He=256, L=24, bf16): the production dispatch (256x256 LDS-DMA conv /
     filter-gradient kernels, whole-sequence encoder kernels -- chosen by shape, no forcing) against the 128x128 and

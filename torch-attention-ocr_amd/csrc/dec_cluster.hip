@@ -31,7 +31,7 @@ typedef unsigned long long u64;
 namespace {
 constexpr int DC_SPIN_LIMIT = 1 << 18;
 constexpr int HD = 512, NM = 32, R = 32, PA = HD * 2 + 16;      // hidden size, members per group, rows per group, LDS operand pitch
-constexpr int LDS_BYTES = 3 * R * PA + 32768;                    // three operand buffers + the reduction scratch
+constexpr int LDS_BYTES = 3 * R * PA + 32768 + 4736;             // three operand buffers + the reduction scratch + the decode scratch
 
 // ---- VMEM in program order: polls first, the previous phase's output stores behind them, then `s_waitcnt vmcnt(#stores)` -- the
 // polls are waited for, the stores are not (vmcnt counts loads and stores in issue order on gfx9).  Every store below is ONE
@@ -148,6 +148,58 @@ __device__ __forceinline__ void load_rows(const bf16_t* src, int row0, int B, un
     *reinterpret_cast<u32x4*>(dst + (size_t)row * PA + ch * 16) = *reinterpret_cast<const u32x4*>(src + (size_t)gr * HD + ch * 8);
   }
 }
+template <int CH, int NST, class DEF>
+__device__ __forceinline__ void fetch_rows(const bf16_t* src, int stride_bytes, int row0, int B, unsigned char* dst, int pitch, int tid, int member, bool local, DEF&& deferred) {
+  // 32 rows x CH KB into LDS (row pitch `pitch`), CH passes of 8 loads per thread, two passes in flight; deferred(): exactly NST stores
+  // behind the first pass
+  u32x4 g0[8], g1[8];
+  auto issue = [&](u32x4 (&g)[8], int c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ld16_sc1(g[j], (unsigned)(min(row0 + (((tid >> 6) + 4 * j + member) & 31), B - 1) * stride_bytes + c * 1024 + (tid & 63) * 16), src, local);
+  };
+  auto land = [&](u32x4 (&g)[8], int c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dpin(g[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(dst + (size_t)(((tid >> 6) + 4 * j + member) & 31) * pitch + c * 1024 + (tid & 63) * 16) = g[j];
+  };
+  issue(g0, 0);
+  if constexpr (CH == 1) {
+    deferred();
+    lds_barrier();                              // every wave of this workgroup is past its reads of the previous contents of dst
+    wait_vm<NST>(); land(g0, 0);
+  } else {
+    static_assert(CH == 4, "1 or 4 KB rows");
+    issue(g1, 1);
+    lds_barrier();
+    wait_vm<8>(); land(g0, 0);
+    issue(g0, 2); wait_vm<8>(); land(g1, 1);
+    issue(g1, 3); wait_vm<8>(); land(g0, 2);
+    deferred();                                 // behind the last pass: no load waits for these acknowledgements
+    wait_vm<NST>(); land(g1, 3);
+  }
+  lds_barrier();
+}
+// payload(): this wave's piece; then the acknowledgement, the flag (one copy per reader) and the wait for all 128 flags of the group
+template <class PAY>
+__device__ __forceinline__ void raise_and_wait(unsigned* flags, unsigned tag, int tid, int wave, int member, bool local, int* err, int code, int* dead_flag, PAY&& payload) {
+  payload();
+  __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the piece is in L2 (and the compiler's own count restarts: see gather)
+  if ((tid & 63) < NM) pst4(flags + (size_t)(tid & 63) * 128 + member * 4 + wave, tag, local);
+  const unsigned foff = (unsigned)(member * 128 + (tid & 63)) * 4;
+  unsigned f0, f1; int spins = 0;
+#pragma nounroll
+  while (true) {
+    ld4_sc1(f0, foff, flags, local); ld4_sc1(f1, foff + 256, flags, local);
+    wait_vm<0>();
+    asm volatile("" : "+v"(f0), "+v"(f1));
+    if (__all(f0 == tag && f1 == tag)) break;
+    asm volatile("" : "+s"(spins));
+    if (++spins > DC_SPIN_LIMIT) { if ((tid & 63) == 0) { atomicExch(err, code); *dead_flag = 1; } break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 }  // namespace
 
 // Debugging aids, compiled in with -DDC_DEBUG_STAMPS only (their global stores make the compiler insert vmcnt waits between the asm loads):
@@ -158,6 +210,11 @@ __device__ __forceinline__ void load_rows(const bf16_t* src, int row0, int B, un
 #define DC_STAMP(k) do { } while (0)
 #endif
 
+// DEC = false: teacher-forced loop (train step, gold pass).  DEC = true: greedy decode (model.lua:376-536 at beam 1): the token fed to step
+// t+1 is the arg-max of step t -- the projector + LogSoftMax + selection of project_select_kernel run inside the loop: every member
+// multiplies its 16 fp32 units of out(t) with its slice of W_o, the partial logits of row r meet on member r (one more exchange),
+// which selects, keeps the running score, writes the label and publishes the token with its next out(t) flag.
+template <bool DEC>
 __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const F = lds;                        // feed (out(t-1)), later c(t)
@@ -166,6 +223,9 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
   float* const red = reinterpret_cast<float*>(lds + 3 * R * PA);     // [4 waves][4 tiles][2][64 lanes][4]: K-split partial tiles (32 KB);
   float* const part = red;                                            // attention: [4 waves][512] partial context,
   float* const sc = red + 2048;                                       //            [256] scores
+  float* const wos = reinterpret_cast<float*>(lds + 3 * R * PA + 32768);      // DEC: [40][16] this member's slice of W_o (fp32)
+  float* const outs = wos + 640;                                              //      [32][16] out(t) of this member's units (fp32)
+  int* const toks = reinterpret_cast<int*>(outs + 512);                       //      [32] the tokens fed to the current step
   __shared__ int s_local, s_dead;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
@@ -217,10 +277,16 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
   for (int rt = 0; rt < 2; ++rt) {
     const int row = min(row0 + 16 * rt + c16, B - 1);
     c1[rt] = p.cs[0][(size_t)row * HD + unit]; c2[rt] = p.cs[1][(size_t)row * HD + unit];
+    const size_t zrow = DEC ? (size_t)(p.tok0[(size_t)row * p.tok0_stride] - 1) : (size_t)row;      // DEC: the per-token table row of the GO token
 #pragma unroll
-    for (int i = 0; i < 4; ++i) zxr[rt][i] = p.zx1[(size_t)row * 4 * HD + i * HD + unit];
+    for (int i = 0; i < 4; ++i) zxr[rt][i] = p.zx1[zrow * 4 * HD + i * HD + unit];
   }
-  unsigned* const xg = reinterpret_cast<unsigned*>(p.xbuf) + (size_t)group * 4 * NM * 128;      // flags [kind: out, h1, h2, c][reader][member][wave]
+  if constexpr (DEC) {
+    for (int i = tid; i < 640; i += 256) { const int v = i >> 4, u = i & 15; wos[i] = v < p.V ? p.wo[(size_t)v * HD + 16 * member + u] : 0.f; }
+    if (tid < 32) toks[tid] = p.tok0[(size_t)min(row0 + tid, B - 1) * p.tok0_stride];
+  }
+  unsigned* const xg = reinterpret_cast<unsigned*>(p.xbuf) + (size_t)group * 5 * NM * 128;      // flags [kind: out, h1, h2, c, logits][reader][member][wave]
+  float score = 0.f; int prev_tok = 0;                              // DEC, wave 0 of the row's owner: running log-probability and last token
   load_rows(p.out_b, row0, B, F, tid); load_rows(p.hsb[0], row0, B, H1, tid); load_rows(p.hsb[1], row0, B, H2, tid);
   __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): nothing of the prologue is in flight inside the loop
   __syncthreads();
@@ -310,6 +376,20 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
                 },
                 [&] { store_out(ot, t - 1); }, gs, p.stamps != nullptr, tl0);
       if (s_dead) break;
+      if constexpr (DEC) {                          // the tokens chosen at step t-1 (published before the owners' out flags)
+        if (wave == 0) {
+          unsigned* const tp = p.tokx + (size_t)group * 32 + (ot & 31);
+          const unsigned tk = local ? __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (ot < 32) toks[ot] = (int)tk;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const size_t zrow = (size_t)(min(max(toks[16 * rt + oc16], 1), p.V) - 1);     // (clamped: a corrupted token must not become a wild address)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) zxr[rt][i] = p.zx1[zrow * 4 * HD + i * HD + ounit];
+        }
+      }
     }
     DC_STAMP(0);
     f32x4 g1[2]; u32x2 hp1[2];
@@ -359,7 +439,7 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
                 [&] { publish_h(1, hp2); }, [&] { store_layer(ot, 1, t, g2, c2, hp2, true); }, gs, p.stamps != nullptr, tl0 ? tl0 + 32 : nullptr);
       if (s_dead) break;
       DC_STAMP(4);
-      {                                                            // zx1 of the next step: lands while the attention runs
+      if constexpr (!DEC) {                                        // zx1 of the next step: lands while the attention runs
         const int tn = min(t + 1, L - 1);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
@@ -455,6 +535,56 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = tanhf_(v[i]);
         ov = v; ovb = u32x2{bfpair(v[0], v[1]), bfpair(v[2], v[3])};         // published behind the polls of the next step's first gather
+        if constexpr (DEC) *reinterpret_cast<f32x4*>(outs + (16 * wave + c16) * 16 + 4 * q) = v;
+      }
+    }
+    if constexpr (DEC) {
+      // projector (output_projector.lua:3-8) on fp32 out: this member's 16 units against its slice of W_o, 32 rows x V partial logits
+      lds_barrier();
+      float* const pp = p.pbuf + (size_t)group * 32 * 32 * 40;                   // [row][source member][40]
+      raise_and_wait(xg + 4 * NM * 128, tagc + 512u, ot, wave, member, local, p.err, 16, &s_dead, [&] {
+        const int r = ot >> 3, j = ot & 7;
+        float o16[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) o16[u] = outs[r * 16 + u];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const int v = j + 8 * k;
+          float acc = 0.f;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc = fmaf(wos[v * 16 + u], o16[u], acc);
+          pst4(pp + ((size_t)r * 32 + member) * 40 + v, __builtin_bit_cast(unsigned, acc), local);
+        }
+      });
+      if (s_dead) break;
+      if (wave == 0) {                     // LogSoftMax + selection of this member's row (project_select_kernel at beam 1)
+        const int V = p.V;
+        float x = -INFINITY;
+        if (olane < V) {
+          x = p.bo[olane];
+          float* const base = pp + (size_t)member * 32 * 40 + olane;
+          float pv[32];
+#pragma unroll
+          for (int sm = 0; sm < 32; ++sm)
+            pv[sm] = local ? __hip_atomic_load(base + sm * 40, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_load(base + sm * 40, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+          for (int sm = 0; sm < 32; ++sm) x += pv[sm];
+        }
+        const float mx = wave_reduce(x, -INFINITY, [](float a, float b) { return fmaxf(a, b); });
+        const float sum = wave_reduce(olane < V ? expf(x - mx) : 0.f, 0.f, [](float a, float b) { return a + b; });
+        float lp = olane < V ? x - (mx + logf(sum)) : -INFINITY;
+        if (t > 0) {
+          if (olane == 0 && (prev_tok == 1 || prev_tok == 3)) lp = 0.f;          // model.lua:448-449: after PAD / EOS only PAD, at no cost
+          lp += score;                                                          // model.lua:450
+        }
+        const float best = wave_reduce(lp, -INFINITY, [](float a, float b) { return fmaxf(a, b); });
+        const unsigned long long tie = __ballot(lp == best && olane < V);        // descending score, ties -> lowest index
+        const int bi = tie ? __ffsll((long long)tie) - 1 : 0;
+        score = best; prev_tok = bi + 1;
+        if (olane == 0) {
+          if (rvalid) { p.labels[(size_t)arow * p.tok0_stride + t] = bi + 1; if (t == L - 1) p.scores[arow] = best; }
+          pst4(p.tokx + (size_t)group * 32 + member, (unsigned)(bi + 1), local);
+        }
       }
     }
     DC_STAMP(7);
@@ -482,58 +612,6 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
 // The four K = 2048 weight slices (rows 16m .. 16m+15 of the TRANSPOSED matrices, K split over the four waves) stay in registers:
 // 256 VGPRs per lane; W_c^T / W_a^T slices (48) too.  Everything the hoisted weight-gradient GEMMs and attention_dctx read is
 // written in the launch chain's layouts: d pre, d c (in d cat), d s, d q, d z (fp32 + bf16), plus the final d c / d h of both layers.
-template <int CH, int NST, class DEF>
-__device__ __forceinline__ void fetch_rows(const bf16_t* src, int stride_bytes, int row0, int B, unsigned char* dst, int pitch, int tid, int member, bool local, DEF&& deferred) {
-  // 32 rows x CH KB into LDS (row pitch `pitch`), CH passes of 8 loads per thread, two passes in flight; deferred(): exactly NST stores
-  // behind the first pass
-  u32x4 g0[8], g1[8];
-  auto issue = [&](u32x4 (&g)[8], int c) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ld16_sc1(g[j], (unsigned)(min(row0 + (((tid >> 6) + 4 * j + member) & 31), B - 1) * stride_bytes + c * 1024 + (tid & 63) * 16), src, local);
-  };
-  auto land = [&](u32x4 (&g)[8], int c) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dpin(g[j]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(dst + (size_t)(((tid >> 6) + 4 * j + member) & 31) * pitch + c * 1024 + (tid & 63) * 16) = g[j];
-  };
-  issue(g0, 0);
-  if constexpr (CH == 1) {
-    deferred();
-    lds_barrier();                              // every wave of this workgroup is past its reads of the previous contents of dst
-    wait_vm<NST>(); land(g0, 0);
-  } else {
-    static_assert(CH == 4, "1 or 4 KB rows");
-    issue(g1, 1);
-    lds_barrier();
-    wait_vm<8>(); land(g0, 0);
-    issue(g0, 2); wait_vm<8>(); land(g1, 1);
-    issue(g1, 3); wait_vm<8>(); land(g0, 2);
-    deferred();                                 // behind the last pass: no load waits for these acknowledgements
-    wait_vm<NST>(); land(g1, 3);
-  }
-  lds_barrier();
-}
-// payload(): this wave's piece; then the acknowledgement, the flag (one copy per reader) and the wait for all 128 flags of the group
-template <class PAY>
-__device__ __forceinline__ void raise_and_wait(unsigned* flags, unsigned tag, int tid, int wave, int member, bool local, int* err, int code, int* dead_flag, PAY&& payload) {
-  payload();
-  __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the piece is in L2 (and the compiler's own count restarts: see gather)
-  if ((tid & 63) < NM) pst4(flags + (size_t)(tid & 63) * 128 + member * 4 + wave, tag, local);
-  const unsigned foff = (unsigned)(member * 128 + (tid & 63)) * 4;
-  unsigned f0, f1; int spins = 0;
-#pragma nounroll
-  while (true) {
-    ld4_sc1(f0, foff, flags, local); ld4_sc1(f1, foff + 256, flags, local);
-    wait_vm<0>();
-    asm volatile("" : "+v"(f0), "+v"(f1));
-    if (__all(f0 == tag && f1 == tag)) break;
-    asm volatile("" : "+s"(spins));
-    if (++spins > DC_SPIN_LIMIT) { if ((tid & 63) == 0) { atomicExch(err, code); *dead_flag = 1; } break; }
-    __builtin_amdgcn_s_sleep(1);
-  }
-}
-
 constexpr int PZ = 4096 + 16;                                      // LDS pitch of a d z operand row (2048 bf16)
 constexpr int BWD_LDS_BYTES = R * PZ + 16384 + 4096;               // operand (d pre / d q alias its start) + partial tiles + attention scratch
 
@@ -857,7 +935,8 @@ __global__ __launch_bounds__(256, 1) void dec_cl_bwd_kernel(DecClBwdArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-size_t dec_cluster_xbuf_bytes(int B) { return (size_t)((B + R - 1) / R) * 4 * NM * 128 * sizeof(unsigned) + 256; }
+size_t dec_cluster_xbuf_bytes(int B) { return (size_t)((B + R - 1) / R) * 5 * NM * 128 * sizeof(unsigned) + 256; }
+size_t dec_cluster_pbuf_bytes(int B) { return (size_t)((B + R - 1) / R) * (32 * 32 * 40 + 32) * sizeof(float) + 256; }   // partial logits + tokens (greedy decode)
 size_t dec_cluster_xtab_bytes(int B) { return (size_t)((B + R - 1) / R) * NM * sizeof(u64) + 512; }   // + two debugging stamp areas
 bool dec_cluster_supported(int Hd, int Ld, int input_feed, int T, int L, int cus) { return Hd == HD && Ld == 2 && input_feed && T >= 1 && T <= 256 && L + 2 < 1024 && cus >= 8 * NM; }
 
@@ -874,15 +953,17 @@ void dec_cluster_backward(hipStream_t s, const DecClBwdArgs& a0) {
   }
 }
 
-void dec_cluster_forward(hipStream_t s, const DecClFwdArgs& a0) {
+void dec_cluster_forward(hipStream_t s, const DecClFwdArgs& a0, bool greedy_decode) {
   static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
   const int groups = (a0.B + R - 1) / R, per_pass = std::max(8, cus / (8 * NM) * 8);
   const size_t lds = LDS_BYTES;
-  (void)hipFuncSetAttribute((const void*)dec_cl_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)dec_cl_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)dec_cl_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   for (int g0 = 0; g0 < groups; g0 += per_pass) {
     DecClFwdArgs a = a0; a.group0 = g0; a.ngroups = std::min(per_pass, groups - g0); a.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;
     a.stamps = getenv("AOCR_DC_STAMPS") ? a.xtab + (size_t)groups * NM : nullptr;   // debugging aid: cycles per phase of workgroup 0
-    hipLaunchKernelGGL(dec_cl_fwd_kernel, dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), lds, s, a);
+    if (greedy_decode) { a.tokx = reinterpret_cast<unsigned*>(a.pbuf + (size_t)groups * 32 * 32 * 40); hipLaunchKernelGGL(dec_cl_fwd_kernel<true>, dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), lds, s, a); }
+    else hipLaunchKernelGGL(dec_cl_fwd_kernel<false>, dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), lds, s, a);
   }
 }
 

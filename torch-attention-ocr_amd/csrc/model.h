@@ -95,7 +95,7 @@ struct aocr_model {
   int last_valid;
   // cluster encoder kernels (rnn_cluster.hip): exchange buffers, error flag, launch epoch (tags = epoch * 4096 + step)
   unsigned long long *cl_xbuf = nullptr, *cl_pbuf = nullptr, *cl_xtab = nullptr; int* cl_err = nullptr; size_t cl_xbytes = 0, cl_pbytes = 0; unsigned cl_epoch = 0;
-  unsigned long long *dc_xbuf = nullptr, *dc_xtab = nullptr; size_t dc_xbytes = 0, dc_tbytes = 0; aocr::bf16_t* ctxa_b = nullptr; bool dgates_il = false; unsigned long long* dc_bxbuf = nullptr; size_t dc_bxbytes = 0;   // decoder cluster kernel (dec_cluster.hip)
+  unsigned long long *dc_xbuf = nullptr, *dc_xtab = nullptr; size_t dc_xbytes = 0, dc_tbytes = 0; aocr::bf16_t* ctxa_b = nullptr; bool dgates_il = false; unsigned long long* dc_bxbuf = nullptr; size_t dc_bxbytes = 0; float* dc_pbuf = nullptr;   // decoder cluster kernel (dec_cluster.hip)
   aocr::CommState comm;
   // per-family HIP-event profile (aocr_profile_enable): a mark = "family `tag` runs from here to the next mark"
   bool prof_on = false;

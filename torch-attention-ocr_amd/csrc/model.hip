@@ -169,6 +169,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
       m->dc_xbuf = a.get<unsigned long long>(m->dc_xbytes / 8); m->dc_xtab = a.get<unsigned long long>(m->dc_tbytes / 8);
       m->ctxa_b = a.get<bf16_t>(B * T * Hd);
       m->dc_bxbytes = dec_cluster_bwd_xbuf_bytes((int)B); m->dc_bxbuf = a.get<unsigned long long>(m->dc_bxbytes / 8);
+      m->dc_pbuf = a.get<float>(dec_cluster_pbuf_bytes((int)B) / 4);
     }
   }
   m->shadow_dev = m->bf16 ? a.get<ShadowJob>(128) : nullptr;
@@ -869,6 +870,23 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
   // The embedding part of the first layer's gate input depends on the token only: one table row per vocabulary entry
   // (lookup W_i2h[:, :E]^T + both biases, LSTM.lua:55-56,79-80), gathered per step instead of a K = 20 GEMM per step.
   gemm(s, bf, m->lookup, E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * Hd, V, 4 * Hd, E, p1.bi, p1.bh, 0);
+  if (k == 1 && !trie && V <= 40 && m->out_b && m->dc_pbuf && !getenv("AOCR_NO_DEC_GREEDY") && dec_cluster_ok(m, T, Lt)) {
+    // greedy decode: the whole loop (cell, attention, projector, LogSoftMax, selection) as one launch of the decoder cluster kernel
+    float* tc0[MAXL]; float* th0[MAXL];
+    for (int l = 0; l < Ld; ++l) { tc0[l] = m->dcs[l]; th0[l] = m->dhs[l]; }
+    dec_init_state(m, d, tc0, th0, m->out_all, B, true);
+    const size_t slot = (size_t)B * Hd; (void)slot;
+    gemm_hh_shadow(s, m->context_b, Hd, m->swa.wtb, Hd, m->dctx, Hd, m->ctxa_b, Hd, B * T, Hd, Hd);
+    DecClFwdArgs a; a.B = B; a.T = T; a.L = Lt; a.epoch = next_epoch(m);
+    a.w1i = m->dec[0].swi.wb; a.w1h = m->dec[0].swh.wb; a.w2i = m->dec[1].swi.wb; a.w2h = m->dec[1].swh.wb; a.wc = m->swc.wb;
+    a.b2i = m->dec[1].bi; a.b2h = m->dec[1].bh; a.zx1 = m->bzx_tab; a.ctxb = m->context_b; a.ctxa = m->ctxa_b;
+    for (int l = 0; l < 2; ++l) { a.cs[l] = m->dcs[l]; a.hsb[l] = m->dhs_b[l]; a.gates[l] = nullptr; }
+    a.a_all = m->a_all; a.out = m->out_all; a.cat_b = m->cat_b; a.out_b = m->out_b;
+    a.xbuf = m->dc_xbuf; a.xtab = m->dc_xtab; a.err = m->cl_err;
+    a.tok0 = tgt; a.tok0_stride = Lt; a.wo = m->wo; a.bo = m->bo; a.V = V; a.pbuf = m->dc_pbuf; a.labels = labels; a.scores = scores;
+    dec_cluster_forward(s, a, true);
+    return;
+  }
   int cur = 0;
   for (int t = 0; t < Lt; ++t) {
     const int kin = t == 0 ? 1 : k, R = B * kin;

@@ -223,6 +223,9 @@ struct DecClFwdArgs {
   float* gates[2];                                     // [L][B][Hd][4] post-activation (i, f, o, g INTERLEAVED per unit), or nullptr
   float *a_all, *out; bf16_t *cat_b, *out_b;           // [c ; h_top] only as its bf16 copy
   unsigned long long *xbuf, *xtab; int* err; unsigned long long* stamps = nullptr;
+  // greedy decode (the kernel's DEC variant): zx1 is the per-token table [V][4 Hd]; tok0 = the GO tokens (row stride tok0_stride = the label width)
+  const int32_t* tok0 = nullptr; int tok0_stride = 0; const float *wo = nullptr, *bo = nullptr; int V = 0;
+  float* pbuf = nullptr; unsigned* tokx = nullptr; int32_t* labels = nullptr; float* scores = nullptr;
 };
 // decoder BPTT in one launch (dec_cluster.hip); reads what the forward cluster kernel saved (interleaved gates)
 struct DecClBwdArgs {
@@ -245,7 +248,8 @@ size_t dec_cluster_bwd_xbuf_bytes(int B);
 void dec_cluster_backward(hipStream_t s, const DecClBwdArgs& a);
 size_t dec_cluster_xbuf_bytes(int B);
 size_t dec_cluster_xtab_bytes(int B);
-void dec_cluster_forward(hipStream_t s, const DecClFwdArgs& a);
+void dec_cluster_forward(hipStream_t s, const DecClFwdArgs& a, bool greedy_decode = false);
+size_t dec_cluster_pbuf_bytes(int B);
 void enc_seq_backward(hipStream_t s, const EncSeqBwdArgs& a);
 void enc_seq_forward(hipStream_t s, const EncSeqFwdArgs& a);
 // data path (data.hip): 255*rgb2y + image.scale to (out_h, out_w) for n images sharing out_w
