@@ -79,6 +79,14 @@ int aocr_model_set_stream(aocr_model* m, void* stream);
 
 /* ---- fused sequence-level entry points (what Model:step uses) */
 
+/* nn.Dropout(p) of LSTM.lua:68-69 (input of every LSTM layer above the first, encoder and decoder) and :116-118 (attention output),
+ * active in the training step only (model.lua:284 `training()`; decode / forward_only run `evaluate()`).  The mask is a counter-based
+ * function of (seed, train_step, site, element index) -- splitmix64, restated in oracle/oracle_torch.py::dropout_mask -- so a step is
+ * reproducible and the oracle can replay it; kept activations are scaled by 1/(1-p) (nn.Dropout v2).  Call before every training
+ * step with the step counter (the reference draws from torch's global generator instead: the mask VALUES cannot match, the
+ * distribution does).  p = 0 (default) disables it.  With p > 0 the decoder runs the per-step launch chain. */
+int aocr_set_dropout(aocr_model* m, double p, uint64_t seed, uint64_t train_step);
+
 /* feval of model.lua:284-696 with forward_only=false: CNN forward (training-mode
  * BatchNorm, running stats updated), encoder fw/bw loops, teacher-forced decoder
  * loop, loss, hand-ordered BPTT, CNN backward.  Gradients are ZEROED then

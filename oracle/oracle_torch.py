@@ -56,6 +56,48 @@ def counter_uniform(seed: int, stream: int, n: int) -> np.ndarray:
     return (r >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
+# nn.Dropout (LSTM.lua:68-69: input of every LSTM layer above the first; :116-118: attention output), training mode only.  The
+# reference draws from torch's global generator; the product and this oracle use a counter-based mask instead so that a step can be
+# replayed: keep(idx) = (splitmix64(base + idx) >> 11) >= ceil(p 2^53), base = splitmix64(seed ^ stream * 0xD1342543DE82EF95),
+# stream = 64 * train_step + site, idx = flat offset of the element in its [time][batch][hidden] buffer; kept values x 1/(1-p).
+# Sites: decoder layer L's input -> L (2..), attention output -> 16, encoder fw / bw layer L's input -> 32 + L / 48 + L.
+_DROP = None            # (p, seed, train_step) while a dropout_state context is active
+
+
+class dropout_state:
+    def __init__(self, p: float, seed: int, train_step: int):
+        self.v = (float(p), int(seed), int(train_step))
+
+    def __enter__(self):
+        global _DROP
+        self.prev = _DROP; _DROP = self.v if self.v[0] > 0.0 else None
+        return self
+
+    def __exit__(self, *a):
+        global _DROP
+        _DROP = self.prev
+
+
+def dropout_mask(p: float, seed: int, train_step: int, site: int, offset: int, n: int) -> np.ndarray:
+    """n mask values (0 or 1/(1-p), float64) for the elements offset .. offset+n-1 of a site's buffer."""
+    with np.errstate(over="ignore"):
+        stream = np.uint64(train_step) * np.uint64(64) + np.uint64(site)
+        base = _splitmix64(np.array([np.uint64(seed) ^ (stream * np.uint64(0xD1342543DE82EF95))], dtype=np.uint64))[0]
+        r = _splitmix64((base + np.uint64(offset) + np.arange(n, dtype=np.uint64)) & _M64)
+    thr = np.uint64(math.ceil(p * 9007199254740992.0))
+    return np.where((r >> np.uint64(11)) >= thr, 1.0 / (1.0 - p), 0.0)
+
+
+def _drop(x, site: int, t: int):
+    """Dropout of a (B, H) activation of time step t at a site (identity outside a dropout_state / in eval mode)."""
+    if _DROP is None:
+        return x
+    p, seed, step = _DROP
+    B, H = x.shape
+    mk = dropout_mask(p, seed, step, site, t * B * H, B * H).reshape(B, H)
+    return x * torch.from_numpy(mk).to(x.dtype)
+
+
 def counter_normal(seed: int, stream: int, n: int) -> np.ndarray:
     u = counter_uniform(seed, stream, 2 * n)
     u1 = np.maximum(u[0::2], 1e-300)
@@ -339,7 +381,7 @@ def encoder_forward(P, cfg: OcrConfig, feats):
                 cn, hn, cache = lstm_cell_fwd(x, c_prev, h_prev, Wi, bi, Wh, bh)
                 step.append((x, c_prev, h_prev, cache))
                 c[L - 1], h[L - 1] = cn, hn
-                x = hn                                                 # Dropout(0) = identity (S6)
+                x = _drop(hn, (32 if prefix == "enc_fw" else 48) + L + 1, t) if L < Le else hn      # LSTM.lua:68-69 (Dropout(0) = identity, S6)
             tr[t] = step
             (ctx_fw if prefix == "enc_fw" else ctx_bw)[t] = h[Le - 1]
         traces[prefix] = (tr, c[Le - 1], h[Le - 1])                  # final top-layer state
@@ -363,7 +405,7 @@ def decoder_init_state(cfg: OcrConfig, traces, B, like, grad_through_quirk: bool
     return c, h
 
 
-def decoder_step_fwd(P, cfg: OcrConfig, tok, ctx, feed, c, h):
+def decoder_step_fwd(P, cfg: OcrConfig, tok, ctx, feed, c, h, t: int = 0):
     """One decoder clone forward, LSTM.lua:18-122.
     tok (B,) 1-based ids.  Returns new (c, h, attn_out) and caches."""
     emb = P["dec.lookup"][tok.long() - 1]
@@ -375,14 +417,23 @@ def decoder_step_fwd(P, cfg: OcrConfig, tok, ctx, feed, c, h):
         c2, h2, cache = lstm_cell_fwd(x, c[L - 1], h[L - 1], Wi, bi, Wh, bh)
         caches.append((x, c[L - 1], h[L - 1], cache))
         cn.append(c2); hn.append(h2)
-        x = h2
+        x = _drop(h2, L + 1, t) if L < cfg.dec_layers else h2                 # LSTM.lua:68-69
     out, acache = attn_fwd(hn[-1], ctx, P["dec.attn.wa"], P["dec.attn.wc"])
+    out = _drop(out, 16, t)                                                   # LSTM.lua:116-118
     return cn, hn, out, (caches, acache)
 
 
 def forward_train(P, bn_state, cfg: OcrConfig, images, targets, targets_eval, training=True,
                   grad_through_quirk=False, update_running=True):
-    """model.lua:285-316 + 537-569 + loss of :643-647.  Returns dict of everything."""
+    """model.lua:285-316 + 537-569 + loss of :643-647.  Returns dict of everything.  Inside a `dropout_state` context (and with
+    training=True) the Dropout sites of LSTM.lua are active."""
+    global _DROP
+    if not training and _DROP is not None:                                   # evaluate(): nn.Dropout is the identity
+        saved, _DROP = _DROP, None
+        try:
+            return forward_train(P, bn_state, cfg, images, targets, targets_eval, training, grad_through_quirk, update_running)
+        finally:
+            _DROP = saved
     B = images.shape[0]
     feats = cnn_forward(P, bn_state, images, training, update_running)
     context, traces = encoder_forward(P, cfg, feats)
@@ -394,7 +445,7 @@ def forward_train(P, bn_state, cfg: OcrConfig, images, targets, targets_eval, tr
     w = torch.ones(cfg.vocab, dtype=feats.dtype); w[PAD - 1] = 0             # criterion.lua:4-5
     for t in range(L):
         c_prev, h_prev, feed_prev = c, h, feed
-        c, h, out, caches = decoder_step_fwd(P, cfg, targets[:, t], context, feed, c, h)
+        c, h, out, caches = decoder_step_fwd(P, cfg, targets[:, t], context, feed, c, h, t)
         if cfg.input_feed:
             feed = out                                                        # model.lua:561-563
         logits, logp = projector_fwd(out, P["proj.w"], P["proj.b"])
@@ -423,6 +474,7 @@ def train_step_manual(P, bn_state, cfg: OcrConfig, images, targets, targets_eval
     """Restates model.lua:634-694: decoder BPTT t=L..1 with input-feed gradient,
     d(context) accumulation, encoder BPTT in both directions, CNN backward.
     The CNN (a plain nn.Sequential, model.lua:692) is differentiated by autograd."""
+    assert _DROP is None, "the hand-rolled BPTT restates the reference at dropout = 0; use train_step_autograd inside dropout_state"
     st = {k: v.clone() for k, v in bn_state.items()}
     Pc = {k: (v.clone().requires_grad_(True) if k.startswith("cnn.") else v) for k, v in P.items()}
     with torch.enable_grad():

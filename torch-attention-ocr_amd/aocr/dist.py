@@ -24,6 +24,11 @@ def world_size() -> int:
     return d.get_world_size() if (d.is_available() and d.is_initialized()) else 1
 
 
+def rank() -> int:
+    d = torch.distributed
+    return d.get_rank() if (d.is_available() and d.is_initialized()) else 0
+
+
 def grad_scale(local_batch: int) -> float:
     """d(loss)/d(pred) scale so that the SUM over ranks equals the reference's 1/batch_size of the global batch."""
     return 1.0 / (local_batch * world_size())

@@ -77,8 +77,9 @@ class Model:
         g = lambda k: _cfg_get(config, k)
         self.cnn_feature_size = 512
         self.dropout = float(g("dropout"))
-        if self.dropout != 0.0:
-            raise NotImplementedError("dropout > 0 is not implemented on the HIP path (reference default is 0.0)")
+        if not 0.0 <= self.dropout < 1.0:
+            raise ValueError(f"dropout {self.dropout} outside [0, 1)")
+        self.dropout_seed = 910820          # the mask is a counter-based function of (seed, global_step, site, element): include/aocr.h
         self.encoder_num_hidden = int(g("encoder_num_hidden"))
         self.encoder_num_layers = int(g("encoder_num_layers"))
         self.decoder_num_hidden = 2 * self.encoder_num_hidden
@@ -304,6 +305,7 @@ class Model:
             dist.attach(self, sync_bn=not os.environ.get("AOCR_NO_SYNC_BN"))       # once: torch.distributed becomes the library's provider
         # d(loss) / (global batch): model.lua:645-647 divides by the step's batch size
         scale = dist.grad_scale(B) if global_batch is None else 1.0 / float(global_batch)
+        self._arm_dropout()
         check(lib.aocr_train_forward_backward(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, target_l,
                                               scale, ptr(loss_dev)), "aocr_train_forward_backward")
         # the one exchange step of data parallelism (RCCL over xGMI), between feval and the per-group clip; bucketed in the order
@@ -430,10 +432,17 @@ class Model:
         B, _, _, W = images.shape
         L = targets.shape[1]
         check(lib.aocr_model_set_stream(self._h, self._stream()))
+        self._arm_dropout()
         check(lib.aocr_train_forward_backward(self._h, ptr(images), ptr(targets), ptr(targets_eval), B, W, L,
                                               (1.0 / B) if grad_scale is None else grad_scale, ptr(self._scal[0:1])),
               "aocr_train_forward_backward")
         return float(self._scal[0].item())
+
+    def _arm_dropout(self):
+        """nn.Dropout(p) of LSTM.lua:68-69,116-118 for the coming training step (rank-dependent seed under data parallelism)."""
+        if self.dropout > 0.0 or getattr(self, "_dropout_armed", False):
+            check(lib.aocr_set_dropout(self._h, self.dropout, self.dropout_seed + 7919 * dist.rank(), int(self.global_step)), "aocr_set_dropout")
+            self._dropout_armed = self.dropout > 0.0
 
     def sgd_step(self, lr=None, clip=5.0):
         norms = self._scal[2:12]

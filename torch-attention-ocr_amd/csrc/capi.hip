@@ -1,4 +1,5 @@
 // capi.hip -- the extern "C" surface declared in include/aocr.h.
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -208,17 +209,27 @@ static int step_dims(aocr_model* m, int32_t B, int32_t W, int32_t L, Dims& d) {
   return 0;
 }
 
+int aocr_set_dropout(aocr_model* m, double p, uint64_t seed, uint64_t train_step) {
+  REQUIRE(m, "NULL model");
+  REQUIRE(p >= 0.0 && p < 1.0, "dropout p=%g outside [0, 1)", p);
+  m->drop_p = p; m->drop_seed = seed; m->drop_step = train_step;
+  m->drop_thr = p > 0.0 ? (unsigned long long)ceil(p * 9007199254740992.0) : 0ull;       // keep <=> (r >> 11) >= p 2^53
+  return 0;
+}
+
 int aocr_train_forward_backward(aocr_model* m, const float* images_dev, const int32_t* targets_dev, const int32_t* targets_eval_dev,
                                 int32_t B, int32_t W, int32_t L, float grad_scale, float* loss_dev) {
   Dims d; if (step_dims(m, B, W, L, d)) return 1;
   REQUIRE(images_dev && targets_dev && targets_eval_dev, "NULL input");
   prof_mark(m, AOCR_PROF_OTHER);
   hipMemsetAsync(m->grads, 0, (size_t)m->layout.group_off[AOCR_NUM_GROUPS] * sizeof(float), m->s);      // model.lua:637-639
+  m->drop_on = m->drop_thr != 0;                                          // nn.Dropout is active in training() mode only (model.lua:284)
   cnn_forward(m, images_dev, d, 1, 1);
   encoder_forward(m, d);
   decoder_tf_forward(m, d, targets_dev, 1, L, true);
   loss_and_dlogits(m, d, targets_eval_dev, 1, L, grad_scale, true, loss_dev);
   backward_all(m, images_dev, targets_dev, d);
+  m->drop_on = false;
   prof_mark(m, -1);
   m->last = d; m->last_valid = 1;
   return check_launch("aocr_train_forward_backward");

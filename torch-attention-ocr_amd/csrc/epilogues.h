@@ -20,6 +20,23 @@ __device__ __forceinline__ float tanhf_(float x) {
   return copysignf(t, x);
 }
 
+// nn.Dropout (LSTM.lua:68-69 on the input of every layer above the first, :116-118 on the attention output): counter-based mask, the
+// same function as oracle_torch.dropout_mask -- keep(idx) = (splitmix64(base + idx) >> 11) >= thr with base = splitmix64(seed ^
+// stream * 0xD1342543DE82EF95), stream = 64 * train step + site, thr = ceil(p * 2^53); kept values are scaled by 1 / (1 - p).
+// idx = the element's flat offset in its [time][batch][hidden] buffer.  thr == 0: no dropout.
+__host__ __device__ __forceinline__ unsigned long long splitmix64_(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  unsigned long long z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+struct DropSpec {
+  unsigned long long base = 0, thr = 0; float scale = 1.f; long long off = 0;       // off: flat offset of row 0 / column 0 of this launch
+  __device__ __forceinline__ bool on() const { return thr != 0; }
+  __device__ __forceinline__ float mask(long long idx) const { return ((splitmix64_(base + (unsigned long long)(off + idx)) >> 11) >= thr) ? scale : 0.f; }
+};
+
 // C[m][n] = act(v + bias[n] + bias2[n]); columns >= N0 go to a second destination (C1, column n-N0).
 struct EpStore {
   float* C; int64_t ldc; int M, N;
@@ -29,6 +46,7 @@ struct EpStore {
   bf16_t* Cb = nullptr; int64_t ldcb = 0; // optional bf16 shadow of C (plain stores only)
   // optional tanh-backward fusion (decoder BPTT, model.lua:649,654-657): x <- (x + dg[m][n]) * (1 - dout[m][n]^2)
   const float* dg = nullptr; const float* dout = nullptr; int64_t ldd = 0;
+  DropSpec drop;                          // dropout of the attention output: forward (with EP_TANH: x <- mask * tanh(x), idx = row * N + col) and, with dg, its backward
   template <int NT> __device__ __forceinline__ void quad(int m, int n, int nstep, const float (&v)[NT][4]) const {
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
@@ -45,8 +63,12 @@ struct EpStore {
         if (row >= M) continue;
         float x = v[ni][i] + bb;
         if (flags & EP_RELU) x = fmaxf(x, 0.f);
-        if (flags & EP_TANH) x = tanhf_(x);
-        if (dg) { const float o = dout[(int64_t)row * ldd + col]; x = (x + dg[(int64_t)row * ldd + col]) * (1.f - o * o); }
+        if (flags & EP_TANH) { x = tanhf_(x); if (drop.on()) x *= drop.mask((long long)row * N + col); }
+        if (dg) {
+          float o = dout[(int64_t)row * ldd + col];
+          if (drop.on()) { const float mk = drop.mask((long long)row * ldd + col); o = mk != 0.f ? o / mk : 0.f; x = (x + dg[(int64_t)row * ldd + col]) * mk * (1.f - o * o); }
+          else x = (x + dg[(int64_t)row * ldd + col]) * (1.f - o * o);
+        }
         float* p = base + (int64_t)row * ld + cc;
         if (flags & EP_ATOMIC) atomicAdd(p, x);
         else if (flags & EP_ACCUM) *p += x;
@@ -68,8 +90,12 @@ struct EpStore {
       if (bias) x += bias[col];
       if (bias2) x += bias2[col];
       if (flags & EP_RELU) x = fmaxf(x, 0.f);
-      if (flags & EP_TANH) x = tanhf_(x);
-      if (dg) { const float o = dout[(int64_t)row * ldd + col]; x = (x + dg[(int64_t)row * ldd + col]) * (1.f - o * o); }
+      if (flags & EP_TANH) { x = tanhf_(x); if (drop.on()) x *= drop.mask((long long)row * N + col); }
+      if (dg) {
+        float o = dout[(int64_t)row * ldd + col];
+        if (drop.on()) { const float mk = drop.mask((long long)row * ldd + col); o = mk != 0.f ? o / mk : 0.f; x = (x + dg[(int64_t)row * ldd + col]) * mk * (1.f - o * o); }
+        else x = (x + dg[(int64_t)row * ldd + col]) * (1.f - o * o);
+      }
       float* p = (C1 && col >= N0) ? C1 + (int64_t)row * ldc1 + (col - N0) : C + (int64_t)row * ldc + col;
       if (flags & EP_ATOMIC) atomicAdd(p, x);
       else if (flags & EP_ACCUM) *p += x;
@@ -135,6 +161,7 @@ struct EpGatesFwd {
   bf16_t* hb = nullptr; int64_t ldhb = 0;   // optional bf16 shadows of h_out / h_out2 (operands of the next contractions)
   bf16_t* hb2 = nullptr; int64_t ldhb2 = 0;
   const int32_t* zx_tok = nullptr; int64_t zx_tok_stride = 1;   // optional: zx is a per-token table, row r reads table row zx_tok[r*stride]-1
+  DropSpec drop;                            // dropout of the SECOND copy (h_out2 / hb2 = the next layer's input), idx = row * H + j
   __device__ __forceinline__ int64_t zrow(int row) const { return zx_tok ? (int64_t)(zx_tok[(int64_t)row * zx_tok_stride] - 1) : (int64_t)row; }
   template <int NT> __device__ __forceinline__ void quad(int m, int j, int, const float (&v)[NT][4]) const {
     static_assert(NT == 4, "gate epilogue needs the 4 gate tiles");
@@ -159,9 +186,10 @@ struct EpGatesFwd {
       float hh = og * tanhf_(c);
       c_out[(int64_t)row * ldc + j] = c;
       h_out[(int64_t)row * ldh + j] = hh;
-      if (h_out2) h_out2[(int64_t)row * ldh2 + j] = hh;
+      const float hh2 = drop.on() ? hh * drop.mask((long long)row * H + j) : hh;
+      if (h_out2) h_out2[(int64_t)row * ldh2 + j] = hh2;
       if (hb) hb[(int64_t)row * ldhb + j] = (bf16_t)hh;
-      if (hb2) hb2[(int64_t)row * ldhb2 + j] = (bf16_t)hh;
+      if (hb2) hb2[(int64_t)row * ldhb2 + j] = (bf16_t)hh2;
       if (gates) {
         float* gp = gates + (int64_t)row * ldg + j;
         gp[0] = ig; gp[H] = fg; gp[2 * H] = og; gp[3 * H] = gg;
@@ -193,9 +221,10 @@ struct EpGatesFwd {
     float hh = og * tanhf_(c);
     c_out[(int64_t)row * ldc + j] = c;
     h_out[(int64_t)row * ldh + j] = hh;
-    if (h_out2) h_out2[(int64_t)row * ldh2 + j] = hh;
+    const float hh2 = drop.on() ? hh * drop.mask((long long)row * H + j) : hh;
+    if (h_out2) h_out2[(int64_t)row * ldh2 + j] = hh2;
     if (hb) hb[(int64_t)row * ldhb + j] = (bf16_t)hh;
-    if (hb2) hb2[(int64_t)row * ldhb2 + j] = (bf16_t)hh;
+    if (hb2) hb2[(int64_t)row * ldhb2 + j] = (bf16_t)hh2;
     if (gates) {
       float* gp = gates + (int64_t)row * ldg + j;
       gp[0] = ig; gp[H] = fg; gp[2 * H] = og; gp[3 * H] = gg;
@@ -215,6 +244,7 @@ struct EpGatesBwd {
   float* dc_out; int64_t lddco;           // d(c_prev)
   int M, H;
   bf16_t* dzb = nullptr; int64_t lddzb = 0; // optional bf16 shadow of dz
+  DropSpec drop;                            // dropout backward of the layer above's input: the GEMM part (d of the masked copy) is scaled by the mask, idx = row * H + j
   bool gil = false;                         // gates stored [m][j][4] (interleaved per unit: the decoder cluster kernel) instead of [m][g*H+j]
   template <int NT> __device__ __forceinline__ void quad(int m, int j, int, const float (&v)[NT][4]) const {
     static_assert(NT == 1, "gate backward epilogue is single-tile");
@@ -224,6 +254,7 @@ struct EpGatesBwd {
       int row = m + i;
       if (row >= M) continue;
       float dh = v[0][i];
+      if (drop.on()) dh *= drop.mask((long long)row * H + j);
       if (dh1) dh += dh1[(int64_t)row * ld1 + j];
       if (dh2) dh += dh2[(int64_t)row * ld2 + j];
       float ig, fg, og, gg;
@@ -259,7 +290,7 @@ struct EpGatesBwd {
   template <int NT> __device__ __forceinline__ void elem(int row, int j, int, const float (&v)[NT], const Pre& pre) const {
     static_assert(NT == 1, "gate backward epilogue is single-tile");
     if (j >= H || row >= M) return;
-    float dh = v[0] + pre.dh;
+    float dh = (drop.on() ? v[0] * drop.mask((long long)row * H + j) : v[0]) + pre.dh;
     float ig = pre.ig, fg = pre.fg, og = pre.og, gg = pre.gg;
     float tc = tanhf_(pre.c);
     float dc = dh * og * (1.f - tc * tc) + pre.dc;

@@ -95,7 +95,11 @@ struct aocr_model {
   int last_valid;
   // cluster encoder kernels (rnn_cluster.hip): exchange buffers, error flag, launch epoch (tags = epoch * 4096 + step)
   unsigned long long *cl_xbuf = nullptr, *cl_pbuf = nullptr, *cl_xtab = nullptr; int* cl_err = nullptr; size_t cl_xbytes = 0, cl_pbytes = 0; unsigned cl_epoch = 0;
-  unsigned long long *dc_xbuf = nullptr, *dc_xtab = nullptr; size_t dc_xbytes = 0, dc_tbytes = 0; aocr::bf16_t* ctxa_b = nullptr; bool dgates_il = false; unsigned long long* dc_bxbuf = nullptr; size_t dc_bxbytes = 0; float* dc_pbuf = nullptr;   // decoder cluster kernel (dec_cluster.hip)
+  unsigned long long *dc_xbuf = nullptr, *dc_xtab = nullptr; size_t dc_xbytes = 0, dc_tbytes = 0; aocr::bf16_t* ctxa_b = nullptr; bool dgates_il = false; unsigned long long* dc_bxbuf = nullptr; size_t dc_bxbytes = 0; float* dc_pbuf = nullptr;
+  // nn.Dropout (LSTM.lua:68-69,116-118), training only: p, threshold ceil(p 2^53), seed, train-step counter; masked copies of the
+  // inputs of the layers above the first (decoder per step: dhm, encoder per layer: ehm)
+  double drop_p = 0.0; unsigned long long drop_thr = 0, drop_seed = 0, drop_step = 0; bool drop_on = false;
+  float* dhm[aocr::MAXL] = {}; aocr::bf16_t* dhm_b[aocr::MAXL] = {}; float* ehm[2][aocr::MAXL] = {}; aocr::bf16_t* ehm_b[2][aocr::MAXL] = {};   // decoder cluster kernel (dec_cluster.hip)
   aocr::CommState comm;
   // per-family HIP-event profile (aocr_profile_enable): a mark = "family `tag` runs from here to the next mark"
   bool prof_on = false;

@@ -172,6 +172,8 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
       m->dc_pbuf = a.get<float>(dec_cluster_pbuf_bytes((int)B) / 4);
     }
   }
+  for (int l = 0; l + 1 < m->Ld; ++l) { m->dhm[l] = a.get<float>(L * B * Hd); m->dhm_b[l] = m->bf16 ? a.get<bf16_t>(L * B * Hd) : nullptr; }
+  for (int dir = 0; dir < 2; ++dir) for (int l = 0; l + 1 < m->Le; ++l) { m->ehm[dir][l] = a.get<float>(T * B * He); m->ehm_b[dir][l] = m->bf16 ? a.get<bf16_t>(T * B * He) : nullptr; }
   m->shadow_dev = m->bf16 ? a.get<ShadowJob>(128) : nullptr;
   m->ws_bytes = a.off + 256;
   if (base && a.off > bytes) return -1;
@@ -402,6 +404,15 @@ static unsigned next_epoch(aocr_model* m) {
   return m->cl_epoch;
 }
 
+// Dropout site codes (stream = 64 * train step + site): decoder layer L's input 2..4, attention output 16, encoder fw / bw layer L's input 32 + L / 48 + L
+static DropSpec drop_site(const aocr_model* m, int site, long long off) {
+  DropSpec d;
+  if (!m->drop_on) return d;
+  const unsigned long long stream = m->drop_step * 64ull + (unsigned long long)site;
+  d.base = splitmix64_(m->drop_seed ^ (stream * 0xD1342543DE82EF95ull)); d.thr = m->drop_thr; d.scale = (float)(1.0 / (1.0 - m->drop_p)); d.off = off;
+  return d;
+}
+
 void encoder_forward(aocr_model* m, const Dims& d) {
   hipStream_t s = m->s; const bool bf = m->bf16;
   const int B = d.B, T = d.T, He = m->He, Hd = m->Hd;
@@ -413,6 +424,10 @@ void encoder_forward(aocr_model* m, const Dims& d) {
       const float* xin = l == 0 ? m->X : m->ehs[dir][l - 1] + slot;        // Dropout(0) = identity (S6)
       const bf16_t* xinb = l == 0 ? m->Xb : (m->ehs_b[dir][l - 1] ? m->ehs_b[dir][l - 1] + slot : nullptr);
       prof_mark(m, AOCR_PROF_RNN_GEMM);
+      if (l > 0 && m->drop_on) {                                           // LSTM.lua:68-69: x = Dropout(h of the layer below)
+        dropout_apply(s, xin, m->ehm[dir][l - 1], m->ehm_b[dir][l - 1], (int64_t)T * B * He, drop_site(m, (dir ? 48 : 32) + l + 1, 0));
+        xin = m->ehm[dir][l - 1]; xinb = m->ehm_b[dir][l - 1];
+      }
       if (bf && xinb && p.swi.wb && p.in % 32 == 0)
         gemm_hh(s, xinb, p.in, p.swi.wb, p.in, m->ezx[dir][l], 4 * He, T * B, 4 * He, p.in, p.bi, p.bh, 0);
       else
@@ -553,6 +568,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       const bf16_t* dzb = m->edz_b[dir][l];
       const bf16_t* xinb = l == 0 ? m->Xb : (m->ehs_b[dir][l - 1] ? m->ehs_b[dir][l - 1] + slot : nullptr);
       const bf16_t* hprevb = m->ehs_b[dir][l] ? m->ehs_b[dir][l] + (dir == 0 ? 0 : 2 * slot) : nullptr;
+      if (l > 0 && m->drop_on) { xin = m->ehm[dir][l - 1]; xinb = m->ehm_b[dir][l - 1]; }          // the layer saw the masked input
       wg[nwg++] = WGradProblem{dz, 4 * He, xin, p.in, p.dwi, p.in, 4 * He, p.in, T * B, dzb, xinb};
       wg[nwg++] = WGradProblem{dz, 4 * He, hprev, He, p.dwh, He, 4 * He, He, T * B, dzb, hprevb};
       if (!cluster) colsum_accum(s, dz, 4 * He, (int64_t)T * B, 4 * He, p.dbi, p.dbh);        // both biases see the same d z (LSTM.lua:79-88); the cluster kernel sums them itself
@@ -561,6 +577,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       if (bf && dzb && p.swi.wtb) gemm_hh(s, dzb, 4 * He, p.swi.wtb, 4 * He, dxo, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dxf);
       else if (p.swi.wtf) gemm(s, bf, dz, 4 * He, true, p.swi.wtf, 4 * He, true, dxo, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dxf);
       else gemm(s, bf, dz, 4 * He, true, p.wi, p.in, false, dxo, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dxf);
+      if (l > 0 && m->drop_on) dropout_apply(s, dxo, dxo, nullptr, (int64_t)T * B * He, drop_site(m, (dir ? 48 : 32) + l + 1, 0));     // Dropout backward
     }
     grouped_wgrad(s, bf, wg, nwg);
   }
@@ -579,6 +596,9 @@ struct DecStepIO {
   // bf16 shadows (teacher-forced path in bf16 mode; nullptr otherwise)
   const bf16_t* feed_b = nullptr; const bf16_t* hb_prev[MAXL] = {nullptr, nullptr, nullptr, nullptr};
   bf16_t* hb_new[MAXL] = {nullptr, nullptr, nullptr, nullptr}; bf16_t* cat_b = nullptr; bf16_t* out_b = nullptr;
+  // dropout (training): masked copies of h_new[l] for the layer above, and the mask of the attention output
+  float* hm_new[MAXL] = {nullptr, nullptr, nullptr, nullptr}; bf16_t* hmb_new[MAXL] = {nullptr, nullptr, nullptr, nullptr};
+  DropSpec drop_h[MAXL]; DropSpec drop_out;
 };
 
 // one decoder clone forward, LSTM.lua:18-122: LSTM layers, then attention (LSTM.lua:124-162).
@@ -596,8 +616,10 @@ static void dec_step_forward(aocr_model* m, const DecStepIO& io, int T) {
       } else { la = make_loadk(io.h_prev[0], Hd, R, Hd); w0 = &p.swh; lah = make_loadkh(sh ? io.hb_prev[0] : nullptr, Hd, R, Hd); }
       e.zx = io.zx1; e.ldzx = 4 * Hd; e.b1 = nullptr; e.b2 = nullptr; e.zx_tok = io.zx_tok; e.zx_tok_stride = io.zx_tok_stride;
     } else {
-      la = make_loadk2(io.h_new[l - 1], Hd, Hd, io.h_prev[l], Hd, Hd, R); w0 = &p.swi; w1 = &p.swh;
-      lah = make_loadkh2(sh ? io.hb_new[l - 1] : nullptr, Hd, Hd, io.hb_prev[l], Hd, Hd, R);
+      const float* xl = io.hm_new[l - 1] ? io.hm_new[l - 1] : io.h_new[l - 1];        // LSTM.lua:68-69: Dropout on the input of the layers above the first
+      const bf16_t* xlb = io.hm_new[l - 1] ? io.hmb_new[l - 1] : io.hb_new[l - 1];
+      la = make_loadk2(xl, Hd, Hd, io.h_prev[l], Hd, Hd, R); w0 = &p.swi; w1 = &p.swh;
+      lah = make_loadkh2(sh ? xlb : nullptr, Hd, Hd, io.hb_prev[l], Hd, Hd, R);
       e.zx = nullptr; e.ldzx = 0; e.b1 = p.bi; e.b2 = p.bh;
     }
     e.c_prev = io.c_prev[l]; e.ldcp = Hd; e.c_out = io.c_new[l]; e.ldc = Hd; e.h_out = io.h_new[l]; e.ldh = Hd;
@@ -605,6 +627,7 @@ static void dec_step_forward(aocr_model* m, const DecStepIO& io, int T) {
     e.h_out2 = top ? io.cat + Hd : nullptr; e.ldh2 = 2 * Hd;                         // JoinTable [c ; h_top], LSTM.lua:153
     e.gates = io.gates[l]; e.ldg = 4 * Hd; e.M = R; e.H = Hd;
     if (sh) { e.hb = io.hb_new[l]; e.ldhb = Hd; if (top) { e.hb2 = io.cat_b + Hd; e.ldhb2 = 2 * Hd; } }
+    if (!top && io.hm_new[l]) { e.h_out2 = io.hm_new[l]; e.ldh2 = Hd; e.hb2 = sh ? io.hmb_new[l] : nullptr; e.ldhb2 = Hd; e.drop = io.drop_h[l]; }
     run_gates_fwd(m, 1, &la, &w0, &w1, &e, R, Hd, &lah);
   }
   {
@@ -613,7 +636,7 @@ static void dec_step_forward(aocr_model* m, const DecStepIO& io, int T) {
     run_store_nt(m, make_loadk(io.h_new[m->Ld - 1], Hd, R, Hd), m->swa, make_store(io.q, Hd, R, Hd), R, &qa);      // q = W_a h_top, LSTM.lua:131
     attention_forward(s, m->context, io.q, io.a, io.cat, 2 * Hd, R, T, Hd, io.ctx_div, io.cat_b, 2 * Hd, m->context_b);
     EpStore eo = make_store(io.out, Hd, R, Hd, nullptr, nullptr, EP_TANH);
-    eo.Cb = io.out_b; eo.ldcb = Hd;
+    eo.Cb = io.out_b; eo.ldcb = Hd; eo.drop = io.drop_out;                            // LSTM.lua:116-118
     LoadKh2 ca = make_loadkh(sh ? io.cat_b : nullptr, 2 * Hd, R, 2 * Hd);
     run_store_nt(m, make_loadk(io.cat, 2 * Hd, R, 2 * Hd), m->swc, eo, R, &ca);                                       // LSTM.lua:155
   }
@@ -681,7 +704,8 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
   prof_mark(m, AOCR_PROF_DEC_FWD);
   dec_init_state(m, d, c0, h0, m->out_all, B, sh);
   m->dgates_il = false;
-  if (sh && dec_cluster_ok(m, T, L)) {
+  const bool drop = keep_gates && m->drop_on;                       // training only
+  if (sh && !drop && dec_cluster_ok(m, T, L)) {
     // scores against the pre-multiplied context: ctx[t] . (W_a h) = (ctx W_a)[t] . h, LSTM.lua:131-137
     gemm_hh_shadow(s, m->context_b, Hd, m->swa.wtb, Hd, m->dctx, Hd, m->ctxa_b, Hd, B * T, Hd, Hd);
     DecClFwdArgs a; a.B = B; a.T = T; a.L = L; a.epoch = next_epoch(m);
@@ -708,6 +732,13 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
     if (sh) {
       io.feed_b = m->out_b + (size_t)t * slot; io.out_b = m->out_b + (size_t)(t + 1) * slot; io.cat_b = m->cat_b + (size_t)t * B * 2 * Hd;
       for (int l = 0; l < m->Ld; ++l) { io.hb_prev[l] = m->dhs_b[l] + (size_t)t * slot; io.hb_new[l] = m->dhs_b[l] + (size_t)(t + 1) * slot; }
+    }
+    if (drop) {
+      for (int l = 0; l + 1 < m->Ld; ++l) {
+        io.hm_new[l] = m->dhm[l] + (size_t)t * slot; io.hmb_new[l] = sh ? m->dhm_b[l] + (size_t)t * slot : nullptr;
+        io.drop_h[l] = drop_site(m, l + 2, (long long)t * (long long)slot);
+      }
+      io.drop_out = drop_site(m, 16, (long long)t * (long long)slot);
     }
     dec_step_forward(m, io, T);
   }
@@ -756,8 +787,9 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
     // d(prev attention output) of step t+1 already wrote dpre(t) through its epilogue (see the grouped launch below).
     const bool sh = m->bf16 && m->dpre_b != nullptr;
     if (!m->cfg.input_feed || last || !feed_fused)
-      dpre_tanh(s, m->dout_proj + (size_t)t * slot, (m->cfg.input_feed && !last) ? m->dfeed : nullptr, out_t, dpre, (int64_t)slot,
-                sh ? m->dpre_b + (size_t)t * slot : nullptr);
+      { const DropSpec dsp = drop_site(m, 16, (long long)t * (long long)slot);
+        dpre_tanh(s, m->dout_proj + (size_t)t * slot, (m->cfg.input_feed && !last) ? m->dfeed : nullptr, out_t, dpre, (int64_t)slot,
+                  sh ? m->dpre_b + (size_t)t * slot : nullptr, &dsp); }
     LoadKh2 dpa = make_loadkh(sh ? m->dpre_b + (size_t)t * slot : nullptr, Hd, B, Hd);
     run_store_nn(m, make_loadk(dpre, Hd, B, Hd), m->swc, make_store(dcat, 2 * Hd, B, 2 * Hd), B, &dpa);      // d[c ; h_top] = dpre W_c
     attention_backward(s, m->context, m->q_all + (size_t)t * slot, m->a_all + (size_t)t * B * T, dcat, 2 * Hd,
@@ -777,6 +809,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
       e.dh2 = m->dh_rec[l]; e.ld2 = Hd;
       e.dc_in = m->dc_st[l]; e.lddc = Hd;
       e.gates = m->dgates[l] + (size_t)t * B * 4 * Hd; e.ldg = 4 * Hd; e.gil = m->dgates_il;
+      if (l < Ld - 1) e.drop = drop_site(m, l + 2, (long long)t * (long long)slot);            // the layer above read Dropout(h_l)
       e.c_prev = m->dcs[l] + (size_t)t * slot; e.ldcp = Hd; e.c = m->dcs[l] + (size_t)(t + 1) * slot; e.ldcc = Hd;
       e.dz = m->ddz[l] + (size_t)t * B * 4 * Hd; e.lddz = 4 * Hd; e.dc_out = m->dc_st[l]; e.lddco = Hd; e.M = B; e.H = Hd;
       if (sh) { e.dzb = m->ddz_b[l] + (size_t)t * B * 4 * Hd; e.lddzb = 4 * Hd; }
@@ -799,6 +832,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
         if (t > 0) {                                      // writes dpre(t-1) = (dout_proj(t-1) + this product) * (1 - out(t-1)^2) directly
           gep[n] = make_store(m->dpre_all + (size_t)(t - 1) * slot, Hd, B, Hd);
           gep[n].dg = m->dout_proj + (size_t)(t - 1) * slot; gep[n].dout = m->out_all + (size_t)t * slot; gep[n].ldd = Hd;
+          gep[n].drop = drop_site(m, 16, (long long)(t - 1) * (long long)slot);
           if (sh) { gep[n].Cb = m->dpre_b + (size_t)(t - 1) * slot; gep[n].ldcb = Hd; }
         } else gep[n] = make_store(m->dfeed, Hd, B, Hd);  // step 0: nothing consumes it
         ++n;
@@ -835,7 +869,8 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
       gemm(s, bf, dz, 4 * Hd, true, p.wi, p.in, false, m->demb_all, E, rows, E, 4 * Hd, nullptr, nullptr, EP_ATOMIC);
       embedding_scatter_accum(s, m->demb_all, tgt, 1, L, m->dlookup, L, B, E, V);
     } else {
-      wg[nwg++] = WGradProblem{dz, 4 * Hd, m->dhs[l - 1] + slot, Hd, p.dwi, Hd, 4 * Hd, Hd, rows, dzb, sh ? m->dhs_b[l - 1] + slot : nullptr};
+      if (m->drop_on) wg[nwg++] = WGradProblem{dz, 4 * Hd, m->dhm[l - 1], Hd, p.dwi, Hd, 4 * Hd, Hd, rows, dzb, sh ? m->dhm_b[l - 1] : nullptr};      // the layer saw Dropout(h)
+      else wg[nwg++] = WGradProblem{dz, 4 * Hd, m->dhs[l - 1] + slot, Hd, p.dwi, Hd, 4 * Hd, Hd, rows, dzb, sh ? m->dhs_b[l - 1] + slot : nullptr};
     }
   }
   grouped_wgrad(s, bf, wg, nwg);

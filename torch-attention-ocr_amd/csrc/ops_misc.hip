@@ -1146,17 +1146,29 @@ void embedding_scatter_accum(hipStream_t s, const float* demb, const int32_t* to
 }
 
 __global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
-                                                   const float* __restrict__ out, float* __restrict__ dpre, int64_t n, bf16_t* __restrict__ dpreb) {
+                                                   const float* __restrict__ out, float* __restrict__ dpre, int64_t n, bf16_t* __restrict__ dpreb, DropSpec drop) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float g = g1[i] + (g2 ? g2[i] : 0.f);
   float o = out[i];
+  if (drop.on()) { const float mk = drop.mask(i); o = mk != 0.f ? o / mk : 0.f; g *= mk; }      // out holds the masked value: tanh' needs the unmasked one
   const float v = g * (1.f - o * o);
   dpre[i] = v;
   if (dpreb) dpreb[i] = (bf16_t)v;
 }
-void dpre_tanh(hipStream_t s, const float* g1, const float* g2, const float* out, float* dpre, int64_t n, bf16_t* dpreb) {
-  hipLaunchKernelGGL(dpre_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, g1, g2, out, dpre, n, dpreb);
+void dpre_tanh(hipStream_t s, const float* g1, const float* g2, const float* out, float* dpre, int64_t n, bf16_t* dpreb, const DropSpec* drop) {
+  hipLaunchKernelGGL(dpre_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, g1, g2, out, dpre, n, dpreb, drop ? *drop : DropSpec{});
+}
+// dropout of a whole buffer (encoder layers above the first): dst = mask * src (+ bf16 copy); in place for the backward scaling
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ src, float* __restrict__ dst, bf16_t* __restrict__ dstb, int64_t n, DropSpec drop) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = src[i] * drop.mask(i);
+  if (dst) dst[i] = v;
+  if (dstb) dstb[i] = (bf16_t)v;
+}
+void dropout_apply(hipStream_t s, const float* src, float* dst, bf16_t* dstb, int64_t n, const DropSpec& drop) {
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, src, dst, dstb, n, drop);
 }
 // several small regions zeroed by ONE launch (each hipMemsetAsync is its own ~5 us dispatch on the step's critical path)
 __global__ __launch_bounds__(256) void zero_many_kernel(ZeroList z) {
