@@ -329,6 +329,9 @@ function model:step(batch, forward_only, beam_size, trie)
     local L = A.lib
     if not forward_only then
         -- feval with training-mode BatchNorm (model.lua:276-278), then optim.sgd_list: clip each of the 5 groups to 5, x -= lr * g
+        if self.dropout and self.dropout > 0 then      -- LSTM.lua:68-69,116-118: masks = f(seed, global_step, site, element), include/aocr.h
+            A.check(L.aocr_set_dropout(self.handle, self.dropout, (cutorch._seed or 910820), self.global_step), 'aocr_set_dropout')
+        end
         A.check(L.aocr_train_forward_backward(self.handle, self.images_dev:as('float*'), self.targets_dev:as('int32_t*'),
                                               self.targets_eval_dev:as('int32_t*'), batch_size, W, target_l,
                                               1.0 / (batch_size * self.world), self.scal_dev:as('float*')), 'aocr_train_forward_backward')
