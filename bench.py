@@ -188,6 +188,7 @@ def main():
         el = float(t.item())
     per_step = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)])
     loss_val = float(loss.item())
+    m.check_health()                                    # a whole-sequence kernel that gave up waiting for its group would invalidate the timed steps
     lines_per_s = global_B * args.steps / el
     # ---- steady state: keep the GPU busy long enough for an external sampler, report it separately (never `value`)
     sustained = None
@@ -199,6 +200,7 @@ def main():
         sync()
         es = time.perf_counter() - t0
         sustained = {"steps": n, "seconds": es, "ms_per_step": 1e3 * es / n, "image_lines_per_s": global_B * n / es}
+        m.check_health()
     replica_drift = None
     if world > 1:                                       # every rank must hold the same parameters after the timed steps
         cs = m.params.double().abs().sum().reshape(1)

@@ -79,6 +79,11 @@ int aocr_model_set_stream(aocr_model* m, void* stream);
 
 /* ---- fused sequence-level entry points (what Model:step uses) */
 
+/* Health of the whole-sequence ("cluster") kernels: the compute units that share a block of batch rows wait for each other with BOUNDED
+ * spins; if a wait ever times out (it cannot unless another kernel keeps part of the chip busy for ~0.3 s) the kernel records a code,
+ * finishes, and the step's results are invalid.  *code = 0: healthy.  Synchronises the model's stream.  No reference counterpart. */
+int aocr_cluster_status(aocr_model* m, int32_t* code);
+
 /* nn.Dropout(p) of LSTM.lua:68-69 (input of every LSTM layer above the first, encoder and decoder) and :116-118 (attention output),
  * active in the training step only (model.lua:284 `training()`; decode / forward_only run `evaluate()`).  The mask is a counter-based
  * function of (seed, train_step, site, element index) -- splitmix64, restated in oracle/oracle_torch.py::dropout_mask -- so a step is

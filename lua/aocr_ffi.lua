@@ -41,6 +41,7 @@ int aocr_model_create(const aocr_config* cfg, float* params_dev, float* grads_de
 int aocr_model_destroy(aocr_model* m);
 int aocr_model_set_stream(aocr_model* m, void* stream);
 int aocr_set_dropout(aocr_model* m, double p, uint64_t seed, uint64_t train_step);
+int aocr_cluster_status(aocr_model* m, int32_t* code);
 int aocr_train_forward_backward(aocr_model* m, const float* images_dev, const int32_t* targets_dev, const int32_t* targets_eval_dev, int32_t B, int32_t W, int32_t L, float grad_scale, float* loss_dev);
 int aocr_sgd_step(aocr_model* m, float lr, float clip, float* norms_dev);
 int aocr_decode_dict(aocr_model* m, const float* images_dev, const int32_t* targets_dev, const int32_t* targets_eval_dev, int32_t B, int32_t W, int32_t L, int32_t beam, const aocr_trie* trie, int32_t* labels_dev, float* scores_dev, float* gold_scores_dev, float* loss_dev);

@@ -62,6 +62,7 @@ SIGNATURES = {
     "aocr_model_set_stream": (C.c_int, [_vp, _vp]),
     "aocr_train_forward_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "aocr_set_dropout": (C.c_int, [_vp, C.c_double, C.c_uint64, C.c_uint64]),
+    "aocr_cluster_status": (C.c_int, [_vp, C.POINTER(_i32)]),
     "aocr_grad_buckets": (C.c_int, [_cfgp, C.POINTER(_i64), C.POINTER(_i64)]),
     "aocr_stream_wait_grads": (C.c_int, [_vp, _i32, _vp]),
     "aocr_comm_unique_id": (C.c_int, [C.c_char_p]),

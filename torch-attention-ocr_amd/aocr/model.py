@@ -388,7 +388,9 @@ class Model:
                 torch.distributed.all_reduce(cnt)
                 global_batch, num_nonzeros = int(cnt[0].item()), int(cnt[1].item())
             loss_dev = self.train_step_device(images, targets, targets_eval, global_batch)
-            return float(loss_dev.item()), [num_nonzeros, 0.0]
+            loss = float(loss_dev.item())
+            self.check_health()
+            return loss, [num_nonzeros, 0.0]
         # forward only: beam search + gold pass
         beam_size = beam_size or 1
         beam_size = min(beam_size, self.target_vocab_size)
@@ -413,7 +415,9 @@ class Model:
                 self.visualize_file.write("%s\t%s\t%s\t%f\t%f\n" % (img_paths[i], labels_gold[i], labels_pred[i],
                                                                     self._dec_out.scores[i], self._dec_out.gold_scores[i]))
             self.visualize_file.flush()
-        return float(loss_dev.item()), [num_nonzeros, accuracy]
+        loss = float(loss_dev.item())
+        self.check_health()
+        return loss, [num_nonzeros, accuracy]
 
     def forward_logits(self, batch, training=False):
         """Teacher-forced decoder logits (L,B,V) and NLL sum (parity tap; the pre-LogSoftMax output of output_projector.lua:5)."""
@@ -437,6 +441,13 @@ class Model:
                                               (1.0 / B) if grad_scale is None else grad_scale, ptr(self._scal[0:1])),
               "aocr_train_forward_backward")
         return float(self._scal[0].item())
+
+    def check_health(self):
+        """Raises if a whole-sequence kernel ever gave up waiting for its group (include/aocr.h: aocr_cluster_status); synchronises."""
+        code = C.c_int32(0)
+        check(lib.aocr_cluster_status(self._h, C.byref(code)), "aocr_cluster_status")
+        if code.value != 0:
+            raise RuntimeError(f"a cluster kernel timed out waiting for its group (code {code.value}): the results of that step are invalid")
 
     def _arm_dropout(self):
         """nn.Dropout(p) of LSTM.lua:68-69,116-118 for the coming training step (rank-dependent seed under data parallelism)."""

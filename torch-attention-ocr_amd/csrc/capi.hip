@@ -209,6 +209,15 @@ static int step_dims(aocr_model* m, int32_t B, int32_t W, int32_t L, Dims& d) {
   return 0;
 }
 
+int aocr_cluster_status(aocr_model* m, int32_t* code) {
+  REQUIRE(m && code, "NULL argument");
+  *code = 0;
+  if (!m->cl_err) return 0;
+  if (hipMemcpyAsync(code, m->cl_err, sizeof(int32_t), hipMemcpyDeviceToHost, m->s) != hipSuccess || hipStreamSynchronize(m->s) != hipSuccess)
+    return fail("aocr_cluster_status: %s", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
+
 int aocr_set_dropout(aocr_model* m, double p, uint64_t seed, uint64_t train_step) {
   REQUIRE(m, "NULL model");
   REQUIRE(p >= 0.0 && p < 1.0, "dropout p=%g outside [0, 1)", p);

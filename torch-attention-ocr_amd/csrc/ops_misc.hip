@@ -948,29 +948,54 @@ void attention_backward(hipStream_t s, const float* ctx, const float* q, const f
 }
 
 // d(ctx)[b,t,j] = sum_l a[l,b,t]*dc[l,b,j] + ds[l,b,t]*q[l,b,j]  (model.lua:652-653 accumulated over the decoder loop)
+// One workgroup per (batch row, 64 columns): the L rows of d c and q for those columns and a 64-step chunk of a / d s are staged once in
+// LDS (the first form had every thread walk all L rows of d c and q from L2: 1.6 GB of L2 traffic per call at C3 for 60 MB of data).
+constexpr int DCTX_L = 32;                                      // decoder steps per pass (accumulators persist over the passes)
 __global__ __launch_bounds__(256) void attn_dctx_kernel(const float* __restrict__ a_all, const float* __restrict__ ds_all,
                                                         const float* __restrict__ dc_all, int64_t lddc,
                                                         const float* __restrict__ q_all, float* __restrict__ dctx, int L, int B,
                                                         int T, int Hd) {
-  const int H4 = Hd >> 2;
-  const int64_t total = (int64_t)B * T * H4;
-  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
-    int j = (int)(id % H4) * 4; int64_t bt = id / H4; int t = (int)(bt % T); int b = (int)(bt / T);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int l = L - 1; l >= 0; --l) {                          // same order as the reference's t = L..1 loop
-      float av = a_all[((int64_t)l * B + b) * T + t], dv = ds_all[((int64_t)l * B + b) * T + t];
-      float4 dc = *reinterpret_cast<const float4*>(dc_all + ((int64_t)l * B + b) * lddc + j);
-      float4 qv = *reinterpret_cast<const float4*>(q_all + ((int64_t)l * B + b) * Hd + j);
-      acc.x += av * dc.x + dv * qv.x; acc.y += av * dc.y + dv * qv.y; acc.z += av * dc.z + dv * qv.z; acc.w += av * dc.w + dv * qv.w;
+  __shared__ __attribute__((aligned(16))) float s_dc[DCTX_L][64], s_q[DCTX_L][64], s_a[DCTX_L][64], s_ds[DCTX_L][64];
+  const int b = blockIdx.y, j0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int jq = tid & 15, ts = tid >> 4;                       // thread -> columns j0 + 4 jq .. + 3, steps ts, ts + 16, ts + 32, ts + 48 of a chunk
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    float4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l1 = L; l1 > 0; l1 -= DCTX_L) {                    // passes from the last decoder step down: the reference's t = L..1 order
+      const int l0 = max(l1 - DCTX_L, 0), nl = l1 - l0;
+      __syncthreads();
+      for (int i = tid; i < nl * 16; i += 256) {
+        const int l = i >> 4, c = (i & 15) * 4;
+        const bool in = j0 + c < Hd;                            // (Hd is a multiple of 32: the last block of columns may be half empty)
+        *reinterpret_cast<float4*>(&s_dc[l][c]) = in ? *reinterpret_cast<const float4*>(dc_all + ((int64_t)(l0 + l) * B + b) * lddc + j0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&s_q[l][c]) = in ? *reinterpret_cast<const float4*>(q_all + ((int64_t)(l0 + l) * B + b) * Hd + j0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      for (int i = tid; i < nl * 64; i += 256) {
+        const int l = i >> 6, t = t0 + (i & 63);
+        s_a[l][i & 63] = t < T ? a_all[((int64_t)(l0 + l) * B + b) * T + t] : 0.f;
+        s_ds[l][i & 63] = t < T ? ds_all[((int64_t)(l0 + l) * B + b) * T + t] : 0.f;
+      }
+      __syncthreads();
+      for (int l = nl - 1; l >= 0; --l) {
+        const float4 dc = *reinterpret_cast<const float4*>(&s_dc[l][4 * jq]), qv = *reinterpret_cast<const float4*>(&s_q[l][4 * jq]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float av = s_a[l][ts + 16 * k], dv = s_ds[l][ts + 16 * k];
+          acc[k].x += av * dc.x + dv * qv.x; acc[k].y += av * dc.y + dv * qv.y; acc[k].z += av * dc.z + dv * qv.z; acc[k].w += av * dc.w + dv * qv.w;
+        }
+      }
     }
-    *reinterpret_cast<float4*>(dctx + ((int64_t)b * T + t) * Hd + j) = acc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = t0 + ts + 16 * k;
+      if (t < T && j0 + 4 * jq < Hd) *reinterpret_cast<float4*>(dctx + ((int64_t)b * T + t) * Hd + j0 + 4 * jq) = acc[k];
+    }
   }
 }
 void attention_dctx(hipStream_t s, const float* a_all, const float* ds_all, const float* dc_all, int64_t lddc, const float* q_all,
                     float* dctx, int L, int B, int T, int Hd) {
-  int64_t total = (int64_t)B * T * (Hd / 4);
-  int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
-  hipLaunchKernelGGL(attn_dctx_kernel, dim3(blocks), dim3(256), 0, s, a_all, ds_all, dc_all, lddc, q_all, dctx, L, B, T, Hd);
+  hipLaunchKernelGGL(attn_dctx_kernel, dim3((Hd + 63) / 64, B), dim3(256), 0, s, a_all, ds_all, dc_all, lddc, q_all, dctx, L, B, T, Hd);
 }
 
 // =============================================================================================
