@@ -23,7 +23,9 @@ __device__ __forceinline__ float tanhf_(float x) {
 // nn.Dropout (LSTM.lua:68-69 on the input of every layer above the first, :116-118 on the attention output): counter-based mask, the
 // same function as oracle_torch.dropout_mask -- keep(idx) = (splitmix64(base + idx) >> 11) >= thr with base = splitmix64(seed ^
 // stream * 0xD1342543DE82EF95), stream = 64 * train step + site, thr = ceil(p * 2^53); kept values are scaled by 1 / (1 - p).
-// idx = the element's flat offset in its [time][batch][hidden] buffer.  thr == 0: no dropout.
+// idx = the element's flat offset in its [time][batch][hidden] buffer.  thr == 0: no dropout.  (Kept OUT of EpStore: that struct travels by
+// value in the grouped launches' argument arrays, and 40 more bytes made the compiler copy the selected problem to scratch -- the
+// grouped weight-gradient kernel went from 128 to 732 us.)
 __host__ __device__ __forceinline__ unsigned long long splitmix64_(unsigned long long x) {
   x += 0x9E3779B97F4A7C15ull;
   unsigned long long z = x;
@@ -46,7 +48,6 @@ struct EpStore {
   bf16_t* Cb = nullptr; int64_t ldcb = 0; // optional bf16 shadow of C (plain stores only)
   // optional tanh-backward fusion (decoder BPTT, model.lua:649,654-657): x <- (x + dg[m][n]) * (1 - dout[m][n]^2)
   const float* dg = nullptr; const float* dout = nullptr; int64_t ldd = 0;
-  DropSpec drop;                          // dropout of the attention output: forward (with EP_TANH: x <- mask * tanh(x), idx = row * N + col) and, with dg, its backward
   template <int NT> __device__ __forceinline__ void quad(int m, int n, int nstep, const float (&v)[NT][4]) const {
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
@@ -63,12 +64,8 @@ struct EpStore {
         if (row >= M) continue;
         float x = v[ni][i] + bb;
         if (flags & EP_RELU) x = fmaxf(x, 0.f);
-        if (flags & EP_TANH) { x = tanhf_(x); if (drop.on()) x *= drop.mask((long long)row * N + col); }
-        if (dg) {
-          float o = dout[(int64_t)row * ldd + col];
-          if (drop.on()) { const float mk = drop.mask((long long)row * ldd + col); o = mk != 0.f ? o / mk : 0.f; x = (x + dg[(int64_t)row * ldd + col]) * mk * (1.f - o * o); }
-          else x = (x + dg[(int64_t)row * ldd + col]) * (1.f - o * o);
-        }
+        if (flags & EP_TANH) x = tanhf_(x);
+        if (dg) { const float o = dout[(int64_t)row * ldd + col]; x = (x + dg[(int64_t)row * ldd + col]) * (1.f - o * o); }
         float* p = base + (int64_t)row * ld + cc;
         if (flags & EP_ATOMIC) atomicAdd(p, x);
         else if (flags & EP_ACCUM) *p += x;
@@ -90,12 +87,8 @@ struct EpStore {
       if (bias) x += bias[col];
       if (bias2) x += bias2[col];
       if (flags & EP_RELU) x = fmaxf(x, 0.f);
-      if (flags & EP_TANH) { x = tanhf_(x); if (drop.on()) x *= drop.mask((long long)row * N + col); }
-      if (dg) {
-        float o = dout[(int64_t)row * ldd + col];
-        if (drop.on()) { const float mk = drop.mask((long long)row * ldd + col); o = mk != 0.f ? o / mk : 0.f; x = (x + dg[(int64_t)row * ldd + col]) * mk * (1.f - o * o); }
-        else x = (x + dg[(int64_t)row * ldd + col]) * (1.f - o * o);
-      }
+      if (flags & EP_TANH) x = tanhf_(x);
+      if (dg) { const float o = dout[(int64_t)row * ldd + col]; x = (x + dg[(int64_t)row * ldd + col]) * (1.f - o * o); }
       float* p = (C1 && col >= N0) ? C1 + (int64_t)row * ldc1 + (col - N0) : C + (int64_t)row * ldc + col;
       if (flags & EP_ATOMIC) atomicAdd(p, x);
       else if (flags & EP_ACCUM) *p += x;

@@ -636,9 +636,10 @@ static void dec_step_forward(aocr_model* m, const DecStepIO& io, int T) {
     run_store_nt(m, make_loadk(io.h_new[m->Ld - 1], Hd, R, Hd), m->swa, make_store(io.q, Hd, R, Hd), R, &qa);      // q = W_a h_top, LSTM.lua:131
     attention_forward(s, m->context, io.q, io.a, io.cat, 2 * Hd, R, T, Hd, io.ctx_div, io.cat_b, 2 * Hd, m->context_b);
     EpStore eo = make_store(io.out, Hd, R, Hd, nullptr, nullptr, EP_TANH);
-    eo.Cb = io.out_b; eo.ldcb = Hd; eo.drop = io.drop_out;                            // LSTM.lua:116-118
+    eo.Cb = io.out_b; eo.ldcb = Hd;
     LoadKh2 ca = make_loadkh(sh ? io.cat_b : nullptr, 2 * Hd, R, 2 * Hd);
     run_store_nt(m, make_loadk(io.cat, 2 * Hd, R, 2 * Hd), m->swc, eo, R, &ca);                                       // LSTM.lua:155
+    if (io.drop_out.thr != 0) dropout_apply(s, io.out, io.out, io.out_b, (int64_t)R * Hd, io.drop_out);                // LSTM.lua:116-118 (training with p > 0 only)
   }
   (void)E; (void)bf;
 }
@@ -768,7 +769,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   colsum_accum(s, m->dlogits, LOGIT_LD, rows, V, m->dbo);
   prof_mark(m, AOCR_PROF_DEC_BWD);
   { ZeroList zl; for (int l = 0; l < Ld; ++l) { zl.add(m->dh_rec[l], slot * sizeof(float)); zl.add(m->dc_st[l], slot * sizeof(float)); } zero_many(s, zl); }
-  const bool feed_fused = m->cfg.input_feed && Ld <= 2;  // the feed product joins the grouped launch and carries the tanh backward
+  const bool feed_fused = m->cfg.input_feed && Ld <= 2 && !m->drop_on;  // the feed product joins the grouped launch and carries the tanh backward (dropout: the separate d pre kernel knows the mask)
   if (m->dgates_il && dec_cluster_bwd_ok(m, T, L)) {     // the whole loop as one launch (dec_cluster.hip); needs the forward cluster kernel's saved state
     DecClBwdArgs a; a.B = B; a.T = T; a.L = L; a.epoch = next_epoch(m);
     a.w2i_t = m->dec[1].swi.wtb; a.w2h_t = m->dec[1].swh.wtb; a.w1h_t = m->dec[0].swh.wtb; a.w1f_t = m->dec[0].swi.wtb;
@@ -824,7 +825,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
         ga[n] = make_loadk(m->ddz[l] + zo, 4 * Hd, B, 4 * Hd); gah[n] = make_loadkh(sh ? m->ddz_b[l] + zo : nullptr, 4 * Hd, B, 4 * Hd);
         gw[n] = &m->dec[l].swh; gep[n] = make_store(m->dh_rec[l], Hd, B, Hd); ++n;
       }
-      const bool feed_grouped = m->cfg.input_feed && n < 3 && Ld <= 2;
+      const bool feed_grouped = m->cfg.input_feed && n < 3 && Ld <= 2 && !m->drop_on;
       if (feed_grouped) {
         const size_t zo = (size_t)t * B * 4 * Hd;
         ga[n] = make_loadk(m->ddz[0] + zo, 4 * Hd, B, 4 * Hd); gah[n] = make_loadkh(sh ? m->ddz_b[0] + zo : nullptr, 4 * Hd, B, 4 * Hd);
@@ -832,7 +833,6 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
         if (t > 0) {                                      // writes dpre(t-1) = (dout_proj(t-1) + this product) * (1 - out(t-1)^2) directly
           gep[n] = make_store(m->dpre_all + (size_t)(t - 1) * slot, Hd, B, Hd);
           gep[n].dg = m->dout_proj + (size_t)(t - 1) * slot; gep[n].dout = m->out_all + (size_t)t * slot; gep[n].ldd = Hd;
-          gep[n].drop = drop_site(m, 16, (long long)(t - 1) * (long long)slot);
           if (sh) { gep[n].Cb = m->dpre_b + (size_t)(t - 1) * slot; gep[n].ldcb = Hd; }
         } else gep[n] = make_store(m->dfeed, Hd, B, Hd);  // step 0: nothing consumes it
         ++n;
