@@ -1,4 +1,7 @@
-"""Debugging aid: cycles per phase of the decoder cluster kernel (AOCR_DC_STAMPS=1), workgroup 0, summed over the L steps."""
+"""Debugging aid: cycles per phase of the decoder cluster kernels (workgroup 0, summed over the L steps) and a real-time timeline of one
+step of group 0.  Needs a library built with the stamps compiled in:
+    make -C torch-attention-ocr_amd/csrc FLAGS_dec_cluster=-DDC_DEBUG_STAMPS   (touch dec_cluster.hip first)
+The stamps' global stores perturb the kernels (the compiler inserts vmcnt waits around them): trust the proportions, not the totals."""
 import os, sys
 os.environ["AOCR_DC_STAMPS"] = "1"
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))

@@ -1,0 +1,20 @@
+"""Soak test of the whole-sequence (cluster) kernels: many train steps and decode calls back to back, then aocr_cluster_status.
+A group member that ever gave up waiting (bounded spins) would show up as a non-zero code."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "torch-attention-ocr_amd"))
+import torch
+from test_step_gpu import make
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+for (B, W, L) in ((256, 256, 24), (70, 416, 13)):
+    m, O, ocfg, P, st, batch = make(dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True), B=B, W=W, maxlen=L - 1, compute="bf16", max_decoder_l=50, max_beam=1)
+    images, targets, targets_eval = m._upload(batch)
+    m.optim_state["learningRate"] = 1e-4
+    t0 = time.time()
+    for i in range(steps):
+        m.train_step_device(images, targets, targets_eval)
+        if i % 10 == 0:
+            m.decode_device(images, targets, targets_eval, 1)
+    torch.cuda.synchronize(); m.check_health()
+    print(f"B={B} W={W}: {steps} train steps + {steps // 10} decode calls in {time.time() - t0:.1f} s, cluster status 0, loss {float(m._scal[0].item()):.3f}")
+    m.shutdown()
