@@ -1,11 +1,15 @@
 // dec_cluster.hip -- the teacher-forced decoder loop (model.lua:553-568 train, :604-627 gold pass; cell LSTM.lua:18-122, attention
 // LSTM.lua:124-162) as ONE launch for all L steps: a GROUP of 32 compute units (one XCD under round-robin dispatch) owns 32 batch
-// rows, and every recurrent weight the loop needs -- W1 = [W1_i2h(feed part) | W1_h2h], W2 = [W2_i2h | W2_h2h], W_a, W_c: 10 MB in bf16
+// rows, and every recurrent weight the loop needs -- W1 = [W1_i2h(feed part) | W1_h2h], W2 = [W2_i2h | W2_h2h], W_c: 9 MB in bf16
 // at Hd = 512 -- is RESIDENT IN THE REGISTERS of the group (288 VGPRs per lane: member m owns hidden units 16m .. 16m+15 of both
-// layers and output columns 16m .. 16m+15 of W_a / W_c).  The launch chain this replaces runs 5 dependent kernels per step, each of
+// layers and output columns 16m .. 16m+15 of W_c).  The launch chain this replaces runs 5 dependent kernels per step, each of
 // which re-streams its weights through L2 and pays a launch + drain (~8 us each at C3: 0.94 ms for 24 steps).
+// The same file holds the BPTT of the loop (dec_cl_bwd_kernel) and the greedy decode variant (dec_cl_fwd_kernel<true>).
 //
-// Per step, four all-gathers of a 32 x 512 bf16 operand inside the group (8-byte {2 x bf16, tag} granules: rnn_cluster.hip):
+// Per step, four all-gathers of a 32 x 512 bf16 operand inside the group.  The payload of an exchange is the real output tensor
+// (h, [c ; h], out as bf16): every wave stores its piece, waits for the acknowledgement and raises its flag; a reader polls the 128
+// flags of the group (512 bytes) and then loads the operand once (`gather`).  (The first version polled 8-byte {2 x bf16, tag}
+// granules as rnn_cluster.hip does: 64 KB per poll round and CU, bound by the CU's 64 B/clk vector-memory path.)
 //   out(t-1) -> [feed ; h1(t-1)] W1^T + zx1(t) -> gates -> c1, h1          (zx1 = embedding part + biases, hoisted over all L steps)
 //   h1(t)    -> [h1(t) ; h2(t-1)] W2^T + b -> gates -> c2, h2
 //   h2(t)    -> attention of row r on member r (q = W_a h2, which only the backward pass reads, is one GEMM over all L steps after the loop):
@@ -13,8 +17,9 @@
 //   c(t)     -> out = tanh(W_c [c ; h2])
 // Operands live in LDS ([32 rows][512] bf16 x 3 buffers); the weights of a wave are MFMA A fragments (transposed products, as in
 // rnn_cluster.hip), tile rows ordered [unit][gate] so that a lane holds the four gates of one (unit, batch row) cell.
-// Everything the backward pass reads (gates, states, q, a, [c ; h2], out; fp32 + bf16 shadows) is written in the layouts of the
-// launch chain, which stays the fallback (fp32 mode, Hd != 512, other layer counts, no input feed).
+// What the backward pass reads is written for all L steps: gates (interleaved per unit), cell states, a, out in fp32; h and [c ; h2]
+// as bf16 only (every reader takes the bf16 copy).  The launch chain stays the fallback (fp32 mode, Hd != 512, other layer counts,
+// no input feed, dropout > 0, beam > 1) and the parity reference (tests/test_step_gpu.py).
 #include "ops.h"
 #include <algorithm>
 #include <cstdio>
