@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
     if (tid < 32) toks[tid] = p.tok0[(size_t)min(row0 + tid, B - 1) * p.tok0_stride];
   }
   unsigned* const xg = reinterpret_cast<unsigned*>(p.xbuf) + (size_t)group * 5 * NM * 128;      // flags [kind: out, h1, h2, c, logits][reader][member][wave]
-  float score = 0.f; int prev_tok = 0;                              // DEC, wave 0 of the row's owner: running log-probability and last token
+  float score = 0.f; int prev_tok = 0, node = 0;                    // DEC, wave 0 of the row's owner: running log-probability, last token, trie node (-use_dictionary)
   load_rows(p.out_b, row0, B, F, tid); load_rows(p.hsb[0], row0, B, H1, tid); load_rows(p.hsb[1], row0, B, H2, tid);
   __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): nothing of the prologue is in flight inside the loop
   __syncthreads();
@@ -582,10 +582,18 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
           if (olane == 0 && (prev_tok == 1 || prev_tok == 3)) lp = 0.f;          // model.lua:448-449: after PAD / EOS only PAD, at no cost
           lp += score;                                                          // model.lua:450
         }
+        unsigned long long tmask = 0;                                            // -use_dictionary: only tokens that continue the row's trie node (model.lua:413,469)
+        if (p.trie_mask) {
+          tmask = p.trie_mask[node];
+          const bool ok = (t > 0 && olane == 0) || ((tmask >> olane) & 1ull);      // PAD is always admissible after the first step
+          if (olane < V && !ok) lp = -INFINITY;
+        }
         const float best = wave_reduce(lp, -INFINITY, [](float a, float b) { return fmaxf(a, b); });
         const unsigned long long tie = __ballot(lp == best && olane < V);        // descending score, ties -> lowest index
         const int bi = tie ? __ffsll((long long)tie) - 1 : 0;
         score = best; prev_tok = bi + 1;
+        if (p.trie_mask && !(t > 0 && bi == 0) && ((tmask >> bi) & 1ull))        // trie_next: PAD keeps the node (model.lua:502-503)
+          node = p.trie_child[p.trie_base[node] + __popcll(tmask & ((1ull << bi) - 1ull))];
         if (olane == 0) {
           if (rvalid) { p.labels[(size_t)arow * p.tok0_stride + t] = bi + 1; if (t == L - 1) p.scores[arow] = best; }
           pst4(p.tokx + (size_t)group * 32 + member, (unsigned)(bi + 1), local);

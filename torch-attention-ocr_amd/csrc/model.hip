@@ -905,7 +905,7 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
   // The embedding part of the first layer's gate input depends on the token only: one table row per vocabulary entry
   // (lookup W_i2h[:, :E]^T + both biases, LSTM.lua:55-56,79-80), gathered per step instead of a K = 20 GEMM per step.
   gemm(s, bf, m->lookup, E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * Hd, V, 4 * Hd, E, p1.bi, p1.bh, 0);
-  if (k == 1 && !trie && V <= 40 && m->out_b && m->dc_pbuf && !getenv("AOCR_NO_DEC_GREEDY") && dec_cluster_ok(m, T, Lt)) {
+  if (k == 1 && V <= 40 && m->out_b && m->dc_pbuf && !getenv("AOCR_NO_DEC_GREEDY") && dec_cluster_ok(m, T, Lt)) {
     // greedy decode: the whole loop (cell, attention, projector, LogSoftMax, selection) as one launch of the decoder cluster kernel
     float* tc0[MAXL]; float* th0[MAXL];
     for (int l = 0; l < Ld; ++l) { tc0[l] = m->dcs[l]; th0[l] = m->dhs[l]; }
@@ -919,6 +919,7 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
     a.a_all = m->a_all; a.out = m->out_all; a.cat_b = m->cat_b; a.out_b = m->out_b;
     a.xbuf = m->dc_xbuf; a.xtab = m->dc_xtab; a.err = m->cl_err;
     a.tok0 = tgt; a.tok0_stride = Lt; a.wo = m->wo; a.bo = m->bo; a.V = V; a.pbuf = m->dc_pbuf; a.labels = labels; a.scores = scores;
+    if (trie) { a.trie_mask = (const unsigned long long*)trie->child_mask_dev; a.trie_base = trie->child_base_dev; a.trie_child = trie->child_dev; }
     dec_cluster_forward(s, a, true);
     return;
   }

@@ -227,6 +227,7 @@ struct DecClFwdArgs {
   // greedy decode (the kernel's DEC variant): zx1 is the per-token table [V][4 Hd]; tok0 = the GO tokens (row stride tok0_stride = the label width)
   const int32_t* tok0 = nullptr; int tok0_stride = 0; const float *wo = nullptr, *bo = nullptr; int V = 0;
   float* pbuf = nullptr; unsigned* tokx = nullptr; int32_t* labels = nullptr; float* scores = nullptr;
+  const unsigned long long* trie_mask = nullptr; const int32_t* trie_base = nullptr; const int32_t* trie_child = nullptr;   // -use_dictionary (flat trie of include/aocr.h) or null
 };
 // decoder BPTT in one launch (dec_cluster.hip); reads what the forward cluster kernel saved (interleaved gates)
 struct DecClBwdArgs {
