@@ -134,8 +134,15 @@ def main():
     if args.compute:
         wl["compute"] = args.compute
     rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("AOCR_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit if the run exceeds N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["AOCR_BENCH_WATCHDOG"]), exit=True)
     if os.environ.get("AOCR_BENCH_ONE_GPU"):            # debugging aid: all ranks on device 0 (with AOCR_BENCH_BACKEND=gloo)
         local = 0
+        # The whole-sequence ("cluster") kernels need the device to themselves: one launch occupies every compute unit and its groups
+        # wait for each other, so two ranks' launches interleaved on ONE device starve each other until the bounded waits give up
+        # (aocr_cluster_status).  Ranks that share a device run the per-step launch chains instead.
+        os.environ.setdefault("AOCR_NO_CLUSTER", "1"); os.environ.setdefault("AOCR_NO_DEC_CLUSTER", "1")
     torch.cuda.set_device(local)
     dist = torch.distributed
     if world > 1:
@@ -210,10 +217,13 @@ def main():
 
     fl = flops(W, wl["He"], wl["Le"], wl["Ld"], L)
     peak = PEAK[wl["compute"]]
-    # ---- per-family HIP-event timing of one step (library marks, include/aocr.h AOCR_PROF_*), rank 0
+    # ---- per-family HIP-event timing of one step (library marks, include/aocr.h AOCR_PROF_*).  EVERY rank runs the profiled steps (a step
+    # contains the gradient all-reduce and the synchronised BatchNorm sums: a rank that skipped them would leave the others waiting);
+    # rank 0 reports
     families = None
+    fam_all = m.profile_families(step, repeats=3)
     if rank == 0:
-        fam = m.profile_families(step, repeats=3)
+        fam = fam_all
         # algorithmic FLOPs per image of each family: the three conv passes; both recurrences of the encoder (h W_h2h forward, dz W_h2h
         # backward); the hoisted GEMMs = input projections / embedding part / projector (forward, d(input), d(weight)) plus the weight
         # gradients of every matrix the two step chains use; the decoder chains themselves (forward = backward in FLOPs)
