@@ -81,7 +81,8 @@ int aocr_model_set_stream(aocr_model* m, void* stream);
 
 /* Health of the whole-sequence ("cluster") kernels: the compute units that share a block of batch rows wait for each other with BOUNDED
  * spins; if a wait ever times out (it cannot unless another kernel keeps part of the chip busy for ~0.3 s) the kernel records a code,
- * finishes, and the step's results are invalid.  *code = 0: healthy.  Synchronises the model's stream.  No reference counterpart.
+ * finishes, and the step's results are invalid.  *code = 0: healthy; a non-zero code is cleared by the call (read and clear).
+ * Synchronises the model's stream.  No reference counterpart.
  * These kernels need the device to themselves: a launch occupies every compute unit, so the steps of two models (or two processes)
  * must not run concurrently on ONE device -- AOCR_NO_CLUSTER=1 AOCR_NO_DEC_CLUSTER=1 selects the per-step launch chains for that case. */
 int aocr_cluster_status(aocr_model* m, int32_t* code);

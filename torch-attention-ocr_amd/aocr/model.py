@@ -442,10 +442,15 @@ class Model:
               "aocr_train_forward_backward")
         return float(self._scal[0].item())
 
-    def check_health(self):
-        """Raises if a whole-sequence kernel ever gave up waiting for its group (include/aocr.h: aocr_cluster_status); synchronises."""
+    def cluster_status(self) -> int:
+        """0 = healthy; otherwise the code of a whole-sequence kernel that gave up waiting for its group since the last call (read and clear)."""
         code = C.c_int32(0)
         check(lib.aocr_cluster_status(self._h, C.byref(code)), "aocr_cluster_status")
+        return int(code.value)
+
+    def check_health(self):
+        """Raises if a whole-sequence kernel ever gave up waiting for its group (include/aocr.h: aocr_cluster_status); synchronises."""
+        code = C.c_int32(self.cluster_status())
         if code.value != 0:
             raise RuntimeError(f"a cluster kernel timed out waiting for its group (code {code.value}): the results of that step are invalid")
 

@@ -215,6 +215,7 @@ int aocr_cluster_status(aocr_model* m, int32_t* code) {
   if (!m->cl_err) return 0;
   if (hipMemcpyAsync(code, m->cl_err, sizeof(int32_t), hipMemcpyDeviceToHost, m->s) != hipSuccess || hipStreamSynchronize(m->s) != hipSuccess)
     return fail("aocr_cluster_status: %s", hipGetErrorString(hipGetLastError()));
+  if (*code != 0) hipMemsetAsync(m->cl_err, 0, sizeof(int32_t), m->s);      // read and clear: the next call reports the steps after this one
   return 0;
 }
 
