@@ -267,10 +267,29 @@ def _q(x):
 # ----------------------------------------------------------------------------
 # forward building blocks
 # ----------------------------------------------------------------------------
-def cnn_forward(P, bn_state, images, training: bool, update_running: bool = True):
-    """src/model/cnn.lua:9-45.  images (B,1,32,W) values 0..255 -> (B,T,512)."""
+def cnn_forward(P, bn_state, images, training: bool, update_running: bool = True, decisions=None):
+    """src/model/cnn.lua:9-45.  images (B,1,32,W) values 0..255 -> (B,T,512).
+    decisions (tests only): the ReLU / max-pool DECISIONS of another forward pass imposed on this one -- {"idx<i>": LongTensor
+    (B,C,Hp,Wp), the window element (scan order kh, kw) that pass selected after conv<i>, "act<i>": BoolTensor, whether its ReLU let
+    the value through} for the layers it names.  With them the remaining differences between two passes are arithmetic only."""
     x = (images + (-128.0)) * (1.0 / 128)                                   # cnn.lua:9-10
+    dec = decisions or {}
+    last = 0
+    skip_pool = False
     for l in CNN_LAYERS:
+        if l[0] == "conv":
+            last = l[1]
+        if l[0] == "relu" and f"idx{last}" in dec:                           # ReLU + pool of this layer follow the imposed decisions (below)
+            continue
+        if l[0] == "pool" and f"idx{last}" in dec:
+            kh, kw = l[1], l[2]
+            Bq, Cq, Hq, Wq = x.shape
+            win = x.reshape(Bq, Cq, Hq // kh, kh, Wq // kw, kw).permute(0, 1, 2, 4, 3, 5).reshape(Bq, Cq, Hq // kh, Wq // kw, kh * kw)
+            x = torch.gather(win, 4, dec[f"idx{last}"].unsqueeze(-1)).squeeze(-1) * dec[f"act{last}"].to(x.dtype)
+            continue
+        if l[0] == "relu" and f"act{last}" in dec:
+            x = x * dec[f"act{last}"].to(x.dtype)
+            continue
         if l[0] == "conv":
             _, i, cin, cout, k, pad = l
             if i == 1:                                                   # K = 9: the product computes conv1 in fp32 in both modes
@@ -424,18 +443,18 @@ def decoder_step_fwd(P, cfg: OcrConfig, tok, ctx, feed, c, h, t: int = 0):
 
 
 def forward_train(P, bn_state, cfg: OcrConfig, images, targets, targets_eval, training=True,
-                  grad_through_quirk=False, update_running=True):
+                  grad_through_quirk=False, update_running=True, cnn_decisions=None):
     """model.lua:285-316 + 537-569 + loss of :643-647.  Returns dict of everything.  Inside a `dropout_state` context (and with
     training=True) the Dropout sites of LSTM.lua are active."""
     global _DROP
     if not training and _DROP is not None:                                   # evaluate(): nn.Dropout is the identity
         saved, _DROP = _DROP, None
         try:
-            return forward_train(P, bn_state, cfg, images, targets, targets_eval, training, grad_through_quirk, update_running)
+            return forward_train(P, bn_state, cfg, images, targets, targets_eval, training, grad_through_quirk, update_running, cnn_decisions)
         finally:
             _DROP = saved
     B = images.shape[0]
-    feats = cnn_forward(P, bn_state, images, training, update_running)
+    feats = cnn_forward(P, bn_state, images, training, update_running, cnn_decisions)
     context, traces = encoder_forward(P, cfg, feats)
     c, h = decoder_init_state(cfg, traces, B, feats, grad_through_quirk)
     feed = feats.new_zeros(B, cfg.dec_hidden)
@@ -461,10 +480,10 @@ def forward_train(P, bn_state, cfg: OcrConfig, images, targets, targets_eval, tr
 # ----------------------------------------------------------------------------
 # training step: autograd version (independent check) and hand-rolled BPTT
 # ----------------------------------------------------------------------------
-def train_step_autograd(P, bn_state, cfg, images, targets, targets_eval):
+def train_step_autograd(P, bn_state, cfg, images, targets, targets_eval, cnn_decisions=None):
     Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     st = {k: v.clone() for k, v in bn_state.items()}
-    r = forward_train(Pg, st, cfg, images, targets, targets_eval, training=True, grad_through_quirk=True)
+    r = forward_train(Pg, st, cfg, images, targets, targets_eval, training=True, grad_through_quirk=True, cnn_decisions=cnn_decisions)
     r["loss"].backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pg.items()}
     return r["loss"].detach(), grads, r, st

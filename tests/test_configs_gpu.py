@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_step_gpu import make, relerr
+from test_step_gpu import make, relerr, _gpu_cnn_decisions
 
 pytestmark = pytest.mark.gpu
 
@@ -152,7 +152,22 @@ def test_c3_bf16_all_gradients_vs_oracle(cuda):
     print(f"[parity] C3 bf16: loss {loss:.4f} vs fp64 {float(loss_ref) * B:.4f} vs bf16-operand oracle {float(loss_q) * B:.4f}; logits max-abs {e:.3e} / {eq:.3e}")
     assert abs(loss - float(loss_ref) * B) < 2e-3 * abs(loss) and abs(loss - float(loss_q) * B) < 2e-4 * abs(loss)
     assert e < 5e-2 and eq < 5e-3
-    check_bf16_gradients("C3 bf16", m.get_gradients(), G, Gq)
+    grads = m.get_gradients()
+    check_bf16_gradients("C3 bf16", grads, G, Gq)
+    # The conv stack's cosine of 0.97-0.999 is ReLU / arg-max DECISION flips between two bf16 forward passes (check_bf16_gradients):
+    # tested here by imposing the GPU's own decisions on the bf16-operand oracle -- then every tensor agrees to bf16 arithmetic noise.
+    dec = _gpu_cnn_decisions(m, B)
+    with O.operand_rounding("bf16"):
+        loss_d, Gd, _, _ = O.train_step_autograd(P, st, ocfg, img, tgt, tge, cnn_decisions=dec)
+    worst = ("", 1.0)
+    for k, g in Gd.items():
+        if k in NOISY:
+            continue
+        c, r = cosine(grads[k], g), relerr(grads[k], g)
+        print(f"[parity] C3 bf16, GPU decisions imposed on the bf16-operand oracle: {k:22s} rel {r:.3e} cos {c:.6f}")
+        if c < worst[1]: worst = (k, c)
+        assert c > 0.9999 and r < 2e-2, (k, c, r)                   # measured: cosine >= 0.99998, rel <= 6e-3 (conv1 included)
+    print(f"[parity] C3 bf16 with imposed decisions: worst cosine {worst[1]:.6f} ({worst[0]})")
     m.shutdown()
 
 

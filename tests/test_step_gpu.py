@@ -473,6 +473,66 @@ def test_train_step_parity_c2_shape(cuda):
     m.shutdown()
 
 
+def _gpu_cnn_decisions(m, B):
+    """The ReLU / max-pool decisions of the GPU's last forward pass as the oracle's `cnn_decisions` (conv2..conv7; conv1's pooling
+    stores no arg-max -- its backward recomputes the window -- and stays with the oracle's own choice)."""
+    dec = {}
+    nchw = lambda t: t.permute(0, 3, 1, 2).contiguous()
+    for i in (2, 4, 6):
+        dec[f"idx{i}"] = nchw(m.get_tensor(f"idx{i}")).long()
+        dec[f"act{i}"] = nchw(m.get_tensor(f"conv{i}")) > 0
+    for i in (3, 5):
+        dec[f"act{i}"] = nchw(m.get_tensor(f"conv{i}")) > 0
+    feats = m.get_tensor("feats")                                   # (T, B, 512) time-major
+    dec["act7"] = (feats > 0).permute(1, 2, 0).unsqueeze(2).contiguous()          # (B, 512, 1, T)
+    return dec
+
+
+def test_c2_gradient_residual_is_decision_flips(cuda):
+    """C2 at full size, exact-fp32 mode.  test_train_step_parity_c2_shape holds the early CNN gradients only to a cosine because a
+    handful of the 1.6 M pooling windows / ReLU inputs are fp32-vs-fp64 near-ties.  Here that explanation is TESTED: the GPU's own
+    decisions (stored arg-max maps, signs of its outputs) are imposed on the fp64 oracle, and then EVERY gradient tensor -- the early
+    convolutions included -- agrees to fp32 accuracy; the number of decisions that differed from the oracle's own is reported."""
+    m, O, ocfg, P, st, batch = make(dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True), B=64, W=100, maxlen=23,
+                                    max_decoder_l=24, max_beam=1)
+    img, tgt, tge = (torch.from_numpy(np.asarray(x)) for x in batch[:3])
+    loss = m.train_forward_backward(batch)
+    grads = m.get_gradients()
+    dec = _gpu_cnn_decisions(m, 64)
+    # how many decisions differ from the oracle's own forward pass
+    import torch.nn.functional as F
+    x = (img.double() - 128.0) / 128.0; st2 = {k: v.clone() for k, v in st.items()}; flips = {}; last = 0; pre = None
+    for l in O.CNN_LAYERS:
+        if l[0] == "conv":
+            _, i, cin, cout, k, pad = l; x = F.conv2d(x, P[f"cnn.conv{i}.w"], P[f"cnn.conv{i}.b"], padding=pad); last = i; pre = x
+        elif l[0] == "relu":
+            x = F.relu(x)
+        elif l[0] == "pool":
+            kh, kw = l[1], l[2]; Bq, Cq, Hq, Wq = pre.shape
+            win = pre.reshape(Bq, Cq, Hq // kh, kh, Wq // kw, kw).permute(0, 1, 2, 4, 3, 5).reshape(Bq, Cq, Hq // kh, Wq // kw, kh * kw)
+            if f"idx{last}" in dec:
+                act = win.max(4).values > 0
+                flips[f"pool{last}"] = int(((win.argmax(4) != dec[f"idx{last}"]) & act).sum()); flips[f"relu{last}"] = int((act != dec[f"act{last}"]).sum())
+            x = F.max_pool2d(x, (kh, kw), (kh, kw))
+        elif l[0] == "bn":
+            i = l[1]
+            x = F.batch_norm(x, st2[f"cnn.bn{i}.rm"], st2[f"cnn.bn{i}.rv"], P[f"cnn.bn{i}.w"], P[f"cnn.bn{i}.b"], training=True, momentum=0.1, eps=1e-5)
+            flips[f"relu{i}"] = int(((x > 0) != dec[f"act{i}"]).sum())
+    print(f"[parity] C2 decisions that differ between the fp32 kernels and the fp64 oracle: {flips}")
+    loss_ref, G, r, _ = O.train_step_autograd(P, st, ocfg, img.double(), tgt, tge, cnn_decisions=dec)
+    assert abs(loss - float(loss_ref) * 64) < 1e-4 * abs(loss)
+    worst = ("", 0.0)
+    for k, g in G.items():
+        if g.abs().max() < 1e-9:
+            continue
+        e = relerr(grads[k], g)
+        if e > worst[1]: worst = (k, e)
+        print(f"[parity] C2 grad, GPU decisions imposed on the oracle: {k:22s} rel {e:.3e}")
+        assert e < 5e-5, (k, e)                                         # (measured <= 7e-6, conv1 included: its own pool decisions did not differ)
+    print(f"[parity] C2 with imposed decisions: worst rel {worst[1]:.3e} ({worst[0]})")
+    m.shutdown()
+
+
 @pytest.mark.parametrize("beam", [1, 3])
 def test_decode_parity_c2_shape(cuda, beam):
     """BASELINE config C2 at full size, eval-mode BatchNorm, 50 decode steps + gold pass: labels, beam scores, gold scores and

@@ -356,6 +356,13 @@ int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32
   else if (n == "conv1") { if (m->bf16) bf16_to_f32(m->s, m->A1b, m->A1, (int64_t)d.B * d.H1 * d.W1 * 64); *ptr_dev = m->A1; *ndim = 4; shape[0] = d.B; shape[1] = d.H1; shape[2] = d.W1; shape[3] = 64; }
   else if (n == "conv2") { if (m->bf16) bf16_to_f32(m->s, m->A2b, m->A2, (int64_t)d.B * d.H2 * d.W2 * 128); *ptr_dev = m->A2; *ndim = 4; shape[0] = d.B; shape[1] = d.H2; shape[2] = d.W2; shape[3] = 128; }
   else if (n == "conv6") { if (m->bf16) bf16_to_f32(m->s, m->A6b, m->A6, (int64_t)d.B * d.H6 * d.W2 * 512); *ptr_dev = m->A6; *ndim = 4; shape[0] = d.B; shape[1] = d.H6; shape[2] = d.W2; shape[3] = 512; }
+  // parity aids: the ReLU / max-pool DECISIONS of the forward pass (tests impose them on the fp64 oracle: tests/test_step_gpu.py)
+  else if (n == "conv3") { if (m->bf16) bf16_to_f32(m->s, m->A3b, m->A3, (int64_t)d.B * d.H2 * d.W2 * 256); *ptr_dev = m->A3; *ndim = 4; shape[0] = d.B; shape[1] = d.H2; shape[2] = d.W2; shape[3] = 256; }
+  else if (n == "conv4") { if (m->bf16) bf16_to_f32(m->s, m->A4b, m->A4, (int64_t)d.B * d.H4 * d.W2 * 256); *ptr_dev = m->A4; *ndim = 4; shape[0] = d.B; shape[1] = d.H4; shape[2] = d.W2; shape[3] = 256; }
+  else if (n == "conv5") { if (m->bf16) bf16_to_f32(m->s, m->A5b, m->A5, (int64_t)d.B * d.H4 * d.W2 * 512); *ptr_dev = m->A5; *ndim = 4; shape[0] = d.B; shape[1] = d.H4; shape[2] = d.W2; shape[3] = 512; }
+  else if (n == "idx2") { u8_to_f32(m->s, m->idx2, m->G0, (int64_t)d.B * d.H2 * d.W2 * 128); *ptr_dev = m->G0; *ndim = 4; shape[0] = d.B; shape[1] = d.H2; shape[2] = d.W2; shape[3] = 128; }
+  else if (n == "idx4") { u8_to_f32(m->s, m->idx4, m->G0, (int64_t)d.B * d.H4 * d.W2 * 256); *ptr_dev = m->G0; *ndim = 4; shape[0] = d.B; shape[1] = d.H4; shape[2] = d.W2; shape[3] = 256; }
+  else if (n == "idx6") { u8_to_f32(m->s, m->idx6, m->G0, (int64_t)d.B * d.H6 * d.W2 * 512); *ptr_dev = m->G0; *ndim = 4; shape[0] = d.B; shape[1] = d.H6; shape[2] = d.W2; shape[3] = 512; }
   else if (n == "enc_dz0" || n == "enc_dz1") {           // debugging aid: bf16 d z of the top encoder layer, direction 0 / 1
     const int dir = n == "enc_dz1"; const int64_t cnt = (int64_t)d.T * d.B * 4 * m->He;
     REQUIRE(m->edz_b[dir][m->Le - 1], "no bf16 d z in this mode");

@@ -1181,6 +1181,14 @@ __global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ g1,
   dpre[i] = v;
   if (dpreb) dpreb[i] = (bf16_t)v;
 }
+// debugging taps: the pooling arg-max maps as floats
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+void u8_to_f32(hipStream_t s, const uint8_t* src, float* dst, int64_t n) {
+  hipLaunchKernelGGL(u8_to_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, src, dst, n);
+}
 void dpre_tanh(hipStream_t s, const float* g1, const float* g2, const float* out, float* dpre, int64_t n, bf16_t* dpreb, const DropSpec* drop) {
   hipLaunchKernelGGL(dpre_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, g1, g2, out, dpre, n, dpreb, drop ? *drop : DropSpec{});
 }
