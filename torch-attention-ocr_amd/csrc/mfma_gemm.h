@@ -1093,12 +1093,13 @@ __device__ __forceinline__ void tr_tile(const LoadMNh& a, const BL& b, const EP&
 }
 
 template <class EP>
-__global__ __launch_bounds__(256, 4) void conv_wgrad_tr_kernel(LoadMNh a, LoadConvXcolh b, EP ep, int K, int kper, int gx, int gy) {
+__global__ __launch_bounds__(256, 4) void conv_wgrad_tr_kernel(LoadMNh a, LoadConvXcolh b, EP ep, int K, int kper, int gx, int gy, int gz) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][32 * TR_PITCH];
-  const int nwg = gx * gy, orig = blockIdx.x;
+  const int nwg = gx * gy * gz, orig = blockIdx.x;                    // flat k-range-major order, see conv_wgrad_dma_kernel
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int kbeg = blockIdx.z * kper;
+  const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int zsp = lin / (gx * gy), bid = lin - zsp * (gx * gy);
+  const int kbeg = zsp * kper;
   tr_tile(a, b, ep, (bid / gx) * 128, (bid % gx) * 128, kbeg, min(K, kbeg + kper), lds);
 }
 
@@ -1112,13 +1113,17 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_kernel(LoadMNh a, LoadCo
 // The im2col operand's piece addresses are per lane: (tap, ci) is a lane constant, the pixel cursor advances by 32.
 // ---------------------------------------------------------------------------
 template <class EP>
-__global__ __launch_bounds__(512, 1) void conv_wgrad_dma_kernel(LoadMNh a, LoadConvXcolh b, EP ep, int K, int kper, int gx, int gy, const bf16_t* zero) {
+__global__ __launch_bounds__(512, 1) void conv_wgrad_dma_kernel(LoadMNh a, LoadConvXcolh b, EP ep, int K, int kper, int gx, int gy, const bf16_t* zero, int gz) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 32768];          // the ONLY LDS object
-  // (Giving every XCD its own K range, so that co-resident workgroups stream the same pixel rows through one L2, was
-  // measured 1.5-2.5x SLOWER than this plain tile-major / split-major order: conv6 635 vs 380 us.)
-  const int nwg = gx * gy, orig = blockIdx.x;
+  // (Round 1 gave every XCD its own K range with 36 tiles on its 32 CUs, i.e. two rounds: 1.5-2.5x slower.)
+  // ONE flat grid over (k range, tile), renumbered so that the workgroups of an XCD are consecutive in k-range-major order: an
+  // XCD's co-resident workgroups then share one (at most two) pixel ranges, so its L2 fetches d y and x of that range once for all
+  // their tiles (before, with the k range on blockIdx.z, every XCD saw every range: 56 % L2 misses, 917 MB of fills per launch).
+  // Worth 1 % on this kernel and 8 % on conv_wgrad_tr_kernel -- neither is bound by those misses.
+  const int nwg = gx * gy * gz, orig = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3), zsp = blockIdx.z;
+  const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int zsp = lin / (gx * gy), bid = lin - zsp * (gx * gy);
   const int m_blk = (bid / gx) * 256, n_blk = (bid % gx) * 256;
   const int kbeg = zsp * kper, kend = min(K, kbeg + kper);
   const int nk = kend > kbeg ? (kend - kbeg + 31) >> 5 : 0;

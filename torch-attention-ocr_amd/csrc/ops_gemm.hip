@@ -354,13 +354,13 @@ void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float*
     const int tiles = cdiv(N, 256) * (Cout / 256);
     if (Cout % 256 == 0 && Cin % 8 == 0 && !dma_disabled() && (dma_forced() || (P >= 8192 && tiles <= 256 && N % 256 == 0 && N >= 2304))) {
       int ks2 = tiles >= 128 ? (tiles >= 200 ? 1 : 2) : 256 / tiles, kper2; split_k(P, 32, ks2, kper2);      // one round of the 256 CUs
-      hipLaunchKernelGGL((conv_wgrad_dma_kernel<EpStore>), dim3(tiles, 1, ks2), dim3(512), 0, s, ah, bh, ep, P, kper2, cdiv(N, 256), Cout / 256, zero_page());
+      hipLaunchKernelGGL((conv_wgrad_dma_kernel<EpStore>), dim3(tiles * ks2), dim3(512), 0, s, ah, bh, ep, P, kper2, cdiv(N, 256), Cout / 256, zero_page(), ks2);
       if (dbias) colsum_accum(s, dy, Cout, P, Cout, dbias);
       return;
     }
     int ks = ksplit, kper; split_k(P, 32, ks, kper);
     const int gx = cdiv(N, 128), gy = cdiv(Cout, 128);
-    hipLaunchKernelGGL((conv_wgrad_tr_kernel<EpStore>), dim3(gx * gy, 1, ks), dim3(256), 0, s, ah, bh, ep, P, kper, gx, gy);
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<EpStore>), dim3(gx * gy * ks), dim3(256), 0, s, ah, bh, ep, P, kper, gx, gy, ks);
   } else {
     launch_conv_wgrad(s, bf16, make_loadmn(dy, Cout, Cout, P), b, ep, Cout, N, P, ksplit);
   }
