@@ -33,6 +33,29 @@ def relerr(got, ref):
     return ((got - ref).abs().max() / (ref.abs().max() + 1e-12)).item()
 
 
+def cosine(a, b):
+    a = a.double().flatten(); b = b.double().flatten()
+    return (a @ b / (a.norm() * b.norm() + 1e-300)).item()
+
+
+def assert_grads_agree_up_to_decisions(ga, gb, what):
+    """Two kernel paths that sum the same products in a different order: every tensor above the CNN agrees to summation-order
+    noise (bf16 re-rounding included); a CNN gradient additionally sees the few ReLU / arg-max decisions that a last-bit
+    difference flips (each moves ONE term of a sum: percent-level in max-norm, nothing in direction -- DESIGN.md section 4,
+    test_c2_gradient_residual_is_decision_flips)."""
+    worst = ("", 0.0)
+    for k in ga:
+        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):      # bias in front of a BatchNorm: exact gradient 0, only rounding noise
+            continue
+        e, c = relerr(gb[k], ga[k]), cosine(gb[k], ga[k])
+        if e > worst[1]: worst = (k, e)
+        if k.startswith("cnn."):
+            assert e < 0.3 and c > 0.995, (what, k, e, c)    # measured cosine 0.998-0.999 (max-norm up to 0.18 on single entries at batch 2-4), the level of GPU-vs-oracle WITHOUT imposed decisions (with them: 0.99998, test_c3_bf16_all_gradients_vs_oracle)
+        else:
+            assert e < 3e-2 and c > 0.9999, (what, k, e, c)
+    print(f"[parity] {what}: worst gradient rel {worst[1]:.3e} ({worst[0]})")
+
+
 CASES = [
     dict(enc_hidden=32, enc_layers=1, dec_layers=2, input_feed=True),
     dict(enc_hidden=32, enc_layers=1, dec_layers=2, input_feed=False),
@@ -187,6 +210,32 @@ def test_dma_conv_kernel_matches_tiled_kernel(cuda, monkeypatch, B, W):
         e = relerr(b["grads"][k], a["grads"][k]); worst = max(worst, e)
         assert e < 2e-2, (k, e)
     print(f"[parity] dma-vs-tiled worst gradient rel {worst:.3e}")
+
+
+@pytest.mark.parametrize("B,W", [(4, 256), (2, 512), (4, 128), (3, 256)])
+def test_halo_conv_kernel_matches_im2col_kernel(cuda, monkeypatch, B, W):
+    """The halo-resident 3x3 kernel (gemm_halo_bf16_kernel: the input halo of a 32-channel chunk staged once in LDS, taps as
+    shifted fragment reads, K chunk-major) against the im2col LDS-DMA kernel (AOCR_NO_HALO=1) on the same bf16 operands, forward
+    (plain, (2,1)- and 2x2-pooled row orders) and data gradient: map widths 64 (R = 4 rows per tile), 128 (R = 2) and 32 (R = 8:
+    only the 8-row maps qualify).  Only the fp32 accumulation order differs."""
+    cfg = dict(enc_hidden=64, enc_layers=1, dec_layers=2, input_feed=True)
+    monkeypatch.setenv("AOCR_FORCE_DMA", "1")
+    out = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("AOCR_NO_HALO", knob)
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=6, compute="bf16")
+        loss = m.train_forward_backward(batch)
+        out[knob] = dict(loss=loss, taps={k: m.get_tensor(k).clone() for k in ("conv3", "conv4", "conv5", "conv6", "feats")},
+                         logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.shutdown()
+    a, b = out["1"], out["0"]
+    for k in a["taps"]:
+        d = (a["taps"][k].double() - b["taps"][k].double()).abs(); e, me = d.max().item(), d.mean().item()
+        print(f"[parity] halo-vs-im2col {k} max-abs {e:.3e} mean-abs {me:.3e}")
+        assert e < 5e-2 and me < (2e-3 if k == "feats" else 2e-4), (k, e, me)       # the taps are bf16 shadows: a value whose fp32 sums differ in the last bits rounds to the neighbouring bf16 (one ulp of a value < 8), and such flips propagate
+    e = (a["logits"].double() - b["logits"].double()).abs().max().item(); print(f"[parity] halo-vs-im2col logits max-abs {e:.3e}"); assert e < 2e-2, e
+    assert abs(a["loss"] - b["loss"]) < 1e-3 * max(1.0, abs(a["loss"]))
+    assert_grads_agree_up_to_decisions(a["grads"], b["grads"], "halo-vs-im2col")
 
 
 @pytest.mark.parametrize("He,B,W,Le", [(64, 16, 40, 1), (256, 32, 72, 1), (128, 16, 36, 1), (64, 16, 44, 2), (256, 16, 36, 2),
@@ -412,17 +461,12 @@ def test_c3_full_size_kernel_paths_agree(cuda, monkeypatch):
                          grads={k: v.clone() for k, v in m.get_gradients().items()})
         m.shutdown()
     a, b = out["1"], out["0"]
-    e = (a["feats"].double() - b["feats"].double()).abs().max().item(); print(f"[parity] C3 full size: feats max-abs {e:.3e}"); assert e < 2e-3
+    # (the halo-resident conv kernel sums K chunk-major, the tiled kernels tap-major: bf16 shadows flip by an ulp where the fp32 sums differ in the last bits)
+    d = (a["feats"].double() - b["feats"].double()).abs(); e, me = d.max().item(), d.mean().item()
+    print(f"[parity] C3 full size: feats max-abs {e:.3e} mean-abs {me:.3e}"); assert e < 5e-2 and me < 2e-3
     e = (a["logits"].double() - b["logits"].double()).abs().max().item(); print(f"[parity] C3 full size: logits max-abs {e:.3e}"); assert e < 5e-3
     assert abs(a["loss"] - b["loss"]) < 2e-3 * abs(a["loss"])
-    worst = ("", 0.0)
-    for k in a["grads"]:
-        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):
-            continue
-        e = relerr(b["grads"][k], a["grads"][k])
-        if e > worst[1]: worst = (k, e)
-        assert e < 3e-2, (k, e)
-    print(f"[parity] C3 full size: worst gradient rel {worst[1]:.3e} ({worst[0]})")
+    assert_grads_agree_up_to_decisions(a["grads"], b["grads"], "C3 full size")
 
 
 def test_logits_c3_shape_bf16(cuda):

@@ -59,7 +59,14 @@ int main() {
     run<0, false>(a, b, e2, M, N, K, zero, "full kernel, plain reads, no fp32 y");
     e2.idx = nullptr; run<7>(a, b, e2, M, N, K, zero, "barrier + epilogue only, bf16 y only");
     e2.yb = nullptr; run<7>(a, b, e2, M, N, K, zero, "barrier + epilogue only, no stores at all"); }
-  for (int rep = 0; rep < 3; ++rep) {
+  for (int rep = 0; rep < 2; ++rep) {                     // round 2: how much of the launch is the im2col (A) stream?
+    run<0, false>(a, b, ep, M, N, K, zero, "full kernel, plain reads");
+    run<16, false>(a, b, ep, M, N, K, zero, "plain reads, A pieces from the zero page");
+    run<32, false>(a, b, ep, M, N, K, zero, "plain reads, no A pieces");
+    run<128, false>(a, b, ep, M, N, K, zero, "plain reads, B pieces from the zero page");
+    run<128 + 16, false>(a, b, ep, M, N, K, zero, "plain reads, A and B pieces from the zero page");
+  }
+  for (int rep = 0; rep < 1; ++rep) {
     run<0, true>(a, b, ep, M, N, K, zero, "full kernel, pipelined reads");
     run<0, false>(a, b, ep, M, N, K, zero, "full kernel, plain reads");
     run<0, false, true>(a, b, ep, M, N, K, zero, "full kernel, two tiles per barrier");

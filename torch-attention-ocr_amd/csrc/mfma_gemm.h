@@ -722,7 +722,7 @@ __device__ __forceinline__ void dma16(const void* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <class AL, class BL, class EP, int ABL = 0, bool PIPE = false, bool PAIRS = false, int TAG = 0>     // TAG: distinct symbol for aocr_profile_kernel's launches (so that rocprofv3 --stats lists them on their own row); PAIRS: two K tiles per barrier; PIPE: fragment reads pipelined across the barrier (inline asm; measured 4-7 % slower); ABL: timing-only ablations (tools/ubench/dma_gemm.hip): 1 no in-loop DMA, 2 no MFMA, 4 no fragment reads
+template <class AL, class BL, class EP, int ABL = 0, bool PIPE = false, bool PAIRS = false, int TAG = 0>     // TAG: distinct symbol for aocr_profile_kernel's launches (so that rocprofv3 --stats lists them on their own row); PAIRS: two K tiles per barrier; PIPE: fragment reads pipelined across the barrier (inline asm; measured 4-7 % slower); ABL: timing-only ablations (tools/ubench/dma_gemm.hip): 1 no in-loop DMA, 2 no MFMA, 4 no fragment reads, 16 / 128 A / B pieces from the zero page (plain form), 32 no A pieces at all (plain form)
 __global__ __launch_bounds__(512, 1)
 void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t* zero) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 32768];          // the ONLY LDS object (a second one makes hipcc drain vmcnt)
@@ -744,12 +744,12 @@ void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t
   int slot = 0;                                       // ring slot the next issue() fills
   auto issue_a = [&]() {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) dma16(a.dsrc(ra[j], ca, zero), wbase + slot * 32768 + j * 8192);
+    for (int j = 0; j < 2; ++j) if constexpr (!(ABL & 32)) dma16((ABL & 16) ? zero : a.dsrc(ra[j], ca, zero), wbase + slot * 32768 + j * 8192);
     a.dadvance(ca);
   };
   auto issue_b = [&]() {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) dma16(b.dsrc(rb[j], cb, zero), wbase + slot * 32768 + 16384 + j * 8192);
+    for (int j = 0; j < 2; ++j) dma16((ABL & 128) ? zero : b.dsrc(rb[j], cb, zero), wbase + slot * 32768 + 16384 + j * 8192);
     b.dadvance(cb); slot = (slot + 1) & 3;
   };
 
@@ -821,6 +821,7 @@ void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t
 #pragma unroll
     for (int t = 0; t < 3; ++t) { issue_a(); issue_b(); }
     for (int kt = 0; kt < nk; ++kt) {
+      if constexpr (ABL & 32) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       const unsigned char* L = lds + (kt & 3) * 32768;
@@ -886,6 +887,156 @@ void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t
   }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the trailing (zero-page) tiles must land before the LDS is released
+  const int m0 = m_blk + wm * 128, n0 = n_blk + wn * 64;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[2][4];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * q + i];
+      ep.template quad<2>(m0 + 32 * mi + 8 * q + 4 * h, n0 + r, 32, v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 3 x 3 convolution (forward / data gradient) with the input HALO resident in LDS.  Ablation of gemm_dma_bf16_kernel at the
+// conv6 shape (tools/ubench/dma_gemm.hip): 295 us full, 206-223 with the im2col pieces read from one cached line, 193 with
+// both operands so -- a third of the launch is the im2col stream, which fetches every input pixel nine times (once per tap)
+// as 64-byte segments of 16 different rows per DMA instruction.  Here a workgroup's 256 output pixels are R = 256 / W whole
+// rows of ONE image, and for a 32-channel chunk their (R + 2) x (W + 2) input halo is staged ONCE (two buffers: chunk c + 1
+// streams in while the nine taps of chunk c are multiplied); a tap is a shift of the fragment read address.  K runs chunk-major
+// (chunk, kh, kw) instead of tap-major, so the weight tile of step (c, tap) starts at k = tap * C + 32 c.  L2 -> LDS bytes per
+// 9 steps: 30 + 144 KB instead of 144 + 144 KB.
+//   halo image: pitch P = W + 16 pixels (16-pixel DMA groups never straddle a row), pixel (row, col) at (row * P + col) * 64 B,
+//   col = x + 1, row = y - y0 + 1; the 16-byte piece at position p of a pixel holds k-chunk p ^ s, s = ((col >> 2) & 3) ^ 2 (row & 1):
+//   any 16 consecutive fragment rows (16 pixels of a row, or 8 + 8 pixels of two adjacent rows under the pooled row orders) hit
+//   all 64 banks once; a tap's dy only toggles bit 1 of s (address ^ 32), its dx picks one of three precomputed lane addresses.
+//   Every step issues exactly 3 DMA instructions per wave (1 halo piece -- a dummy into a dump page once the next halo is
+//   complete -- and 2 weight pieces), so the counted wait is uniform: vmcnt(6) = the pieces of this step's weight tile landed.
+// Shapes: W in {32, 64, 128}, H % R == 0 (R even under the pooled orders), C % 32 == 0, N % 256 == 0; SGN = +1 forward, -1 data gradient.
+// ---------------------------------------------------------------------------
+constexpr int HALO_MAX = 36864;                        // bytes of one halo buffer: (R + 2) * (W + 16) * 64 <= 4 * 144 * 64
+constexpr int HALO_BRING = 2 * HALO_MAX, HALO_DUMP = HALO_BRING + 4 * 16384, HALO_LDS = HALO_DUMP + 8 * 1024;
+
+template <class EP, int SGN>
+__global__ __launch_bounds__(512, 1)
+void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const bf16_t* zero) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[HALO_LDS];           // the ONLY LDS object (a second one makes hipcc drain vmcnt)
+  const int nwg = gx * gy, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int m_blk = (bid / gx) * 256, n_blk = (bid % gx) * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5, wm = wave >> 2, wn = wave & 3;
+  const LoadConvK& g = a.g;
+  const int W = g.Wr, H = g.Hr, C = g.C, P = W + 16, R = 256 / W;
+  const int NG = (R + 2) * (P >> 4);                     // 16-pixel DMA groups of one halo
+  const int NC = C >> 5, NT = 9 * NC;                    // channel chunks, K steps
+  const LoadConvK::Ctx c0 = g.row(m_blk);                // first pixel of the tile: (b, y0, 0)
+  const int y0 = __builtin_amdgcn_readfirstlane(c0.y);
+  const bf16_t* const img = a.src + (int64_t)__builtin_amdgcn_readfirstlane(c0.b) * H * W * C;
+
+  // ---- fragment addresses: abase[mi][dxi] = byte offset of (halo row ty, col tx + dxi) for k-chunk h, i.e. tap dy = -1, dx = dxi - 1
+  unsigned abase[4][3];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int local = wm * 128 + mi * 32 + r;
+    int ty, tx;
+    if (g.pmode == 1) { const int win = local >> 2, wx = win % g.Wp; ty = 2 * (win / g.Wp) + ((local >> 1) & 1); tx = 2 * wx + (local & 1); }
+    else if (g.pmode == 2) { const int win = local >> 1; tx = win % W; ty = 2 * (win / W) + (local & 1); }
+    else { ty = local / W; tx = local - ty * W; }
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi) {
+      const int col = tx + dxi, sw = ((col >> 2) & 3) ^ ((ty & 1) << 1);
+      abase[mi][dxi] = (unsigned)(ty * P + col) * 64u + (unsigned)((h ^ sw) << 4);
+    }
+  }
+  const int swzb = (r >> 2) & 3;
+  unsigned boff[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) boff[s2] = HALO_BRING + (wn * 64 + r) * 64 + (((2 * s2 + h) ^ swzb) << 4);
+
+  // ---- weight staging (as in gemm_dma_bf16_kernel): rows (tid >> 2) + 128 j, position tid & 3 holds k-chunk (tid & 3) ^ ((tid >> 4) & 3)
+  const int srow = tid >> 2, bchunk = (tid & 3) ^ ((tid >> 4) & 3);
+  LoadKh::DRow rb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) rb[j] = b.drow(n_blk + 128 * j + srow, bchunk);
+  unsigned char* const wbase = lds + wave * 1024;
+  // ---- halo staging: group gq = 16 pixels of one halo row; lane -> pixel (lane >> 2), position lane & 3
+  const int hx = (lane >> 2) - 1, hchunk = (lane & 3) ^ ((lane >> 4) & 3);
+  auto issue_halo = [&](int gq, int chunk, bool real) {   // gq, chunk, real: wave-uniform
+    const int row = gq / (P >> 4), col0 = (gq - row * (P >> 4)) << 4;
+    const int y = y0 - 1 + row, x = col0 + hx;
+    const bool ok = real && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    const bf16_t* src = img + ((int64_t)(y * W + x) * C + (chunk << 5) + ((hchunk ^ ((row & 1) << 1)) << 3));
+    dma16(dma_select(ok, src, zero), real ? lds + (chunk & 1) * HALO_MAX + gq * 1024 : lds + HALO_DUMP + wave * 1024);
+  };
+  auto issue_b = [&](int step) {                         // weight tile of K step `step` (chunk-major): k = tap * C + 32 chunk
+    const int chunk = step / 9, tap = step - chunk * 9;
+    const int k = step < NT ? tap * C + (chunk << 5) : b.K;            // past the end: zero page
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      dma16(dma_select(rb[j].b != nullptr && k < b.K, rb[j].b + k, zero), wbase + HALO_BRING + (step & 3) * 16384 + j * 8192);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // prologue: the whole halo of chunk 0 and three weight tiles, all landed before the first step
+  for (int gq = wave; gq < NG; gq += 8) issue_halo(gq, 0, true);
+  issue_b(0); issue_b(1); issue_b(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  int step = 0;
+  for (int chunk = 0; chunk < NC; ++chunk) {
+    const unsigned hb = (chunk & 1) * HALO_MAX;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int dyi = SGN > 0 ? kh : 2 - kh;             // halo row offset of this tap: dy + 1
+      const unsigned U = hb + (unsigned)(dyi * P) * 64u, flip = (dyi & 1) << 5;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw, ++step) {
+        const int dxi = SGN > 0 ? kw : 2 - kw;
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // this wave's pieces of this step's weight tile (and of everything older) have landed
+        __builtin_amdgcn_s_barrier();                     // ... everyone's have, and everyone is done reading the previous step
+        const unsigned char* Lb = lds + (step & 3) * 16384;
+        bf16x8 af[2][4], bf[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const unsigned a0 = (abase[mi][dxi] + U) ^ flip;
+          af[0][mi] = *reinterpret_cast<const bf16x8*>(lds + a0);
+          af[1][mi] = *reinterpret_cast<const bf16x8*>(lds + (a0 ^ 32u));
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) bf[s2][ni] = *reinterpret_cast<const bf16x8*>(Lb + boff[s2] + ni * 2048);
+        {                                                 // one piece of the NEXT chunk's halo (its buffer was last read a chunk ago)
+          const int gq = (kh * 3 + kw) * 8 + wave;
+          issue_halo(gq < NG ? gq : 0, chunk + 1, gq < NG && chunk + 1 < NC);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], bf[0][ni], acc[mi][ni], 0, 0, 0);
+        issue_b(step + 3);                                // -> the slot of the previous step
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][mi], bf[1][ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the trailing (zero-page) pieces must land before the LDS is released
   const int m0 = m_blk + wm * 128, n0 = n_blk + wn * 64;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)

@@ -51,6 +51,21 @@ static void launch_dma(hipStream_t s, const AL& a, const BL& b, const EP& ep, in
   if (tag) hipLaunchKernelGGL((gemm_dma_bf16_kernel<AL, BL, EP, 0, false, false, 1>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page());
   else hipLaunchKernelGGL((gemm_dma_bf16_kernel<AL, BL, EP>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page());
 }
+// halo-resident 3 x 3 kernel (gemm_halo_bf16_kernel): the tile must be 256 / W whole rows of one image
+static bool halo_eligible(const LoadConvK& g, int N) {
+  const char* e = getenv("AOCR_NO_HALO");                      // read per call (A/B runs, parity tests against the im2col kernel)
+  if (e && e[0] == '1') return false;
+  const int W = g.Wr;
+  if (g.KW != 3 || g.W != g.Wr || g.H != g.Hr || (W != 32 && W != 64 && W != 128)) return false;
+  const int R = 256 / W;
+  if (g.Hr % R || (g.pmode != 0 && (R & 1)) || g.C % 32 || N % 256 || g.rows % 256 || g.K != 9 * g.C) return false;
+  return true;
+}
+template <int SGN, class EP>
+static void launch_halo(hipStream_t s, const LoadConvKh& a, const LoadKh& b, const EP& ep, int M, int N) {
+  const int gx = N / 256, gy = M / 256;
+  hipLaunchKernelGGL((gemm_halo_bf16_kernel<EP, SGN>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, gx, gy, zero_page());
+}
 // BK = 64 variant for bf16 K-contiguous operand pairs (conv forward / data gradient): half the barriers per FLOP
 template <class AL, class BL, class EP>
 [[maybe_unused]] static void launch_lds64(hipStream_t s, const AL& a, const BL& b, const EP& ep, int M, int N, int K) {
@@ -312,7 +327,8 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
   if (bf16 && xb && wb) {
     LoadConvKh ah; ah.src = xb; ah.g = a;
     LoadKh bh; bh.p = wb; bh.ld = a.K; bh.rows = Cout; bh.K = a.K;
-    if (dma_eligible(a.rows, Cout, a.K, Cin)) launch_dma(s, ah, bh, ep, a.rows, Cout, a.K, profile_tag);
+    if (dma_eligible(a.rows, Cout, a.K, Cin) && !profile_tag && pad == 1 && halo_eligible(a, Cout)) launch_halo<1>(s, ah, bh, ep, a.rows, Cout);
+    else if (dma_eligible(a.rows, Cout, a.K, Cin)) launch_dma(s, ah, bh, ep, a.rows, Cout, a.K, profile_tag);
     else if (dma_narrow_eligible(a.rows, Cout, a.K, Cin)) launch_dma_narrow(s, ah, bh, ep, a.rows, Cout, a.K);
     else launch_lds(s, ah, bh, ep, a.rows, Cout, a.K, 1);       // (BK = 64 variant measured no faster: launch_lds64)
   } else {
@@ -328,7 +344,8 @@ void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* 
   if (bf16 && dyb && wtb) {
     LoadConvKh ah; ah.src = dyb; ah.g = a;
     LoadKh bh; bh.p = wtb; bh.ld = a.K; bh.rows = Cin; bh.K = a.K;          // wtb [Cin][tap][Cout]: K-contiguous over (tap, co)
-    if (dma_eligible(a.rows, Cin, a.K, Cout)) launch_dma(s, ah, bh, ep, a.rows, Cin, a.K);
+    if (dma_eligible(a.rows, Cin, a.K, Cout) && pad == 1 && halo_eligible(a, Cin)) launch_halo<-1>(s, ah, bh, ep, a.rows, Cin);
+    else if (dma_eligible(a.rows, Cin, a.K, Cout)) launch_dma(s, ah, bh, ep, a.rows, Cin, a.K);
     else if (dma_narrow_eligible(a.rows, Cin, a.K, Cout)) launch_dma_narrow(s, ah, bh, ep, a.rows, Cin, a.K);
     else launch_lds(s, ah, bh, ep, a.rows, Cin, a.K, 1);
   } else if (wtf) {                                          // fp32 taps re-laid [Cin][tap][Cout]: K-contiguous dwordx4 loads
