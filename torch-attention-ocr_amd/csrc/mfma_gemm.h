@@ -401,17 +401,17 @@ struct LoadConvKh {
 struct LoadMNh {
   const bf16_t* p; int64_t ld; int rows; int K;
   struct Ctx8 { const bf16_t* b; bool ok; };
-  struct Cur { int k; };
+  struct Cur { int k; const bf16_t* q; };              // q = &element(r, k): advanced by 32 ld per tile (no multiply per load)
   __device__ __forceinline__ Ctx8 row8(int r) const { Ctx8 c; c.ok = r + 7 < rows; c.b = p + (c.ok ? r : 0); return c; }
-  __device__ __forceinline__ Cur seek(const Ctx8&, int k) const { Cur c; c.k = k; return c; }
-  __device__ __forceinline__ void advance(Cur& c) const { c.k += 32; }
+  __device__ __forceinline__ Cur seek(const Ctx8& c, int k) const { Cur u; u.k = k; u.q = c.b + (int64_t)k * ld; return u; }
+  __device__ __forceinline__ void advance(const Ctx8&, Cur& u) const { u.k += 32; u.q += 32 * ld; }
   __device__ __forceinline__ uint4 load8(const Ctx8& c, const Cur& u) const {        // 8 rows of ONE k
-    return (c.ok && u.k < K) ? *reinterpret_cast<const uint4*>(c.b + (int64_t)u.k * ld) : make_uint4(0, 0, 0, 0);
+    return (c.ok && u.k < K) ? *reinterpret_cast<const uint4*>(u.q) : make_uint4(0, 0, 0, 0);
   }
   __device__ __forceinline__ void load8x4(uint4 (&v)[4], const Ctx8& c, const Cur& u) const {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
-      v[kk] = (c.ok && u.k + kk < K) ? *reinterpret_cast<const uint4*>(c.b + (int64_t)(u.k + kk) * ld) : make_uint4(0, 0, 0, 0);
+      v[kk] = (c.ok && u.k + kk < K) ? *reinterpret_cast<const uint4*>(u.q + kk * ld) : make_uint4(0, 0, 0, 0);
   }
 };
 // filter-gradient B operand over a bf16 input map (same geometry as LoadConvXcol); 8 consecutive ci of one tap;
@@ -419,33 +419,40 @@ struct LoadMNh {
 struct LoadConvXcolh {
   const bf16_t* x; LoadConvXcol g;
   struct Ctx8 { int dy, dx, ci; bool ok; };     // dy = kh - pad, dx = kw - pad
-  struct Cur { int px, py, b, k; };
+  // p = &x[b, py + dy, px + dx, ci] (may point outside the map: never dereferenced then).  When the output grid is the input grid
+  // (Ho == H, Wo == W: every 3 x 3 / pad 1 layer) pixel k IS the raster index of the input pixel, so the address is linear in k and
+  // advance() is one pointer add -- the (b, y, x) -> address multiplies per piece and step cost the filter-gradient kernels as
+  // many VALU issue cycles as their MFMAs.
+  struct Cur { int px, py, b, k; const bf16_t* p; };
   __device__ __forceinline__ Ctx8 row8(int n) const {
     Ctx8 c; c.ok = n + 7 < g.N; int nn = c.ok ? n : 0; int tap = nn / g.Cin; c.ci = nn - tap * g.Cin;
     int kh = tap / g.KW; c.dy = kh - g.pad; c.dx = tap - kh * g.KW - g.pad; return c;
   }
-  __device__ __forceinline__ Cur seek(const Ctx8&, int k) const {
-    Cur c; c.k = k; c.px = k % g.Wo; int t = k / g.Wo; c.py = t % g.Ho; c.b = t / g.Ho; return c;
+  __device__ __forceinline__ const bf16_t* addr(const Ctx8& c, int b, int py, int px) const {
+    return x + (((int64_t)b * g.H + (py + c.dy)) * g.W + (px + c.dx)) * g.Cin + c.ci;
   }
-  __device__ __forceinline__ void advance(Cur& c) const {
-    c.k += 32; c.px += 32;
+  __device__ __forceinline__ Cur seek(const Ctx8& c, int k) const {
+    Cur u; u.k = k; u.px = k % g.Wo; int t = k / g.Wo; u.py = t % g.Ho; u.b = t / g.Ho; u.p = addr(c, u.b, u.py, u.px); return u;
+  }
+  __device__ __forceinline__ void advance(const Ctx8& c, Cur& u) const {
+    u.k += 32; u.px += 32;
     if (g.Wo >= 32) {                                   // at most one row wrap: no per-lane loop (uniform branch)
-      const int w = c.px >= g.Wo; c.px -= w ? g.Wo : 0; c.py += w;
-      const int w2 = c.py == g.Ho; c.py = w2 ? 0 : c.py; c.b += w2;
+      const int w = u.px >= g.Wo; u.px -= w ? g.Wo : 0; u.py += w;
+      const int w2 = u.py == g.Ho; u.py = w2 ? 0 : u.py; u.b += w2;
     } else {
-      while (c.px >= g.Wo) { c.px -= g.Wo; if (++c.py == g.Ho) { c.py = 0; ++c.b; } }
+      while (u.px >= g.Wo) { u.px -= g.Wo; if (++u.py == g.Ho) { u.py = 0; ++u.b; } }
     }
+    if (g.Ho == g.H && g.Wo == g.W) u.p += 32 * g.Cin; else u.p = addr(c, u.b, u.py, u.px);
+  }
+  __device__ __forceinline__ bool inside(const Ctx8& c, const Cur& u) const {
+    return c.ok && (unsigned)(u.py + c.dy) < (unsigned)g.H && (unsigned)(u.px + c.dx) < (unsigned)g.W;
   }
   // LDS-DMA staging (conv_wgrad_dma_kernel): source pointer of 8 channels of ONE pixel, zero page outside the map / past kend
   __device__ __forceinline__ const bf16_t* dsrc8(const Ctx8& c, const Cur& u, int kend, const bf16_t* zero) const {
-    int sy = u.py + c.dy, sx = u.px + c.dx;
-    bool ok = c.ok && u.k < kend && (unsigned)sy < (unsigned)g.H && (unsigned)sx < (unsigned)g.W;
-    return dma_select(ok, x + (((int64_t)u.b * g.H + sy) * g.W + sx) * g.Cin + c.ci, zero);
+    return dma_select(inside(c, u) && u.k < kend, u.p, zero);
   }
   __device__ __forceinline__ uint4 load8(const Ctx8& c, const Cur& u) const {        // 8 channels of ONE pixel
-    int sy = u.py + c.dy, sx = u.px + c.dx;
-    bool ok = c.ok && u.k < g.K && (unsigned)sy < (unsigned)g.H && (unsigned)sx < (unsigned)g.W;
-    return ok ? *reinterpret_cast<const uint4*>(x + (((int64_t)u.b * g.H + sy) * g.W + sx) * g.Cin + c.ci) : make_uint4(0, 0, 0, 0);
+    return (inside(c, u) && u.k < g.K) ? *reinterpret_cast<const uint4*>(u.p) : make_uint4(0, 0, 0, 0);
   }
   __device__ __forceinline__ void load8x4(uint4 (&v)[4], const Ctx8& c, const Cur& u) const {
     int px = u.px, py = u.py, b = u.b;
@@ -593,8 +600,8 @@ template <class LD> struct Stager<LD, 32, false, true> {
     active = (tid >> 7) == half; int t = tid & 127;
     k4 = (t & 7) * 4; row8 = (t >> 3) * 8; ctx = l.row8(base + row8); cur = l.seek(ctx, kbeg + k4);      // k-groups fastest: 2-way instead of 16-way write conflicts
   }
-  __device__ __forceinline__ void load(const LD& l) { if (active) { l.load8x4(reg, ctx, cur); l.advance(cur); } }
-  __device__ __forceinline__ void skip(const LD& l) { if (active) l.advance(cur); }
+  __device__ __forceinline__ void load(const LD& l) { if (active) { l.load8x4(reg, ctx, cur); l.advance(ctx, cur); } }
+  __device__ __forceinline__ void skip(const LD& l) { if (active) l.advance(ctx, cur); }
   __device__ __forceinline__ void store(unsigned char* tile) const {
     if (!active) return;
     const unsigned* w0 = reinterpret_cast<const unsigned*>(&reg[0]);
@@ -1174,12 +1181,14 @@ __device__ __forceinline__ void tr_tile(const LoadMNh& a, const BL& b, const EP&
   typename BL::Ctx8 cb = b.row8(n_blk + piece * 8);
   typename BL::Cur cur0 = b.seek(cb, kbeg + krow), cur1 = b.seek(cb, kbeg + krow + 16);
   int ka = kbeg + krow;
+  const bf16_t* pa = ca.b + (int64_t)ka * a.ld;          // running pointers: no multiply per load
+  const int64_t a16 = 16 * a.ld;
   uint4 ra[2], rb[2];
   auto gload = [&]() {
-    ra[0] = (ca.ok && ka < a.K) ? *reinterpret_cast<const uint4*>(ca.b + (int64_t)ka * a.ld) : make_uint4(0, 0, 0, 0);
-    ra[1] = (ca.ok && ka + 16 < a.K) ? *reinterpret_cast<const uint4*>(ca.b + (int64_t)(ka + 16) * a.ld) : make_uint4(0, 0, 0, 0);
+    ra[0] = (ca.ok && ka < a.K) ? *reinterpret_cast<const uint4*>(pa) : make_uint4(0, 0, 0, 0);
+    ra[1] = (ca.ok && ka + 16 < a.K) ? *reinterpret_cast<const uint4*>(pa + a16) : make_uint4(0, 0, 0, 0);
     rb[0] = b.load8(cb, cur0); rb[1] = b.load8(cb, cur1);
-    ka += 32; b.advance(cur0); b.advance(cur1);
+    ka += 32; pa += 2 * a16; b.advance(cb, cur0); b.advance(cb, cur1);
   };
   auto lwrite = [&](int buf) {
     *reinterpret_cast<uint4*>(&lds[buf][0][krow * TR_PITCH + piece * 16]) = ra[0];
@@ -1263,7 +1272,7 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_kernel(LoadMNh a, LoadCo
 // pixel rows one transposed read touches then sit in four different quarters of the 256-byte bank row.
 // The im2col operand's piece addresses are per lane: (tap, ci) is a lane constant, the pixel cursor advances by 32.
 // ---------------------------------------------------------------------------
-template <class EP>
+template <class EP, int ABL = 0>                        // ABL: timing-only ablations (tools/ubench/wgrad_dma.hip): 1 no in-loop DMA, 2 no MFMA, 4 no fragment reads, 16 / 128 d y / x pieces from the zero page
 __global__ __launch_bounds__(512, 1) void conv_wgrad_dma_kernel(LoadMNh a, LoadConvXcolh b, EP ep, int K, int kper, int gx, int gy, const bf16_t* zero, int gz) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 32768];          // the ONLY LDS object
   // (Round 1 gave every XCD its own K range with 36 tiles on its 32 CUs, i.e. two rounds: 1.5-2.5x slower.)
@@ -1296,19 +1305,21 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_dma_kernel(LoadMNh a, LoadC
     ca[j] = a.row8(m_blk + 8 * chunk[j]); cb[j] = b.row8(n_blk + 8 * chunk[j]);
     cur[j] = b.seek(cb[j], kbeg + krow[j]); ka[j] = kbeg + krow[j];
   }
+  const bf16_t* pa[2]; const int64_t astep = 32 * a.ld;   // running source pointers of the d y pieces (no multiply per piece and step)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) pa[j] = ca[j].b + (int64_t)ka[j] * a.ld;
   unsigned char* const wbase = lds + (2 * wave) * 1024;
   int slot = 0;
   auto issue = [&]() {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const bf16_t* pa = dma_select(ca[j].ok && ka[j] < kend, ca[j].b + (int64_t)ka[j] * a.ld, zero);
-      dma16(pa, wbase + slot * 32768 + j * 1024);
-      ka[j] += 32;
+      dma16((ABL & 16) ? zero : dma_select(ca[j].ok && ka[j] < kend, pa[j], zero), wbase + slot * 32768 + j * 1024);
+      ka[j] += 32; pa[j] += astep;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      dma16(b.dsrc8(cb[j], cur[j], kend, zero), wbase + slot * 32768 + 16384 + j * 1024);
-      b.advance(cur[j]);
+      dma16((ABL & 128) ? zero : b.dsrc8(cb[j], cur[j], kend, zero), wbase + slot * 32768 + 16384 + j * 1024);
+      b.advance(cb[j], cur[j]);
     }
     slot = (slot + 1) & 3;
   };
@@ -1330,38 +1341,54 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_dma_kernel(LoadMNh a, LoadC
 #pragma unroll
   for (int i = 0; i < 2; ++i) bseg[i] = 16384 + rowoff + (((wn * 2 + i) ^ q) << 6);
 
+  // The transposed reads are inline asm with a hand-placed lgkmcnt wait: behind the builtin (__builtin_amdgcn_ds_read_tr16_b64) hipcc
+  // put `s_waitcnt vmcnt(0)` in front of the first read of every step -- it orders LDS reads behind ALL pending LDS-DMA -- which
+  // drained the two tiles in flight, i.e. every step paid a full DMA round trip (found in the ISA; the kernel ran 1.37 us per
+  // step against 1.04 for the forward kernel).  The wait asm takes the fragments as in/out operands so that no MFMA moves above it.
+  typedef unsigned long long u64;
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
+#define AOCR_TRR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
 #pragma unroll
   for (int t = 0; t < 3; ++t) issue();
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // this wave's pieces of tile kt have landed (two later tiles in flight)
     __builtin_amdgcn_s_barrier();                       // ... everyone's have, and everyone is done reading tile kt-1
-    const unsigned char* L = lds + (kt & 3) * 32768;
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    bf16x8 af[2][4], bf[2][2];
+    const unsigned sl = lbase + (kt & 3) * 32768;
+    u64 fa[2][4][2], fb[2][2][2];                       // [k half][tile][low / high four k]
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        s16x4 lo = lds_tr_read(L + aseg[i] + (16 * s2) * 512), hi = lds_tr_read(L + aseg[i] + (16 * s2 + 4) * 512);
-        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        af[s2][i] = __builtin_bit_cast(bf16x8, v);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        s16x4 lo = lds_tr_read(L + bseg[i] + (16 * s2) * 512), hi = lds_tr_read(L + bseg[i] + (16 * s2 + 4) * 512);
-        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bf[s2][i] = __builtin_bit_cast(bf16x8, v);
-      }
+    for (int i = 0; i < 4; ++i) {
+      const unsigned ad = sl + aseg[i];
+      if constexpr (ABL & 4) { fa[0][i][0] = fa[0][i][1] = fa[1][i][0] = fa[1][i][1] = ad; continue; }
+      AOCR_TRR(fa[0][i][0], ad, 0); AOCR_TRR(fa[0][i][1], ad, 2048); AOCR_TRR(fa[1][i][0], ad, 8192); AOCR_TRR(fa[1][i][1], ad, 10240);
     }
-    issue();                                            // tile kt+3 -> the slot of tile kt-1
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned ad = sl + bseg[i];
+      if constexpr (ABL & 4) { fb[0][i][0] = fb[0][i][1] = fb[1][i][0] = fb[1][i][1] = ad; continue; }
+      AOCR_TRR(fb[0][i][0], ad, 0); AOCR_TRR(fb[0][i][1], ad, 2048); AOCR_TRR(fb[1][i][0], ad, 8192); AOCR_TRR(fb[1][i][1], ad, 10240);
+    }
+    if constexpr (!(ABL & 1)) issue();                  // tile kt+3 -> the slot of tile kt-1
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]), "+v"(fa[0][2][0]), "+v"(fa[0][2][1]),
+                   "+v"(fa[0][3][0]), "+v"(fa[0][3][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][1][0]), "+v"(fb[0][1][1])
+                 :: "memory");
+    asm volatile(""
+                 : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]), "+v"(fa[1][2][0]), "+v"(fa[1][2][1]),
+                   "+v"(fa[1][3][0]), "+v"(fa[1][3][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][1][0]), "+v"(fb[1][1][1])
+                 :: "memory");
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s2][mi], bf[s2][ni], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < 2; ++ni) {
+          const u64x2 av = {fa[s2][mi][0], fa[s2][mi][1]}, bv = {fb[s2][ni][0], fb[s2][ni][1]};
+          if constexpr (ABL & 2) { acc[mi][ni][0] += (float)(unsigned)(av[0] ^ bv[1]); continue; }
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[mi][ni], 0, 0, 0);
+        }
   }
+#undef AOCR_TRR
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   const int r = lane & 31;
   const int m0 = m_blk + wm * 128, n0 = n_blk + wn * 64;
