@@ -923,34 +923,40 @@ void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t
 //   all 64 banks once; a tap's dy only toggles bit 1 of s (address ^ 32), its dx picks one of three precomputed lane addresses.
 //   Every step issues exactly 3 DMA instructions per wave (1 halo piece -- a dummy into a dump page once the next halo is
 //   complete -- and 2 weight pieces), so the counted wait is uniform: vmcnt(6) = the pieces of this step's weight tile landed.
-// Shapes: W in {32, 64, 128}, H % R == 0 (R even under the pooled orders), C % 32 == 0, N % 256 == 0; SGN = +1 forward, -1 data gradient.
+// Shapes: W in {32, 64, 128}, H % R == 0 (R even under the pooled orders), C % 32 == 0, N % NT == 0; SGN = +1 forward, -1 data gradient.
 // ---------------------------------------------------------------------------
-constexpr int HALO_MAX = 36864;                        // bytes of one halo buffer: (R + 2) * (W + 16) * 64 <= 4 * 144 * 64
-constexpr int HALO_BRING = 2 * HALO_MAX, HALO_DUMP = HALO_BRING + 4 * 16384, HALO_LDS = HALO_DUMP + 8 * 1024;
+// Tile shapes MT x NT (8 waves, every wave 32 MI x 64 outputs): 256 x 256 (2 x 4 waves, MI = 4) for layers with >= 256 output columns;
+// 512 x 128 (4 x 2, MI = 4) and 512 x 64 (8 x 1, MI = 2) for the narrow layers (conv2 forward, the data gradients of conv2 / conv3),
+// whose im2col stream is 4-9x their weight stream: there the halo cuts the L2 -> LDS bytes per step from 32 + 8 KB to 6 + 8 KB.
+template <int MT> struct HaloGeom { static constexpr int HMAX = MT == 256 ? 36864 : 55296; };   // one halo buffer: (R + 2) (W + 16) 64 B for W in {32, 64, 128}
 
-template <class EP, int SGN>
+template <class EP, int SGN, int MT, int NT>
 __global__ __launch_bounds__(512, 1)
 void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const bf16_t* zero) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[HALO_LDS];           // the ONLY LDS object (a second one makes hipcc drain vmcnt)
+  constexpr int HMAX = HaloGeom<MT>::HMAX, BSLOT = NT * 64, BRING = 2 * HMAX, DUMP = BRING + 4 * BSLOT, LDS_BYTES = DUMP + 8 * 1024;
+  constexpr int NWN = NT / 64, NWM = 8 / NWN, WM = MT / NWM, MI = WM / 32;          // wave grid and wave tile (WM x 64)
+  constexpr int NBW = NT >= 128 ? NT / 128 : 1;          // weight pieces per wave and step (NT = 64: waves 4-7 issue a dummy)
+  static_assert(MI == 4 || MI == 2, "wave tile");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];          // the ONLY LDS object (a second one makes hipcc drain vmcnt)
   const int nwg = gx * gy, orig = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
   const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int m_blk = (bid / gx) * 256, n_blk = (bid % gx) * 256;
+  const int m_blk = (bid / gx) * MT, n_blk = (bid % gx) * NT;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5, wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 31, h = lane >> 5, wm = wave / NWN, wn = wave % NWN;
   const LoadConvK& g = a.g;
-  const int W = g.Wr, H = g.Hr, C = g.C, P = W + 16, R = 256 / W;
+  const int W = g.Wr, H = g.Hr, C = g.C, P = W + 16, R = MT / W;
   const int NG = (R + 2) * (P >> 4);                     // 16-pixel DMA groups of one halo
-  const int NC = C >> 5, NT = 9 * NC;                    // channel chunks, K steps
+  const int NC = C >> 5, NT9 = 9 * NC;                   // channel chunks, K steps
   const LoadConvK::Ctx c0 = g.row(m_blk);                // first pixel of the tile: (b, y0, 0)
   const int y0 = __builtin_amdgcn_readfirstlane(c0.y);
   const bf16_t* const img = a.src + (int64_t)__builtin_amdgcn_readfirstlane(c0.b) * H * W * C;
 
   // ---- fragment addresses: abase[mi][dxi] = byte offset of (halo row ty, col tx + dxi) for k-chunk h, i.e. tap dy = -1, dx = dxi - 1
-  unsigned abase[4][3];
+  unsigned abase[MI][3];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int local = wm * 128 + mi * 32 + r;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int local = wm * WM + mi * 32 + r;
     int ty, tx;
     if (g.pmode == 1) { const int win = local >> 2, wx = win % g.Wp; ty = 2 * (win / g.Wp) + ((local >> 1) & 1); tx = 2 * wx + (local & 1); }
     else if (g.pmode == 2) { const int win = local >> 1; tx = win % W; ty = 2 * (win / W) + (local & 1); }
@@ -964,13 +970,14 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
   const int swzb = (r >> 2) & 3;
   unsigned boff[2];
 #pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) boff[s2] = HALO_BRING + (wn * 64 + r) * 64 + (((2 * s2 + h) ^ swzb) << 4);
+  for (int s2 = 0; s2 < 2; ++s2) boff[s2] = BRING + (wn * 64 + r) * 64 + (((2 * s2 + h) ^ swzb) << 4);
 
   // ---- weight staging (as in gemm_dma_bf16_kernel): rows (tid >> 2) + 128 j, position tid & 3 holds k-chunk (tid & 3) ^ ((tid >> 4) & 3)
   const int srow = tid >> 2, bchunk = (tid & 3) ^ ((tid >> 4) & 3);
-  LoadKh::DRow rb[2];
+  const bool bwave = NT >= 128 || wave < 4;              // NT = 64: rows 0..63 are waves 0-3
+  LoadKh::DRow rb[NBW];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) rb[j] = b.drow(n_blk + 128 * j + srow, bchunk);
+  for (int j = 0; j < NBW; ++j) rb[j] = b.drow(n_blk + 128 * j + srow, bchunk);
   unsigned char* const wbase = lds + wave * 1024;
   // ---- halo staging: group gq = 16 pixels of one halo row; lane -> pixel (lane >> 2), position lane & 3
   const int hx = (lane >> 2) - 1, hchunk = (lane & 3) ^ ((lane >> 4) & 3);
@@ -979,19 +986,20 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
     const int y = y0 - 1 + row, x = col0 + hx;
     const bool ok = real && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
     const bf16_t* src = img + ((int64_t)(y * W + x) * C + (chunk << 5) + ((hchunk ^ ((row & 1) << 1)) << 3));
-    dma16(dma_select(ok, src, zero), real ? lds + (chunk & 1) * HALO_MAX + gq * 1024 : lds + HALO_DUMP + wave * 1024);
+    dma16(dma_select(ok, src, zero), real ? lds + (chunk & 1) * HMAX + gq * 1024 : lds + DUMP + wave * 1024);
   };
   auto issue_b = [&](int step) {                         // weight tile of K step `step` (chunk-major): k = tap * C + 32 chunk
     const int chunk = step / 9, tap = step - chunk * 9;
-    const int k = step < NT ? tap * C + (chunk << 5) : b.K;            // past the end: zero page
+    const int k = step < NT9 ? tap * C + (chunk << 5) : b.K;           // past the end: zero page
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      dma16(dma_select(rb[j].b != nullptr && k < b.K, rb[j].b + k, zero), wbase + HALO_BRING + (step & 3) * 16384 + j * 8192);
+    for (int j = 0; j < NBW; ++j)
+      dma16(dma_select(bwave && rb[j].b != nullptr && k < b.K, rb[j].b + k, zero),
+            bwave ? wbase + BRING + (step & 3) * BSLOT + j * 8192 : lds + DUMP + wave * 1024);
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1004,19 +1012,20 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
 
   int step = 0;
   for (int chunk = 0; chunk < NC; ++chunk) {
-    const unsigned hb = (chunk & 1) * HALO_MAX;
+    const unsigned hb = (chunk & 1) * HMAX;
     for (int kh = 0; kh < 3; ++kh) {
       const int dyi = SGN > 0 ? kh : 2 - kh;             // halo row offset of this tap: dy + 1
       const unsigned U = hb + (unsigned)(dyi * P) * 64u, flip = (dyi & 1) << 5;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw, ++step) {
         const int dxi = SGN > 0 ? kw : 2 - kw;
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // this wave's pieces of this step's weight tile (and of everything older) have landed
+        // this wave's pieces of this step's weight tile (and of everything older) have landed: 2 steps x (1 + NBW) pieces may be pending
+        if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // ... everyone's have, and everyone is done reading the previous step
-        const unsigned char* Lb = lds + (step & 3) * 16384;
-        bf16x8 af[2][4], bf[2][2];
+        const unsigned char* Lb = lds + (step & 3) * BSLOT;
+        bf16x8 af[2][MI], bf[2][2];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
           const unsigned a0 = (abase[mi][dxi] + U) ^ flip;
           af[0][mi] = *reinterpret_cast<const bf16x8*>(lds + a0);
           af[1][mi] = *reinterpret_cast<const bf16x8*>(lds + (a0 ^ 32u));
@@ -1030,13 +1039,13 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
           issue_halo(gq < NG ? gq : 0, chunk + 1, gq < NG && chunk + 1 < NC);
         }
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], bf[0][ni], acc[mi][ni], 0, 0, 0);
         issue_b(step + 3);                                // -> the slot of the previous step
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][mi], bf[1][ni], acc[mi][ni], 0, 0, 0);
@@ -1044,9 +1053,9 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the trailing (zero-page) pieces must land before the LDS is released
-  const int m0 = m_blk + wm * 128, n0 = n_blk + wn * 64;
+  const int m0 = m_blk + wm * WM, n0 = n_blk + wn * 64;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float v[2][4];

@@ -51,21 +51,24 @@ static void launch_dma(hipStream_t s, const AL& a, const BL& b, const EP& ep, in
   if (tag) hipLaunchKernelGGL((gemm_dma_bf16_kernel<AL, BL, EP, 0, false, false, 1>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page());
   else hipLaunchKernelGGL((gemm_dma_bf16_kernel<AL, BL, EP>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page());
 }
-// halo-resident 3 x 3 kernel (gemm_halo_bf16_kernel): the tile must be 256 / W whole rows of one image
-static bool halo_eligible(const LoadConvK& g, int N) {
-  const char* e = getenv("AOCR_NO_HALO");                      // read per call (A/B runs, parity tests against the im2col kernel)
+// halo-resident 3 x 3 kernel (gemm_halo_bf16_kernel): the tile must be MT / W whole rows of one image
+static bool halo_eligible(const LoadConvK& g, int N, int MT, int NT) {
+  const char* e = getenv("AOCR_NO_HALO");                      // read per call (A/B runs, parity tests against the im2col kernels)
   if (e && e[0] == '1') return false;
   const int W = g.Wr;
   if (g.KW != 3 || g.W != g.Wr || g.H != g.Hr || (W != 32 && W != 64 && W != 128)) return false;
-  const int R = 256 / W;
-  if (g.Hr % R || (g.pmode != 0 && (R & 1)) || g.C % 32 || N % 256 || g.rows % 256 || g.K != 9 * g.C) return false;
+  const int R = MT / W;
+  if (g.Hr % R || (g.pmode != 0 && (R & 1)) || g.C % 32 || N % NT || g.rows % MT || g.K != 9 * g.C) return false;
   return true;
 }
-template <int SGN, class EP>
+template <int SGN, int MT, int NT, class EP>
 static void launch_halo(hipStream_t s, const LoadConvKh& a, const LoadKh& b, const EP& ep, int M, int N) {
-  const int gx = N / 256, gy = M / 256;
-  hipLaunchKernelGGL((gemm_halo_bf16_kernel<EP, SGN>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, gx, gy, zero_page());
+  const int gx = N / NT, gy = M / MT;
+  hipLaunchKernelGGL((gemm_halo_bf16_kernel<EP, SGN, MT, NT>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, gx, gy, zero_page());
 }
+// (512 x 128 / 512 x 64 instantiations for the narrow layers -- conv2 forward, the data gradients of conv2 / conv3 -- were measured
+// no faster than gemm_dma_narrow_kernel: 121 / 139 / 99 us against 103 / 137 / 102: with 8-16 MFMAs per wave and step those launches
+// are bound by the per-step barrier + issue overhead and by their epilogues, which two workgroups per CU overlap, not by the im2col stream.)
 // BK = 64 variant for bf16 K-contiguous operand pairs (conv forward / data gradient): half the barriers per FLOP
 template <class AL, class BL, class EP>
 [[maybe_unused]] static void launch_lds64(hipStream_t s, const AL& a, const BL& b, const EP& ep, int M, int N, int K) {
@@ -327,7 +330,7 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
   if (bf16 && xb && wb) {
     LoadConvKh ah; ah.src = xb; ah.g = a;
     LoadKh bh; bh.p = wb; bh.ld = a.K; bh.rows = Cout; bh.K = a.K;
-    if (dma_eligible(a.rows, Cout, a.K, Cin) && !profile_tag && pad == 1 && halo_eligible(a, Cout)) launch_halo<1>(s, ah, bh, ep, a.rows, Cout);
+    if (dma_eligible(a.rows, Cout, a.K, Cin) && !profile_tag && pad == 1 && halo_eligible(a, Cout, 256, 256)) launch_halo<1, 256, 256>(s, ah, bh, ep, a.rows, Cout);
     else if (dma_eligible(a.rows, Cout, a.K, Cin)) launch_dma(s, ah, bh, ep, a.rows, Cout, a.K, profile_tag);
     else if (dma_narrow_eligible(a.rows, Cout, a.K, Cin)) launch_dma_narrow(s, ah, bh, ep, a.rows, Cout, a.K);
     else launch_lds(s, ah, bh, ep, a.rows, Cout, a.K, 1);       // (BK = 64 variant measured no faster: launch_lds64)
@@ -344,7 +347,7 @@ void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* 
   if (bf16 && dyb && wtb) {
     LoadConvKh ah; ah.src = dyb; ah.g = a;
     LoadKh bh; bh.p = wtb; bh.ld = a.K; bh.rows = Cin; bh.K = a.K;          // wtb [Cin][tap][Cout]: K-contiguous over (tap, co)
-    if (dma_eligible(a.rows, Cin, a.K, Cout) && pad == 1 && halo_eligible(a, Cin)) launch_halo<-1>(s, ah, bh, ep, a.rows, Cin);
+    if (dma_eligible(a.rows, Cin, a.K, Cout) && pad == 1 && halo_eligible(a, Cin, 256, 256)) launch_halo<-1, 256, 256>(s, ah, bh, ep, a.rows, Cin);
     else if (dma_eligible(a.rows, Cin, a.K, Cout)) launch_dma(s, ah, bh, ep, a.rows, Cin, a.K);
     else if (dma_narrow_eligible(a.rows, Cin, a.K, Cout)) launch_dma_narrow(s, ah, bh, ep, a.rows, Cin, a.K);
     else launch_lds(s, ah, bh, ep, a.rows, Cin, a.K, 1);
