@@ -930,7 +930,7 @@ void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t
 // whose im2col stream is 4-9x their weight stream: there the halo cuts the L2 -> LDS bytes per step from 32 + 8 KB to 6 + 8 KB.
 template <int MT> struct HaloGeom { static constexpr int HMAX = MT == 256 ? 36864 : 55296; };   // one halo buffer: (R + 2) (W + 16) 64 B for W in {32, 64, 128}
 
-template <class EP, int SGN, int MT, int NT>
+template <class EP, int SGN, int MT, int NT, int TAG = 0>          // TAG: distinct symbol for aocr_profile_kernel's launches (their own row in rocprofv3 --stats)
 __global__ __launch_bounds__(512, 1)
 void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const bf16_t* zero) {
   constexpr int HMAX = HaloGeom<MT>::HMAX, BSLOT = NT * 64, BRING = 2 * HMAX, DUMP = BRING + 4 * BSLOT, LDS_BYTES = DUMP + 8 * 1024;

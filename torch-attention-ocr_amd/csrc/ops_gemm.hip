@@ -62,9 +62,10 @@ static bool halo_eligible(const LoadConvK& g, int N, int MT, int NT) {
   return true;
 }
 template <int SGN, int MT, int NT, class EP>
-static void launch_halo(hipStream_t s, const LoadConvKh& a, const LoadKh& b, const EP& ep, int M, int N) {
+static void launch_halo(hipStream_t s, const LoadConvKh& a, const LoadKh& b, const EP& ep, int M, int N, int tag = 0) {
   const int gx = N / NT, gy = M / MT;
-  hipLaunchKernelGGL((gemm_halo_bf16_kernel<EP, SGN, MT, NT>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, gx, gy, zero_page());
+  if (tag) hipLaunchKernelGGL((gemm_halo_bf16_kernel<EP, SGN, MT, NT, 1>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, gx, gy, zero_page());
+  else hipLaunchKernelGGL((gemm_halo_bf16_kernel<EP, SGN, MT, NT>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, gx, gy, zero_page());
 }
 // (512 x 128 / 512 x 64 instantiations for the narrow layers -- conv2 forward, the data gradients of conv2 / conv3 -- were measured
 // no faster than gemm_dma_narrow_kernel: 121 / 139 / 99 us against 103 / 137 / 102: with 8-16 MFMAs per wave and step those launches
@@ -244,7 +245,13 @@ int gemm(hipStream_t s, bool bf16, const float* A, int64_t lda, bool a_k, const 
           int64_t ldc, int M, int N, int K, const float* bias, const float* bias2, int flags) {
   EpStore ep = make_store(C, ldc, M, N, bias, bias2, flags);
   int ks = (flags & EP_ATOMIC) ? pick_ksplit(M, N, K, bf16) : 1;
-  if (a_k && b_k) launch_big_kk(s, bf16, make_loadk(A, lda, M, K), make_loadk(B, ldb, N, K), ep, M, N, K, ks);
+  // skinny products (a 20- or 39-wide side: embedding part of the first decoder layer, projector and their backward): 128 x 128 tiles
+  // give 48 workgroups for 6144 rows and pad N or K 3-6x; the 32 x 32 step kernel (K quartered over its waves) fills the chip
+  // (only where K is a multiple of the step kernel's 16-deep chunk: its fragment loads have no K tail)
+  const bool skinny = bf16 && M >= 1024 && N <= 64 && K % 16 == 0 && !getenv("AOCR_NO_SKINNY");     // (an EP_ATOMIC epilogue stays atomic: one add per element, no split-K)
+  if (skinny && a_k && b_k) { SmallKKArgs z; z.a = make_loadk(A, lda, M, K); z.b = make_loadk(B, ldb, N, K); z.ep = ep; z.K = K; launch_small_kk(s, true, 1, &z, M, N); }
+  else if (skinny && a_k && !b_k) { SmallKMNArgs z; z.a = make_loadk(A, lda, M, K); z.b = make_loadmn(B, ldb, N, K); z.ep = ep; z.K = K; launch_small_kmn(s, true, 1, &z, M, N); }
+  else if (a_k && b_k) launch_big_kk(s, bf16, make_loadk(A, lda, M, K), make_loadk(B, ldb, N, K), ep, M, N, K, ks);
   else if (a_k && !b_k) launch_big_kmn(s, bf16, make_loadk(A, lda, M, K), make_loadmn(B, ldb, N, K), ep, M, N, K, ks);
   else if (!a_k && !b_k) launch_big_mnmn(s, bf16, make_loadmn(A, lda, M, K), make_loadmn(B, ldb, N, K), ep, M, N, K, ks);
   else return -1;   // A^T * B^T never occurs on the hot path
@@ -330,7 +337,7 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
   if (bf16 && xb && wb) {
     LoadConvKh ah; ah.src = xb; ah.g = a;
     LoadKh bh; bh.p = wb; bh.ld = a.K; bh.rows = Cout; bh.K = a.K;
-    if (dma_eligible(a.rows, Cout, a.K, Cin) && !profile_tag && pad == 1 && halo_eligible(a, Cout, 256, 256)) launch_halo<1, 256, 256>(s, ah, bh, ep, a.rows, Cout);
+    if (dma_eligible(a.rows, Cout, a.K, Cin) && pad == 1 && halo_eligible(a, Cout, 256, 256)) launch_halo<1, 256, 256>(s, ah, bh, ep, a.rows, Cout, profile_tag);
     else if (dma_eligible(a.rows, Cout, a.K, Cin)) launch_dma(s, ah, bh, ep, a.rows, Cout, a.K, profile_tag);
     else if (dma_narrow_eligible(a.rows, Cout, a.K, Cin)) launch_dma_narrow(s, ah, bh, ep, a.rows, Cout, a.K);
     else launch_lds(s, ah, bh, ep, a.rows, Cout, a.K, 1);       // (BK = 64 variant measured no faster: launch_lds64)
