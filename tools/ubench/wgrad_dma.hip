@@ -56,6 +56,11 @@ int main() {
     run<128>(a, b, ep, P, N, Cout, zero, "x pieces from the zero page");
     run<144>(a, b, ep, P, N, Cout, zero, "both from the zero page");
     run<0>(a, b, ep, P, N, Cout, zero, "full kernel");
+    { EpStore e2 = ep; e2.flags = 0; run<7>(a, b, e2, P, N, Cout, zero, "barrier + epilogue only, plain stores");
+      run<0>(a, b, e2, P, N, Cout, zero, "full kernel, plain stores");
+      LoadMNh a1 = a; LoadConvXcolh b1 = b; const int P1 = 32 * (256 / ((N / 256) * (Cout / 256)));
+      run<7>(a1, b1, ep, P1, N, Cout, zero, "one step per workgroup: prologue + atomic epilogue");
+      run<7>(a1, b1, e2, P1, N, Cout, zero, "one step per workgroup: prologue + plain-store epilogue"); }
     CK(hipFree(x)); CK(hipFree(dy)); CK(hipFree(dw)); CK(hipFree(zero));
   }
   return 0;
