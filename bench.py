@@ -266,7 +266,7 @@ def main():
         sync()
         eld = (time.perf_counter() - t0) / args.decode_steps
         Hd, T = 2 * wl["He"], W // 4 - 1
-        dec = {"chars_per_s": world * B * 50 / eld, "what": "decoder steps/s: B*50 per call, beam pass + gold pass (model.lua:376-627)",
+        dec = {"chars_per_s": world * B * 50 / eld, "what": "decoder steps/s: B*50 per call = one -phase test call of the reference, beam pass over max_decoder_l = 50 steps + gold pass (model.lua:376-627; the gold pass runs the steps the targets span -- its all-PAD steps add nothing to any output)",
                "emitted_chars_per_s": world * nnz / eld, "ms_per_call": 1e3 * eld}
         if rank == 0:
             fam = m.profile_families(lambda: m.decode_device(images, targets, targets_eval, 1), repeats=2)

@@ -332,11 +332,14 @@ int aocr_decode_dict(aocr_model* m, const float* images_dev, const int32_t* targ
   encoder_forward(m, d);
   prof_mark(m, AOCR_PROF_DECODE);
   decode_beam(m, d, m->tgt_pad, beam, labels_dev, scores_dev, trie);
-  // gold pass, model.lua:589-627
+  // gold pass, model.lua:589-627.  The reference runs it over all max_decoder_l steps of the PAD-filled target (model.lua:266-274); a step
+  // whose targets are all PAD adds nothing to the loss (criterion weight 0, criterion.lua:4-5) nor to the gold scores (model.lua:614-618)
+  // and no later code reads the decoder state, so the L steps the caller's targets span give identical outputs.
+  d.L = L < Lt ? L : Lt;
   decoder_tf_forward(m, d, m->tgt_pad, 1, Lt, false);
   prof_mark(m, AOCR_PROF_OTHER);
   loss_and_dlogits(m, d, m->tge_pad, 1, Lt, 0.f, false, loss_dev);
-  if (gold_scores_dev) gold_scores(m->s, m->nll_rows, gold_scores_dev, Lt, B);
+  if (gold_scores_dev) gold_scores(m->s, m->nll_rows, gold_scores_dev, d.L, B);
   prof_mark(m, -1);
   m->last = d; m->last_valid = 1;
   return check_launch(trie ? "aocr_decode_dict" : "aocr_decode");

@@ -95,7 +95,7 @@ struct aocr_model {
   int last_valid;
   // cluster encoder kernels (rnn_cluster.hip): exchange buffers, error flag, launch epoch (tags = epoch * 4096 + step)
   unsigned long long *cl_xbuf = nullptr, *cl_pbuf = nullptr, *cl_xtab = nullptr; int* cl_err = nullptr; size_t cl_xbytes = 0, cl_pbytes = 0; unsigned cl_epoch = 0;
-  unsigned long long *dc_xbuf = nullptr, *dc_xtab = nullptr; size_t dc_xbytes = 0, dc_tbytes = 0; aocr::bf16_t* ctxa_b = nullptr; bool dgates_il = false; unsigned long long* dc_bxbuf = nullptr; size_t dc_bxbytes = 0; float* dc_pbuf = nullptr;
+  unsigned long long *dc_xbuf = nullptr, *dc_xtab = nullptr; size_t dc_xbytes = 0, dc_tbytes = 0; aocr::bf16_t* ctxa_b = nullptr; bool ctxa_fresh = false; /* ctxa_b holds ctx W_a of the CURRENT context (set by the beam pass, consumed by the gold pass of the same decode call) */ bool dgates_il = false; unsigned long long* dc_bxbuf = nullptr; size_t dc_bxbytes = 0; float* dc_pbuf = nullptr;
   // nn.Dropout (LSTM.lua:68-69,116-118), training only: p, threshold ceil(p 2^53), seed, train-step counter; masked copies of the
   // inputs of the layers above the first (decoder per step: dhm, encoder per layer: ehm)
   double drop_p = 0.0; unsigned long long drop_thr = 0, drop_seed = 0, drop_step = 0; bool drop_on = false;

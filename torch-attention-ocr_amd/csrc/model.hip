@@ -414,6 +414,7 @@ static DropSpec drop_site(const aocr_model* m, int site, long long off) {
 }
 
 void encoder_forward(aocr_model* m, const Dims& d) {
+  m->ctxa_fresh = false;                                             // new context
   hipStream_t s = m->s; const bool bf = m->bf16;
   const int B = d.B, T = d.T, He = m->He, Hd = m->Hd;
   const size_t slot = (size_t)B * He;
@@ -708,7 +709,8 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
   const bool drop = keep_gates && m->drop_on;                       // training only
   if (sh && !drop && dec_cluster_ok(m, T, L)) {
     // scores against the pre-multiplied context: ctx[t] . (W_a h) = (ctx W_a)[t] . h, LSTM.lua:131-137
-    gemm_hh_shadow(s, m->context_b, Hd, m->swa.wtb, Hd, m->dctx, Hd, m->ctxa_b, Hd, B * T, Hd, Hd);
+    if (!m->ctxa_fresh) gemm_hh_shadow(s, m->context_b, Hd, m->swa.wtb, Hd, m->dctx, Hd, m->ctxa_b, Hd, B * T, Hd, Hd);
+    m->ctxa_fresh = false;
     DecClFwdArgs a; a.B = B; a.T = T; a.L = L; a.epoch = next_epoch(m);
     a.w1i = m->dec[0].swi.wb; a.w1h = m->dec[0].swh.wb; a.w2i = m->dec[1].swi.wb; a.w2h = m->dec[1].swh.wb; a.wc = m->swc.wb;
     a.b2i = m->dec[1].bi; a.b2h = m->dec[1].bh; a.zx1 = m->zx1_all; a.ctxb = m->context_b; a.ctxa = m->ctxa_b;
@@ -912,6 +914,7 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
     dec_init_state(m, d, tc0, th0, m->out_all, B, true);
     const size_t slot = (size_t)B * Hd; (void)slot;
     gemm_hh_shadow(s, m->context_b, Hd, m->swa.wtb, Hd, m->dctx, Hd, m->ctxa_b, Hd, B * T, Hd, Hd);
+    m->ctxa_fresh = true;                                            // the gold pass of this call scores against the same context
     DecClFwdArgs a; a.B = B; a.T = T; a.L = Lt; a.epoch = next_epoch(m);
     a.w1i = m->dec[0].swi.wb; a.w1h = m->dec[0].swh.wb; a.w2i = m->dec[1].swi.wb; a.w2h = m->dec[1].swh.wb; a.wc = m->swc.wb;
     a.b2i = m->dec[1].bi; a.b2h = m->dec[1].bh; a.zx1 = m->bzx_tab; a.ctxb = m->context_b; a.ctxa = m->ctxa_b;
