@@ -569,7 +569,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const int C4 = C >> 2;                                // one channel quad per thread and iteration (16-byte accesses)
   const int64_t total = rows * C4;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+  // rows are walked from the END: the partial-sum pass that ran just before read x / dA / y front to back (301 MB at conv3: more than the
+  // 256 MB Infinity Cache), so its tail is what is still cached
+  const int64_t stride = (int64_t)gridDim.x * 256, first = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t niter = first < total ? (total - 1 - first) / stride + 1 : 0;
+  for (int64_t it = niter - 1; it >= 0; --it) {
+    const int64_t id = first + it * stride;
     const int c = (int)(id % C4) * 4; const int64_t r = id / C4;
     int64_t ro = r;
     if (tb_rows > 0) { int64_t bi = r / T, t = r - bi * T; ro = t * tb_rows + bi; }
