@@ -36,7 +36,7 @@ typedef unsigned long long u64;
 namespace {
 constexpr int DC_SPIN_LIMIT = 1 << 18;
 constexpr int HD = 512, NM = 32, R = 32, PA = HD * 2 + 16;      // hidden size, members per group, rows per group, LDS operand pitch
-constexpr int LDS_BYTES = 3 * R * PA + 32768 + 4736;             // three operand buffers + the reduction scratch + the decode scratch
+constexpr int LDS_BYTES = 3 * R * PA + 32768 + 4736 + 10240;     // three operand buffers + the reduction scratch + the decode scratch (+ its gate-input table slice)
 
 // ---- VMEM in program order: polls first, the previous phase's output stores behind them, then `s_waitcnt vmcnt(#stores)` -- the
 // polls are waited for, the stores are not (vmcnt counts loads and stores in issue order on gfx9).  Every store below is ONE
@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
   float* const wos = reinterpret_cast<float*>(lds + 3 * R * PA + 32768);      // DEC: [40][16] this member's slice of W_o (fp32)
   float* const outs = wos + 640;                                              //      [32][16] out(t) of this member's units (fp32)
   int* const toks = reinterpret_cast<int*>(outs + 512);                       //      [32] the tokens fed to the current step
+  float* const ztab = reinterpret_cast<float*>(toks + 32);                    //      [40 tokens][4 gates][16] this member's columns of the per-token gate-input table
   __shared__ int s_local, s_dead;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
@@ -288,6 +289,10 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
   }
   if constexpr (DEC) {
     for (int i = tid; i < 640; i += 256) { const int v = i >> 4, u = i & 15; wos[i] = v < p.V ? p.wo[(size_t)v * HD + 16 * member + u] : 0.f; }
+    for (int i = tid; i < 2560; i += 256) {            // 10 KB: a step's table lookup is an LDS read behind the token, not a second L2 round trip
+      const int v = i >> 6, g = (i >> 4) & 3, u = i & 15;
+      ztab[i] = v < p.V ? p.zx1[(size_t)v * 4 * HD + g * HD + 16 * member + u] : 0.f;
+    }
     if (tid < 32) toks[tid] = p.tok0[(size_t)min(row0 + tid, B - 1) * p.tok0_stride];
   }
   unsigned* const xg = reinterpret_cast<unsigned*>(p.xbuf) + (size_t)group * 5 * NM * 128;      // flags [kind: out, h1, h2, c, logits][reader][member][wave]
@@ -381,19 +386,12 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
                 },
                 [&] { store_out(ot, t - 1); }, gs, p.stamps != nullptr, tl0);
       if (s_dead) break;
-      if constexpr (DEC) {                          // the tokens chosen at step t-1 (published before the owners' out flags)
-        if (wave == 0) {
-          unsigned* const tp = p.tokx + (size_t)group * 32 + (ot & 31);
-          const unsigned tk = local ? __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          if (ot < 32) toks[ot] = (int)tk;
-        }
-        lds_barrier();
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          const size_t zrow = (size_t)(min(max(toks[16 * rt + oc16], 1), p.V) - 1);     // (clamped: a corrupted token must not become a wild address)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) zxr[rt][i] = p.zx1[zrow * 4 * HD + i * HD + ounit];
-        }
+    }
+    unsigned tk = 0;
+    if constexpr (DEC) {                            // the tokens chosen at step t-1 (published before the owners' out flags): the load is
+      if (t > 0 && wave == 0) {                     // issued here and consumed AFTER the layer-1 products, which do not depend on it
+        unsigned* const tp = p.tokx + (size_t)group * 32 + (ot & 31);
+        tk = local ? __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     DC_STAMP(0);
@@ -401,6 +399,18 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
     {
       f32x4 z[2];
       product(w1a, w1b, F, H1, z);
+      if constexpr (DEC) {
+        if (t > 0) {
+          if (wave == 0 && ot < 32) toks[ot] = (int)tk;
+          lds_barrier();
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            const int zrow = min(max(toks[16 * rt + oc16], 1), p.V) - 1;        // (clamped: a corrupted token must not become a wild address)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zxr[rt][i] = ztab[zrow * 64 + i * 16 + 4 * wave + oq];
+          }
+        }
+      }
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
