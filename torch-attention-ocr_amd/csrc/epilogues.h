@@ -101,6 +101,9 @@ struct EpStore {
 struct EpConv {
   float* y; uint8_t* idx; const float* bias; int Cout; int rows; int pmode; int relu;   // y may be null when yb is given (bf16 mode keeps only the shadow)
   bf16_t* yb;                              // optional bf16 shadow of y (operand of the next contraction)
+  // optional evaluation-mode BatchNorm + ReLU folded into the store (cnn.lua:23,32 under evaluate(): a per-channel affine map of the
+  // conv output): bn_save = {mean, 1/sqrt(var + eps)}[2][Cout] (bn_eval_prepare), the same expression as bn_apply_relu_kernel
+  const float* bn_save = nullptr; const float* bn_w = nullptr; const float* bn_b = nullptr;
   template <int NT> __device__ __forceinline__ void quad(int m, int n, int nstep, const float (&v)[NT][4]) const {
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
@@ -110,6 +113,11 @@ struct EpConv {
       float x[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { x[i] = v[ni][i] + bb; if (relu) x[i] = fmaxf(x[i], 0.f); }
+      if (bn_save) {
+        const float mu = bn_save[col], iv = bn_save[Cout + col], ww = bn_w[col], b2 = bn_b[col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = fmaxf((x[i] - mu) * iv * ww + b2, 0.f);
+      }
       if (pmode == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (m + i < rows) {

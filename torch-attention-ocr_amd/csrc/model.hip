@@ -320,13 +320,28 @@ void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training
   // un-pool -- reads the shadow; aocr_get_tensor materialises fp32 on demand)
   prof_mark(m, AOCR_PROF_POOL_CONV1); conv1_forward(s, images, m->conv[1].w, m->conv[1].b, bf ? nullptr : m->A1, B, d.H, d.W, m->A1b);
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A1, m->conv[2].w, m->conv[2].b, bf ? nullptr : m->A2, m->idx2, B, d.H1, d.W1, 64, 128, 3, 1, 1, 1, m->A1b, m->wb[2], m->A2b);
+  // evaluation mode, bf16: BatchNorm + ReLU of conv3 / conv5 are a per-channel affine map -> folded into the conv epilogue, which then writes only
+  // the bf16 shadow (no fp32 map, no apply pass); conv7's BatchNorm also transposes to (T, B) and stays a pass of its own
+  const bool fold = bf && !training && !getenv("AOCR_NO_BN_FOLD");
+  if (fold) {
+    prof_mark(m, AOCR_PROF_BN); bn_eval_prepare(s, m->bn[3].rm, m->bn[3].rv, m->bn[3].save, 256);
+    prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A2, m->conv[3].w, m->conv[3].b, nullptr, nullptr, B, d.H2, d.W2, 128, 256, 3, 1, 0, 0, m->A2b, m->wb[3], m->A3b, 0,
+                                                   m->bn[3].save, m->bn[3].w, m->bn[3].b);
+  } else {
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A2, m->conv[3].w, m->conv[3].b, m->Y3, nullptr, B, d.H2, d.W2, 128, 256, 3, 1, 0, 0, m->A2b, m->wb[3], nullptr);
   prof_mark(m, AOCR_PROF_BN); bn_relu_forward(s, m->Y3, bf ? nullptr : m->A3, m->bn[3].w, m->bn[3].b, m->bn[3].rm, m->bn[3].rv, m->bn[3].save, m->bn_scratch,
                   (int64_t)B * d.H2 * d.W2, 256, training, update_running, 0, m->A3b, bsync);
+  }
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A3, m->conv[4].w, m->conv[4].b, bf ? nullptr : m->A4, m->idx4, B, d.H2, d.W2, 256, 256, 3, 1, 1, 2, m->A3b, m->wb[4], m->A4b);
+  if (fold) {
+    prof_mark(m, AOCR_PROF_BN); bn_eval_prepare(s, m->bn[5].rm, m->bn[5].rv, m->bn[5].save, 512);
+    prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A4, m->conv[5].w, m->conv[5].b, nullptr, nullptr, B, d.H4, d.W2, 256, 512, 3, 1, 0, 0, m->A4b, m->wb[5], m->A5b, 0,
+                                                   m->bn[5].save, m->bn[5].w, m->bn[5].b);
+  } else {
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A4, m->conv[5].w, m->conv[5].b, m->Y5, nullptr, B, d.H4, d.W2, 256, 512, 3, 1, 0, 0, m->A4b, m->wb[5], nullptr);
   prof_mark(m, AOCR_PROF_BN); bn_relu_forward(s, m->Y5, bf ? nullptr : m->A5, m->bn[5].w, m->bn[5].b, m->bn[5].rm, m->bn[5].rv, m->bn[5].save, m->bn_scratch,
                   (int64_t)B * d.H4 * d.W2, 512, training, update_running, 0, m->A5b, bsync);
+  }
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A5, m->conv[6].w, m->conv[6].b, bf ? nullptr : m->A6, m->idx6, B, d.H4, d.W2, 512, 512, 3, 1, 1, 2, m->A5b, m->wb[6], m->A6b);
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A6, m->conv[7].w, m->conv[7].b, m->Y7, nullptr, B, d.H6, d.W2, 512, 512, 2, 0, 0, 0, m->A6b, m->wb[7], nullptr);
   prof_mark(m, AOCR_PROF_BN); bn_relu_forward(s, m->Y7, m->X, m->bn[7].w, m->bn[7].b, m->bn[7].rm, m->bn[7].rv, m->bn[7].save, m->bn_scratch,

@@ -98,7 +98,10 @@ void gemm_hh_shadow(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B
 // bf16-source path); yb: optional bf16 shadow of the output to write.
 void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, const float* bias, float* y, uint8_t* idx,
                   int B, int H, int W, int Cin, int Cout, int ks, int pad, int relu, int pool,
-                  const bf16_t* xb = nullptr, const bf16_t* wb = nullptr, bf16_t* yb = nullptr, int profile_tag = 0);
+                  const bf16_t* xb = nullptr, const bf16_t* wb = nullptr, bf16_t* yb = nullptr, int profile_tag = 0,
+                  const float* bn_save = nullptr, const float* bn_w = nullptr, const float* bn_b = nullptr);
+// bn_save != nullptr: evaluation-mode BatchNorm + ReLU folded into the conv epilogue (bn_save from bn_eval_prepare)
+void bn_eval_prepare(hipStream_t s, const float* rm, const float* rv, float* save, int C);
 // profile_tag != 0: the same kernel under a distinct symbol (aocr_profile_kernel), so profilers list these launches separately
 void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* w, float* dx, int B, int H, int W, int Cin,
                         int Cout, int ks, int pad, const bf16_t* dyb = nullptr, const bf16_t* wtb = nullptr, const float* wtf = nullptr);

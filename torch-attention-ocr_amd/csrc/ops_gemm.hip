@@ -330,10 +330,11 @@ static LoadConvK make_convk(const float* src, int B, int Hs, int Ws, int C, int 
 
 void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, const float* bias, float* y, uint8_t* idx, int B,
                   int H, int W, int Cin, int Cout, int ks, int pad, int relu, int pool, const bf16_t* xb, const bf16_t* wb,
-                  bf16_t* yb, int profile_tag) {
+                  bf16_t* yb, int profile_tag, const float* bn_save, const float* bn_w, const float* bn_b) {
   const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
   LoadConvK a = make_convk(x, B, H, W, Cin, ks, 1, -pad, Ho, Wo, pool);
   EpConv ep; ep.y = y; ep.idx = idx; ep.bias = bias; ep.Cout = Cout; ep.rows = a.rows; ep.pmode = pool; ep.relu = relu; ep.yb = yb;
+  ep.bn_save = bn_save; ep.bn_w = bn_w; ep.bn_b = bn_b;
   if (bf16 && xb && wb) {
     LoadConvKh ah; ah.src = xb; ah.g = a;
     LoadKh bh; bh.p = wb; bh.ld = a.K; bh.rows = Cout; bh.K = a.K;

@@ -529,6 +529,9 @@ __global__ void bn_eval_prepare_kernel(const float* rm, const float* rv, float* 
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) { save[c] = rm[c]; save[C + c] = (float)(1.0 / sqrt((double)rv[c] + 1e-5)); }
 }
+void bn_eval_prepare(hipStream_t s, const float* rm, const float* rv, float* save, int C) {
+  hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(cdiv(C, 128)), dim3(128), 0, s, rm, rv, save, C);
+}
 __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             const float* __restrict__ save, int64_t rows, int C, int tb_rows,
