@@ -63,7 +63,7 @@ struct aocr_model {
   // CNN
   float *A1, *A2, *Y3, *A3, *A4, *Y5, *A5, *A6, *Y7, *X;
   uint8_t *idx2, *idx4, *idx6;
-  float *G0, *G1, *dX;
+  float *G0, *G1, *dX; size_t gmax = 0;   // gmax: floats in G0 / G1
   // bf16 shadows of the contraction operands (bf16 compute mode only; nullptr otherwise)
   aocr::bf16_t *A1b, *A2b, *A3b, *A4b, *A5b, *A6b, *G0b;
   aocr::bf16_t *wb[8], *wtb[8];

@@ -93,7 +93,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
   m->A6 = a.get<float>(B * d.H6 * d.W2 * 512); m->idx6 = a.get<uint8_t>(B * d.H6 * d.W2 * 512);
   m->Y7 = a.get<float>(B * T * 512); m->X = a.get<float>(T * B * 512); m->dX = a.get<float>(T * B * 512);
   size_t gmax = B * d.H1 * d.W1 * 128;                                      // d(conv2 pre-pool output): the largest gradient map
-  m->G0 = a.get<float>(gmax); m->G1 = a.get<float>(gmax);
+  m->G0 = a.get<float>(gmax); m->G1 = a.get<float>(gmax); m->gmax = gmax;
   m->A1b = m->A2b = m->A3b = m->A4b = m->A5b = m->A6b = m->G0b = nullptr;
   for (int i = 0; i < 8; ++i) { m->wb[i] = nullptr; m->wtb[i] = nullptr; m->wtf[i] = nullptr; }
   if (!m->bf16) {
@@ -352,37 +352,46 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
   const BnSync bsync_v{bn_sync_allreduce, m}; const BnSync* bsync = sync_bn_on(m) ? &bsync_v : nullptr;
   float *G0 = m->G0, *G1 = m->G1; bf16_t* G0b = m->G0b;
+  // bf16 mode: fp32 G0 is free for the whole pass (every gradient map lives in its bf16 shadow), so the eight partial slabs of the fused bias /
+  // conv1 gradients get regions of their own and their column sums are finished by TWO launches (before the bucket event, at the end)
+  // instead of eight dependent ~10 us dispatches
+  constexpr size_t SLAB = (size_t)4 << 20;                      // floats per slab: >= 2048 x 1024 (BatchNorm), 4096 x 640 (conv1)
+  ColsumJobs cj; cj.n = 0; cj.total = 0;
+  ColsumJobs* defer = (bf && m->gmax >= 8 * SLAB && !getenv("AOCR_NO_COLSUM_DEFER")) ? &cj : nullptr;
+  auto slab = [&](int k) { return defer ? G0 + (size_t)k * SLAB : G0; };
   // bn7 + relu (dX is time-major, Y7 batch-major)
   // bf16 mode: the BatchNorm backward writes only the bf16 shadow of its gradient, takes the ReLU mask from the bf16 output
   // shadow and accumulates the preceding conv's bias gradient (fp32 G0 is free there: partial slab)
   prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y7, m->X, m->dX, m->bn[7].w, m->bn[7].save, bf ? nullptr : G0, m->bn[7].dw, m->bn[7].db, m->bn_scratch,
-                   (int64_t)B * d.T, 512, B, G0b, bf ? m->Xb : nullptr, bf ? m->conv[7].db : nullptr, bf ? G0 : nullptr, bsync);
+                   (int64_t)B * d.T, 512, B, G0b, bf ? m->Xb : nullptr, bf ? m->conv[7].db : nullptr, bf ? slab(0) : nullptr, bsync, defer);
   const char* dbg_stop = getenv("AOCR_DBG_STOP");          // debugging aid: leave the gradient map of a stage in place (tap "g0")
   const int stop = dbg_stop ? atoi(dbg_stop) : 0;
-  if (stop == 1) return;
+  if (stop == 1) { if (defer) colsum_flush(s, cj); return; }
   prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A6, G0, m->conv[7].dw, bf ? nullptr : m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0, m->A6b, G0b);
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0, G0b, m->wtb[7], m->wtf[7]);
-  prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A6, m->idx6, bf ? nullptr : G0, B, d.H4, d.W2, 512, 2, G0b, bf ? m->conv[6].db : nullptr, bf ? G0 : nullptr, bf ? m->A6b : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
-  if (stop == 2) return;
+  prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A6, m->idx6, bf ? nullptr : G0, B, d.H4, d.W2, 512, 2, G0b, bf ? m->conv[6].db : nullptr, bf ? slab(1) : nullptr, bf ? m->A6b : nullptr, defer);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
+  if (stop == 2) { if (defer) colsum_flush(s, cj); return; }
   prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, bf ? nullptr : m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, G0b);
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, G0b, m->wtb[6], m->wtf[6]);
   prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, bf ? nullptr : G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
-                   (int64_t)B * d.H4 * d.W2, 512, 0, G0b, bf ? m->A5b : nullptr, bf ? m->conv[5].db : nullptr, bf ? G0 : nullptr, bsync);
+                   (int64_t)B * d.H4 * d.W2, 512, 0, G0b, bf ? m->A5b : nullptr, bf ? m->conv[5].db : nullptr, bf ? slab(2) : nullptr, bsync, defer);
   prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, bf ? nullptr : m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, G0b);
+  if (defer) colsum_flush(s, cj);                               // conv7.b, conv6.b, conv5.b
   hipEventRecord(m->grad_ev[2], s);                             // every CNN gradient from conv5.w upwards is complete
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1, G0b, m->wtb[5], m->wtf[5]);
-  prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A4, m->idx4, bf ? nullptr : G0, B, d.H2, d.W2, 256, 2, G0b, bf ? m->conv[4].db : nullptr, bf ? G0 : nullptr, bf ? m->A4b : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
+  prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A4, m->idx4, bf ? nullptr : G0, B, d.H2, d.W2, 256, 2, G0b, bf ? m->conv[4].db : nullptr, bf ? slab(3) : nullptr, bf ? m->A4b : nullptr, defer);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
   prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, bf ? nullptr : m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, G0b);
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, G0b, m->wtb[4], m->wtf[4]);
   prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y3, m->A3, G1, m->bn[3].w, m->bn[3].save, bf ? nullptr : G0, m->bn[3].dw, m->bn[3].db, m->bn_scratch,
-                   (int64_t)B * d.H2 * d.W2, 256, 0, G0b, bf ? m->A3b : nullptr, bf ? m->conv[3].db : nullptr, bf ? G0 : nullptr, bsync);
+                   (int64_t)B * d.H2 * d.W2, 256, 0, G0b, bf ? m->A3b : nullptr, bf ? m->conv[3].db : nullptr, bf ? slab(4) : nullptr, bsync, defer);
   prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A2, G0, m->conv[3].dw, bf ? nullptr : m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, G0b);
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1, G0b, m->wtb[3], m->wtf[3]);
-  prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A2, m->idx2, bf ? nullptr : G0, B, d.H1, d.W1, 128, 1, G0b, bf ? m->conv[2].db : nullptr, bf ? G0 : nullptr, bf ? m->A2b : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
+  prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A2, m->idx2, bf ? nullptr : G0, B, d.H1, d.W1, 128, 1, G0b, bf ? m->conv[2].db : nullptr, bf ? slab(5) : nullptr, bf ? m->A2b : nullptr, defer);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
   prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A1, G0, m->conv[2].dw, bf ? nullptr : m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1, m->A1b, G0b);
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1, G0b, m->wtb[2], m->wtf[2]);
   prof_mark(m, AOCR_PROF_POOL_CONV1); conv1_backward(s, images, m->conv[1].w, m->conv[1].b, G1, m->conv[1].dw, m->conv[1].db, B, d.H, d.W,
-                 (size_t)B * d.H1 * d.W1 * 128 >= (size_t)4096 * 640 ? G0 : nullptr);      // G0 is free here: use it as the partial slab
+                 (size_t)B * d.H1 * d.W1 * 128 >= (size_t)4096 * 640 ? slab(6) : nullptr, defer);      // G0 is free here: use it as the partial slab
+  if (defer) colsum_flush(s, cj);                               // conv4.b, conv3.b, conv2.b, conv1.w, conv1.b
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -783,7 +792,8 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   prof_mark(m, AOCR_PROF_RNN_GEMM);
   gemm(s, bf, m->dlogits, LOGIT_LD, true, m->wo, Hd, false, m->dout_proj, Hd, rows, Hd, V, nullptr, nullptr, 0);
   gemm(s, bf, m->dlogits, LOGIT_LD, false, m->out_all + slot, Hd, false, m->dwo, Hd, V, Hd, rows, nullptr, nullptr, EP_ATOMIC);
-  colsum_accum(s, m->dlogits, LOGIT_LD, rows, V, m->dbo);
+  ColsumJobs cj; cj.n = 0; cj.total = 0;                          // projector bias + the LSTM biases of every layer: one launch at the end of this pass
+  colsum_defer(cj, m->dlogits, LOGIT_LD, rows, V, m->dbo);
   prof_mark(m, AOCR_PROF_DEC_BWD);
   { ZeroList zl; for (int l = 0; l < Ld; ++l) { zl.add(m->dh_rec[l], slot * sizeof(float)); zl.add(m->dc_st[l], slot * sizeof(float)); } zero_many(s, zl); }
   const bool feed_fused = m->cfg.input_feed && Ld <= 2 && !m->drop_on;  // the feed product joins the grouped launch and carries the tanh backward (dropout: the separate d pre kernel knows the mask)
@@ -877,7 +887,8 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
     const LstmP& p = m->dec[l]; const float* dz = m->ddz[l];
     const bf16_t* dzb = sh ? m->ddz_b[l] : nullptr;
     wg[nwg++] = WGradProblem{dz, 4 * Hd, m->dhs[l], Hd, p.dwh, Hd, 4 * Hd, Hd, rows, dzb, sh ? m->dhs_b[l] : nullptr};
-    colsum_accum(s, dz, 4 * Hd, rows, 4 * Hd, p.dbi, p.dbh);
+    if (cj.n >= 8) colsum_flush(s, cj);
+    colsum_defer(cj, dz, 4 * Hd, rows, 4 * Hd, p.dbi, p.dbh);
     if (l == 0) {
       wg[nwg++] = WGradProblem{dz, 4 * Hd, m->emb_all, E, p.dwi, p.in, 4 * Hd, E, rows};
       if (m->cfg.input_feed) wg[nwg++] = WGradProblem{dz, 4 * Hd, m->out_all, Hd, p.dwi + E, p.in, 4 * Hd, Hd, rows, dzb, sh ? m->out_b : nullptr};
@@ -890,6 +901,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
       else wg[nwg++] = WGradProblem{dz, 4 * Hd, m->dhs[l - 1] + slot, Hd, p.dwi, Hd, 4 * Hd, Hd, rows, dzb, sh ? m->dhs_b[l - 1] + slot : nullptr};
     }
   }
+  colsum_flush(s, cj);
   grouped_wgrad(s, bf, wg, nwg);
   // d(context), model.lua:652-653 summed over the loop
   attention_dctx(s, m->a_all, m->ds_all, m->dcat_all, 2 * Hd, m->q_all, m->dctx, L, B, T, Hd);

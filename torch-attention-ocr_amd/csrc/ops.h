@@ -112,11 +112,13 @@ void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float*
 void conv1_forward(hipStream_t s, const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
                    bf16_t* yb = nullptr);
 void conv_weight_shadows(hipStream_t s, const float* w, bf16_t* wb, bf16_t* wtb, int Cout, int KK, int Cin);
+struct ColsumJobs;
 void conv1_backward(hipStream_t s, const float* x, const float* w, const float* bias, const float* dyp, float* dw, float* db,
-                    int B, int H, int W, float* scratch = nullptr);
+                    int B, int H, int W, float* scratch = nullptr, ColsumJobs* defer = nullptr);
 void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pooled, const uint8_t* idx, float* dy, int B,
                           int Ho, int Wo, int C, int pool, bf16_t* dyb = nullptr, float* dbias = nullptr,
-                          float* partial = nullptr, const bf16_t* pooledb = nullptr);
+                          float* partial = nullptr, const bf16_t* pooledb = nullptr, ColsumJobs* defer = nullptr);
+// defer: the column sum that finishes a partial slab is queued (colsum_flush) instead of launched -- the slab must then stay untouched until the flush
 // dbias + partial (>= 2048*C floats scratch): fused bias gradient, dy may then be null; pooledb: bf16 shadow of pooled (mask source)
 void bf16_to_f32(hipStream_t s, const bf16_t* src, float* dst, int64_t n);
 size_t bn_scratch_bytes(int C);
@@ -127,7 +129,8 @@ void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, co
                      bf16_t* yb = nullptr, const BnSync* sync = nullptr);
 void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
                       float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb = nullptr,
-                      const bf16_t* yb = nullptr, float* conv_dbias = nullptr, float* partial = nullptr, const BnSync* sync = nullptr);
+                      const bf16_t* yb = nullptr, float* conv_dbias = nullptr, float* partial = nullptr, const BnSync* sync = nullptr,
+                      ColsumJobs* defer = nullptr);
 // yb: bf16 shadow of y (ReLU mask source); conv_dbias + partial (>= 4096*256 floats): fused bias gradient of the preceding conv, dx may then be null
 // ctx_div: rows r share context row r / ctx_div (beam search keeps one context per image, model.lua:373)
 void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a, float* c, int64_t ldc, int B, int T, int Hd,
@@ -147,6 +150,11 @@ struct ZeroList { void* p[16]; size_t bytes[16]; int n = 0;
   void add(void* q, size_t b) { if (q && b && n < 16) { p[n] = q; bytes[n] = b; ++n; } } };
 void zero_many(hipStream_t s, const ZeroList& z);    // all listed regions (16-byte aligned) in one launch
 void colsum_accum(hipStream_t s, const float* A, int64_t ld, int64_t rows, int N, float* out, float* out2 = nullptr);   // out[n] (and out2[n]) += sum_r A[r][n]
+// deferred form: up to 8 column sums finished by ONE launch (each small sum is otherwise its own ~10 us dispatch on the step's critical path)
+struct ColsumJob { const float* A; int64_t ld, rows; int N; float* out; float* out2; int first, nb, chunks; };
+struct ColsumJobs { int n, total; ColsumJob j[8]; };
+void colsum_defer(ColsumJobs& g, const float* A, int64_t ld, int64_t rows, int N, float* out, float* out2 = nullptr);
+void colsum_flush(hipStream_t s, ColsumJobs& g);
 void embedding_gather(hipStream_t s, const float* table, const int32_t* tok, int64_t stride_t, int64_t stride_b, float* out,
                       int L, int B, int E);
 void embedding_scatter_accum(hipStream_t s, const float* demb, const int32_t* tok, int64_t stride_t, int64_t stride_b,

@@ -183,14 +183,15 @@ void conv1_forward(hipStream_t s, const float* x, const float* w, const float* b
   hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, y, yb, B, H, W, Hp, Wp);
 }
 void conv1_backward(hipStream_t s, const float* x, const float* w, const float* bias, const float* dyp, float* dw, float* db,
-                    int B, int H, int W, float* scratch) {
+                    int B, int H, int W, float* scratch, ColsumJobs* defer) {
   int Hp = H / 2, Wp = W / 2;
   int64_t strips = (int64_t)B * Hp * ((Wp + C1S - 1) / C1S);
   // with a scratch slab (>= 4096*640 floats) every workgroup writes its partial sums and two column sums finish the job:
   // no contended global atomics, more workgroups
   int blocks = (int)std::min<int64_t>((strips + 3) / 4, scratch ? 2048 : 1024);
   hipLaunchKernelGGL(conv1_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, dyp, dw, db, B, H, W, Hp, Wp, scratch);
-  if (scratch) {
+  if (scratch && defer) { colsum_defer(*defer, scratch, 640, blocks, 576, dw); colsum_defer(*defer, scratch + 576, 640, blocks, 64, db); }
+  else if (scratch) {
     colsum_accum(s, scratch, 640, blocks, 576, dw);
     colsum_accum(s, scratch + 576, 640, blocks, 64, db);
   }
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256) void unpool_kernel(const float* __restrict__ d
   }
 }
 void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pooled, const uint8_t* idx, float* dy, int B, int Ho,
-                          int Wo, int C, int pool, bf16_t* dyb, float* dbias, float* partial, const bf16_t* pooledb) {
+                          int Wo, int C, int pool, bf16_t* dyb, float* dbias, float* partial, const bf16_t* pooledb, ColsumJobs* defer) {
   int Hp = Ho / 2, Wp = pool == 1 ? Wo / 2 : Wo;
   if ((Ho & 1) || (pool == 1 && (Wo & 1))) {                                      // floor-mode leftovers
     if (dy) hipMemsetAsync(dy, 0, (size_t)B * Ho * Wo * C * sizeof(float), s);
@@ -346,7 +347,7 @@ void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pool
     int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);             // grid stride 2048*256 is a multiple of every C4 | 256
     if (dy) hipLaunchKernelGGL((unpool_kernel<true, true>), dim3(blocks), dim3(256), 0, s, dpooled, pooled, idx, dy, dyb, partial, B, Ho, Wo, C, pool, Hp, Wp, pooledb);
     else    hipLaunchKernelGGL((unpool_kernel<false, true>), dim3(blocks), dim3(256), 0, s, dpooled, pooled, idx, dy, dyb, partial, B, Ho, Wo, C, pool, Hp, Wp, pooledb);
-    colsum_accum(s, partial, C, blocks, C, dbias);
+    if (defer) colsum_defer(*defer, partial, C, blocks, C, dbias); else colsum_accum(s, partial, C, blocks, C, dbias);
     return;
   }
   int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
@@ -629,7 +630,7 @@ void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, co
 }
 void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
                       float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb,
-                      const bf16_t* yb, float* conv_dbias, float* partial, const BnSync* sync) {
+                      const bf16_t* yb, float* conv_dbias, float* partial, const BnSync* sync, ColsumJobs* defer) {
   int T = tb_rows > 0 ? (int)(rows / tb_rows) : 0;
   double* part = (double*)scratch;
   double* fin = part + (size_t)BN_CHUNKS * C * 2;
@@ -651,7 +652,7 @@ void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float
     int fb = (int)std::min<int64_t>((total + 255) / 256, 2048);
     if (dx) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), dim3(fb), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, partial);
     else    hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), dim3(fb), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, partial);
-    colsum_accum(s, partial, C, (int64_t)fb * 256 / C4, C, conv_dbias);
+    if (defer) colsum_defer(*defer, partial, C, (int64_t)fb * 256 / C4, C, conv_dbias); else colsum_accum(s, partial, C, (int64_t)fb * 256 / C4, C, conv_dbias);
     return;
   }
   hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), dim3(blocks), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, nullptr);
@@ -1159,12 +1160,12 @@ void gold_scores(hipStream_t s, const float* nll_rows, float* gold, int L, int B
 
 // out[n] += sum_r A[r][n]   (bias gradients).  grid = (column blocks of 64, row chunks); a workgroup is 16 row lanes x
 // 16 column quads (dwordx4 loads, two rows in flight per lane), reduced through LDS; one atomic per column per workgroup.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t ld, int64_t rows, int N, float* out, float* out2) {
+__device__ __forceinline__ void colsum_body(const float* __restrict__ A, int64_t ld, int64_t rows, int N, float* out, float* out2, int bx, int by, int ny) {
   __shared__ float sh[16][65];
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int n = blockIdx.x * 64 + cq * 4;
-  const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
-  const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(rows, r0 + per);
+  const int n = bx * 64 + cq * 4;
+  const int64_t per = (rows + ny - 1) / ny;
+  const int64_t r0 = (int64_t)by * per, r1 = min(rows, r0 + per);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f), t = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool vec = (n + 3 < N) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   if (vec) {
@@ -1185,20 +1186,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A
   sh[rl][cq * 4] = s.x + t.x; sh[rl][cq * 4 + 1] = s.y + t.y; sh[rl][cq * 4 + 2] = s.z + t.z; sh[rl][cq * 4 + 3] = s.w + t.w;
   __syncthreads();
   if (threadIdx.x < 64) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int c = bx * 64 + threadIdx.x;
     if (c < N) {
       float v = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) v += sh[i][threadIdx.x];
-      if (gridDim.y == 1) out[c] += v; else atomicAdd(&out[c], v);
-      if (out2) { if (gridDim.y == 1) out2[c] += v; else atomicAdd(&out2[c], v); }      // second accumulator of the same sums (the two LSTM biases)
+      if (ny == 1) out[c] += v; else atomicAdd(&out[c], v);
+      if (out2) { if (ny == 1) out2[c] += v; else atomicAdd(&out2[c], v); }      // second accumulator of the same sums (the two LSTM biases)
     }
   }
+}
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t ld, int64_t rows, int N, float* out, float* out2) {
+  colsum_body(A, ld, rows, N, out, out2, blockIdx.x, blockIdx.y, gridDim.y);
+}
+__global__ __launch_bounds__(256) void colsum_jobs_kernel(ColsumJobs g) {
+  int ji = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.j[i].first) ji = i;
+  const ColsumJob& J = g.j[ji];
+  const int local = blockIdx.x - J.first;
+  colsum_body(J.A, J.ld, J.rows, J.N, J.out, J.out2, local % J.nb, local / J.nb, J.chunks);
 }
 void colsum_accum(hipStream_t s, const float* A, int64_t ld, int64_t rows, int N, float* out, float* out2) {
   int nb = cdiv(N, 64);
   int chunks = (int)std::min<int64_t>(std::max<int64_t>(1, 2048 / nb), (rows + 511) / 512);
   hipLaunchKernelGGL(colsum_kernel, dim3(nb, chunks), dim3(256), 0, s, A, ld, rows, N, out, out2);
+}
+void colsum_defer(ColsumJobs& g, const float* A, int64_t ld, int64_t rows, int N, float* out, float* out2) {
+  if (g.n >= 8) return;                                         // (callers flush before the table is full)
+  ColsumJob& J = g.j[g.n];
+  J.A = A; J.ld = ld; J.rows = rows; J.N = N; J.out = out; J.out2 = out2;
+  J.nb = cdiv(N, 64);
+  J.chunks = (int)std::min<int64_t>(std::max<int64_t>(1, 2048 / J.nb), (rows + 511) / 512);
+  if (J.chunks < 1) J.chunks = 1;
+  J.first = g.total; g.total += J.nb * J.chunks; ++g.n;
+}
+void colsum_flush(hipStream_t s, ColsumJobs& g) {
+  if (g.n > 0) hipLaunchKernelGGL(colsum_jobs_kernel, dim3(g.total), dim3(256), 0, s, g);
+  g.n = 0; g.total = 0;
 }
 
 // nn.LookupTable forward / accGradParameters (LSTM.lua:55-56)
