@@ -4,13 +4,15 @@ R=$GRAFT_REPO_ROOT; tag=$1; shift; O=$R/gpurun_out/pmc; mkdir -p $O; rm -rf $O/r
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/raw_$tag -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --decode-steps 1 --no-secondary --sustain-seconds 0 > $O/run_$tag.log 2>&1
 cd $R
-f=$(ls $O/raw_$tag/*/*counter_collection.csv | head -1)
-python - "$f" "$@" > $O/$tag.txt <<'PY'
+f=$(ls $O/raw_$tag/*/*counter_collection.csv | head -1); kt=$(ls $O/raw_$tag/*/*kernel_trace.csv | head -1)
+python - "$f" "$kt" "$@" > $O/$tag.txt <<'PY'
 import csv, sys, collections
-names = sys.argv[2:]
+names = sys.argv[3:] + ["duration_us_in_this_run"]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for r in csv.DictReader(open(sys.argv[2])):                        # durations of the SAME (counter-collecting, serialised) run
+    acc[r["Kernel_Name"]]["duration_us_in_this_run"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 rows = []
 for k, c in acc.items():
     n = max(len(v) for v in c.values())
