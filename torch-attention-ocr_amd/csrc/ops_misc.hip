@@ -238,11 +238,36 @@ __global__ __launch_bounds__(256) void weight_shadow_kernel(const float* __restr
 // is one piece per tap (wtb is [Cin][tap][Cout]).  16 separate launches cost ~100 us of dispatch latency for ~20 us of traffic.
 __global__ __launch_bounds__(256) void shadow_jobs_kernel(const ShadowJob* __restrict__ jobs, int njobs) {
   __shared__ float tile[32][33];
-  int j = 0;
-  for (int i = 1; i < njobs; ++i) if ((int)blockIdx.x >= jobs[i].tile0) j = i;      // uniform scan over <= 64 entries
+  int j = 0, hi = njobs;                                // uniform binary search: last job whose first tile is <= this workgroup's (tile0 ascends)
+  while (hi - j > 1) { const int mid = (j + hi) >> 1; if ((int)blockIdx.x >= jobs[mid].tile0) j = mid; else hi = mid; }
   const ShadowJob J = jobs[j];
   const int t = blockIdx.x - J.tile0;
   const int c0 = (t % J.tx) * 32, r0 = (t / J.tx) * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  // 16-byte loads / 8-byte stores when the piece allows it (every matrix of the model does): one load and two stores per thread
+  const bool vec = ((J.C | J.R | (int)J.ld | (int)J.ldb | (int)J.ldt) & 3) == 0 && ((reinterpret_cast<uintptr_t>(J.w) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(J.wb) & 7) == 0) && ((reinterpret_cast<uintptr_t>(J.wtb) & 7) == 0);
+  if (vec) {
+    const int q = threadIdx.x & 7, l = threadIdx.x >> 3;           // load: row l, columns 4q..4q+3; transposed store: column l, rows 4q..4q+3
+    {
+      const int r = r0 + l, c = c0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < J.R && c < J.C) {
+        v = *reinterpret_cast<const float4*>(J.w + (int64_t)r * J.ld + c);
+        bf16x4 hb; hb[0] = (bf16_t)v.x; hb[1] = (bf16_t)v.y; hb[2] = (bf16_t)v.z; hb[3] = (bf16_t)v.w;
+        *reinterpret_cast<bf16x4*>(J.wb + (int64_t)r * J.ldb + c) = hb;
+      }
+      tile[l][4 * q] = v.x; tile[l][4 * q + 1] = v.y; tile[l][4 * q + 2] = v.z; tile[l][4 * q + 3] = v.w;
+    }
+    __syncthreads();
+    {
+      const int c = c0 + l, r = r0 + 4 * q;
+      if (c < J.C && r < J.R) {
+        bf16x4 hb; hb[0] = (bf16_t)tile[4 * q][l]; hb[1] = (bf16_t)tile[4 * q + 1][l]; hb[2] = (bf16_t)tile[4 * q + 2][l]; hb[3] = (bf16_t)tile[4 * q + 3][l];
+        *reinterpret_cast<bf16x4*>(J.wtb + (int64_t)c * J.ldt + r) = hb;
+      }
+    }
+    return;
+  }
   for (int i = ty; i < 32; i += 8) {
     const int r = r0 + i, c = c0 + tx;
     const float v = (r < J.R && c < J.C) ? J.w[(int64_t)r * J.ld + c] : 0.f;
