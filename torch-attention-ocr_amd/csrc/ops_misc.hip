@@ -502,8 +502,18 @@ __device__ __forceinline__ bool bn_reduce_partials(const double* __restrict__ pa
   const int cl = threadIdx.x & 15, ks = threadIdx.x >> 4;
   c = blockIdx.x * 16 + cl;
   double a = 0, b = 0;
-  if (c < C)
-    for (int k = ks; k < nchunk; k += 16) { a += part[((int64_t)k * C + c) * 2]; b += part[((int64_t)k * C + c) * 2 + 1]; }
+  if (c < C) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    int k = ks;
+    for (; k + 7 * 16 < nchunk; k += 8 * 16) {                    // eight 16-byte loads in flight (a serial chain of 32 round trips cost ~10 us per launch)
+      d2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const d2*>(part + ((int64_t)(k + 16 * u) * C + c) * 2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a += v[u][0]; b += v[u][1]; }
+    }
+    for (; k < nchunk; k += 16) { a += part[((int64_t)k * C + c) * 2]; b += part[((int64_t)k * C + c) * 2 + 1]; }
+  }
   sh[0][ks][cl] = a; sh[1][ks][cl] = b;
   __syncthreads();
   if (ks != 0 || c >= C) return false;
