@@ -1370,7 +1370,20 @@ __global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restri
 void bf16_to_f32(hipStream_t s, const bf16_t* src, float* dst, int64_t n) {
   hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((int)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, src, dst, n);
 }
+__global__ __launch_bounds__(256) void copy2d_bf16x4_kernel(const float* __restrict__ src, int64_t lds, bf16_t* __restrict__ dst, int64_t ldd,
+                                                            int rows, int cols4) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)rows * cols4) return;
+  const int c = (int)(i % cols4) * 4; const int64_t r = i / cols4;
+  const float4 v = *reinterpret_cast<const float4*>(src + r * lds + c);
+  bf16x4 hb; hb[0] = (bf16_t)v.x; hb[1] = (bf16_t)v.y; hb[2] = (bf16_t)v.z; hb[3] = (bf16_t)v.w;
+  *reinterpret_cast<bf16x4*>(dst + r * ldd + c) = hb;
+}
 void copy2d_bf16(hipStream_t s, const float* src, int64_t lds, bf16_t* dst, int64_t ldd, int rows, int cols) {
+  if (((cols | lds | ldd) & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0) {
+    hipLaunchKernelGGL(copy2d_bf16x4_kernel, dim3(cdiv((int64_t)rows * (cols / 4), 256)), dim3(256), 0, s, src, lds, dst, ldd, rows, cols / 4);
+    return;
+  }
   hipLaunchKernelGGL(copy2d_bf16_kernel, dim3(cdiv((int64_t)rows * cols, 256)), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
 }
 void copy2d(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols) {
