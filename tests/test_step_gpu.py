@@ -385,6 +385,35 @@ def test_greedy_decode_cluster_kernel_matches_launch_chain(cuda, monkeypatch, B,
     assert np.abs(a["gold"] - b["gold"]).max() < 2e-2 * max(1.0, np.abs(a["gold"]).max())
 
 
+@pytest.mark.parametrize("boost", [60.0, 0.45, 0.3])
+def test_greedy_decode_early_exit(cuda, monkeypatch, boost):
+    """The greedy cluster kernel leaves its loop once every row of a 32-row group has emitted EOS / PAD (all later steps select PAD at no
+    cost, model.lua:448-449) and fills the remaining labels with PAD.  A projector bias that favours EOS makes rows finish early (boost 60:
+    every row at step 0; 0.45: the smallest boost that still does; 0.3: no row finishes, no exit); labels, scores and gold scores must equal the run that takes all max_decoder_l steps."""
+    cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for knob in ("0", "1"):
+        if knob == "1":
+            monkeypatch.setenv("AOCR_NO_DEC_EARLY", "1")
+        else:
+            monkeypatch.delenv("AOCR_NO_DEC_EARLY", raising=False)
+        m, O, ocfg, P, st, batch = make(cfg, B=70, W=72, maxlen=5, compute="bf16", max_decoder_l=20, max_beam=1)
+        P2 = dict(P); P2["proj.w"] = P["proj.w"] * 40.0
+        b2 = P["proj.b"].clone(); b2[2] += boost; P2["proj.b"] = b2          # class index 2 = token 3 = EOS
+        m.set_parameters(P2, st)
+        loss, stats = m.step(batch, True, 1)
+        assert int(m.get_tensor("cl_err").view(torch.int32)[0]) == 0
+        o = m._dec_out
+        out[knob] = dict(labels=np.array(o.labels), scores=np.array(o.scores), gold=np.array(o.gold_scores), loss=loss)
+        m.shutdown()
+    a, b = out["1"], out["0"]
+    lens = (b["labels"] != 1).sum(axis=1)
+    print(f"[parity] greedy early exit boost={boost}: emitted lengths min {lens.min()} max {lens.max()} of 20 steps")
+    assert (a["labels"] == b["labels"]).all()
+    assert np.array_equal(a["scores"], b["scores"]) and np.array_equal(a["gold"], b["gold"]) and a["loss"] == b["loss"]
+    if boost > 10: assert lens.max() < 20                             # every row finished at once: the exit path was certainly taken
+
+
 @pytest.mark.parametrize("case,p", [(dict(enc_hidden=32, enc_layers=2, dec_layers=2, input_feed=True), 0.3),
                                     (dict(enc_hidden=32, enc_layers=1, dec_layers=3, input_feed=False), 0.5),
                                     (dict(enc_hidden=64, enc_layers=2, dec_layers=2, input_feed=True), 0.1)])

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
   float* const outs = wos + 640;                                              //      [32][16] out(t) of this member's units (fp32)
   int* const toks = reinterpret_cast<int*>(outs + 512);                       //      [32] the tokens fed to the current step
   float* const ztab = reinterpret_cast<float*>(toks + 32);                    //      [40 tokens][4 gates][16] this member's columns of the per-token gate-input table
-  __shared__ int s_local, s_dead;
+  __shared__ int s_local, s_dead, s_allfin;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
   const int wid = blockIdx.x, xcd = wid & 7, i8 = wid >> 3;
@@ -296,6 +296,7 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
     if (tid < 32) toks[tid] = p.tok0[(size_t)min(row0 + tid, B - 1) * p.tok0_stride];
   }
   unsigned* const xg = reinterpret_cast<unsigned*>(p.xbuf) + (size_t)group * 5 * NM * 128;      // flags [kind: out, h1, h2, c, logits][reader][member][wave]
+  int t_exit = -1;                                                  // DEC: the step at which every row of the group had finished (early exit)
   float score = 0.f; int prev_tok = 0, node = 0;                    // DEC, wave 0 of the row's owner: running log-probability, last token, trie node (-use_dictionary)
   load_rows(p.out_b, row0, B, F, tid); load_rows(p.hsb[0], row0, B, H1, tid); load_rows(p.hsb[1], row0, B, H2, tid);
   __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): nothing of the prologue is in flight inside the loop
@@ -401,8 +402,16 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
       product(w1a, w1b, F, H1, z);
       if constexpr (DEC) {
         if (t > 0) {
-          if (wave == 0 && ot < 32) toks[ot] = (int)tk;
+          if (wave == 0) {
+            if (ot < 32) toks[ot] = (int)tk;
+            // Every row of the group has emitted EOS (or PAD): from here on each step selects PAD at no cost (model.lua:448-449), so the
+            // labels of the remaining steps are PAD and the scores final (all members see the same 32 tokens, so all leave together).
+            const bool done = tk == 1u || tk == 3u || row0 + (ot & 31) >= B;
+            const unsigned long long all = __ballot(done);
+            if (ot == 0) s_allfin = all == ~0ull;
+          }
           lds_barrier();
+          if (s_allfin && !p.no_early) { t_exit = t; break; }       // (the PAD labels / final scores are written behind the loop)
 #pragma unroll
           for (int rt = 0; rt < 2; ++rt) {
             const int zrow = min(max(toks[16 * rt + oc16], 1), p.V) - 1;        // (clamped: a corrupted token must not become a wild address)
@@ -611,6 +620,12 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
       }
     }
     DC_STAMP(7);
+  }
+  if constexpr (DEC) {
+    if (t_exit >= 0 && wave == 0 && lane == 0 && rvalid) {
+      for (int tt = t_exit; tt < L; ++tt) p.labels[(size_t)arow * p.tok0_stride + tt] = 1;
+      p.scores[arow] = score;
+    }
   }
   if (!s_dead) {
     store_out(tid, L - 1);
@@ -983,7 +998,7 @@ void dec_cluster_forward(hipStream_t s, const DecClFwdArgs& a0, bool greedy_deco
   (void)hipFuncSetAttribute((const void*)dec_cl_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)hipFuncSetAttribute((const void*)dec_cl_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   for (int g0 = 0; g0 < groups; g0 += per_pass) {
-    DecClFwdArgs a = a0; a.group0 = g0; a.ngroups = std::min(per_pass, groups - g0); a.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;
+    DecClFwdArgs a = a0; a.group0 = g0; a.ngroups = std::min(per_pass, groups - g0); a.force_remote = getenv("AOCR_CL_REMOTE") != nullptr; a.no_early = getenv("AOCR_NO_DEC_EARLY") != nullptr;
     a.stamps = getenv("AOCR_DC_STAMPS") ? a.xtab + (size_t)groups * NM : nullptr;   // debugging aid: cycles per phase of workgroup 0
     if (greedy_decode) { a.tokx = reinterpret_cast<unsigned*>(a.pbuf + (size_t)groups * 32 * 32 * 40); hipLaunchKernelGGL(dec_cl_fwd_kernel<true>, dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), lds, s, a); }
     else hipLaunchKernelGGL(dec_cl_fwd_kernel<false>, dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), lds, s, a);

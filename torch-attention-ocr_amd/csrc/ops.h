@@ -227,7 +227,7 @@ void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a, int G, int RT);
 void enc_cluster_backward(hipStream_t s, const EncClBwdArgs& a, int G, int RT);
 // teacher-forced decoder loop in one launch (dec_cluster.hip): Hd = 512, two layers, input feed, bf16 mode
 struct DecClFwdArgs {
-  int B, T, L; unsigned epoch; int group0 = 0, ngroups = 0, force_remote = 0;
+  int B, T, L; unsigned epoch; int group0 = 0, ngroups = 0, force_remote = 0; int no_early = 0;   /* greedy decode: do not leave the loop when every row of a group has finished (debugging aid) */
   const bf16_t *w1i, *w1h, *w2i, *w2h, *wc;           // bf16 shadows: [4 Hd][Hd] x 4, W_c [Hd][2 Hd]
   const float *b2i, *b2h;                              // layer-2 biases (layer 1's are inside zx1)
   const float* zx1;                                    // [L][B][4 Hd]: embedding part of layer 1 + both biases
