@@ -62,6 +62,56 @@ def run_case(kw, B, W, maxlen):
     return out
 
 
+
+def s9_inputs():
+    """The S9 case (model.lua:402-404,516): B = 6, He = 16, input feed, Ld = 2, calibrated BatchNorm statistics,
+    projector bias of id 39 raised so that some rows -- NOT the last one, for which Torch7 would raise an index error at beam 1 --
+    emit id 39 (= V) at the first step."""
+    cfg = O.OcrConfig(enc_hidden=16, enc_layers=1, dec_layers=2, input_feed=True)
+    P = O.init_params(cfg, SEED)
+    img, tgt, tge, nnz = O.synth_batch(6, 36, max_len=5, min_len=2)
+    img = torch.from_numpy(img); tgt = torch.from_numpy(tgt); tge = torch.from_numpy(tge)
+    st = O.calibrated_bn_state(P, img)
+    # first-step margin of every row: best other logit - logit of id 39; the bias is the midpoint of the widest gap between the
+    # n-th and (n+1)-th smallest margins (n = 2..4), so exactly n rows emit id 39 first (the gap is asserted wide enough for any
+    # fp32 evaluation to agree)
+    with torch.no_grad():
+        feats = O.cnn_forward(P, st, img, False)
+        ctx, tr = O.encoder_forward(P, cfg, feats)
+        c0, h0 = O.decoder_init_state(cfg, tr, 6, feats)
+        _, _, out, _ = O.decoder_step_fwd(P, cfg, tgt[:, 0], ctx, feats.new_zeros(6, cfg.dec_hidden), c0, h0)
+        lg, _ = O.projector_fwd(out, P["proj.w"], P["proj.b"])
+    other = lg.clone(); other[:, 38] = -1e30
+    margin = other.max(1).values - lg[:, 38]
+    srt, order = torch.sort(margin)
+    n = max((n for n in (2, 3, 4) if 5 not in order[:n].tolist()), key=lambda n: float(srt[n] - srt[n - 1]))
+    assert float(srt[n] - srt[n - 1]) > 1e-3, (margin, order)
+    P = dict(P); P["proj.b"] = P["proj.b"].clone(); P["proj.b"][38] += 0.5 * float(srt[n - 1] + srt[n])
+    return cfg, P, st, img, tgt, tge
+
+
+def s9_fixture():
+    """Expected decode of the S9 case under the build's documented choice (parent = beam 1 at t = 1) and, recorded beside it, what
+    the reference's literal arithmetic gathers (oracle_torch.decode_beam(s9="reference"))."""
+    cfg, P, st, img, tgt, tge = s9_inputs()
+    out = {}
+    for beam in (1, 5):
+        fx = O.decode_beam(P, st, cfg, img, tgt, tge, beam=beam, max_decoder_l=8)
+        rf = O.decode_beam(P, st, cfg, img, tgt, tge, beam=beam, max_decoder_l=8, s9="reference")
+        first = fx["hist_tok"][0][:, 0]
+        out[f"b{beam}:first_token"] = first.numpy()
+        for tag, d in (("fixed", fx), ("ref", rf)):
+            out[f"b{beam}:{tag}:labels"] = d["labels"].numpy(); out[f"b{beam}:{tag}:scores"] = d["scores"].numpy()
+            out[f"b{beam}:{tag}:gold"] = d["gold_scores"].numpy(); out[f"b{beam}:{tag}:src"] = d["s9_src"].numpy()
+            out[f"b{beam}:{tag}:loss"] = np.float64(d["loss"])
+    assert 2 <= (out["b1:first_token"] == 39).sum() <= 4 and out["b1:first_token"][-1] != 39
+    # beam 1: the literal arithmetic continues the id-39 rows from the NEXT image's state -> different strings; beam 5: replicas are
+    # identical at t = 1 and the recorded parent is never read -> identical results
+    assert not np.array_equal(out["b1:fixed:labels"], out["b1:ref:labels"]) or not np.allclose(out["b1:fixed:scores"], out["b1:ref:scores"])
+    assert np.array_equal(out["b5:fixed:labels"], out["b5:ref:labels"]) and np.allclose(out["b5:fixed:scores"], out["b5:ref:scores"])
+    return out
+
+
 def leaf_fixtures():
     """Hand-checkable known answers for the leaf ops."""
     out = {}
@@ -98,6 +148,7 @@ def main():
     for name, (kw, B, W, ml) in CASES.items():
         np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **run_case(kw, B, W, ml))
         print("wrote", name)
+    np.savez_compressed(os.path.join(OUT, "s9_first39.npz"), **s9_fixture())
     np.savez_compressed(os.path.join(OUT, "leaf_ops.npz"), **leaf_fixtures())
     np.savez_compressed(os.path.join(OUT, "data_path.npz"), **data_fixture())
 

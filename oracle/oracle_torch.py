@@ -314,6 +314,19 @@ def cnn_forward(P, bn_state, images, training: bool, update_running: bool = True
     return x
 
 
+@torch.no_grad()
+def calibrated_bn_state(P, images, iters: int = 80):
+    """BatchNorm running statistics that an evaluation-mode forward can use meaningfully (tests only): `iters` training-mode
+    forwards of `images` with the momentum-0.1 update of cnn.lua:23,32,41, i.e. the running statistics converge to the batch
+    statistics (0.9^80 = 2e-4 of the initial 0 / 1 left).  With the initial statistics an evaluation-mode CNN is not normalised at
+    all, the LSTM gates saturate and every image decodes to the same string -- a decode test on them is blind to the image."""
+    st = init_bn_state(dtype=images.dtype if images.dtype.is_floating_point else torch.float64)
+    x = images.to(next(iter(P.values())).dtype)
+    for _ in range(iters):
+        cnn_forward(P, st, x, True, True)
+    return st
+
+
 def lstm_cell_fwd(x, c_prev, h_prev, Wi, bi, Wh, bh):
     """src/model/LSTM.lua:79-105; gate order [in, forget, out, g]."""
     H = c_prev.shape[1]
@@ -624,11 +637,18 @@ def _topk_sorted(scores: torch.Tensor, k: int):
 
 
 @torch.no_grad()
-def decode_beam(P, bn_state, cfg: OcrConfig, images, targets, targets_eval, beam: int = 1, max_decoder_l: int = 50, trie=None):
+def decode_beam(P, bn_state, cfg: OcrConfig, images, targets, targets_eval, beam: int = 1, max_decoder_l: int = 50, trie=None,
+                s9: str = "fixed"):
     """forward_only step: beam search (beam=1 -> greedy), back-trace, exact-match
     accuracy and the teacher-forced gold pass.  Deviations from the reference,
     both documented in DESIGN.md: S9 (t=1 parent index is computed from a 0-based
     id, i.e. always beam 1) and S10 (top-k order = sorted, ties to lowest index).
+    s9="reference" replays what model.lua:402-404,516 literally does at t = 1: `raw_indices` is still the 1-based top-k index
+    there, so beam_parents = floor(raw / V) + 1 is 2 (not 1) exactly when the first token is id V (= 39).  With beam > 1 that
+    gathers the second of `beam` IDENTICAL replicas of the image's state (:524-533 replicate before the gather) and the parent
+    recorded for t = 1 is never read by the back-trace (:573-585): no effect.  With beam = 1 the gather row is b + 1: the NEXT
+    image's decoder state (an index error in Torch7 for the last row of the batch -- raised here as IndexError).  The returned
+    dict carries `s9_src` = the rows gathered after the first step.
     trie: root node from oracle/dict_oracle.load_dictionary (-use_dictionary,
     model.lua:380-387,405-445,460-513) or None."""
     B = images.shape[0]
@@ -659,11 +679,19 @@ def decode_beam(P, bn_state, cfg: OcrConfig, images, targets, targets_eval, beam
             nodes = [x[2] for x in sel]
             parents = torch.zeros(B, k, dtype=torch.int64)
             src = torch.arange(B).unsqueeze(1).expand(B, k).reshape(-1)
+            s9_src = src.clone()
         elif t == 0:
             beam_scores, raw = _topk_sorted(logp, k)                         # :402
             cur = raw + 1
             parents = torch.zeros(B, k, dtype=torch.int64)                   # S9 fixed: parent beam 0
             src = torch.arange(B).unsqueeze(1).expand(B, k).reshape(-1)      # beam_replicate, :524-533
+            if s9 == "reference" and trie is None:
+                parents = cur // V                                           # :516 on the 1-based index: 1 iff the token is id V
+                rep = parents + (torch.arange(B) * k).unsqueeze(1)           # row of the REPLICATED (B*k) state, :524-533
+                if int(rep.max()) >= B * k:
+                    raise IndexError("model.lua:524-533: index out of range (first token of the last row is id V with beam 1)")
+                src = (rep // k).reshape(-1)                                 # replica r of image b is image b's state
+            s9_src = src.clone()
         else:
             logp = logp.clone()
             fin = (tok == PAD) | (tok == EOS)
@@ -716,4 +744,4 @@ def decode_beam(P, bn_state, cfg: OcrConfig, images, targets, targets_eval, beam
         if cfg.input_feed:
             feed = out
     return dict(labels=labels, scores=scores, gold_scores=gold, loss=loss * B, num_correct=num_correct,
-                context=context, feats=feats, hist_tok=torch.stack(hist_tok), hist_par=torch.stack(hist_par))
+                context=context, feats=feats, hist_tok=torch.stack(hist_tok), hist_par=torch.stack(hist_par), s9_src=s9_src)

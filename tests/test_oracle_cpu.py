@@ -81,3 +81,38 @@ def test_synth_batch_layout():
         n = int((te[b] == 3).argmax())
         assert np.array_equal(t[b, 1:n + 1], te[b, :n]) and np.all(te[b, n + 1:] == 1) and np.all(t[b, n + 1:] == 1)
     assert nnz == int((te != 1).sum())
+
+
+def test_s9_fixture_first_token_39():
+    """Quirk S9 (model.lua:402-404,516): the oracle regenerates the committed fixture, whose two halves record the build's choice
+    (parent = beam 1 at t = 1) and the reference's literal arithmetic.  Beam 5: identical (the replicas are identical at t = 1 and the
+    recorded parent is never read).  Beam 1: the literal arithmetic gathers row b + 1 for the rows whose first token is id 39."""
+    g = _gen()
+    got = g.s9_fixture()
+    ref = np.load(os.path.join(GOLD, "s9_first39.npz"))
+    assert set(got) == set(ref.files)
+    for k in ref.files:
+        a, b = np.asarray(got[k]), ref[k]
+        assert np.array_equal(a, b) if a.dtype.kind in "iu" else np.allclose(a, b, rtol=1e-9, atol=1e-11), k
+    first = ref["b1:first_token"]
+    rows39 = np.nonzero(first == 39)[0]
+    assert 2 <= len(rows39) <= 4 and first[-1] != 39
+    assert np.array_equal(ref["b1:fixed:src"], np.arange(6))
+    want = np.arange(6); want[rows39] += 1
+    assert np.array_equal(ref["b1:ref:src"], want)                                    # the next image's decoder state
+    assert np.array_equal(ref["b5:fixed:labels"], ref["b5:ref:labels"]) and np.array_equal(ref["b5:fixed:scores"], ref["b5:ref:scores"])
+    assert not np.allclose(ref["b1:fixed:scores"][rows39], ref["b1:ref:scores"][rows39])
+    other = np.setdiff1d(np.arange(6), rows39)
+    assert np.allclose(ref["b1:fixed:scores"][other], ref["b1:ref:scores"][other])
+
+
+def test_s9_reference_mode_raises_for_last_row():
+    """Torch7 raises an index error when the LAST row of a beam-1 batch emits id 39 first (row B + 1 does not exist)."""
+    import oracle_torch as O
+    g = _gen()
+    cfg, P, st, img, tgt, tge = g.s9_inputs()
+    P = dict(P); P["proj.b"] = P["proj.b"].clone(); P["proj.b"][38] += 1.0           # every row now emits id 39 first
+    with pytest.raises(IndexError):
+        O.decode_beam(P, st, cfg, img, tgt, tge, beam=1, max_decoder_l=8, s9="reference")
+    d = O.decode_beam(P, st, cfg, img, tgt, tge, beam=1, max_decoder_l=8)            # the build's choice decodes every row
+    assert (d["hist_tok"][0][:, 0] == 39).all()

@@ -80,8 +80,8 @@ def attach(model, sync_bn: bool = True) -> None:
     sync_bn -- the three BatchNorm layers normalise with the statistics of the GLOBAL batch, so that N ranks on slices of a batch
     compute what one GPU computes on the whole batch.  A Lua / C host uses `aocr_comm_init_rank` (RCCL bound by the library) instead."""
     from ._lib import ALLREDUCE_FN, check, lib
-    if world_size() <= 1 or getattr(model, "_comm_cb", None) is not None:
-        return
+    if world_size() <= 1 or getattr(model, "_comm_cb", None) is not None or getattr(model, "_comm_rccl", False):
+        return                                       # already attached (callback or the library's own RCCL provider)
     d = torch.distributed
 
     def view(ptr, count, dtype):
@@ -104,8 +104,9 @@ def attach(model, sync_bn: bool = True) -> None:
         except Exception as e:                       # never let an exception cross the C boundary
             print(f"[aocr.dist] all-reduce callback failed: {e!r}", flush=True)
             return 1
-    model._comm_cb = ALLREDUCE_FN(cb)                # keep the trampoline alive as long as the model
-    check(lib.aocr_comm_set_callback(model._h, C.cast(model._comm_cb, C.c_void_p), None, world_size(), int(sync_bn)), "aocr_comm_set_callback")
+    tramp = ALLREDUCE_FN(cb)
+    check(lib.aocr_comm_set_callback(model._h, C.cast(tramp, C.c_void_p), None, world_size(), int(sync_bn)), "aocr_comm_set_callback")
+    model._comm_cb = tramp                           # only once the library took it; keeps the trampoline alive as long as the model
 
 
 def attach_rccl(model, sync_bn: bool = True) -> None:

@@ -71,6 +71,7 @@ class Model:
         self.last_norms = None
         self._comm_stream = None
         self._buckets = None
+        self._drop_last_gs, self._drop_repeat = None, 0
 
     # ------------------------------------------------------------------ construction
     def _set_structure(self, config):
@@ -457,7 +458,13 @@ class Model:
     def _arm_dropout(self):
         """nn.Dropout(p) of LSTM.lua:68-69,116-118 for the coming training step (rank-dependent seed under data parallelism)."""
         if self.dropout > 0.0 or getattr(self, "_dropout_armed", False):
-            check(lib.aocr_set_dropout(self._h, self.dropout, self.dropout_seed + 7919 * dist.rank(), int(self.global_step)), "aocr_set_dropout")
+            # mask counter = global_step (train.lua:115 advances it in the host loop) + 2^32 x (training steps already taken at this
+            # global_step): a caller that never advances global_step still draws a fresh mask every step, and the first step at a
+            # given global_step uses exactly (seed, global_step) -- what the oracle replays (oracle_torch.dropout_state)
+            gs = int(self.global_step)
+            rep = self._drop_repeat + 1 if gs == self._drop_last_gs else 0
+            self._drop_last_gs, self._drop_repeat = gs, rep
+            check(lib.aocr_set_dropout(self._h, self.dropout, self.dropout_seed + 7919 * dist.rank(), gs + (rep << 32)), "aocr_set_dropout")
             self._dropout_armed = self.dropout > 0.0
 
     def sgd_step(self, lr=None, clip=5.0):
@@ -497,10 +504,8 @@ class Model:
         A path ending in .t7 is written in Torch7 serialization instead (aocr.checkpoint.write_flat_checkpoint).
         NOT readable by the reference's model:load (which expects the five serialized nn modules): the reference-format writer is
         the Lua side of the boundary (lua/model.lua model:save, which keeps the reference's own nets as parameter containers).
-        Under data parallelism without synchronised BatchNorm the running statistics are rank-local; they are averaged over the ranks
-        here so that a rank-0 checkpoint does not carry one rank's statistics."""
-        if dist.world_size() > 1 and getattr(self, "_comm_cb", None) is None:
-            torch.distributed.all_reduce(self.bn_state); self.bn_state.div_(dist.world_size())
+        No collective happens here (train.lua saves from one process): under data parallelism WITHOUT synchronised BatchNorm the
+        running statistics are rank-local -- every rank calls `sync_bn_state()` before rank 0 saves."""
         if str(model_path).endswith(".t7"):
             from .checkpoint import write_flat_checkpoint
             write_flat_checkpoint(model_path, {k: v.numpy() for k, v in self.get_parameters().items()},
@@ -508,6 +513,20 @@ class Model:
             return
         torch.save({"params": self.params.detach().cpu(), "bn_state": self.bn_state.detach().cpu(), "config": self.config,
                     "global_step": self.global_step, "optim_state": dict(self.optim_state)}, model_path)
+
+    def sync_bn_state(self):
+        """COLLECTIVE (every rank calls it): averages the BatchNorm running statistics over the ranks.  Needed only when the step ran
+        with rank-local batch statistics; with synchronised BatchNorm (the default of aocr.dist.attach / attach_rccl) the running
+        statistics are already identical on all ranks and this returns without communicating."""
+        if dist.world_size() <= 1 or self.sync_bn_active():
+            return
+        torch.distributed.all_reduce(self.bn_state); self.bn_state.div_(dist.world_size())
+
+    def sync_bn_active(self) -> bool:
+        """True when the library normalises with the statistics of the global batch (asked of the library, include/aocr.h)."""
+        n, sb, prov = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib.aocr_comm_info(self._h, C.byref(n), C.byref(sb), C.byref(prov)), "aocr_comm_info")
+        return bool(sb.value) and prov.value != 0
 
     def shutdown(self):
         if self.visualize_file:
