@@ -135,6 +135,8 @@ int aocr_comm_init_rank(aocr_model* m, const char id[128], int32_t nranks, int32
 int aocr_comm_set_callback(aocr_model* m, aocr_allreduce_fn fn, void* user, int32_t nranks, int32_t sync_bn);
 int aocr_allreduce_grads(aocr_model* m, float* loss_dev);
 int aocr_comm_destroy(aocr_model* m);
+/* What is attached: *nranks (1 without a communicator), *sync_bn (0 / 1), *provider (0 none, 1 RCCL, 2 host callback).  Any pointer may be NULL. */
+int aocr_comm_info(aocr_model* m, int32_t* nranks, int32_t* sync_bn, int32_t* provider);
 
 /* optim.sgd_list, src/optim/optim_sgd.lua:38-95 with the options the reference
  * leaves at 0: per group, if ||g||_2 > clip then g *= clip/||g||_2; w -= lr*g.
@@ -192,7 +194,8 @@ int aocr_decode_dict(aocr_model* m, const float* images_dev, const int32_t* targ
 int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32_t* ndim, int64_t shape[4]);
 
 /* Times `iters` launches of one hot kernel of the LAST step's shape with HIP events
- * on the model's stream; which: 0 = conv6 forward implicit GEMM (largest layer).
+ * on the model's stream; which: 0 = conv6 forward implicit GEMM (largest layer), 1 = conv6 filter gradient (the split-K
+ * kernel + the sum of its slabs, as the backward pass launches them; the result goes to scratch).
  * ms_per_launch and flops_per_launch are host outputs (this call synchronises). */
 int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_per_launch, double* flops_per_launch);
 

@@ -24,13 +24,10 @@ hipError_t hipStreamDestroy(hipStream_t stream);
 hipError_t hipStreamSynchronize(hipStream_t stream);
 const char* hipGetErrorString(hipError_t e);
 
-/* ---- include/aocr.h */
+/* ---- include/aocr.h: every declaration of the header, comments stripped, array bounds resolved (tests/test_lua_cdef_cpu.py
+   compares this block with the header declaration by declaration) */
 typedef struct aocr_model aocr_model;
-typedef struct aocr_config {
-  int32_t batch_size, img_h, max_img_w, enc_hidden, enc_layers, dec_layers, vocab, emb, input_feed, max_decoder_l, max_beam, compute;
-} aocr_config;
-typedef struct aocr_trie { const uint64_t* child_mask_dev; const int32_t* child_base_dev; const int32_t* child_dev; int32_t n_nodes, n_edges; } aocr_trie;
-typedef struct aocr_image_desc { int64_t offset; int32_t height, width, channels, reserved; } aocr_image_desc;
+typedef struct aocr_config { int32_t batch_size; int32_t img_h; int32_t max_img_w; int32_t enc_hidden; int32_t enc_layers; int32_t dec_layers; int32_t vocab; int32_t emb; int32_t input_feed; int32_t max_decoder_l; int32_t max_beam; int32_t compute; } aocr_config;
 const char* aocr_last_error(void);
 int aocr_version(void);
 int aocr_param_counts(const aocr_config* cfg, int64_t counts[5]);
@@ -40,17 +37,47 @@ size_t aocr_workspace_bytes(const aocr_config* cfg);
 int aocr_model_create(const aocr_config* cfg, float* params_dev, float* grads_dev, float* bn_state_dev, void* workspace_dev, size_t workspace_bytes, void* stream, aocr_model** out);
 int aocr_model_destroy(aocr_model* m);
 int aocr_model_set_stream(aocr_model* m, void* stream);
-int aocr_set_dropout(aocr_model* m, double p, uint64_t seed, uint64_t train_step);
 int aocr_cluster_status(aocr_model* m, int32_t* code);
+int aocr_set_dropout(aocr_model* m, double p, uint64_t seed, uint64_t train_step);
 int aocr_train_forward_backward(aocr_model* m, const float* images_dev, const int32_t* targets_dev, const int32_t* targets_eval_dev, int32_t B, int32_t W, int32_t L, float grad_scale, float* loss_dev);
-int aocr_sgd_step(aocr_model* m, float lr, float clip, float* norms_dev);
-int aocr_decode_dict(aocr_model* m, const float* images_dev, const int32_t* targets_dev, const int32_t* targets_eval_dev, int32_t B, int32_t W, int32_t L, int32_t beam, const aocr_trie* trie, int32_t* labels_dev, float* scores_dev, float* gold_scores_dev, float* loss_dev);
-int aocr_edit_distance(void* stream, const int32_t* labels_dev, const int32_t* targets_dev, int32_t B, int32_t L, int32_t* dist_dev, int32_t* target_len_dev);
-int aocr_preprocess_lines(void* stream, const uint8_t* src_dev, const aocr_image_desc* desc_dev, int32_t n_images, int32_t out_h, int32_t out_w, float* out_dev);
-/* data parallelism inside the library: RCCL over xGMI (one process per GPU) */
+int aocr_grad_buckets(const aocr_config* cfg, int64_t begin[4], int64_t end[4]);
+int aocr_stream_wait_grads(aocr_model* m, int32_t bucket, void* stream);
+typedef int (*aocr_allreduce_fn)(void* user, void* buf_dev, int64_t count, int32_t dtype, void* stream);
 int aocr_comm_unique_id(char id[128]);
 int aocr_comm_init_rank(aocr_model* m, const char id[128], int32_t nranks, int32_t rank, int32_t sync_bn);
+int aocr_comm_set_callback(aocr_model* m, aocr_allreduce_fn fn, void* user, int32_t nranks, int32_t sync_bn);
 int aocr_allreduce_grads(aocr_model* m, float* loss_dev);
+int aocr_comm_destroy(aocr_model* m);
+int aocr_comm_info(aocr_model* m, int32_t* nranks, int32_t* sync_bn, int32_t* provider);
+int aocr_sgd_step(aocr_model* m, float lr, float clip, float* norms_dev);
+int aocr_adadelta_step(aocr_model* m, float rho, float eps, float weight_decay, float* state_dev);
+int aocr_forward_logits(aocr_model* m, const float* images_dev, const int32_t* targets_dev, const int32_t* targets_eval_dev, int32_t B, int32_t W, int32_t L, int32_t training, float* logits_dev, float* loss_dev);
+int aocr_decode(aocr_model* m, const float* images_dev, const int32_t* targets_dev, const int32_t* targets_eval_dev, int32_t B, int32_t W, int32_t L, int32_t beam, int32_t* labels_dev, float* scores_dev, float* gold_scores_dev, float* loss_dev);
+typedef struct aocr_trie { const uint64_t* child_mask_dev; const int32_t* child_base_dev; const int32_t* child_dev; int32_t n_nodes, n_edges; } aocr_trie;
+int aocr_decode_dict(aocr_model* m, const float* images_dev, const int32_t* targets_dev, const int32_t* targets_eval_dev, int32_t B, int32_t W, int32_t L, int32_t beam, const aocr_trie* trie, int32_t* labels_dev, float* scores_dev, float* gold_scores_dev, float* loss_dev);
+int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32_t* ndim, int64_t shape[4]);
+int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_per_launch, double* flops_per_launch);
+int aocr_profile_enable(aocr_model* m, int32_t on);
+int aocr_profile_read(aocr_model* m, float ms[12], int32_t* marks);
+int aocr_gemm(void* stream, int32_t compute, const float* A_dev, int64_t lda, int32_t a_kmajor, const float* B_dev, int64_t ldb, int32_t b_kmajor, float* C_dev, int64_t ldc, int32_t M, int32_t N, int32_t K, const float* bias_dev, int32_t accumulate);
+int aocr_conv2d_forward(void* stream, int32_t compute, const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, uint8_t* idx_dev, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t pad, int32_t relu, int32_t pool);
+int aocr_conv2d_backward_data(void* stream, int32_t compute, const float* dy_dev, const float* w_dev, float* dx_dev, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t pad);
+int aocr_conv2d_backward_filter(void* stream, int32_t compute, const float* x_dev, const float* dy_dev, float* dw_dev, float* dbias_dev, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t pad);
+int aocr_unpool_relu_backward(void* stream, const float* dpooled_dev, const float* pooled_dev, const uint8_t* idx_dev, float* dy_dev, int32_t B, int32_t Ho, int32_t Wo, int32_t C, int32_t pool);
+int aocr_conv1_forward(void* stream, const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int32_t B, int32_t H, int32_t W);
+int aocr_conv1_backward(void* stream, const float* x_dev, const float* w_dev, const float* bias_dev, const float* dy_pooled_dev, float* dw_dev, float* dbias_dev, int32_t B, int32_t H, int32_t W);
+int aocr_batchnorm_relu_forward(void* stream, const float* x_dev, float* y_dev, const float* weight_dev, const float* bias_dev, float* running_mean_dev, float* running_var_dev, float* save_dev, void* scratch_dev, int64_t rows, int32_t C, int32_t training, int32_t update_running, int32_t tb_rows);
+int aocr_batchnorm_relu_backward(void* stream, const float* x_dev, const float* y_dev, const float* dA_dev, const float* weight_dev, const float* save_dev, float* dx_dev, float* dweight_dev, float* dbias_dev, void* scratch_dev, int64_t rows, int32_t C, int32_t tb_rows);
+int aocr_lstm_cell_forward(void* stream, int32_t compute, const float* x_dev, int32_t in_size, const float* h_prev_dev, const float* c_prev_dev, const float* w_i2h_dev, const float* b_i2h_dev, const float* w_h2h_dev, const float* b_h2h_dev, float* c_dev, float* h_dev, float* gates_dev, int32_t B, int32_t H);
+int aocr_lstm_cell_backward(void* stream, const float* dc_dev, const float* dh_dev, const float* gates_dev, const float* c_prev_dev, const float* c_dev, float* dz_dev, float* dc_prev_dev, int32_t B, int32_t H);
+int aocr_attention_forward(void* stream, const float* ctx_dev, const float* q_dev, float* a_dev, float* c_dev, int64_t ldc, int32_t B, int32_t T, int32_t Hd);
+int aocr_attention_backward(void* stream, const float* ctx_dev, const float* q_dev, const float* a_dev, const float* dc_dev, int64_t lddc, float* ds_dev, float* dq_dev, int32_t B, int32_t T, int32_t Hd);
+int aocr_logsoftmax_nll(void* stream, const float* logits_dev, int64_t ld, const int32_t* targets_dev, float* logp_dev, float* dlogits_dev, float* nll_rows_dev, int64_t rows, int32_t V, float grad_scale);
+int aocr_beam_select(void* stream, const float* logp_dev, const int32_t* prev_tok_dev, float* beam_scores_dev, int32_t* tokens_dev, int32_t* parents_dev, int32_t B, int32_t kin, int32_t kout, int32_t V);
+int aocr_beam_select_dict(void* stream, const float* logp_dev, const int32_t* prev_tok_dev, float* beam_scores_dev, int32_t* tokens_dev, int32_t* parents_dev, int32_t B, int32_t kin, int32_t kout, int32_t V, const aocr_trie* trie, const int32_t* loc_in_dev, int32_t* loc_out_dev);
+int aocr_edit_distance(void* stream, const int32_t* labels_dev, const int32_t* targets_dev, int32_t B, int32_t L, int32_t* dist_dev, int32_t* target_len_dev);
+typedef struct aocr_image_desc { int64_t offset; int32_t height, width, channels, reserved; } aocr_image_desc;
+int aocr_preprocess_lines(void* stream, const uint8_t* src_dev, const aocr_image_desc* desc_dev, int32_t n_images, int32_t out_h, int32_t out_w, float* out_dev);
 ]]
 
 local M = {}

@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- BEFORE libaocr.so: the process must end up with O
 #                libaocr.so first pulls in /opt/rocm's libamdhip64 next to PyTorch's own copy, and the library then sees no device
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaocr.so")
+LIB_PATH = os.environ.get("AOCR_LIB") or os.path.join(_HERE, "libaocr.so")     # AOCR_LIB: another build of the SAME library (debug stamps), as in lua/aocr_ffi.lua
 
 NUM_GROUPS = 5
 COMPUTE_F32, COMPUTE_BF16 = 0, 1
@@ -70,6 +70,7 @@ SIGNATURES = {
     "aocr_comm_set_callback": (C.c_int, [_vp, _vp, _vp, _i32, _i32]),
     "aocr_allreduce_grads": (C.c_int, [_vp, _vp]),
     "aocr_comm_destroy": (C.c_int, [_vp]),
+    "aocr_comm_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "aocr_sgd_step": (C.c_int, [_vp, _f32, _f32, _vp]),
     "aocr_adadelta_step": (C.c_int, [_vp, _f32, _f32, _f32, _vp]),
     "aocr_forward_logits": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -183,6 +183,13 @@ int aocr_allreduce_grads(aocr_model* m, float* loss_dev) {
   return 0;
 }
 int aocr_comm_destroy(aocr_model* m) { REQUIRE(m, "NULL model"); comm_destroy(m); return 0; }
+int aocr_comm_info(aocr_model* m, int32_t* nranks, int32_t* sync_bn, int32_t* provider) {
+  REQUIRE(m, "NULL model");
+  if (nranks) *nranks = m->comm.provider ? m->comm.nranks : 1;
+  if (sync_bn) *sync_bn = sync_bn_on(m) ? 1 : 0;
+  if (provider) *provider = m->comm.provider;
+  return 0;
+}
 int aocr_profile_enable(aocr_model* m, int32_t on) { REQUIRE(m, "NULL model"); m->prof_on = on != 0; m->prof_n = 0; return 0; }
 int aocr_profile_read(aocr_model* m, float ms[AOCR_PROF_FAMILIES], int32_t* marks) {
   REQUIRE(m && ms, "NULL argument");
@@ -395,13 +402,16 @@ int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32
 int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_per_launch, double* flops_per_launch) {
   REQUIRE(m && ms_per_launch && flops_per_launch, "NULL argument");
   REQUIRE(m->last_valid, "run a step first");
-  REQUIRE(which == 0, "unknown kernel id %d", which);
+  REQUIRE(which == 0 || which == 1, "unknown kernel id %d", which);
   REQUIRE(iters >= 1, "iters must be >= 1");
   const Dims& d = m->last;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto run = [&]() {
-    conv_forward(m->s, m->bf16, m->A5, m->conv[6].w, m->conv[6].b, m->bf16 ? nullptr : m->A6, m->idx6, d.B, d.H4, d.W2, 512, 512, 3, 1, 1, 2, m->A5b, m->wb[6],
-                 m->A6b, 1);                                // exactly the launch cnn_forward makes for conv6 (distinct symbol: TAG = 1)
+    if (which == 0)
+      conv_forward(m->s, m->bf16, m->A5, m->conv[6].w, m->conv[6].b, m->bf16 ? nullptr : m->A6, m->idx6, d.B, d.H4, d.W2, 512, 512, 3, 1, 1, 2, m->A5b, m->wb[6],
+                   m->A6b, 1);                              // exactly the launch cnn_forward makes for conv6 (distinct symbol: TAG = 1)
+    else                                                    // conv6 filter gradient as backward_all launches it (split-K slabs + their sum), summed into scratch
+      conv_backward_filter(m->s, m->bf16, m->A5, m->G0, m->G1, nullptr, d.B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, m->G0b, m->wg_part, m->wg_part_floats, 1);
   };
   run();
   hipEventRecord(e0, m->s);

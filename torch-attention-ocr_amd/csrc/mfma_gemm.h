@@ -1262,13 +1262,14 @@ __device__ __forceinline__ void tr_tile(const LoadMNh& a, const BL& b, const EP&
 }
 
 template <class EP>
-__global__ __launch_bounds__(256, 4) void conv_wgrad_tr_kernel(LoadMNh a, LoadConvXcolh b, EP ep, int K, int kper, int gx, int gy, int gz) {
+__global__ __launch_bounds__(256, 4) void conv_wgrad_tr_kernel(LoadMNh a, LoadConvXcolh b, EP ep, int K, int kper, int gx, int gy, int gz, float* part, long long pstride) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][32 * TR_PITCH];
   const int nwg = gx * gy * gz, orig = blockIdx.x;                    // flat k-range-major order, see conv_wgrad_dma_kernel
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
   const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   const int zsp = lin / (gx * gy), bid = lin - zsp * (gx * gy);
   const int kbeg = zsp * kper;
+  if (part) { ep.C = part + (size_t)zsp * pstride; ep.flags &= ~8 /* EP_ATOMIC (epilogues.h) */; }     // split-K slab of this k range: plain stores, summed by splitk_reduce
   tr_tile(a, b, ep, (bid / gx) * 128, (bid % gx) * 128, kbeg, min(K, kbeg + kper), lds);
 }
 
@@ -1282,7 +1283,7 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_kernel(LoadMNh a, LoadCo
 // The im2col operand's piece addresses are per lane: (tap, ci) is a lane constant, the pixel cursor advances by 32.
 // ---------------------------------------------------------------------------
 template <class EP, int ABL = 0>                        // ABL: timing-only ablations (tools/ubench/wgrad_dma.hip): 1 no in-loop DMA, 2 no MFMA, 4 no fragment reads, 16 / 128 d y / x pieces from the zero page
-__global__ __launch_bounds__(512, 1) void conv_wgrad_dma_kernel(LoadMNh a, LoadConvXcolh b, EP ep, int K, int kper, int gx, int gy, const bf16_t* zero, int gz) {
+__global__ __launch_bounds__(512, 1) void conv_wgrad_dma_kernel(LoadMNh a, LoadConvXcolh b, EP ep, int K, int kper, int gx, int gy, const bf16_t* zero, int gz, float* part, long long pstride) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 32768];          // the ONLY LDS object
   // (Round 1 gave every XCD its own K range with 36 tiles on its 32 CUs, i.e. two rounds: 1.5-2.5x slower.)
   // ONE flat grid over (k range, tile), renumbered so that the workgroups of an XCD are consecutive in k-range-major order: an
@@ -1295,6 +1296,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_dma_kernel(LoadMNh a, LoadC
   const int zsp = lin / (gx * gy), bid = lin - zsp * (gx * gy);
   const int m_blk = (bid / gx) * 256, n_blk = (bid % gx) * 256;
   const int kbeg = zsp * kper, kend = min(K, kbeg + kper);
+  // Split-K epilogue: float atomics execute at the memory side at ~1.3 TB/s chip-wide (66 MB of partial tiles = ~50 us of every
+  // launch); with a slab per k range the partial tiles are plain stores (~6 TB/s) and one HBM-bound pass sums the slabs (splitk_reduce)
+  if (part) { ep.C = part + (size_t)zsp * pstride; ep.flags &= ~8 /* EP_ATOMIC (epilogues.h) */; }
   const int nk = kend > kbeg ? (kend - kbeg + 31) >> 5 : 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, wm = wave >> 2, wn = wave & 3;

@@ -86,6 +86,7 @@ struct aocr_model {
   float *bzx1, *bzx_tab, *bq, *ba, *bcat, *bout, *blogits, *blogp, *beam_scores;     // bzx_tab [V][4Hd]: per-token first-layer gate input
   int32_t *hist_tok, *hist_par, *tgt_pad, *tge_pad, *trie_loc[2];   // trie_loc: dictionary node of every beam (ping-pong)
   void* sgd_scratch;
+  float* wg_part = nullptr; size_t wg_part_floats = 0;     // split-K slabs of the filter gradients (conv_backward_filter)
 
   std::vector<aocr::ShadowJob> shadow_host;   // bf16 mode: job table of the one-launch weight shadow refresh
   aocr::ShadowJob* shadow_dev; int shadow_tiles;

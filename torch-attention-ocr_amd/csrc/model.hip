@@ -159,6 +159,8 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
   m->tgt_pad = a.get<int32_t>(B * L); m->tge_pad = a.get<int32_t>(B * L);
   m->trie_loc[0] = a.get<int32_t>(R); m->trie_loc[1] = a.get<int32_t>(R);
   m->sgd_scratch = a.get<char>(sgd_scratch_bytes());
+  // split-K slabs of the filter gradients (bf16 mode): one resident round of workgroups x one fp32 tile each = 64 MiB at most
+  m->wg_part_floats = m->bf16 ? (size_t)16 << 20 : 0; m->wg_part = m->wg_part_floats ? a.get<float>(m->wg_part_floats) : nullptr;
   if (m->bf16 && He % 64 == 0 && He <= 512) {                    // exchange buffers of the cluster encoder kernels
     m->cl_xbytes = enc_cluster_xbuf_bytes((int)B, (int)He); m->cl_pbytes = enc_cluster_pbuf_bytes((int)B, (int)He);
     m->cl_xbuf = a.get<unsigned long long>(m->cl_xbytes / 8); m->cl_pbuf = a.get<unsigned long long>(m->cl_pbytes / 8);
@@ -367,27 +369,27 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   const char* dbg_stop = getenv("AOCR_DBG_STOP");          // debugging aid: leave the gradient map of a stage in place (tap "g0")
   const int stop = dbg_stop ? atoi(dbg_stop) : 0;
   if (stop == 1) { if (defer) colsum_flush(s, cj); return; }
-  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A6, G0, m->conv[7].dw, bf ? nullptr : m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0, m->A6b, G0b);
+  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A6, G0, m->conv[7].dw, bf ? nullptr : m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0, m->A6b, G0b, m->wg_part, m->wg_part_floats);
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0, G0b, m->wtb[7], m->wtf[7]);
   prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A6, m->idx6, bf ? nullptr : G0, B, d.H4, d.W2, 512, 2, G0b, bf ? m->conv[6].db : nullptr, bf ? slab(1) : nullptr, bf ? m->A6b : nullptr, defer);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
   if (stop == 2) { if (defer) colsum_flush(s, cj); return; }
-  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, bf ? nullptr : m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, G0b);
+  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, bf ? nullptr : m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, G0b, m->wg_part, m->wg_part_floats);
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, G0b, m->wtb[6], m->wtf[6]);
   prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, bf ? nullptr : G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
                    (int64_t)B * d.H4 * d.W2, 512, 0, G0b, bf ? m->A5b : nullptr, bf ? m->conv[5].db : nullptr, bf ? slab(2) : nullptr, bsync, defer);
-  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, bf ? nullptr : m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, G0b);
+  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, bf ? nullptr : m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, G0b, m->wg_part, m->wg_part_floats);
   if (defer) colsum_flush(s, cj);                               // conv7.b, conv6.b, conv5.b
   hipEventRecord(m->grad_ev[2], s);                             // every CNN gradient from conv5.w upwards is complete
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1, G0b, m->wtb[5], m->wtf[5]);
   prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A4, m->idx4, bf ? nullptr : G0, B, d.H2, d.W2, 256, 2, G0b, bf ? m->conv[4].db : nullptr, bf ? slab(3) : nullptr, bf ? m->A4b : nullptr, defer);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
-  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, bf ? nullptr : m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, G0b);
+  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, bf ? nullptr : m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, G0b, m->wg_part, m->wg_part_floats);
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, G0b, m->wtb[4], m->wtf[4]);
   prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y3, m->A3, G1, m->bn[3].w, m->bn[3].save, bf ? nullptr : G0, m->bn[3].dw, m->bn[3].db, m->bn_scratch,
                    (int64_t)B * d.H2 * d.W2, 256, 0, G0b, bf ? m->A3b : nullptr, bf ? m->conv[3].db : nullptr, bf ? slab(4) : nullptr, bsync, defer);
-  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A2, G0, m->conv[3].dw, bf ? nullptr : m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, G0b);
+  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A2, G0, m->conv[3].dw, bf ? nullptr : m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, G0b, m->wg_part, m->wg_part_floats);
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1, G0b, m->wtb[3], m->wtf[3]);
   prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A2, m->idx2, bf ? nullptr : G0, B, d.H1, d.W1, 128, 1, G0b, bf ? m->conv[2].db : nullptr, bf ? slab(5) : nullptr, bf ? m->A2b : nullptr, defer);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
-  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A1, G0, m->conv[2].dw, bf ? nullptr : m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1, m->A1b, G0b);
+  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A1, G0, m->conv[2].dw, bf ? nullptr : m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1, m->A1b, G0b, m->wg_part, m->wg_part_floats);
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1, G0b, m->wtb[2], m->wtf[2]);
   prof_mark(m, AOCR_PROF_POOL_CONV1); conv1_backward(s, images, m->conv[1].w, m->conv[1].b, G1, m->conv[1].dw, m->conv[1].db, B, d.H, d.W,
                  (size_t)B * d.H1 * d.W1 * 128 >= (size_t)4096 * 640 ? slab(6) : nullptr, defer);      // G0 is free here: use it as the partial slab

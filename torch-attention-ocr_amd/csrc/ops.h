@@ -106,7 +106,9 @@ void bn_eval_prepare(hipStream_t s, const float* rm, const float* rv, float* sav
 void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* w, float* dx, int B, int H, int W, int Cin,
                         int Cout, int ks, int pad, const bf16_t* dyb = nullptr, const bf16_t* wtb = nullptr, const float* wtf = nullptr);
 void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float* dy, float* dw, float* dbias, int B, int H,
-                          int W, int Cin, int Cout, int ks, int pad, const bf16_t* xb = nullptr, const bf16_t* dyb = nullptr);
+                          int W, int Cin, int Cout, int ks, int pad, const bf16_t* xb = nullptr, const bf16_t* dyb = nullptr,
+                          float* part = nullptr, size_t part_floats = 0, int profile_tag = 0);   // part: scratch for the split-K slabs (else fp32 atomics)
+void splitk_reduce(hipStream_t s, const float* part, int ks, size_t n, float* out);   // out[i] += sum_z part[z * n + i]  (n % 4 == 0)
 
 // ---- everything that is not a contraction (ops_misc.hip)
 void conv1_forward(hipStream_t s, const float* x, const float* w, const float* bias, float* y, int B, int H, int W,

@@ -368,7 +368,7 @@ void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* 
 }
 
 void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float* dy, float* dw, float* dbias, int B, int H,
-                          int W, int Cin, int Cout, int ks, int pad, const bf16_t* xb, const bf16_t* dyb) {
+                          int W, int Cin, int Cout, int ks, int pad, const bf16_t* xb, const bf16_t* dyb, float* part, size_t part_floats, int profile_tag) {
   const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
   const int P = B * Ho * Wo, N = ks * ks * Cin;
   LoadConvXcol b; b.x = x; b.H = H; b.W = W; b.Cin = Cin; b.KW = ks; b.pad = pad; b.Ho = Ho; b.Wo = Wo; b.N = N; b.K = P;
@@ -382,13 +382,22 @@ void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float*
     const int tiles = cdiv(N, 256) * (Cout / 256);
     if (Cout % 256 == 0 && Cin % 8 == 0 && !dma_disabled() && (dma_forced() || (P >= 8192 && tiles <= 256 && N % 256 == 0 && N >= 2304))) {
       int ks2 = tiles >= 128 ? (tiles >= 200 ? 1 : 2) : 256 / tiles, kper2; split_k(P, 32, ks2, kper2);      // one round of the 256 CUs
-      hipLaunchKernelGGL((conv_wgrad_dma_kernel<EpStore>), dim3(tiles * ks2), dim3(512), 0, s, ah, bh, ep, P, kper2, cdiv(N, 256), Cout / 256, zero_page(), ks2);
+      const size_t mn = (size_t)Cout * N;
+      float* const slab = (part && ks2 > 1 && mn * ks2 <= part_floats && !getenv("AOCR_WGRAD_ATOMIC")) ? part : nullptr;
+      if (profile_tag)        // the same kernel under its own symbol (ABL bit 256 selects nothing): aocr_profile_kernel, per-kernel rocprofv3 / PMC rows
+        hipLaunchKernelGGL((conv_wgrad_dma_kernel<EpStore, 256>), dim3(tiles * ks2), dim3(512), 0, s, ah, bh, ep, P, kper2, cdiv(N, 256), Cout / 256, zero_page(), ks2, slab, (long long)mn);
+      else
+        hipLaunchKernelGGL((conv_wgrad_dma_kernel<EpStore>), dim3(tiles * ks2), dim3(512), 0, s, ah, bh, ep, P, kper2, cdiv(N, 256), Cout / 256, zero_page(), ks2, slab, (long long)mn);
+      if (slab) splitk_reduce(s, slab, ks2, mn, dw);
       if (dbias) colsum_accum(s, dy, Cout, P, Cout, dbias);
       return;
     }
     int ks = ksplit, kper; split_k(P, 32, ks, kper);
     const int gx = cdiv(N, 128), gy = cdiv(Cout, 128);
-    hipLaunchKernelGGL((conv_wgrad_tr_kernel<EpStore>), dim3(gx * gy * ks), dim3(256), 0, s, ah, bh, ep, P, kper, gx, gy, ks);
+    const size_t mn = (size_t)Cout * N;
+    float* const slab = (part && ks > 1 && mn * ks <= part_floats && !getenv("AOCR_WGRAD_ATOMIC")) ? part : nullptr;
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<EpStore>), dim3(gx * gy * ks), dim3(256), 0, s, ah, bh, ep, P, kper, gx, gy, ks, slab, (long long)mn);
+    if (slab) splitk_reduce(s, slab, ks, mn, dw);
   } else {
     launch_conv_wgrad(s, bf16, make_loadmn(dy, Cout, Cout, P), b, ep, Cout, N, P, ksplit);
   }

@@ -1179,6 +1179,29 @@ __global__ __launch_bounds__(256) void sum_scalar_kernel(const float* __restrict
   __syncthreads();
   if (threadIdx.x == 0) out[0] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
 }
+// Sum of the split-K slabs of a filter gradient (conv_wgrad_*_kernel with `part`): out[i] += sum_z part[z][i].  HBM-bound: every
+// thread owns 4 consecutive floats, all `ks` 16-byte loads of a group of 8 slabs in flight before the first add.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ks, size_t n4, float* __restrict__ out) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f4* p = reinterpret_cast<const f4*>(part) + i;
+  f4 acc = reinterpret_cast<const f4*>(out)[i];
+  int z = 0;
+  for (; z + 8 <= ks; z += 8) {
+    f4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(p + (size_t)(z + j) * n4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += v[j];
+  }
+  for (; z < ks; ++z) acc += __builtin_nontemporal_load(p + (size_t)z * n4);
+  reinterpret_cast<f4*>(out)[i] = acc;
+}
+void splitk_reduce(hipStream_t s, const float* part, int ks, size_t n, float* out) {
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, ks, n4, out);
+}
 void sum_to_scalar(hipStream_t s, const float* x, int64_t n, float* out) {
   hipLaunchKernelGGL(sum_scalar_kernel, dim3(1), dim3(256), 0, s, x, n, out);
 }
