@@ -76,20 +76,33 @@ def _cpu_baseline_worker(wl, budget_s):
     Bd = min(B, 64)
     img, tgt, tge, _ = O.synth_batch(Bd, wl["W"], max_len=wl["L"] - 1)
     t0 = time.time(); R.decode(rc, flat, bn, img, tgt, tge, 1, 50); td = time.time() - t0
+    # the same port on BASELINE.json configs[1] (C2: 32x100, batch 64, fp32 and fp64) -- SURVEY.md 8(d) asks for the small shapes beside C3
+    c2 = None
+    if wl["W"] != 100:
+        w2 = dict(wl, W=100)
+        def run2(dtype):
+            img2, tgt2, tge2, _ = O.synth_batch(64, 100, max_len=wl["L"] - 1)
+            t0 = time.time()
+            r = R.train_step(rc, flat, bn, img2, tgt2, tge2, dtype=dtype)
+            R.sgd(rc, flat, r["grads"], 0.1, 5.0, dtype=dtype)
+            return time.time() - t0
+        a32, a64 = run2(np.float32), run2(np.float64)
+        c2 = {"workload": "c2: 32x100 crops, batch 64", "value_f32": 64 / a32, "value_f64": 64 / a64, "unit": "image-lines/s", "seconds": [a32, a64]}
     print(json.dumps({"value": B / t64, "unit": "image-lines/s", "cores": cores, "kind": "port",
                       "impl": "cpp-restatement: oracle/cpu_ref (im2col+GEMM conv, per-timestep LSTM, unfused attention, OpenMP), checked "
                               "against tests/golden in the CPU suite",
                       "dtype": "f64", "batch": B, "value_f32": B / t32, "decode_chars_per_s_f64": Bd * 50 / td,
                       "sample": f"1 train step (forward + BPTT + clip + SGD) of batch {B} at 32x{wl['W']} in fp64 ({t64:.1f} s) and one in fp32 "
                                 f"({t32:.1f} s), after a warm-up step of batch {Bc}; greedy decode of {Bd} lines ({td:.1f} s); "
-                                f"{cores} OpenMP threads = all {os.cpu_count()} host cores"}))
+                                f"{cores} OpenMP threads on the {len(os.sched_getaffinity(0))} cores this process may run on (os.cpu_count() = {os.cpu_count()})",
+                      "c2_shape": c2}))
 
 
 def cpu_baseline(wl, budget_s=40.0):
     code = ("import json,sys; sys.argv=['bench.py']; import importlib.util as u; s=u.spec_from_file_location('bench', %r); "
             "b=u.module_from_spec(s); s.loader.exec_module(b); b._cpu_baseline_worker(json.loads(%r), %f)"
             % (os.path.join(ROOT, "bench.py"), json.dumps(wl), budget_s))
-    n = os.cpu_count() or 1
+    n = len(os.sched_getaffinity(0)) or 1                   # the cores this process may actually run on, not the host's total
     env = dict(os.environ, OMP_NUM_THREADS=str(n), OMP_PROC_BIND="false", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
@@ -111,7 +124,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-steps", type=int, default=3)
     ap.add_argument("--no-secondary", action="store_true", help="skip the C2 fp32 and data-path secondary measurements")
-    ap.add_argument("--sustain-seconds", type=float, default=1.5, help="keep stepping after the timed steps until this much GPU time has passed")
+    ap.add_argument("--sustain-seconds", type=float, default=8.0, help="keep stepping after the timed steps until this much GPU time has passed")
     return ap.parse_args()
 
 
@@ -300,7 +313,19 @@ def main():
             for _ in range(args.decode_steps):
                 m.decode_device(images, targets, targets_eval, 1, trie)
             sync()
-            dec_dict = {"chars_per_s": world * B * 50 * args.decode_steps / (time.perf_counter() - t0), "words": len(words),
+            eldd = (time.perf_counter() - t0) / args.decode_steps
+            lab = m.decode_device(images, targets, targets_eval, 1, trie)[0]
+            # the greedy kernel leaves its loop once every row of a 32-row group has emitted EOS / PAD: steps a group actually ran =
+            # 1 + the last position at which any of its rows still emitted a token other than PAD / EOS (an upper bound: + the EOS step)
+            live = ((lab != 1) & (lab != 3)).cpu().numpy()
+            last = np.where(live.any(axis=1), live.shape[1] - np.argmax(live[:, ::-1], axis=1), 0)
+            grp = [int(min(50, last[g:g + 32].max() + 2)) for g in range(0, B, 32)]
+            executed = int(sum(min(32, B - g) * grp[g // 32] for g in range(0, B, 32)))
+            dec_dict = {"chars_per_s": world * B * 50 / eldd, "executed_steps_per_s": world * executed / eldd, "executed_steps_per_call": executed,
+                        "nominal_steps_per_call": B * 50, "ms_per_call": 1e3 * eldd,
+                        "what": "chars_per_s divides the nominal B*50 decoder steps of a -phase test call by the time; the greedy kernel's early exit "
+                                "(every row of a 32-row group at EOS / PAD) skips most of them under a dictionary: executed_steps_per_s is the "
+                                "comparable rate", "words": len(words),
                         "trie_nodes": trie.n_nodes, "trie_bytes": int(trie.mask.nbytes + trie.base.nbytes + trie.child.nbytes)}
 
     # ---- secondary line (N = 1 only): BASELINE.json configs[1] = C2 in exact-fp32 MFMA mode (the 1e-4 logit-parity configuration)
@@ -352,12 +377,25 @@ def main():
         bf16 = wl["compute"] == "bf16"
         ms, kfl = m.profile_kernel(0, 20)                # conv6 forward, HIP events on the model's stream
         ach = kfl / (ms * 1e-3) / 1e12
+        best = {"bound": "mfma", "kernel": "conv6 forward implicit GEMM (512->512 3x3 + ReLU + pool), gemm_halo_bf16_kernel", "achieved": ach,
+                "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "ms_per_launch": ms}
+        # the DOMINANT kernel of the step by time share: the split-K filter gradient (conv_wgrad_dma_kernel: conv4 + conv5 + conv6, 12-13 % of
+        # the kernel time, profiles/*_kernel_stats.csv); timed on the conv6 launch exactly as backward_all makes it (kernel + the sum of its slabs)
+        msw, kflw = m.profile_kernel(1, 20)
+        achw = kflw / (msw * 1e-3) / 1e12
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_conv6_fwd_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r03_wgrad_pmc.json")
         if bf16 and args.workload == "c3" and world == 1 and args.scaling == "weak" and os.path.exists(pmc):
             traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
-            traffic_source = ("profiles/r02_conv6_fwd_pmc.json: rocprofv3 --pmc passes of this command (tools/pmc_traffic.py); PMC counters cannot "
-                              "be read from inside the timed process, so this field is NOT measured in this run")
+            traffic_source = ("profiles/r03_wgrad_pmc.json: rocprofv3 --pmc passes of this command on the tagged conv6 filter-gradient launch "
+                              "(tools/pmc_traffic.py); PMC counters cannot be read from inside the timed process, so this field is NOT measured in this run")
+        step_frac = 3 * fl["total"] * lines_per_s / 1e12 / (peak * world)
+        wg_share = (families or {}).get("conv_wgrad", {}).get("ms_per_step", 0.0) / max(1e-9, (families or {}).get("_sum_ms", 1.0))
+        roof = {"bound": "mfma", "kernel": "conv6 filter gradient (512x4608 over 65536 pixels): conv_wgrad_dma_kernel + splitk_reduce -- the dominant "
+                                           "kernel family of the step by time",
+                "achieved": achw, "peak": peak, "unit": "TFLOP/s", "frac": achw / peak, "traffic": traffic, "traffic_source": traffic_source,
+                "ms_per_launch": msw, "algorithmic_gflop_per_launch": kflw / 1e9, "family_share_of_step": wg_share,
+                "step_frac": step_frac, "step_frac_what": "SURVEY.md 8(d): train GFLOP per image x image-lines/s / bf16 MFMA peak over the WHOLE step (north-star target 0.40)"}
         out = {
             "metric": "image-lines/sec (train step)", "value": lines_per_s, "unit": "image-lines/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
@@ -373,9 +411,7 @@ def main():
             "families": families,
             "decode_chars_per_s": dec["chars_per_s"] if dec else None, "decode": dec, "decode_dict": dec_dict,
             "replica_drift": replica_drift, "loss": loss_val, "secondary": c2, "data_path": dp,
-            "roofline": {"bound": "mfma", "kernel": "conv6 forward implicit GEMM (512->512 3x3 + ReLU + pool)",
-                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                         "traffic_source": traffic_source, "ms_per_launch": ms},
+            "roofline": roof, "roofline_best": best,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl)

@@ -81,7 +81,9 @@ int aocr_model_set_stream(aocr_model* m, void* stream);
 
 /* Health of the whole-sequence ("cluster") kernels: the compute units that share a block of batch rows wait for each other with BOUNDED
  * spins; if a wait ever times out (it cannot unless another kernel keeps part of the chip busy for ~0.3 s) the kernel records a code,
- * finishes, and the step's results are invalid.  *code = 0: healthy; a non-zero code is cleared by the call (read and clear).
+ * finishes, and the step's results are invalid: aocr_sgd_step / aocr_adadelta_step then leave the parameters untouched (device-side
+ * predicate on the same flag, no host sync), so a host that polls this call only every N steps loses steps, never its weights.
+ * *code = 0: healthy; a non-zero code is cleared by the call (read and clear).
  * Synchronises the model's stream.  No reference counterpart.
  * These kernels need the device to themselves: a launch occupies every compute unit, so the steps of two models (or two processes)
  * must not run concurrently on ONE device -- AOCR_NO_CLUSTER=1 AOCR_NO_DEC_CLUSTER=1 selects the per-step launch chains for that case. */
@@ -124,11 +126,15 @@ int aocr_stream_wait_grads(aocr_model* m, int32_t bucket, void* stream);
  * compute what one GPU computes on the whole batch (training-mode statistics included; running statistics stay identical on all ranks).
  * Provider 1: RCCL over xGMI.  rank 0 calls aocr_comm_unique_id, the host hands the 128 bytes to the other ranks (file, socket, MPI:
  * its choice), every rank calls aocr_comm_init_rank (collective, like ncclCommInitRank).  librccl.so is bound at run time.
- * Provider 2: a host callback that sums `count` elements (dtype 0 = fp32, 1 = fp64) of a device buffer over the ranks in place,
- * enqueued on `stream` (the Python mirror routes torch.distributed through it; the tests use gloo).
+ * Provider 2: a host callback that sums `count` elements (dtype & 0xff: 0 = fp32, 1 = fp64) of a device buffer over the ranks in place,
+ * enqueued on `stream` (the Python mirror routes torch.distributed through it; the tests use gloo).  dtype & AOCR_COMM_CHANNEL_BN
+ * marks the BatchNorm sums: they are issued from inside the forward / backward pass while the gradient buckets are issued after it,
+ * and a communicator runs its operations in issue order -- give that channel a communicator (process group) of its own, as provider 1
+ * does (ncclCommSplit), or bucket 0 queues behind the last BatchNorm-backward sum and the overlap with the backward pass is lost.
  * aocr_allreduce_grads: after aocr_train_forward_backward and before aocr_sgd_step; the buckets of aocr_grad_buckets are summed on a
  * second stream as the backward pass completes them (overlap), loss_dev (optional, 1 float) is summed too, and the model's stream
  * waits for the last bucket.  Pass grad_scale = 1 / GLOBAL batch to aocr_train_forward_backward. */
+#define AOCR_COMM_CHANNEL_BN 0x100
 typedef int (*aocr_allreduce_fn)(void* user, void* buf_dev, int64_t count, int32_t dtype, void* stream);
 int aocr_comm_unique_id(char id[128]);
 int aocr_comm_init_rank(aocr_model* m, const char id[128], int32_t nranks, int32_t rank, int32_t sync_bn);

@@ -294,6 +294,7 @@ function model:_build()
     self.world = tonumber(os.getenv('AOCR_WORLD_SIZE') or '1')
     if self.world > 1 then
         local rank = tonumber(os.getenv('AOCR_RANK'))
+        self.rank = rank
         local path = assert(os.getenv('AOCR_COMM_ID_FILE'), 'AOCR_COMM_ID_FILE not set')
         local id = ffi.new('char[128]')
         if rank == 0 then
@@ -330,7 +331,8 @@ function model:step(batch, forward_only, beam_size, trie)
     if not forward_only then
         -- feval with training-mode BatchNorm (model.lua:276-278), then optim.sgd_list: clip each of the 5 groups to 5, x -= lr * g
         if self.dropout and self.dropout > 0 then      -- LSTM.lua:68-69,116-118: masks = f(seed, global_step, site, element), include/aocr.h
-            A.check(L.aocr_set_dropout(self.handle, self.dropout, (cutorch._seed or 910820), self.global_step), 'aocr_set_dropout')
+            -- (rank-dependent seed under data parallelism: every rank drops different units of its slice, as aocr/model.py does)
+            A.check(L.aocr_set_dropout(self.handle, self.dropout, (cutorch._seed or 910820) + 7919 * (self.rank or 0), self.global_step), 'aocr_set_dropout')
         end
         A.check(L.aocr_train_forward_backward(self.handle, self.images_dev:as('float*'), self.targets_dev:as('int32_t*'),
                                               self.targets_eval_dev:as('int32_t*'), batch_size, W, target_l,
@@ -338,6 +340,17 @@ function model:step(batch, forward_only, beam_size, trie)
         if self.world > 1 then A.check(L.aocr_allreduce_grads(self.handle, self.scal_dev:as('float*')), 'aocr_allreduce_grads') end
         A.check(L.aocr_sgd_step(self.handle, self.optim_state.learningRate, 5.0, self.scal_dev:as('float*') + 2), 'aocr_sgd_step')
         local loss = A.read_scalar(self.scal_dev, 0)                          -- = loss * batch_size of model.lua:701
+        -- health of the whole-sequence kernels (include/aocr.h: aocr_cluster_status).  A timed-out wait invalidates the step; the
+        -- library then skips the update itself (aocr_sgd_step's device-side predicate), so the weights are intact: report and redo.
+        local code = ffi.new('int32_t[1]')
+        A.check(L.aocr_cluster_status(self.handle, code), 'aocr_cluster_status')
+        if code[0] ~= 0 then
+            self.redo = (self.redo or 0) + 1
+            assert(self.redo <= 3, string.format('cluster kernel timed out (code %d) three times in a row: is another process using this GPU?', code[0]))
+            log(string.format('Warning: a cluster kernel timed out waiting for its group (code %d); the step is repeated', code[0]))
+            return self:step(batch, forward_only, beam_size, trie)
+        end
+        self.redo = 0
         return loss, {num_nonzeros, 0.0}
     end
     -- forward only: beam search over max_decoder_l steps + gold pass (model.lua:321-627)

@@ -33,6 +33,7 @@ def _worker(rank, world, port, q, sync_bn):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if not sync_bn:
         os.environ["AOCR_NO_SYNC_BN"] = "1"
+    os.environ["AOCR_COMM_LOG"] = "1"
     m, O, ocfg, P, st, batch = _build(8, 40)                      # the GLOBAL batch: every rank generates it, then keeps its slice
     half = 8 // world
     sl = slice(rank * half, (rank + 1) * half)
@@ -41,7 +42,7 @@ def _worker(rank, world, port, q, sync_bn):
     grads = {k: v.numpy() for k, v in m.get_gradients().items()}
     params = {k: v.numpy() for k, v in m.get_parameters().items()}
     bn = {k: v.numpy() for k, v in m.get_bn_state().items()}
-    q.put((rank, loss, grads, params, bn))
+    q.put((rank, loss, grads, params, bn, list(m._comm_log or [])))
     dist.barrier()
     m.shutdown()
     dist.destroy_process_group()
@@ -65,7 +66,13 @@ def test_dp2_equals_single_gpu_in_training_mode(cuda, sync_bn):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, l0, g0, p0, bn0), (_, l1, gr1, pr1, bnr1) = res
+    (_, l0, g0, p0, bn0, log0), (_, l1, gr1, pr1, bnr1, log1) = res
+    # the exchange as the library issued it: identical on both ranks (a mismatch would deadlock RCCL), the BatchNorm sums on their own
+    # channel (fp64, AOCR_COMM_CHANNEL_BN) -- 3 layers x (forward + backward) -- the four gradient buckets + the loss on channel 0 (fp32)
+    assert log0 == log1 and len(log0) > 0
+    grads_ch = [e for e in log0 if e[0] == 0]; bn_ch = [e for e in log0 if e[0] == 1]
+    assert len(grads_ch) == 5 and all(e[1] == 0 for e in grads_ch) and sorted(e[2] for e in grads_ch)[0] == 1
+    assert (len(bn_ch) == 6 and all(e[1] == 1 for e in bn_ch)) if sync_bn else not bn_ch
     for k in g0:                                   # both ranks hold the same summed gradients and the same updated parameters
         assert np.array_equal(g0[k], gr1[k]) and np.array_equal(p0[k], pr1[k]), k
     assert l0 == pytest.approx(l1)
@@ -105,4 +112,20 @@ def test_rccl_provider_single_rank(cuda):
         assert (g - g0).abs().max().item() <= 1e-4 * g0.abs().max().item()
         assert loss.item() == pytest.approx(loss0, rel=1e-5)
     check(lib.aocr_comm_destroy(m._h))
+    m.shutdown()
+
+
+def test_attach_is_a_no_op_after_attach_rccl(cuda, monkeypatch):
+    """Model.train_step_device calls dist.attach() on every step of a multi-rank run; on a model that already carries
+    the library's own RCCL provider (attach_rccl) that must return early instead of tripping aocr_comm_set_callback's
+    'already attached' error, and a failed attach must not leave `_comm_cb` set."""
+    from aocr import dist as adist
+    m, O, ocfg, P, st, batch = _build(4, 40, compute="f32")
+    adist.attach_rccl(m, sync_bn=True)                                    # 1-rank communicator
+    monkeypatch.setattr(adist, "world_size", lambda: 2)                   # as seen from inside a 2-rank job
+    adist.attach(m)                                                       # no error, nothing attached on top
+    assert getattr(m, "_comm_cb", None) is None and m._comm_rccl
+    assert m.sync_bn_active()
+    loss = m.train_forward_backward(batch)                                # the 1-rank communicator still works (sums are identities)
+    assert np.isfinite(loss)
     m.shutdown()

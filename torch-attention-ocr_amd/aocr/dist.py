@@ -15,6 +15,7 @@ about a millisecond at 8 GPUs -- only the last 3.8 MB bucket (conv1..conv4) is e
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -83,6 +84,11 @@ def attach(model, sync_bn: bool = True) -> None:
     if world_size() <= 1 or getattr(model, "_comm_cb", None) is not None or getattr(model, "_comm_rccl", False):
         return                                       # already attached (callback or the library's own RCCL provider)
     d = torch.distributed
+    # the BatchNorm sums travel on a process group of their own (include/aocr.h, AOCR_COMM_CHANNEL_BN): a group runs its collectives in
+    # issue order, and the gradient buckets -- issued after the whole backward pass has been enqueued -- must not queue behind the last
+    # BatchNorm-backward sum.  new_group is collective: every rank attaches at the same point (the first training step).
+    model._bn_group = d.new_group() if (sync_bn and not os.environ.get("AOCR_ONE_COMM")) else None
+    model._comm_log = [] if os.environ.get("AOCR_COMM_LOG") else None
 
     def view(ptr, count, dtype):
         nbytes = count * (8 if dtype else 4)
@@ -96,10 +102,13 @@ def attach(model, sync_bn: bool = True) -> None:
 
     def cb(user, buf, count, dtype, stream):
         try:
+            chan, dtype = dtype >> 8, dtype & 0xFF
             v = view(buf, count, dtype)
+            if model._comm_log is not None:
+                model._comm_log.append((chan, dtype, int(count)))
             ext = torch.cuda.ExternalStream(stream, device=model.device) if stream else torch.cuda.default_stream(model.device)
             with torch.cuda.stream(ext):
-                d.all_reduce(v)
+                d.all_reduce(v, group=model._bn_group if chan else None)
             return 0
         except Exception as e:                       # never let an exception cross the C boundary
             print(f"[aocr.dist] all-reduce callback failed: {e!r}", flush=True)

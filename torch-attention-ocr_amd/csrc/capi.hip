@@ -153,6 +153,9 @@ int aocr_model_create(const aocr_config* cfg, float* params_dev, float* grads_de
 }
 int aocr_model_destroy(aocr_model* m) {
   if (m) for (int i = 0; i < 4; ++i) if (m->grad_ev[i]) hipEventDestroy(m->grad_ev[i]);
+  if (m && m->side) { hipStreamSynchronize(m->side); hipStreamDestroy(m->side); }
+  if (m && m->side_go) hipEventDestroy(m->side_go);
+  if (m && m->side_done) hipEventDestroy(m->side_done);
   if (m) for (hipEvent_t e : m->prof_ev) hipEventDestroy(e);
   if (m) comm_destroy(m);
   delete m; return 0;
@@ -278,7 +281,7 @@ int aocr_stream_wait_grads(aocr_model* m, int32_t bucket, void* stream) {
 int aocr_sgd_step(aocr_model* m, float lr, float clip, float* norms_dev) {
   REQUIRE(m, "NULL model");
   prof_mark(m, AOCR_PROF_SGD);
-  sgd_clip_update(m->s, m->params, m->grads, m->layout.group_off, lr, clip, norms_dev, m->sgd_scratch);
+  sgd_clip_update(m->s, m->params, m->grads, m->layout.group_off, lr, clip, norms_dev, m->sgd_scratch, m->cl_err);
   prof_mark(m, -1);
   return check_launch("aocr_sgd_step");
 }
@@ -287,7 +290,7 @@ int aocr_adadelta_step(aocr_model* m, float rho, float eps, float weight_decay, 
   REQUIRE(m && state_dev, "NULL argument");
   REQUIRE(rho >= 0.f && rho < 1.f && eps > 0.f, "rho=%g eps=%g out of range", rho, eps);
   const int64_t n = m->layout.group_off[AOCR_NUM_GROUPS];
-  adadelta_update(m->s, m->params, m->grads, state_dev, state_dev + n, n, rho, eps, weight_decay);
+  adadelta_update(m->s, m->params, m->grads, state_dev, state_dev + n, n, rho, eps, weight_decay, m->cl_err);
   return check_launch("aocr_adadelta_step");
 }
 

@@ -17,8 +17,9 @@ typedef int (*GetUniqueIdFn)(NcclId*);
 typedef int (*CommInitRankFn)(void**, int, NcclId, int);
 typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*CommDestroyFn)(void*);
+typedef int (*CommSplitFn)(void*, int, int, void**, void*);
 typedef const char* (*GetErrorStringFn)(int);
-struct Rccl { void* h = nullptr; GetUniqueIdFn uid; CommInitRankFn init; AllReduceFn allreduce; CommDestroyFn destroy; GetErrorStringFn errstr; };
+struct Rccl { void* h = nullptr; GetUniqueIdFn uid; CommInitRankFn init; AllReduceFn allreduce; CommDestroyFn destroy; GetErrorStringFn errstr; CommSplitFn split; };
 Rccl g_rccl;
 const char* load_rccl() {
   if (g_rccl.h) return nullptr;
@@ -30,6 +31,7 @@ const char* load_rccl() {
   g_rccl.uid = (GetUniqueIdFn)dlsym(h, "ncclGetUniqueId"); g_rccl.init = (CommInitRankFn)dlsym(h, "ncclCommInitRank");
   g_rccl.allreduce = (AllReduceFn)dlsym(h, "ncclAllReduce"); g_rccl.destroy = (CommDestroyFn)dlsym(h, "ncclCommDestroy");
   g_rccl.errstr = (GetErrorStringFn)dlsym(h, "ncclGetErrorString");
+  g_rccl.split = (CommSplitFn)dlsym(h, "ncclCommSplit");                       // optional (NCCL >= 2.18 API): second communicator for the BatchNorm sums
   if (!g_rccl.uid || !g_rccl.init || !g_rccl.allreduce || !g_rccl.destroy) return "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
   g_rccl.h = h;
   return nullptr;
@@ -57,6 +59,15 @@ const char* comm_init_rccl(aocr_model* m, const char id[128], int nranks, int ra
   const int rc = g_rccl.init(&c, nranks, u, rank);
   if (rc != 0) { static thread_local char buf[160]; snprintf(buf, sizeof buf, "ncclCommInitRank: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "error"); return buf; }
   m->comm.rccl = c; m->comm.provider = 1;
+  // A communicator executes its operations in the order the host issued them.  The BatchNorm sums are issued from inside the forward /
+  // backward pass, the gradient buckets after the whole backward pass has been enqueued: on ONE communicator bucket 0 (ready 45 % into
+  // the backward pass) would queue behind the last BatchNorm-backward sum (near its end) and the overlap would be lost.  So the
+  // BatchNorm sums get a communicator of their own (same ranks, ncclCommSplit); without that entry point they share the first one.
+  m->comm.rccl_bn = nullptr;
+  if (sync_bn && g_rccl.split && !getenv("AOCR_ONE_COMM")) {
+    void* c2 = nullptr;
+    if (g_rccl.split(c, 0, rank, &c2, nullptr) == 0 && c2) m->comm.rccl_bn = c2;
+  }
   return comm_common_init(m, nranks, sync_bn);
 }
 const char* comm_init_callback(aocr_model* m, aocr_allreduce_fn fn, void* user, int nranks, int sync_bn) {
@@ -64,17 +75,20 @@ const char* comm_init_callback(aocr_model* m, aocr_allreduce_fn fn, void* user, 
   return comm_common_init(m, nranks, sync_bn);
 }
 void comm_destroy(aocr_model* m) {
+  if (m->comm.provider == 1 && m->comm.rccl_bn && g_rccl.h) g_rccl.destroy(m->comm.rccl_bn);
   if (m->comm.provider == 1 && m->comm.rccl && g_rccl.h) g_rccl.destroy(m->comm.rccl);
   if (m->comm.stream) hipStreamDestroy(m->comm.stream);
   if (m->comm.done) hipEventDestroy(m->comm.done);
   m->comm = CommState{};
 }
 
-// in-place sum over ranks of `count` elements (dtype 0 = fp32, 1 = fp64) enqueued on `stream`
-int comm_allreduce(aocr_model* m, void* buf, int64_t count, int dtype, hipStream_t stream) {
+// in-place sum over ranks of `count` elements (dtype 0 = fp32, 1 = fp64) enqueued on `stream`; channel 0 = gradient exchange,
+// 1 = BatchNorm sums (a communicator / process group of its own: see comm_init_rccl)
+int comm_allreduce(aocr_model* m, void* buf, int64_t count, int dtype, hipStream_t stream, int channel) {
   if (m->comm.nranks <= 1 && m->comm.provider != 1) return 0;
-  if (m->comm.provider == 1) return g_rccl.allreduce(buf, buf, (size_t)count, dtype ? NCCL_F64 : NCCL_F32, NCCL_SUM, m->comm.rccl, stream);
-  if (m->comm.provider == 2) return m->comm.fn(m->comm.user, buf, count, dtype, (void*)stream);
+  if (m->comm.provider == 1)
+    return g_rccl.allreduce(buf, buf, (size_t)count, dtype ? NCCL_F64 : NCCL_F32, NCCL_SUM, (channel && m->comm.rccl_bn) ? m->comm.rccl_bn : m->comm.rccl, stream);
+  if (m->comm.provider == 2) return m->comm.fn(m->comm.user, buf, count, dtype | (channel ? AOCR_COMM_CHANNEL_BN : 0), (void*)stream);
   return 0;
 }
 
@@ -88,8 +102,8 @@ int comm_allreduce_grads(aocr_model* m, float* loss_dev) {
   aocr_grad_buckets(&m->cfg, b, e);
   for (int k = 0; k < AOCR_GRAD_BUCKETS; ++k) {
     if (hipStreamWaitEvent(cs, m->grad_ev[k], 0) != hipSuccess) return 1;
-    if (comm_allreduce(m, m->grads + b[k], e[k] - b[k], 0, cs) != 0) return 2;
-    if (k == 0 && loss_dev && comm_allreduce(m, loss_dev, 1, 0, cs) != 0) return 2;      // the loss is final before the backward pass starts
+    if (comm_allreduce(m, m->grads + b[k], e[k] - b[k], 0, cs, 0) != 0) return 2;
+    if (k == 0 && loss_dev && comm_allreduce(m, loss_dev, 1, 0, cs, 0) != 0) return 2;      // the loss is final before the backward pass starts
   }
   if (hipEventRecord(m->comm.done, cs) != hipSuccess || hipStreamWaitEvent(m->s, m->comm.done, 0) != hipSuccess) return 1;
   return 0;

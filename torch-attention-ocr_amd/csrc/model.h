@@ -33,7 +33,7 @@ struct Arena {
 // data-parallel exchange state (comm.hip): provider 0 = none, 1 = RCCL, 2 = host callback
 struct CommState {
   int nranks = 1; bool sync_bn = false; int provider = 0;
-  void* rccl = nullptr; aocr_allreduce_fn fn = nullptr; void* user = nullptr;
+  void* rccl = nullptr; void* rccl_bn = nullptr; aocr_allreduce_fn fn = nullptr; void* user = nullptr;
   hipStream_t stream = nullptr; hipEvent_t done = nullptr;
 };
 
@@ -91,6 +91,7 @@ struct aocr_model {
   std::vector<aocr::ShadowJob> shadow_host;   // bf16 mode: job table of the one-launch weight shadow refresh
   aocr::ShadowJob* shadow_dev; int shadow_tiles;
   hipEvent_t grad_ev[4];          // gradient-ready points of the backward pass (aocr_grad_buckets)
+  hipStream_t side = nullptr; hipEvent_t side_go = nullptr, side_done = nullptr; bool side_busy = false;   // side stream of the backward pass (model.hip: decoder_backward)
   int64_t conv5_off;              // offset of cnn.conv5.w in the flat vectors: the CNN group is split there
   aocr::Dims last;                // dims of the last step (for the parity taps)
   int last_valid;
@@ -112,7 +113,7 @@ const char* comm_unique_id(char id[128]);
 const char* comm_init_rccl(aocr_model* m, const char id[128], int nranks, int rank, int sync_bn);
 const char* comm_init_callback(aocr_model* m, aocr_allreduce_fn fn, void* user, int nranks, int sync_bn);
 void comm_destroy(aocr_model* m);
-int comm_allreduce(aocr_model* m, void* buf, int64_t count, int dtype, hipStream_t stream);
+int comm_allreduce(aocr_model* m, void* buf, int64_t count, int dtype, hipStream_t stream, int channel);
 int comm_allreduce_grads(aocr_model* m, float* loss_dev);
 inline bool sync_bn_on(const aocr_model* m) { return m->comm.provider != 0 && m->comm.sync_bn; }
 void prof_mark_slow(aocr_model* m, int tag);

@@ -304,7 +304,7 @@ static void run_gates_bwd(aocr_model* m, int nz, const LoadK* a, const ShW* cons
 // ------------------------------------------------------------------------------------------------
 // CNN forward, cnn.lua:9-45.  Output X is time-major (T,B,512) (= cnn_output:transpose(1,2), model.lua:288).
 // ------------------------------------------------------------------------------------------------
-static int bn_sync_allreduce(void* ctx, void* buf, int64_t count, int dtype, hipStream_t s) { return comm_allreduce((aocr_model*)ctx, buf, count, dtype, s); }
+static int bn_sync_allreduce(void* ctx, void* buf, int64_t count, int dtype, hipStream_t s) { return comm_allreduce((aocr_model*)ctx, buf, count, dtype, s, 1); }
 
 void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training, int update_running) {
   hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
@@ -784,6 +784,17 @@ void loss_and_dlogits(aocr_model* m, const Dims& d, const int32_t* tge, int64_t 
   if (loss_dev) sum_to_scalar(m->s, m->nll_rows, rows, loss_dev);
 }
 
+// the side stream of the backward pass (created on first use, lowest priority) -- AOCR_NO_SIDE_WGRAD=1 keeps everything on one stream
+static bool side_stream_on(aocr_model* m) {
+  if (m->prof_on || !m->bf16 || getenv("AOCR_NO_SIDE_WGRAD")) return false;
+  if (!m->side) {
+    int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);            // lo = numerically greatest = lowest priority
+    if (hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, lo) != hipSuccess) { m->side = nullptr; return false; }
+    if (hipEventCreateWithFlags(&m->side_go, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&m->side_done, hipEventDisableTiming) != hipSuccess) return false;
+  }
+  return m->side_go && m->side_done;
+}
+
 // decoder BPTT, model.lua:643-661, t = L..1.
 static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   hipStream_t s = m->s; const bool bf = m->bf16;
@@ -878,8 +889,17 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
       }
     }
   }
-  // ---- hoisted parameter gradients (accGradParameters of every clone summed over time)
+  // d(context), model.lua:652-653 summed over the loop: the ONE result of this pass the encoder BPTT waits for
   prof_mark(m, AOCR_PROF_RNN_GEMM);
+  attention_dctx(s, m->a_all, m->ds_all, m->dcat_all, 2 * Hd, m->q_all, m->dctx, L, B, T, Hd);
+  // ---- hoisted parameter gradients (accGradParameters of every clone summed over time).  Nothing downstream of them but the
+  // optimizer: they run on the side stream beside the encoder BPTT, whose whole-sequence kernel occupies HALF the compute units
+  // (16 groups x 2 directions x 4 members at C3) for ~0.2 ms.  The side stream has the lowest priority, so the encoder kernel's
+  // workgroups are placed first.  Off while the per-family profile marks are on (the marks live on the model's stream).
+  hipStream_t ms = s;
+  if (side_stream_on(m)) {
+    hipEventRecord(m->side_go, ms); s = m->side; hipStreamWaitEvent(s, m->side_go, 0); m->side_busy = true;
+  }
   const float* h_top_all = m->dhs[Ld - 1] + slot;
   WGradProblem wg[16]; int nwg = 0;
   const bool sh = m->bf16 && m->dpre_b != nullptr;
@@ -905,17 +925,17 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   }
   colsum_flush(s, cj);
   grouped_wgrad(s, bf, wg, nwg);
-  // d(context), model.lua:652-653 summed over the loop
-  attention_dctx(s, m->a_all, m->ds_all, m->dcat_all, 2 * Hd, m->q_all, m->dctx, L, B, T, Hd);
 }
 
 // The flat gradient vector completes back to front: decoder + projector groups, then both encoder groups, then the CNN from conv7
 // down.  An event marks each point so that a data-parallel caller can start summing a bucket while the rest of the backward pass
 // still runs (aocr_grad_buckets / aocr_stream_wait_grads).
 void backward_all(aocr_model* m, const float* images, const int32_t* tgt, const Dims& d) {
+  m->side_busy = false;
   decoder_backward(m, d, tgt);
-  hipEventRecord(m->grad_ev[0], m->s);
+  hipEventRecord(m->grad_ev[0], m->side_busy ? m->side : m->s);          // decoder + projector gradients complete (on the side stream when it ran them)
   encoder_backward(m, d);
+  if (m->side_busy) { hipEventRecord(m->side_done, m->side); hipStreamWaitEvent(m->s, m->side_done, 0); }   // join before the CNN backward fills the chip
   hipEventRecord(m->grad_ev[1], m->s);
   cnn_backward(m, images, d);
   hipEventRecord(m->grad_ev[3], m->s);

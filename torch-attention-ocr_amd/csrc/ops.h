@@ -167,9 +167,9 @@ void dropout_apply(hipStream_t s, const float* src, float* dst, bf16_t* dstb, in
 void copy2d_bf16(hipStream_t s, const float* src, int64_t lds, bf16_t* dst, int64_t ldd, int rows, int cols);
 void copy2d(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols);
 void sgd_clip_update(hipStream_t s, float* params, float* grads, const int64_t* group_off /*6 host values*/, float lr,
-                     float clip, float* norms_out, void* scratch);
+                     float clip, float* norms_out, void* scratch, const int* skip = nullptr);
 size_t sgd_scratch_bytes();
-void adadelta_update(hipStream_t s, float* params, float* grads, float* var, float* acc, int64_t n, float rho, float eps, float wd);
+void adadelta_update(hipStream_t s, float* params, float* grads, float* var, float* acc, int64_t n, float rho, float eps, float wd, const int* skip = nullptr);
 // one 2-D piece of the per-step bf16 weight shadow refresh (shadow_jobs_kernel); tile0 = first 32x32 tile of the piece, tx = tiles per row
 struct ShadowJob { const float* w; bf16_t* wb; bf16_t* wtb; int64_t ld, ldb, ldt; int R, C, tile0, tx; };
 void shadow_jobs(hipStream_t s, const ShadowJob* jobs_dev, int njobs, int total_tiles);
