@@ -229,7 +229,12 @@ int aocr_profile_read(aocr_model* m, float ms[AOCR_PROF_FAMILIES], int32_t* mark
 
 /* C[M,N] (ldc) = op(A) * op(B) (+bias[n]) ; a_kmajor: 1 = A stored [M][K] (lda), 0 = [K][M];
  * b_kmajor: 1 = B stored [N][K] (ldb), 0 = [K][N].  nn.Linear forward is (1,1) with bias
- * (LSTM.lua:79-88), its gradInput (1,0), its gradWeight (0,0).  accumulate: C += . */
+ * (LSTM.lua:79-88), its gradInput (1,0), its gradWeight (0,0).
+ * accumulate: bit field -- 1: C += (instead of C =), 2: ReLU on the result, 4: tanh on the result (nn.Tanh fused behind
+ * nn.LinearNoBias, LSTM.lua:155-157); 0 / 1 keep their round-1 meaning. */
+#define AOCR_GEMM_ACCUMULATE 1
+#define AOCR_GEMM_RELU 2
+#define AOCR_GEMM_TANH 4
 int aocr_gemm(void* stream, int32_t compute, const float* A_dev, int64_t lda, int32_t a_kmajor,
               const float* B_dev, int64_t ldb, int32_t b_kmajor, float* C_dev, int64_t ldc,
               int32_t M, int32_t N, int32_t K, const float* bias_dev, int32_t accumulate);
@@ -260,7 +265,9 @@ int aocr_conv1_backward(void* stream, const float* x_dev, const float* w_dev, co
 /* nn.SpatialBatchNormalization (+ the ReLU that follows it in cnn.lua:23-24,32-33,41-42).
  * x,y (rows,C) channels-last.  training: batch stats (biased var, eps 1e-5), running stats updated with
  * momentum 0.1 and unbiased var when update_running; save_dev gets [mean(C), invstd(C)].
- * tb_rows>0 writes y transposed from (B,T,C) to (T,B,C) with B = tb_rows (cnn.lua:44-45 + model.lua:288). */
+ * tb_rows>0 writes y transposed from (B,T,C) to (T,B,C) with B = tb_rows (cnn.lua:44-45 + model.lua:288).
+ * scratch_dev: AOCR_BN_SCRATCH_BYTES of device memory the call may overwrite (partial sums), shared between calls on one stream. */
+#define AOCR_BN_SCRATCH_BYTES (8u << 20)
 int aocr_batchnorm_relu_forward(void* stream, const float* x_dev, float* y_dev, const float* weight_dev,
                                 const float* bias_dev, float* running_mean_dev, float* running_var_dev,
                                 float* save_dev, void* scratch_dev, int64_t rows, int32_t C, int32_t training,
@@ -270,12 +277,18 @@ int aocr_batchnorm_relu_backward(void* stream, const float* x_dev, const float* 
                                  const float* weight_dev, const float* save_dev, float* dx_dev, float* dweight_dev,
                                  float* dbias_dev, void* scratch_dev, int64_t rows, int32_t C, int32_t tb_rows);
 
-/* One LSTM cell, LSTM.lua:79-105 (gate order in,forget,out,g; two biases).  zx (B,4H) optional pre-computed
- * input part; x (B,in) may be NULL when zx carries W_i2h x + b.  Outputs c,h (B,H) and gates (B,4H) post-activation. */
+/* One LSTM cell, LSTM.lua:79-105 (gate order in,forget,out,g; two biases): z = W_i2h x + b_i2h + W_h2h h_prev + b_h2h.
+ * x (B,in), in and H multiples of 16.  Outputs c,h (B,H) and gates (B,4H) post-activation. */
 int aocr_lstm_cell_forward(void* stream, int32_t compute, const float* x_dev, int32_t in_size, const float* h_prev_dev,
                            const float* c_prev_dev, const float* w_i2h_dev, const float* b_i2h_dev,
                            const float* w_h2h_dev, const float* b_h2h_dev, float* c_dev, float* h_dev,
                            float* gates_dev, int32_t B, int32_t H);
+/* The same cell with the input part pre-computed, as the fused path hoists it out of the time loops (and for input widths that are
+ * not multiples of 16: the decoder's first layer sees E + Hd = 532 columns): zx (B,4H) row stride ldzx = W_i2h x + b_i2h + b_h2h
+ * (aocr_gemm with the summed bias), the call adds W_h2h h_prev and applies the gates. */
+int aocr_lstm_cell_forward_zx(void* stream, int32_t compute, const float* zx_dev, int64_t ldzx, const float* h_prev_dev,
+                              const float* c_prev_dev, const float* w_h2h_dev, float* c_dev, float* h_dev, float* gates_dev,
+                              int32_t B, int32_t H);
 /* Backward of the cell given d(c_out), d(h_out): writes dz (B,4H), dc_prev; dx/dh_prev via aocr_gemm(dz, W). */
 int aocr_lstm_cell_backward(void* stream, const float* dc_dev, const float* dh_dev, const float* gates_dev,
                             const float* c_prev_dev, const float* c_dev, float* dz_dev, float* dc_prev_dev,
@@ -290,6 +303,22 @@ int aocr_attention_forward(void* stream, const float* ctx_dev, const float* q_de
 int aocr_attention_backward(void* stream, const float* ctx_dev, const float* q_dev, const float* a_dev,
                             const float* dc_dev, int64_t lddc, float* ds_dev, float* dq_dev, int32_t B, int32_t T,
                             int32_t Hd);
+
+/* Element-wise helpers of the module-level surface (n fp32 elements; y may alias a or b):
+ *   AOCR_PW_ADD        y = a + b                  nn.CAddTable (LSTM.lua:88), gradient fan-in of a shared input
+ *   AOCR_PW_TANH_BWD   y = a * (1 - b^2)          nn.Tanh:updateGradInput (a = gradOutput, b = the tanh OUTPUT; LSTM.lua:157)
+ *   AOCR_PW_RELU_BWD   y = a * (b > 0)            cudnn.ReLU:updateGradInput where no pool follows (b = the ReLU output)
+ *   AOCR_PW_RELU       y = max(a, 0)              cudnn.ReLU:updateOutput on its own (b ignored, may be NULL) */
+#define AOCR_PW_ADD 0
+#define AOCR_PW_TANH_BWD 1
+#define AOCR_PW_RELU_BWD 2
+#define AOCR_PW_RELU 3
+int aocr_pointwise(void* stream, int32_t op, const float* a_dev, const float* b_dev, float* y_dev, int64_t n);
+
+/* nn.LookupTable (LSTM.lua:55-56): out (n, E) = weight[ids - 1] for n 1-based int32 ids; backward accumulates
+ * gradWeight[ids - 1] += gradOutput rows (accGradParameters).  weight / gradWeight (V, E). */
+int aocr_lookup_forward(void* stream, const float* weight_dev, const int32_t* ids_dev, float* out_dev, int32_t n, int32_t E);
+int aocr_lookup_backward(void* stream, const float* grad_out_dev, const int32_t* ids_dev, float* grad_weight_dev, int32_t n, int32_t E, int32_t V);
 
 /* nn.LogSoftMax + nn.ClassNLLCriterion(weights; PAD weight 0; sizeAverage=false): output_projector.lua:6,
  * criterion.lua:3-8, model.lua:644-648.  logits (rows, ld) ; targets (rows) 1-based.  logp (rows,V) optional,

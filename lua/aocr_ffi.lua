@@ -30,7 +30,7 @@ typedef struct aocr_model aocr_model;
 typedef struct aocr_config { int32_t batch_size; int32_t img_h; int32_t max_img_w; int32_t enc_hidden; int32_t enc_layers; int32_t dec_layers; int32_t vocab; int32_t emb; int32_t input_feed; int32_t max_decoder_l; int32_t max_beam; int32_t compute; } aocr_config;
 const char* aocr_last_error(void);
 int aocr_version(void);
-int aocr_param_counts(const aocr_config* cfg, int64_t counts[5]);
+int aocr_param_counts(const aocr_config* cfg, int64_t counts[AOCR_NUM_GROUPS]);
 int aocr_param_entry(const aocr_config* cfg, int32_t index, char name[64], int32_t* group, int64_t* offset, int32_t* ndim, int64_t shape[4]);
 int64_t aocr_bn_state_count(void);
 size_t aocr_workspace_bytes(const aocr_config* cfg);
@@ -69,9 +69,13 @@ int aocr_conv1_backward(void* stream, const float* x_dev, const float* w_dev, co
 int aocr_batchnorm_relu_forward(void* stream, const float* x_dev, float* y_dev, const float* weight_dev, const float* bias_dev, float* running_mean_dev, float* running_var_dev, float* save_dev, void* scratch_dev, int64_t rows, int32_t C, int32_t training, int32_t update_running, int32_t tb_rows);
 int aocr_batchnorm_relu_backward(void* stream, const float* x_dev, const float* y_dev, const float* dA_dev, const float* weight_dev, const float* save_dev, float* dx_dev, float* dweight_dev, float* dbias_dev, void* scratch_dev, int64_t rows, int32_t C, int32_t tb_rows);
 int aocr_lstm_cell_forward(void* stream, int32_t compute, const float* x_dev, int32_t in_size, const float* h_prev_dev, const float* c_prev_dev, const float* w_i2h_dev, const float* b_i2h_dev, const float* w_h2h_dev, const float* b_h2h_dev, float* c_dev, float* h_dev, float* gates_dev, int32_t B, int32_t H);
+int aocr_lstm_cell_forward_zx(void* stream, int32_t compute, const float* zx_dev, int64_t ldzx, const float* h_prev_dev, const float* c_prev_dev, const float* w_h2h_dev, float* c_dev, float* h_dev, float* gates_dev, int32_t B, int32_t H);
 int aocr_lstm_cell_backward(void* stream, const float* dc_dev, const float* dh_dev, const float* gates_dev, const float* c_prev_dev, const float* c_dev, float* dz_dev, float* dc_prev_dev, int32_t B, int32_t H);
 int aocr_attention_forward(void* stream, const float* ctx_dev, const float* q_dev, float* a_dev, float* c_dev, int64_t ldc, int32_t B, int32_t T, int32_t Hd);
 int aocr_attention_backward(void* stream, const float* ctx_dev, const float* q_dev, const float* a_dev, const float* dc_dev, int64_t lddc, float* ds_dev, float* dq_dev, int32_t B, int32_t T, int32_t Hd);
+int aocr_pointwise(void* stream, int32_t op, const float* a_dev, const float* b_dev, float* y_dev, int64_t n);
+int aocr_lookup_forward(void* stream, const float* weight_dev, const int32_t* ids_dev, float* out_dev, int32_t n, int32_t E);
+int aocr_lookup_backward(void* stream, const float* grad_out_dev, const int32_t* ids_dev, float* grad_weight_dev, int32_t n, int32_t E, int32_t V);
 int aocr_logsoftmax_nll(void* stream, const float* logits_dev, int64_t ld, const int32_t* targets_dev, float* logp_dev, float* dlogits_dev, float* nll_rows_dev, int64_t rows, int32_t V, float grad_scale);
 int aocr_beam_select(void* stream, const float* logp_dev, const int32_t* prev_tok_dev, float* beam_scores_dev, int32_t* tokens_dev, int32_t* parents_dev, int32_t B, int32_t kin, int32_t kout, int32_t V);
 int aocr_beam_select_dict(void* stream, const float* logp_dev, const int32_t* prev_tok_dev, float* beam_scores_dev, int32_t* tokens_dev, int32_t* parents_dev, int32_t B, int32_t kin, int32_t kout, int32_t V, const aocr_trie* trie, const int32_t* loc_in_dev, int32_t* loc_out_dev);

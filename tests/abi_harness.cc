@@ -2,6 +2,10 @@
 // stream, parameters filled in aocr_param_entry order from the counter-based generator, then exactly the call sequence the Lua shim
 // (lua/model.lua, the replacement of src/model/model.lua:18-731) makes for one `-phase train` step followed by a `-phase test` step:
 //   aocr_model_create -> aocr_train_forward_backward -> aocr_sgd_step -> aocr_decode (greedy) -> aocr_decode (beam 5) -> destroy.
+// Between the train step and the update the SAME step is run a second time through the MODULE-level entry points, one call per
+// nn.Module of the reference's graphs (cnn.lua:12-45, LSTM.lua:18-162, output_projector.lua:3-8, criterion.lua:3-9) in the order a
+// reference-style `cnn_model:forward(x)` / `decoder_clones[t]:forward(...)` / `cnn_model:backward(...)` walks them -- the executed
+// twin of lua/aocr_nn.lua (which cannot run here: no Lua toolchain).  Checked against the fused step's taps and the golden logits.
 // The expected values come from the fp64 oracle's golden fixture (tests/golden/feed_ld2.npz), handed over as a plain text file by
 // tests/test_abi_harness_gpu.py:  `key n v0 v1 ...` per line.  Exit code 0 = every check passed.
 //
@@ -147,6 +151,150 @@ int main(int argc, char** argv) {
       printf("[harness] grad %s: max-abs error %.3e (max %.3e)\n", k, worst, mag);
       check(k, worst / (mag + 1e-30), 0.0, 2e-3);
     } }
+  // =====================================================================================================================
+  // module-level twin of lua/aocr_nn.lua: the same step, one ABI call per nn.Module
+  // =====================================================================================================================
+  {
+    const int cmp = AOCR_COMPUTE_F32, He = 16, Hd = 32, E = 20, V = 39, T = W / 4 - 1;
+    std::vector<void*> owned;
+    auto dalloc = [&](size_t floats) -> float* { void* p = nullptr; if (hipMalloc(&p, std::max<size_t>(floats, 4) * 4) != hipSuccess) return nullptr; hipMemset(p, 0, std::max<size_t>(floats, 4) * 4); owned.push_back(p); return (float*)p; };
+    auto P = [&](const char* k) -> float* { return d_params + where[k].first; };
+    auto tap = [&](const char* name, std::vector<float>& out) -> int {
+      const void* p; int32_t nd; int64_t sh[4]; if (aocr_get_tensor(m, name, &p, &nd, sh) != 0) return 1;
+      size_t n = 1; for (int i = 0; i < nd; ++i) n *= (size_t)sh[i];
+      out.resize(n); return hipMemcpy(out.data(), p, n * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1; };
+    auto maxdiff = [&](const float* dev, const std::vector<float>& ref, double* mag) -> double {
+      std::vector<float> h(ref.size()); hipMemcpy(h.data(), dev, ref.size() * 4, hipMemcpyDeviceToHost);
+      double w = 0, g = 0; for (size_t i = 0; i < ref.size(); ++i) { w = std::max(w, std::fabs((double)h[i] - ref[i])); g = std::max(g, std::fabs((double)ref[i])); }
+      if (mag) *mag = g; return w; };
+    std::vector<float> t_feats, t_ctx, t_logits, t_dfeats;
+    if (tap("feats", t_feats) || tap("context", t_ctx) || tap("logits", t_logits) || tap("dfeats", t_dfeats)) { fprintf(stderr, "tap failed: %s\n", aocr_last_error()); return 3; }
+    std::vector<float> fused_grads((size_t)total); HIP_OK(hipMemcpy(fused_grads.data(), d_grads, total * 4, hipMemcpyDeviceToHost));
+    // geometry of cnn.lua:12-45 on (B,1,32,W)
+    const int H1 = 16, W1 = W / 2, H2 = 8, W2 = W1 / 2, H4 = 4, H6 = 2;
+    float* bn2 = dalloc(bn.size()); HIP_OK(hipMemcpy(bn2, bn.data(), bn.size() * 4, hipMemcpyHostToDevice));   // a scratch copy: the fused step already updated the real running statistics
+    float* scratch = dalloc(AOCR_BN_SCRATCH_BYTES / 4);
+    float *A1 = dalloc((size_t)B * H1 * W1 * 64), *A2 = dalloc((size_t)B * H2 * W2 * 128), *Y3 = dalloc((size_t)B * H2 * W2 * 256), *A3 = dalloc((size_t)B * H2 * W2 * 256);
+    float *A4 = dalloc((size_t)B * H4 * W2 * 256), *Y5 = dalloc((size_t)B * H4 * W2 * 512), *A5 = dalloc((size_t)B * H4 * W2 * 512), *A6 = dalloc((size_t)B * H6 * W2 * 512);
+    float *Y7 = dalloc((size_t)B * T * 512), *X = dalloc((size_t)T * B * 512), *sv3 = dalloc(512), *sv5 = dalloc(1024), *sv7 = dalloc(1024);
+    uint8_t *i2 = (uint8_t*)dalloc((size_t)B * H2 * W2 * 128), *i4 = (uint8_t*)dalloc((size_t)B * H4 * W2 * 256), *i6 = (uint8_t*)dalloc((size_t)B * H6 * W2 * 512);
+    // ---- createCNNModel, cnn.lua:9-45: AddConstant/MulConstant + conv1 + ReLU + pool are ONE call; conv + ReLU + pool fuse; BN + ReLU fuse
+    AOCR_OK(aocr_conv1_forward(nullptr, d_img, P("cnn.conv1.w"), P("cnn.conv1.b"), A1, B, 32, W));
+    AOCR_OK(aocr_conv2d_forward(nullptr, cmp, A1, P("cnn.conv2.w"), P("cnn.conv2.b"), A2, i2, B, H1, W1, 64, 128, 3, 1, 1, 1));
+    AOCR_OK(aocr_conv2d_forward(nullptr, cmp, A2, P("cnn.conv3.w"), P("cnn.conv3.b"), Y3, nullptr, B, H2, W2, 128, 256, 3, 1, 0, 0));
+    AOCR_OK(aocr_batchnorm_relu_forward(nullptr, Y3, A3, P("cnn.bn3.w"), P("cnn.bn3.b"), bn2, bn2 + 256, sv3, scratch, (int64_t)B * H2 * W2, 256, 1, 1, 0));
+    AOCR_OK(aocr_conv2d_forward(nullptr, cmp, A3, P("cnn.conv4.w"), P("cnn.conv4.b"), A4, i4, B, H2, W2, 256, 256, 3, 1, 1, 2));
+    AOCR_OK(aocr_conv2d_forward(nullptr, cmp, A4, P("cnn.conv5.w"), P("cnn.conv5.b"), Y5, nullptr, B, H4, W2, 256, 512, 3, 1, 0, 0));
+    AOCR_OK(aocr_batchnorm_relu_forward(nullptr, Y5, A5, P("cnn.bn5.w"), P("cnn.bn5.b"), bn2 + 512, bn2 + 1024, sv5, scratch, (int64_t)B * H4 * W2, 512, 1, 1, 0));
+    AOCR_OK(aocr_conv2d_forward(nullptr, cmp, A5, P("cnn.conv6.w"), P("cnn.conv6.b"), A6, i6, B, H4, W2, 512, 512, 3, 1, 1, 2));
+    AOCR_OK(aocr_conv2d_forward(nullptr, cmp, A6, P("cnn.conv7.w"), P("cnn.conv7.b"), Y7, nullptr, B, H6, W2, 512, 512, 2, 0, 0, 0));
+    AOCR_OK(aocr_batchnorm_relu_forward(nullptr, Y7, X, P("cnn.bn7.w"), P("cnn.bn7.b"), bn2 + 1536, bn2 + 2048, sv7, scratch, (int64_t)B * T, 512, 1, 1, B));   // + View / Transpose -> (T,B,512)
+    { double mag; const double e = maxdiff(X, t_feats, &mag); printf("[harness] module-level CNN output vs the fused step: max-abs %.3e (max %.3e)\n", e, mag); check("modules: feats", e, 0.0, 1e-5 * std::max(1.0, mag)); }
+    { std::vector<float> b2(bn.size()), b1(bn.size()); HIP_OK(hipMemcpy(b2.data(), bn2, bn.size() * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(b1.data(), d_bn, bn.size() * 4, hipMemcpyDeviceToHost));
+      double w = 0; for (size_t i = 0; i < bn.size(); ++i) w = std::max(w, std::fabs((double)b2[i] - b1[i])); check("modules: BatchNorm running statistics", w, 0.0, 1e-5); }
+    // ---- encoder, model.lua:291-316: one cell call per (direction, time step); context (B,T,2He)
+    float* ctx = dalloc((size_t)B * T * Hd); float* zero = dalloc((size_t)B * Hd);
+    float *ec[2][2], *eh[2][2], *eg = dalloc((size_t)B * 4 * He);
+    for (int d = 0; d < 2; ++d) for (int k = 0; k < 2; ++k) { ec[d][k] = dalloc((size_t)B * He); eh[d][k] = dalloc((size_t)B * He); }
+    int efin[2] = {0, 0};
+    for (int d = 0; d < 2; ++d) {
+      const std::string pf = d == 0 ? "enc_fw.l1." : "enc_bw.l1.";
+      int cur = 0;
+      for (int step = 0; step < T; ++step) {
+        const int t = d == 0 ? step : T - 1 - step;
+        AOCR_OK(aocr_lstm_cell_forward(nullptr, cmp, X + (size_t)t * B * 512, 512, eh[d][cur], ec[d][cur], P((pf + "i2h.w").c_str()), P((pf + "i2h.b").c_str()),
+                                       P((pf + "h2h.w").c_str()), P((pf + "h2h.b").c_str()), ec[d][cur ^ 1], eh[d][cur ^ 1], eg, B, He));
+        cur ^= 1;
+        HIP_OK(hipMemcpy2D(ctx + (size_t)t * Hd + d * He, (size_t)T * Hd * 4, eh[d][cur], He * 4, He * 4, B, hipMemcpyDeviceToDevice));     // context[{{},t,{dir}}]:copy(h), model.lua:303,315
+      }
+      efin[d] = cur;
+    }
+    { double mag; const double e = maxdiff(ctx, t_ctx, &mag); printf("[harness] module-level context vs the fused step: max-abs %.3e\n", e); check("modules: context", e, 0.0, 1e-5); }
+    // ---- decoder clones, model.lua:537-569 + LSTM.lua:18-162: LookupTable, two LSTM layers, attention, combine; projector + criterion
+    float *dc[2][2], *dh[2][2];
+    for (int l = 0; l < 2; ++l) for (int k = 0; k < 2; ++k) { dc[l][k] = dalloc((size_t)B * Hd); dh[l][k] = dalloc((size_t)B * Hd); }
+    for (int d = 0; d < 2; ++d) {     // layer-1 state = final encoder states, forward | backward halves (model.lua:543-548); quirk S5: h1(0) stays zero
+      HIP_OK(hipMemcpy2D(dc[0][0] + d * He, Hd * 4, ec[d][efin[d]], He * 4, He * 4, B, hipMemcpyDeviceToDevice));
+    }
+    float *emb = dalloc((size_t)B * E), *zx = dalloc((size_t)B * 4 * Hd), *feed = dalloc((size_t)B * Hd), *q = dalloc((size_t)B * Hd), *att = dalloc((size_t)B * T);
+    float *cat = dalloc((size_t)B * 2 * Hd), *gates = dalloc((size_t)B * 4 * Hd), *logits = dalloc((size_t)L * B * 40), *nll = dalloc((size_t)L * B), *dlog = dalloc((size_t)L * B * 40);
+    float *outs = dalloc((size_t)L * B * Hd), *bsum1 = dalloc(4 * Hd);
+    AOCR_OK(aocr_pointwise(nullptr, AOCR_PW_ADD, P("dec.l1.i2h.b"), P("dec.l1.h2h.b"), bsum1, 4 * Hd));
+    int32_t* ids; HIP_OK(hipMalloc(&ids, (size_t)L * B * 4)); owned.push_back(ids);
+    int32_t* tge_tm; HIP_OK(hipMalloc(&tge_tm, (size_t)L * B * 4)); owned.push_back(tge_tm);
+    { std::vector<int32_t> a((size_t)L * B), e2((size_t)L * B); for (int t = 0; t < L; ++t) for (int b = 0; b < B; ++b) { a[(size_t)t * B + b] = tgt[(size_t)b * L + t]; e2[(size_t)t * B + b] = tge[(size_t)b * L + t]; }
+      HIP_OK(hipMemcpy(ids, a.data(), a.size() * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(tge_tm, e2.data(), e2.size() * 4, hipMemcpyHostToDevice)); }
+    int cur = 0;
+    for (int t = 0; t < L; ++t) {
+      AOCR_OK(aocr_lookup_forward(nullptr, P("dec.lookup"), ids + (size_t)t * B, emb, B, E));                                       // nn.LookupTable, LSTM.lua:55-56
+      // layer 1: i2h over JoinTable{embedding, input feed} (LSTM.lua:59-64,79-80) as two products into one pre-activation, then the cell
+      AOCR_OK(aocr_gemm(nullptr, cmp, emb, E, 1, P("dec.l1.i2h.w"), E + Hd, 1, zx, 4 * Hd, B, 4 * Hd, E, bsum1, 0));
+      AOCR_OK(aocr_gemm(nullptr, cmp, t == 0 ? zero : feed, Hd, 1, P("dec.l1.i2h.w") + E, E + Hd, 1, zx, 4 * Hd, B, 4 * Hd, Hd, nullptr, AOCR_GEMM_ACCUMULATE));
+      AOCR_OK(aocr_lstm_cell_forward_zx(nullptr, cmp, zx, 4 * Hd, dh[0][cur], dc[0][cur], P("dec.l1.h2h.w"), dc[0][cur ^ 1], dh[0][cur ^ 1], gates, B, Hd));
+      AOCR_OK(aocr_lstm_cell_forward(nullptr, cmp, dh[0][cur ^ 1], Hd, dh[1][cur], dc[1][cur], P("dec.l2.i2h.w"), P("dec.l2.i2h.b"), P("dec.l2.h2h.w"), P("dec.l2.h2h.b"),
+                                     dc[1][cur ^ 1], dh[1][cur ^ 1], gates, B, Hd));
+      cur ^= 1;
+      // create_decoder_attn, LSTM.lua:124-162: q = W_a h (LinearNoBias), scores / softmax / context, JoinTable{c, h}, LinearNoBias + Tanh
+      AOCR_OK(aocr_gemm(nullptr, cmp, dh[1][cur], Hd, 1, P("dec.attn.wa"), Hd, 1, q, Hd, B, Hd, Hd, nullptr, 0));
+      AOCR_OK(aocr_attention_forward(nullptr, ctx, q, att, cat, 2 * Hd, B, T, Hd));                                                     // c lands in the first half of the JoinTable buffer
+      HIP_OK(hipMemcpy2D(cat + Hd, 2 * Hd * 4, dh[1][cur], Hd * 4, Hd * 4, B, hipMemcpyDeviceToDevice));
+      AOCR_OK(aocr_gemm(nullptr, cmp, cat, 2 * Hd, 1, P("dec.attn.wc"), 2 * Hd, 1, outs + (size_t)t * B * Hd, Hd, B, Hd, 2 * Hd, nullptr, AOCR_GEMM_TANH));
+      HIP_OK(hipMemcpy(feed, outs + (size_t)t * B * Hd, (size_t)B * Hd * 4, hipMemcpyDeviceToDevice));                                   // input feed of the next clone
+      // createOutputUnit, output_projector.lua:3-8 (the LogSoftMax is fused with the criterion below)
+      AOCR_OK(aocr_gemm(nullptr, cmp, outs + (size_t)t * B * Hd, Hd, 1, P("proj.w"), Hd, 1, logits + (size_t)t * B * 40, 40, B, V, Hd, P("proj.b"), 0));
+    }
+    // criterion.lua:3-9 + model.lua:644-648: ClassNLLCriterion(weights, PAD weight 0, sizeAverage false), d(loss) scaled by 1 / batch_size
+    AOCR_OK(aocr_logsoftmax_nll(nullptr, logits, 40, tge_tm, nullptr, dlog, nll, (int64_t)L * B, V, 1.0f / B));
+    { std::vector<float> lg((size_t)L * B * 40), nl((size_t)L * B); HIP_OK(hipMemcpy(lg.data(), logits, lg.size() * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(nl.data(), nll, nl.size() * 4, hipMemcpyDeviceToHost));
+      const std::vector<double>& e = exp["logits"]; double worst = 0, wf = 0, ls = 0;
+      for (int t = 0; t < L; ++t) for (int b = 0; b < B; ++b) for (int v = 0; v < V; ++v) {
+        worst = std::max(worst, std::fabs((double)lg[((size_t)t * B + b) * 40 + v] - e[((size_t)t * B + b) * V + v]));
+        wf = std::max(wf, std::fabs((double)lg[((size_t)t * B + b) * 40 + v] - t_logits[((size_t)t * B + b) * 40 + v])); }
+      for (float x : nl) ls += x;
+      printf("[harness] module-level decoder logits: max-abs %.3e vs the fp64 oracle, %.3e vs the fused step; loss %.6f\n", worst, wf, ls);
+      check("modules: logits vs oracle", worst, 0.0, 1e-4); check("modules: logits vs fused", wf, 0.0, 2e-5); check("modules: loss", ls, exp["loss"][0] * B, 1e-3); }
+    // projector backward (model.lua:648): gradWeight = dlogits^T out, gradBias = column sums -- against the fused step's gradients
+    { float* dwo = dalloc((size_t)V * Hd);
+      AOCR_OK(aocr_gemm(nullptr, cmp, dlog, 40, 0, outs, Hd, 0, dwo, Hd, V, Hd, L * B, nullptr, 0));
+      const auto w = where["proj.w"]; std::vector<float> ref(fused_grads.begin() + w.first, fused_grads.begin() + w.first + w.second);
+      double mag; const double e = maxdiff(dwo, ref, &mag); printf("[harness] module-level proj.w gradient vs the fused step: max-abs %.3e (max %.3e)\n", e, mag);
+      check("modules: d proj.w", e / (mag + 1e-30), 0.0, 1e-4); }
+    // ---- cnn_model:backward(cnn_input, cnn_grad), model.lua:692, module by module in reverse (d(features) from the fused step's tap)
+    { float* dX = dalloc(t_dfeats.size()); HIP_OK(hipMemcpy(dX, t_dfeats.data(), t_dfeats.size() * 4, hipMemcpyHostToDevice));
+      const size_t gmax = (size_t)B * H1 * W1 * 128;
+      float *G0 = dalloc(gmax), *G1 = dalloc(gmax), *mg = dalloc((size_t)total);     // mg: module-level gradient vector, same layout as d_grads
+      auto Gp = [&](const char* k) -> float* { return mg + where[k].first; };
+      AOCR_OK(aocr_batchnorm_relu_backward(nullptr, Y7, X, dX, P("cnn.bn7.w"), sv7, G0, Gp("cnn.bn7.w"), Gp("cnn.bn7.b"), scratch, (int64_t)B * T, 512, B));
+      AOCR_OK(aocr_conv2d_backward_filter(nullptr, cmp, A6, G0, Gp("cnn.conv7.w"), Gp("cnn.conv7.b"), B, H6, W2, 512, 512, 2, 0));
+      AOCR_OK(aocr_conv2d_backward_data(nullptr, cmp, G0, P("cnn.conv7.w"), G1, B, H6, W2, 512, 512, 2, 0));
+      AOCR_OK(aocr_unpool_relu_backward(nullptr, G1, A6, i6, G0, B, H4, W2, 512, 2));
+      AOCR_OK(aocr_conv2d_backward_filter(nullptr, cmp, A5, G0, Gp("cnn.conv6.w"), Gp("cnn.conv6.b"), B, H4, W2, 512, 512, 3, 1));
+      AOCR_OK(aocr_conv2d_backward_data(nullptr, cmp, G0, P("cnn.conv6.w"), G1, B, H4, W2, 512, 512, 3, 1));
+      AOCR_OK(aocr_batchnorm_relu_backward(nullptr, Y5, A5, G1, P("cnn.bn5.w"), sv5, G0, Gp("cnn.bn5.w"), Gp("cnn.bn5.b"), scratch, (int64_t)B * H4 * W2, 512, 0));
+      AOCR_OK(aocr_conv2d_backward_filter(nullptr, cmp, A4, G0, Gp("cnn.conv5.w"), Gp("cnn.conv5.b"), B, H4, W2, 256, 512, 3, 1));
+      AOCR_OK(aocr_conv2d_backward_data(nullptr, cmp, G0, P("cnn.conv5.w"), G1, B, H4, W2, 256, 512, 3, 1));
+      AOCR_OK(aocr_unpool_relu_backward(nullptr, G1, A4, i4, G0, B, H2, W2, 256, 2));
+      AOCR_OK(aocr_conv2d_backward_filter(nullptr, cmp, A3, G0, Gp("cnn.conv4.w"), Gp("cnn.conv4.b"), B, H2, W2, 256, 256, 3, 1));
+      AOCR_OK(aocr_conv2d_backward_data(nullptr, cmp, G0, P("cnn.conv4.w"), G1, B, H2, W2, 256, 256, 3, 1));
+      AOCR_OK(aocr_batchnorm_relu_backward(nullptr, Y3, A3, G1, P("cnn.bn3.w"), sv3, G0, Gp("cnn.bn3.w"), Gp("cnn.bn3.b"), scratch, (int64_t)B * H2 * W2, 256, 0));
+      AOCR_OK(aocr_conv2d_backward_filter(nullptr, cmp, A2, G0, Gp("cnn.conv3.w"), Gp("cnn.conv3.b"), B, H2, W2, 128, 256, 3, 1));
+      AOCR_OK(aocr_conv2d_backward_data(nullptr, cmp, G0, P("cnn.conv3.w"), G1, B, H2, W2, 128, 256, 3, 1));
+      AOCR_OK(aocr_unpool_relu_backward(nullptr, G1, A2, i2, G0, B, H1, W1, 128, 1));
+      AOCR_OK(aocr_conv2d_backward_filter(nullptr, cmp, A1, G0, Gp("cnn.conv2.w"), Gp("cnn.conv2.b"), B, H1, W1, 64, 128, 3, 1));
+      AOCR_OK(aocr_conv2d_backward_data(nullptr, cmp, G0, P("cnn.conv2.w"), G1, B, H1, W1, 64, 128, 3, 1));
+      AOCR_OK(aocr_conv1_backward(nullptr, d_img, P("cnn.conv1.w"), P("cnn.conv1.b"), G1, Gp("cnn.conv1.w"), Gp("cnn.conv1.b"), B, 32, W));
+      double worst = 0; std::string wk;
+      for (const char* k : {"cnn.conv1.w", "cnn.conv1.b", "cnn.conv2.w", "cnn.conv2.b", "cnn.conv3.w", "cnn.bn3.w", "cnn.bn3.b", "cnn.conv4.w", "cnn.conv4.b", "cnn.conv5.w",
+                            "cnn.bn5.w", "cnn.bn5.b", "cnn.conv6.w", "cnn.conv6.b", "cnn.conv7.w", "cnn.bn7.w", "cnn.bn7.b"}) {      // (conv3/5/7 biases sit in front of a BatchNorm: exact gradient 0, rounding noise)
+        const auto w = where[k]; std::vector<float> ref(fused_grads.begin() + w.first, fused_grads.begin() + w.first + w.second);
+        double mag; const double e = maxdiff(Gp(k), ref, &mag) / (mag + 1e-30);
+        if (e > worst) { worst = e; wk = k; }
+        check((std::string("modules: d ") + k).c_str(), e, 0.0, 2e-4);
+      }
+      printf("[harness] module-level CNN backward vs the fused step, 17 gradient tensors: worst relative max-abs %.3e (%s)\n", worst, wk.c_str()); }
+    HIP_OK(hipDeviceSynchronize());
+    for (void* p : owned) hipFree(p);
+  }
   AOCR_OK(aocr_sgd_step(m, 0.1f, 5.0f, d_scal + 2));
   { float n[10]; HIP_OK(hipMemcpy(n, d_scal + 2, 40, hipMemcpyDeviceToHost));
     for (int g = 0; g < 5; ++g) { check("param norm", n[2 * g], exp["norms"][2 * g], 1e-4 * std::max(1.0, exp["norms"][2 * g])); check("grad norm", n[2 * g + 1], exp["norms"][2 * g + 1], 2e-3 * std::max(1e-3, exp["norms"][2 * g + 1])); } }

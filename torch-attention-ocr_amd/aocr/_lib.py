@@ -90,9 +90,13 @@ SIGNATURES = {
     "aocr_batchnorm_relu_forward": (C.c_int, [_vp] * 9 + [_i64, _i32, _i32, _i32, _i32]),
     "aocr_batchnorm_relu_backward": (C.c_int, [_vp] * 10 + [_i64, _i32, _i32]),
     "aocr_lstm_cell_forward": (C.c_int, [_vp, _i32, _vp, _i32] + [_vp] * 9 + [_i32, _i32]),
+    "aocr_lstm_cell_forward_zx": (C.c_int, [_vp, _i32, _vp, _i64] + [_vp] * 6 + [_i32, _i32]),
     "aocr_lstm_cell_backward": (C.c_int, [_vp] * 8 + [_i32, _i32]),
     "aocr_attention_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32]),
     "aocr_attention_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32]),
+    "aocr_pointwise": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64]),
+    "aocr_lookup_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32]),
+    "aocr_lookup_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32]),
     "aocr_logsoftmax_nll": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _f32]),
     "aocr_beam_select_dict": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "aocr_edit_distance": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),

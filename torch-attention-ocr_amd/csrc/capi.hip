@@ -434,10 +434,28 @@ int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_p
 int aocr_gemm(void* stream, int32_t compute, const float* A_dev, int64_t lda, int32_t a_kmajor, const float* B_dev, int64_t ldb,
               int32_t b_kmajor, float* C_dev, int64_t ldc, int32_t M, int32_t N, int32_t K, const float* bias_dev, int32_t accumulate) {
   REQUIRE(A_dev && B_dev && C_dev && M >= 0 && N >= 0 && K >= 0, "bad gemm arguments");
+  REQUIRE((accumulate & ~7) == 0, "unknown gemm flag bits %d", accumulate);
+  const int fl = ((accumulate & AOCR_GEMM_ACCUMULATE) ? EP_ACCUM : 0) | ((accumulate & AOCR_GEMM_RELU) ? EP_RELU : 0) | ((accumulate & AOCR_GEMM_TANH) ? EP_TANH : 0);
+  REQUIRE(!((fl & EP_ACCUM) && (fl & (EP_RELU | EP_TANH))), "an activation on an accumulating product is not a module of the path");
   int rc = gemm((hipStream_t)stream, compute == AOCR_COMPUTE_BF16, A_dev, lda, a_kmajor != 0, B_dev, ldb, b_kmajor != 0, C_dev, ldc,
-                M, N, K, bias_dev, nullptr, accumulate ? EP_ACCUM : 0);
+                M, N, K, bias_dev, nullptr, fl);
   REQUIRE(rc == 0, "gemm: the (A column-major, B row-major-by-K) combination is not supported");
   return check_launch("aocr_gemm");
+}
+int aocr_pointwise(void* stream, int32_t op, const float* a_dev, const float* b_dev, float* y_dev, int64_t n) {
+  REQUIRE(a_dev && y_dev && n >= 0 && op >= 0 && op <= 3 && (b_dev || op == AOCR_PW_RELU), "bad arguments");
+  pointwise((hipStream_t)stream, op, a_dev, b_dev, y_dev, n);
+  return check_launch("aocr_pointwise");
+}
+int aocr_lookup_forward(void* stream, const float* weight_dev, const int32_t* ids_dev, float* out_dev, int32_t n, int32_t E) {
+  REQUIRE(weight_dev && ids_dev && out_dev && n >= 0 && E > 0, "bad arguments");
+  embedding_gather((hipStream_t)stream, weight_dev, ids_dev, 0, 1, out_dev, 1, n, E);
+  return check_launch("aocr_lookup_forward");
+}
+int aocr_lookup_backward(void* stream, const float* grad_out_dev, const int32_t* ids_dev, float* grad_weight_dev, int32_t n, int32_t E, int32_t V) {
+  REQUIRE(grad_out_dev && ids_dev && grad_weight_dev && n >= 0 && E > 0 && E <= 256 && V > 0, "bad arguments");
+  embedding_scatter_accum((hipStream_t)stream, grad_out_dev, ids_dev, 0, 1, grad_weight_dev, 1, n, E, V);
+  return check_launch("aocr_lookup_backward");
 }
 int aocr_conv2d_forward(void* stream, int32_t compute, const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,
                         uint8_t* idx_dev, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t pad,
@@ -509,6 +527,19 @@ int aocr_lstm_cell_forward(void* stream, int32_t compute, const float* x_dev, in
   e.c_out = c_dev; e.ldc = H; e.h_out = h_dev; e.ldh = H; e.h_out2 = nullptr; e.ldh2 = 0; e.gates = gates_dev; e.ldg = 4 * H; e.M = B; e.H = H;
   launch_small_gates_fwd((hipStream_t)stream, compute == AOCR_COMPUTE_BF16, 1, &z, B, H);
   return check_launch("aocr_lstm_cell_forward");
+}
+int aocr_lstm_cell_forward_zx(void* stream, int32_t compute, const float* zx_dev, int64_t ldzx, const float* h_prev_dev, const float* c_prev_dev,
+                              const float* w_h2h_dev, float* c_dev, float* h_dev, float* gates_dev, int32_t B, int32_t H) {
+  REQUIRE(zx_dev && h_prev_dev && c_prev_dev && w_h2h_dev && c_dev && h_dev, "NULL argument");
+  REQUIRE(H % 16 == 0 && ldzx >= 4 * (int64_t)H, "H must be a multiple of 16 and ldzx >= 4H");
+  GatesFwdArgs z;
+  z.a = make_loadk(h_prev_dev, H, B, H);
+  z.b = make_loadk(w_h2h_dev, H, 4 * H, H);
+  z.K = H;
+  EpGatesFwd& e = z.ep; e.zx = zx_dev; e.ldzx = ldzx; e.b1 = nullptr; e.b2 = nullptr; e.c_prev = c_prev_dev; e.ldcp = H;
+  e.c_out = c_dev; e.ldc = H; e.h_out = h_dev; e.ldh = H; e.h_out2 = nullptr; e.ldh2 = 0; e.gates = gates_dev; e.ldg = 4 * H; e.M = B; e.H = H;
+  launch_small_gates_fwd((hipStream_t)stream, compute == AOCR_COMPUTE_BF16, 1, &z, B, H);
+  return check_launch("aocr_lstm_cell_forward_zx");
 }
 int aocr_lstm_cell_backward(void* stream, const float* dc_dev, const float* dh_dev, const float* gates_dev, const float* c_prev_dev,
                             const float* c_dev, float* dz_dev, float* dc_prev_dev, int32_t B, int32_t H) {

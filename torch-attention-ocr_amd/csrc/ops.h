@@ -162,6 +162,7 @@ void embedding_gather(hipStream_t s, const float* table, const int32_t* tok, int
 void embedding_scatter_accum(hipStream_t s, const float* demb, const int32_t* tok, int64_t stride_t, int64_t stride_b,
                              float* dtable, int L, int B, int E, int V);
 void dpre_tanh(hipStream_t s, const float* g1, const float* g2, const float* out, float* dpre, int64_t n, bf16_t* dpreb = nullptr, const DropSpec* drop = nullptr);
+void pointwise(hipStream_t s, int op, const float* a, const float* b, float* y, int64_t n);   // AOCR_PW_* of include/aocr.h
 void u8_to_f32(hipStream_t s, const uint8_t* src, float* dst, int64_t n);
 void dropout_apply(hipStream_t s, const float* src, float* dst, bf16_t* dstb, int64_t n, const DropSpec& drop);  // (g1+g2)*(1-out^2)
 void copy2d_bf16(hipStream_t s, const float* src, int64_t lds, bf16_t* dst, int64_t ldd, int rows, int cols);

@@ -1284,6 +1284,24 @@ void colsum_flush(hipStream_t s, ColsumJobs& g) {
   g.n = 0; g.total = 0;
 }
 
+// element-wise helpers of the module-level surface (AOCR_PW_* of include/aocr.h): 16-byte accesses on the aligned body, HBM-bound
+__global__ __launch_bounds__(256) void pointwise_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n, int vec) {
+  auto f = [op](float x, float z) { return op == 0 ? x + z : op == 1 ? x * (1.f - z * z) : op == 2 ? (z > 0.f ? x : 0.f) : fmaxf(x, 0.f); };
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (vec) {
+    if (i * 4 + 3 < n) {
+      const float4 x = reinterpret_cast<const float4*>(a)[i]; const float4 z = b ? reinterpret_cast<const float4*>(b)[i] : x;
+      reinterpret_cast<float4*>(y)[i] = make_float4(f(x.x, z.x), f(x.y, z.y), f(x.z, z.z), f(x.w, z.w));
+    } else for (int64_t j = i * 4; j < n; ++j) y[j] = f(a[j], b ? b[j] : a[j]);
+  } else if (i < n) y[i] = f(a[i], b ? b[i] : a[i]);
+}
+void pointwise(hipStream_t s, int op, const float* a, const float* b, float* y, int64_t n) {
+  if (n <= 0) return;
+  const int vec = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  const int64_t items = vec ? (n + 3) / 4 : n;
+  hipLaunchKernelGGL(pointwise_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, op, a, b, y, n, vec);
+}
+
 // nn.LookupTable forward / accGradParameters (LSTM.lua:55-56)
 __global__ void emb_gather_kernel(const float* __restrict__ table, const int32_t* __restrict__ tok, int64_t st, int64_t sb,
                                   float* out, int L, int B, int E) {
