@@ -154,3 +154,38 @@ def test_flat_checkpoint_round_trip(tmp_path):
     ck = read_t7_checkpoint(path)
     assert all(np.array_equal(ck["params"][k], P[k]) for k in P) and all(np.array_equal(ck["bn_state"][k], S[k]) for k in S)
     assert ck["global_step"] == 77 and ck["optim_state"] == {"learningRate": 0.1} and ck["config"]["decoder_num_layers"] == 2
+
+
+@pytest.mark.parametrize("He,Le,Ld,feed,pre", [(8, 1, 2, True, True), (16, 2, 3, False, False), (8, 3, 1, True, False)])
+def test_reference_layout_writer_round_trip(tmp_path, He, Le, Ld, feed, pre):
+    """aocr.checkpoint.write_reference_checkpoint: model:save's own table ({5 nets as nn / nngraph object trees, config, global_step,
+    optim_state}, model.lua:720-725) from Python.  Read back by the reader (written against the independent fixture trees of
+    t7_fixtures.py): every tensor bit for bit, and the structure model:load walks (model.lua:51-59: checkpoint[1] = the five nets in
+    order, [2] config, [3] step, [4] optimizer state).  Unverified against Torch7 itself (no Lua here) -- said so in the module."""
+    from aocr import t7
+    from aocr.checkpoint import read_t7_checkpoint, write_reference_checkpoint
+    from t7_fixtures import random_params
+    P, S, config = random_params(He, Le, Ld, feed, seed=He + Le)
+    config["prealloc"] = pre
+    path = str(tmp_path / "model.t7")
+    write_reference_checkpoint(path, P, S, config, 4321, {"learningRate": 0.025})
+    ck = read_t7_checkpoint(path)
+    assert set(ck["params"]) == set(P)
+    assert all(np.array_equal(ck["params"][k], P[k]) for k in P) and all(np.array_equal(ck["bn_state"][k], S[k]) for k in S)
+    assert ck["global_step"] == 4321 and ck["optim_state"] == {"learningRate": 0.025}
+    assert ck["config"]["encoder_num_layers"] == Le and bool(ck["config"]["input_feed"]) == bool(feed)
+    raw = t7.load(path)
+    nets = raw[1]
+    assert [nets[i].typename for i in range(1, 6)] == ["nn.Sequential", "nn.gModule", "nn.gModule", "nn.gModule", "nn.Sequential"]
+    kinds = [m.typename for m in nets[1]["modules"].array_part()]
+    assert kinds[:5] == ["nn.AddConstant", "nn.MulConstant", "cudnn.SpatialConvolution", "cudnn.ReLU", "cudnn.SpatialMaxPooling"]   # cnn.lua:9-15
+    assert kinds.count("cudnn.SpatialConvolution") == 7 and kinds.count("nn.SpatialBatchNormalization") == 3 and kinds[-2:] == ["nn.View", "nn.Transpose"]
+    pools = [m for m in nets[1]["modules"].array_part() if m.typename == "cudnn.SpatialMaxPooling"]
+    assert [(p["kW"], p["kH"]) for p in pools] == [(2, 2), (2, 2), (1, 2), (1, 2)]                          # cnn.lua:15,20,29,38
+    # gModule inputs: x [, context [, input feed]] + 2 per layer (LSTM.lua:30-45); the decoder ends in Dropout(attention) (:116-118)
+    assert nets[2]["nInputs"] == 1 + 2 * Le and nets[4]["nInputs"] == 2 + (1 if feed else 0) + 2 * Ld
+    last = nets[4]["forwardnodes"].array_part()[-1]["data"]["module"]
+    assert last.typename == "nn.Dropout"
+    if pre:
+        names = [n["data"]["module"].get("name") for n in nets[4]["forwardnodes"].array_part() if n["data"]["module"].typename == "nn.Linear"]
+        assert f"decoder_L{Ld}_h2h-reuse" in names and "decoder_L1_i2h-reuse" in names                      # memory.lua:55-66

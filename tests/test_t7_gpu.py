@@ -36,14 +36,19 @@ def test_load_reference_t7_then_logits_match_oracle(cuda, tmp_path, Le, Ld, feed
     m.shutdown()
 
 
-def test_save_t7_round_trip(cuda, tmp_path):
+@pytest.mark.parametrize("layout", ["reference", "flat"])
+def test_save_t7_round_trip(cuda, tmp_path, layout):
+    """Model.save to Torch7 serialization in the reference's own layout (the five nets as nn / nngraph trees, model.lua:720-725) and in
+    the flat layout; Model.load reads both back bit for bit."""
     import aocr
     from test_step_gpu import CASES, make
     m, O, ocfg, P, st, batch = make(CASES[0], B=4, W=36, maxlen=5)
     m.train_forward_backward(batch); m.sgd_step()
     m.global_step = 17; m.optim_state = {"learningRate": 0.05}
     path = str(tmp_path / "model.t7")
-    m.save(path)
+    m.save(path, layout=layout)
+    from aocr import t7
+    assert isinstance(t7.load(path).get(1), dict) == (layout == "reference")
     m2 = aocr.Model().load(path, dict(batch_size=4, max_img_w=36, max_decoder_l=12, max_beam=5))
     assert m2.global_step == 17 and m2.optim_state == {"learningRate": 0.05}
     assert torch.equal(m.params.cpu(), m2.params.cpu()) and torch.equal(m.bn_state.cpu(), m2.bn_state.cpu())

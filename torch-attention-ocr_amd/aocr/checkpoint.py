@@ -19,10 +19,16 @@ PARITY UNPINNED, and stated as such: no Torch7 runs here and the reference ships
 produced by aocr.t7's own writer from object trees that restate what nn / nngraph serialize ([upstream] nngraph.Node: fields
 `data` {module, mapindex[i] = parent's data, ...}, `children`; nn.gModule: `forwardnodes`) -- tests/test_t7_cpu.py.
 
-`write_flat_checkpoint` is the way back: a `.t7` holding ONE plain table of named FloatTensors in Torch7 layouts (+ BatchNorm
-running statistics, config, global_step, optim_state) that ten lines of Lua pour into a freshly created reference model
-(INTEGRATION.md); writing the nets themselves would mean re-creating nngraph's private graph objects bit for bit, which cannot be
-checked without Torch7.
+Two ways back:
+  * `write_reference_checkpoint` (round 3) emits the reference's OWN layout -- the five nets as nn / nngraph object trees built the
+    way cnn.lua:9-45, LSTM.lua:18-162 and output_projector.lua:3-8 build them, {nets, config, global_step, optim_state} -- so that
+    the reference's `model:load` (model.lua:45-80) has a file of the shape it expects.  UNVERIFIED AGAINST TORCH7: what is checked is
+    that this package's reader (written against the fixture trees of tests/t7_fixtures.py, an independent restatement) recovers every
+    tensor bit for bit; the private fields nn / nngraph / cudnn.torch add to their objects beyond those the constructors of the
+    un-pinned upstream packages set are not knowable here.
+  * `write_flat_checkpoint`: a `.t7` holding ONE plain table of named FloatTensors in Torch7 layouts (+ BatchNorm running statistics,
+    config, global_step, optim_state) that ten lines of Lua pour into a freshly created reference model -- the
+    conservative route, which depends on nothing but torch.load of a plain table.
 """
 from __future__ import annotations
 
@@ -182,6 +188,151 @@ def parse_reference_checkpoint(ck) -> dict:
         raise CheckpointError(f"proj.w is {P['proj.w'].shape}, the config says ({config['target_vocab_size']}, {Hd})")
     optim = dict(ck.get(4) or {}) if isinstance(ck.get(4), dict) else {}
     return {"params": P, "bn_state": S, "config": config, "global_step": int(ck.get(3) or 0), "optim_state": optim}
+
+
+# ------------------------------------------------------------------------------------------------ the reference's own layout
+def _module(cls: str, **fields) -> TorchObject:
+    """an nn.Module as nn.Module.__init leaves it ([upstream] nn/Module.lua: gradInput, output, _type) + its own fields."""
+    f = LuaTable(gradInput=np.zeros((0,), np.float32), output=np.zeros((0,), np.float32), _type="torch.FloatTensor")
+    f.update(fields)
+    return TorchObject(cls, f)
+
+
+def _param_fields(weight, bias=None) -> dict:
+    w = np.ascontiguousarray(np.asarray(weight, np.float32))
+    f = dict(weight=w, gradWeight=np.zeros_like(w))
+    if bias is not None:
+        b = np.ascontiguousarray(np.asarray(bias, np.float32))
+        f.update(bias=b, gradBias=np.zeros_like(b))
+    return f
+
+
+class _Graph:
+    """nngraph as data: node(module, *parents) -> nngraph.Node ([upstream] graph.Node + nngraph: `data` = {module, mapindex}, where
+    mapindex[i] is the i-th parent's data table and mapindex[that table] = i; `children`; a gModule lists its nodes in forward
+    (topological) order in `forwardnodes`).  Nodes are created in the order the reference's Lua creates them, which is topological."""
+
+    def __init__(self):
+        self.nodes = []
+
+    def node(self, module, *parents):
+        data = LuaTable(module=module)
+        mi = LuaTable()
+        for i, par in enumerate(parents, 1):
+            pd = par.fields["data"]
+            mi[i] = pd; mi[pd] = i
+        data["mapindex"] = mi
+        n = TorchObject("nngraph.Node", LuaTable(data=data, children=LuaTable(), id=len(self.nodes) + 1, visited=False))
+        for par in parents:
+            ch = par.fields["children"]; ch[len(ch) + 1] = n
+        self.nodes.append(n)
+        return n
+
+    def gmodule(self, n_inputs: int, name: Optional[str] = None) -> TorchObject:
+        f = dict(forwardnodes=LuaTable((i, n) for i, n in enumerate(self.nodes, 1)), verbose=False, nInputs=n_inputs)
+        if name:
+            f["name"] = name
+        return _module("nn.gModule", **f)
+
+
+def _lstm_net(P, prefix: str, n_layers: int, hidden: int, dropout: float, attention=False, input_feed=False, lookup=False, mem_name=None):
+    """createLSTM, LSTM.lua:18-122 (node creation order = the source's)."""
+    g = _Graph()
+    ident = lambda: g.node(_module("nn.Identity"))
+    inputs = [ident()]                                            # x, :30
+    offset = 0
+    if attention:
+        inputs.append(ident()); offset += 1                       # context, :34
+        if input_feed:
+            inputs.append(ident()); offset += 1                   # prev attention output, :38
+    for _ in range(n_layers):
+        inputs += [ident(), ident()]                              # prev_c[L], prev_h[L], :42-45
+    outputs = []
+    for L in range(1, n_layers + 1):
+        prev_c, prev_h = inputs[L * 2 - 1 + offset], inputs[L * 2 + offset]       # :50-51
+        if L == 1:
+            x = inputs[0]
+            if lookup:                                            # :55-56
+                x = g.node(_module("nn.LookupTable", **_param_fields(P[f"{prefix}.lookup"]), paddingValue=0), x)
+            if input_feed:                                        # :59-64
+                x = g.node(_module("nn.JoinTable", dimension=2), x, inputs[offset])
+        else:                                                     # :66-69
+            x = g.node(_module("nn.Dropout", p=float(dropout), train=True, v2=True, inplace=False), outputs[(L - 1) * 2 - 1])
+
+        def linear(role):
+            f = _param_fields(P[f"{prefix}.l{L}.{role}.w"], P[f"{prefix}.l{L}.{role}.b"])
+            if mem_name:                                          # memory.lua:55-66 under -prealloc
+                f["name"] = f"{mem_name}_L{L}_" + ("i2h-reuse" if role == "i2h" else "h2h-reuse")
+            return _module("nn.Linear", **f)
+        i2h = g.node(linear("i2h"), x)                            # :79-80
+        h2h = g.node(linear("h2h"), prev_h)                       # :84-85
+        sums = g.node(_module("nn.CAddTable"), i2h, h2h)          # :86-88
+        resh = g.node(_module("nn.Reshape", size=np.array([4, hidden], np.int64), nelement=4 * hidden, batchMode=True), sums)   # :89
+        split = g.node(_module("nn.SplitTable", dimension=2), resh)
+        n = [g.node(_module("nn.SelectTable", index=i), split) for i in range(1, 5)]
+        ig, fg, og = (g.node(_module("nn.Sigmoid"), n[i]) for i in range(3))      # :94-97 gate order in, forget, out
+        it = g.node(_module("nn.Tanh"), n[3])
+        next_c = g.node(_module("nn.CAddTable"), g.node(_module("nn.CMulTable"), fg, prev_c), g.node(_module("nn.CMulTable"), ig, it))   # :99-102
+        next_h = g.node(_module("nn.CMulTable"), og, g.node(_module("nn.Tanh"), next_c))                                              # :104
+        outputs += [next_c, next_h]
+    if attention:                                                 # :110-118 + create_decoder_attn :124-162
+        a = _Graph()
+        ai = [a.node(_module("nn.Identity")), a.node(_module("nn.Identity"))]
+        tt = a.node(_module("nn.LinearNoBias", **_param_fields(P[f"{prefix}.attn.wa"])), ai[0])
+        mm1 = a.node(_module("nn.MM", transA=False, transB=False), ai[1], a.node(_module("nn.Replicate", nfeatures=1, dim=3, ndim=2), tt))
+        sm = a.node(_module("nn.SoftMax", name="softmax_attn"), a.node(_module("nn.Sum", dimension=3), mm1))
+        mm2 = a.node(_module("nn.MM", transA=False, transB=False), a.node(_module("nn.Replicate", nfeatures=1, dim=2, ndim=2), sm), ai[1])
+        join = a.node(_module("nn.JoinTable", dimension=2), a.node(_module("nn.Sum", dimension=2), mm2), ai[0])
+        a.node(_module("nn.Tanh"), a.node(_module("nn.LinearNoBias", **_param_fields(P[f"{prefix}.attn.wc"])), join))
+        attn = g.node(a.gmodule(2, "decoder_attn"), outputs[-1], inputs[1])
+        g.node(_module("nn.Dropout", p=float(dropout), train=True, v2=True, inplace=False), attn)
+    return g.gmodule(len(inputs))
+
+
+def build_reference_checkpoint(params: Dict[str, np.ndarray], bn_state: Dict[str, np.ndarray], config: dict, global_step: int,
+                               optim_state: dict) -> LuaTable:
+    """{ {cnn_model, encoder_fw, encoder_bw, decoder, output_projector}, config, global_step, optim_state } (model.lua:720-725) as a
+    t7 object tree; `params` / `bn_state` in Torch7 layouts under the names of aocr.Model.get_parameters / get_bn_state."""
+    P = params
+    He, Le, Ld = int(config["encoder_num_hidden"]), int(config["encoder_num_layers"]), int(config["decoder_num_layers"])
+    drop = float(config.get("dropout", 0.0))
+    seq = [_module("nn.AddConstant", constant_scalar=-128.0, inplace=False), _module("nn.MulConstant", constant_scalar=1.0 / 128, inplace=False)]   # cnn.lua:9-10
+    spec = {1: ("R", (2, 2)), 2: ("R", (2, 2)), 3: ("BR", None), 4: ("R", (1, 2)), 5: ("BR", None), 6: ("R", (1, 2)), 7: ("BR", None)}            # cnn.lua:12-42
+    for i in range(1, 8):
+        w = np.asarray(P[f"cnn.conv{i}.w"], np.float32)
+        k, pad = w.shape[2], (1 if i < 7 else 0)
+        seq.append(_module("cudnn.SpatialConvolution", **_param_fields(w, P[f"cnn.conv{i}.b"]), nOutputPlane=w.shape[0], nInputPlane=w.shape[1],
+                           kH=k, kW=k, dW=1, dH=1, padW=pad, padH=pad, groups=1))
+        acts, pool = spec[i]
+        for c in acts:
+            if c == "B":
+                seq.append(_module("nn.SpatialBatchNormalization", **_param_fields(P[f"cnn.bn{i}.w"], P[f"cnn.bn{i}.b"]),
+                                   running_mean=np.ascontiguousarray(np.asarray(bn_state[f"cnn.bn{i}.rm"], np.float32)),
+                                   running_var=np.ascontiguousarray(np.asarray(bn_state[f"cnn.bn{i}.rv"], np.float32)),
+                                   eps=1e-5, momentum=0.1, affine=True, train=True, nDim=4))
+            else:
+                seq.append(_module("cudnn.ReLU", inplace=True, mode="CUDNN_ACTIVATION_RELU"))
+        if pool:
+            seq.append(_module("cudnn.SpatialMaxPooling", kW=pool[0], kH=pool[1], dW=pool[0], dH=pool[1], padW=0, padH=0, ceil_mode=False))
+    seq.append(_module("nn.View", size=np.array([512, -1], np.int64), numElements=512, numInputDims=3))                                          # cnn.lua:44
+    seq.append(_module("nn.Transpose", permutations=LuaTable({1: LuaTable({1: 2, 2: 3})})))                                                     # cnn.lua:45
+    cnn = _module("nn.Sequential", modules=LuaTable((i, m) for i, m in enumerate(seq, 1)), train=True)
+    pre = bool(config.get("prealloc", False))
+    enc_fw = _lstm_net(P, "enc_fw", Le, He, drop, mem_name="encoder-fw" if pre else None)
+    enc_bw = _lstm_net(P, "enc_bw", Le, He, drop, mem_name="encoder-bw" if pre else None)
+    dec = _lstm_net(P, "dec", Ld, 2 * He, drop, attention=True, input_feed=bool(config.get("input_feed", False)), lookup=True,
+                    mem_name="decoder" if pre else None)
+    proj = _module("nn.Sequential", modules=LuaTable({1: _module("nn.Linear", **_param_fields(P["proj.w"], P["proj.b"])), 2: _module("nn.LogSoftMax")}),
+                   train=True)                                    # output_projector.lua:3-8
+    cfg = LuaTable((k, config[k]) for k in CONFIG_KEYS if k in config)
+    cfg.setdefault("decoder_num_hidden", 2 * He)
+    return LuaTable({1: LuaTable({1: cnn, 2: enc_fw, 3: enc_bw, 4: dec, 5: proj}), 2: cfg, 3: int(global_step), 4: LuaTable(optim_state)})
+
+
+def write_reference_checkpoint(path: str, params, bn_state, config: dict, global_step: int, optim_state: dict, cuda: bool = False):
+    """`model:save(path)` of the reference (model.lua:720-725) from Python.  cuda=True writes torch.CudaTensor class names, which is
+    what a checkpoint saved from the reference's GPU run carries (and what a reference WITHOUT cutorch cannot read back)."""
+    t7.save(path, build_reference_checkpoint(params, bn_state, config, global_step, optim_state), cuda=cuda)
 
 
 def write_flat_checkpoint(path: str, params: Dict[str, np.ndarray], bn_state: Dict[str, np.ndarray], config: dict, global_step: int,

@@ -499,17 +499,19 @@ class Model:
             self.visualize = False
             self.visualize_file = None
 
-    def save(self, model_path):
-        """model:save, model.lua:720-725 ({nets, config, global_step, optim_state}); nets = the flat parameter vector.
-        A path ending in .t7 is written in Torch7 serialization instead (aocr.checkpoint.write_flat_checkpoint).
-        NOT readable by the reference's model:load (which expects the five serialized nn modules): the reference-format writer is
-        the Lua side of the boundary (lua/model.lua model:save, which keeps the reference's own nets as parameter containers).
+    def save(self, model_path, layout=None):
+        """model:save, model.lua:720-725 ({nets, config, global_step, optim_state}).
+        layout None: a torch.save file with the flat parameter vector (fast path for this package);  a path ending in .t7 is written
+        in Torch7 serialization: layout "reference" (default for .t7 since round 3) = the reference's own table with the five nets as
+        nn / nngraph object trees (aocr.checkpoint.write_reference_checkpoint: what model:load, model.lua:45-80, expects; unverified
+        against Torch7 -- see that module's header), layout "flat" = one plain table of named FloatTensors (write_flat_checkpoint).
         No collective happens here (train.lua saves from one process): under data parallelism WITHOUT synchronised BatchNorm the
         running statistics are rank-local -- every rank calls `sync_bn_state()` before rank 0 saves."""
-        if str(model_path).endswith(".t7"):
-            from .checkpoint import write_flat_checkpoint
-            write_flat_checkpoint(model_path, {k: v.numpy() for k, v in self.get_parameters().items()},
-                                  {k: v.numpy() for k, v in self.get_bn_state().items()}, self.config, self.global_step, self.optim_state)
+        if str(model_path).endswith(".t7") or layout in ("reference", "flat"):
+            from .checkpoint import write_flat_checkpoint, write_reference_checkpoint
+            writer = write_flat_checkpoint if layout == "flat" else write_reference_checkpoint
+            writer(model_path, {k: v.numpy() for k, v in self.get_parameters().items()},
+                   {k: v.numpy() for k, v in self.get_bn_state().items()}, self.config, self.global_step, self.optim_state)
             return
         torch.save({"params": self.params.detach().cpu(), "bn_state": self.bn_state.detach().cpu(), "config": self.config,
                     "global_step": self.global_step, "optim_state": dict(self.optim_state)}, model_path)
