@@ -25,16 +25,20 @@ WORKLOADS = {
     "c3": dict(B=256, W=256, L=24, He=256, Le=1, Ld=2, compute="bf16", name="32x256 crops, batch 256/GPU, VGG-7 + BiLSTM(256) + 2-layer attn decoder, L=24"),
     "c2": dict(B=64, W=100, L=24, He=256, Le=1, Ld=2, compute="f32", name="32x100 crops, batch 64/GPU, VGG-7 + BiLSTM(256) + 2-layer attn decoder, L=24"),
     "ref": dict(B=400, W=100, L=24, He=512, Le=1, Ld=2, compute="bf16", name="32x100 crops, batch 400/GPU, VGG-7 + BiLSTM(512) + 2-layer attn decoder (train.lua defaults), L=24"),
+    # BASELINE.json configs[4]: 128x1024 full-line strips (the CNN leaves 7 x 255 feature positions: T = 1785), 2-layer BiLSTM(512), beam-5 decode
+    "c5": dict(B=16, W=1024, H=128, L=24, He=512, Le=2, Ld=2, compute="bf16", beam=5, name="128x1024 strips, batch 16/GPU, VGG-7 + 2-layer BiLSTM(512) + 2-layer attn decoder, L=24, beam-5 decode"),
 }
 PEAK = {"bf16": 2500.0, "f32": 157.3}          # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0
 
 
-def flops(W, He, Le, Ld, L, E=20, V=39):
-    """Algorithmic forward FLOPs per image-line by family (2*M*N*K per contraction)."""
-    Hd, T = 2 * He, W // 4 - 1
-    conv1 = 2 * 9 * 64 * 32 * W
-    convs = 2 * (9 * 64 * 128 * 8 * W + 9 * 128 * 256 * 2 * W + 9 * 256 * 256 * 2 * W + 9 * 256 * 512 * W + 9 * 512 * 512 * W + 4 * 512 * 512 * T)
+def flops(W, He, Le, Ld, L, E=20, V=39, H=32):
+    """Algorithmic forward FLOPs per image-line by family (2*M*N*K per contraction).  H > 32 (strips): every map has
+    H / 32 times the rows, the 2x2 convolution leaves (H / 16 - 1) x (W / 4 - 1) feature positions."""
+    Hd, T = 2 * He, (H // 16 - 1) * (W // 4 - 1)
+    hs = H // 32
+    conv1 = 2 * 9 * 64 * 32 * W * hs
+    convs = 2 * (hs * (9 * 64 * 128 * 8 * W + 9 * 128 * 256 * 2 * W + 9 * 256 * 256 * 2 * W + 9 * 256 * 512 * W + 9 * 512 * 512 * W) + 4 * 512 * 512 * T)
     enc_in = 2 * T * sum(2 * (512 if l == 0 else He) * 4 * He for l in range(Le))        # hoisted input projections
     enc_rec = 2 * T * Le * 2 * He * 4 * He                                                # recurrent h . W_h2h
     dec_emb = L * 2 * E * 4 * Hd                                                          # hoisted embedding part of layer 1
@@ -168,15 +172,16 @@ def main():
     global_B = wl["B"] * world if args.scaling == "weak" else wl["B"]
     assert global_B % world == 0, "strong scaling needs the global batch to divide by the rank count"
     B, W, L = global_B // world, wl["W"], wl["L"]
+    IMG_H, BEAM = wl.get("H", 32), wl.get("beam", 1)
     m = aocr.Model().create(dict(encoder_num_hidden=wl["He"], encoder_num_layers=wl["Le"], decoder_num_layers=wl["Ld"],
-                                 input_feed=True, batch_size=B, max_img_w=W, max_decoder_l=50, max_beam=1,
+                                 input_feed=True, batch_size=B, img_h=IMG_H, max_img_w=W, max_decoder_l=50, max_beam=BEAM,
                                  compute=wl["compute"], learning_rate=0.1, seed=910820))
     rccl_ranks = None
     if world > 1:
         dist.broadcast(m.params, 0); dist.broadcast(m.bn_state, 0)       # identical replicas (parameters and running statistics)
         probe = torch.ones(1, device=m.device); dist.all_reduce(probe)   # an actual collective: how many ranks does it span?
         rccl_ranks = int(probe.item())
-    img, tgt, tge, nnz = aocr.synth.synth_batch(B, W, seed=1234 + rank, max_len=L - 1)
+    img, tgt, tge, nnz = aocr.synth.synth_batch(B, W, seed=1234 + rank, max_len=L - 1, H=IMG_H)
     dev = m.device
     images = torch.from_numpy(img).to(device=dev, dtype=torch.float32)
     targets = torch.from_numpy(tgt).to(dev); targets_eval = torch.from_numpy(tge).to(dev)
@@ -243,7 +248,7 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX); dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         replica_drift = float((hi - lo).item())
 
-    fl = flops(W, wl["He"], wl["Le"], wl["Ld"], L)
+    fl = flops(W, wl["He"], wl["Le"], wl["Ld"], L, H=IMG_H)
     peak = PEAK[wl["compute"]]
     # ---- per-family HIP-event timing of one step (library marks, include/aocr.h AOCR_PROF_*).  EVERY rank runs the profiled steps (a step
     # contains the gradient all-reduce and the synchronised BatchNorm sums: a rank that skipped them would leave the others waiting);
@@ -272,17 +277,17 @@ def main():
     # ---- decode throughput (greedy, max_decoder_l = 50 steps + gold pass = the reference's -phase test step), no exchange across ranks
     dec = None; dec_dict = None
     if args.decode_steps > 0:
-        m.decode_device(images, targets, targets_eval, 1); sync()
+        m.decode_device(images, targets, targets_eval, BEAM); sync()
         t0 = time.perf_counter()
         for _ in range(args.decode_steps):
-            m.decode_device(images, targets, targets_eval, 1)
+            m.decode_device(images, targets, targets_eval, BEAM)
         sync()
         eld = (time.perf_counter() - t0) / args.decode_steps
-        Hd, T = 2 * wl["He"], W // 4 - 1
+        Hd, T = 2 * wl["He"], (IMG_H // 16 - 1) * (W // 4 - 1)
         dec = {"chars_per_s": world * B * 50 / eld, "what": "decoder steps/s: B*50 per call = one -phase test call of the reference, beam pass over max_decoder_l = 50 steps + gold pass (model.lua:376-627; the gold pass runs the steps the targets span -- its all-PAD steps add nothing to any output)",
-               "emitted_chars_per_s": world * nnz / eld, "ms_per_call": 1e3 * eld}
+               "emitted_chars_per_s": world * nnz / eld, "ms_per_call": 1e3 * eld, "beam": BEAM}
         if rank == 0:
-            fam = m.profile_families(lambda: m.decode_device(images, targets, targets_eval, 1), repeats=2)
+            fam = m.profile_families(lambda: m.decode_device(images, targets, targets_eval, BEAM), repeats=2)
             chain = fam["decode_chain"]; gold = fam["decoder_fwd"] + fam["rnn_gemm"]
             wbytes = 2 * (sum((Hd + Hd) * 4 * Hd for _ in range(wl["Ld"])) + Hd * Hd + 2 * Hd * Hd) + 4 * 39 * Hd   # bf16 recurrent weights + fp32 projector
             sbytes = B * T * Hd * 2 + B * Hd * 4 * (4 * wl["Ld"] + 6)                                                # context (bf16) + state rows
@@ -300,7 +305,7 @@ def main():
                         "ONE launch of the decoder cluster kernel (weights resident in registers, so these bytes are not streamed at all); a step is "
                         "bound by its five in-XCD exchanges (~1.7 us each) and the context stream.  Otherwise: 6 dependent launches per step"}
         # the same step under -use_dictionary: a synthetic 90 k-word lexicon as a device-resident flat trie
-        if not args.no_secondary:
+        if not args.no_secondary and BEAM == 1:
             rng = np.random.default_rng(1234)
             lens = rng.integers(3, 11, size=90000)
             letters = rng.integers(0, 26, size=int(lens.sum())).astype(np.uint8) + 97
@@ -400,7 +405,7 @@ def main():
             "metric": "image-lines/sec (train step)", "value": lines_per_s, "unit": "image-lines/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
             "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {wl['name']}", "global_batch": global_B, "per_gpu_batch": B, "img": f"32x{W}",
+            "config": {"workload": f"{args.workload}: {wl['name']}", "global_batch": global_B, "per_gpu_batch": B, "img": f"{IMG_H}x{W}",
                        "decoder_steps": L, "parallelism": f"dp{world}", "input_feed": True},
             "scaling_measured": world > 1, "rccl_ranks": rccl_ranks, "cluster_fallback": cluster_fallback,
             "step_ms_events": {"median": float(np.median(per_step)), "p10": float(np.percentile(per_step, 10)),

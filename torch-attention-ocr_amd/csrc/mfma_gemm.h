@@ -503,6 +503,7 @@ template <> struct SrcBf16<LoadConvXcolh> { static constexpr bool v = true; };
 template <> struct SrcBf16<LoadKh2> { static constexpr bool v = true; };
 
 constexpr int LDS_PITCH = 80;             // bytes per 32-k row of bf16 (64) + 16 pad
+constexpr int LDS_PITCH32 = 144;          // bytes per 32-k row of fp32 (128) + 16 pad: 36 dwords, so 16 rows distinct mod 16 hit 16 different 4-bank slots
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -535,6 +536,14 @@ template <class LD> struct Stager<LD, 32, true, false> {
       *reinterpret_cast<bf16x8*>(tile + row[i] * LDS_PITCH + chunk * 16) = v;
     }
   }
+  __device__ __forceinline__ void store32(unsigned char* tile) const {          // exact-fp32 image (gemm_lds_f32_kernel): 144-byte rows
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4* d = reinterpret_cast<float4*>(tile + row[i] * LDS_PITCH32 + chunk * 32);
+      d[0] = make_float4(reg[i].v[0], reg[i].v[1], reg[i].v[2], reg[i].v[3]);
+      d[1] = make_float4(reg[i].v[4], reg[i].v[5], reg[i].v[6], reg[i].v[7]);
+    }
+  }
 };
 
 // M/N-contiguous operand: one 4-row x 4-k micro-block per thread, loaded as 4 dwordx4 along the contiguous
@@ -560,6 +569,11 @@ template <class LD> struct Stager<LD, 32, false, false> {
       for (int kk = 0; kk < 4; ++kk) v[kk] = (__bf16)reg[kk][j];
       *reinterpret_cast<bf16x4*>(tile + (row4 + j) * LDS_PITCH + k4 * 2) = v;
     }
+  }
+  __device__ __forceinline__ void store32(unsigned char* tile) const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(tile + (row4 + j) * LDS_PITCH32 + k4 * 4) = make_float4(reg[0][j], reg[1][j], reg[2][j], reg[3][j]);
   }
 };
 
@@ -700,6 +714,83 @@ __device__ __forceinline__ void lds_tile(const AL& a, const BL& b, const EP& ep,
         for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * q + i];
       ep.template quad<2>(m0 + 32 * mi + 8 * q + 4 * h, n0 + r, 32, v);
     }
+}
+
+// ---------------------------------------------------------------------------
+// LDS-tiled EXACT-fp32 kernel (fp32 compute mode: BASELINE configs[1], the 1e-4 logit-parity configuration).  Same 128 x 128 x 32
+// block tile and staging as lds_tile, the LDS image kept in fp32 (144-byte rows), v_mfma_f32_32x32x2_f32 in the k order of
+// gemm_big_kernel<false> (lane (r, h) holds k = 8 c + 4 h + s of chunk c, MFMA s = 0..3), so the results are bit-identical to that
+// kernel's.  gemm_big_kernel<false> loads every fragment straight from global memory -- 16 bytes of 32 different rows per wave
+// instruction and no reuse between the two waves that share an operand: 0.29 of the fp32 MFMA peak on the conv layers at C2; here a
+// tile is fetched once per workgroup with whole 128-byte lines and the fp32 MFMA (64 cycles each) hides the LDS traffic easily.
+// ---------------------------------------------------------------------------
+template <class AL, class BL, class EP>
+__device__ __forceinline__ void lds_tile_f32(const AL& a, const BL& b, const EP& ep, int m_blk, int n_blk, int kbeg, int kend,
+                                             unsigned char (&lds)[2][2][128 * LDS_PITCH32]) {
+  constexpr int PITCH = LDS_PITCH32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = (kend - kbeg + 31) / 32;
+  Stager<AL, 32> sa; Stager<BL, 32> sb;
+  sa.init(a, m_blk, tid, 0, kbeg); sb.init(b, n_blk, tid, 1, kbeg);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  if (nk > 0) { sa.load(a); sb.load(b); sa.store32(&lds[0][0][0]); sb.store32(&lds[0][1][0]); }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) { sa.load(a); sb.load(b); }            // tile kt+1: global -> registers while tile kt is multiplied
+    const unsigned char* la = &lds[buf][0][(wm * 64 + r) * PITCH + 16 * h];
+    const unsigned char* lb = &lds[buf][1][(wn * 64 + r) * PITCH + 16 * h];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float4 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const float4*>(la + i * 32 * PITCH + 32 * c);
+        bf[i] = *reinterpret_cast<const float4*>(lb + i * 32 * PITCH + 32 * c);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const float x = s == 0 ? af[mi].x : s == 1 ? af[mi].y : s == 2 ? af[mi].z : af[mi].w;
+            const float y = s == 0 ? bf[ni].x : s == 1 ? bf[ni].y : s == 2 ? bf[ni].z : bf[ni].w;
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[mi][ni], 0, 0, 0);
+          }
+    }
+    if (kt + 1 < nk) { sa.store32(&lds[buf ^ 1][0][0]); sb.store32(&lds[buf ^ 1][1][0]); }
+    __syncthreads();
+  }
+  const int m0 = m_blk + wm * 64, n0 = n_blk + wn * 64;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[2][4];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * q + i];
+      ep.template quad<2>(m0 + 32 * mi + 8 * q + 4 * h, n0 + r, 32, v);
+    }
+}
+template <class AL, class BL, class EP>
+__global__ __launch_bounds__(256, 2) void gemm_lds_f32_kernel(AL a, BL b, EP ep, int K, int kper, int gx, int gy) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][128 * LDS_PITCH32];        // 73.7 KB: two workgroups per CU
+  const int nwg = gx * gy, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int kbeg = blockIdx.z * kper;
+  lds_tile_f32(a, b, ep, (bid / gx) * 128, (bid % gx) * 128, kbeg, min(K, kbeg + kper), lds);
 }
 
 template <class AL, class BL, class EP, int BK = 32>
@@ -930,7 +1021,11 @@ void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t
 // whose im2col stream is 4-9x their weight stream: there the halo cuts the L2 -> LDS bytes per step from 32 + 8 KB to 6 + 8 KB.
 template <int MT> struct HaloGeom { static constexpr int HMAX = MT == 256 ? 36864 : 55296; };   // one halo buffer: (R + 2) (W + 16) 64 B for W in {32, 64, 128}
 
-template <class EP, int SGN, int MT, int NT, int TAG = 0>          // TAG: distinct symbol for aocr_profile_kernel's launches (their own row in rocprofv3 --stats)
+// LW (round 3): only waves 0-3 -- one per SIMD -- issue the LDS-DMA pieces of a step (6 each: two halo pieces, four weight pieces); their
+// SIMD partners 4-7 issue none.  A DMA instruction holds its wave's instruction stream for 100-185 cycles; with every wave issuing its
+// three pieces right behind the step's barrier, both waves of a SIMD sit in DMA issue at the same time and the MFMA pipe idles.  With
+// the pieces on ONE wave per SIMD the partner multiplies meanwhile.
+template <class EP, int SGN, int MT, int NT, int TAG = 0, bool LW = false>          // TAG: distinct symbol for aocr_profile_kernel's launches (their own row in rocprofv3 --stats)
 __global__ __launch_bounds__(512, 1)
 void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const bf16_t* zero) {
   constexpr int HMAX = HaloGeom<MT>::HMAX, BSLOT = NT * 64, BRING = 2 * HMAX, DUMP = BRING + 4 * BSLOT, LDS_BYTES = DUMP + 8 * 1024;
@@ -973,11 +1068,13 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
   for (int s2 = 0; s2 < 2; ++s2) boff[s2] = BRING + (wn * 64 + r) * 64 + (((2 * s2 + h) ^ swzb) << 4);
 
   // ---- weight staging (as in gemm_dma_bf16_kernel): rows (tid >> 2) + 128 j, position tid & 3 holds k-chunk (tid & 3) ^ ((tid >> 4) & 3)
+  static_assert(!LW || NT == 256, "loader-wave form: 256-column tiles");
   const int srow = tid >> 2, bchunk = (tid & 3) ^ ((tid >> 4) & 3);
-  const bool bwave = NT >= 128 || wave < 4;              // NT = 64: rows 0..63 are waves 0-3
-  LoadKh::DRow rb[NBW];
+  const bool bwave = LW ? wave < 4 : (NT >= 128 || wave < 4);              // NT = 64: rows 0..63 are waves 0-3
+  constexpr int NBJ = LW ? 4 : NBW, BSTEP = LW ? 64 : 128;                 // LW: thread t < 256 stages rows (t >> 2) + 64 j, j < 4
+  LoadKh::DRow rb[NBJ];
 #pragma unroll
-  for (int j = 0; j < NBW; ++j) rb[j] = b.drow(n_blk + 128 * j + srow, bchunk);
+  for (int j = 0; j < NBJ; ++j) rb[j] = b.drow(n_blk + BSTEP * j + srow, bchunk);
   unsigned char* const wbase = lds + wave * 1024;
   // ---- halo staging: group gq = 16 pixels of one halo row; lane -> pixel (lane >> 2), position lane & 3
   const int hx = (lane >> 2) - 1, hchunk = (lane & 3) ^ ((lane >> 4) & 3);
@@ -991,10 +1088,17 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
   auto issue_b = [&](int step) {                         // weight tile of K step `step` (chunk-major): k = tap * C + 32 chunk
     const int chunk = step / 9, tap = step - chunk * 9;
     const int k = step < NT9 ? tap * C + (chunk << 5) : b.K;           // past the end: zero page
+    if constexpr (LW) {
+      if (wave < 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(dma_select(rb[j].b != nullptr && k < b.K, rb[j].b + k, zero), wbase + BRING + (step & 3) * BSLOT + j * 4096);
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < NBW; ++j)
       dma16(dma_select(bwave && rb[j].b != nullptr && k < b.K, rb[j].b + k, zero),
             bwave ? wbase + BRING + (step & 3) * BSLOT + j * 8192 : lds + DUMP + wave * 1024);
+    }
   };
 
   f32x16 acc[MI][2];
@@ -1006,7 +1110,7 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // prologue: the whole halo of chunk 0 and three weight tiles, all landed before the first step
-  for (int gq = wave; gq < NG; gq += 8) issue_halo(gq, 0, true);
+  for (int gq = wave; gq < NG; gq += 8) issue_halo(gq, 0, true);        // (the prologue's halo is staged by all eight waves in both forms)
   issue_b(0); issue_b(1); issue_b(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -1020,7 +1124,8 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
       for (int kw = 0; kw < 3; ++kw, ++step) {
         const int dxi = SGN > 0 ? kw : 2 - kw;
         // this wave's pieces of this step's weight tile (and of everything older) have landed: 2 steps x (1 + NBW) pieces may be pending
-        if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (LW) { if (wave < 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }          // 2 steps x 6 pieces of a loader wave may be pending
+        else if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // ... everyone's have, and everyone is done reading the previous step
         const unsigned char* Lb = lds + (step & 3) * BSLOT;
         bf16x8 af[2][MI], bf[2][2];
@@ -1034,7 +1139,12 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) bf[s2][ni] = *reinterpret_cast<const bf16x8*>(Lb + boff[s2] + ni * 2048);
-        {                                                 // one piece of the NEXT chunk's halo (its buffer was last read a chunk ago)
+        if constexpr (LW) {                               // two pieces of the NEXT chunk's halo per loader wave
+          if (wave < 4) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int gq = (kh * 3 + kw) * 8 + wave + 4 * u; issue_halo(gq < NG ? gq : 0, chunk + 1, gq < NG && chunk + 1 < NC); }
+          }
+        } else {                                          // one piece of the NEXT chunk's halo (its buffer was last read a chunk ago)
           const int gq = (kh * 3 + kw) * 8 + wave;
           issue_halo(gq < NG ? gq : 0, chunk + 1, gq < NG && chunk + 1 < NC);
         }

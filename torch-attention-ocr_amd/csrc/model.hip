@@ -789,7 +789,8 @@ static bool side_stream_on(aocr_model* m) {
   if (m->prof_on || !m->bf16 || getenv("AOCR_NO_SIDE_WGRAD")) return false;
   if (!m->side) {
     int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);            // lo = numerically greatest = lowest priority
-    if (hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, lo) != hipSuccess) { m->side = nullptr; return false; }
+    const hipError_t e = getenv("AOCR_SIDE_PLAIN") ? hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) : hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, lo);
+    if (e != hipSuccess) { m->side = nullptr; return false; }
     if (hipEventCreateWithFlags(&m->side_go, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&m->side_done, hipEventDisableTiming) != hipSuccess) return false;
   }
   return m->side_go && m->side_done;

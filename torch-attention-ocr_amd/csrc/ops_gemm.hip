@@ -64,6 +64,14 @@ static bool halo_eligible(const LoadConvK& g, int N, int MT, int NT) {
 template <int SGN, int MT, int NT, class EP>
 static void launch_halo(hipStream_t s, const LoadConvKh& a, const LoadKh& b, const EP& ep, int M, int N, int tag = 0) {
   const int gx = N / NT, gy = M / MT;
+  if constexpr (NT == 256) {
+    const char* lw = getenv("AOCR_HALO_LW");                  // A/B: LDS-DMA pieces issued by one wave per SIMD (see the kernel)
+    if (lw && lw[0] == '1') {
+      if (tag) hipLaunchKernelGGL((gemm_halo_bf16_kernel<EP, SGN, MT, NT, 1, true>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, gx, gy, zero_page());
+      else hipLaunchKernelGGL((gemm_halo_bf16_kernel<EP, SGN, MT, NT, 0, true>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, gx, gy, zero_page());
+      return;
+    }
+  }
   if (tag) hipLaunchKernelGGL((gemm_halo_bf16_kernel<EP, SGN, MT, NT, 1>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, gx, gy, zero_page());
   else hipLaunchKernelGGL((gemm_halo_bf16_kernel<EP, SGN, MT, NT>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, gx, gy, zero_page());
 }
@@ -81,6 +89,17 @@ template <class AL, class BL, class EP>
 static void launch_big(hipStream_t s, bool bf16, const AL& a, const BL& b, const EP& ep, int M, int N, int K, int ksplit) {
   if (M <= 0 || N <= 0) return;
   if (bf16) { launch_lds(s, a, b, ep, M, N, K, ksplit); return; }
+  // exact-fp32 mode: the LDS-tiled kernel for K-contiguous operand pairs (conv forward, conv data gradient over the re-laid taps,
+  // nn.Linear forward) wherever a 128 x 128 tile is mostly full: C2 conv forward 1.86 -> 1.35 ms, data gradient 2.46 -> 1.98 ms per step.
+  // The M/N-contiguous pairs (filter / weight gradients: transposing stagers, split-K) measured SLOWER on it (1.67 -> 1.85 ms) and keep
+  // the fragment-from-global kernel.  AOCR_NO_LDS_F32=1 restores that kernel everywhere (bit-identical results).
+  const bool no_lds32 = getenv("AOCR_NO_LDS_F32") != nullptr;          // read per call: tests toggle it
+  if (KContig<AL>::v && KContig<BL>::v && !no_lds32 && M >= 96 && N >= 64 && K >= 32) {
+    int kp; split_k(K, 32, ksplit, kp);
+    const int gx = cdiv(N, 128), gy = cdiv(M, 128);
+    hipLaunchKernelGGL((gemm_lds_f32_kernel<AL, BL, EP>), dim3(gx * gy, 1, ksplit), dim3(256), 0, s, a, b, ep, K, kp, gx, gy);
+    return;
+  }
   int kper; split_k(K, 8, ksplit, kper);
   hipLaunchKernelGGL((gemm_big_kernel<false, 2, 2, AL, BL, EP>), dim3(cdiv(N, 128), cdiv(M, 128), ksplit), dim3(256), 0, s, a, b, ep, K, kper);
 }
