@@ -256,3 +256,67 @@ def test_beam_select(cuda, kin, kout):
     assert torch.equal(tk.cpu().long(), toks), (tk.cpu(), toks)
     assert torch.equal(pr.cpu().long(), par)
     report("beam scores", bsd[:B * kout].reshape(B, kout), vals, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ round 3: the rest of the module surface
+@pytest.mark.parametrize("flag,fn", [(2, torch.relu), (4, torch.tanh)])
+def test_gemm_activation_flags(cuda, flag, fn):
+    """aocr_gemm's flag bits: 2 = ReLU, 4 = tanh on the result (nn.Tanh behind nn.LinearNoBias, LSTM.lua:155-157); 1 = accumulate."""
+    a = _lib()
+    M, N, K = 70, 96, 128
+    A = rnd(M, K, seed=1); Bm = rnd(N, K, seed=2)
+    Cd = torch.zeros(M, N, device="cuda")
+    a.check(a.lib.aocr_gemm(stream(), 0, a.ptr(dev(A)), K, 1, a.ptr(dev(Bm)), K, 1, a.ptr(Cd), N, M, N, K, None, flag))
+    report(f"gemm flag {flag}", Cd, fn(A @ Bm.t()), 2e-4)
+    a.check(a.lib.aocr_gemm(stream(), 0, a.ptr(dev(A)), K, 1, a.ptr(dev(Bm)), K, 1, a.ptr(Cd), N, M, N, K, None, 1))
+    report("gemm accumulate on top", Cd, fn(A @ Bm.t()) + A @ Bm.t(), 4e-4)
+    assert a.lib.aocr_gemm(stream(), 0, a.ptr(dev(A)), K, 1, a.ptr(dev(Bm)), K, 1, a.ptr(Cd), N, M, N, K, None, 5) != 0     # activation on an accumulating product: refused
+
+
+@pytest.mark.parametrize("n", [5, 4096, 100003])
+def test_pointwise(cuda, n):
+    a = _lib()
+    x = rnd(n, seed=1); y = rnd(n, seed=2)
+    out = torch.zeros(n, device="cuda")
+    for op, ref in ((0, x + y), (1, x * (1 - y * y)), (2, x * (y > 0)), (3, torch.relu(x))):
+        a.check(a.lib.aocr_pointwise(stream(), op, a.ptr(dev(x)), a.ptr(dev(y)) if op != 3 else None, a.ptr(out), n))
+        report(f"pointwise op {op} n={n}", out, ref, 1e-6)
+    buf = dev(x).clone()                                              # in place, from an address that is not 16-byte aligned
+    a.check(a.lib.aocr_pointwise(stream(), 0, C.c_void_p(buf.data_ptr() + 4), C.c_void_p(buf.data_ptr() + 4), C.c_void_p(buf.data_ptr() + 4), n - 1))
+    report("pointwise in place, unaligned", buf[1:], 2 * x[1:], 1e-6)
+
+
+def test_lookup_forward_backward(cuda):
+    """nn.LookupTable (LSTM.lua:55-56): gather of 1-based ids; accGradParameters = scatter-add of the output gradient rows."""
+    a = _lib()
+    V, E, n = 39, 20, 777
+    W = rnd(V, E, seed=1)
+    ids = torch.randint(1, V + 1, (n,), generator=torch.Generator().manual_seed(2), dtype=torch.int32)
+    out = torch.zeros(n, E, device="cuda")
+    a.check(a.lib.aocr_lookup_forward(stream(), a.ptr(dev(W)), a.ptr(dev(ids, torch.int32)), a.ptr(out), n, E))
+    report("lookup forward", out, W[ids.long() - 1].float(), 0.0)
+    g = rnd(n, E, seed=3)
+    dW = torch.zeros(V, E, device="cuda")
+    a.check(a.lib.aocr_lookup_backward(stream(), a.ptr(dev(g)), a.ptr(dev(ids, torch.int32)), a.ptr(dW), n, E, V))
+    ref = torch.zeros(V, E, dtype=torch.float64).index_add_(0, ids.long() - 1, g)
+    report("lookup backward", dW, ref, 1e-4)
+
+
+@pytest.mark.parametrize("B,H,inp", [(5, 32, 52), (33, 64, 532), (7, 16, 20)])
+def test_lstm_cell_forward_zx(cuda, B, H, inp):
+    """The cell with the input part pre-computed (input widths that are not multiples of 16: the decoder's first layer sees E + Hd
+    columns): zx = W_i2h x + b_i2h + b_h2h by aocr_gemm with the summed bias, then aocr_lstm_cell_forward_zx; against LSTM.lua:79-105."""
+    a = _lib()
+    x = rnd(B, inp, seed=1); hp = rnd(B, H, seed=2); cp = rnd(B, H, seed=3)
+    Wi = rnd(4 * H, inp, seed=4, scale=0.3); bi = rnd(4 * H, seed=5); Wh = rnd(4 * H, H, seed=6, scale=0.3); bh = rnd(4 * H, seed=7)
+    z = x @ Wi.t() + bi + hp @ Wh.t() + bh
+    i, f, o, g = (torch.sigmoid(z[:, k * H:(k + 1) * H]) if k < 3 else torch.tanh(z[:, k * H:(k + 1) * H]) for k in range(4))
+    c_ref = f * cp + i * g; h_ref = o * torch.tanh(c_ref)
+    bsum = torch.zeros(4 * H, device="cuda"); zx = torch.zeros(B, 4 * H, device="cuda")
+    a.check(a.lib.aocr_pointwise(stream(), 0, a.ptr(dev(bi)), a.ptr(dev(bh)), a.ptr(bsum), 4 * H))
+    a.check(a.lib.aocr_gemm(stream(), 0, a.ptr(dev(x)), inp, 1, a.ptr(dev(Wi)), inp, 1, a.ptr(zx), 4 * H, B, 4 * H, inp, a.ptr(bsum), 0))
+    c = torch.zeros(B, H, device="cuda"); h = torch.zeros(B, H, device="cuda"); gates = torch.zeros(B, 4 * H, device="cuda")
+    a.check(a.lib.aocr_lstm_cell_forward_zx(stream(), 0, a.ptr(zx), 4 * H, a.ptr(dev(hp)), a.ptr(dev(cp)), a.ptr(dev(Wh)), a.ptr(c), a.ptr(h), a.ptr(gates), B, H))
+    report(f"lstm cell zx c B={B} H={H} in={inp}", c, c_ref, 2e-5)
+    report(f"lstm cell zx h B={B} H={H} in={inp}", h, h_ref, 2e-5)
+    report("lstm cell zx gates", gates, torch.cat([i, f, o, g], 1), 2e-5)

@@ -453,9 +453,47 @@ def test_dropout_train_step_vs_oracle(cuda, case, p):
     m.shutdown()
 
 
+@pytest.mark.parametrize("p,B,W,maxlen", [(0.25, 45, 52, 5), (0.5, 32, 72, 6), (0.1, 70, 100, 9)])
+def test_dropout_cluster_kernels_match_launch_chain(cuda, monkeypatch, p, B, W, maxlen):
+    """nn.Dropout(p > 0) inside the decoder cluster kernels (round 3: the masks of LSTM.lua:68-69,116-118 are evaluated in the gate /
+    attention epilogues of dec_cl_fwd_kernel<false, true> and dec_cl_bwd_kernel<true>) against the per-step launch chain
+    (AOCR_NO_DEC_CLUSTER_DROP=1) under the SAME counter-based masks: loss, logits, d(context) and every gradient tensor."""
+    cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for knob in ("cluster", "chain"):
+        monkeypatch.delenv("AOCR_NO_DEC_CLUSTER_DROP", raising=False)
+        if knob == "chain":
+            monkeypatch.setenv("AOCR_NO_DEC_CLUSTER_DROP", "1")
+        monkeypatch.setenv("AOCR_TRACE", "1")
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=maxlen, compute="bf16", max_decoder_l=maxlen + 1, max_beam=1)
+        m.dropout = p; m.global_step = 11
+        loss = m.train_forward_backward(batch)
+        assert int(m.get_tensor("cl_err").view(torch.int32)[0]) == 0
+        out[knob] = dict(loss=loss, logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), dctx=m.get_tensor("dcontext").clone(),
+                         grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.global_step = 12
+        out[knob]["loss2"] = m.train_forward_backward(batch)      # another step: another mask
+        m.shutdown()
+    a, b = out["chain"], out["cluster"]
+    e = (a["logits"].double() - b["logits"].double()).abs().max().item()
+    r = relerr(b["dctx"], a["dctx"])
+    print(f"[parity] dropout p={p} cluster vs chain B={B} W={W}: logits max-abs {e:.3e}, d(context) rel {r:.3e}, loss {b['loss']:.5f} vs {a['loss']:.5f}")
+    assert e < 2e-2 and r < 3e-2
+    assert abs(a["loss"] - b["loss"]) < 2e-3 * max(1.0, abs(a["loss"])) and abs(a["loss2"] - b["loss2"]) < 2e-3 * max(1.0, abs(a["loss2"]))
+    assert abs(a["loss"] - a["loss2"]) > 1e-4                     # the mask depends on the step
+    worst = ("", 0.0)
+    for k in a["grads"]:
+        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):
+            continue
+        x = relerr(b["grads"][k], a["grads"][k])
+        if x > worst[1]: worst = (k, x)
+        assert x < 4e-2, (k, x)
+    print(f"[parity] dropout cluster vs chain: worst gradient rel {worst[1]:.3e} ({worst[0]})")
+
+
 def test_dropout_bf16_cluster_shape(cuda):
-    """Dropout at the shape the decoder cluster kernels serve (Hd = 512, bf16): the step falls back to the launch chain with masked bf16
-    copies of the layer inputs; loss against the fp64 oracle within the bf16 tolerance, the decoder's gradients by cosine."""
+    """Dropout at the shape the decoder cluster kernels serve (Hd = 512, bf16; since round 3 THROUGH those kernels): loss against the
+    fp64 oracle within the bf16 tolerance, the decoder's gradients by cosine."""
     case = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
     m, O, ocfg, P, st, batch = make(case, B=6, W=52, maxlen=5, compute="bf16", max_decoder_l=8, max_beam=1)
     img, tgt, tge = (torch.from_numpy(np.asarray(x)) for x in batch[:3])

@@ -219,8 +219,14 @@ __device__ __forceinline__ void raise_and_wait(unsigned* flags, unsigned tag, in
 // t+1 is the arg-max of step t -- the projector + LogSoftMax + selection of project_select_kernel run inside the loop: every member
 // multiplies its 16 fp32 units of out(t) with its slice of W_o, the partial logits of row r meet on member r (one more exchange),
 // which selects, keeps the running score, writes the label and publishes the token with its next out(t) flag.
-template <bool DEC>
+// DROP: nn.Dropout(p > 0) of the training step (LSTM.lua:68-69: layer 2 reads Dropout(h1); :116-118: Dropout on the attention output).
+// The masks are the counter-based function of epilogues.h::DropSpec the launch chain uses (same sites, same indices).  h1(t) is
+// published twice -- as it is (the recurrence of layer 1 reads it at step t+1) and masked (hm_b: the operand of layer 2, gathered into
+// the H1 buffer; H1 is re-fetched unmasked at the start of the next step) --, out(t) only masked (projector, input feed and the
+// backward kernel all see Dropout(out); the backward kernel divides the mask out again for tanh').
+template <bool DEC, bool DROP = false>
 __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
+  static_assert(!(DEC && DROP), "evaluate(): no dropout in decode");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const F = lds;                        // feed (out(t-1)), later c(t)
   unsigned char* const H1 = lds + R * PA;              // h1(t-1), later h1(t)
@@ -336,7 +342,8 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
     }
   };
   // LSTM cell on this lane's (unit, row) pairs; returns the packed h of the four units of (row, wave) in lanes q == 0
-  auto cell = [&](const f32x4 (&z)[2], float (&c)[2], f32x4 (&g)[2], u32x2 (&hp)[2]) {
+  u32x2 hpm[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};                    // DROP: Dropout(h1) of this lane's cells, packed like hp
+  auto cell = [&](const f32x4 (&z)[2], float (&c)[2], f32x4 (&g)[2], u32x2 (&hp)[2], long long moff = -1) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const float ig = sigmoidf_(z[rt][0]), fg = sigmoidf_(z[rt][1]), og = sigmoidf_(z[rt][2]), gg = tanhf_(z[rt][3]);
@@ -345,6 +352,14 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
       const unsigned hb = bfbits(hn);
       const unsigned h1v = __shfl(hb, lane + 16, 64), h2v = __shfl(hb, lane + 32, 64), h3v = __shfl(hb, lane + 48, 64);
       hp[rt] = u32x2{hb | (h1v << 16), h2v | (h3v << 16)};
+      if constexpr (DROP) {
+        if (moff >= 0) {                                              // mask index = step offset + row * Hd + unit (EpGatesFwd::drop)
+          DropSpec d = p.drop_h; d.off = moff;
+          const unsigned mb = bfbits(hn * d.mask((long long)(row0 + 16 * rt + c16) * HD + unit));
+          const unsigned m1 = __shfl(mb, lane + 16, 64), m2 = __shfl(mb, lane + 32, 64), m3 = __shfl(mb, lane + 48, 64);
+          hpm[rt] = u32x2{mb | (m1 << 16), m2 | (m3 << 16)};
+        }
+      }
     }
   };
   // deferred stores of one LSTM layer (4 instructions; 6 with the [c ; h] shadow of the top layer); the bf16 h is the exchange payload
@@ -388,6 +403,9 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
                 [&] { store_out(ot, t - 1); }, gs, p.stamps != nullptr, tl0);
       if (s_dead) break;
     }
+    if constexpr (DROP) {                           // H1 holds Dropout(h1(t-1)) (layer 2's operand): layer 1's recurrence needs h1(t-1) itself
+      if (t > 0) fetch_rows<1, 0>(p.hsb[0] + (size_t)t * slot, HD * 2, row0, B, H1, PA, ot, member, local, [] {});      // (all 128 flags of h1(t-1) were seen a step ago)
+    }
     unsigned tk = 0;
     if constexpr (DEC) {                            // the tokens chosen at step t-1 (published before the owners' out flags): the load is
       if (t > 0 && wave == 0) {                     // issued here and consumed AFTER the layer-1 products, which do not depend on it
@@ -424,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) z[rt][i] += zxr[rt][i];
-      cell(z, c1, g1, hp1);
+      cell(z, c1, g1, hp1, DROP ? (long long)t * (long long)slot : -1);
     }
     DC_STAMP(1);
     // =================== layer 2: z2 = [h1(t) ; h2(t-1)] W2^T + b
@@ -435,8 +453,17 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
         pst8(oq == 0 && row < B ? (void*)(p.hsb[l] + (size_t)(t + 1) * slot + (size_t)row * HD + 16 * member + 4 * wave) : (void*)otrash, hp[rt], local);
       }
     };
-    gather<4>(xg + 1 * NM * 128, tagc + 1024u, p.hsb[0] + (size_t)(t + 1) * slot, HD * 2, row0, B, H1, ot, wave, member, local, p.err, 12, &s_dead,
-              [&] { publish_h(0, hp1); }, [&] { store_layer(ot, 0, t, g1, c1, hp1, false); }, gs, p.stamps != nullptr, tl0 ? tl0 + 16 : nullptr);
+    gather<4>(xg + 1 * NM * 128, tagc + 1024u, DROP ? p.hm_b + (size_t)t * slot : p.hsb[0] + (size_t)(t + 1) * slot, HD * 2, row0, B, H1, ot, wave, member, local, p.err, 12, &s_dead,
+              [&] {
+                publish_h(0, hp1);
+                if constexpr (DROP) {
+#pragma unroll
+                  for (int rt = 0; rt < 2; ++rt) {
+                    const int row = row0 + 16 * rt + oc16;
+                    pst8(oq == 0 && row < B ? (void*)(p.hm_b + (size_t)t * slot + (size_t)row * HD + 16 * member + 4 * wave) : (void*)otrash, hpm[rt], local);
+                  }
+                }
+              }, [&] { store_layer(ot, 0, t, g1, c1, hp1, false); }, gs, p.stamps != nullptr, tl0 ? tl0 + 16 : nullptr);
     if (s_dead) break;
     DC_STAMP(2);
     f32x4 g2[2]; u32x2 hp2[2];
@@ -558,6 +585,11 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
         for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(red + ((w * 2 + wave) * 64 + lane) * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = tanhf_(v[i]);
+        if constexpr (DROP) {                                      // Dropout on the attention output (LSTM.lua:116-118): idx = row * Hd + column, step offset t * B * Hd
+          DropSpec d = p.drop_out; d.off = (long long)t * (long long)slot;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] *= d.mask((long long)(row0 + 16 * wave + c16) * HD + 16 * member + 4 * q + i);
+        }
         ov = v; ovb = u32x2{bfpair(v[0], v[1]), bfpair(v[2], v[3])};         // published behind the polls of the next step's first gather
         if constexpr (DEC) *reinterpret_cast<f32x4*>(outs + (16 * wave + c16) * 16 + 4 * q) = v;
       }
@@ -653,6 +685,7 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
 constexpr int PZ = 4096 + 16;                                      // LDS pitch of a d z operand row (2048 bf16)
 constexpr int BWD_LDS_BYTES = R * PZ + 16384 + 4096;               // operand (d pre / d q alias its start) + partial tiles + attention scratch
 
+template <bool DROP = false>                                        // DROP: the forward kernel ran with nn.Dropout(p > 0) (masked attention output, masked layer-2 input)
 __global__ __launch_bounds__(256, 1) void dec_cl_bwd_kernel(DecClBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const X = lds;                                     // [32][PA]: d pre, later d q;  [32][PZ]: d z2, later d z1
@@ -771,8 +804,18 @@ __global__ __launch_bounds__(256, 1) void dec_cl_bwd_kernel(DecClBwdArgs p) {
     // =================== d pre
     f32x4 dpre = {0.f, 0.f, 0.f, 0.f};
     if (wave < 2) {
+      if constexpr (DROP) {                                         // `out` holds Dropout(tanh): the gradient passes the mask, tanh' needs the unmasked value (dpre_kernel)
+        DropSpec d = p.drop_out; d.off = (long long)t * (long long)slot;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float mk = d.mask((long long)erow * HD + 16 * member + 4 * oq + i);
+          const float o = mk != 0.f ? on[i] / mk : 0.f;
+          dpre[i] = (dpn[i] + dfeed[i]) * mk * (1.f - o * o);
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) dpre[i] = (dpn[i] + dfeed[i]) * (1.f - on[i] * on[i]);
+      }
     }
     raise_and_wait(xg + 0 * NM * 128, tagc, ot, wave, member, local, p.err, 21, &s_dead,
                    [&] { pst8(eok ? (void*)(p.dpre_b + (size_t)t * slot + eoff) : (void*)otrash, u32x2{bfpair(dpre[0], dpre[1]), bfpair(dpre[2], dpre[3])}, local); });
@@ -938,7 +981,15 @@ __global__ __launch_bounds__(256, 1) void dec_cl_bwd_kernel(DecClBwdArgs p) {
     {
       f32x4 v[2];
       zprod(wz[0], wz[1], v);                                               // d z2 W2_i2h (-> d h1), d z2 W2_h2h (-> d h2rec of step t-1)
-      if (wave < 2) { dh2rec = v[1]; const f32x4 dh1 = v[0] + dh1rec; CellIn ci; cell_load(ot, 0, t, ci); cell_bwd(ci, dh1, dc1, dz); }
+      if (wave < 2) {
+        dh2rec = v[1];
+        if constexpr (DROP) {                                       // layer 2 read Dropout(h1): its input gradient passes the mask (EpGatesBwd::drop)
+          DropSpec d = p.drop_h; d.off = (long long)t * (long long)slot;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[0][i] *= d.mask((long long)erow * HD + 16 * member + 4 * oq + i);
+        }
+        const f32x4 dh1 = v[0] + dh1rec; CellIn ci; cell_load(ot, 0, t, ci); cell_bwd(ci, dh1, dc1, dz);
+      }
     }
     DC_STAMP(10);
     raise_and_wait(xg + 4 * NM * 128, tagc + 2048u, ot, wave, member, local, p.err, 26, &s_dead, [&] { dz_payload(0); });
@@ -983,11 +1034,13 @@ bool dec_cluster_bwd_supported(int Hd, int Ld, int input_feed, int T, int L, int
 void dec_cluster_backward(hipStream_t s, const DecClBwdArgs& a0) {
   static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
   const int groups = (a0.B + R - 1) / R, per_pass = std::max(8, cus / (8 * NM) * 8);
-  (void)hipFuncSetAttribute((const void*)dec_cl_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES);
+  (void)hipFuncSetAttribute((const void*)dec_cl_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES);
+  (void)hipFuncSetAttribute((const void*)dec_cl_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES);
   for (int g0 = 0; g0 < groups; g0 += per_pass) {
     DecClBwdArgs a = a0; a.group0 = g0; a.ngroups = std::min(per_pass, groups - g0); a.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;
     a.stamps = getenv("AOCR_DC_STAMPS") ? a.xtab + (size_t)groups * NM + 16 : nullptr;   // debugging aid (-DDC_DEBUG_STAMPS): cycles per phase of workgroup 0
-    hipLaunchKernelGGL(dec_cl_bwd_kernel, dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), (size_t)BWD_LDS_BYTES, s, a);
+    if (a.drop_h.thr != 0 || a.drop_out.thr != 0) hipLaunchKernelGGL(dec_cl_bwd_kernel<true>, dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), (size_t)BWD_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL(dec_cl_bwd_kernel<false>, dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), (size_t)BWD_LDS_BYTES, s, a);
   }
 }
 
@@ -997,10 +1050,12 @@ void dec_cluster_forward(hipStream_t s, const DecClFwdArgs& a0, bool greedy_deco
   const size_t lds = LDS_BYTES;
   (void)hipFuncSetAttribute((const void*)dec_cl_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)hipFuncSetAttribute((const void*)dec_cl_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)dec_cl_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   for (int g0 = 0; g0 < groups; g0 += per_pass) {
     DecClFwdArgs a = a0; a.group0 = g0; a.ngroups = std::min(per_pass, groups - g0); a.force_remote = getenv("AOCR_CL_REMOTE") != nullptr; a.no_early = getenv("AOCR_NO_DEC_EARLY") != nullptr;
     a.stamps = getenv("AOCR_DC_STAMPS") ? a.xtab + (size_t)groups * NM : nullptr;   // debugging aid: cycles per phase of workgroup 0
     if (greedy_decode) { a.tokx = reinterpret_cast<unsigned*>(a.pbuf + (size_t)groups * 32 * 32 * 40); hipLaunchKernelGGL(dec_cl_fwd_kernel<true>, dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), lds, s, a); }
+    else if (a.drop_h.thr != 0 || a.drop_out.thr != 0) hipLaunchKernelGGL((dec_cl_fwd_kernel<false, true>), dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(dec_cl_fwd_kernel<false>, dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), lds, s, a);
   }
 }

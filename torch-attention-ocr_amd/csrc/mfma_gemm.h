@@ -1021,11 +1021,14 @@ void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t
 // whose im2col stream is 4-9x their weight stream: there the halo cuts the L2 -> LDS bytes per step from 32 + 8 KB to 6 + 8 KB.
 template <int MT> struct HaloGeom { static constexpr int HMAX = MT == 256 ? 36864 : 55296; };   // one halo buffer: (R + 2) (W + 16) 64 B for W in {32, 64, 128}
 
-// LW (round 3): only waves 0-3 -- one per SIMD -- issue the LDS-DMA pieces of a step (6 each: two halo pieces, four weight pieces); their
-// SIMD partners 4-7 issue none.  A DMA instruction holds its wave's instruction stream for 100-185 cycles; with every wave issuing its
-// three pieces right behind the step's barrier, both waves of a SIMD sit in DMA issue at the same time and the MFMA pipe idles.  With
-// the pieces on ONE wave per SIMD the partner multiplies meanwhile.
-template <class EP, int SGN, int MT, int NT, int TAG = 0, bool LW = false>          // TAG: distinct symbol for aocr_profile_kernel's launches (their own row in rocprofv3 --stats)
+// (Round 3, measured and removed: all LDS-DMA pieces of a step issued by ONE wave per SIMD -- waves 0-3, six pieces each -- so that the
+// SIMD partner multiplies while the loader wave sits in DMA issue: conv6 forward 0.246 -> 0.29 ms per launch, conv forward + data
+// gradient +10 % per step.  The issue cost is serial per wave; spread over eight waves it is half as long.)
+// (Round 3, measured and removed: the weight tile of a step -- 16 KB, 94 % of this kernel's LDS-DMA bytes -- staged global -> registers ->
+// ds_write_b128 instead of by LDS-DMA, one step ahead, the halo piece still a DMA: conv forward 0.84 -> 0.88 ms per step, conv6
+// forward 0.254 -> 0.264 ms per launch, bit-identical results.  Neither fewer DMA instructions per wave nor fewer waves issuing them
+// helps: the step is not bound by DMA issue alone.)
+template <class EP, int SGN, int MT, int NT, int TAG = 0>          // TAG: distinct symbol for aocr_profile_kernel's launches (their own row in rocprofv3 --stats)
 __global__ __launch_bounds__(512, 1)
 void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const bf16_t* zero) {
   constexpr int HMAX = HaloGeom<MT>::HMAX, BSLOT = NT * 64, BRING = 2 * HMAX, DUMP = BRING + 4 * BSLOT, LDS_BYTES = DUMP + 8 * 1024;
@@ -1068,13 +1071,11 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
   for (int s2 = 0; s2 < 2; ++s2) boff[s2] = BRING + (wn * 64 + r) * 64 + (((2 * s2 + h) ^ swzb) << 4);
 
   // ---- weight staging (as in gemm_dma_bf16_kernel): rows (tid >> 2) + 128 j, position tid & 3 holds k-chunk (tid & 3) ^ ((tid >> 4) & 3)
-  static_assert(!LW || NT == 256, "loader-wave form: 256-column tiles");
   const int srow = tid >> 2, bchunk = (tid & 3) ^ ((tid >> 4) & 3);
-  const bool bwave = LW ? wave < 4 : (NT >= 128 || wave < 4);              // NT = 64: rows 0..63 are waves 0-3
-  constexpr int NBJ = LW ? 4 : NBW, BSTEP = LW ? 64 : 128;                 // LW: thread t < 256 stages rows (t >> 2) + 64 j, j < 4
-  LoadKh::DRow rb[NBJ];
+  const bool bwave = NT >= 128 || wave < 4;              // NT = 64: rows 0..63 are waves 0-3
+  LoadKh::DRow rb[NBW];
 #pragma unroll
-  for (int j = 0; j < NBJ; ++j) rb[j] = b.drow(n_blk + BSTEP * j + srow, bchunk);
+  for (int j = 0; j < NBW; ++j) rb[j] = b.drow(n_blk + 128 * j + srow, bchunk);
   unsigned char* const wbase = lds + wave * 1024;
   // ---- halo staging: group gq = 16 pixels of one halo row; lane -> pixel (lane >> 2), position lane & 3
   const int hx = (lane >> 2) - 1, hchunk = (lane & 3) ^ ((lane >> 4) & 3);
@@ -1088,17 +1089,10 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
   auto issue_b = [&](int step) {                         // weight tile of K step `step` (chunk-major): k = tap * C + 32 chunk
     const int chunk = step / 9, tap = step - chunk * 9;
     const int k = step < NT9 ? tap * C + (chunk << 5) : b.K;           // past the end: zero page
-    if constexpr (LW) {
-      if (wave < 4) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma16(dma_select(rb[j].b != nullptr && k < b.K, rb[j].b + k, zero), wbase + BRING + (step & 3) * BSLOT + j * 4096);
-      }
-    } else {
 #pragma unroll
     for (int j = 0; j < NBW; ++j)
       dma16(dma_select(bwave && rb[j].b != nullptr && k < b.K, rb[j].b + k, zero),
             bwave ? wbase + BRING + (step & 3) * BSLOT + j * 8192 : lds + DUMP + wave * 1024);
-    }
   };
 
   f32x16 acc[MI][2];
@@ -1110,7 +1104,7 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // prologue: the whole halo of chunk 0 and three weight tiles, all landed before the first step
-  for (int gq = wave; gq < NG; gq += 8) issue_halo(gq, 0, true);        // (the prologue's halo is staged by all eight waves in both forms)
+  for (int gq = wave; gq < NG; gq += 8) issue_halo(gq, 0, true);
   issue_b(0); issue_b(1); issue_b(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -1124,8 +1118,7 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
       for (int kw = 0; kw < 3; ++kw, ++step) {
         const int dxi = SGN > 0 ? kw : 2 - kw;
         // this wave's pieces of this step's weight tile (and of everything older) have landed: 2 steps x (1 + NBW) pieces may be pending
-        if constexpr (LW) { if (wave < 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }          // 2 steps x 6 pieces of a loader wave may be pending
-        else if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // ... everyone's have, and everyone is done reading the previous step
         const unsigned char* Lb = lds + (step & 3) * BSLOT;
         bf16x8 af[2][MI], bf[2][2];
@@ -1139,12 +1132,7 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) bf[s2][ni] = *reinterpret_cast<const bf16x8*>(Lb + boff[s2] + ni * 2048);
-        if constexpr (LW) {                               // two pieces of the NEXT chunk's halo per loader wave
-          if (wave < 4) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) { const int gq = (kh * 3 + kw) * 8 + wave + 4 * u; issue_halo(gq < NG ? gq : 0, chunk + 1, gq < NG && chunk + 1 < NC); }
-          }
-        } else {                                          // one piece of the NEXT chunk's halo (its buffer was last read a chunk ago)
+        {                                                 // one piece of the NEXT chunk's halo (its buffer was last read a chunk ago)
           const int gq = (kh * 3 + kw) * 8 + wave;
           issue_halo(gq < NG ? gq : 0, chunk + 1, gq < NG && chunk + 1 < NC);
         }

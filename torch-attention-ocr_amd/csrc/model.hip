@@ -733,7 +733,8 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
   dec_init_state(m, d, c0, h0, m->out_all, B, sh);
   m->dgates_il = false;
   const bool drop = keep_gates && m->drop_on;                       // training only
-  if (sh && !drop && dec_cluster_ok(m, T, L)) {
+  const bool drop_cl = drop && m->dhm_b[0] && !getenv("AOCR_NO_DEC_CLUSTER_DROP");     // round 3: the cluster kernels evaluate the masks themselves
+  if (sh && (!drop || drop_cl) && dec_cluster_ok(m, T, L)) {
     // scores against the pre-multiplied context: ctx[t] . (W_a h) = (ctx W_a)[t] . h, LSTM.lua:131-137
     if (!m->ctxa_fresh) gemm_hh_shadow(s, m->context_b, Hd, m->swa.wtb, Hd, m->dctx, Hd, m->ctxa_b, Hd, B * T, Hd, Hd);
     m->ctxa_fresh = false;
@@ -743,6 +744,7 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
     for (int l = 0; l < 2; ++l) { a.cs[l] = m->dcs[l]; a.hsb[l] = m->dhs_b[l]; a.gates[l] = keep_gates ? m->dgates[l] : nullptr; }
     a.a_all = m->a_all; a.out = m->out_all; a.cat_b = m->cat_b; a.out_b = m->out_b;
     a.xbuf = m->dc_xbuf; a.xtab = m->dc_xtab; a.err = m->cl_err;
+    if (drop) { a.drop_h = drop_site(m, 2, 0); a.drop_out = drop_site(m, 16, 0); a.hm_b = m->dhm_b[0]; }     // (.off = the step's offset, added in the kernel)
     dec_cluster_forward(s, a);
     m->dgates_il = true;
     if (keep_gates)                                                // q = W_a h_top for all L steps: only the backward pass reads it
@@ -785,8 +787,19 @@ void loss_and_dlogits(aocr_model* m, const Dims& d, const int32_t* tge, int64_t 
 }
 
 // the side stream of the backward pass (created on first use, lowest priority) -- AOCR_NO_SIDE_WGRAD=1 keeps everything on one stream
-static bool side_stream_on(aocr_model* m) {
+static bool side_stream_on(aocr_model* m, int B, int T) {
   if (m->prof_on || !m->bf16 || getenv("AOCR_NO_SIDE_WGRAD")) return false;
+  // The encoder BPTT cluster kernel needs every workgroup of a group resident at once; beside it the side stream's GEMM workgroups
+  // must find free compute units, or they delay the group members that are placed last (bounded spins, aocr_cluster_status).
+  // C3: 16 groups x 2 directions x 4 members = 128 of 256 units -> on.  He = 512 at batch 400: 256 workgroups per pass -> off.
+  {
+    int G = 0, RT = 0, groups = 0;
+    if (cluster_ok(m, B, T, G, RT, groups)) {
+      static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+      const int per_pass = std::max(8, cus / (8 * G) * 8);
+      if (std::min(2 * groups, per_pass) * G * 4 > cus * 3) return false;
+    }
+  }
   if (!m->side) {
     int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);            // lo = numerically greatest = lowest priority
     const hipError_t e = getenv("AOCR_SIDE_PLAIN") ? hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) : hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, lo);
@@ -818,6 +831,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
     for (int l = 0; l < 2; ++l) { a.cs[l] = m->dcs[l]; a.gates[l] = m->dgates[l]; a.dz[l] = m->ddz[l]; a.dzb[l] = m->ddz_b[l]; a.dc_st[l] = m->dc_st[l]; a.dh_rec[l] = m->dh_rec[l]; }
     a.dpre = m->dpre_all; a.dpre_b = m->dpre_b; a.dcat = m->dcat_all; a.ds_all = m->ds_all; a.dq = m->dq_all; a.dq_b = m->dq_b; a.dfeed = m->dfeed;
     a.xbuf = m->dc_bxbuf; a.xtab = m->dc_xtab; a.err = m->cl_err;
+    if (m->drop_on) { a.drop_h = drop_site(m, 2, 0); a.drop_out = drop_site(m, 16, 0); }      // the forward cluster kernel ran with these masks
     dec_cluster_backward(s, a);
   } else
   for (int t = L - 1; t >= 0; --t) {
@@ -898,7 +912,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   // (16 groups x 2 directions x 4 members at C3) for ~0.2 ms.  The side stream has the lowest priority, so the encoder kernel's
   // workgroups are placed first.  Off while the per-family profile marks are on (the marks live on the model's stream).
   hipStream_t ms = s;
-  if (side_stream_on(m)) {
+  if (side_stream_on(m, B, T)) {
     hipEventRecord(m->side_go, ms); s = m->side; hipStreamWaitEvent(s, m->side_go, 0); m->side_busy = true;
   }
   const float* h_top_all = m->dhs[Ld - 1] + slot;

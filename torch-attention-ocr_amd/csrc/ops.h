@@ -243,6 +243,9 @@ struct DecClFwdArgs {
   const int32_t* tok0 = nullptr; int tok0_stride = 0; const float *wo = nullptr, *bo = nullptr; int V = 0;
   float* pbuf = nullptr; unsigned* tokx = nullptr; int32_t* labels = nullptr; float* scores = nullptr;
   const unsigned long long* trie_mask = nullptr; const int32_t* trie_base = nullptr; const int32_t* trie_child = nullptr;   // -use_dictionary (flat trie of include/aocr.h) or null
+  // nn.Dropout(p) (training, LSTM.lua:68-69,116-118): masks of layer 2's input (site 2) and of the attention output (site 16), flat index
+  // = step * B * Hd + row * Hd + unit added to .off = 0; hm_b [L][B][Hd]: the masked bf16 copy of h1 (operand of layer 2 and of its weight gradient)
+  DropSpec drop_h, drop_out; bf16_t* hm_b = nullptr;
 };
 // decoder BPTT in one launch (dec_cluster.hip); reads what the forward cluster kernel saved (interleaved gates)
 struct DecClBwdArgs {
@@ -258,6 +261,7 @@ struct DecClBwdArgs {
   float* dz[2]; bf16_t* dzb[2];                        // [L][B][4 Hd]
   float* dc_st[2]; float* dh_rec[2]; float* dfeed;     // [B][Hd]: gradients of the initial state
   unsigned long long *xbuf, *xtab; int* err; unsigned long long* stamps = nullptr;
+  DropSpec drop_h, drop_out;                           // as in DecClFwdArgs (the forward kernel stored the MASKED attention output)
 };
 bool dec_cluster_supported(int Hd, int Ld, int input_feed, int T, int L, int cus);
 bool dec_cluster_bwd_supported(int Hd, int Ld, int input_feed, int T, int L, int cus);
