@@ -128,6 +128,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-steps", type=int, default=3)
     ap.add_argument("--no-secondary", action="store_true", help="skip the C2 fp32 and data-path secondary measurements")
+    ap.add_argument("--dropout", type=float, default=0.0, help="-dropout of the reference (LSTM.lua:68-69,116-118); 0 = the reference default")
+    ap.add_argument("--provider", default="callback", choices=["callback", "rccl"],
+                    help="N > 1: who sums the gradients -- torch.distributed through aocr_comm_set_callback, or the library's own RCCL binding (aocr_comm_init_rank)")
     ap.add_argument("--sustain-seconds", type=float, default=8.0, help="keep stepping after the timed steps until this much GPU time has passed")
     return ap.parse_args()
 
@@ -176,8 +179,12 @@ def main():
     m = aocr.Model().create(dict(encoder_num_hidden=wl["He"], encoder_num_layers=wl["Le"], decoder_num_layers=wl["Ld"],
                                  input_feed=True, batch_size=B, img_h=IMG_H, max_img_w=W, max_decoder_l=50, max_beam=BEAM,
                                  compute=wl["compute"], learning_rate=0.1, seed=910820))
+    if args.dropout > 0:
+        m.dropout = float(args.dropout)                                  # masks advance with every step (Model._arm_dropout)
     rccl_ranks = None
     if world > 1:
+        if args.provider == "rccl":                                      # the library's own binding: ncclCommInitRank + ncclCommSplit inside libaocr
+            aocr.dist.attach_rccl(m, sync_bn=not os.environ.get("AOCR_NO_SYNC_BN"))
         dist.broadcast(m.params, 0); dist.broadcast(m.bn_state, 0)       # identical replicas (parameters and running statistics)
         probe = torch.ones(1, device=m.device); dist.all_reduce(probe)   # an actual collective: how many ranks does it span?
         rccl_ranks = int(probe.item())
@@ -241,6 +248,11 @@ def main():
         sync()
         es = time.perf_counter() - t0
         sustained = {"steps": n, "seconds": es, "ms_per_step": 1e3 * es / n, "image_lines_per_s": global_B * n / es, "healthy": healthy()}
+    exposed = None
+    if world > 1:                                       # part of the gradient exchange the backward pass did not hide, last step (max over ranks)
+        ex = torch.tensor([m.comm_exposed_ms()], device=dev, dtype=torch.float64)
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        exposed = float(ex.item())
     replica_drift = None
     if world > 1:                                       # every rank must hold the same parameters after the timed steps
         cs = m.params.double().abs().sum().reshape(1)
@@ -408,6 +420,7 @@ def main():
             "config": {"workload": f"{args.workload}: {wl['name']}", "global_batch": global_B, "per_gpu_batch": B, "img": f"{IMG_H}x{W}",
                        "decoder_steps": L, "parallelism": f"dp{world}", "input_feed": True},
             "scaling_measured": world > 1, "rccl_ranks": rccl_ranks, "cluster_fallback": cluster_fallback,
+            "exchange_provider": args.provider if world > 1 else None, "exchange_exposed_ms": exposed, "dropout": args.dropout,
             "step_ms_events": {"median": float(np.median(per_step)), "p10": float(np.percentile(per_step, 10)),
                                "p90": float(np.percentile(per_step, 90)), "n": int(args.steps)},
             "sustained": sustained,

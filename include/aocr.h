@@ -94,7 +94,7 @@ int aocr_cluster_status(aocr_model* m, int32_t* code);
  * function of (seed, train_step, site, element index) -- splitmix64, restated in oracle/oracle_torch.py::dropout_mask -- so a step is
  * reproducible and the oracle can replay it; kept activations are scaled by 1/(1-p) (nn.Dropout v2).  Call before every training
  * step with the step counter (the reference draws from torch's global generator instead: the mask VALUES cannot match, the
- * distribution does).  p = 0 (default) disables it.  With p > 0 the decoder runs the per-step launch chain. */
+ * distribution does).  p = 0 (default) disables it.  (Round 3: the whole-sequence decoder kernels evaluate the same masks.) */
 int aocr_set_dropout(aocr_model* m, double p, uint64_t seed, uint64_t train_step);
 
 /* feval of model.lua:284-696 with forward_only=false: CNN forward (training-mode
@@ -143,6 +143,9 @@ int aocr_allreduce_grads(aocr_model* m, float* loss_dev);
 int aocr_comm_destroy(aocr_model* m);
 /* What is attached: *nranks (1 without a communicator), *sync_bn (0 / 1), *provider (0 none, 1 RCCL, 2 host callback).  Any pointer may be NULL. */
 int aocr_comm_info(aocr_model* m, int32_t* nranks, int32_t* sync_bn, int32_t* provider);
+/* Measurement: milliseconds the model's stream waited for the exchange stream at the end of the LAST aocr_allreduce_grads -- the part
+ * of the gradient exchange that the backward pass did not hide (0 without a communicator).  Synchronises that step. */
+int aocr_comm_exposed_ms(aocr_model* m, float* ms);
 
 /* optim.sgd_list, src/optim/optim_sgd.lua:38-95 with the options the reference
  * leaves at 0: per group, if ||g||_2 > clip then g *= clip/||g||_2; w -= lr*g.

@@ -49,6 +49,7 @@ int aocr_comm_set_callback(aocr_model* m, aocr_allreduce_fn fn, void* user, int3
 int aocr_allreduce_grads(aocr_model* m, float* loss_dev);
 int aocr_comm_destroy(aocr_model* m);
 int aocr_comm_info(aocr_model* m, int32_t* nranks, int32_t* sync_bn, int32_t* provider);
+int aocr_comm_exposed_ms(aocr_model* m, float* ms);
 int aocr_sgd_step(aocr_model* m, float lr, float clip, float* norms_dev);
 int aocr_adadelta_step(aocr_model* m, float rho, float eps, float weight_decay, float* state_dev);
 int aocr_forward_logits(aocr_model* m, const float* images_dev, const int32_t* targets_dev, const int32_t* targets_eval_dev, int32_t B, int32_t W, int32_t L, int32_t training, float* logits_dev, float* loss_dev);

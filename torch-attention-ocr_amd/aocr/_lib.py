@@ -70,6 +70,7 @@ SIGNATURES = {
     "aocr_comm_set_callback": (C.c_int, [_vp, _vp, _vp, _i32, _i32]),
     "aocr_allreduce_grads": (C.c_int, [_vp, _vp]),
     "aocr_comm_destroy": (C.c_int, [_vp]),
+    "aocr_comm_exposed_ms": (C.c_int, [_vp, C.POINTER(_f32)]),
     "aocr_comm_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "aocr_sgd_step": (C.c_int, [_vp, _f32, _f32, _vp]),
     "aocr_adadelta_step": (C.c_int, [_vp, _f32, _f32, _f32, _vp]),

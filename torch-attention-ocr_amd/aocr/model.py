@@ -524,6 +524,12 @@ class Model:
             return
         torch.distributed.all_reduce(self.bn_state); self.bn_state.div_(dist.world_size())
 
+    def comm_exposed_ms(self) -> float:
+        """ms the model's stream waited for the gradient exchange at the end of the last step (include/aocr.h: aocr_comm_exposed_ms)."""
+        ms = C.c_float(0.0)
+        check(lib.aocr_comm_exposed_ms(self._h, C.byref(ms)), "aocr_comm_exposed_ms")
+        return float(ms.value)
+
     def sync_bn_active(self) -> bool:
         """True when the library normalises with the statistics of the global batch (asked of the library, include/aocr.h)."""
         n, sb, prov = C.c_int32(), C.c_int32(), C.c_int32()

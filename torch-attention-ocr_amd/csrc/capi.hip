@@ -185,6 +185,14 @@ int aocr_allreduce_grads(aocr_model* m, float* loss_dev) {
   REQUIRE(rc == 0, rc == 2 ? "the all-reduce provider reported an error" : "stream / event error in the gradient exchange");
   return 0;
 }
+int aocr_comm_exposed_ms(aocr_model* m, float* ms) {
+  REQUIRE(m && ms, "NULL argument");
+  *ms = 0.f;
+  if (!m->comm.timed) return 0;
+  if (hipEventSynchronize(m->comm.wait1) != hipSuccess || hipEventElapsedTime(ms, m->comm.wait0, m->comm.wait1) != hipSuccess)
+    return fail("aocr_comm_exposed_ms: %s", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
 int aocr_comm_destroy(aocr_model* m) { REQUIRE(m, "NULL model"); comm_destroy(m); return 0; }
 int aocr_comm_info(aocr_model* m, int32_t* nranks, int32_t* sync_bn, int32_t* provider) {
   REQUIRE(m, "NULL model");

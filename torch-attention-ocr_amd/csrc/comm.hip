@@ -50,6 +50,7 @@ static const char* comm_common_init(aocr_model* m, int nranks, int sync_bn) {
   m->comm.nranks = nranks; m->comm.sync_bn = sync_bn != 0;
   if (!m->comm.stream && hipStreamCreateWithFlags(&m->comm.stream, hipStreamNonBlocking) != hipSuccess) return "hipStreamCreate failed";
   if (!m->comm.done && hipEventCreateWithFlags(&m->comm.done, hipEventDisableTiming) != hipSuccess) return "hipEventCreate failed";
+  if (!m->comm.wait0 && (hipEventCreate(&m->comm.wait0) != hipSuccess || hipEventCreate(&m->comm.wait1) != hipSuccess)) return "hipEventCreate failed";
   return nullptr;
 }
 const char* comm_init_rccl(aocr_model* m, const char id[128], int nranks, int rank, int sync_bn) {
@@ -79,6 +80,8 @@ void comm_destroy(aocr_model* m) {
   if (m->comm.provider == 1 && m->comm.rccl && g_rccl.h) g_rccl.destroy(m->comm.rccl);
   if (m->comm.stream) hipStreamDestroy(m->comm.stream);
   if (m->comm.done) hipEventDestroy(m->comm.done);
+  if (m->comm.wait0) hipEventDestroy(m->comm.wait0);
+  if (m->comm.wait1) hipEventDestroy(m->comm.wait1);
   m->comm = CommState{};
 }
 
@@ -105,7 +108,12 @@ int comm_allreduce_grads(aocr_model* m, float* loss_dev) {
     if (comm_allreduce(m, m->grads + b[k], e[k] - b[k], 0, cs, 0) != 0) return 2;
     if (k == 0 && loss_dev && comm_allreduce(m, loss_dev, 1, 0, cs, 0) != 0) return 2;      // the loss is final before the backward pass starts
   }
-  if (hipEventRecord(m->comm.done, cs) != hipSuccess || hipStreamWaitEvent(m->s, m->comm.done, 0) != hipSuccess) return 1;
+  // the model's stream joins here.  wait0 fires when the backward pass is done, wait1 when the last bucket is: their distance is the
+  // part of the exchange the backward pass did NOT hide (aocr_comm_exposed_ms)
+  if (hipEventRecord(m->comm.done, cs) != hipSuccess) return 1;
+  hipEventRecord(m->comm.wait0, m->s);
+  if (hipStreamWaitEvent(m->s, m->comm.done, 0) != hipSuccess) return 1;
+  hipEventRecord(m->comm.wait1, m->s); m->comm.timed = true;
   return 0;
 }
 

@@ -35,6 +35,7 @@ struct CommState {
   int nranks = 1; bool sync_bn = false; int provider = 0;
   void* rccl = nullptr; void* rccl_bn = nullptr; aocr_allreduce_fn fn = nullptr; void* user = nullptr;
   hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+  hipEvent_t wait0 = nullptr, wait1 = nullptr; bool timed = false;   // timing pair around the join of the exchange stream (aocr_comm_exposed_ms)
 };
 
 struct Dims {                     // geometry of one step
