@@ -1024,10 +1024,13 @@ template <int MT> struct HaloGeom { static constexpr int HMAX = MT == 256 ? 3686
 // (Round 3, measured and removed: all LDS-DMA pieces of a step issued by ONE wave per SIMD -- waves 0-3, six pieces each -- so that the
 // SIMD partner multiplies while the loader wave sits in DMA issue: conv6 forward 0.246 -> 0.29 ms per launch, conv forward + data
 // gradient +10 % per step.  The issue cost is serial per wave; spread over eight waves it is half as long.)
-// BREG (round 3, experiment): the weight tile of a step -- 16 KB, 94 % of this kernel's LDS-DMA bytes -- staged global -> registers ->
-// ds_write_b128 instead of by LDS-DMA, THREE tiles in flight (set = step % 3 = kw; tile t+1 is written into its slot during step t and
-// its registers reloaded with tile t+4); the halo piece stays a DMA.  (With ONE tile in flight: conv forward 0.84 -> 0.88 ms per step.)
-template <class EP, int SGN, int MT, int NT, int TAG = 0, bool BREG = false>          // TAG: distinct symbol for aocr_profile_kernel's launches (their own row in rocprofv3 --stats)
+// (Round 3, measured and removed: the weight tile of a step -- 16 KB, 94 % of this kernel's LDS-DMA bytes -- staged global -> registers ->
+// ds_write_b128 instead of by LDS-DMA, the halo piece still a DMA, bit-identical results.  One tile in flight: conv forward 0.84 -> 0.88 ms
+// per step; THREE tiles in flight (asm loads, counted vmcnt(7), 244 VGPRs, no spill): conv6 forward 0.247 -> 0.265 ms per launch, conv
+// forward 0.83 -> 0.865 ms.  Neither fewer DMA instructions per wave, nor fewer waves issuing them, nor taking 94 % of the bytes off the
+// LDS-DMA path helps: within a wave fragment reads, DMA issue and MFMA issue serialise (0.19 + 0.30 + 0.45 us of a 1.0 us step, ablations of
+// round 2), and the two waves of a SIMD cannot fill each other's gaps because the per-step barrier keeps them in the same phase.)
+template <class EP, int SGN, int MT, int NT, int TAG = 0>          // TAG: distinct symbol for aocr_profile_kernel's launches (their own row in rocprofv3 --stats)
 __global__ __launch_bounds__(512, 1)
 void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const bf16_t* zero) {
   constexpr int HMAX = HaloGeom<MT>::HMAX, BSLOT = NT * 64, BRING = 2 * HMAX, DUMP = BRING + 4 * BSLOT, LDS_BYTES = DUMP + 8 * 1024;
@@ -1094,19 +1097,6 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
             bwave ? wbase + BRING + (step & 3) * BSLOT + j * 8192 : lds + DUMP + wave * 1024);
   };
 
-  static_assert(!BREG || NT == 256, "register-staged weights: 256-column tiles");
-  typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
-  u32x4w w00 = {0u, 0u, 0u, 0u}, w01 = w00, w10 = w00, w11 = w00, w20 = w00, w21 = w00;      // sets 0..2 x this thread's two 16-byte pieces (named: an array became an LDS scratch area)
-  // (asm loads: hipcc's own waitcnt pass drained vmcnt(0) at every third step around C++ loads mixed with the DMA builtins; the counted
-  //  wait at the top of a step covers them instead -- the set written at step t was loaded at step t-3, and 7 younger operations follow it)
-  auto bload = [&](u32x4w& w, int step, int j) {
-    const int chunk = step / 9, tap = step - chunk * 9;
-    const int k = step < NT9 ? tap * C + (chunk << 5) : b.K;
-    const bf16_t* src = dma_select(rb[j].b != nullptr && k < b.K, rb[j].b + k, zero);
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w) : "v"(src) : "memory");
-  };
-  auto bdst = [&](int step) { return lds + BRING + (step & 3) * BSLOT + srow * 64 + (tid & 3) * 16; };
-
   f32x16 acc[MI][2];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -1117,9 +1107,8 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
 
   // prologue: the whole halo of chunk 0 and three weight tiles, all landed before the first step
   for (int gq = wave; gq < NG; gq += 8) issue_halo(gq, 0, true);
-  if constexpr (BREG) {
-    bload(w00, 0, 0); bload(w01, 0, NBW - 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  issue_b(0); issue_b(1); issue_b(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     *reinterpret_cast<u32x4w*>(bdst(0)) = w00; *reinterpret_cast<u32x4w*>(bdst(0) + 8192) = w01;       // tile 0 straight into its slot
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  // (before its registers are reloaded)
     bload(w10, 1, 0); bload(w11, 1, NBW - 1); bload(w20, 2, 0); bload(w21, 2, NBW - 1); bload(w00, 3, 0); bload(w01, 3, NBW - 1);   // set = tile % 3
@@ -1136,11 +1125,7 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
       for (int kw = 0; kw < 3; ++kw, ++step) {
         const int dxi = SGN > 0 ? kw : 2 - kw;
         // this wave's pieces of this step's weight tile (and of everything older) have landed: 2 steps x (1 + NBW) pieces may be pending
-        // (BREG: per step a wave issues two register loads and one halo piece.  vmcnt(7): the set this step writes to LDS was loaded three
-        //  steps ago, followed by that step's halo piece and two steps of 3 operations; every halo piece this chunk reads is older still --
-        //  the last real one of a chunk is issued at its tap 4.  lgkmcnt(0): this wave's ds_write of the current tile is complete.)
-        if constexpr (BREG) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
-        else if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // ... everyone's have, and everyone is done reading the previous step
         const unsigned char* Lb = lds + (step & 3) * BSLOT;
         bf16x8 af[2][MI], bf[2][2];
@@ -1154,14 +1139,6 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) bf[s2][ni] = *reinterpret_cast<const bf16x8*>(Lb + boff[s2] + ni * 2048);
-        if constexpr (BREG) {                             // tile t+1 (set (kw + 1) % 3) -> its slot, last read at step t-3; that set <- tile t+4
-          unsigned char* const d = bdst(step + 1);
-          // (the ds_write must have READ its registers before the reload overwrites them: LDS instructions of a wave issue in order and
-          //  read their data operands at issue, the s_nop covers the VALU -> VMEM data hazard of a just-issued ds_write)
-          if (kw == 0) { *reinterpret_cast<u32x4w*>(d) = w10; *reinterpret_cast<u32x4w*>(d + 8192) = w11; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); bload(w10, step + 4, 0); bload(w11, step + 4, NBW - 1); }
-          else if (kw == 1) { *reinterpret_cast<u32x4w*>(d) = w20; *reinterpret_cast<u32x4w*>(d + 8192) = w21; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); bload(w20, step + 4, 0); bload(w21, step + 4, NBW - 1); }
-          else { *reinterpret_cast<u32x4w*>(d) = w00; *reinterpret_cast<u32x4w*>(d + 8192) = w01; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); bload(w00, step + 4, 0); bload(w01, step + 4, NBW - 1); }
-        }
         {                                                 // one piece of the NEXT chunk's halo (its buffer was last read a chunk ago)
           const int gq = (kh * 3 + kw) * 8 + wave;
           issue_halo(gq < NG ? gq : 0, chunk + 1, gq < NG && chunk + 1 < NC);
@@ -1171,7 +1148,7 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], bf[0][ni], acc[mi][ni], 0, 0, 0);
-        if constexpr (!BREG) issue_b(step + 3);           // -> the slot of the previous step
+        issue_b(step + 3);                                // -> the slot of the previous step
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll

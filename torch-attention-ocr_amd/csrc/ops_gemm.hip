@@ -64,14 +64,6 @@ static bool halo_eligible(const LoadConvK& g, int N, int MT, int NT) {
 template <int SGN, int MT, int NT, class EP>
 static void launch_halo(hipStream_t s, const LoadConvKh& a, const LoadKh& b, const EP& ep, int M, int N, int tag = 0) {
   const int gx = N / NT, gy = M / MT;
-  if constexpr (NT == 256) {
-    const char* br = getenv("AOCR_HALO_BREG");                // A/B: weight tiles through registers instead of LDS-DMA (see the kernel)
-    if (br && br[0] == '1') {
-      if (tag) hipLaunchKernelGGL((gemm_halo_bf16_kernel<EP, SGN, MT, NT, 1, true>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, gx, gy, zero_page());
-      else hipLaunchKernelGGL((gemm_halo_bf16_kernel<EP, SGN, MT, NT, 0, true>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, gx, gy, zero_page());
-      return;
-    }
-  }
   if (tag) hipLaunchKernelGGL((gemm_halo_bf16_kernel<EP, SGN, MT, NT, 1>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, gx, gy, zero_page());
   else hipLaunchKernelGGL((gemm_halo_bf16_kernel<EP, SGN, MT, NT>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, gx, gy, zero_page());
 }
