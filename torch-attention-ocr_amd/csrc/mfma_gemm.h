@@ -1109,11 +1109,6 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
   for (int gq = wave; gq < NG; gq += 8) issue_halo(gq, 0, true);
   issue_b(0); issue_b(1); issue_b(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    *reinterpret_cast<u32x4w*>(bdst(0)) = w00; *reinterpret_cast<u32x4w*>(bdst(0) + 8192) = w01;       // tile 0 straight into its slot
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  // (before its registers are reloaded)
-    bload(w10, 1, 0); bload(w11, 1, NBW - 1); bload(w20, 2, 0); bload(w21, 2, NBW - 1); bload(w00, 3, 0); bload(w01, 3, NBW - 1);   // set = tile % 3
-  } else { issue_b(0); issue_b(1); issue_b(2); }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   int step = 0;
   for (int chunk = 0; chunk < NC; ++chunk) {
