@@ -6,15 +6,17 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "torch-attentio
 import torch
 from test_step_gpu import make
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+drop = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0            # round 3: the dropout instances of the decoder cluster kernels
 for (B, W, L) in ((256, 256, 24), (70, 416, 13)):
     m, O, ocfg, P, st, batch = make(dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True), B=B, W=W, maxlen=L - 1, compute="bf16", max_decoder_l=50, max_beam=1)
     images, targets, targets_eval = m._upload(batch)
     m.optim_state["learningRate"] = 1e-4
+    m.dropout = drop
     t0 = time.time()
     for i in range(steps):
         m.train_step_device(images, targets, targets_eval)
         if i % 10 == 0:
             m.decode_device(images, targets, targets_eval, 1)
     torch.cuda.synchronize(); m.check_health()
-    print(f"B={B} W={W}: {steps} train steps + {steps // 10} decode calls in {time.time() - t0:.1f} s, cluster status 0, loss {float(m._scal[0].item()):.3f}")
+    print(f"B={B} W={W}: {steps} train steps + {steps // 10} decode calls in {time.time() - t0:.1f} s, dropout {drop}, cluster status 0, loss {float(m._scal[0].item()):.3f}")
     m.shutdown()
