@@ -365,6 +365,21 @@ def main():
               "unit": "image-lines/s", "step_mfma_frac": 3 * f2 * w2["B"] * 10 / e / 1e12 / PEAK["f32"]}
         m2.shutdown()
 
+    # ---- beam-5 decode of the same lines (N = 1 only; model.lua:376-536 with -beam_size 5): the per-step launch chain + one fused state gather
+    beam5 = None
+    if world == 1 and args.workload == "c3" and not args.no_secondary and args.decode_steps > 0:
+        m5 = aocr.Model().create(dict(encoder_num_hidden=wl["He"], encoder_num_layers=wl["Le"], decoder_num_layers=wl["Ld"], input_feed=True,
+                                      batch_size=B, max_img_w=W, max_decoder_l=50, max_beam=5, compute=wl["compute"], learning_rate=0.1, seed=910820))
+        m5.decode_device(images, targets, targets_eval, 5); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.decode_steps):
+            m5.decode_device(images, targets, targets_eval, 5)
+        torch.cuda.synchronize()
+        e5 = (time.perf_counter() - t0) / args.decode_steps
+        beam5 = {"beam": 5, "chars_per_s": B * 50 / e5, "ms_per_call": 1e3 * e5,
+                 "what": "B*50 decoder steps per -phase test call at beam 5 (5 hypotheses per line advance per step), beam pass + gold pass"}
+        m5.shutdown()
+
     # ---- data path, HBM-bound
     dp = None
     if world == 1 and not args.no_secondary:
@@ -427,7 +442,7 @@ def main():
             "train_gflop_per_image": 3 * fl["total"] / 1e9, "step_tflops": 3 * fl["total"] * lines_per_s / 1e12,
             "step_mfma_frac": 3 * fl["total"] * lines_per_s / 1e12 / (peak * world),
             "families": families,
-            "decode_chars_per_s": dec["chars_per_s"] if dec else None, "decode": dec, "decode_dict": dec_dict,
+            "decode_chars_per_s": dec["chars_per_s"] if dec else None, "decode": dec, "decode_dict": dec_dict, "decode_beam5": beam5,
             "replica_drift": replica_drift, "loss": loss_val, "secondary": c2, "data_path": dp,
             "roofline": roof, "roofline_best": best,
         }

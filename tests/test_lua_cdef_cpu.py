@@ -61,3 +61,23 @@ def test_lua_sources_only_call_declared_entry_points():
         if f.endswith(".lua"):
             used |= set(re.findall(r"\b(?:lib|L|C)\.(aocr_\w+)", open(os.path.join(ROOT, "lua", f)).read()))
     assert used and not (used - set(l["functions"])), sorted(used - set(l["functions"]))
+
+
+def test_lua_files_are_block_balanced():
+    """No Lua interpreter exists here; the least a test can do for the unexecuted files is a lexical check: every block opener
+    (function / if / do / repeat) has its end / until, and brackets balance, after comments and string literals are stripped."""
+    for f in sorted(os.listdir(os.path.join(ROOT, "lua"))):
+        if not f.endswith(".lua"):
+            continue
+        s = open(os.path.join(ROOT, "lua", f)).read()
+        s = re.sub(r"--\[\[.*?\]\]", "", s, flags=re.S)
+        s = re.sub(r"ffi\.cdef\s*\[\[.*?\]\]", "", s, flags=re.S)
+        s = re.sub(r"--[^\n]*", "", s)
+        s = re.sub(r"'(?:\\.|[^'\\\n])*'", "''", s)
+        s = re.sub(r'"(?:\\.|[^"\\\n])*"', '""', s)
+        toks = re.findall(r"\b(function|if|do|repeat|end|until)\b", s)
+        opens = sum(t in ("function", "if", "do", "repeat") for t in toks)
+        closes = sum(t in ("end", "until") for t in toks)
+        assert opens == closes, (f, opens, closes)
+        for a, b in ("()", "{}", "[]"):
+            assert s.count(a) == s.count(b), (f, a, s.count(a), s.count(b))

@@ -1027,11 +1027,11 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
     }
     if (!direct) {
       const int32_t* par = m->hist_par + (size_t)t * B * k;
-      for (int l = 0; l < Ld; ++l) {                                   // model.lua:521-535: gather states by parent beam
-        gather_beam_rows(s, m->bc_new[l], Hd, m->bc[nxt][l], Hd, par, B, kin, k, Hd);
-        gather_beam_rows(s, m->bh_new[l], Hd, m->bh[nxt][l], Hd, par, B, kin, k, Hd);
-      }
-      if (m->cfg.input_feed) gather_beam_rows(s, m->bout, Hd, m->bfeed[nxt], Hd, par, B, kin, k, Hd);
+      const float* gs[2 * MAXL + 1]; float* gd[2 * MAXL + 1]; int ng = 0;      // model.lua:521-535: gather states by parent beam, one launch
+      for (int l = 0; l < Ld; ++l) { gs[ng] = m->bc_new[l]; gd[ng++] = m->bc[nxt][l]; gs[ng] = m->bh_new[l]; gd[ng++] = m->bh[nxt][l]; }
+      if (m->cfg.input_feed) { gs[ng] = m->bout; gd[ng++] = m->bfeed[nxt]; }
+      if (ng <= 8) gather_beam_rows_many(s, ng, gs, gd, Hd, par, B, kin, k, Hd);
+      else for (int i = 0; i < ng; ++i) gather_beam_rows(s, gs[i], Hd, gd[i], Hd, par, B, kin, k, Hd);
     }
     cur = nxt;
   }

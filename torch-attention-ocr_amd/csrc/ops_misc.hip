@@ -1695,6 +1695,24 @@ void token_rows(hipStream_t s, const float* table, const int32_t* tok, int64_t s
   const int64_t n = (int64_t)R * (width / 4);
   hipLaunchKernelGGL(token_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, table, tok, stride, dst, R, width / 4);
 }
+void gather_beam_rows(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, const int32_t* parents, int B, int kin, int kout, int width);
+// the same gather for up to 8 state tensors of one decode step in ONE launch (model.lua:521-535 gathers c and h of every layer and the
+// input feed by the same parents: five dependent ~6 us dispatches per beam step before); 16-byte accesses, blockIdx.y = tensor
+struct GatherMany { const float* src[8]; float* dst[8]; };
+__global__ __launch_bounds__(256) void gather_rows_many_kernel(GatherMany g, int64_t ld, const int32_t* __restrict__ parents, int B, int kin, int kout, int width4) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (int64_t)B * kout * width4) return;
+  const int c = (int)(id % width4); const int64_t r = id / width4; const int b = (int)(r / kout);
+  const int sr = (kin == 1) ? b : b * kin + parents[r];
+  reinterpret_cast<float4*>(g.dst[blockIdx.y] + r * ld)[c] = reinterpret_cast<const float4*>(g.src[blockIdx.y] + (int64_t)sr * ld)[c];
+}
+void gather_beam_rows_many(hipStream_t s, int n, const float* const* src, float* const* dst, int64_t ld, const int32_t* parents, int B, int kin, int kout, int width) {
+  if (n <= 0) return;
+  if (width % 4 || ld % 4 || n > 8) { for (int i = 0; i < n; ++i) gather_beam_rows(s, src[i], ld, dst[i], ld, parents, B, kin, kout, width); return; }
+  GatherMany g; for (int i = 0; i < 8; ++i) { g.src[i] = src[i < n ? i : 0]; g.dst[i] = dst[i < n ? i : 0]; }
+  const int64_t items = (int64_t)B * kout * (width / 4);
+  hipLaunchKernelGGL(gather_rows_many_kernel, dim3((unsigned)cdiv(items, 256), n), dim3(256), 0, s, g, ld, parents, B, kin, kout, width / 4);
+}
 void gather_beam_rows(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, const int32_t* parents, int B, int kin,
                       int kout, int width) {
   int64_t n = (int64_t)B * kout * width;
