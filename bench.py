@@ -126,7 +126,7 @@ def parse():
     ap.add_argument("--compute", default=None, choices=["f32", "bf16"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--decode-steps", type=int, default=3)
+    ap.add_argument("--decode-steps", type=int, default=20)
     ap.add_argument("--no-secondary", action="store_true", help="skip the C2 fp32 and data-path secondary measurements")
     ap.add_argument("--dropout", type=float, default=0.0, help="-dropout of the reference (LSTM.lua:68-69,116-118); 0 = the reference default")
     ap.add_argument("--provider", default="callback", choices=["callback", "rccl"],
