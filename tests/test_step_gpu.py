@@ -799,3 +799,63 @@ def test_full_size_properties(cuda, compute, B, W):
     assert lossp == pytest.approx(loss1, rel=(1e-4 if compute == "bf16" else 1e-6))
     assert worst < (3e-2 if compute == "bf16" else 1e-3)
     m.shutdown()
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_cluster_kernels_remote_exchange_mode(cuda, monkeypatch, p):
+    """The whole-sequence kernels assume that the workgroups of a group land on ONE XCD (round-robin dispatch), check it at run time
+    through HW_REG_XCC_ID and otherwise exchange with write-through (sc0 sc1) stores and system-scope loads -- the path a partitioned
+    device or an unexpected placement takes.  AOCR_CL_REMOTE=1 forces that path: the same arithmetic, so loss and logits must be
+    IDENTICAL to the in-XCD mode (the gradients up to the order of the split-K sums), encoder and decoder, training (with and without
+    dropout) and greedy decode."""
+    cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for mode in ("local", "remote"):
+        monkeypatch.delenv("AOCR_CL_REMOTE", raising=False)
+        if mode == "remote":
+            monkeypatch.setenv("AOCR_CL_REMOTE", "1")
+        m, O, ocfg, P, st, batch = make(cfg, B=70, W=100, maxlen=9, compute="bf16", max_decoder_l=12, max_beam=1)
+        m.dropout = p; m.global_step = 5
+        loss = m.train_forward_backward(batch)
+        assert m.cluster_status() == 0
+        logits = m.get_tensor("logits")[:, :, :ocfg.vocab].clone()
+        grads = {k: v.clone() for k, v in m.get_gradients().items()}
+        m.dropout = 0.0
+        dl, _ = m.step(batch, True, 1)
+        out[mode] = (loss, logits, grads, m._dec_out.labels.copy(), m._dec_out.scores.copy(), dl)
+        m.shutdown()
+    a, b = out["local"], out["remote"]
+    assert a[0] == b[0] and torch.equal(a[1], b[1]), (a[0], b[0], (a[1] - b[1]).abs().max().item())
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and a[5] == b[5]
+    worst = max(relerr(b[2][k], a[2][k]) for k in a[2] if k not in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"))
+    print(f"[parity] cluster kernels, remote exchange mode (dropout {p}): loss and logits identical, worst gradient rel {worst:.2e}")
+    assert worst < 1e-4
+
+
+def test_update_is_skipped_when_a_cluster_kernel_timed_out(cuda):
+    """include/aocr.h (aocr_cluster_status): a whole-sequence kernel whose bounded wait expired leaves a non-zero code; the step's
+    gradients are invalid, and aocr_sgd_step / aocr_adadelta_step must then leave the parameters untouched (device-side predicate, no
+    host sync) until the host has read -- and thereby cleared -- the code.  The code is injected here (a real timeout needs a co-tenant)."""
+    import ctypes as C
+    import aocr
+    from aocr import check, lib
+    m, O, ocfg, P, st, batch = make(dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True), B=32, W=72, maxlen=5, compute="bf16",
+                                    max_decoder_l=8, max_beam=1)
+    m.train_forward_backward(batch)
+    p = C.c_void_p(); nd = C.c_int32(); shape = (C.c_int64 * 4)()
+    check(lib.aocr_get_tensor(m._h, b"cl_err", C.byref(p), C.byref(nd), shape))
+    off = p.value - m.workspace.data_ptr()
+    flag = m.workspace[off:off + 4].view(torch.int32)
+    before = m.params.clone()
+    flag.fill_(23)                                                  # "dq raise/wait timed out"
+    m.sgd_step(lr=0.1)
+    m.adadelta_step()
+    torch.cuda.synchronize()
+    assert torch.equal(m.params, before), "the update ran on gradients flagged invalid"
+    assert m.cluster_status() == 23 and m.cluster_status() == 0     # read and clear
+    m.sgd_step(lr=0.1)
+    torch.cuda.synchronize()
+    assert not torch.equal(m.params, before)
+    with pytest.raises(RuntimeError):
+        flag.fill_(11); m.check_health()
+    m.shutdown()
