@@ -25,6 +25,10 @@ WORKLOADS = {
     "c3": dict(B=256, W=256, L=24, He=256, Le=1, Ld=2, compute="bf16", name="32x256 crops, batch 256/GPU, VGG-7 + BiLSTM(256) + 2-layer attn decoder, L=24"),
     "c2": dict(B=64, W=100, L=24, He=256, Le=1, Ld=2, compute="f32", name="32x100 crops, batch 64/GPU, VGG-7 + BiLSTM(256) + 2-layer attn decoder, L=24"),
     "ref": dict(B=400, W=100, L=24, He=512, Le=1, Ld=2, compute="bf16", name="32x100 crops, batch 400/GPU, VGG-7 + BiLSTM(512) + 2-layer attn decoder (train.lua defaults), L=24"),
+    # BASELINE.json configs[3]: variable-width crops 32x{64..800} in width buckets (data_gen.lua:91-99 emits one width per batch), 64 lines per GPU
+    # (global batch 512 on 8 GPUs); every step draws its bucket from a fixed seeded sequence, so the FLOPs per step vary: mean reported
+    "c4": dict(B=64, W=800, L=24, He=256, Le=1, Ld=2, compute="bf16", widths=list(range(64, 801, 32)),
+               name="32x{64..800} crops in 24 width buckets, batch 64/GPU, VGG-7 + BiLSTM(256) + 2-layer attn decoder, L=24"),
     # BASELINE.json configs[4]: 128x1024 full-line strips (the CNN leaves 7 x 255 feature positions: T = 1785), 2-layer BiLSTM(512), beam-5 decode
     "c5": dict(B=16, W=1024, H=128, L=24, He=512, Le=2, Ld=2, compute="bf16", beam=5, name="128x1024 strips, batch 16/GPU, VGG-7 + 2-layer BiLSTM(512) + 2-layer attn decoder, L=24, beam-5 decode"),
 }
@@ -199,7 +203,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    bucket_imgs = None
+    if wl.get("widths"):                                # c4: one pre-generated batch per width bucket, visited in a fixed seeded order
+        order = np.random.default_rng(4321).permutation(len(wl["widths"]))
+        bucket_imgs = []
+        for wi in order:
+            bi, _, _, _ = aocr.synth.synth_batch(B, wl["widths"][wi], seed=1234 + rank, max_len=L - 1, H=IMG_H)
+            bucket_imgs.append(torch.from_numpy(bi).to(device=dev, dtype=torch.float32))
+    step_no = [0]
+
     def step():
+        if bucket_imgs is not None:
+            im = bucket_imgs[step_no[0] % len(bucket_imgs)]; step_no[0] += 1
+            return m.train_step_device(im, targets, targets_eval)
         return m.train_step_device(images, targets, targets_eval)
 
     def healthy() -> bool:
@@ -261,6 +277,9 @@ def main():
         replica_drift = float((hi - lo).item())
 
     fl = flops(W, wl["He"], wl["Le"], wl["Ld"], L, H=IMG_H)
+    if wl.get("widths"):                                # mean over the buckets (every bucket is visited equally often over a whole cycle)
+        per = [flops(w_, wl["He"], wl["Le"], wl["Ld"], L, H=IMG_H) for w_ in wl["widths"]]
+        fl = {k: sum(p_[k] for p_ in per) / len(per) for k in per[0]}
     peak = PEAK[wl["compute"]]
     # ---- per-family HIP-event timing of one step (library marks, include/aocr.h AOCR_PROF_*).  EVERY rank runs the profiled steps (a step
     # contains the gradient all-reduce and the synchronised BatchNorm sums: a rank that skipped them would leave the others waiting);

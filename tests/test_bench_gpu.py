@@ -40,5 +40,7 @@ def test_bench_line_contract(cuda):
 def test_bench_other_workloads_run(cuda):
     d = _run("--workload", "c2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--decode-steps", "0", "--sustain-seconds", "0")
     assert d["dtype"] == "f32" and d["roofline"]["peak"] == 157.3 and d["config"]["img"] == "32x100"
+    d = _run("--workload", "c4", "--steps", "24", "--warmup", "2", "--no-cpu-baseline", "--no-secondary", "--decode-steps", "0", "--sustain-seconds", "0")
+    assert d["config"]["per_gpu_batch"] == 64 and d["cluster_fallback"] is False and d["value"] > 1000
     d = _run("--dropout", "0.3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--decode-steps", "0", "--sustain-seconds", "0")
     assert d["dropout"] == 0.3 and d["cluster_fallback"] is False

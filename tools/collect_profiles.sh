@@ -11,6 +11,7 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --decode-steps 0 --no-secondary --sustain-seconds 0 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -- python $R/bench.py --workload c2 --steps 10 --warmup 3 --no-cpu-baseline --sustain-seconds 1 > $O/bench_c2.log 2>&1
 timeout 300 python $R/bench.py --workload c5 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --sustain-seconds 1 > $O/bench_c5.json 2> $O/bench_c5.err
+timeout 300 python $R/bench.py --workload c4 --steps 48 --warmup 24 --no-cpu-baseline --no-secondary --sustain-seconds 1 > $O/bench_c4.json 2> $O/bench_c4.err
 timeout 300 python $R/bench.py --workload ref --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --sustain-seconds 1 > $O/bench_ref.json 2> $O/bench_ref.err
 cd $R
 f=$(ls $O/pmc_fetch/*/*counter_collection.csv | head -1); w=$(ls $O/pmc_write/*/*counter_collection.csv | head -1)
