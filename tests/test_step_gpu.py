@@ -284,6 +284,63 @@ def test_seq_encoder_kernels_match_step_kernels(cuda, monkeypatch, He, B, W, Le)
         print(f"[parity] {name}-vs-step worst gradient rel {worst:.3e}")
 
 
+@pytest.mark.parametrize("He,B,W,Le,chunks,p", [(64, 16, 44, 2, 3, 0.0), (256, 16, 100, 2, 4, 0.0), (512, 40, 52, 2, 5, 0.0), (128, 21, 60, 3, 2, 0.0),
+                                                 (512, 16, 804, 2, 0, 0.0),          # chunks = 0: the production choice (T = 200: 4 chunks)
+                                                 (256, 16, 60, 2, 3, 0.3), (64, 35, 44, 3, 11, 0.2)])   # dropout between the layers; one step per chunk
+def test_encoder_layer_wavefront_matches_sequential(cuda, monkeypatch, capfd, He, B, W, Le, chunks, p):
+    """Stacked encoder (Le >= 2, BASELINE C5): the layers run as a wavefront of sequence chunks on separate streams (model.hip
+    encoder_forward_pipe / encoder_backward_pipe: layer l starts chunk c when layer l-1 has finished it; the cluster kernels take an
+    iteration range and pick c / bf16 h / d c / bf16 d z of the iteration before from the state slots) against the same kernels run
+    layer after layer (AOCR_NO_LAYER_PIPE=1).  The arithmetic is the same: context and logits bit-identical; gradients up to the order
+    of the fp32 atomics of the split-K weight gradients and of the bias sums.  With p > 0 the cluster path also has to agree with the
+    per-step kernels (the masked input of layer l is made from the bf16 h of layer l-1: the cluster kernels write no fp32 h)."""
+    cfg = dict(enc_hidden=He, enc_layers=Le, dec_layers=2, input_feed=True)
+    out = {}
+    variants = {"pipe": {"AOCR_LAYER_PIPE_CHUNKS": str(chunks)} if chunks else {}, "seq": {"AOCR_NO_LAYER_PIPE": "1"}}
+    if p > 0:
+        variants["step"] = {"AOCR_NO_SEQ": "1"}
+    for name, env in variants.items():
+        for k in ("AOCR_LAYER_PIPE_CHUNKS", "AOCR_NO_LAYER_PIPE", "AOCR_NO_SEQ"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setenv("AOCR_TRACE", "1")
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=6, compute="bf16")
+        if p > 0:
+            m.dropout = p; m.global_step = 5
+        capfd.readouterr()
+        loss = m.train_forward_backward(batch)
+        err = capfd.readouterr().err
+        assert ("layer wavefront" in err) == (name == "pipe"), err[-2000:]
+        loss2 = m.train_forward_backward(batch)                 # again on the same model: new launch epochs, re-recorded events
+        if p == 0:
+            assert loss2 == pytest.approx(loss, rel=1e-5)       # (p > 0: a repeated step draws another mask, the same one in every variant)
+        assert int(m.get_tensor("cl_err").view(torch.int32)[0]) == 0, "a cluster kernel timed out waiting for its group"
+        out[name] = dict(loss=loss2, context=m.get_tensor("context").clone(), logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(),
+                         dfeats=m.get_tensor("dfeats").clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.shutdown()
+    a, b = out["seq"], out["pipe"]
+    assert torch.equal(a["context"], b["context"]) and torch.equal(a["logits"], b["logits"]) and a["loss"] == b["loss"]
+    e = relerr(b["dfeats"], a["dfeats"]); print(f"[parity] layer wavefront He={He} B={B} Le={Le} chunks={chunks}: dfeats rel {e:.3e}"); assert e < 1e-4
+    worst = ("", 0.0)
+    for k in a["grads"]:
+        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):
+            continue
+        x = relerr(b["grads"][k], a["grads"][k])
+        if x > worst[1]: worst = (k, x)
+        assert x < 1e-4, (k, x)
+    print(f"[parity] layer wavefront vs sequential: worst gradient rel {worst[1]:.3e} ({worst[0]})")
+    if p > 0:
+        c = out["step"]
+        e = (c["context"].double() - a["context"].double()).abs().max().item()
+        print(f"[parity] dropout p={p} Le={Le}: cluster vs per-step context max-abs {e:.3e}, loss {a['loss']:.5f} vs {c['loss']:.5f}")
+        assert e < 5e-3 and abs(a["loss"] - c["loss"]) < 2e-3 * max(1.0, abs(c["loss"]))
+        for k in a["grads"]:
+            if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):
+                continue
+            assert relerr(a["grads"][k], c["grads"][k]) < 4e-2, k
+
+
 @pytest.mark.parametrize("He,B,W", [(256, 8, 416), (256, 8, 800), (256, 4, 1100), (512, 8, 100), (512, 8, 420), (512, 4, 600)])
 def test_attention_bf16_general_T_matches_generic(cuda, monkeypatch, He, B, W):
     """attn_bf16_kernel (bf16 context shadow; register-resident slice for T <= 256 at Hd = 512 / T <= 128 at Hd = 1024, two streamed

@@ -140,7 +140,7 @@ int aocr_model_create(const aocr_config* cfg, float* params_dev, float* grads_de
   }
   if (m->cl_xbuf) {                                     // tags start at epoch 1: the exchange buffers must not hold a stale match
     hipMemsetAsync(m->cl_xbuf, 0, m->cl_xbytes, m->s); hipMemsetAsync(m->cl_pbuf, 0, m->cl_pbytes, m->s); hipMemsetAsync(m->cl_err, 0, 64, m->s);
-    hipMemsetAsync(m->cl_xtab, 0, ((size_t)2 * ((cfg->batch_size + 15) / 16) * 8 + 64) * 8, m->s);
+    hipMemsetAsync(m->cl_xtab, 0, m->cl_tbytes, m->s);
     if (m->dc_xbuf) { hipMemsetAsync(m->dc_xbuf, 0, m->dc_xbytes, m->s); hipMemsetAsync(m->dc_xtab, 0, m->dc_tbytes, m->s); hipMemsetAsync(m->dc_bxbuf, 0, m->dc_bxbytes, m->s); }
   }
   for (int i = 0; i < 4; ++i)
@@ -157,6 +157,8 @@ int aocr_model_destroy(aocr_model* m) {
   if (m && m->side_go) hipEventDestroy(m->side_go);
   if (m && m->side_done) hipEventDestroy(m->side_done);
   if (m) for (hipEvent_t e : m->prof_ev) hipEventDestroy(e);
+  if (m) for (hipStream_t ls : m->lay_s) if (ls) { hipStreamSynchronize(ls); hipStreamDestroy(ls); }
+  if (m) for (hipEvent_t e : m->lay_ev) hipEventDestroy(e);
   if (m) comm_destroy(m);
   delete m; return 0;
 }

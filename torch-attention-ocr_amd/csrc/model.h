@@ -73,7 +73,7 @@ struct aocr_model {
   aocr::bf16_t *Xb, *ehs_b[2][aocr::MAXL], *edz_b[2][aocr::MAXL], *dhs_b[aocr::MAXL], *ddz_b[aocr::MAXL], *out_b, *cat_b, *dpre_b, *dq_b;
   void* bn_scratch; float* bn_save;
   // encoder [dir][layer]
-  float *ezx[2][aocr::MAXL], *ehs[2][aocr::MAXL], *ecs[2][aocr::MAXL], *egates[2][aocr::MAXL], *edz[2][aocr::MAXL], *edc[2];
+  float *ezx[2][aocr::MAXL], *ehs[2][aocr::MAXL], *ecs[2][aocr::MAXL], *egates[2][aocr::MAXL], *edz[2][aocr::MAXL], *edc[2][aocr::MAXL];
   float *edxl[2];
   float *context, *dctx;
   aocr::bf16_t* context_b;        // bf16 shadow of the context for the attention kernels (bf16 mode)
@@ -92,12 +92,14 @@ struct aocr_model {
   std::vector<aocr::ShadowJob> shadow_host;   // bf16 mode: job table of the one-launch weight shadow refresh
   aocr::ShadowJob* shadow_dev; int shadow_tiles;
   hipEvent_t grad_ev[4];          // gradient-ready points of the backward pass (aocr_grad_buckets)
+  // stacked encoder (Le >= 2): the layers run as a wavefront of sequence chunks, layer l on lay_s[l] (layer 0 / the top layer of the BPTT on the main stream)
+  hipStream_t lay_s[aocr::MAXL] = {}; std::vector<hipEvent_t> lay_ev;
   hipStream_t side = nullptr; hipEvent_t side_go = nullptr, side_done = nullptr; bool side_busy = false;   // side stream of the backward pass (model.hip: decoder_backward)
   int64_t conv5_off;              // offset of cnn.conv5.w in the flat vectors: the CNN group is split there
   aocr::Dims last;                // dims of the last step (for the parity taps)
   int last_valid;
   // cluster encoder kernels (rnn_cluster.hip): exchange buffers, error flag, launch epoch (tags = epoch * 4096 + step)
-  unsigned long long *cl_xbuf = nullptr, *cl_pbuf = nullptr, *cl_xtab = nullptr; int* cl_err = nullptr; size_t cl_xbytes = 0, cl_pbytes = 0; unsigned cl_epoch = 0;
+  unsigned long long *cl_xbuf = nullptr, *cl_pbuf = nullptr, *cl_xtab = nullptr; int* cl_err = nullptr; size_t cl_xbytes = 0, cl_pbytes = 0, cl_tbytes = 0; unsigned cl_epoch = 0;
   unsigned long long *dc_xbuf = nullptr, *dc_xtab = nullptr; size_t dc_xbytes = 0, dc_tbytes = 0; aocr::bf16_t* ctxa_b = nullptr; bool ctxa_fresh = false; /* ctxa_b holds ctx W_a of the CURRENT context (set by the beam pass, consumed by the gold pass of the same decode call) */ bool dgates_il = false; unsigned long long* dc_bxbuf = nullptr; size_t dc_bxbytes = 0; float* dc_pbuf = nullptr;
   // nn.Dropout (LSTM.lua:68-69,116-118), training only: p, threshold ceil(p 2^53), seed, train-step counter; masked copies of the
   // inputs of the layers above the first (decoder per step: dhm, encoder per layer: ehm)

@@ -124,7 +124,8 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
       m->ecs[dir][l] = a.get<float>((T + 2) * B * He); m->egates[dir][l] = a.get<float>(T * B * 4 * He);
       m->edz[dir][l] = a.get<float>(T * B * 4 * He);
     }
-    m->edc[dir] = a.get<float>(B * He); m->edxl[dir] = a.get<float>(T * B * He);
+    for (int l = 0; l < m->Le; ++l) m->edc[dir][l] = a.get<float>(B * He);
+    m->edxl[dir] = a.get<float>(T * B * He);
   }
   m->context = a.get<float>(B * T * Hd); m->dctx = a.get<float>(B * T * Hd);
   m->context_b = m->bf16 ? a.get<bf16_t>(B * T * Hd) : nullptr;
@@ -162,9 +163,11 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
   // split-K slabs of the filter gradients (bf16 mode): one resident round of workgroups x one fp32 tile each = 64 MiB at most
   m->wg_part_floats = m->bf16 ? (size_t)16 << 20 : 0; m->wg_part = m->wg_part_floats ? a.get<float>(m->wg_part_floats) : nullptr;
   if (m->bf16 && He % 64 == 0 && He <= 512) {                    // exchange buffers of the cluster encoder kernels
-    m->cl_xbytes = enc_cluster_xbuf_bytes((int)B, (int)He); m->cl_pbytes = enc_cluster_pbuf_bytes((int)B, (int)He);
+    // one set of group slots per layer: the layers of a stacked encoder run concurrently (layer wavefront, encoder_forward)
+    m->cl_xbytes = m->Le * enc_cluster_xbuf_bytes((int)B, (int)He); m->cl_pbytes = m->Le * enc_cluster_pbuf_bytes((int)B, (int)He);
     m->cl_xbuf = a.get<unsigned long long>(m->cl_xbytes / 8); m->cl_pbuf = a.get<unsigned long long>(m->cl_pbytes / 8);
-    m->cl_xtab = a.get<unsigned long long>((size_t)2 * ((B + 15) / 16) * 8 + 64);      // XCC ids of the members of every group
+    m->cl_tbytes = ((size_t)m->Le * 2 * ((B + 15) / 16) * 8 + 64) * 8;
+    m->cl_xtab = a.get<unsigned long long>(m->cl_tbytes / 8);      // XCC ids of the members of every group
     m->cl_err = a.get<int>(16 + 256 * 8 + 4096);                 // error flag + the trash slots rows >= B store to + a debugging timeline
     if (Hd == 512 && m->Ld == 2 && m->cfg.input_feed) {          // the decoder loop as one launch (dec_cluster.hip)
       m->dc_xbytes = dec_cluster_xbuf_bytes((int)B); m->dc_tbytes = dec_cluster_xtab_bytes((int)B);
@@ -424,7 +427,7 @@ static bool cluster_ok(const aocr_model* m, int B, int T, int& G, int& RT, int& 
 static unsigned next_epoch(aocr_model* m) {
   if (++m->cl_epoch >= (1u << 20)) {                              // tags would repeat: clear the buffers and start over
     hipMemsetAsync(m->cl_xbuf, 0, m->cl_xbytes, m->s); hipMemsetAsync(m->cl_pbuf, 0, m->cl_pbytes, m->s); m->cl_epoch = 1;
-    hipMemsetAsync(m->cl_xtab, 0, ((size_t)2 * ((m->cfg.batch_size + 15) / 16) * 8 + 64) * 8, m->s);
+    hipMemsetAsync(m->cl_xtab, 0, m->cl_tbytes, m->s);
     if (m->dc_xbuf) { hipMemsetAsync(m->dc_xbuf, 0, m->dc_xbytes, m->s); hipMemsetAsync(m->dc_xtab, 0, m->dc_tbytes, m->s); hipMemsetAsync(m->dc_bxbuf, 0, m->dc_bxbytes, m->s); }
   }
   return m->cl_epoch;
@@ -439,11 +442,104 @@ static DropSpec drop_site(const aocr_model* m, int site, long long off) {
   return d;
 }
 
+// ---- layer wavefront of a stacked encoder (Le >= 2) ----------------------------------------------------------------------------
+// The fw / bw stacks are independent (model.lua:291-316: layer l of a direction reads only layer l-1 of the SAME direction), and a
+// cluster launch keeps 2 x groups x He/64 compute units busy (C5: 16 of 256) for T latency-bound steps.  So the sequence is cut into
+// C chunks of iterations and layer l runs chunk c (its hoisted input GEMM over the chunk's rows, then the cluster kernel with
+// it0 / it1) on its own stream as soon as layer l-1 has finished chunk c: Le layers take (C + Le - 1) / C sequence times instead of Le.
+// State crosses the chunk boundary through the slots the kernels write anyway (c, bf16 h; d c, bf16 d z on the way back).
+// Off under the family profile (prof_on: one stream), AOCR_NO_LAYER_PIPE=1, or when the layers' groups do not fit the chip at once.
+// AOCR_LAYER_PIPE_CHUNKS=n forces the chunk count (tests: short sequences).
+static int layer_pipe_chunks(const aocr_model* m, int T, int G, int groups) {
+  if (m->Le < 2 || m->prof_on || getenv("AOCR_NO_LAYER_PIPE")) return 0;
+  static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  if (2 * groups * G * m->Le > cus) return 0;
+  int C = std::min(8, T / 48);
+  if (const char* e = getenv("AOCR_LAYER_PIPE_CHUNKS")) C = std::min(atoi(e), T);
+  return C >= 2 ? C : 0;
+}
+static bool layer_pipe_streams(aocr_model* m, int n_events) {
+  for (int l = 1; l < m->Le; ++l)
+    if (!m->lay_s[l] && hipStreamCreateWithFlags(&m->lay_s[l], hipStreamNonBlocking) != hipSuccess) { m->lay_s[l] = nullptr; return false; }
+  while ((int)m->lay_ev.size() < n_events) {
+    hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+    m->lay_ev.push_back(e);
+  }
+  return true;
+}
+// the exchange buffers are cleared on the main stream when the launch epochs wrap: never while another stream is inside a cluster kernel
+static void reserve_epochs(aocr_model* m, unsigned n) { if (m->cl_epoch + n + 1 >= (1u << 20)) { m->cl_epoch = (1u << 20); (void)next_epoch(m); } }
+
+static void encoder_forward_pipe(aocr_model* m, const Dims& d, int C, int clG, int clRT, int clGroups) {
+  hipStream_t s0 = m->s;
+  const int B = d.B, T = d.T, He = m->He, Hd = m->Hd, Le = m->Le;
+  const size_t slot = (size_t)B * He;
+  for (int l = 0; l < Le; ++l) {                          // zero initial states of every layer; layer 0's input part for the whole sequence
+    ZeroList zl;
+    for (int dir = 0; dir < 2; ++dir) {
+      zl.add(m->ehs[dir][l], slot * sizeof(float)); zl.add(m->ehs[dir][l] + (size_t)(T + 1) * slot, slot * sizeof(float));
+      zl.add(m->ecs[dir][l], slot * sizeof(float)); zl.add(m->ecs[dir][l] + (size_t)(T + 1) * slot, slot * sizeof(float));
+      zl.add(m->ehs_b[dir][l], slot * sizeof(bf16_t)); zl.add(m->ehs_b[dir][l] + (size_t)(T + 1) * slot, slot * sizeof(bf16_t));
+    }
+    zero_many(s0, zl);
+  }
+  for (int dir = 0; dir < 2; ++dir) {
+    const LstmP& p = m->enc[dir][0];
+    gemm_hh(s0, m->Xb, p.in, p.swi.wb, p.in, m->ezx[dir][0], 4 * He, T * B, 4 * He, p.in, p.bi, p.bh, 0);
+  }
+  reserve_epochs(m, (unsigned)(C * Le));
+  hipEvent_t* ev = m->lay_ev.data();                       // [l * C + c]: layer l finished chunk c; [Le * C + l]: joins
+  hipEventRecord(ev[Le * C], s0);
+  for (int l = 1; l < Le; ++l) hipStreamWaitEvent(m->lay_s[l], ev[Le * C], 0);
+  const int Tc = (T + C - 1) / C;
+  for (int c = 0; c < C; ++c) {
+    const int it0 = c * Tc, it1 = std::min(T, it0 + Tc);
+    if (it0 >= it1) break;
+    for (int l = 0; l < Le; ++l) {
+      hipStream_t sl = l == 0 ? s0 : m->lay_s[l];
+      if (l > 0) {
+        hipStreamWaitEvent(sl, ev[(l - 1) * C + c], 0);
+        for (int dir = 0; dir < 2; ++dir) {                // the input part of this chunk's steps: t = it (fw) / T-1-it (bw)
+          const LstmP& p = m->enc[dir][l];
+          const int t_lo = dir ? T - it1 : it0, n = it1 - it0;
+          const bf16_t* xinb = m->ehs_b[dir][l - 1] + (size_t)(t_lo + 1) * slot;
+          if (m->drop_on) {                                // LSTM.lua:68-69: x = Dropout(h of the layer below)
+            dropout_apply_b(sl, xinb, m->ehm[dir][l - 1] + (size_t)t_lo * slot, m->ehm_b[dir][l - 1] + (size_t)t_lo * slot, (int64_t)n * slot,
+                            drop_site(m, (dir ? 48 : 32) + l + 1, (long long)t_lo * (long long)slot));
+            xinb = m->ehm_b[dir][l - 1] + (size_t)t_lo * slot;
+          }
+          gemm_hh(sl, xinb, p.in, p.swi.wb, p.in, m->ezx[dir][l] + (size_t)t_lo * B * 4 * He, 4 * He, n * B, 4 * He, p.in, p.bi, p.bh, 0);
+        }
+      }
+      const bool top = l == Le - 1;
+      EncClFwdArgs a; a.B = B; a.T = T; a.He = He; a.Hd = Hd; a.groups = clGroups; a.epoch = next_epoch(m); a.xbuf = m->cl_xbuf; a.err = m->cl_err; a.xtab = m->cl_xtab;
+      a.it0 = it0; a.it1 = it1; a.gslot = l * 2 * clGroups;
+      for (int dir = 0; dir < 2; ++dir) {
+        EncSeqDir& e = a.d[dir];
+        e.w = m->enc[dir][l].swh.wb; e.zx = m->ezx[dir][l]; e.hs = m->ehs[dir][l]; e.cs = m->ecs[dir][l]; e.hsb = m->ehs_b[dir][l];
+        e.gates = m->egates[dir][l]; e.ctx = top ? m->context + dir * He : nullptr; e.reverse = dir;
+      }
+      enc_cluster_forward(sl, a, clG, clRT);
+      if (!top) hipEventRecord(ev[l * C + c], sl);
+    }
+  }
+  for (int l = 1; l < Le; ++l) { hipEventRecord(ev[Le * C + l], m->lay_s[l]); hipStreamWaitEvent(s0, ev[Le * C + l], 0); }
+}
+
 void encoder_forward(aocr_model* m, const Dims& d) {
   m->ctxa_fresh = false;                                             // new context
   hipStream_t s = m->s; const bool bf = m->bf16;
   const int B = d.B, T = d.T, He = m->He, Hd = m->Hd;
   const size_t slot = (size_t)B * He;
+  int clG = 0, clRT = 0, clGroups = 0;
+  const bool cluster = cluster_ok(m, B, T, clG, clRT, clGroups);
+  const int pipeC = cluster ? layer_pipe_chunks(m, T, clG, clGroups) : 0;
+  if (pipeC && layer_pipe_streams(m, (m->Le + 1) * pipeC + m->Le + 1)) {
+    if (getenv("AOCR_TRACE")) fprintf(stderr, "[aocr] encoder forward: cluster kernels, layer wavefront of %d chunks\n", pipeC);
+    encoder_forward_pipe(m, d, pipeC, clG, clRT, clGroups);
+    if (m->context_b) copy2d_bf16(s, m->context, Hd, m->context_b, Hd, B * T, Hd);
+    return;
+  }
   for (int l = 0; l < m->Le; ++l) {
     ZeroList zl;
     for (int dir = 0; dir < 2; ++dir) {
@@ -452,6 +548,9 @@ void encoder_forward(aocr_model* m, const Dims& d) {
       const bf16_t* xinb = l == 0 ? m->Xb : (m->ehs_b[dir][l - 1] ? m->ehs_b[dir][l - 1] + slot : nullptr);
       prof_mark(m, AOCR_PROF_RNN_GEMM);
       if (l > 0 && m->drop_on) {                                           // LSTM.lua:68-69: x = Dropout(h of the layer below)
+        if (cluster && xinb)                                               // the cluster kernels write h as bf16 only (the fp32 slots stay empty)
+          dropout_apply_b(s, xinb, m->ehm[dir][l - 1], m->ehm_b[dir][l - 1], (int64_t)T * B * He, drop_site(m, (dir ? 48 : 32) + l + 1, 0));
+        else
         dropout_apply(s, xin, m->ehm[dir][l - 1], m->ehm_b[dir][l - 1], (int64_t)T * B * He, drop_site(m, (dir ? 48 : 32) + l + 1, 0));
         xin = m->ehm[dir][l - 1]; xinb = m->ehm_b[dir][l - 1];
       }
@@ -470,8 +569,6 @@ void encoder_forward(aocr_model* m, const Dims& d) {
     zero_many(s, zl);
     prof_mark(m, AOCR_PROF_ENC_SEQ);
     const bool top = l == m->Le - 1;
-    int clG = 0, clRT = 0, clGroups = 0;
-    const bool cluster = cluster_ok(m, B, T, clG, clRT, clGroups);
     if (getenv("AOCR_TRACE")) fprintf(stderr, "[aocr] encoder layer %d forward: %s kernels\n", l, cluster ? "cluster" : seq_kernels_ok(m, B) ? "whole-sequence" : "per-step");
     if (cluster) {                                        // groups of He/64 CUs, recurrent weights resident in registers
       EncClFwdArgs a; a.B = B; a.T = T; a.He = He; a.Hd = Hd; a.groups = clGroups; a.epoch = next_epoch(m); a.xbuf = m->cl_xbuf; a.err = m->cl_err; a.xtab = m->cl_xtab;
@@ -521,16 +618,97 @@ void encoder_forward(aocr_model* m, const Dims& d) {
 
 // BPTT through both encoder directions, model.lua:662-690.  On entry dc_st[0] / dh_rec[0] of the decoder hold
 // d c1(0) / d h1(0) (quirk S5: d h1(0) is passed on even when h1(0) was zeroed in the forward pass).
+// the layer wavefront on the way back (see encoder_forward_pipe): the top layer on the main stream, layer l on lay_s[Le-1-l]; layer l
+// starts chunk c when layer l+1's d x of that chunk (GEMM over the chunk's rows) is complete.  The weight gradients (and layer 0's d x)
+// need the whole sequence: behind the layer's last chunk, on its stream.
+static void encoder_backward_pipe(aocr_model* m, const Dims& d, int C, int clG, int clRT, int clGroups) {
+  hipStream_t s0 = m->s;
+  const int B = d.B, T = d.T, He = m->He, Hd = m->Hd, Le = m->Le;
+  const size_t slot = (size_t)B * He;
+  for (int dir = 0; dir < 2; ++dir)
+    for (int l = 0; l < Le; ++l) {
+      if (l == Le - 1) copy2d(s0, m->dc_st[0] + dir * He, Hd, m->edc[dir][l], He, B, He);        // model.lua:666,680
+      else hipMemsetAsync(m->edc[dir][l], 0, slot * sizeof(float), s0);
+    }
+  reserve_epochs(m, (unsigned)(C * Le));
+  hipEvent_t* ev = m->lay_ev.data();
+  hipEventRecord(ev[Le * C], s0);
+  for (int l = 1; l < Le; ++l) hipStreamWaitEvent(m->lay_s[l], ev[Le * C], 0);
+  auto stream_of = [&](int l) { return l == Le - 1 ? s0 : m->lay_s[Le - 1 - l]; };
+  const int Tc = (T + C - 1) / C;
+  for (int c = 0; c < C; ++c) {
+    const int it0 = c * Tc, it1 = std::min(T, it0 + Tc);
+    if (it0 >= it1) break;
+    for (int l = Le - 1; l >= 0; --l) {
+      hipStream_t sl = stream_of(l);
+      const bool top = l == Le - 1;
+      if (!top) hipStreamWaitEvent(sl, ev[(l + 1) * C + c], 0);
+      EncClBwdArgs a; a.B = B; a.T = T; a.He = He; a.groups = clGroups; a.epoch = next_epoch(m); a.pbuf = m->cl_pbuf; a.err = m->cl_err; a.xtab = m->cl_xtab;
+      a.it0 = it0; a.it1 = it1; a.gslot = l * 2 * clGroups;
+      for (int dir = 0; dir < 2; ++dir) {
+        EncSeqBwdDir& e = a.d[dir];
+        e.wt = m->enc[dir][l].swh.wtb;
+        if (top) { e.dh1 = m->dctx + dir * He; e.dh1_row = (int64_t)T * Hd; e.dh1_t = Hd; }      // model.lua:670,684
+        else { e.dh1 = m->edxl[dir]; e.dh1_row = He; e.dh1_t = (int64_t)slot; }
+        e.dh2 = top ? m->dh_rec[0] + dir * He : nullptr; e.dh2_row = Hd;                            // model.lua:667,681
+        e.dc = m->edc[dir][l]; e.gates = m->egates[dir][l]; e.cs = m->ecs[dir][l];
+        e.dz = m->edz[dir][l]; e.dzb = m->edz_b[dir][l]; e.forward_dir = dir == 0;
+        e.dbi = m->enc[dir][l].dbi; e.dbh = m->enc[dir][l].dbh;
+      }
+      enc_cluster_backward(sl, a, clG, clRT);
+      if (l > 0) {
+        for (int dir = 0; dir < 2; ++dir) {                // d x of this chunk's steps: t = T-1-it (the fw direction's BPTT) / it
+          const LstmP& p = m->enc[dir][l];
+          const int t_lo = dir == 0 ? T - it1 : it0, n = it1 - it0;
+          float* dxo = m->edxl[dir] + (size_t)t_lo * slot;
+          gemm_hh(sl, m->edz_b[dir][l] + (size_t)t_lo * B * 4 * He, 4 * He, p.swi.wtb, 4 * He, dxo, p.in, n * B, p.in, 4 * He, nullptr, nullptr, 0);
+          if (m->drop_on) dropout_apply(sl, dxo, dxo, nullptr, (int64_t)n * slot, drop_site(m, (dir ? 48 : 32) + l + 1, (long long)t_lo * (long long)slot));     // Dropout backward
+        }
+        hipEventRecord(ev[l * C + c], sl);
+      }
+    }
+  }
+  for (int l = Le - 1; l >= 0; --l) {
+    hipStream_t sl = stream_of(l);
+    WGradProblem wg[4]; int nwg = 0;
+    for (int dir = 0; dir < 2; ++dir) {
+      const LstmP& p = m->enc[dir][l];
+      const float* xin = l == 0 ? m->X : m->ehs[dir][l - 1] + slot;
+      const float* hprev = m->ehs[dir][l] + (dir == 0 ? 0 : 2 * slot);
+      const bf16_t* dzb = m->edz_b[dir][l];
+      const bf16_t* xinb = l == 0 ? m->Xb : m->ehs_b[dir][l - 1] + slot;
+      const bf16_t* hprevb = m->ehs_b[dir][l] + (dir == 0 ? 0 : 2 * slot);
+      if (l > 0 && m->drop_on) { xin = m->ehm[dir][l - 1]; xinb = m->ehm_b[dir][l - 1]; }          // the layer saw the masked input
+      wg[nwg++] = WGradProblem{m->edz[dir][l], 4 * He, xin, p.in, p.dwi, p.in, 4 * He, p.in, T * B, dzb, xinb};
+      wg[nwg++] = WGradProblem{m->edz[dir][l], 4 * He, hprev, He, p.dwh, He, 4 * He, He, T * B, dzb, hprevb};
+      if (l == 0) gemm_hh(sl, dzb, 4 * He, p.swi.wtb, 4 * He, m->dX, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dir == 1 ? EP_ACCUM : 0);   // model.lua:675 copy, :689 add
+    }
+    grouped_wgrad(sl, true, wg, nwg);
+  }
+  for (int l = 1; l < Le; ++l) { hipEventRecord(ev[Le * C + l], m->lay_s[l]); hipStreamWaitEvent(s0, ev[Le * C + l], 0); }
+}
+
 static void encoder_backward(aocr_model* m, const Dims& d) {
   hipStream_t s = m->s; const bool bf = m->bf16;
   const int B = d.B, T = d.T, He = m->He, Hd = m->Hd;
   const size_t slot = (size_t)B * He;
+  {
+    int clG = 0, clRT = 0, clGroups = 0;
+    bool cluster = cluster_ok(m, B, T, clG, clRT, clGroups);
+    for (int l = 0; l < m->Le && cluster; ++l) cluster = m->edz_b[0][l] && m->enc[0][l].swh.wtb && m->enc[0][l].swi.wtb;
+    const int pipeC = cluster ? layer_pipe_chunks(m, T, clG, clGroups) : 0;
+    if (pipeC && layer_pipe_streams(m, (m->Le + 1) * pipeC + m->Le + 1)) {
+      if (getenv("AOCR_TRACE")) fprintf(stderr, "[aocr] encoder backward: cluster kernels, layer wavefront of %d chunks\n", pipeC);
+      encoder_backward_pipe(m, d, pipeC, clG, clRT, clGroups);
+      return;
+    }
+  }
   for (int l = m->Le - 1; l >= 0; --l) {
     const bool top = l == m->Le - 1;
     prof_mark(m, AOCR_PROF_ENC_SEQ);
     for (int dir = 0; dir < 2; ++dir) {
-      if (top) copy2d(s, m->dc_st[0] + dir * He, Hd, m->edc[dir], He, B, He);        // model.lua:666,680
-      else hipMemsetAsync(m->edc[dir], 0, slot * sizeof(float), s);
+      if (top) copy2d(s, m->dc_st[0] + dir * He, Hd, m->edc[dir][l], He, B, He);        // model.lua:666,680
+      else hipMemsetAsync(m->edc[dir][l], 0, slot * sizeof(float), s);
     }
     int clG = 0, clRT = 0, clGroups = 0;
     const bool cluster = cluster_ok(m, B, T, clG, clRT, clGroups) && m->edz_b[0][l] && m->enc[0][l].swh.wtb;
@@ -544,7 +722,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
         if (top) { e.dh1 = m->dctx + dir * He; e.dh1_row = (int64_t)T * Hd; e.dh1_t = Hd; }      // model.lua:670,684
         else { e.dh1 = m->edxl[dir]; e.dh1_row = He; e.dh1_t = (int64_t)slot; }
         e.dh2 = top ? m->dh_rec[0] + dir * He : nullptr; e.dh2_row = Hd;                            // model.lua:667,681
-        e.dc = m->edc[dir]; e.gates = m->egates[dir][l]; e.cs = m->ecs[dir][l];
+        e.dc = m->edc[dir][l]; e.gates = m->egates[dir][l]; e.cs = m->ecs[dir][l];
         e.dz = m->edz[dir][l]; e.dzb = m->edz_b[dir][l]; e.forward_dir = dir == 0;
         e.dbi = m->enc[dir][l].dbi; e.dbh = m->enc[dir][l].dbh;
       }
@@ -557,7 +735,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
         if (top) { e.dh1 = m->dctx + dir * He; e.dh1_row = (int64_t)T * Hd; e.dh1_t = Hd; }      // model.lua:670,684
         else { e.dh1 = m->edxl[dir]; e.dh1_row = He; e.dh1_t = (int64_t)slot; }
         e.dh2 = top ? m->dh_rec[0] + dir * He : nullptr; e.dh2_row = Hd;                            // model.lua:667,681
-        e.dc = m->edc[dir]; e.gates = m->egates[dir][l]; e.cs = m->ecs[dir][l];
+        e.dc = m->edc[dir][l]; e.gates = m->egates[dir][l]; e.cs = m->ecs[dir][l];
         e.dz = m->edz[dir][l]; e.dzb = m->edz_b[dir][l]; e.forward_dir = dir == 0;
       }
       enc_seq_backward(s, a);
@@ -577,10 +755,10 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
         if (top) { e.dh1 = m->dctx + (size_t)t * Hd + dir * He; e.ld1 = (int64_t)T * Hd; }    // model.lua:670,684
         else { e.dh1 = m->edxl[dir] + (size_t)t * slot; e.ld1 = He; }
         e.dh2 = (top && i == 0) ? m->dh_rec[0] + dir * He : nullptr; e.ld2 = Hd;               // model.lua:667,681
-        e.dc_in = m->edc[dir]; e.lddc = He;
+        e.dc_in = m->edc[dir][l]; e.lddc = He;
         e.gates = m->egates[dir][l] + (size_t)t * B * 4 * He; e.ldg = 4 * He;
         e.c_prev = m->ecs[dir][l] + prev * slot; e.ldcp = He; e.c = m->ecs[dir][l] + (size_t)(t + 1) * slot; e.ldcc = He;
-        e.dz = dz + (size_t)t * B * 4 * He; e.lddz = 4 * He; e.dc_out = m->edc[dir]; e.lddco = He; e.M = B; e.H = He;
+        e.dz = dz + (size_t)t * B * 4 * He; e.lddz = 4 * He; e.dc_out = m->edc[dir][l]; e.lddco = He; e.M = B; e.H = He;
         if (m->edz_b[dir][l]) { e.dzb = m->edz_b[dir][l] + (size_t)t * B * 4 * He; e.lddzb = 4 * He; }
       }
       run_gates_bwd(m, 2, la, ww, ee, B, He, lah);

@@ -164,7 +164,8 @@ void embedding_scatter_accum(hipStream_t s, const float* demb, const int32_t* to
 void dpre_tanh(hipStream_t s, const float* g1, const float* g2, const float* out, float* dpre, int64_t n, bf16_t* dpreb = nullptr, const DropSpec* drop = nullptr);
 void pointwise(hipStream_t s, int op, const float* a, const float* b, float* y, int64_t n);   // AOCR_PW_* of include/aocr.h
 void u8_to_f32(hipStream_t s, const uint8_t* src, float* dst, int64_t n);
-void dropout_apply(hipStream_t s, const float* src, float* dst, bf16_t* dstb, int64_t n, const DropSpec& drop);  // (g1+g2)*(1-out^2)
+void dropout_apply(hipStream_t s, const float* src, float* dst, bf16_t* dstb, int64_t n, const DropSpec& drop);
+void dropout_apply_b(hipStream_t s, const bf16_t* src, float* dst, bf16_t* dstb, int64_t n, const DropSpec& drop);  // (g1+g2)*(1-out^2)
 void copy2d_bf16(hipStream_t s, const float* src, int64_t lds, bf16_t* dst, int64_t ldd, int rows, int cols);
 void copy2d(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols);
 void sgd_clip_update(hipStream_t s, float* params, float* grads, const int64_t* group_off /*6 host values*/, float lr,
@@ -222,8 +223,8 @@ struct EncSeqBwdDir {
 struct EncSeqBwdArgs { EncSeqBwdDir d[2]; int B, T, He; };
 bool enc_seq_supported(int B, int He, int blocks_limit);
 // ---- the same recurrences on clusters of CUs with register-resident weights (rnn_cluster.hip)
-struct EncClFwdArgs { EncSeqDir d[2]; int B, T, He, Hd, groups; unsigned epoch; unsigned long long* xbuf; int* err; int gid0 = 0, ngid = 0; unsigned long long* xtab = nullptr; int force_remote = 0; };
-struct EncClBwdArgs { EncSeqBwdDir d[2]; int B, T, He, groups; unsigned epoch; unsigned long long* pbuf; int* err; int gid0 = 0, ngid = 0; unsigned long long* xtab = nullptr; int force_remote = 0; };
+struct EncClFwdArgs { EncSeqDir d[2]; int B, T, He, Hd, groups; unsigned epoch; unsigned long long* xbuf; int* err; int gid0 = 0, ngid = 0; unsigned long long* xtab = nullptr; int force_remote = 0; int it0 = 0, it1 = 0 /* iterations [it0, it1) of the T in this launch; it1 = 0: all */, gslot = 0 /* group-slot offset into xbuf / xtab (one set of slots per layer) */; };
+struct EncClBwdArgs { EncSeqBwdDir d[2]; int B, T, He, groups; unsigned epoch; unsigned long long* pbuf; int* err; int gid0 = 0, ngid = 0; unsigned long long* xtab = nullptr; int force_remote = 0; int it0 = 0, it1 = 0, gslot = 0; };
 bool enc_cluster_plan(int B, int He, int T, int cus, int& G, int& RT, int& groups);
 size_t enc_cluster_xbuf_bytes(int B, int He);
 size_t enc_cluster_pbuf_bytes(int B, int He);

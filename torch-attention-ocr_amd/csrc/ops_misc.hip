@@ -1379,6 +1379,17 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restr
 void dropout_apply(hipStream_t s, const float* src, float* dst, bf16_t* dstb, int64_t n, const DropSpec& drop) {
   hipLaunchKernelGGL(dropout_apply_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, src, dst, dstb, n, drop);
 }
+// the same from a bf16 source (the encoder cluster kernels keep h as bf16 only)
+__global__ __launch_bounds__(256) void dropout_apply_b_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, bf16_t* __restrict__ dstb, int64_t n, DropSpec drop) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = (float)src[i] * drop.mask(i);
+  if (dst) dst[i] = v;
+  if (dstb) dstb[i] = (bf16_t)v;
+}
+void dropout_apply_b(hipStream_t s, const bf16_t* src, float* dst, bf16_t* dstb, int64_t n, const DropSpec& drop) {
+  hipLaunchKernelGGL(dropout_apply_b_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, src, dst, dstb, n, drop);
+}
 // several small regions zeroed by ONE launch (each hipMemsetAsync is its own ~5 us dispatch on the step's critical path)
 __global__ __launch_bounds__(256) void zero_many_kernel(ZeroList z) {
   unsigned char* p = (unsigned char*)z.p[blockIdx.y];

@@ -129,9 +129,13 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
   f32x4 cst[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) cst[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  u64* const xg = p.xbuf + (size_t)gid * 2 * G * R * 32;         // [parity][member][row][32 granules]
+  u64* const xg = p.xbuf + (size_t)(gid + p.gslot) * 2 * G * R * 32;         // [parity][member][row][32 granules]
   float* const trash = reinterpret_cast<float*>(p.err + 16) + (threadIdx.x & 255) * 4;   // rows >= B store here
-  const bool local = group_is_local<G>(p.xtab + (size_t)gid * 8, member, p.epoch, p.err) && !p.force_remote;
+  const bool local = group_is_local<G>(p.xtab + (size_t)(gid + p.gslot) * 8, member, p.epoch, p.err) && !p.force_remote;
+  // This launch runs iterations it0 .. it1-1 of the T (a CHUNK of the sequence: model.hip runs the layers of a stacked encoder as a
+  // wavefront of chunks on separate streams).  A chunk that does not start the sequence takes c and h of the iteration before from the
+  // state slots the previous chunk's launch wrote.
+  const int it0 = p.it0, it1 = p.it1 > 0 ? p.it1 : T;
 
   auto dma_zx = [&](int t) {                                     // RT * 4 LDS-DMA loads: the input part of step t for this lane's cells
 #pragma unroll
@@ -141,7 +145,18 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
       for (int g = 0; g < 4; ++g) cl_dma16(d.zx + ((size_t)t * B + row) * 4 * He + g * He + u0, zxl + (rt * 4 + g) * 1024);
     }
   };
-  dma_zx(d.reverse ? T - 1 : 0);
+  dma_zx(d.reverse ? T - 1 - it0 : it0);
+  if (it0 > 0) {
+    const int tp = d.reverse ? T - it0 : it0 - 1;               // the step of iteration it0 - 1: its state is in slot tp + 1
+    unsigned char* const hb = hbuf + (size_t)(it0 & 1) * R * HP;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) { const int row = min(row0 + 16 * rt + c16, B - 1); cst[rt] = *reinterpret_cast<const f32x4*>(d.cs + ((size_t)(tp + 1) * B + row) * He + u0); }
+    for (int x = threadIdx.x; x < R * (He / 8); x += 256) {
+      const int rr = x / (He / 8), k8 = x - rr * (He / 8), row = min(row0 + rr, B - 1);
+      *reinterpret_cast<u32x4*>(hb + (size_t)rr * HP + k8 * 16) = *reinterpret_cast<const u32x4*>(d.hsb + ((size_t)(tp + 1) * B + row) * He + k8 * 8);
+    }
+    __syncthreads();
+  }
   wait_vm<0>();
   __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0) the compiler can see: no wait of its own for the prologue loads inside the loop
   f32x4 gat[RT][4], hh[RT], cc[RT];                              // outputs of the step before ([unit i] = {in, forget, out, g}), stored one step late
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
   };
   bool dead = false;
 
-  for (int it = 0; it < T && !dead; ++it) {
+  for (int it = it0; it < it1 && !dead; ++it) {
     const int t = d.reverse ? T - 1 - it : it;
     const int tprev = d.reverse ? t + 1 : t - 1;
     f32x4 acc[RT][4];
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
       for (int g = 0; g < 4; ++g) acc[rt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned tag = p.epoch * 4096u + (unsigned)it;
     const u64* xp = xg + (size_t)((it - 1) & 1) * G * R * 32 + c16 * 32 + 4 * q;
-    if (it > 0) {
+    if (it > it0) {
       // ---- all-gather of h(t-1), shared by the four waves: the 2G (member, k-step) pieces are dealt to the waves (piece x = wave + 4 j),
       // each wave polls its pieces (2 RT loads of 16 bytes per lane and piece), drops the bf16 payload into LDS as the B operand
       // [row][k], and after ONE barrier every wave reads its fragments for all of K.  LDS alternates with the step parity.
@@ -232,6 +247,9 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
       __syncthreads();
       dead = __syncthreads_or(dead);                             // a timeout anywhere in the workgroup stops all of it
       if (dead) break;
+    }
+    if (it > 0) {                                                // (the first iteration of a later chunk: h(t-1) was put into LDS by the prologue)
+      const unsigned char* const hb = hbuf + (size_t)(it & 1) * R * HP;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -259,16 +277,16 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
         const float cn = fg * cst[rt][i] + ig * gg;
         cst[rt][i] = cn; cc[rt][i] = cn; hh[rt][i] = og * tanhf_(cn); gat[rt][i] = f32x4{ig, fg, og, gg};
       }
-      if (it + 1 < T) {
+      if (it + 1 < it1) {
         const u32x4 gv = {bf16_bits(hh[rt][0]) | (bf16_bits(hh[rt][1]) << 16), tagn, bf16_bits(hh[rt][2]) | (bf16_bits(hh[rt][3]) << 16), tagn};
         st_granules(xw + (size_t)(16 * rt + c16) * 32, gv, local);
       }
     }
-    dma_zx(it + 1 < T ? (d.reverse ? t - 1 : t + 1) : t);        // the next step's input part: issued behind the granules, older than the next polls
+    dma_zx(it + 1 < it1 ? (d.reverse ? t - 1 : t + 1) : t);        // the next step's input part: issued behind the granules, older than the next polls
   }
   wait_vm<0>();
   if (!dead) {                                                   // the last step's outputs + its fp32 h (the decoder's initial state reads it)
-    const int tl = d.reverse ? 0 : T - 1;
+    const int tl = d.reverse ? T - it1 : it1 - 1;
     store_outputs(tl);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) { const int row = row0 + 16 * rt + c16; if (row < B) *reinterpret_cast<f32x4*>(d.hs + ((size_t)(tl + 1) * B + row) * He + u0) = hh[rt]; }
@@ -342,8 +360,9 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
       x.dh[rt] = *reinterpret_cast<const f32x4*>(pl + 6 * 1024);
     }
   };
-  u64* const pb = p.pbuf + (size_t)gid * 2 * G * G * 4 * RT * 256;            // [parity][dest][src][tile][rt][lane][4 granules]
-  const bool local = group_is_local<G>(p.xtab + (size_t)gid * 8, member, p.epoch, p.err) && !p.force_remote;
+  u64* const pb = p.pbuf + (size_t)(gid + p.gslot) * 2 * G * G * 4 * RT * 256;            // [parity][dest][src][tile][rt][lane][4 granules]
+  const bool local = group_is_local<G>(p.xtab + (size_t)(gid + p.gslot) * 8, member, p.epoch, p.err) && !p.force_remote;
+  const int it0 = p.it0, it1 = p.it1 > 0 ? p.it1 : T;          // this launch's chunk of the T iterations (see the forward kernel)
   f32x4 zprev[RT][4];                                            // d z of the step before ([gate][unit i]): stored to HBM one step late
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -362,9 +381,30 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
     }
   };
   bool dead = false;
+  if (it0 > 0) {
+    // a later chunk: d z of the iteration before (written as bf16 by the previous chunk's launch) is this chunk's first B operand, and
+    // is what the first iteration re-stores "one step late" (bf16 -> float -> bf16 is exact)
+    const int tp = d.forward_dir ? T - it0 : it0 - 1;
+    unsigned char* const ab = abuf + (size_t)((it0 - 1) & 1) * R * AP;
+    for (int x = tid; x < R * 32; x += 256) {                    // 16 B pieces: [row][gate][8 pieces of 8 units]
+      const int rr = x >> 5, g = (x >> 3) & 3, k8 = x & 7, row = min(row0 + rr, B - 1);
+      *reinterpret_cast<u32x4*>(ab + (size_t)rr * AP + (g * 64 + k8 * 8) * 2) = *reinterpret_cast<const u32x4*>(d.dzb + ((size_t)tp * B + row) * KG + g * He + 64 * member + k8 * 8);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int row = min(row0 + 16 * rt + c16, B - 1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 zz = *reinterpret_cast<const u32x2*>(d.dzb + ((size_t)tp * B + row) * KG + g * He + u0);
+        zprev[rt][g] = f32x4{__uint_as_float(zz[0] << 16), __uint_as_float(zz[0] & 0xFFFF0000u), __uint_as_float(zz[1] << 16), __uint_as_float(zz[1] & 0xFFFF0000u)};
+      }
+    }
+    __syncthreads();
+  }
   __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0) the compiler can see: no wait of its own for the prologue loads inside the loop
 
-  for (int it = 0; it < T; ++it) {
+  for (int it = it0; it < it1; ++it) {
     const int t = d.forward_dir ? T - 1 - it : it;
     const int tprev = d.forward_dir ? t + 1 : t - 1;
     const unsigned tag = p.epoch * 4096u + (unsigned)it;
@@ -505,7 +545,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
     }
     __syncthreads();                                             // d z(t) complete in LDS
   }
-  store_dz(d.forward_dir ? 0 : T - 1);
+  store_dz(d.forward_dir ? T - it1 : it1 - 1);
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) { const int row = row0 + 16 * rt + c16; if (row < B) *reinterpret_cast<f32x4*>(d.dc + (size_t)row * He + u0) = dcr[rt]; }
   // bias gradients: both Linear layers see the same d z (LSTM.lua:79-88); sum over this lane's steps, then over the 16 rows of the tile
