@@ -434,6 +434,10 @@ int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_p
   float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
   hipEventDestroy(e0); hipEventDestroy(e1);
   *ms_per_launch = ms / iters;
+  if (which == 0 && getenv("AOCR_PROBE")) {
+    unsigned long long pr[8] = {0}; kprobe_read(pr);
+    for (int k = 0; k < 2; ++k) if (pr[4 * k + 1]) fprintf(stderr, "[aocr] probe (%s halo kernel, conv6 forward): K loop of one workgroup %llu shader cycles in %.1f us = %.2f GHz\n", k ? "4-wave" : "8-wave", pr[4 * k], pr[4 * k + 1] / 100.0, pr[4 * k] / (pr[4 * k + 1] * 10.0)), fprintf(stderr, "[aocr]   prologue %.1f us, whole workgroup %.1f us (stores acknowledged)\n", pr[4 * k + 2] / 100.0, pr[4 * k + 3] / 100.0);
+  }
   *flops_per_launch = 2.0 * (double)d.B * d.H4 * d.W2 * 512.0 * (9.0 * 512.0);
   return check_launch("aocr_profile_kernel");
 }

@@ -1019,6 +1019,8 @@ void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t
 // Tile shapes MT x NT (8 waves, every wave 32 MI x 64 outputs): 256 x 256 (2 x 4 waves, MI = 4) for layers with >= 256 output columns;
 // 512 x 128 (4 x 2, MI = 4) and 512 x 64 (8 x 1, MI = 2) for the narrow layers (conv2 forward, the data gradients of conv2 / conv3),
 // whose im2col stream is 4-9x their weight stream: there the halo cuts the L2 -> LDS bytes per step from 32 + 8 KB to 6 + 8 KB.
+// debugging probe of the TAG = 1 instantiations (aocr_profile_kernel under AOCR_PROBE=1): shader cycles / 100 MHz wall ticks of one workgroup's K loop and of the whole workgroup
+static __device__ unsigned long long g_kprobe[8];
 template <int MT> struct HaloGeom { static constexpr int HMAX = MT == 256 ? 36864 : 55296; };   // one halo buffer: (R + 2) (W + 16) 64 B for W in {32, 64, 128}
 
 // (Round 3, measured and removed: all LDS-DMA pieces of a step issued by ONE wave per SIMD -- waves 0-3, six pieces each -- so that the
@@ -1033,6 +1035,7 @@ template <int MT> struct HaloGeom { static constexpr int HMAX = MT == 256 ? 3686
 template <class EP, int SGN, int MT, int NT, int TAG = 0>          // TAG: distinct symbol for aocr_profile_kernel's launches (their own row in rocprofv3 --stats)
 __global__ __launch_bounds__(512, 1)
 void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const bf16_t* zero) {
+  unsigned long long pe0 = 0; if constexpr (TAG == 1) pe0 = wall_clock64();
   constexpr int HMAX = HaloGeom<MT>::HMAX, BSLOT = NT * 64, BRING = 2 * HMAX, DUMP = BRING + 4 * BSLOT, LDS_BYTES = DUMP + 8 * 1024;
   constexpr int NWN = NT / 64, NWM = 8 / NWN, WM = MT / NWM, MI = WM / 32;          // wave grid and wave tile (WM x 64)
   constexpr int NBW = NT >= 128 ? NT / 128 : 1;          // weight pieces per wave and step (NT = 64: waves 4-7 issue a dummy)
@@ -1110,6 +1113,7 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
   issue_b(0); issue_b(1); issue_b(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+  unsigned long long pc0 = 0, pw0 = 0; if constexpr (TAG == 1) { pc0 = __builtin_readcyclecounter(); pw0 = wall_clock64(); }
   int step = 0;
   for (int chunk = 0; chunk < NC; ++chunk) {
     const unsigned hb = (chunk & 1) * HMAX;
@@ -1153,6 +1157,7 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the trailing (zero-page) pieces must land before the LDS is released
+  if constexpr (TAG == 1) { if (blockIdx.x == 17 && tid == 0) { g_kprobe[0] = __builtin_readcyclecounter() - pc0; g_kprobe[1] = wall_clock64() - pw0; g_kprobe[2] = pw0 - pe0; } }
   const int m0 = m_blk + wm * WM, n0 = n_blk + wn * 64;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -1165,6 +1170,325 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
         for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * q + i];
       ep.template quad<2>(m0 + 32 * mi + 8 * q + 4 * h, n0 + r, 32, v);
     }
+  if constexpr (TAG == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (blockIdx.x == 17 && tid == 0) g_kprobe[3] = wall_clock64() - pe0; }
+}
+
+// ---------------------------------------------------------------------------
+// The halo-resident kernel as FOUR waves of 128 x 128 outputs (16 accumulator tiles = 256 AGPRs, one wave per SIMD), 256 x 256 tiles
+// only.  tools/ubench/gemm4w.hip: the 8-wave form reads 96 KB of fragments per K step (A rows by four waves, B rows by two) and its
+// two waves per SIMD sit in the same phase behind the per-step barrier; four waves read 64 KB and -- with every fragment read and
+// LDS-DMA piece pinned BETWEEN two MFMAs (one read per two MFMAs, asm reads + sched_barrier, fragments of the next k-half always in
+// flight under the MFMAs of the current one) -- the reads cost no MFMA cycles at all (155 k vs 152 k shader cycles per workgroup for
+// the MFMA-only loop); what remains is ~24 cycles per global_load_lds.
+//   step s = (chunk, tap); halves h0 / h1 = k 0..15 / 16..31 of the 32-channel chunk.
+//     half 1:  MFMAs on F0(s) | reads of F1(s) | DMA: weight pieces 0, 1 of step s+3 [+ one halo piece of chunk+1 while tap <= 4]
+//     wait (own weight pieces of step s+1 landed, F1 reads back) + barrier
+//     half 2:  MFMAs on F1(s) | reads of F0(s+1) | DMA: weight pieces 2, 3 of step s+3 [+ one halo piece while tap <= 4]
+//   The barrier in the MIDDLE of a step is what lets F0(s+1) be read under the second half's MFMAs.  Weight slot (s+3) & 3 was last read
+//   in half 1 of step s-1; the halo buffer of chunk+1 was last read in half 1 of the previous chunk's last step.  The nine taps are
+//   unrolled (compile-time tap -> compile-time vmcnt: the pieces issued since the last piece of step s+1's weights number
+//   6 + H(t-2) + 2 H(t-1) + H(t), H = 1 while tap <= 4); the <= 36 halo groups of a chunk are all issued by tap 4, so they have
+//   landed long before the last step's barrier.  Same k order per output element as the 8-wave kernel: bit-identical results.
+// ---------------------------------------------------------------------------
+struct EpConv; struct EpStore;
+// Output tile of gemm_halo4_bf16_kernel through LDS (free once the K loop is over): the direct epilogue costs a lane 128-256 scattered 1-,
+// 2- or 4-byte stores (35 us of a 133 us workgroup at conv6 forward: 64-byte segments of 2-byte values, 32-byte segments of arg-max
+// bytes); staged, the tile leaves as 16-byte stores of whole rows.  Handles the plain fp32 tile (EpStore without options: the data
+// gradients; EpConv pmode 0 with an fp32 destination: conv3 / conv5 in front of their BatchNorm) in two passes of 128 rows, and the
+// (2,1)-pooled bf16 + arg-max tile of conv4 / conv6 in one; anything else returns false (-> the quad epilogue).
+// the fp32 tile: two passes of 128 rows
+__device__ __forceinline__ void halo4_store_f32(float* dst, int64_t ldc, const float* bias, bool relu, const f32x16 (&acc)[4][4], unsigned char* lds,
+                                                int m_blk, int n_blk, int wm, int wn, int r, int h, int tid) {
+  constexpr int PITCH = 1040;                             // 256 fp32 + 16 bytes
+  float bb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bb[ni] = bias[n_blk + wn * 128 + ni * 32 + r];
+  }
+  __syncthreads();                                        // every wave is out of the K loop
+  for (int p = 0; p < 2; ++p) {
+    if (wm == p) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float x = acc[mi][ni][4 * q + i] + bb[ni];
+              if (relu) x = fmaxf(x, 0.f);
+              *reinterpret_cast<float*>(lds + (mi * 32 + 8 * q + 4 * h + i) * PITCH + (wn * 128 + ni * 32 + r) * 4) = x;
+            }
+    }
+    __syncthreads();
+    float* const d0 = dst + (int64_t)(m_blk + p * 128) * ldc + n_blk;
+#pragma unroll 4
+    for (int it = 0; it < 32; ++it) {
+      const int idx = it * 256 + tid, row = idx >> 6, c = idx & 63;
+      const float4 v = *reinterpret_cast<const float4*>(lds + row * PITCH + c * 16);
+      *reinterpret_cast<float4*>(d0 + (int64_t)row * ldc + c * 4) = v;
+    }
+    __syncthreads();
+  }
+}
+// the (2,1)-pooled tile: 128 pooled rows of 256 bf16 + 256 arg-max bytes
+__device__ __forceinline__ void halo4_store_pooled(bf16_t* yb, uint8_t* idxp, int Cout, const float* bias, bool relu, const f32x16 (&acc)[4][4], unsigned char* lds,
+                                                   int m_blk, int n_blk, int wm, int wn, int r, int h, int tid) {
+  constexpr int PB = 528, PI = 272, IOFF = 128 * PB;      // pooled rows: 256 bf16 + 16 bytes; 256 arg-max bytes + 16
+  float bb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bb[ni] = bias[n_blk + wn * 128 + ni * 32 + r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = acc[mi][ni][4 * q + i] + bb[ni]; if (relu) x[i] = fmaxf(x[i], 0.f); }
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const float a_ = x[2 * w], b_ = x[2 * w + 1];
+          const int prow = wm * 64 + mi * 16 + 4 * q + 2 * h + w, col = wn * 128 + ni * 32 + r;
+          *reinterpret_cast<bf16_t*>(lds + prow * PB + col * 2) = (bf16_t)((b_ > a_) ? b_ : a_);
+          *reinterpret_cast<uint8_t*>(lds + IOFF + prow * PI + col) = (uint8_t)(b_ > a_);
+        }
+      }
+  __syncthreads();
+  const int64_t prow0 = m_blk >> 1;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int idx = it * 256 + tid, row = idx >> 5, c = idx & 31;
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * PB + c * 16);
+    *reinterpret_cast<uint4*>(yb + (prow0 + row) * Cout + n_blk + c * 8) = v;
+  }
+#pragma unroll 4
+  for (int it = 0; it < 8; ++it) {
+    const int idx = it * 256 + tid, row = idx >> 4, c = idx & 15;
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + IOFF + row * PI + c * 16);
+    *reinterpret_cast<uint4*>(idxp + (prow0 + row) * Cout + n_blk + c * 16) = v;
+  }
+}
+template <class EP>
+__device__ __forceinline__ bool halo4_store_staged(const EP& ep, const f32x16 (&acc)[4][4], unsigned char* lds, int m_blk, int n_blk, int wm, int wn, int r, int h, int tid, int opt) {
+  if constexpr (std::is_same<EP, EpConv>::value) {
+    if (ep.bn_save) return false;
+    if (ep.pmode == 2 && ep.yb && ep.idx && !ep.y && (opt & 4)) { halo4_store_pooled(ep.yb, ep.idx, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
+    if (ep.pmode == 0 && ep.y && !ep.yb && (opt & 2)) { halo4_store_f32(ep.y, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
+    return false;
+  } else if constexpr (std::is_same<EP, EpStore>::value) {
+    if (ep.flags || ep.bias || ep.bias2 || ep.C1 || ep.Cb || ep.dg || !(opt & 1)) return false;
+    halo4_store_f32(ep.C, ep.ldc, nullptr, false, acc, lds, m_blk, n_blk, wm, wn, r, h, tid);
+    return true;
+  } else return false;
+}
+
+template <class EP, int SGN, int TAG = 0>
+__global__ __launch_bounds__(256, 1)
+void gemm_halo4_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const bf16_t* zero, int opt) {
+  unsigned long long pe0 = 0; if constexpr (TAG == 1) pe0 = wall_clock64();
+  constexpr int MT = 256, NT = 256, HMAX = HaloGeom<MT>::HMAX, BSLOT = NT * 64, BRING = 2 * HMAX, DUMP = BRING + 4 * BSLOT, LDS_BYTES = DUMP + 4 * 1024;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];          // the ONLY LDS object
+  const int nwg = gx * gy, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int m_blk = (bid / gx) * MT, n_blk = (bid % gx) * NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const LoadConvK& g = a.g;
+  const int W = g.Wr, H = g.Hr, C = g.C, P = W + 16, R = MT / W;
+  const int NG = (R + 2) * (P >> 4);                     // 16-pixel DMA groups of one halo (<= 36)
+  const int NC = C >> 5, NT9 = 9 * NC;
+  const LoadConvK::Ctx c0 = g.row(m_blk);
+  const int y0 = __builtin_amdgcn_readfirstlane(c0.y);
+  const bf16_t* const img = a.src + (int64_t)__builtin_amdgcn_readfirstlane(c0.b) * H * W * C;
+  const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
+
+  unsigned abase[4][3];                                  // as in the 8-wave kernel: (halo row ty, col tx + dxi), k-chunk h
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int local = wm * 128 + mi * 32 + r;
+    int ty, tx;
+    if (g.pmode == 1) { const int win = local >> 2, wx = win % g.Wp; ty = 2 * (win / g.Wp) + ((local >> 1) & 1); tx = 2 * wx + (local & 1); }
+    else if (g.pmode == 2) { const int win = local >> 1; tx = win % W; ty = 2 * (win / W) + (local & 1); }
+    else { ty = local / W; tx = local - ty * W; }
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi) {
+      const int col = tx + dxi, sw = ((col >> 2) & 3) ^ ((ty & 1) << 1);
+      abase[mi][dxi] = lbase + (unsigned)(ty * P + col) * 64u + (unsigned)((h ^ sw) << 4);
+    }
+  }
+  const int swzb = (r >> 2) & 3;
+  unsigned boff[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) boff[s2] = lbase + BRING + (wn * 128 + r) * 64 + (((2 * s2 + h) ^ swzb) << 4);
+
+  // weight staging: rows (tid >> 2) + 64 j, position tid & 3 holds k-chunk (tid & 3) ^ ((tid >> 4) & 3).  N % 256 == 0: every row exists;
+  // address = uniform base + 32-bit lane offset + 32-bit uniform k offset (one VALU add per piece, SGPR-base addressing); a step past the
+  // end of K re-reads the last tile (never consumed) instead of selecting the zero page.
+  const int srow = tid >> 2, bchunk = (tid & 3) ^ ((tid >> 4) & 3);
+  const char* const wsrc = reinterpret_cast<const char*>(b.p);
+  unsigned woff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) woff[j] = (unsigned)(((int64_t)(n_blk + 64 * j + srow) * b.ld + 8 * bchunk) * 2);
+  unsigned char* const wbase = lds + wave * 1024;
+  auto issue_b1 = [&](int step, unsigned kbytes, int j) {  // piece j (rows 64 j + 16 wave ..) of the weight tile of K step `step`
+    dma16(wsrc + (woff[j] + kbytes), wbase + BRING + (step & 3) * BSLOT + j * 4096);
+  };
+  auto kof = [&](int step) -> unsigned { const int st = step < NT9 ? step : NT9 - 1, chunk = st / 9, tap = st - chunk * 9; return (unsigned)(tap * C + (chunk << 5)) * 2u; };
+  // halo staging: this wave's ten pieces of a chunk (taps 0-4, two per step): group gq = 8 tap + 2 wave + e = 16 pixels of one halo row; lane ->
+  // pixel (lane >> 2), position lane & 3.  Source pointer of chunk 0 per piece, 64 more bytes per chunk for the lanes inside the image; the
+  // others (border, groups >= NG) stay on the zero page.  The last chunk re-reads its own halo into the other buffer (never consumed).
+  const int hx = (lane >> 2) - 1, hchunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const bf16_t* hsrc[10]; unsigned hinc = 0;              // bit i of hinc: lane is inside the image for piece i
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const int gq = (i >> 1) * 8 + wave * 2 + (i & 1);
+    const int row = gq / (P >> 4), col0 = (gq - row * (P >> 4)) << 4;
+    const int y = y0 - 1 + row, x = col0 + hx;
+    const bool ok = gq < NG && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    hsrc[i] = dma_select(ok, img + ((int64_t)(y * W + x) * C + ((hchunk ^ ((row & 1) << 1)) << 3)), zero);
+    hinc |= ok ? (1u << i) : 0u;
+  }
+  auto issue_halo_i = [&](int i, int chunk, unsigned buf) {   // piece i of chunk `chunk`'s halo -> halo buffer at byte offset buf
+    const int gq = (i >> 1) * 8 + wave * 2 + (i & 1);
+    const unsigned inc = ((hinc >> i) & 1u) ? (unsigned)chunk << 6 : 0u;
+    dma16(reinterpret_cast<const char*>(hsrc[i]) + inc, gq < NG ? lds + buf + gq * 1024 : lds + DUMP + wave * 1024);
+  };
+  auto issue_halo0 = [&](int gq) {                        // prologue: group gq of chunk 0
+    const int row = gq / (P >> 4), col0 = (gq - row * (P >> 4)) << 4;
+    const int y = y0 - 1 + row, x = col0 + hx;
+    const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    dma16(dma_select(ok, img + ((int64_t)(y * W + x) * C + ((hchunk ^ ((row & 1) << 1)) << 3)), zero), lds + gq * 1024);
+  };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // prologue: the whole halo of chunk 0 and three weight tiles
+  for (int gq = wave; gq < NG; gq += 4) issue_halo0(gq);
+#pragma unroll
+  for (int st = 0; st < 3; ++st)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_b1(st, kof(st), j);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 a0[4], b0[4], a1[4], b1[4];
+#define AOCR_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+#define AOCR_SB() __builtin_amdgcn_sched_barrier(0)
+  // A fragment addresses: ab[mi][dxi] = abase + (halo buffer + dyi P 64) for the CURRENT (chunk, kernel row) -- twelve adds per three
+  // steps -- and per read one XOR with the uniform (row-parity flip | k-half) bits, which sit below the 64-byte pixel pitch
+  unsigned ab[4][3];
+  auto set_ab = [&](unsigned hb, int kh) {
+    const int dyi = SGN > 0 ? kh : 2 - kh;
+    const unsigned U = hb + (unsigned)(dyi * P) * 64u;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int dxi = 0; dxi < 3; ++dxi) ab[mi][dxi] = abase[mi][dxi] + U;
+  };
+  auto a_addr = [&](int mi, int tap, int half) -> unsigned {   // tap, half: compile-time at every call site
+    const int kh = tap / 3, kw = tap - 3 * kh;
+    const int dyi = SGN > 0 ? kh : 2 - kh, dxi = SGN > 0 ? kw : 2 - kw;
+    const unsigned x = ((dyi & 1) << 5) ^ (half ? 32u : 0u);
+    return x ? ab[mi][dxi] ^ x : ab[mi][dxi];
+  };
+  set_ab(0, 0);
+  {                                                       // F0 of step 0
+    AOCR_DSR(a0[0], a_addr(0, 0, 0), 0); AOCR_DSR(a0[1], a_addr(1, 0, 0), 0); AOCR_DSR(a0[2], a_addr(2, 0, 0), 0); AOCR_DSR(a0[3], a_addr(3, 0, 0), 0);
+    AOCR_DSR(b0[0], boff[0], 0); AOCR_DSR(b0[1], boff[0], 2048); AOCR_DSR(b0[2], boff[0], 4096); AOCR_DSR(b0[3], boff[0], 6144);
+  }
+  unsigned long long pc0 = 0, pw0 = 0; if constexpr (TAG == 1) { pc0 = __builtin_readcyclecounter(); pw0 = wall_clock64(); }
+  for (int chunk = 0; chunk < NC; ++chunk) {
+    const unsigned hb = (chunk & 1) * HMAX, hbn = ((chunk + 1) & 1) * HMAX;
+    const int chn = chunk + 1 < NC ? chunk + 1 : chunk;   // the chunk whose halo streams in (last chunk: its own again, into the other buffer)
+    auto step_fn = [&](auto tapc) {
+      constexpr int TAP = decltype(tapc)::value;
+      constexpr int TN = (TAP + 1) % 9;                   // the next step's tap (chunk + 1 when TN == 0)
+      constexpr int HT = TAP <= 4, HT1 = ((TAP + 8) % 9) <= 4, HT2 = ((TAP + 7) % 9) <= 4;
+      constexpr int NVM = 6 + HT2 + 2 * HT1 + HT;
+      const int step = chunk * 9 + TAP;
+      constexpr int T3 = (TAP + 3) % 9, DC3 = (TAP + 3) / 9;      // (chunk, tap) of step s+3
+      const unsigned k3 = chunk + DC3 < NC ? (unsigned)(T3 * C + ((chunk + DC3) << 5)) * 2u : (unsigned)(8 * C + ((NC - 1) << 5)) * 2u;
+      const unsigned bs1 = (unsigned)((step & 3) * BSLOT), bs0n = (unsigned)(((step + 1) & 3) * BSLOT);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // F0(s), read under the MFMAs of the previous half
+      AOCR_SB();
+      // ---- half 1
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
+          AOCR_SB();
+          if (ni == 0) AOCR_DSR(a1[mi], a_addr(mi, TAP, 1), 0);
+          if (ni == 2) { if (mi == 0) AOCR_DSR(b1[0], boff[1] + bs1, 0); else if (mi == 1) AOCR_DSR(b1[1], boff[1] + bs1, 2048); else if (mi == 2) AOCR_DSR(b1[2], boff[1] + bs1, 4096); else AOCR_DSR(b1[3], boff[1] + bs1, 6144); }
+          if (ni == 3 && mi < 2) issue_b1(step + 3, k3, mi);
+          if (ni == 3 && mi == 2 && HT) issue_halo_i(2 * TAP, chn, hbn);
+          AOCR_SB();
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NVM) : "memory");   // own weight pieces of step s+1 landed; F1(s) back
+      __builtin_amdgcn_s_barrier();                       // ... everyone's; everyone is done with weight slot s-1 and (last tap) with this chunk's first-half reads
+      AOCR_SB();
+      // ---- half 2 (its reads are the next step's first k-half: a new kernel row / chunk moves the A address table first)
+      if (TN % 3 == 0) { set_ab(TN == 0 ? hbn : hb, TN / 3); AOCR_SB(); }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
+          AOCR_SB();
+          if (ni == 0) AOCR_DSR(a0[mi], a_addr(mi, TN, 0), 0);
+          if (ni == 2) { if (mi == 0) AOCR_DSR(b0[0], boff[0] + bs0n, 0); else if (mi == 1) AOCR_DSR(b0[1], boff[0] + bs0n, 2048); else if (mi == 2) AOCR_DSR(b0[2], boff[0] + bs0n, 4096); else AOCR_DSR(b0[3], boff[0] + bs0n, 6144); }
+          if (ni == 3 && mi < 2) issue_b1(step + 3, k3, 2 + mi);
+          if (ni == 3 && mi == 2 && HT) issue_halo_i(2 * TAP + 1, chn, hbn);
+          AOCR_SB();
+        }
+      }
+    };
+    step_fn(std::integral_constant<int, 0>{}); step_fn(std::integral_constant<int, 1>{}); step_fn(std::integral_constant<int, 2>{});
+    step_fn(std::integral_constant<int, 3>{}); step_fn(std::integral_constant<int, 4>{}); step_fn(std::integral_constant<int, 5>{});
+    step_fn(std::integral_constant<int, 6>{}); step_fn(std::integral_constant<int, 7>{}); step_fn(std::integral_constant<int, 8>{});
+  }
+#undef AOCR_DSR
+#undef AOCR_SB
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the trailing (zero-page) pieces and reads must land before the LDS is released
+  // the last half-step's reads of "the next step" are never consumed: keep their destination registers allocated up to here, or the compiler
+  // hands them to the epilogue (seen: the destination pointer) while the LDS data is still in flight and lands on top of the new value
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(a0[i]), "v"(b0[i]), "v"(a1[i]), "v"(b1[i]));
+  if constexpr (TAG == 1) { if ((blockIdx.x == 17 || blockIdx.x == 300) && tid == 0) { const int o = blockIdx.x == 17 ? 4 : 0; g_kprobe[o] = __builtin_readcyclecounter() - pc0; g_kprobe[o + 1] = wall_clock64() - pw0; g_kprobe[o + 2] = pw0 - pe0; } }
+  const int m0 = m_blk + wm * 128, n0 = n_blk + wn * 128;
+  if (halo4_store_staged(ep, acc, lds, m_blk, n_blk, wm, wn, r, h, tid, opt)) {
+    if constexpr (TAG == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((blockIdx.x == 17 || blockIdx.x == 300) && tid == 0) g_kprobe[blockIdx.x == 17 ? 7 : 3] = wall_clock64() - pe0; }
+    return;
+  }
+  auto store_mi = [&](auto mic) {                         // compile-time mi: a rolled loop would index the accumulators dynamically (scratch)
+    constexpr int mi = decltype(mic)::value;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[4][4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * q + i];
+      ep.template quad<4>(m0 + 32 * mi + 8 * q + 4 * h, n0 + r, 32, v);
+    }
+  };
+  store_mi(std::integral_constant<int, 0>{}); store_mi(std::integral_constant<int, 1>{});
+  store_mi(std::integral_constant<int, 2>{}); store_mi(std::integral_constant<int, 3>{});
+  if constexpr (TAG == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (blockIdx.x == 17 && tid == 0) g_kprobe[7] = wall_clock64() - pe0; }
 }
 
 // ---------------------------------------------------------------------------

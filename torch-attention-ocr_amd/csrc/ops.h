@@ -85,6 +85,7 @@ int gemm(hipStream_t s, bool bf16, const float* A, int64_t lda, bool a_kmajor, c
 struct WGradProblem { const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int M, N, K;
                       const bf16_t* Ab = nullptr; const bf16_t* Bb = nullptr; };     // optional bf16 shadows of A and B (same lda/ldb)
 void grouped_wgrad(hipStream_t s, bool bf16, const WGradProblem* p, int n);
+void kprobe_read(unsigned long long out[8]);   // debugging probe of the tagged halo kernels (mfma_gemm.h: g_kprobe)
 
 // C = A B^T (+bias) with both operands read from K-contiguous bf16 shadows (A [M][K], B [N][K])
 void gemm_hh(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
