@@ -1196,36 +1196,36 @@ struct EpConv; struct EpStore;
 // bytes); staged, the tile leaves as 16-byte stores of whole rows.  Handles the plain fp32 tile (EpStore without options: the data
 // gradients; EpConv pmode 0 with an fp32 destination: conv3 / conv5 in front of their BatchNorm) in two passes of 128 rows, and the
 // (2,1)-pooled bf16 + arg-max tile of conv4 / conv6 in one; anything else returns false (-> the quad epilogue).
-// the fp32 tile: two passes of 128 rows
-__device__ __forceinline__ void halo4_store_f32(float* dst, int64_t ldc, const float* bias, bool relu, const f32x16 (&acc)[4][4], unsigned char* lds,
-                                                int m_blk, int n_blk, int wm, int wn, int r, int h, int tid) {
-  constexpr int PITCH = 1040;                             // 256 fp32 + 16 bytes
-  float bb[4] = {0.f, 0.f, 0.f, 0.f};
-  if (bias) {
+// the fp32 tile of a 256 x 256 workgroup: two passes of 128 rows (the waves with wm == pass hold them) through a [128][256] fp32 LDS image.
+// NI = 32-column accumulator tiles per wave (wave tile 128 x 32 NI), NTH = threads of the workgroup.
+template <int NI, int NTH>
+__device__ __forceinline__ void tile256_store_f32(float* dst, int64_t ldc, const float* bias, bool relu, const f32x16 (&acc)[4][NI], unsigned char* lds,
+                                                  int m_blk, int n_blk, int wm, int wn, int r, int h, int tid) {
+  constexpr int PITCH = 1024;                             // lanes r = consecutive dwords, the two row groups h are separate LDS cycles: no padding needed
+  float bb[NI];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) bb[ni] = bias[n_blk + wn * 128 + ni * 32 + r];
-  }
+  for (int ni = 0; ni < NI; ++ni) bb[ni] = bias ? bias[n_blk + wn * 32 * NI + ni * 32 + r] : 0.f;
   __syncthreads();                                        // every wave is out of the K loop
   for (int p = 0; p < 2; ++p) {
     if (wm == p) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               float x = acc[mi][ni][4 * q + i] + bb[ni];
               if (relu) x = fmaxf(x, 0.f);
-              *reinterpret_cast<float*>(lds + (mi * 32 + 8 * q + 4 * h + i) * PITCH + (wn * 128 + ni * 32 + r) * 4) = x;
+              *reinterpret_cast<float*>(lds + (mi * 32 + 8 * q + 4 * h + i) * PITCH + (wn * 32 * NI + ni * 32 + r) * 4) = x;
             }
     }
     __syncthreads();
     float* const d0 = dst + (int64_t)(m_blk + p * 128) * ldc + n_blk;
 #pragma unroll 4
-    for (int it = 0; it < 32; ++it) {
-      const int idx = it * 256 + tid, row = idx >> 6, c = idx & 63;
+    for (int it = 0; it < 8192 / NTH; ++it) {
+      const int idx = it * NTH + tid, row = idx >> 6, c = idx & 63;
       const float4 v = *reinterpret_cast<const float4*>(lds + row * PITCH + c * 16);
       *reinterpret_cast<float4*>(d0 + (int64_t)row * ldc + c * 4) = v;
     }
@@ -1279,11 +1279,11 @@ __device__ __forceinline__ bool halo4_store_staged(const EP& ep, const f32x16 (&
   if constexpr (std::is_same<EP, EpConv>::value) {
     if (ep.bn_save) return false;
     if (ep.pmode == 2 && ep.yb && ep.idx && !ep.y && (opt & 4)) { halo4_store_pooled(ep.yb, ep.idx, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
-    if (ep.pmode == 0 && ep.y && !ep.yb && (opt & 2)) { halo4_store_f32(ep.y, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
+    if (ep.pmode == 0 && ep.y && !ep.yb && (opt & 2)) { tile256_store_f32<4, 256>(ep.y, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
     return false;
   } else if constexpr (std::is_same<EP, EpStore>::value) {
     if (ep.flags || ep.bias || ep.bias2 || ep.C1 || ep.Cb || ep.dg || !(opt & 1)) return false;
-    halo4_store_f32(ep.C, ep.ldc, nullptr, false, acc, lds, m_blk, n_blk, wm, wn, r, h, tid);
+    tile256_store_f32<4, 256>(ep.C, ep.ldc, nullptr, false, acc, lds, m_blk, n_blk, wm, wn, r, h, tid);
     return true;
   } else return false;
 }
@@ -1829,6 +1829,14 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_dma_kernel(LoadMNh a, LoadC
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   const int r = lane & 31;
   const int m0 = m_blk + wm * 128, n0 = n_blk + wn * 64;
+  if constexpr (std::is_same<EP, EpStore>::value && ABL == 0) {
+    // the slab tile of a k range is a plain fp32 store of a full 256 x 256 tile: through LDS as whole 1 KB rows (16-byte stores) instead of
+    // 128 four-byte stores per lane
+    if (part && !ep.flags && !ep.bias && !ep.bias2 && !ep.C1 && !ep.Cb && !ep.dg && m_blk + 256 <= ep.M && n_blk + 256 <= ep.N) {
+      tile256_store_f32<2, 512>(ep.C, ep.ldc, nullptr, false, acc, lds, m_blk, n_blk, wm, wn, r, h, tid);
+      return;
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
