@@ -428,7 +428,7 @@ def main():
         bf16 = wl["compute"] == "bf16"
         ms, kfl = m.profile_kernel(0, 20)                # conv6 forward, HIP events on the model's stream
         ach = kfl / (ms * 1e-3) / 1e12
-        best = {"bound": "mfma", "kernel": "conv6 forward implicit GEMM (512->512 3x3 + ReLU + pool), gemm_halo_bf16_kernel", "achieved": ach,
+        best = {"bound": "mfma", "kernel": "conv6 forward implicit GEMM (512->512 3x3 + ReLU + pool), gemm_halo4_bf16_kernel", "achieved": ach,
                 "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "ms_per_launch": ms}
         # the DOMINANT kernel of the step by time share: the split-K filter gradient (conv_wgrad_dma_kernel: conv4 + conv5 + conv6, 12-13 % of
         # the kernel time, profiles/*_kernel_stats.csv); timed on the conv6 launch exactly as backward_all makes it (kernel + the sum of its slabs)

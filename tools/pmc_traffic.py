@@ -1,5 +1,5 @@
 """HBM-side traffic per launch of the two kernels bench.py's roofline fields name, from two rocprofv3 --pmc passes (FETCH_SIZE,
-WRITE_SIZE) of the bench command: the tagged launches of aocr_profile_kernel -- id 0 = conv6 forward (gemm_halo_bf16_kernel<..., TAG 1>),
+WRITE_SIZE) of the bench command: the tagged launches of aocr_profile_kernel -- id 0 = conv6 forward (gemm_halo4_bf16_kernel<EpConv, 1, TAG 1>; under AOCR_HALO8=1 the 8-wave gemm_halo_bf16_kernel<..., 1>),
 id 1 = conv6 filter gradient (conv_wgrad_dma_kernel<EpStore, 256> + the splitk_reduce_kernel launch behind each of them).
 Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KB; FETCH_SIZE reports
 exactly half the bytes of a wide (16 B/lane) coalesced read stream -> doubled.  Writes JSON next to the text summary when asked:
@@ -9,7 +9,7 @@ import json
 import os
 import sys
 
-FWD = "gemm_halo_bf16_kernel<aocr::EpConv, 1, 256, 256, 1>"
+FWD = "gemm_halo4_bf16_kernel<aocr::EpConv, 1, 1>"
 WG = "conv_wgrad_dma_kernel<aocr::EpStore, 256>"
 RED = "splitk_reduce_kernel"
 
