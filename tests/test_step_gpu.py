@@ -238,6 +238,43 @@ def test_halo_conv_kernel_matches_im2col_kernel(cuda, monkeypatch, B, W):
     assert_grads_agree_up_to_decisions(a["grads"], b["grads"], "halo-vs-im2col")
 
 
+@pytest.mark.parametrize("B,W", [(8, 128), (6, 256), (4, 512)])
+def test_halo_four_wave_kernel_matches_eight_wave_kernel(cuda, monkeypatch, B, W):
+    """gemm_halo4_bf16_kernel (four waves of 128 x 128, fragment reads / LDS-DMA pieces pinned between the MFMAs, output tiles staged
+    through LDS) against the 8-wave gemm_halo_bf16_kernel it replaces (AOCR_HALO8=1) and against its own direct epilogue
+    (AOCR_HALO4_STAGED=0): the same k order per output element, so the forward pass is bit-identical; the gradients agree up to
+    the order of the fp32 atomics of the split-K weight gradients.  Map widths 32 / 64 / 128 (image widths 128 / 256 / 512): all three
+    halo geometries, forward (plain, (2,1)-pooled, fp32 in front of a BatchNorm) and data gradient."""
+    cfg = dict(enc_hidden=64, enc_layers=1, dec_layers=2, input_feed=True)
+    monkeypatch.setenv("AOCR_FORCE_DMA", "1")                   # small batches: take the 256 x 256 kernels although they do not fill the chip
+    out = {}
+    for name, env in (("four", {}), ("eight", {"AOCR_HALO8": "1"}), ("direct", {"AOCR_HALO4_STAGED": "0"})):
+        for k in ("AOCR_HALO8", "AOCR_HALO4_STAGED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=5, compute="bf16")
+        loss = m.train_forward_backward(batch)
+        out[name] = dict(loss=loss, feats=m.get_tensor("feats").clone(), logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(),
+                         taps={k: m.get_tensor(k).clone() for k in ("conv3", "conv4", "conv5", "conv6")},
+                         dfeats=m.get_tensor("dfeats").clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.shutdown()
+    a = out["eight"]
+    for name in ("four", "direct"):
+        b = out[name]
+        assert torch.equal(a["feats"], b["feats"]) and torch.equal(a["logits"], b["logits"]) and a["loss"] == b["loss"], name
+        for k in a["taps"]:
+            assert torch.equal(a["taps"][k], b["taps"][k]), (name, k)
+        worst = ("", 0.0)
+        for k in a["grads"]:
+            if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):
+                continue
+            x = relerr(b["grads"][k], a["grads"][k])
+            if x > worst[1]: worst = (k, x)
+            assert x < 1e-4, (name, k, x)
+        print(f"[parity] halo {name}-vs-eight B={B} W={W}: forward bit-identical, worst gradient rel {worst[1]:.3e} ({worst[0]})")
+
+
 @pytest.mark.parametrize("He,B,W,Le", [(64, 16, 40, 1), (256, 32, 72, 1), (128, 16, 36, 1), (64, 16, 44, 2), (256, 16, 36, 2),
                                         (64, 16, 800, 1),           # W = 800: T = 199 steps (BASELINE C4 upper width)
                                         (512, 16, 100, 1), (512, 40, 52, 2), (256, 21, 60, 1), (128, 70, 36, 1)])   # He = 512; ragged batches

@@ -66,9 +66,10 @@ template <int SGN, int MT, int NT, class EP>
 static void launch_halo(hipStream_t s, const LoadConvKh& a, const LoadKh& b, const EP& ep, int M, int N, int tag = 0) {
   const int gx = N / NT, gy = M / MT;
   if constexpr (MT == 256 && NT == 256) {                 // four waves of 128 x 128 with hand-placed reads / DMA (AOCR_HALO8=1: the 8-wave kernel; bit-identical)
-    static const bool eight = getenv("AOCR_HALO8") != nullptr;
+    const bool eight = getenv("AOCR_HALO8") != nullptr;          // read per call: tests toggle it
     if (!eight) {
-      static const int opt = getenv("AOCR_HALO4_STAGED") ? atoi(getenv("AOCR_HALO4_STAGED")) : 7;   // 1: fp32 tile of the data gradient, 2: of conv3 / conv5 forward, 4: pooled tile -- through LDS
+      const char* const so = getenv("AOCR_HALO4_STAGED");
+      const int opt = so ? atoi(so) : 7;   // 1: fp32 tile of the data gradient, 2: of conv3 / conv5 forward, 4: pooled tile -- through LDS
       if (tag) hipLaunchKernelGGL((gemm_halo4_bf16_kernel<EP, SGN, 1>), dim3(gx * gy), dim3(256), 0, s, a, b, ep, gx, gy, zero_page(), opt);
       else hipLaunchKernelGGL((gemm_halo4_bf16_kernel<EP, SGN>), dim3(gx * gy), dim3(256), 0, s, a, b, ep, gx, gy, zero_page(), opt);
       return;
