@@ -816,13 +816,111 @@ void gemm_lds_bf16_kernel(AL a, BL b, EP ep, int K, int kper, int gx, int gy) {
 // Every issue() is exactly 4 DMA instructions per lane (tiles past K read the zero page), which keeps the vmcnt
 // arithmetic uniform.  Both operands bf16, K-contiguous, K % 32 == 0.
 // ---------------------------------------------------------------------------
+struct EpConv; struct EpStore;
+// Output tile of the 256 x 256 kernels (gemm_halo4_bf16_kernel, gemm_dma_bf16_kernel, conv_wgrad_dma_kernel) through LDS (free once the K loop is over): the direct epilogue costs a lane 128-256 scattered 1-,
+// 2- or 4-byte stores (35 us of a 133 us workgroup at conv6 forward: 64-byte segments of 2-byte values, 32-byte segments of arg-max
+// bytes); staged, the tile leaves as 16-byte stores of whole rows.  Handles the plain fp32 tile (EpStore without options: the data
+// gradients; EpConv pmode 0 with an fp32 destination: conv3 / conv5 in front of their BatchNorm) in two passes of 128 rows, and the
+// (2,1)-pooled bf16 + arg-max tile of conv4 / conv6 in one; anything else returns false (-> the quad epilogue).
+// the fp32 tile of a 256 x 256 workgroup: two passes of 128 rows (the waves with wm == pass hold them) through a [128][256] fp32 LDS image.
+// NI = 32-column accumulator tiles per wave (wave tile 128 x 32 NI), NTH = threads of the workgroup.
+template <int NI, int NTH>
+__device__ __forceinline__ void tile256_store_f32(float* dst, int64_t ldc, const float* bias, bool relu, const f32x16 (&acc)[4][NI], unsigned char* lds,
+                                                  int m_blk, int n_blk, int wm, int wn, int r, int h, int tid) {
+  constexpr int PITCH = 1024;                             // lanes r = consecutive dwords, the two row groups h are separate LDS cycles: no padding needed
+  float bb[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) bb[ni] = bias ? bias[n_blk + wn * 32 * NI + ni * 32 + r] : 0.f;
+  __syncthreads();                                        // every wave is out of the K loop
+  for (int p = 0; p < 2; ++p) {
+    if (wm == p) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float x = acc[mi][ni][4 * q + i] + bb[ni];
+              if (relu) x = fmaxf(x, 0.f);
+              *reinterpret_cast<float*>(lds + (mi * 32 + 8 * q + 4 * h + i) * PITCH + (wn * 32 * NI + ni * 32 + r) * 4) = x;
+            }
+    }
+    __syncthreads();
+    float* const d0 = dst + (int64_t)(m_blk + p * 128) * ldc + n_blk;
+#pragma unroll 4
+    for (int it = 0; it < 8192 / NTH; ++it) {
+      const int idx = it * NTH + tid, row = idx >> 6, c = idx & 63;
+      const float4 v = *reinterpret_cast<const float4*>(lds + row * PITCH + c * 16);
+      *reinterpret_cast<float4*>(d0 + (int64_t)row * ldc + c * 4) = v;
+    }
+    __syncthreads();
+  }
+}
+// the (2,1)-pooled tile: 128 pooled rows of 256 bf16 + 256 arg-max bytes
+template <int NI, int NTH>
+__device__ __forceinline__ void tile256_store_pooled(bf16_t* yb, uint8_t* idxp, int Cout, const float* bias, bool relu, const f32x16 (&acc)[4][NI], unsigned char* lds,
+                                                     int m_blk, int n_blk, int wm, int wn, int r, int h, int tid) {
+  constexpr int PB = 528, PI = 272, IOFF = 128 * PB;      // pooled rows: 256 bf16 + 16 bytes; 256 arg-max bytes + 16
+  float bb[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) bb[ni] = bias ? bias[n_blk + wn * 32 * NI + ni * 32 + r] : 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = acc[mi][ni][4 * q + i] + bb[ni]; if (relu) x[i] = fmaxf(x[i], 0.f); }
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const float a_ = x[2 * w], b_ = x[2 * w + 1];
+          const int prow = wm * 64 + mi * 16 + 4 * q + 2 * h + w, col = wn * 32 * NI + ni * 32 + r;
+          *reinterpret_cast<bf16_t*>(lds + prow * PB + col * 2) = (bf16_t)((b_ > a_) ? b_ : a_);
+          *reinterpret_cast<uint8_t*>(lds + IOFF + prow * PI + col) = (uint8_t)(b_ > a_);
+        }
+      }
+  __syncthreads();
+  const int64_t prow0 = m_blk >> 1;
+#pragma unroll 4
+  for (int it = 0; it < 4096 / NTH; ++it) {
+    const int idx = it * NTH + tid, row = idx >> 5, c = idx & 31;
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * PB + c * 16);
+    *reinterpret_cast<uint4*>(yb + (prow0 + row) * Cout + n_blk + c * 8) = v;
+  }
+#pragma unroll 4
+  for (int it = 0; it < 2048 / NTH; ++it) {
+    const int idx = it * NTH + tid, row = idx >> 4, c = idx & 15;
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + IOFF + row * PI + c * 16);
+    *reinterpret_cast<uint4*>(idxp + (prow0 + row) * Cout + n_blk + c * 16) = v;
+  }
+}
+// full 256 x 256 tiles only (the callers' grids may end in a ragged tile: that one takes the quad epilogue)
+template <int NI, int NTH, class EP>
+__device__ __forceinline__ bool tile256_store_staged(const EP& ep, const f32x16 (&acc)[4][NI], unsigned char* lds, int m_blk, int n_blk, int wm, int wn, int r, int h, int tid, int opt) {
+  if constexpr (std::is_same<EP, EpConv>::value) {
+    if (ep.bn_save || m_blk + 256 > ep.rows || n_blk + 256 > ep.Cout) return false;
+    if (ep.pmode == 2 && ep.yb && ep.idx && !ep.y && (opt & 4)) { tile256_store_pooled<NI, NTH>(ep.yb, ep.idx, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
+    if (ep.pmode == 0 && ep.y && !ep.yb && (opt & 2)) { tile256_store_f32<NI, NTH>(ep.y, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
+    return false;
+  } else if constexpr (std::is_same<EP, EpStore>::value) {
+    if (ep.flags || ep.bias || ep.bias2 || ep.C1 || ep.Cb || ep.dg || !(opt & 1) || m_blk + 256 > ep.M || n_blk + 256 > ep.N) return false;
+    tile256_store_f32<NI, NTH>(ep.C, ep.ldc, nullptr, false, acc, lds, m_blk, n_blk, wm, wn, r, h, tid);
+    return true;
+  } else return false;
+}
+
 __device__ __forceinline__ void dma16(const void* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
 template <class AL, class BL, class EP, int ABL = 0, bool PIPE = false, bool PAIRS = false, int TAG = 0>     // TAG: distinct symbol for aocr_profile_kernel's launches (so that rocprofv3 --stats lists them on their own row); PAIRS: two K tiles per barrier; PIPE: fragment reads pipelined across the barrier (inline asm; measured 4-7 % slower); ABL: timing-only ablations (tools/ubench/dma_gemm.hip): 1 no in-loop DMA, 2 no MFMA, 4 no fragment reads, 16 / 128 A / B pieces from the zero page (plain form), 32 no A pieces at all (plain form)
 __global__ __launch_bounds__(512, 1)
-void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t* zero) {
+void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t* zero, int opt = 0) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 32768];          // the ONLY LDS object (a second one makes hipcc drain vmcnt)
   const int nwg = gx * gy, orig = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
@@ -986,6 +1084,7 @@ void gemm_dma_bf16_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the trailing (zero-page) tiles must land before the LDS is released
   const int m0 = m_blk + wm * 128, n0 = n_blk + wn * 64;
+  if constexpr (ABL == 0) { if (opt && tile256_store_staged<2, 512>(ep, acc, lds, m_blk, n_blk, wm, wn, r, h, tid, opt)) return; }
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -1190,104 +1289,6 @@ void gemm_halo_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const 
 //   6 + H(t-2) + 2 H(t-1) + H(t), H = 1 while tap <= 4); the <= 36 halo groups of a chunk are all issued by tap 4, so they have
 //   landed long before the last step's barrier.  Same k order per output element as the 8-wave kernel: bit-identical results.
 // ---------------------------------------------------------------------------
-struct EpConv; struct EpStore;
-// Output tile of gemm_halo4_bf16_kernel through LDS (free once the K loop is over): the direct epilogue costs a lane 128-256 scattered 1-,
-// 2- or 4-byte stores (35 us of a 133 us workgroup at conv6 forward: 64-byte segments of 2-byte values, 32-byte segments of arg-max
-// bytes); staged, the tile leaves as 16-byte stores of whole rows.  Handles the plain fp32 tile (EpStore without options: the data
-// gradients; EpConv pmode 0 with an fp32 destination: conv3 / conv5 in front of their BatchNorm) in two passes of 128 rows, and the
-// (2,1)-pooled bf16 + arg-max tile of conv4 / conv6 in one; anything else returns false (-> the quad epilogue).
-// the fp32 tile of a 256 x 256 workgroup: two passes of 128 rows (the waves with wm == pass hold them) through a [128][256] fp32 LDS image.
-// NI = 32-column accumulator tiles per wave (wave tile 128 x 32 NI), NTH = threads of the workgroup.
-template <int NI, int NTH>
-__device__ __forceinline__ void tile256_store_f32(float* dst, int64_t ldc, const float* bias, bool relu, const f32x16 (&acc)[4][NI], unsigned char* lds,
-                                                  int m_blk, int n_blk, int wm, int wn, int r, int h, int tid) {
-  constexpr int PITCH = 1024;                             // lanes r = consecutive dwords, the two row groups h are separate LDS cycles: no padding needed
-  float bb[NI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) bb[ni] = bias ? bias[n_blk + wn * 32 * NI + ni * 32 + r] : 0.f;
-  __syncthreads();                                        // every wave is out of the K loop
-  for (int p = 0; p < 2; ++p) {
-    if (wm == p) {
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              float x = acc[mi][ni][4 * q + i] + bb[ni];
-              if (relu) x = fmaxf(x, 0.f);
-              *reinterpret_cast<float*>(lds + (mi * 32 + 8 * q + 4 * h + i) * PITCH + (wn * 32 * NI + ni * 32 + r) * 4) = x;
-            }
-    }
-    __syncthreads();
-    float* const d0 = dst + (int64_t)(m_blk + p * 128) * ldc + n_blk;
-#pragma unroll 4
-    for (int it = 0; it < 8192 / NTH; ++it) {
-      const int idx = it * NTH + tid, row = idx >> 6, c = idx & 63;
-      const float4 v = *reinterpret_cast<const float4*>(lds + row * PITCH + c * 16);
-      *reinterpret_cast<float4*>(d0 + (int64_t)row * ldc + c * 4) = v;
-    }
-    __syncthreads();
-  }
-}
-// the (2,1)-pooled tile: 128 pooled rows of 256 bf16 + 256 arg-max bytes
-__device__ __forceinline__ void halo4_store_pooled(bf16_t* yb, uint8_t* idxp, int Cout, const float* bias, bool relu, const f32x16 (&acc)[4][4], unsigned char* lds,
-                                                   int m_blk, int n_blk, int wm, int wn, int r, int h, int tid) {
-  constexpr int PB = 528, PI = 272, IOFF = 128 * PB;      // pooled rows: 256 bf16 + 16 bytes; 256 arg-max bytes + 16
-  float bb[4] = {0.f, 0.f, 0.f, 0.f};
-  if (bias) {
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) bb[ni] = bias[n_blk + wn * 128 + ni * 32 + r];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float x[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { x[i] = acc[mi][ni][4 * q + i] + bb[ni]; if (relu) x[i] = fmaxf(x[i], 0.f); }
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-          const float a_ = x[2 * w], b_ = x[2 * w + 1];
-          const int prow = wm * 64 + mi * 16 + 4 * q + 2 * h + w, col = wn * 128 + ni * 32 + r;
-          *reinterpret_cast<bf16_t*>(lds + prow * PB + col * 2) = (bf16_t)((b_ > a_) ? b_ : a_);
-          *reinterpret_cast<uint8_t*>(lds + IOFF + prow * PI + col) = (uint8_t)(b_ > a_);
-        }
-      }
-  __syncthreads();
-  const int64_t prow0 = m_blk >> 1;
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int idx = it * 256 + tid, row = idx >> 5, c = idx & 31;
-    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * PB + c * 16);
-    *reinterpret_cast<uint4*>(yb + (prow0 + row) * Cout + n_blk + c * 8) = v;
-  }
-#pragma unroll 4
-  for (int it = 0; it < 8; ++it) {
-    const int idx = it * 256 + tid, row = idx >> 4, c = idx & 15;
-    const uint4 v = *reinterpret_cast<const uint4*>(lds + IOFF + row * PI + c * 16);
-    *reinterpret_cast<uint4*>(idxp + (prow0 + row) * Cout + n_blk + c * 16) = v;
-  }
-}
-template <class EP>
-__device__ __forceinline__ bool halo4_store_staged(const EP& ep, const f32x16 (&acc)[4][4], unsigned char* lds, int m_blk, int n_blk, int wm, int wn, int r, int h, int tid, int opt) {
-  if constexpr (std::is_same<EP, EpConv>::value) {
-    if (ep.bn_save) return false;
-    if (ep.pmode == 2 && ep.yb && ep.idx && !ep.y && (opt & 4)) { halo4_store_pooled(ep.yb, ep.idx, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
-    if (ep.pmode == 0 && ep.y && !ep.yb && (opt & 2)) { tile256_store_f32<4, 256>(ep.y, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
-    return false;
-  } else if constexpr (std::is_same<EP, EpStore>::value) {
-    if (ep.flags || ep.bias || ep.bias2 || ep.C1 || ep.Cb || ep.dg || !(opt & 1)) return false;
-    tile256_store_f32<4, 256>(ep.C, ep.ldc, nullptr, false, acc, lds, m_blk, n_blk, wm, wn, r, h, tid);
-    return true;
-  } else return false;
-}
-
 template <class EP, int SGN, int TAG = 0>
 __global__ __launch_bounds__(256, 1)
 void gemm_halo4_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const bf16_t* zero, int opt) {
@@ -1470,7 +1471,7 @@ void gemm_halo4_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const
   for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(a0[i]), "v"(b0[i]), "v"(a1[i]), "v"(b1[i]));
   if constexpr (TAG == 1) { if ((blockIdx.x == 17 || blockIdx.x == 300) && tid == 0) { const int o = blockIdx.x == 17 ? 4 : 0; g_kprobe[o] = __builtin_readcyclecounter() - pc0; g_kprobe[o + 1] = wall_clock64() - pw0; g_kprobe[o + 2] = pw0 - pe0; } }
   const int m0 = m_blk + wm * 128, n0 = n_blk + wn * 128;
-  if (halo4_store_staged(ep, acc, lds, m_blk, n_blk, wm, wn, r, h, tid, opt)) {
+  if (tile256_store_staged<4, 256>(ep, acc, lds, m_blk, n_blk, wm, wn, r, h, tid, opt)) {
     if constexpr (TAG == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((blockIdx.x == 17 || blockIdx.x == 300) && tid == 0) g_kprobe[blockIdx.x == 17 ? 7 : 3] = wall_clock64() - pe0; }
     return;
   }

@@ -48,8 +48,10 @@ static void launch_dma_narrow(hipStream_t s, const AL& a, const BL& b, const EP&
 template <class AL, class BL, class EP>
 static void launch_dma(hipStream_t s, const AL& a, const BL& b, const EP& ep, int M, int N, int K, int tag = 0) {
   const int gx = N / 256, gy = cdiv(M, 256);
-  if (tag) hipLaunchKernelGGL((gemm_dma_bf16_kernel<AL, BL, EP, 0, false, false, 1>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page());
-  else hipLaunchKernelGGL((gemm_dma_bf16_kernel<AL, BL, EP>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page());
+  const char* const so = getenv("AOCR_HALO4_STAGED");        // the same switch as the halo kernel's: output tiles through LDS (read per call: tests toggle it)
+  const int opt = so ? atoi(so) : 7;
+  if (tag) hipLaunchKernelGGL((gemm_dma_bf16_kernel<AL, BL, EP, 0, false, false, 1>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page(), opt);
+  else hipLaunchKernelGGL((gemm_dma_bf16_kernel<AL, BL, EP>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page(), opt);
 }
 // halo-resident 3 x 3 kernel (gemm_halo_bf16_kernel): the tile must be MT / W whole rows of one image
 static bool halo_eligible(const LoadConvK& g, int N, int MT, int NT) {
