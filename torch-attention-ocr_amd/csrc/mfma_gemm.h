@@ -899,11 +899,46 @@ __device__ __forceinline__ void tile256_store_pooled(bf16_t* yb, uint8_t* idxp, 
     *reinterpret_cast<uint4*>(idxp + (prow0 + row) * Cout + n_blk + c * 16) = v;
   }
 }
+// the bf16-only tile (evaluation mode: conv3 / conv5 with their BatchNorm + ReLU folded in, EpConv::bn_save): [256][256] bf16 = 128 KB, one pass
+template <int NI, int NTH>
+__device__ __forceinline__ void tile256_store_bf16(bf16_t* yb, int Cout, const float* bias, bool relu, const float* bn_save, const float* bn_w, const float* bn_b,
+                                                   const f32x16 (&acc)[4][NI], unsigned char* lds, int m_blk, int n_blk, int wm, int wn, int r, int h, int tid) {
+  float bb[NI], mu[NI], iv[NI], ww[NI], b2[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int col = n_blk + wn * 32 * NI + ni * 32 + r;
+    bb[ni] = bias ? bias[col] : 0.f;
+    mu[ni] = bn_save ? bn_save[col] : 0.f; iv[ni] = bn_save ? bn_save[Cout + col] : 1.f; ww[ni] = bn_save ? bn_w[col] : 1.f; b2[ni] = bn_save ? bn_b[col] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float x = acc[mi][ni][4 * q + i] + bb[ni];
+          if (relu) x = fmaxf(x, 0.f);
+          if (bn_save) x = fmaxf((x - mu[ni]) * iv[ni] * ww[ni] + b2[ni], 0.f);      // the same expression as EpConv::quad / bn_apply_relu_kernel
+          *reinterpret_cast<bf16_t*>(lds + (wm * 128 + mi * 32 + 8 * q + 4 * h + i) * 512 + (wn * 32 * NI + ni * 32 + r) * 2) = (bf16_t)x;
+        }
+  __syncthreads();
+#pragma unroll 4
+  for (int it = 0; it < 8192 / NTH; ++it) {
+    const int idx = it * NTH + tid, row = idx >> 5, c = idx & 31;
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * 512 + c * 16);
+    *reinterpret_cast<uint4*>(yb + (int64_t)(m_blk + row) * Cout + n_blk + c * 8) = v;
+  }
+}
 // full 256 x 256 tiles only (the callers' grids may end in a ragged tile: that one takes the quad epilogue)
 template <int NI, int NTH, class EP>
 __device__ __forceinline__ bool tile256_store_staged(const EP& ep, const f32x16 (&acc)[4][NI], unsigned char* lds, int m_blk, int n_blk, int wm, int wn, int r, int h, int tid, int opt) {
   if constexpr (std::is_same<EP, EpConv>::value) {
-    if (ep.bn_save || m_blk + 256 > ep.rows || n_blk + 256 > ep.Cout) return false;
+    if (m_blk + 256 > ep.rows || n_blk + 256 > ep.Cout) return false;
+    if (ep.pmode == 0 && ep.yb && !ep.y && (opt & 2)) { tile256_store_bf16<NI, NTH>(ep.yb, ep.Cout, ep.bias, ep.relu != 0, ep.bn_save, ep.bn_w, ep.bn_b, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
+    if (ep.bn_save) return false;
     if (ep.pmode == 2 && ep.yb && ep.idx && !ep.y && (opt & 4)) { tile256_store_pooled<NI, NTH>(ep.yb, ep.idx, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
     if (ep.pmode == 0 && ep.y && !ep.yb && (opt & 2)) { tile256_store_f32<NI, NTH>(ep.y, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
     return false;
