@@ -18,11 +18,11 @@ __global__ void fill(bf16_t* p, size_t n, unsigned seed) {
 template <int ABL> static int run(const LoadMNh& a, const LoadConvXcolh& b, const EpStore& ep, int P, int N, int Cout, const bf16_t* zero, const char* name) {
   const int tiles = (N / 256) * (Cout / 256); int ks = 256 / tiles; int kper = ((P + ks - 1) / ks + 31) / 32 * 32; ks = (P + kper - 1) / kper;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv_wgrad_dma_kernel<EpStore, ABL>), dim3(tiles * ks), dim3(512), 0, 0, a, b, ep, P, kper, N / 256, Cout / 256, zero, ks);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv_wgrad_dma_kernel<EpStore, ABL>), dim3(tiles * ks), dim3(512), 0, 0, a, b, ep, P, kper, N / 256, Cout / 256, zero, ks, (float*)nullptr, 0ll);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   const int it = 20;
-  for (int i = 0; i < it; ++i) hipLaunchKernelGGL((conv_wgrad_dma_kernel<EpStore, ABL>), dim3(tiles * ks), dim3(512), 0, 0, a, b, ep, P, kper, N / 256, Cout / 256, zero, ks);
+  for (int i = 0; i < it; ++i) hipLaunchKernelGGL((conv_wgrad_dma_kernel<EpStore, ABL>), dim3(tiles * ks), dim3(512), 0, 0, a, b, ep, P, kper, N / 256, Cout / 256, zero, ks, (float*)nullptr, 0ll);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   double us = ms * 1e3 / it;
