@@ -104,6 +104,9 @@ struct EpConv {
   // optional evaluation-mode BatchNorm + ReLU folded into the store (cnn.lua:23,32 under evaluate(): a per-channel affine map of the
   // conv output): bn_save = {mean, 1/sqrt(var + eps)}[2][Cout] (bn_eval_prepare), the same expression as bn_apply_relu_kernel
   const float* bn_save = nullptr; const float* bn_w = nullptr; const float* bn_b = nullptr;
+  // optional (training-mode BatchNorm behind this conv, staged 256 x 256 tiles only: tile256_store_f32): per-tile partial sums (sum y, sum y^2)
+  // of every output column, [row tile][Cout][2] doubles -- the layout bn_fwd_finalize_kernel / bn_sums_kernel read, so the statistics pass over y is not needed
+  double* bn_part = nullptr;
   template <int NT> __device__ __forceinline__ void quad(int m, int n, int nstep, const float (&v)[NT][4]) const {
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {

@@ -826,11 +826,12 @@ struct EpConv; struct EpStore;
 // NI = 32-column accumulator tiles per wave (wave tile 128 x 32 NI), NTH = threads of the workgroup.
 template <int NI, int NTH>
 __device__ __forceinline__ void tile256_store_f32(float* dst, int64_t ldc, const float* bias, bool relu, const f32x16 (&acc)[4][NI], unsigned char* lds,
-                                                  int m_blk, int n_blk, int wm, int wn, int r, int h, int tid) {
+                                                  int m_blk, int n_blk, int wm, int wn, int r, int h, int tid, double* part = nullptr, int C = 0) {
   constexpr int PITCH = 1024;                             // lanes r = consecutive dwords, the two row groups h are separate LDS cycles: no padding needed
   float bb[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) bb[ni] = bias ? bias[n_blk + wn * 32 * NI + ni * 32 + r] : 0.f;
+  float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   __syncthreads();                                        // every wave is out of the K loop
   for (int p = 0; p < 2; ++p) {
     if (wm == p) {
@@ -854,8 +855,27 @@ __device__ __forceinline__ void tile256_store_f32(float* dst, int64_t ldc, const
       const int idx = it * NTH + tid, row = idx >> 6, c = idx & 63;
       const float4 v = *reinterpret_cast<const float4*>(lds + row * PITCH + c * 16);
       *reinterpret_cast<float4*>(d0 + (int64_t)row * ldc + c * 4) = v;
+      if (part) {                                         // a thread keeps its four columns (c = tid & 63): column sums of exactly the stored values
+        ps[0] += v.x; ps[1] += v.y; ps[2] += v.z; ps[3] += v.w;
+        ps[4] = fmaf(v.x, v.x, ps[4]); ps[5] = fmaf(v.y, v.y, ps[5]); ps[6] = fmaf(v.z, v.z, ps[6]); ps[7] = fmaf(v.w, v.w, ps[7]);
+      }
     }
     __syncthreads();
+  }
+  if (part) {                                             // 32 (NTH = 512) / 64 rows per thread so far: the NTH / 64 row groups meet in LDS, fp64 from there on
+    float* const red = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[((tid >> 6) * 64 + (tid & 63)) * 8 + k] = ps[k];
+    __syncthreads();
+    if (tid < 64) {
+      double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int g = 0; g < NTH / 64; ++g)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) S[k] += (double)red[(g * 64 + tid) * 8 + k];
+      double* o = part + ((int64_t)(m_blk >> 8) * C + n_blk + tid * 4) * 2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o[2 * j] = S[j]; o[2 * j + 1] = S[4 + j]; }
+    }
   }
 }
 // the (2,1)-pooled tile: 128 pooled rows of 256 bf16 + 256 arg-max bytes
@@ -940,7 +960,7 @@ __device__ __forceinline__ bool tile256_store_staged(const EP& ep, const f32x16 
     if (ep.pmode == 0 && ep.yb && !ep.y && (opt & 2)) { tile256_store_bf16<NI, NTH>(ep.yb, ep.Cout, ep.bias, ep.relu != 0, ep.bn_save, ep.bn_w, ep.bn_b, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
     if (ep.bn_save) return false;
     if (ep.pmode == 2 && ep.yb && ep.idx && !ep.y && (opt & 4)) { tile256_store_pooled<NI, NTH>(ep.yb, ep.idx, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
-    if (ep.pmode == 0 && ep.y && !ep.yb && (opt & 2)) { tile256_store_f32<NI, NTH>(ep.y, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
+    if (ep.pmode == 0 && ep.y && !ep.yb && (opt & 2)) { tile256_store_f32<NI, NTH>(ep.y, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid, ep.bn_part, ep.Cout); return true; }
     return false;
   } else if constexpr (std::is_same<EP, EpStore>::value) {
     if (ep.flags || ep.bias || ep.bias2 || ep.C1 || ep.Cb || ep.dg || !(opt & 1) || m_blk + 256 > ep.M || n_blk + 256 > ep.N) return false;

@@ -333,9 +333,11 @@ void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training
     prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A2, m->conv[3].w, m->conv[3].b, nullptr, nullptr, B, d.H2, d.W2, 128, 256, 3, 1, 0, 0, m->A2b, m->wb[3], m->A3b, 0,
                                                    m->bn[3].save, m->bn[3].w, m->bn[3].b);
   } else {
-  prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A2, m->conv[3].w, m->conv[3].b, m->Y3, nullptr, B, d.H2, d.W2, 128, 256, 3, 1, 0, 0, m->A2b, m->wb[3], nullptr);
+  int bnc = 0;                                              // > 0: the conv's staged epilogue left the BatchNorm's partial sums in bn_scratch (training only)
+  prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A2, m->conv[3].w, m->conv[3].b, m->Y3, nullptr, B, d.H2, d.W2, 128, 256, 3, 1, 0, 0, m->A2b, m->wb[3], nullptr, 0,
+                                                 nullptr, nullptr, nullptr, training ? (double*)m->bn_scratch : nullptr, &bnc);
   prof_mark(m, AOCR_PROF_BN); bn_relu_forward(s, m->Y3, bf ? nullptr : m->A3, m->bn[3].w, m->bn[3].b, m->bn[3].rm, m->bn[3].rv, m->bn[3].save, m->bn_scratch,
-                  (int64_t)B * d.H2 * d.W2, 256, training, update_running, 0, m->A3b, bsync);
+                  (int64_t)B * d.H2 * d.W2, 256, training, update_running, 0, m->A3b, bsync, bnc);
   }
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A3, m->conv[4].w, m->conv[4].b, bf ? nullptr : m->A4, m->idx4, B, d.H2, d.W2, 256, 256, 3, 1, 1, 2, m->A3b, m->wb[4], m->A4b);
   if (fold) {
@@ -343,9 +345,11 @@ void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training
     prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A4, m->conv[5].w, m->conv[5].b, nullptr, nullptr, B, d.H4, d.W2, 256, 512, 3, 1, 0, 0, m->A4b, m->wb[5], m->A5b, 0,
                                                    m->bn[5].save, m->bn[5].w, m->bn[5].b);
   } else {
-  prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A4, m->conv[5].w, m->conv[5].b, m->Y5, nullptr, B, d.H4, d.W2, 256, 512, 3, 1, 0, 0, m->A4b, m->wb[5], nullptr);
+  int bnc = 0;
+  prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A4, m->conv[5].w, m->conv[5].b, m->Y5, nullptr, B, d.H4, d.W2, 256, 512, 3, 1, 0, 0, m->A4b, m->wb[5], nullptr, 0,
+                                                 nullptr, nullptr, nullptr, training ? (double*)m->bn_scratch : nullptr, &bnc);
   prof_mark(m, AOCR_PROF_BN); bn_relu_forward(s, m->Y5, bf ? nullptr : m->A5, m->bn[5].w, m->bn[5].b, m->bn[5].rm, m->bn[5].rv, m->bn[5].save, m->bn_scratch,
-                  (int64_t)B * d.H4 * d.W2, 512, training, update_running, 0, m->A5b, bsync);
+                  (int64_t)B * d.H4 * d.W2, 512, training, update_running, 0, m->A5b, bsync, bnc);
   }
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A5, m->conv[6].w, m->conv[6].b, bf ? nullptr : m->A6, m->idx6, B, d.H4, d.W2, 512, 512, 3, 1, 1, 2, m->A5b, m->wb[6], m->A6b);
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A6, m->conv[7].w, m->conv[7].b, m->Y7, nullptr, B, d.H6, d.W2, 512, 512, 2, 0, 0, 0, m->A6b, m->wb[7], nullptr);

@@ -100,7 +100,10 @@ void gemm_hh_shadow(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B
 void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, const float* bias, float* y, uint8_t* idx,
                   int B, int H, int W, int Cin, int Cout, int ks, int pad, int relu, int pool,
                   const bf16_t* xb = nullptr, const bf16_t* wb = nullptr, bf16_t* yb = nullptr, int profile_tag = 0,
-                  const float* bn_save = nullptr, const float* bn_w = nullptr, const float* bn_b = nullptr);
+                  const float* bn_save = nullptr, const float* bn_w = nullptr, const float* bn_b = nullptr,
+                  double* bn_part = nullptr, int* bn_chunks = nullptr);
+// bn_part / bn_chunks: scratch of the training-mode BatchNorm that follows (bn_relu_forward's `scratch`); when the launch taken stages its output tiles through
+// LDS the per-tile column sums are written there and *bn_chunks = the number of row tiles (pass it to bn_relu_forward as stats_chunks), else *bn_chunks = 0
 // bn_save != nullptr: evaluation-mode BatchNorm + ReLU folded into the conv epilogue (bn_save from bn_eval_prepare)
 void bn_eval_prepare(hipStream_t s, const float* rm, const float* rv, float* save, int C);
 // profile_tag != 0: the same kernel under a distinct symbol (aocr_profile_kernel), so profilers list these launches separately
@@ -129,7 +132,7 @@ size_t bn_scratch_bytes(int C);
 struct BnSync { int (*allreduce)(void* ctx, void* buf, int64_t count, int dtype, hipStream_t s); void* ctx; };
 void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, const float* b, float* rm, float* rv,
                      float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows,
-                     bf16_t* yb = nullptr, const BnSync* sync = nullptr);
+                     bf16_t* yb = nullptr, const BnSync* sync = nullptr, int stats_chunks = 0 /* > 0: scratch already holds that many chunks of partial sums (conv_forward's bn_part) */);
 void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
                       float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb = nullptr,
                       const bf16_t* yb = nullptr, float* conv_dbias = nullptr, float* partial = nullptr, const BnSync* sync = nullptr,

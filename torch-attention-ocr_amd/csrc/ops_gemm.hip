@@ -355,14 +355,23 @@ static LoadConvK make_convk(const float* src, int B, int Hs, int Ws, int C, int 
 
 void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, const float* bias, float* y, uint8_t* idx, int B,
                   int H, int W, int Cin, int Cout, int ks, int pad, int relu, int pool, const bf16_t* xb, const bf16_t* wb,
-                  bf16_t* yb, int profile_tag, const float* bn_save, const float* bn_w, const float* bn_b) {
+                  bf16_t* yb, int profile_tag, const float* bn_save, const float* bn_w, const float* bn_b, double* bn_part, int* bn_chunks) {
   const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
   LoadConvK a = make_convk(x, B, H, W, Cin, ks, 1, -pad, Ho, Wo, pool);
   EpConv ep; ep.y = y; ep.idx = idx; ep.bias = bias; ep.Cout = Cout; ep.rows = a.rows; ep.pmode = pool; ep.relu = relu; ep.yb = yb;
   ep.bn_save = bn_save; ep.bn_w = bn_w; ep.bn_b = bn_b;
+  if (bn_chunks) *bn_chunks = 0;
   if (bf16 && xb && wb) {
     LoadConvKh ah; ah.src = xb; ah.g = a;
     LoadKh bh; bh.p = wb; bh.ld = a.K; bh.rows = Cout; bh.K = a.K;
+    // BatchNorm statistics in the epilogue: only where EVERY tile of the launch takes tile256_store_f32 (full 256 x 256 tiles of a 256-wide LDS-DMA kernel with the
+    // staged fp32 tile switched on; the 8-wave halo kernel has no staged epilogue), and the row tiles fit bn_relu_forward's chunk table (512)
+    if (bn_part && bn_chunks && y && !yb && !bn_save && pool == 0 && dma_eligible(a.rows, Cout, a.K, Cin) && a.rows % 256 == 0 && a.rows / 256 <= 512 && !getenv("AOCR_NO_BN_STATS_FUSE")) {
+      const char* const so = getenv("AOCR_HALO4_STAGED");
+      const bool staged = ((so ? atoi(so) : 7) & 2) != 0;
+      const bool halo = pad == 1 && halo_eligible(a, Cout, 256, 256);
+      if (staged && !(halo && getenv("AOCR_HALO8"))) { ep.bn_part = bn_part; *bn_chunks = a.rows / 256; }
+    }
     if (dma_eligible(a.rows, Cout, a.K, Cin) && pad == 1 && halo_eligible(a, Cout, 256, 256)) launch_halo<1, 256, 256>(s, ah, bh, ep, a.rows, Cout, profile_tag);
     else if (dma_eligible(a.rows, Cout, a.K, Cin)) launch_dma(s, ah, bh, ep, a.rows, Cout, a.K, profile_tag);
     else if (dma_narrow_eligible(a.rows, Cout, a.K, Cin)) launch_dma_narrow(s, ah, bh, ep, a.rows, Cout, a.K);

@@ -640,11 +640,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, const float* b, float* rm, float* rv,
                      float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows, bf16_t* yb,
-                     const BnSync* sync) {
+                     const BnSync* sync, int stats_chunks) {
   int T = tb_rows > 0 ? (int)(rows / tb_rows) : 0;
   if (training) {
     double* part = (double*)scratch;
     int nchunk = (int)std::min<int64_t>(BN_CHUNKS, (rows + 63) / 64);
+    if (stats_chunks > 0 && stats_chunks <= BN_CHUNKS) nchunk = stats_chunks;      // the producing conv's epilogue wrote the partial sums (EpConv::bn_part)
+    else
     if (bn_partial4_ok(C)) hipLaunchKernelGGL(bn_partial4_kernel<0>, dim3(nchunk), dim3(1024), 0, s, x, nullptr, nullptr, nullptr, part, rows, C, 0, 0, nullptr);
     else hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, x, nullptr, nullptr, nullptr, part, rows,
                             C, 0, 0, 0, nullptr);
