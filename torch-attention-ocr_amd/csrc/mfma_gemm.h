@@ -826,11 +826,11 @@ struct EpConv; struct EpStore;
 // NI = 32-column accumulator tiles per wave (wave tile 128 x 32 NI), NTH = threads of the workgroup.
 template <int NI, int NTH>
 __device__ __forceinline__ void tile256_store_f32(float* dst, int64_t ldc, const float* bias, bool relu, const f32x16 (&acc)[4][NI], unsigned char* lds,
-                                                  int m_blk, int n_blk, int wm, int wn, int r, int h, int tid, double* part = nullptr, int C = 0) {
+                                                  int m_blk, int n_blk, int wm, int wn, int r, int h, int tid, double* part = nullptr, int C = 0, const float* bias2 = nullptr) {
   constexpr int PITCH = 1024;                             // lanes r = consecutive dwords, the two row groups h are separate LDS cycles: no padding needed
   float bb[NI];
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) bb[ni] = bias ? bias[n_blk + wn * 32 * NI + ni * 32 + r] : 0.f;
+  for (int ni = 0; ni < NI; ++ni) bb[ni] = (bias ? bias[n_blk + wn * 32 * NI + ni * 32 + r] : 0.f) + (bias2 ? bias2[n_blk + wn * 32 * NI + ni * 32 + r] : 0.f);
   float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   __syncthreads();                                        // every wave is out of the K loop
   for (int p = 0; p < 2; ++p) {
@@ -963,8 +963,8 @@ __device__ __forceinline__ bool tile256_store_staged(const EP& ep, const f32x16 
     if (ep.pmode == 0 && ep.y && !ep.yb && (opt & 2)) { tile256_store_f32<NI, NTH>(ep.y, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid, ep.bn_part, ep.Cout); return true; }
     return false;
   } else if constexpr (std::is_same<EP, EpStore>::value) {
-    if (ep.flags || ep.bias || ep.bias2 || ep.C1 || ep.Cb || ep.dg || !(opt & 1) || m_blk + 256 > ep.M || n_blk + 256 > ep.N) return false;
-    tile256_store_f32<NI, NTH>(ep.C, ep.ldc, nullptr, false, acc, lds, m_blk, n_blk, wm, wn, r, h, tid);
+    if (ep.flags || ep.C1 || ep.Cb || ep.dg || !(opt & 1) || m_blk + 256 > ep.M || n_blk + 256 > ep.N) return false;
+    tile256_store_f32<NI, NTH>(ep.C, ep.ldc, ep.bias, false, acc, lds, m_blk, n_blk, wm, wn, r, h, tid, nullptr, 0, ep.bias2);
     return true;
   } else return false;
 }

@@ -289,6 +289,7 @@ void gemm_hh(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64
   // (the 256 x 256 LDS-DMA kernel was measured slower here: K = 512 is only 16 tiles deep -- hoisted encoder projection at C3,
   // 63 x 4 workgroups: 56 / 47 us against 47 / 43 us; round 3: the BK = 64 form of the 128 x 128 kernel -- half the barriers and
   // staging round trips over the 16 tiles -- measured slower too: hoisted GEMMs 0.726 -> 0.745 ms per step)
+  // (round 3, again with that kernel's output tile staged through LDS: hoisted GEMMs 0.750 -> 0.760 ms per step: still no faster)
   launch_lds(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K, 1);
 }
 
