@@ -7,8 +7,8 @@ import torch
 from test_step_gpu import make
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 drop = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0            # round 3: the dropout instances of the decoder cluster kernels
-for (B, W, L) in ((256, 256, 24), (70, 416, 13)):
-    m, O, ocfg, P, st, batch = make(dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True), B=B, W=W, maxlen=L - 1, compute="bf16", max_decoder_l=50, max_beam=1)
+for (B, W, L, He, Le) in ((256, 256, 24, 256, 1), (70, 416, 13, 256, 1), (16, 1024, 13, 512, 2)):       # the third: a stacked encoder as a layer wavefront on its own streams (T = 255: 5 chunks)
+    m, O, ocfg, P, st, batch = make(dict(enc_hidden=He, enc_layers=Le, dec_layers=2, input_feed=True), B=B, W=W, maxlen=L - 1, compute="bf16", max_decoder_l=50, max_beam=1)
     images, targets, targets_eval = m._upload(batch)
     m.optim_state["learningRate"] = 1e-4
     m.dropout = drop
