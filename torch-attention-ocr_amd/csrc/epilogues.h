@@ -107,6 +107,9 @@ struct EpConv {
   // optional (training-mode BatchNorm behind this conv, staged 256 x 256 tiles only: tile256_store_f32): per-tile partial sums (sum y, sum y^2)
   // of every output column, [row tile][Cout][2] doubles -- the layout bn_fwd_finalize_kernel / bn_sums_kernel read, so the statistics pass over y is not needed
   double* bn_part = nullptr;
+  // with bn_part: write the (pre-BatchNorm) output as bf16 here instead of fp32 into y -- its statistics are taken from the fp32 accumulators in the
+  // epilogue, and every later reader (apply pass, both backward passes) then moves half the bytes (staged tiles only: conv_forward guarantees that)
+  bf16_t* y16 = nullptr;
   template <int NT> __device__ __forceinline__ void quad(int m, int n, int nstep, const float (&v)[NT][4]) const {
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {

@@ -922,7 +922,7 @@ __device__ __forceinline__ void tile256_store_pooled(bf16_t* yb, uint8_t* idxp, 
 // the bf16-only tile (evaluation mode: conv3 / conv5 with their BatchNorm + ReLU folded in, EpConv::bn_save): [256][256] bf16 = 128 KB, one pass
 template <int NI, int NTH>
 __device__ __forceinline__ void tile256_store_bf16(bf16_t* yb, int Cout, const float* bias, bool relu, const float* bn_save, const float* bn_w, const float* bn_b,
-                                                   const f32x16 (&acc)[4][NI], unsigned char* lds, int m_blk, int n_blk, int wm, int wn, int r, int h, int tid) {
+                                                   const f32x16 (&acc)[4][NI], unsigned char* lds, int m_blk, int n_blk, int wm, int wn, int r, int h, int tid, double* part = nullptr) {
   float bb[NI], mu[NI], iv[NI], ww[NI], b2[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -930,6 +930,9 @@ __device__ __forceinline__ void tile256_store_bf16(bf16_t* yb, int Cout, const f
     bb[ni] = bias ? bias[col] : 0.f;
     mu[ni] = bn_save ? bn_save[col] : 0.f; iv[ni] = bn_save ? bn_save[Cout + col] : 1.f; ww[ni] = bn_save ? bn_w[col] : 1.f; b2[ni] = bn_save ? bn_b[col] : 0.f;
   }
+  float ps[NI], pss[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) { ps[ni] = 0.f; pss[ni] = 0.f; }
   __syncthreads();
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
@@ -942,6 +945,7 @@ __device__ __forceinline__ void tile256_store_bf16(bf16_t* yb, int Cout, const f
           float x = acc[mi][ni][4 * q + i] + bb[ni];
           if (relu) x = fmaxf(x, 0.f);
           if (bn_save) x = fmaxf((x - mu[ni]) * iv[ni] * ww[ni] + b2[ni], 0.f);      // the same expression as EpConv::quad / bn_apply_relu_kernel
+          ps[ni] += x; pss[ni] = fmaf(x, x, pss[ni]);                                 // (part: column sums of the UNROUNDED values, 64 per lane and column)
           *reinterpret_cast<bf16_t*>(lds + (wm * 128 + mi * 32 + 8 * q + 4 * h + i) * 512 + (wn * 32 * NI + ni * 32 + r) * 2) = (bf16_t)x;
         }
   __syncthreads();
@@ -951,12 +955,31 @@ __device__ __forceinline__ void tile256_store_bf16(bf16_t* yb, int Cout, const f
     const uint4 v = *reinterpret_cast<const uint4*>(lds + row * 512 + c * 16);
     *reinterpret_cast<uint4*>(yb + (int64_t)(m_blk + row) * Cout + n_blk + c * 8) = v;
   }
+  if (part) {                                             // the four (row half wm, row group h) partials of a column meet in LDS, fp64 from there on
+    __syncthreads();
+    float* const red = reinterpret_cast<float*>(lds);     // [wm][h][256 columns][2]
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      float* o = red + (((wm * 2 + h) * 256) + wn * 32 * NI + ni * 32 + r) * 2;
+      o[0] = ps[ni]; o[1] = pss[ni];
+    }
+    __syncthreads();
+    if (tid < 256) {
+      double S = 0.0, SS = 0.0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { S += (double)red[((g * 256) + tid) * 2]; SS += (double)red[((g * 256) + tid) * 2 + 1]; }
+      double* o = part + ((int64_t)(m_blk >> 8) * Cout + n_blk + tid) * 2;
+      o[0] = S; o[1] = SS;
+    }
+  }
 }
 // full 256 x 256 tiles only (the callers' grids may end in a ragged tile: that one takes the quad epilogue)
 template <int NI, int NTH, class EP>
 __device__ __forceinline__ bool tile256_store_staged(const EP& ep, const f32x16 (&acc)[4][NI], unsigned char* lds, int m_blk, int n_blk, int wm, int wn, int r, int h, int tid, int opt) {
   if constexpr (std::is_same<EP, EpConv>::value) {
     if (m_blk + 256 > ep.rows || n_blk + 256 > ep.Cout) return false;
+    if (ep.pmode == 0 && ep.y16 && ep.bn_part && !ep.yb && !ep.bn_save && (opt & 2)) {     // pre-BatchNorm output as bf16 + its statistics (training)
+      tile256_store_bf16<NI, NTH>(ep.y16, ep.Cout, ep.bias, ep.relu != 0, nullptr, nullptr, nullptr, acc, lds, m_blk, n_blk, wm, wn, r, h, tid, ep.bn_part); return true; }
     if (ep.pmode == 0 && ep.yb && !ep.y && (opt & 2)) { tile256_store_bf16<NI, NTH>(ep.yb, ep.Cout, ep.bias, ep.relu != 0, ep.bn_save, ep.bn_w, ep.bn_b, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
     if (ep.bn_save) return false;
     if (ep.pmode == 2 && ep.yb && ep.idx && !ep.y && (opt & 4)) { tile256_store_pooled<NI, NTH>(ep.yb, ep.idx, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }

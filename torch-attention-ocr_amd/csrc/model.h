@@ -72,6 +72,7 @@ struct aocr_model {
   // bf16 shadows of the recurrent activations / gradients (written by the producing epilogues)
   aocr::bf16_t *Xb, *ehs_b[2][aocr::MAXL], *edz_b[2][aocr::MAXL], *dhs_b[aocr::MAXL], *ddz_b[aocr::MAXL], *out_b, *cat_b, *dpre_b, *dq_b;
   void* bn_scratch; float* bn_save;
+  int y16[2] = {0, 0};            // the last forward pass left Y3 / Y5 (pre-BatchNorm maps) as bf16 in the first half of their buffers (conv_forward: y_bf16)
   // encoder [dir][layer]
   float *ezx[2][aocr::MAXL], *ehs[2][aocr::MAXL], *ecs[2][aocr::MAXL], *egates[2][aocr::MAXL], *edz[2][aocr::MAXL], *edc[2][aocr::MAXL];
   float *edxl[2];

@@ -335,9 +335,9 @@ void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training
   } else {
   int bnc = 0;                                              // > 0: the conv's staged epilogue left the BatchNorm's partial sums in bn_scratch (training only)
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A2, m->conv[3].w, m->conv[3].b, m->Y3, nullptr, B, d.H2, d.W2, 128, 256, 3, 1, 0, 0, m->A2b, m->wb[3], nullptr, 0,
-                                                 nullptr, nullptr, nullptr, training ? (double*)m->bn_scratch : nullptr, &bnc);
+                                                 nullptr, nullptr, nullptr, training ? (double*)m->bn_scratch : nullptr, &bnc, &m->y16[0]);
   prof_mark(m, AOCR_PROF_BN); bn_relu_forward(s, m->Y3, bf ? nullptr : m->A3, m->bn[3].w, m->bn[3].b, m->bn[3].rm, m->bn[3].rv, m->bn[3].save, m->bn_scratch,
-                  (int64_t)B * d.H2 * d.W2, 256, training, update_running, 0, m->A3b, bsync, bnc);
+                  (int64_t)B * d.H2 * d.W2, 256, training, update_running, 0, m->A3b, bsync, bnc, m->y16[0] ? reinterpret_cast<const bf16_t*>(m->Y3) : nullptr);
   }
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A3, m->conv[4].w, m->conv[4].b, bf ? nullptr : m->A4, m->idx4, B, d.H2, d.W2, 256, 256, 3, 1, 1, 2, m->A3b, m->wb[4], m->A4b);
   if (fold) {
@@ -347,9 +347,9 @@ void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training
   } else {
   int bnc = 0;
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A4, m->conv[5].w, m->conv[5].b, m->Y5, nullptr, B, d.H4, d.W2, 256, 512, 3, 1, 0, 0, m->A4b, m->wb[5], nullptr, 0,
-                                                 nullptr, nullptr, nullptr, training ? (double*)m->bn_scratch : nullptr, &bnc);
+                                                 nullptr, nullptr, nullptr, training ? (double*)m->bn_scratch : nullptr, &bnc, &m->y16[1]);
   prof_mark(m, AOCR_PROF_BN); bn_relu_forward(s, m->Y5, bf ? nullptr : m->A5, m->bn[5].w, m->bn[5].b, m->bn[5].rm, m->bn[5].rv, m->bn[5].save, m->bn_scratch,
-                  (int64_t)B * d.H4 * d.W2, 512, training, update_running, 0, m->A5b, bsync, bnc);
+                  (int64_t)B * d.H4 * d.W2, 512, training, update_running, 0, m->A5b, bsync, bnc, m->y16[1] ? reinterpret_cast<const bf16_t*>(m->Y5) : nullptr);
   }
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A5, m->conv[6].w, m->conv[6].b, bf ? nullptr : m->A6, m->idx6, B, d.H4, d.W2, 512, 512, 3, 1, 1, 2, m->A5b, m->wb[6], m->A6b);
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A6, m->conv[7].w, m->conv[7].b, m->Y7, nullptr, B, d.H6, d.W2, 512, 512, 2, 0, 0, 0, m->A6b, m->wb[7], nullptr);
@@ -383,7 +383,7 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, bf ? nullptr : m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, G0b, m->wg_part, m->wg_part_floats);
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, G0b, m->wtb[6], m->wtf[6]);
   prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, bf ? nullptr : G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
-                   (int64_t)B * d.H4 * d.W2, 512, 0, G0b, bf ? m->A5b : nullptr, bf ? m->conv[5].db : nullptr, bf ? slab(2) : nullptr, bsync, defer);
+                   (int64_t)B * d.H4 * d.W2, 512, 0, G0b, bf ? m->A5b : nullptr, bf ? m->conv[5].db : nullptr, bf ? slab(2) : nullptr, bsync, defer, m->y16[1] ? reinterpret_cast<const bf16_t*>(m->Y5) : nullptr);
   prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, bf ? nullptr : m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, G0b, m->wg_part, m->wg_part_floats);
   if (defer) colsum_flush(s, cj);                               // conv7.b, conv6.b, conv5.b
   hipEventRecord(m->grad_ev[2], s);                             // every CNN gradient from conv5.w upwards is complete
@@ -392,7 +392,7 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, bf ? nullptr : m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, G0b, m->wg_part, m->wg_part_floats);
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, G0b, m->wtb[4], m->wtf[4]);
   prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y3, m->A3, G1, m->bn[3].w, m->bn[3].save, bf ? nullptr : G0, m->bn[3].dw, m->bn[3].db, m->bn_scratch,
-                   (int64_t)B * d.H2 * d.W2, 256, 0, G0b, bf ? m->A3b : nullptr, bf ? m->conv[3].db : nullptr, bf ? slab(4) : nullptr, bsync, defer);
+                   (int64_t)B * d.H2 * d.W2, 256, 0, G0b, bf ? m->A3b : nullptr, bf ? m->conv[3].db : nullptr, bf ? slab(4) : nullptr, bsync, defer, m->y16[0] ? reinterpret_cast<const bf16_t*>(m->Y3) : nullptr);
   prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A2, G0, m->conv[3].dw, bf ? nullptr : m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, G0b, m->wg_part, m->wg_part_floats);
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1, G0b, m->wtb[3], m->wtf[3]);
   prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A2, m->idx2, bf ? nullptr : G0, B, d.H1, d.W1, 128, 1, G0b, bf ? m->conv[2].db : nullptr, bf ? slab(5) : nullptr, bf ? m->A2b : nullptr, defer);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)

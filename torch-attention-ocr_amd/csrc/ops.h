@@ -101,9 +101,10 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
                   int B, int H, int W, int Cin, int Cout, int ks, int pad, int relu, int pool,
                   const bf16_t* xb = nullptr, const bf16_t* wb = nullptr, bf16_t* yb = nullptr, int profile_tag = 0,
                   const float* bn_save = nullptr, const float* bn_w = nullptr, const float* bn_b = nullptr,
-                  double* bn_part = nullptr, int* bn_chunks = nullptr);
+                  double* bn_part = nullptr, int* bn_chunks = nullptr, int* y_bf16 = nullptr);
 // bn_part / bn_chunks: scratch of the training-mode BatchNorm that follows (bn_relu_forward's `scratch`); when the launch taken stages its output tiles through
-// LDS the per-tile column sums are written there and *bn_chunks = the number of row tiles (pass it to bn_relu_forward as stats_chunks), else *bn_chunks = 0
+// LDS the per-tile column sums are written there and *bn_chunks = the number of row tiles (pass it to bn_relu_forward as stats_chunks), else *bn_chunks = 0.
+// y_bf16 (with them): the caller accepts y written as bf16 INTO THE SAME BUFFER (half of it); *y_bf16 = 1 when that happened (only under AOCR_BN_Y16=1: see conv_forward)
 // bn_save != nullptr: evaluation-mode BatchNorm + ReLU folded into the conv epilogue (bn_save from bn_eval_prepare)
 void bn_eval_prepare(hipStream_t s, const float* rm, const float* rv, float* save, int C);
 // profile_tag != 0: the same kernel under a distinct symbol (aocr_profile_kernel), so profilers list these launches separately
@@ -132,11 +133,12 @@ size_t bn_scratch_bytes(int C);
 struct BnSync { int (*allreduce)(void* ctx, void* buf, int64_t count, int dtype, hipStream_t s); void* ctx; };
 void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, const float* b, float* rm, float* rv,
                      float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows,
-                     bf16_t* yb = nullptr, const BnSync* sync = nullptr, int stats_chunks = 0 /* > 0: scratch already holds that many chunks of partial sums (conv_forward's bn_part) */);
+                     bf16_t* yb = nullptr, const BnSync* sync = nullptr, int stats_chunks = 0 /* > 0: scratch already holds that many chunks of partial sums (conv_forward's bn_part) */,
+                     const bf16_t* xh = nullptr /* x as bf16 (conv_forward wrote it so: *y_bf16) */);
 void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
                       float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb = nullptr,
                       const bf16_t* yb = nullptr, float* conv_dbias = nullptr, float* partial = nullptr, const BnSync* sync = nullptr,
-                      ColsumJobs* defer = nullptr);
+                      ColsumJobs* defer = nullptr, const bf16_t* xh = nullptr /* x as bf16 */);
 // yb: bf16 shadow of y (ReLU mask source); conv_dbias + partial (>= 4096*256 floats): fused bias gradient of the preceding conv, dx may then be null
 // ctx_div: rows r share context row r / ctx_div (beam search keeps one context per image, model.lua:373)
 void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a, float* c, int64_t ldc, int B, int T, int Hd,

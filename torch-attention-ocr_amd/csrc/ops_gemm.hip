@@ -356,12 +356,13 @@ static LoadConvK make_convk(const float* src, int B, int Hs, int Ws, int C, int 
 
 void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, const float* bias, float* y, uint8_t* idx, int B,
                   int H, int W, int Cin, int Cout, int ks, int pad, int relu, int pool, const bf16_t* xb, const bf16_t* wb,
-                  bf16_t* yb, int profile_tag, const float* bn_save, const float* bn_w, const float* bn_b, double* bn_part, int* bn_chunks) {
+                  bf16_t* yb, int profile_tag, const float* bn_save, const float* bn_w, const float* bn_b, double* bn_part, int* bn_chunks, int* y_bf16) {
   const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
   LoadConvK a = make_convk(x, B, H, W, Cin, ks, 1, -pad, Ho, Wo, pool);
   EpConv ep; ep.y = y; ep.idx = idx; ep.bias = bias; ep.Cout = Cout; ep.rows = a.rows; ep.pmode = pool; ep.relu = relu; ep.yb = yb;
   ep.bn_save = bn_save; ep.bn_w = bn_w; ep.bn_b = bn_b;
   if (bn_chunks) *bn_chunks = 0;
+  if (y_bf16) *y_bf16 = 0;
   if (bf16 && xb && wb) {
     LoadConvKh ah; ah.src = xb; ah.g = a;
     LoadKh bh; bh.p = wb; bh.ld = a.K; bh.rows = Cout; bh.K = a.K;
@@ -371,7 +372,13 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
       const char* const so = getenv("AOCR_HALO4_STAGED");
       const bool staged = ((so ? atoi(so) : 7) & 2) != 0;
       const bool halo = pad == 1 && halo_eligible(a, Cout, 256, 256);
-      if (staged && !(halo && getenv("AOCR_HALO8"))) { ep.bn_part = bn_part; *bn_chunks = a.rows / 256; }
+      if (staged && !(halo && getenv("AOCR_HALO8"))) {
+        ep.bn_part = bn_part; *bn_chunks = a.rows / 256;
+        // The statistics come from the accumulators, so y itself could be stored as bf16 (AOCR_BN_Y16=1): -0.065 ms per C3 step (BatchNorm 0.49 -> 0.46 ms, conv forward
+        // 0.83 -> 0.755) -- NOT the default: it is one more rounding than "bf16 contraction operands" (the model tests/test_configs_gpu.py holds the product to), and the
+        // ReLU / arg-max decisions it flips take the conv-stack gradients from cosine 0.997 to 0.986 against the bf16-operand oracle (limit 0.995).
+        if (y_bf16 && getenv("AOCR_BN_Y16")) { ep.y16 = reinterpret_cast<bf16_t*>(y); ep.y = nullptr; *y_bf16 = 1; }
+      }
     }
     if (dma_eligible(a.rows, Cout, a.K, Cin) && pad == 1 && halo_eligible(a, Cout, 256, 256)) launch_halo<1, 256, 256>(s, ah, bh, ep, a.rows, Cout, profile_tag);
     else if (dma_eligible(a.rows, Cout, a.K, Cin)) launch_dma(s, ah, bh, ep, a.rows, Cout, a.K, profile_tag);

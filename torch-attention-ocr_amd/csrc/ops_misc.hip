@@ -483,11 +483,16 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 // The same partial sums with 16-byte accesses and four rows in flight per thread (C / 4 a power of two <= 256): one thread =
 // one channel quad, 1024 threads = 1024 / (C/4) rows per pass; the row groups are combined through LDS one value at a time.
 // (bn_partial_kernel: 4-byte accesses, one or two loads in flight per thread -- 2.9 TB/s on the 268 MB backward pass of conv3.)
+// x of a BatchNorm either as fp32 or (xh != nullptr: the conv epilogue wrote the pre-BatchNorm map as bf16, EpConv::y16) as bf16
+__device__ __forceinline__ float4 bn_ldx4(const float* __restrict__ x, const bf16_t* __restrict__ xh, int64_t off) {
+  if (xh) { const bf16x4 t = *reinterpret_cast<const bf16x4*>(xh + off); return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]); }
+  return *reinterpret_cast<const float4*>(x + off);
+}
 template <int MODE>
 __global__ __launch_bounds__(1024) void bn_partial4_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dA, const float* __restrict__ save,
                                                            double* __restrict__ part, int64_t rows, int C, int tb_rows, int T,
-                                                           const bf16_t* __restrict__ yb) {
+                                                           const bf16_t* __restrict__ yb, const bf16_t* __restrict__ xh = nullptr) {
   __shared__ double sh[1024];
   const int C4 = C >> 2, q = threadIdx.x & (C4 - 1), rl = threadIdx.x / C4, RP = 1024 / C4, c = q * 4;
   const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(1024) void bn_partial4_kernel(const float* __restri
     float4 xv[4], dv[4]; float yy[4][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      xv[u] = *reinterpret_cast<const float4*>(x + (r + u * RP) * C + c);
+      xv[u] = bn_ldx4(x, xh, (r + u * RP) * C + c);
       if (MODE == 1) { const int64_t ro = orow(r + u * RP); dv[u] = *reinterpret_cast<const float4*>(dA + ro * C + c); loady(ro, yy[u]); }
       else dv[u] = xv[u];
     }
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(1024) void bn_partial4_kernel(const float* __restri
     for (int u = 0; u < 4; ++u) accum(xv[u], dv[u], yy[u]);
   }
   for (; r < r1; r += RP) {
-    const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c); float4 dv = xv; float yy[4] = {0.f, 0.f, 0.f, 0.f};
+    const float4 xv = bn_ldx4(x, xh, r * C + c); float4 dv = xv; float yy[4] = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 1) { const int64_t ro = orow(r); dv = *reinterpret_cast<const float4*>(dA + ro * C + c); loady(ro, yy); }
     accum(xv, dv, yy);
   }
@@ -621,12 +626,12 @@ void bn_eval_prepare(hipStream_t s, const float* rm, const float* rv, float* sav
 __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             const float* __restrict__ save, int64_t rows, int C, int tb_rows,
-                                                            int T, bf16_t* __restrict__ yb) {
+                                                            int T, bf16_t* __restrict__ yb, const bf16_t* __restrict__ xh = nullptr) {
   const int C4 = C >> 2;
   const int64_t total = rows * C4;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
     int c = (int)(id % C4) * 4; int64_t r = id / C4;
-    float4 xv = *reinterpret_cast<const float4*>(x + r * C + c);
+    float4 xv = bn_ldx4(x, xh, r * C + c);
     float4 m = *reinterpret_cast<const float4*>(save + c), iv = *reinterpret_cast<const float4*>(save + C + c);
     float4 ww = *reinterpret_cast<const float4*>(w + c), bb = *reinterpret_cast<const float4*>(b + c);
     float4 o;
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ save, const double* __restrict__ fin,
                                                            float* __restrict__ dx, int64_t rows, int C, int tb_rows, int T,
                                                            bf16_t* __restrict__ dxb, const bf16_t* __restrict__ yb,
-                                                           float* __restrict__ partial) {
+                                                           float* __restrict__ partial, const bf16_t* __restrict__ xh = nullptr) {
   const int C4 = C >> 2;                                // one channel quad per thread and iteration (16-byte accesses)
   const int64_t total = rows * C4;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -671,7 +676,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     if (yb) { bf16x4 t4 = *reinterpret_cast<const bf16x4*>(yb + ro * C + c); yy[0] = (float)t4[0]; yy[1] = (float)t4[1]; yy[2] = (float)t4[2]; yy[3] = (float)t4[3]; }
     else { float4 t4 = *reinterpret_cast<const float4*>(y + ro * C + c); yy[0] = t4.x; yy[1] = t4.y; yy[2] = t4.z; yy[3] = t4.w; }
     const float4 da4 = *reinterpret_cast<const float4*>(dA + ro * C + c);
-    const float4 x4 = *reinterpret_cast<const float4*>(x + r * C + c);
+    const float4 x4 = bn_ldx4(x, xh, r * C + c);
     const float da[4] = {da4.x, da4.y, da4.z, da4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
     float gx[4];
 #pragma unroll
@@ -690,7 +695,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, const float* b, float* rm, float* rv,
                      float* save, void* scratch, int64_t rows, int C, int training, int update_running, int tb_rows, bf16_t* yb,
-                     const BnSync* sync, int stats_chunks) {
+                     const BnSync* sync, int stats_chunks, const bf16_t* xh) {
   int T = tb_rows > 0 ? (int)(rows / tb_rows) : 0;
   if (training) {
     double* part = (double*)scratch;
@@ -713,16 +718,16 @@ void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, co
   }
   int64_t total = rows * (C / 4);
   int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
-  hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(blocks), dim3(256), 0, s, x, y, w, b, save, rows, C, tb_rows, T, yb);
+  hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(blocks), dim3(256), 0, s, x, y, w, b, save, rows, C, tb_rows, T, yb, xh);
 }
 void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
                       float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb,
-                      const bf16_t* yb, float* conv_dbias, float* partial, const BnSync* sync, ColsumJobs* defer) {
+                      const bf16_t* yb, float* conv_dbias, float* partial, const BnSync* sync, ColsumJobs* defer, const bf16_t* xh) {
   int T = tb_rows > 0 ? (int)(rows / tb_rows) : 0;
   double* part = (double*)scratch;
   double* fin = part + (size_t)BN_CHUNKS * C * 2;
   int nchunk = (int)std::min<int64_t>(BN_CHUNKS, (rows + 63) / 64);
-  if (bn_partial4_ok(C)) hipLaunchKernelGGL(bn_partial4_kernel<1>, dim3(nchunk), dim3(1024), 0, s, x, y, dA, save, part, rows, C, tb_rows, T, yb);
+  if (bn_partial4_ok(C)) hipLaunchKernelGGL(bn_partial4_kernel<1>, dim3(nchunk), dim3(1024), 0, s, x, y, dA, save, part, rows, C, tb_rows, T, yb, xh);
   else hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, x, y, dA, save, part, rows, C, 1, tb_rows, T, yb);
   if (sync) {                                             // mean(dy), mean(dy * xhat) over the GLOBAL batch
     hipLaunchKernelGGL(bn_sums_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, part, nchunk, rows, C, fin, dw, db);
@@ -737,12 +742,12 @@ void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float
     // the grid stride (blocks * 256 quads) is a multiple of C4, so a thread keeps its channel quad: the flat partial slab
     // [blocks * 256][4] is a [blocks * 256 / C4][C] matrix whose column sums are the bias gradient
     int fb = (int)std::min<int64_t>((total + 255) / 256, 2048);
-    if (dx) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), dim3(fb), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, partial);
-    else    hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), dim3(fb), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, partial);
+    if (dx) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), dim3(fb), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, partial, xh);
+    else    hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), dim3(fb), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, partial, xh);
     if (defer) colsum_defer(*defer, partial, C, (int64_t)fb * 256 / C4, C, conv_dbias); else colsum_accum(s, partial, C, (int64_t)fb * 256 / C4, C, conv_dbias);
     return;
   }
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), dim3(blocks), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, nullptr);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), dim3(blocks), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, nullptr, xh);
 }
 
 // =============================================================================================
