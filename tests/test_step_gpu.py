@@ -249,8 +249,8 @@ def test_halo_four_wave_kernel_matches_eight_wave_kernel(cuda, monkeypatch, B, W
     monkeypatch.setenv("AOCR_FORCE_DMA", "1")                   # small batches: take the 256 x 256 kernels although they do not fill the chip
     out = {}
     # (the staged fp32 tile also leaves the BatchNorm's partial sums: another summation order of the statistics, compared separately below)
-    for name, env in (("four", {"AOCR_NO_BN_STATS_FUSE": "1"}), ("eight", {"AOCR_HALO8": "1", "AOCR_NO_BN_STATS_FUSE": "1"}), ("direct", {"AOCR_HALO4_STAGED": "0"}), ("fused", {})):
-        for k in ("AOCR_HALO8", "AOCR_HALO4_STAGED", "AOCR_NO_BN_STATS_FUSE"):
+    for name, env in (("four", {"AOCR_NO_BN_STATS_FUSE": "1"}), ("eight", {"AOCR_HALO8": "1", "AOCR_NO_BN_STATS_FUSE": "1"}), ("direct", {"AOCR_HALO4_STAGED": "0"}), ("fused", {}), ("y16", {"AOCR_BN_Y16": "1"})):
+        for k in ("AOCR_HALO8", "AOCR_HALO4_STAGED", "AOCR_NO_BN_STATS_FUSE", "AOCR_BN_Y16"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -283,6 +283,11 @@ def test_halo_four_wave_kernel_matches_eight_wave_kernel(cuda, monkeypatch, B, W
     bn = {k: cosine(b["grads"][k], a["grads"][k]) for k in a["grads"] if k.startswith("cnn.bn")}
     print(f"[parity]   running statistics rel {es:.3e}; BatchNorm weight / bias gradients, cosine:", {k: f"{v:.6f}" for k, v in bn.items()})
     assert es < 1e-5
+    # the opt-in bf16 pre-BatchNorm maps (AOCR_BN_Y16=1; off by default: one rounding more than the bf16-operand model): activations and the later layers' statistics within bf16 noise
+    c = out["y16"]
+    ey = relerr(c["feats"], b["feats"]); esy = relerr(c["bn_state"], b["bn_state"])
+    print(f"[parity]   AOCR_BN_Y16=1: feats rel {ey:.3e}, running statistics rel {esy:.3e}, loss {c['loss']:.5f} vs {b['loss']:.5f}")
+    assert ey < 3e-2 and esy < 1e-3 and abs(c["loss"] - b["loss"]) < 2e-3 * max(1.0, abs(b["loss"]))
     assert min(bn.values()) > 0.995       # (a handful of images: the single ReLU / arg-max decisions that flip with a one-ulp bf16 change of an activation are visible in these sums)
 
 
