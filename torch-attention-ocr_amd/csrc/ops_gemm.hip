@@ -42,8 +42,14 @@ static bool dma_narrow_eligible(int M, int N, int K, int C) {
 template <class AL, class BL, class EP>
 static void launch_dma_narrow(hipStream_t s, const AL& a, const BL& b, const EP& ep, int M, int N, int K) {
   const int gy = cdiv(M, 256);
-  if (N == 128) hipLaunchKernelGGL((gemm_dma_narrow_kernel<AL, BL, EP, 2>), dim3(gy), dim3(512), 0, s, a, b, ep, K, 1, gy, zero_page());
+  if (N % 128 == 0) { const int gx = N / 128; hipLaunchKernelGGL((gemm_dma_narrow_kernel<AL, BL, EP, 2>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page()); }   // (N > 128: column blocks of 128)
   else          hipLaunchKernelGGL((gemm_dma_narrow_kernel<AL, BL, EP, 1>), dim3(gy), dim3(512), 0, s, a, b, ep, K, 1, gy, zero_page());
+}
+// 256 x 128 tiles of the narrow kernel for a WIDE product whose 256 x 256 grid would leave half the chip idle (conv7 forward: 63 x 2 tiles)
+static bool dma_mid_eligible(int M, int N, int K, int C) {
+  if (N % 128 || K % 32 || C % 32 || M < 256 || dma_disabled() || getenv("AOCR_NO_NARROW_WIDE")) return false;       // conv forward 0.846 -> 0.825 ms per C3 step (conv7: 74.6 us on 128 x 128 tiles)
+  const int blocks = cdiv(M, 256) * (N / 128);
+  return blocks >= 200 && blocks <= 512;
 }
 template <class AL, class BL, class EP>
 static void launch_dma(hipStream_t s, const AL& a, const BL& b, const EP& ep, int M, int N, int K, int tag = 0) {
@@ -290,6 +296,9 @@ void gemm_hh(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64
   // 63 x 4 workgroups: 56 / 47 us against 47 / 43 us; round 3: the BK = 64 form of the 128 x 128 kernel -- half the barriers and
   // staging round trips over the 16 tiles -- measured slower too: hoisted GEMMs 0.726 -> 0.745 ms per step)
   // (round 3, again with that kernel's output tile staged through LDS: hoisted GEMMs 0.750 -> 0.760 ms per step: still no faster)
+  // hoisted bf16 GEMMs with full 256 x 128 tiles that fill the chip: the narrow LDS-DMA kernel (two workgroups per CU: one's epilogue under the other's 16-step K loop):
+  // hoisted GEMMs 0.739 -> 0.713 ms per C3 step (AOCR_NO_HH_NARROW=1: the 128 x 128 kernel)
+  if (!getenv("AOCR_NO_HH_NARROW") && !dma_disabled() && M % 256 == 0 && N % 128 == 0 && K % 32 == 0 && (M / 256) * (N / 128) >= 200) { launch_dma_narrow(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K); return; }
   launch_lds(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K, 1);
 }
 
@@ -382,7 +391,7 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
     }
     if (dma_eligible(a.rows, Cout, a.K, Cin) && pad == 1 && halo_eligible(a, Cout, 256, 256)) launch_halo<1, 256, 256>(s, ah, bh, ep, a.rows, Cout, profile_tag);
     else if (dma_eligible(a.rows, Cout, a.K, Cin)) launch_dma(s, ah, bh, ep, a.rows, Cout, a.K, profile_tag);
-    else if (dma_narrow_eligible(a.rows, Cout, a.K, Cin)) launch_dma_narrow(s, ah, bh, ep, a.rows, Cout, a.K);
+    else if (dma_narrow_eligible(a.rows, Cout, a.K, Cin) || dma_mid_eligible(a.rows, Cout, a.K, Cin)) launch_dma_narrow(s, ah, bh, ep, a.rows, Cout, a.K);
     else launch_lds(s, ah, bh, ep, a.rows, Cout, a.K, 1);       // (BK = 64 variant measured no faster: launch_lds64)
   } else {
     launch_conv_fwd(s, bf16, a, make_loadk(w, a.K, Cout, a.K), ep, a.rows, Cout, a.K);
