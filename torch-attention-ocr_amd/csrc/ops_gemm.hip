@@ -307,6 +307,7 @@ void gemm_hh_shadow(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B
   LoadKh a; a.p = A; a.ld = lda; a.rows = M; a.K = K;
   LoadKh b; b.p = B; b.ld = ldb; b.rows = N; b.K = K;
   EpStore e = make_store(C, ldc, M, N, nullptr, nullptr, 0); e.Cb = Cb; e.ldcb = ldcb;
+  if (!getenv("AOCR_NO_HH_NARROW") && !dma_disabled() && M % 256 == 0 && N % 128 == 0 && K % 32 == 0 && (M / 256) * (N / 128) >= 200) { launch_dma_narrow(s, a, b, e, M, N, K); return; }
   launch_lds(s, a, b, e, M, N, K, 1);
 }
 
