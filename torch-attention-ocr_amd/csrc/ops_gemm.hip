@@ -390,6 +390,8 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
         if (y_bf16 && getenv("AOCR_BN_Y16")) { ep.y16 = reinterpret_cast<bf16_t*>(y); ep.y = nullptr; *y_bf16 = 1; }
       }
     }
+    // (conv3 -- K = 1152: 36 steps under an un-overlapped epilogue -- on 256 x 128 tiles of the narrow kernel instead: conv forward 0.79 -> 0.763 ms, but that kernel's
+    // epilogue cannot leave the BatchNorm sums, which are worth more (0.04 ms for conv3): not taken)
     if (dma_eligible(a.rows, Cout, a.K, Cin) && pad == 1 && halo_eligible(a, Cout, 256, 256)) launch_halo<1, 256, 256>(s, ah, bh, ep, a.rows, Cout, profile_tag);
     else if (dma_eligible(a.rows, Cout, a.K, Cin)) launch_dma(s, ah, bh, ep, a.rows, Cout, a.K, profile_tag);
     else if (dma_narrow_eligible(a.rows, Cout, a.K, Cin) || dma_mid_eligible(a.rows, Cout, a.K, Cin)) launch_dma_narrow(s, ah, bh, ep, a.rows, Cout, a.K);
