@@ -447,6 +447,13 @@ def main():
                 "achieved": achw, "peak": peak, "unit": "TFLOP/s", "frac": achw / peak, "traffic": traffic, "traffic_source": traffic_source,
                 "ms_per_launch": msw, "algorithmic_gflop_per_launch": kflw / 1e9, "family_share_of_step": wg_share,
                 "step_frac": step_frac, "step_frac_what": "SURVEY.md 8(d): train GFLOP per image x image-lines/s / bf16 MFMA peak over the WHOLE step (north-star target 0.40)"}
+        if bf16:
+            # context for `peak` (not a replacement for it): what a K loop that does nothing but v_mfma_f32_32x32x16_bf16 on register-resident RANDOM bf16
+            # operands sustains on this chip -- the shader clock falls from 2.4 to ~1.7 GHz under it (power); profiles/r03_gemm4w_ubench.txt, tools/ubench/gemm4w.hip
+            for r_ in (roof, best):
+                r_["mfma_only_sustained_TFLOPs"] = 1550.0
+                r_["frac_of_mfma_only_sustained"] = r_["achieved"] / 1550.0
+                r_["mfma_only_source"] = "profiles/r03_gemm4w_ubench.txt (a constant from that measurement, NOT measured in this run)"
         out = {
             "metric": "image-lines/sec (train step)", "value": lines_per_s, "unit": "image-lines/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
