@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     const int64_t o0 = (((int64_t)b * Hp + py) * Wp + px0) * 64 + lane;
 #pragma unroll 1
     for (int w0 = 0; w0 < nw; w0 += 4) {
-      float p[4][10];
+      float p[4][10];                                           // (the packed-math form of conv1_bwd_pk_kernel measured SLOWER here: 39.5 -> 44.1 us -- without the 36 accumulate FMAs the pair assembly outweighs the 18 FMAs saved)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -176,6 +176,93 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
   }
 }
 
+// The same with PACKED fp32 math (v_pk_fma_f32: two FMAs per instruction): the two columns dx = 0, 1 of a pooling window are the two
+// halves of a register pair -- even pairs come straight from the LDS block, the odd ones (kernel column 1) are assembled from their
+// neighbours.  Per window and lane 18 + 18 packed FMAs instead of 36 + 36; every conv value still sums its nine taps in the forward
+// pass's order, so the arg-max / ReLU routing is unchanged; the tap accumulators are kept per column parity and added at the end.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void conv1_bwd_pk_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, const float* __restrict__ dyp,
+                                                           float* __restrict__ dw, float* __restrict__ db, int B, int H, int W,
+                                                           int Hp, int Wp, float* __restrict__ partial) {
+  __shared__ float sx[4][4][2 * C1S + 4];                       // [wave][row][col]
+  __shared__ float swave[4][640];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  f32x2 wk[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { const float v = w[lane * 9 + k]; wk[k] = f32x2{v, v}; }
+  const float bb = bias[lane];
+  f32x2 acc[9]; float accb = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = f32x2{0.f, 0.f};
+  const int spr = (Wp + C1S - 1) / C1S;
+  const int64_t nstrips = (int64_t)B * Hp * spr;
+  for (int64_t st = (int64_t)blockIdx.x * 4 + wave; st < nstrips; st += (int64_t)gridDim.x * 4) {
+    const int sp = (int)(st % spr); const int64_t t = st / spr; const int py = (int)(t % Hp), b = (int)(t / Hp);
+    const int px0 = sp * C1S, nw = min(C1S, Wp - px0);
+    conv1_stage(x + (int64_t)b * H * W, py, px0, H, W, lane, sx[wave]);
+    const float* gp = dyp + (((int64_t)b * Hp + py) * Wp + px0) * 64 + lane;
+#pragma unroll 1
+    for (int w0 = 0; w0 < nw; w0 += 4) {
+      float g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g[u] = (w0 + u < nw) ? gp[(int64_t)(w0 + u) * 64] : 0.f;
+      f32x2 pe[4][5], po[4][4];                                 // even pairs (columns 2k, 2k+1 of the 10-column slice), odd pairs (2k+1, 2k+2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) pe[i][k] = *reinterpret_cast<const f32x2*>(&sx[wave][i][2 * w0 + 2 * k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) po[i][k] = f32x2{pe[i][k][1], pe[i][k + 1][0]};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x2 sv[2];                                            // sv[dy] = conv outputs (dx = 0, dx = 1) of window row dy
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          f32x2 s2 = f32x2{bb, bb};
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            s2 = __builtin_elementwise_fma(wk[kh * 3 + 0], pe[dy + kh][u], s2);
+            s2 = __builtin_elementwise_fma(wk[kh * 3 + 1], po[dy + kh][u], s2);
+            s2 = __builtin_elementwise_fma(wk[kh * 3 + 2], pe[dy + kh][u + 1], s2);
+          }
+          sv[dy] = s2;
+        }
+        // first strict maximum above the ReLU floor, in the order (0,0),(0,1),(1,0),(1,1) -- the forward's fmaxf chain
+        float best = 0.f; int bi = -1;
+        if (sv[0][0] > best) { best = sv[0][0]; bi = 0; }
+        if (sv[0][1] > best) { best = sv[0][1]; bi = 1; }
+        if (sv[1][0] > best) { best = sv[1][0]; bi = 2; }
+        if (sv[1][1] > best) { best = sv[1][1]; bi = 3; }
+        const float gg = g[u];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const f32x2 gq = f32x2{bi == 2 * dy ? gg : 0.f, bi == 2 * dy + 1 ? gg : 0.f};
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            acc[kh * 3 + 0] = __builtin_elementwise_fma(gq, pe[dy + kh][u], acc[kh * 3 + 0]);
+            acc[kh * 3 + 1] = __builtin_elementwise_fma(gq, po[dy + kh][u], acc[kh * 3 + 1]);
+            acc[kh * 3 + 2] = __builtin_elementwise_fma(gq, pe[dy + kh][u + 1], acc[kh * 3 + 2]);
+          }
+        }
+        accb += bi >= 0 ? gg : 0.f;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                            // the next strip overwrites this wave's block
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) swave[wave][lane * 10 + k] = acc[k][0] + acc[k][1];
+  swave[wave][lane * 10 + 9] = accb;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 640; i += 256) {
+    const float t = (swave[0][i] + swave[1][i]) + (swave[2][i] + swave[3][i]);
+    int c = i / 10, k = i % 10;
+    if (partial) partial[(int64_t)blockIdx.x * 640 + (k < 9 ? c * 9 + k : 576 + c)] = t;
+    else if (k < 9) atomicAdd(&dw[c * 9 + k], t); else atomicAdd(&db[c], t);
+  }
+}
+
 void conv1_forward(hipStream_t s, const float* x, const float* w, const float* bias, float* y, int B, int H, int W, bf16_t* yb) {
   int Hp = H / 2, Wp = W / 2;
   int64_t strips = (int64_t)B * Hp * ((Wp + C1S - 1) / C1S);
@@ -189,7 +276,8 @@ void conv1_backward(hipStream_t s, const float* x, const float* w, const float* 
   // with a scratch slab (>= 4096*640 floats) every workgroup writes its partial sums and two column sums finish the job:
   // no contended global atomics, more workgroups
   int blocks = (int)std::min<int64_t>((strips + 3) / 4, scratch ? 2048 : 1024);
-  hipLaunchKernelGGL(conv1_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, dyp, dw, db, B, H, W, Hp, Wp, scratch);
+  if (getenv("AOCR_CONV1_SCALAR")) hipLaunchKernelGGL(conv1_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, dyp, dw, db, B, H, W, Hp, Wp, scratch);
+  else hipLaunchKernelGGL(conv1_bwd_pk_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, dyp, dw, db, B, H, W, Hp, Wp, scratch);
   if (scratch && defer) { colsum_defer(*defer, scratch, 640, blocks, 576, dw); colsum_defer(*defer, scratch + 576, 640, blocks, 64, db); }
   else if (scratch) {
     colsum_accum(s, scratch, 640, blocks, 576, dw);
