@@ -24,8 +24,18 @@ CASES = {
     "nofeed_ld2": (dict(enc_hidden=16, enc_layers=1, dec_layers=2, input_feed=False), 2, 36, 5),
     "feed_ld1": (dict(enc_hidden=16, enc_layers=1, dec_layers=1, input_feed=True), 2, 36, 5),
     "le2_ld3": (dict(enc_hidden=16, enc_layers=2, dec_layers=3, input_feed=True), 2, 36, 5),
+    # sharpened weights (oracle_torch.sharpen_params): |logit| O(1), peaked attention -- the regime random init never visits
+    "sharp_feed_ld2": (dict(enc_hidden=16, enc_layers=1, dec_layers=2, input_feed=True), 3, 52, 6),
+    "sharp_le2_ld3": (dict(enc_hidden=32, enc_layers=2, dec_layers=3, input_feed=True), 2, 36, 5),
 }
+SHARP = {"sharp_feed_ld2": dict(), "sharp_le2_ld3": dict(wa=200.0, proj=12.0)}      # sharpen_params keyword overrides per case
 SEED = 910820
+
+
+def params_for(name, cfg):
+    """Initial weights of a fixture case (seeded generator; the sharp_* cases scale them, see oracle_torch.sharpen_params)."""
+    P = O.init_params(cfg, SEED)
+    return O.sharpen_params(P, **SHARP[name]) if name in SHARP else P
 
 
 def probes(t, n=32):
@@ -35,9 +45,9 @@ def probes(t, n=32):
     return f[torch.from_numpy(idx)].numpy()
 
 
-def run_case(kw, B, W, maxlen):
+def run_case(kw, B, W, maxlen, name=""):
     cfg = O.OcrConfig(**kw)
-    P, st = O.init_params(cfg, SEED), O.init_bn_state()
+    P, st = params_for(name, cfg), O.init_bn_state()
     img, tgt, tge, nnz = O.synth_batch(B, W, max_len=maxlen, min_len=2)
     img = torch.from_numpy(img); tgt = torch.from_numpy(tgt); tge = torch.from_numpy(tge)
     loss, G, aux, st2 = O.train_step_manual(P, st, cfg, img, tgt, tge)
@@ -46,6 +56,12 @@ def run_case(kw, B, W, maxlen):
     out = dict(loss=np.float64(loss), nnz=np.int64(nnz),
                feats_first=aux["feats"][:, :, :64].numpy(), feats_last=aux["feats"][:, :, -64:].numpy(),
                context=aux["context"].numpy(), logits=aux["logits"].numpy())
+    if name in SHARP:                       # facts of the regime, pinned: peaked attention, O(1) logits
+        with torch.no_grad():
+            r = O.forward_train(P, {k: v.clone() for k, v in st.items()}, cfg, img, tgt, tge, training=True)
+        ent = O.attention_entropy(r)
+        out["attn_entropy_mean"] = np.float64(ent.mean()); out["logit_absmax"] = np.float64(aux["logits"].abs().max())
+        assert float(ent.mean()) < 1.0 and float(aux["logits"].abs().max()) > 1.0, (float(ent.mean()), float(aux["logits"].abs().max()))
     newP, norms = O.sgd_list(P, G, 0.1, 5.0)
     newP2, _ = O.sgd_list(P, G, 0.1, 0.05)
     out["norms"] = np.array(norms)
@@ -146,7 +162,7 @@ def data_fixture():
 def main():
     os.makedirs(OUT, exist_ok=True)
     for name, (kw, B, W, ml) in CASES.items():
-        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **run_case(kw, B, W, ml))
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **run_case(kw, B, W, ml, name))
         print("wrote", name)
     np.savez_compressed(os.path.join(OUT, "s9_first39.npz"), **s9_fixture())
     np.savez_compressed(os.path.join(OUT, "leaf_ops.npz"), **leaf_fixtures())

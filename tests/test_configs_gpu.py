@@ -14,6 +14,7 @@ import pytest
 import torch
 
 from test_step_gpu import make, relerr, _gpu_cnn_decisions
+from tol import check_logits
 
 pytestmark = pytest.mark.gpu
 
@@ -65,7 +66,7 @@ def test_reference_default_he512_fp32_vs_oracle(cuda):
     lg = m.get_tensor("logits")[:, :, :ocfg.vocab]
     e = (lg.double() - aux["logits"]).abs().max().item()
     print(f"[parity] He=512 fp32: logits max-abs {e:.3e}; loss {loss:.5f} vs {float(loss_ref) * 6:.5f}")
-    assert e < 1e-4
+    check_logits(lg, aux["logits"], "f32", "He=512")
     assert abs(loss - float(loss_ref) * 6) < 1e-4 * abs(loss)
     grads = m.get_gradients()
     worst = ("", 0.0)
@@ -88,7 +89,8 @@ def test_reference_default_he512_bf16_vs_oracle(cuda, B):
     e = (lg.double() - aux["logits"]).abs().max().item()
     ec = (m.get_tensor("context").double() - aux["context"]).abs().max().item()
     print(f"[parity] He=512 bf16 B={B}: context max-abs {ec:.3e}, logits max-abs {e:.3e}; loss {loss:.4f} vs {float(loss_ref) * B:.4f}")
-    assert e < 5e-2 and ec < 2e-2
+    check_logits(lg, aux["logits"], "bf16", f"He=512 B={B}")
+    assert ec < 2e-2
     assert abs(loss - float(loss_ref) * B) < 5e-3 * abs(loss)
     grads = m.get_gradients()
     for k in ("proj.w", "dec.attn.wa", "dec.attn.wc", "dec.l1.i2h.w", "dec.l2.h2h.w", "enc_fw.l1.h2h.w", "enc_bw.l1.h2h.w", "enc_fw.l1.i2h.w",
@@ -151,7 +153,8 @@ def test_c3_bf16_all_gradients_vs_oracle(cuda):
     e, eq = (lg.double() - aux["logits"]).abs().max().item(), (lg.double() - rq["logits"].detach()).abs().max().item()
     print(f"[parity] C3 bf16: loss {loss:.4f} vs fp64 {float(loss_ref) * B:.4f} vs bf16-operand oracle {float(loss_q) * B:.4f}; logits max-abs {e:.3e} / {eq:.3e}")
     assert abs(loss - float(loss_ref) * B) < 2e-3 * abs(loss) and abs(loss - float(loss_q) * B) < 2e-4 * abs(loss)
-    assert e < 5e-2 and eq < 5e-3
+    check_logits(lg, aux["logits"], "bf16", "C3")
+    assert eq < 1e-3                                     # against the bf16-operand oracle: measured 2.6e-4
     grads = m.get_gradients()
     check_bf16_gradients("C3 bf16", grads, G, Gq)
     # The conv stack's cosine of 0.97-0.999 is ReLU / arg-max DECISION flips between two bf16 forward passes (check_bf16_gradients):
@@ -184,7 +187,7 @@ def test_c4_width_vs_oracle(cuda, W, compute):
     lg = m.get_tensor("logits")[:, :, :ocfg.vocab]
     e = (lg.double() - aux["logits"]).abs().max().item()
     print(f"[parity] C4 W={W} {compute}: T={aux['context'].shape[1]} logits max-abs {e:.3e}; loss {loss:.4f} vs {float(loss_ref) * B:.4f}")
-    assert e < (1e-4 if compute == "f32" else 5e-2)
+    check_logits(lg, aux["logits"], compute, f"C4 W={W}")
     assert abs(loss - float(loss_ref) * B) < (1e-4 if compute == "f32" else 3e-3) * abs(loss)
     grads = m.get_gradients()
     if compute == "bf16":

@@ -28,14 +28,14 @@ def _probe(t, n=32):
     return f[torch.from_numpy(idx)].double().numpy()
 
 
-@pytest.mark.parametrize("name", ["feed_ld2", "nofeed_ld2", "feed_ld1", "le2_ld3"])
+@pytest.mark.parametrize("name", ["feed_ld2", "nofeed_ld2", "feed_ld1", "le2_ld3", "sharp_feed_ld2", "sharp_le2_ld3"])
 def test_hip_matches_golden_fixture(cuda, name):
     import aocr
     g = _gen(); O = g.O
     kw, B, W, ml = g.CASES[name]
     ref = np.load(os.path.join(GOLD, f"{name}.npz"))
     cfg = O.OcrConfig(**kw)
-    P, st = O.init_params(cfg, g.SEED), O.init_bn_state()
+    P, st = g.params_for(name, cfg), O.init_bn_state()          # sharp_*: the seeded weights scaled by oracle_torch.sharpen_params
     img, tgt, tge, nnz = O.synth_batch(B, W, max_len=ml, min_len=2)
     assert nnz == int(ref["nnz"])
     m = aocr.Model()
@@ -54,6 +54,10 @@ def test_hip_matches_golden_fixture(cuda, name):
     lg = m.get_tensor("logits")[:, :, :cfg.vocab].double().numpy()
     e = np.abs(lg - ref["logits"]).max(); print(f"[parity] golden {name}: logits max-abs {e:.2e}")
     assert e < 1e-4                                                                   # BASELINE.json north_star tolerance
+    assert e < 1e-4 * np.abs(ref["logits"]).max()                                     # ... and relative to the largest logit (tests/tol.py)
+    if "attn_entropy_mean" in ref.files:
+        print(f"[parity] golden {name}: sharpened regime, max |logit| {float(ref['logit_absmax']):.2f}, mean attention entropy {float(ref['attn_entropy_mean']):.2f} nat")
+        assert float(ref["logit_absmax"]) > 1.0 and float(ref["attn_entropy_mean"]) < 1.0
     grads = m.get_gradients()
     worst = 0.0
     for k in grads:

@@ -18,11 +18,11 @@ def _gen():
     return m
 
 
-@pytest.mark.parametrize("name", ["feed_ld2", "nofeed_ld2", "feed_ld1", "le2_ld3"])
+@pytest.mark.parametrize("name", ["feed_ld2", "nofeed_ld2", "feed_ld1", "le2_ld3", "sharp_feed_ld2", "sharp_le2_ld3"])
 def test_oracle_matches_golden(name):
     g = _gen()
     kw, B, W, ml = g.CASES[name]
-    got = g.run_case(kw, B, W, ml)
+    got = g.run_case(kw, B, W, ml, name)
     ref = np.load(os.path.join(GOLD, f"{name}.npz"))
     assert set(got) == set(ref.files)
     for k in ref.files:

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from tol import check_logits
+
 pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 1e-4          # BASELINE.json north_star: decoder logits within 1e-4 max-abs (fp32 MFMA path)
@@ -77,7 +79,7 @@ def test_train_step_parity_small(cuda, case):
     e = (feats.double() - aux["feats"]).abs().max().item(); print(f"[parity] feats max-abs {e:.3e}"); assert e < 2e-4
     e = (m.get_tensor("context").double() - aux["context"]).abs().max().item(); print(f"[parity] context max-abs {e:.3e}"); assert e < 1e-4
     lg = m.get_tensor("logits")[:, :, :ocfg.vocab]
-    e = (lg.double() - aux["logits"]).abs().max().item(); print(f"[parity] logits max-abs {e:.3e}"); assert e < LOGIT_TOL
+    e = (lg.double() - aux["logits"]).abs().max().item(); print(f"[parity] logits max-abs {e:.3e}"); check_logits(lg, aux["logits"], "f32", f"small case {case}")
     assert abs(loss - float(loss_ref) * B) < 1e-3 * max(1.0, abs(float(loss_ref) * B))
     e = relerr(m.get_tensor("dcontext"), aux["dctx"]); print(f"[parity] dcontext rel {e:.3e}"); assert e < 1e-3
     e = relerr(m.get_tensor("dfeats").transpose(0, 1), aux["dfeats"]); print(f"[parity] dfeats rel {e:.3e}"); assert e < 1e-3
@@ -120,7 +122,7 @@ def test_ragged_widths(cuda, W, compute):
     lg = m.get_tensor("logits")[:, :, :ocfg.vocab]
     e = (lg.double() - aux["logits"]).abs().max().item()
     print(f"[parity] W={W} {compute}: T={aux['context'].shape[1]} logits max-abs {e:.3e}; loss {loss:.4f} vs {float(loss_ref) * 3:.4f}")
-    assert e < (LOGIT_TOL if compute == "f32" else 5e-2)
+    check_logits(lg, aux["logits"], compute, f"ragged W={W}")
     if compute == "f32":
         grads = m.get_gradients()
         for k in ("cnn.conv2.w", "cnn.conv4.w", "cnn.conv7.w", "enc_bw.l1.i2h.w", "dec.attn.wa", "dec.lookup"):
@@ -156,14 +158,15 @@ def test_logits_c2_shape(cuda):
         r = O.forward_train(P, {k: v.clone() for k, v in st.items()}, ocfg, img, tgt, tge, training=True)
     logits, loss = m.forward_logits(batch, training=True)
     e = (logits.double() - r["logits"]).abs().max().item()
-    print(f"[parity] C2 logits max-abs {e:.3e} (mean |logit| {r['logits'].abs().mean().item():.3f}); loss {loss:.4f} vs {float(r['loss']) * 64:.4f}")
-    assert e < LOGIT_TOL
+    print(f"[parity] C2 logits max-abs {e:.3e} (mean |logit| {r['logits'].abs().mean().item():.3f}, max {r['logits'].abs().max().item():.3f}); loss {loss:.4f} vs {float(r['loss']) * 64:.4f}")
+    check_logits(logits, r["logits"], "f32", "C2")
     m.shutdown()
 
 
 @pytest.mark.parametrize("case,B", [(0, 5), (4, 5), (4, 16)])      # B = 16, He = 64: the whole-sequence encoder kernels
 def test_bf16_path_runs_close(cuda, case, B):
-    """bf16-operand MFMA path: stated tolerance 5e-2 max-abs on logits (fp32 accumulate, fp32 master copies)."""
+    """bf16-operand MFMA path (fp32 accumulate, fp32 master copies): logits within tests/tol.py's bf16 bounds (2e-3 max-abs and
+    2.5 % of the largest reference logit; measured 5.8e-4)."""
     m, O, ocfg, P, st, batch = make(CASES[case], B=B, W=36, maxlen=6, compute="bf16")
     img, tgt, tge = (torch.from_numpy(np.asarray(x)) for x in batch[:3])
     loss_ref, G, aux, _ = O.train_step_manual(P, st, ocfg, img, tgt, tge)
@@ -171,7 +174,7 @@ def test_bf16_path_runs_close(cuda, case, B):
     lg = m.get_tensor("logits")[:, :, :ocfg.vocab]
     e = (lg.double() - aux["logits"]).abs().max().item()
     print(f"[parity] bf16 logits max-abs {e:.3e}; loss {loss:.4f} vs {float(loss_ref) * B:.4f}")
-    assert e < 5e-2
+    check_logits(lg, aux["logits"], "bf16", f"small case {case} B={B}")
     grads = m.get_gradients()
     for k in ("proj.w", "dec.attn.wc", "enc_fw.l1.h2h.w", "enc_bw.l1.h2h.w", "enc_fw.l1.i2h.w", "cnn.conv6.w", "cnn.conv2.b", "cnn.conv4.b",
               "cnn.conv6.b"):
@@ -648,7 +651,7 @@ def test_c3_full_size_kernel_paths_agree(cuda, monkeypatch):
 
 def test_logits_c3_shape_bf16(cuda):
     """BASELINE config C3 at full size through the production bf16 dispatch: decoder logits against the fp64 oracle
-    (stated bf16 tolerance 5e-2 max-abs; fp32 accumulation, fp32 master copies)."""
+    (tests/tol.py: 2e-3 max-abs and 2.5 % of the largest reference logit; measured 4.2e-4; fp32 accumulation, fp32 master copies)."""
     m, O, ocfg, P, st, batch = make(dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True), B=256, W=256, maxlen=23,
                                     compute="bf16", max_decoder_l=24, max_beam=1)
     img, tgt, tge = (torch.from_numpy(np.asarray(x)) for x in batch[:3])
@@ -656,8 +659,8 @@ def test_logits_c3_shape_bf16(cuda):
         r = O.forward_train(P, {k: v.clone() for k, v in st.items()}, ocfg, img, tgt, tge, training=True)
     logits, loss = m.forward_logits(batch, training=True)
     e = (logits.double() - r["logits"]).abs().max().item()
-    print(f"[parity] C3 bf16 logits max-abs {e:.3e} (mean |logit| {r['logits'].abs().mean().item():.3f}); loss {loss:.4f} vs {float(r['loss']) * 256:.4f}")
-    assert e < 5e-2
+    print(f"[parity] C3 bf16 logits max-abs {e:.3e} (mean |logit| {r['logits'].abs().mean().item():.3f}, max {r['logits'].abs().max().item():.3f}); loss {loss:.4f} vs {float(r['loss']) * 256:.4f}")
+    check_logits(logits, r["logits"], "bf16", "C3 full size")
     assert abs(loss - float(r["loss"]) * 256) < 2e-3 * abs(loss)
     m.shutdown()
 
@@ -864,7 +867,7 @@ def test_tall_strips_two_layer_encoder_beam5(cuda, compute):
     lg = m.get_tensor("logits")[:, :, :ocfg.vocab]
     e = (lg.double() - aux["logits"]).abs().max().item()
     print(f"[parity] tall strips {compute}: T={aux['context'].shape[1]} logits max-abs {e:.3e}; loss {loss:.4f} vs {float(loss_ref) * B:.4f}")
-    assert e < (LOGIT_TOL if compute == "f32" else 5e-2)
+    check_logits(lg, aux["logits"], compute, "tall strips")
     if compute == "f32":
         grads = m.get_gradients()
         for k in ("cnn.conv7.w", "cnn.conv4.w", "enc_fw.l2.i2h.w", "enc_bw.l1.h2h.w", "dec.attn.wa"):
