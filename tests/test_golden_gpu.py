@@ -64,8 +64,9 @@ def test_hip_matches_golden_fixture(cuda, name):
         want = ref["g:" + k]
         scale = float(ref_scale := max(float(np.abs(want).max()), 1e-30))
         e = float(np.abs(_probe(grads[k]) - want).max())
-        if float(grads[k].abs().max()) < 1e-6 and ref_scale < 1e-6:     # conv bias in front of a BatchNorm: exact gradient 0, rounding noise only
-            assert e < 1e-6, (k, e)
+        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):          # conv bias in front of a BatchNorm: exact gradient 0, rounding noise only
+            w = k[:-1] + "w"                                            # ... measured against the size of the same layer's filter gradient
+            assert ref_scale < 1e-9 and float(grads[k].abs().max()) < 1e-5 * float(grads[w].abs().max()), (k, float(grads[k].abs().max()))
             continue
         e /= max(scale, float(grads[k].abs().max()))
         worst = max(worst, e)

@@ -216,6 +216,88 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16_t* __restrict
 #undef DSR1
 #undef SB
   }
+
+  if constexpr (HALFBAR == 4) {
+    // Round 4: the same 4-wave / 128 x 128 tile on v_mfma_f32_16x16x32_bf16 -- 8 x 8 accumulator tiles of 16 x 16 (256 AGPRs as before), an A / B fragment
+    // = 16 rows x the WHOLE 32-deep k tile (lane l: row l % 16, k-chunk l / 16), 64 MFMAs of 16 cycles per tile = the same 1024 MFMA cycles and the same
+    // 16 ds_read_b128 per wave and tile.  /opt/skills/guides/MI355X_MICROARCH.md (DVFS give-back, item 7): under the power cap the 16x16x32 loop holds a
+    // clock ~1.12-1.15 x that of the 32x32x16 loop.  ONE barrier per tile: block kt multiplies F(kt), reads F(kt+1) (slot (kt+1) & 3) and issues the DMA
+    // of tile kt+4 into slot kt & 3 (read during block kt-1); every read (one per four MFMAs) and DMA piece (one per eight) pinned between two MFMAs.
+    // LDS image unchanged (piece position p of row r holds k-chunk p ^ ((r >> 2) & 3)); the 16 x 4-chunk fragment read is conflict-free on it when
+    // fragment row i sits on physical row 4 sigma(i >> 2) + (i & 3), sigma = (0, 3, 2, 1) (tools/bank16.py); the output rows / columns permute with it.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int sg = (i16 >> 2) == 1 ? 3 : ((i16 >> 2) == 3 ? 1 : (i16 >> 2));
+    const int prow16 = sg * 4 + (i16 & 3);
+    const unsigned fa0 = lbase + (wm * 128 + prow16) * 64 + ((g16 ^ sg) << 4), fb0 = lbase + 16384 + (wn * 128 + prow16) * 64 + ((g16 ^ sg) << 4);
+    f32x4 c4[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 pa[8], pb[8], qa[8], qb[8];
+#define DSR4(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+#define SB4() __builtin_amdgcn_sched_barrier(0)
+    auto rd1 = [&](bf16x8 (&na)[8], bf16x8 (&nb)[8], unsigned pa_, unsigned pb_, int q) {     // read q (0..15) of a tile's fragments: a0 b0 a1 b1 ...
+      const int i = q >> 1;
+      if (q & 1) { if (i == 0) DSR4(nb[0], pb_, 0); else if (i == 1) DSR4(nb[1], pb_, 1024); else if (i == 2) DSR4(nb[2], pb_, 2048); else if (i == 3) DSR4(nb[3], pb_, 3072);
+                   else if (i == 4) DSR4(nb[4], pb_, 4096); else if (i == 5) DSR4(nb[5], pb_, 5120); else if (i == 6) DSR4(nb[6], pb_, 6144); else DSR4(nb[7], pb_, 7168); }
+      else { if (i == 0) DSR4(na[0], pa_, 0); else if (i == 1) DSR4(na[1], pa_, 1024); else if (i == 2) DSR4(na[2], pa_, 2048); else if (i == 3) DSR4(na[3], pa_, 3072);
+             else if (i == 4) DSR4(na[4], pa_, 4096); else if (i == 5) DSR4(na[5], pa_, 5120); else if (i == 6) DSR4(na[6], pa_, 6144); else DSR4(na[7], pa_, 7168); }
+    };
+    auto block = [&](const bf16x8 (&ca)[8], const bf16x8 (&cb)[8], bf16x8 (&na)[8], bf16x8 (&nb)[8], int kt) {
+      const unsigned so = (unsigned)(((kt + 1) & 3) * 32768);
+      const unsigned ra = fa0 + so, rb = fb0 + so;
+      const int dkt = kt + 4, k = (dkt < nk ? dkt : nk - 1) << 5;
+      unsigned char* dbase = lds + (dkt & 3) * 32768 + wave * 4096;
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+          if constexpr (!(MODE & 2)) c4[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[mi], cb[ni], c4[mi][ni], 0, 0, 0);
+          SB4();
+          const int q = mi * 8 + ni;
+          if constexpr (!(MODE & 4)) { if ((q & 3) == 1 && (!(MODE & 8) || kt < 0)) rd1(na, nb, ra, rb, q >> 2); }
+          if constexpr (!(MODE & 1)) { if ((q & 7) == 6 && (!(MODE & 16) || (q >> 3) >= 2)) { const int j = (q >> 3) & 3; dma16((q >> 3) < 4 ? asrc[j] + (k & (kwrap - 1)) : bsrc[j] + k, dbase + ((q >> 3) < 4 ? 0 : 16384) + j * 1024); } }
+          SB4();
+        }
+      }
+    };
+    issue(3);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) rd1(pa, pb, fa0, fb0, q);
+    for (int kt = 0; kt < nk; kt += 2) {
+      if constexpr (MODE & 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else if constexpr (MODE & 16) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      SB4();
+      block(pa, pb, qa, qb, kt);
+      if constexpr (MODE & 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else if constexpr (MODE & 16) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      SB4();
+      block(qa, qb, pa, pb, kt + 1);
+    }
+#undef DSR4
+#undef SB4
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(pa[i]), "v"(pb[i]), "v"(qa[i]), "v"(qb[i]));
+    if (blockIdx.x == 17 && tid == 0) { g_probe[0] = __builtin_readcyclecounter() - pc0; g_probe[1] = wall_clock64() - pw0; }
+    // D tile (mi, ni): lane l holds fragment column j = l % 16 (B row) and fragment rows 4 (l / 16) + v (A rows), v = 0..3
+    const int sgr = g16 == 1 ? 3 : (g16 == 3 ? 1 : g16);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = m_blk + wm * 128 + 16 * mi + 4 * sgr + v, col = n_blk + wn * 128 + 16 * ni + prow16;
+          if (row < M && col < N) C[(size_t)row * N + col] = c4[mi][ni][v];
+        }
+    return;
+  }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   if (blockIdx.x == 17 && tid == 0) { g_probe[0] = __builtin_readcyclecounter() - pc0; g_probe[1] = wall_clock64() - pw0; }
   const int m0 = m_blk + wm * 128, n0 = n_blk + wn * 128;
@@ -300,6 +382,12 @@ int main() {
     run<4, 2>(A, B, C, M, N, K, "  hand: no fragment reads", 512, 512);
     run<9, 2>(A, B, C, M, N, K, "  hand: MFMA on resident random fragments + barrier", 512, 512);
     run<8, 2>(A, B, C, M, N, K, "  hand: the same + DMA stream", 512, 512);
+    run<0, 4>(A, B, C, M, N, K, "16x16x32: 4 waves x 128x128, reads + DMA spread between MFMAs", 512, 512);
+    run<16, 4>(A, B, C, M, N, K, "  16x16x32: 2 A pieces + 4 B pieces per wave and tile (halo-like volume; results wrong)", 512, 512);
+    run<1, 4>(A, B, C, M, N, K, "  16x16x32: no in-loop DMA", 512, 512);
+    run<4, 4>(A, B, C, M, N, K, "  16x16x32: no fragment reads", 512, 512);
+    run<9, 4>(A, B, C, M, N, K, "  16x16x32: MFMA on resident random fragments + barrier", 512, 512);
+    run<8, 4>(A, B, C, M, N, K, "  16x16x32: the same + DMA stream", 512, 512);
   }
   // spot check of the 4-wave kernel against the 8-wave one
   std::vector<float> c4((size_t)256 * N), c8((size_t)256 * N);
@@ -310,5 +398,10 @@ int main() {
   double md = 0, mx = 0;
   for (size_t i = 0; i < c4.size(); ++i) { md = std::max(md, (double)fabsf(c4[i] - c8[i])); mx = std::max(mx, (double)fabsf(c8[i])); }
   printf("4-wave vs 8-wave: max abs diff %.3e (max |c| %.3e)\n", md, mx);
+  hipLaunchKernelGGL((gemm4w_kernel<0, 4>), dim3((N / 256) * (M / 256)), dim3(256), 0, 0, A, B, C, M, N, K, N / 256, M / 256, K, 8192);
+  CK(hipMemcpy(c4.data(), C + (size_t)1000 * 256 / 256 * 256 * N, c4.size() * 4, hipMemcpyDeviceToHost));
+  md = 0;
+  for (size_t i = 0; i < c4.size(); ++i) md = std::max(md, (double)fabsf(c4[i] - c8[i]));
+  printf("16x16x32 4-wave vs 8-wave: max abs diff %.3e (max |c| %.3e; the 16x16x32 instruction sums a k tile in a different order)\n", md, mx);
   return 0;
 }

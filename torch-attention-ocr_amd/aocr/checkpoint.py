@@ -314,7 +314,7 @@ def build_reference_checkpoint(params: Dict[str, np.ndarray], bn_state: Dict[str
                 seq.append(_module("cudnn.ReLU", inplace=True, mode="CUDNN_ACTIVATION_RELU"))
         if pool:
             seq.append(_module("cudnn.SpatialMaxPooling", kW=pool[0], kH=pool[1], dW=pool[0], dH=pool[1], padW=0, padH=0, ceil_mode=False))
-    seq.append(_module("nn.View", size=np.array([512, -1], np.int64), numElements=512, numInputDims=3))                                          # cnn.lua:44
+    seq.append(_module("nn.View", size=t7.Storage(np.array([512, -1], np.int64)), numElements=512, numInputDims=3))      # nn.View keeps its size as a torch.LongStorage                                          # cnn.lua:44
     seq.append(_module("nn.Transpose", permutations=LuaTable({1: LuaTable({1: 2, 2: 3})})))                                                     # cnn.lua:45
     cnn = _module("nn.Sequential", modules=LuaTable((i, m) for i, m in enumerate(seq, 1)), train=True)
     pre = bool(config.get("prealloc", False))

@@ -87,7 +87,17 @@ def attach(model, sync_bn: bool = True) -> None:
     # the BatchNorm sums travel on a process group of their own (include/aocr.h, AOCR_COMM_CHANNEL_BN): a group runs its collectives in
     # issue order, and the gradient buckets -- issued after the whole backward pass has been enqueued -- must not queue behind the last
     # BatchNorm-backward sum.  new_group is collective: every rank attaches at the same point (the first training step).
-    model._bn_group = d.new_group() if (sync_bn and not os.environ.get("AOCR_ONE_COMM")) else None
+    # new_group is collective, so it must not hang on a per-rank difference: every rank creates the group, and the two switches that decide
+    # whether it is USED (sync_bn, AOCR_ONE_COMM) are first agreed on -- a rank whose switches differ from its peers' raises instead of
+    # summing its BatchNorm statistics on a different group than they do (mismatched collectives: a hang at the first sum).
+    mine = torch.tensor([float(bool(sync_bn)), float(bool(os.environ.get("AOCR_ONE_COMM")))], dtype=torch.float32,
+                        device=model.device if d.get_backend() == "nccl" else "cpu")       # nccl (= RCCL) sums device tensors only
+    lo, hi = mine.clone(), mine.clone()
+    d.all_reduce(lo, op=d.ReduceOp.MIN); d.all_reduce(hi, op=d.ReduceOp.MAX)
+    if not (torch.equal(lo, mine) and torch.equal(hi, mine)):
+        raise RuntimeError(f"aocr.dist.attach: sync_bn / AOCR_ONE_COMM differ between the ranks (this rank {mine.tolist()}, min {lo.tolist()}, max {hi.tolist()})")
+    group = d.new_group()
+    model._bn_group = group if (sync_bn and not os.environ.get("AOCR_ONE_COMM")) else None
     model._comm_log = [] if os.environ.get("AOCR_COMM_LOG") else None
 
     def view(ptr, count, dtype):

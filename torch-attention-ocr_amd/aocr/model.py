@@ -284,6 +284,15 @@ class Model:
         assert 0 <= off and off + 4 * n <= self.workspace.numel() and off % 4 == 0
         return self.workspace[off:off + 4 * n].view(torch.float32).reshape(shp).cpu()
 
+    def get_tensor_view(self, name: str, dtype=torch.int32) -> torch.Tensor:
+        """A named tap IN PLACE (device view into the workspace, 4-byte elements): tests write the cluster kernels' status word through it."""
+        p, nd, shape = C.c_void_p(), C.c_int32(), (C.c_int64 * 4)()
+        check(lib.aocr_get_tensor(self._h, name.encode(), C.byref(p), C.byref(nd), shape), "aocr_get_tensor")
+        n = int(np.prod([shape[i] for i in range(nd.value)]))
+        off = p.value - self.workspace.data_ptr()
+        assert 0 <= off and off + 4 * n <= self.workspace.numel() and off % 4 == 0
+        return self.workspace[off:off + 4 * n].view(dtype)
+
     # ------------------------------------------------------------------ one step, model.lua:226-706
     def _upload(self, batch):
         dev = self.device
@@ -502,14 +511,18 @@ class Model:
     def save(self, model_path, layout=None):
         """model:save, model.lua:720-725 ({nets, config, global_step, optim_state}).
         layout None: a torch.save file with the flat parameter vector (fast path for this package);  a path ending in .t7 is written
-        in Torch7 serialization: layout "reference" (default for .t7 since round 3) = the reference's own table with the five nets as
-        nn / nngraph object trees (aocr.checkpoint.write_reference_checkpoint: what model:load, model.lua:45-80, expects; unverified
-        against Torch7 -- see that module's header), layout "flat" = one plain table of named FloatTensors (write_flat_checkpoint).
+        in Torch7 serialization: layout "flat" (the default for .t7) = one plain Lua table of named FloatTensors (write_flat_checkpoint:
+        depends on nothing but torch.load of a table; INTEGRATION.md shows the Lua that pours it into a model the reference has just
+        created), layout "reference" (opt-in) = the reference's own table with the five nets as nn / nngraph object trees
+        (aocr.checkpoint.write_reference_checkpoint).  The object trees are UNVERIFIED against Torch7 -- nngraph's gModule is an
+        nn.Container whose parameters() / type() walk self.modules and whose forward / backward use fg, bg, innode, outnode and
+        backwardnodes, none of which can be reproduced faithfully without the un-vendored packages -- so that layout is never what a
+        caller gets without asking for it.
         No collective happens here (train.lua saves from one process): under data parallelism WITHOUT synchronised BatchNorm the
         running statistics are rank-local -- every rank calls `sync_bn_state()` before rank 0 saves."""
         if str(model_path).endswith(".t7") or layout in ("reference", "flat"):
             from .checkpoint import write_flat_checkpoint, write_reference_checkpoint
-            writer = write_flat_checkpoint if layout == "flat" else write_reference_checkpoint
+            writer = write_reference_checkpoint if layout == "reference" else write_flat_checkpoint
             writer(model_path, {k: v.numpy() for k, v in self.get_parameters().items()},
                    {k: v.numpy() for k, v in self.get_bn_state().items()}, self.config, self.global_step, self.optim_state)
             return

@@ -78,6 +78,13 @@ class TorchObject:
         return f"<{self.typename}>"
 
 
+class Storage:
+    """A bare torch.*Storage (host side: never a Cuda type) -- e.g. nn.View's `size` field is a torch.LongStorage, not a tensor."""
+
+    def __init__(self, array):
+        self.array = np.ascontiguousarray(np.asarray(array).reshape(-1))
+
+
 class LuaFunction:
     def __init__(self, dumped: bytes, upvalues: Any, kind: int = TYPE_RECUR):
         self.dumped, self.upvalues, self.kind = dumped, upvalues, kind
@@ -224,6 +231,12 @@ class Writer:
                     self._int(TYPE_NIL) if a.ndim == 0 else self._storage(a.reshape(-1))
                 else:
                     self._storage(a.reshape(-1))
+        elif isinstance(obj, Storage):
+            if self._ref(obj, TYPE_TORCH):
+                cuda, self.cuda = self.cuda, False
+                self._str("V 1"); self._str(self._tensor_name(obj.array.dtype, "Storage"))
+                self.cuda = cuda
+                self._long(obj.array.shape[0]); self.out += obj.array.tobytes()
         elif isinstance(obj, TorchObject):
             if self._ref(obj, TYPE_TORCH):
                 self._str(f"V {obj.version}"); self._str(obj.typename)

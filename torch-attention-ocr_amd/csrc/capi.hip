@@ -235,7 +235,12 @@ int aocr_cluster_status(aocr_model* m, int32_t* code) {
   if (!m->cl_err) return 0;
   if (hipMemcpyAsync(code, m->cl_err, sizeof(int32_t), hipMemcpyDeviceToHost, m->s) != hipSuccess || hipStreamSynchronize(m->s) != hipSuccess)
     return fail("aocr_cluster_status: %s", hipGetErrorString(hipGetLastError()));
-  if (*code != 0) hipMemsetAsync(m->cl_err, 0, sizeof(int32_t), m->s);      // read and clear: the next call reports the steps after this one
+  if (*code != 0) {
+    hipMemsetAsync(m->cl_err, 0, sizeof(int32_t), m->s);      // read and clear: the next call reports the steps after this one
+    // the host repeats the step whose update was skipped (lua/model.lua, include/aocr.h): that step's CNN forward -- untouched by the
+    // time-out -- has already moved the BatchNorm running statistics once, so the repeat must not move them again
+    m->skip_running_once = true;
+  }
   return 0;
 }
 
@@ -254,7 +259,8 @@ int aocr_train_forward_backward(aocr_model* m, const float* images_dev, const in
   prof_mark(m, AOCR_PROF_OTHER);
   hipMemsetAsync(m->grads, 0, (size_t)m->layout.group_off[AOCR_NUM_GROUPS] * sizeof(float), m->s);      // model.lua:637-639
   m->drop_on = m->drop_thr != 0;                                          // nn.Dropout is active in training() mode only (model.lua:284)
-  cnn_forward(m, images_dev, d, 1, 1);
+  cnn_forward(m, images_dev, d, 1, m->skip_running_once ? 0 : 1);
+  m->skip_running_once = false;
   encoder_forward(m, d);
   decoder_tf_forward(m, d, targets_dev, 1, L, true);
   loss_and_dlogits(m, d, targets_eval_dev, 1, L, grad_scale, true, loss_dev);

@@ -37,6 +37,15 @@ const char* load_rccl() {
   return nullptr;
 }
 constexpr int NCCL_SUM = 0, NCCL_F32 = 7, NCCL_F64 = 8;
+
+// A whole-sequence kernel that gave up waiting for its group leaves a code in cl_err[0]; the optimizers skip the update on it (device-side
+// predicate) and the host repeats the step.  Under data parallelism that decision must be the SAME on every rank: the peers would otherwise
+// apply an update computed from a sum that contains this rank's invalid gradients while this rank keeps its parameters (the replicas
+// diverge), and a rank-local repeat would issue collectives no peer matches.  So the flag travels with the exchange: 1.0 per rank whose
+// code is non-zero, summed, and a rank that sees a positive sum with a clean local code takes AOCR_CL_PEER_TIMEOUT.
+constexpr int AOCR_CL_PEER_TIMEOUT = 0x7e;
+__global__ void cl_flag_pack_kernel(const int* __restrict__ err, float* __restrict__ flag) { flag[0] = err[0] != 0 ? 1.f : 0.f; }
+__global__ void cl_flag_merge_kernel(int* __restrict__ err, const float* __restrict__ flag) { if (flag[0] > 0.f && err[0] == 0) err[0] = AOCR_CL_PEER_TIMEOUT; }
 }  // namespace
 
 const char* comm_unique_id(char id[128]) {
@@ -65,9 +74,19 @@ const char* comm_init_rccl(aocr_model* m, const char id[128], int nranks, int ra
   // the backward pass) would queue behind the last BatchNorm-backward sum (near its end) and the overlap would be lost.  So the
   // BatchNorm sums get a communicator of their own (same ranks, ncclCommSplit); without that entry point they share the first one.
   m->comm.rccl_bn = nullptr;
+  // ncclCommSplit is collective: a failure on a SUBSET of the ranks would leave some summing BatchNorm statistics on the second
+  // communicator and the others on the first -- mismatched collectives, a hang at the first SyncBN sum.  So a failed split is an error on
+  // the rank that sees it (the host aborts the job), never a silent fall-back; only a librccl WITHOUT the entry point (the same on every
+  // rank of a node: one library) or AOCR_ONE_COMM=1 (set for the whole job) share one communicator.
   if (sync_bn && g_rccl.split && !getenv("AOCR_ONE_COMM")) {
     void* c2 = nullptr;
-    if (g_rccl.split(c, 0, rank, &c2, nullptr) == 0 && c2) m->comm.rccl_bn = c2;
+    const int rs = g_rccl.split(c, 0, rank, &c2, nullptr);
+    if (rs != 0 || !c2) {
+      static thread_local char buf[200]; snprintf(buf, sizeof buf, "ncclCommSplit (second communicator for the BatchNorm sums) failed: %s; set AOCR_ONE_COMM=1 on EVERY rank to share one communicator", rs != 0 && g_rccl.errstr ? g_rccl.errstr(rs) : "no communicator returned");
+      g_rccl.destroy(c); m->comm.rccl = nullptr; m->comm.provider = 0;
+      return buf;
+    }
+    m->comm.rccl_bn = c2;
   }
   return comm_common_init(m, nranks, sync_bn);
 }
@@ -107,6 +126,13 @@ int comm_allreduce_grads(aocr_model* m, float* loss_dev) {
     if (hipStreamWaitEvent(cs, m->grad_ev[k], 0) != hipSuccess) return 1;
     if (comm_allreduce(m, m->grads + b[k], e[k] - b[k], 0, cs, 0) != 0) return 2;
     if (k == 0 && loss_dev && comm_allreduce(m, loss_dev, 1, 0, cs, 0) != 0) return 2;      // the loss is final before the backward pass starts
+    if (k == 1 && m->cl_err) {
+      // every whole-sequence kernel of the step has completed (grad_ev[1] is recorded behind the encoder BPTT): agree on the time-out flag
+      float* flag = reinterpret_cast<float*>(m->cl_err + 4);                               // ints 4..7 of the flag block: exchange scratch
+      hipLaunchKernelGGL(cl_flag_pack_kernel, dim3(1), dim3(1), 0, cs, m->cl_err, flag);
+      if (comm_allreduce(m, flag, 1, 0, cs, 0) != 0) return 2;
+      hipLaunchKernelGGL(cl_flag_merge_kernel, dim3(1), dim3(1), 0, cs, m->cl_err, flag);
+    }
   }
   // the model's stream joins here.  wait0 fires when the backward pass is done, wait1 when the last bucket is: their distance is the
   // part of the exchange the backward pass did NOT hide (aocr_comm_exposed_ms)

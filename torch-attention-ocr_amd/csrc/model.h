@@ -107,6 +107,7 @@ struct aocr_model {
   double drop_p = 0.0; unsigned long long drop_thr = 0, drop_seed = 0, drop_step = 0; bool drop_on = false;
   float* dhm[aocr::MAXL] = {}; aocr::bf16_t* dhm_b[aocr::MAXL] = {}; float* ehm[2][aocr::MAXL] = {}; aocr::bf16_t* ehm_b[2][aocr::MAXL] = {};   // decoder cluster kernel (dec_cluster.hip)
   aocr::CommState comm;
+  bool skip_running_once = false;  // set by aocr_cluster_status when it reports a time-out: the next training forward is the repeat of a skipped step
   // per-family HIP-event profile (aocr_profile_enable): a mark = "family `tag` runs from here to the next mark"
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev; std::vector<int> prof_tag; size_t prof_n = 0;
@@ -120,6 +121,18 @@ void comm_destroy(aocr_model* m);
 int comm_allreduce(aocr_model* m, void* buf, int64_t count, int dtype, hipStream_t stream, int channel);
 int comm_allreduce_grads(aocr_model* m, float* loss_dev);
 inline bool sync_bn_on(const aocr_model* m) { return m->comm.provider != 0 && m->comm.sync_bn; }
+// Exchange vs whole-sequence kernels.  Default with a communicator attached: bucket 0 of the gradient exchange is
+// held behind the encoder BPTT, so no collective kernel is ever co-resident with a cluster kernel.  AOCR_COMM_EARLY_BUCKET0=1 releases it
+// as soon as the decoder's gradients are complete; the encoder cluster launches then keep comm_reserved_cus() compute units free for the
+// collective's workgroups (AOCR_COMM_RESERVE_CUS, default 32 = RCCL's channel count on an 8-GPU xGMI node).
+inline bool comm_early_bucket0() { return getenv("AOCR_COMM_EARLY_BUCKET0") != nullptr; }      // read per call, like every dispatch switch
+inline bool comm_holds_bucket0(const aocr_model* m) { return m->comm.provider != 0 && !comm_early_bucket0(); }
+inline int comm_reserved_cus(const aocr_model* m) {
+  if (m->comm.provider == 0 || !comm_early_bucket0()) return 0;
+  const char* e = getenv("AOCR_COMM_RESERVE_CUS");
+  const int n = e ? atoi(e) : 32;
+  return n < 0 ? 0 : (n > 128 ? 128 : n);
+}
 void prof_mark_slow(aocr_model* m, int tag);
 inline void prof_mark(aocr_model* m, int tag) { if (m->prof_on) prof_mark_slow(m, tag); }
 void build_shadow_jobs(aocr_model* m);                              // after bind_params + model_carve

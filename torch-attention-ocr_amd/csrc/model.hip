@@ -311,6 +311,7 @@ static int bn_sync_allreduce(void* ctx, void* buf, int64_t count, int dtype, hip
 
 void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training, int update_running) {
   hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
+  m->y16[0] = m->y16[1] = 0;                                     // only a training conv_forward below sets them again: the evaluation / folded branch leaves Y3 / Y5 untouched, never "bf16 from an older step"
   const BnSync bsync_v{bn_sync_allreduce, m}; const BnSync* bsync = (training && sync_bn_on(m)) ? &bsync_v : nullptr;
   if (bf && !m->shadow_host.empty()) {                          // every bf16 shadow of the step in one launch
     shadow_jobs(s, m->shadow_dev, (int)m->shadow_host.size(), m->shadow_tiles);
@@ -426,7 +427,7 @@ static bool cluster_ok(const aocr_model* m, int B, int T, int& G, int& RT, int& 
   e = getenv("AOCR_NO_SEQ");                              // "no whole-sequence kernels at all": the per-step launch chain
   if (e && e[0] == '1') return false;
   static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
-  return enc_cluster_plan(B, m->He, T, cus, G, RT, groups);
+  return enc_cluster_plan(B, m->He, T, cus - comm_reserved_cus(m), G, RT, groups);
 }
 static unsigned next_epoch(aocr_model* m) {
   if (++m->cl_epoch >= (1u << 20)) {                              // tags would repeat: clear the buffers and start over
@@ -523,7 +524,7 @@ static void encoder_forward_pipe(aocr_model* m, const Dims& d, int C, int clG, i
         e.w = m->enc[dir][l].swh.wb; e.zx = m->ezx[dir][l]; e.hs = m->ehs[dir][l]; e.cs = m->ecs[dir][l]; e.hsb = m->ehs_b[dir][l];
         e.gates = m->egates[dir][l]; e.ctx = top ? m->context + dir * He : nullptr; e.reverse = dir;
       }
-      enc_cluster_forward(sl, a, clG, clRT);
+      enc_cluster_forward(sl, a, clG, clRT, comm_reserved_cus(m));
       if (!top) hipEventRecord(ev[l * C + c], sl);
     }
   }
@@ -581,7 +582,7 @@ void encoder_forward(aocr_model* m, const Dims& d) {
         e.w = m->enc[dir][l].swh.wb; e.zx = m->ezx[dir][l]; e.hs = m->ehs[dir][l]; e.cs = m->ecs[dir][l]; e.hsb = m->ehs_b[dir][l];
         e.gates = m->egates[dir][l]; e.ctx = top ? m->context + dir * He : nullptr; e.reverse = dir;
       }
-      enc_cluster_forward(s, a, clG, clRT);
+      enc_cluster_forward(s, a, clG, clRT, comm_reserved_cus(m));
       continue;
     }
     if (seq_kernels_ok(m, B)) {                         // whole-sequence kernel: one launch for all T steps of both directions
@@ -659,7 +660,7 @@ static void encoder_backward_pipe(aocr_model* m, const Dims& d, int C, int clG, 
         e.dz = m->edz[dir][l]; e.dzb = m->edz_b[dir][l]; e.forward_dir = dir == 0;
         e.dbi = m->enc[dir][l].dbi; e.dbh = m->enc[dir][l].dbh;
       }
-      enc_cluster_backward(sl, a, clG, clRT);
+      enc_cluster_backward(sl, a, clG, clRT, comm_reserved_cus(m));
       if (l > 0) {
         for (int dir = 0; dir < 2; ++dir) {                // d x of this chunk's steps: t = T-1-it (the fw direction's BPTT) / it
           const LstmP& p = m->enc[dir][l];
@@ -730,7 +731,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
         e.dz = m->edz[dir][l]; e.dzb = m->edz_b[dir][l]; e.forward_dir = dir == 0;
         e.dbi = m->enc[dir][l].dbi; e.dbh = m->enc[dir][l].dbh;
       }
-      enc_cluster_backward(s, a, clG, clRT);
+      enc_cluster_backward(s, a, clG, clRT, comm_reserved_cus(m));
     } else if (seq) {
       EncSeqBwdArgs a; a.B = B; a.T = T; a.He = He;
       for (int dir = 0; dir < 2; ++dir) {
@@ -978,8 +979,11 @@ static bool side_stream_on(aocr_model* m, int B, int T) {
     int G = 0, RT = 0, groups = 0;
     if (cluster_ok(m, B, T, G, RT, groups)) {
       static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
-      const int per_pass = std::max(8, cus / (8 * G) * 8);
-      if (std::min(2 * groups, per_pass) * G * 4 > cus * 3) return false;
+      const int per_pass = std::max(8, (cus - comm_reserved_cus(m)) / (8 * G) * 8);
+      if ((std::min(2 * groups, per_pass) * G + comm_reserved_cus(m)) * 4 > cus * 3) return false;
+      // a stacked encoder's BPTT runs up to Le cluster launches at once on lay_s[] (encoder_backward_pipe), each needing its groups co-resident;
+      // the occupancy estimate above is for ONE launch -- no side stream beside the wavefront
+      if (layer_pipe_chunks(m, T, G, groups) > 0) return false;
     }
   }
   if (!m->side) {
@@ -1130,9 +1134,16 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
 void backward_all(aocr_model* m, const float* images, const int32_t* tgt, const Dims& d) {
   m->side_busy = false;
   decoder_backward(m, d, tgt);
-  hipEventRecord(m->grad_ev[0], m->side_busy ? m->side : m->s);          // decoder + projector gradients complete (on the side stream when it ran them)
+  // Exchange policy: NO collective is in flight while a whole-sequence kernel runs.  A collective's kernel stays
+  // resident until every peer has joined it; a cluster kernel needs all members of a group resident at once and bounds its spins.  With
+  // a communicator attached, bucket 0 (ready here) is therefore released only behind the encoder BPTT kernel -- it still has the whole
+  // CNN backward pass to hide in.  AOCR_COMM_EARLY_BUCKET0=1 restores the early release; the encoder kernels then leave
+  // comm_reserved_cus() compute units free (rnn_cluster.hip).
+  const bool hold0 = comm_holds_bucket0(m);
+  if (!hold0) hipEventRecord(m->grad_ev[0], m->side_busy ? m->side : m->s);          // decoder + projector gradients complete (on the side stream when it ran them)
   encoder_backward(m, d);
   if (m->side_busy) { hipEventRecord(m->side_done, m->side); hipStreamWaitEvent(m->s, m->side_done, 0); }   // join before the CNN backward fills the chip
+  if (hold0) hipEventRecord(m->grad_ev[0], m->s);
   hipEventRecord(m->grad_ev[1], m->s);
   cnn_backward(m, images, d);
   hipEventRecord(m->grad_ev[3], m->s);

@@ -387,7 +387,8 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
         // The statistics come from the accumulators, so y itself could be stored as bf16 (AOCR_BN_Y16=1): -0.065 ms per C3 step (BatchNorm 0.49 -> 0.46 ms, conv forward
         // 0.83 -> 0.755) -- NOT the default: it is one more rounding than "bf16 contraction operands" (the model tests/test_configs_gpu.py holds the product to), and the
         // ReLU / arg-max decisions it flips take the conv-stack gradients from cosine 0.997 to 0.986 against the bf16-operand oracle (limit 0.995).
-        if (y_bf16 && getenv("AOCR_BN_Y16")) { ep.y16 = reinterpret_cast<bf16_t*>(y); ep.y = nullptr; *y_bf16 = 1; }
+        if (y_bf16 && getenv("AOCR_BN_Y16") && Cout % 4 == 0 && !getenv("AOCR_BN_PARTIAL_OLD")) {   // only bn_partial4_kernel / bn_apply_relu_kernel read a bf16 x (xh): never with the 4-byte-access fallback
+          ep.y16 = reinterpret_cast<bf16_t*>(y); ep.y = nullptr; *y_bf16 = 1; }
       }
     }
     // (conv3 -- K = 1152: 36 steps under an un-overlapped epilogue -- on 256 x 128 tiles of the narrow kernel instead: conv forward 0.79 -> 0.763 ms, but that kernel's

@@ -596,9 +596,9 @@ static int cluster_cus() {
   static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
   return cus;
 }
-void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a00, int G, int RT) {
+void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a00, int G, int RT, int reserve_cus) {
   EncClFwdArgs a0 = a00; a0.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;    // testing aid: write-through granules even inside one XCD
-  const int per_pass = std::max(8, cluster_cus() / (8 * G) * 8);          // groups (gids) one launch can keep resident
+  const int per_pass = std::max(8, (cluster_cus() - reserve_cus) / (8 * G) * 8);          // groups (gids) one launch can keep resident; reserve_cus: compute units left to a co-resident collective (model.h: comm_reserved_cus)
   for (int g0 = 0; g0 < 2 * a0.groups; g0 += per_pass) {
     EncClFwdArgs a = a0; a.gid0 = g0; a.ngid = std::min(per_pass, 2 * a0.groups - g0);
     const int grid = 8 * G * ((a.ngid + 7) / 8);
@@ -607,9 +607,9 @@ void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a00, int G, int RT) 
 #undef AOCR_CL
   }
 }
-void enc_cluster_backward(hipStream_t s, const EncClBwdArgs& a00, int G, int RT) {
+void enc_cluster_backward(hipStream_t s, const EncClBwdArgs& a00, int G, int RT, int reserve_cus) {
   EncClBwdArgs a0 = a00; a0.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;
-  const int per_pass = std::max(8, cluster_cus() / (8 * G) * 8);
+  const int per_pass = std::max(8, (cluster_cus() - reserve_cus) / (8 * G) * 8);
   for (int g0 = 0; g0 < 2 * a0.groups; g0 += per_pass) {
     EncClBwdArgs a = a0; a.gid0 = g0; a.ngid = std::min(per_pass, 2 * a0.groups - g0);
     const int grid = 8 * G * ((a.ngid + 7) / 8);
