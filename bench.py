@@ -23,6 +23,8 @@ sys.path.insert(0, os.path.join(ROOT, "torch-attention-ocr_amd"))
 
 WORKLOADS = {
     "c3": dict(B=256, W=256, L=24, He=256, Le=1, Ld=2, compute="bf16", name="32x256 crops, batch 256/GPU, VGG-7 + BiLSTM(256) + 2-layer attn decoder, L=24"),
+    # the strong-scaling slice of C3: BASELINE's "batch 256" read as the GLOBAL batch of an 8-GPU job = 32 lines per GPU
+    "c3s": dict(B=32, W=256, L=24, He=256, Le=1, Ld=2, compute="bf16", name="32x256 crops, batch 32/GPU (C3's global batch 256 over 8 GPUs), VGG-7 + BiLSTM(256) + 2-layer attn decoder, L=24"),
     "c2": dict(B=64, W=100, L=24, He=256, Le=1, Ld=2, compute="f32", name="32x100 crops, batch 64/GPU, VGG-7 + BiLSTM(256) + 2-layer attn decoder, L=24"),
     "ref": dict(B=400, W=100, L=24, He=512, Le=1, Ld=2, compute="bf16", name="32x100 crops, batch 400/GPU, VGG-7 + BiLSTM(512) + 2-layer attn decoder (train.lua defaults), L=24"),
     # BASELINE.json configs[3]: variable-width crops 32x{64..800} in width buckets (data_gen.lua:91-99 emits one width per batch), 64 lines per GPU
@@ -424,6 +426,27 @@ def main():
               "frac": byts / (msd * 1e-3) / 1e9 / HBM_PEAK_GBPS}
 
     out = None
+    hbm_kernels = None
+    if rank == 0 and wl["compute"] == "bf16" and world == 1 and not wl.get("widths"):
+        # ---- the BANDWIDTH-bound kernels ("report HBM GB/s for those kernels separately"): each replayed by the library on the
+        # buffers of a training step with the arguments the step passes (aocr_profile_kernel ids >= 2), HIP events on the model's stream;
+        # algorithmic bytes = what the kernel must read and write once.  `frac` is against the 8 TB/s spec; ~6.3 TB/s is what a float4 copy
+        # reaches on this chip (MI355X_MICROARCH.md), so 0.79 is the practical ceiling.  PMC cross-check: profiles/r04_hbm_pmc.txt.
+        step(); torch.cuda.synchronize()
+        names = {2: ("conv1_fwd_kernel", "normalise + conv1 + ReLU + 2x2 pool: fp32 image in, pooled bf16 map out"),
+                 3: ("conv1_bwd_pk_kernel", "conv1 filter gradient: image + fp32 d(pooled map) in; VALU-bound (~110 instructions per window and lane), not byte-bound"),
+                 4: ("bn_fwd_finalize_kernel + bn_apply_relu_kernel", "conv5 BatchNorm + ReLU: fp32 map in, bf16 out (sums from the conv epilogue)"),
+                 5: ("bn_partial4_kernel<1> + bn_bwd_finalize_kernel + bn_bwd_apply_kernel", "conv5 BatchNorm backward: sums pass (10 B / element) + apply pass (12 B / element)"),
+                 6: ("unpool8_kernel", "conv6 (2,1) un-pool + ReLU backward: fp32 d(pooled), arg-max, bf16 mask in; bf16 gradient map out"),
+                 7: ("attn_dctx_kernel", "d(context) over the L decoder steps: (L,B,T) weights and score gradients + (L,B,Hd) vectors in, (B,T,Hd) fp32 out; the L x re-reads are served by L2"),
+                 8: ("splitk_reduce_kernel", "sum of conv6's 7 split-K filter-gradient slabs (fp32) into the gradient")}
+        hbm_kernels = {}
+        for kid, (kname, what) in names.items():
+            ms_k, by = m.profile_kernel(kid, 20)
+            gbps = by / (ms_k * 1e-3) / 1e9
+            hbm_kernels[kname] = {"us_per_launch": 1e3 * ms_k, "algorithmic_MB": by / 1e6, "GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS,
+                                  "frac_of_6.3TBps_achievable": gbps / 6300.0, "what": what}
+        step(); torch.cuda.synchronize()                  # the replays clobbered activations / gradients: leave the model in a defined state
     if rank == 0:
         bf16 = wl["compute"] == "bf16"
         ms, kfl = m.profile_kernel(0, 20)                # conv6 forward, HIP events on the model's stream
@@ -470,7 +493,7 @@ def main():
             "families": families,
             "decode_chars_per_s": dec["chars_per_s"] if dec else None, "decode": dec, "decode_dict": dec_dict, "decode_beam5": beam5,
             "replica_drift": replica_drift, "loss": loss_val, "secondary": c2, "data_path": dp,
-            "roofline": roof, "roofline_best": best,
+            "roofline": roof, "roofline_best": best, "hbm_kernels": hbm_kernels,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl)

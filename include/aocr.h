@@ -205,7 +205,21 @@ int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32
 /* Times `iters` launches of one hot kernel of the LAST step's shape with HIP events
  * on the model's stream; which: 0 = conv6 forward implicit GEMM (largest layer), 1 = conv6 filter gradient (the split-K
  * kernel + the sum of its slabs, as the backward pass launches them; the result goes to scratch).
- * ms_per_launch and flops_per_launch are host outputs (this call synchronises). */
+ * ms_per_launch and flops_per_launch are host outputs (this call synchronises).
+ * which >= 2 (round 4): the BANDWIDTH-bound kernels of the bf16 training step, each replayed with the arguments and on the buffers of the last
+ * aocr_train_forward_backward (whose image buffer must still be valid); *flops_per_launch then returns the ALGORITHMIC BYTES of one launch
+ * (what the kernel must read and write once), so bytes / ms = the HBM rate to hold against ~6.3 TB/s achievable.
+ * These replays overwrite activations / gradient maps / gradients: taps and gradients are undefined until the next step. */
+#define AOCR_PK_CONV6_FWD 0
+#define AOCR_PK_CONV6_WGRAD 1
+#define AOCR_PK_CONV1_FWD 2      /* normalise + conv1 + ReLU + 2x2 pool (cnn.lua:9-15): image in, pooled bf16 map out */
+#define AOCR_PK_CONV1_BWD 3      /* its filter / bias gradient (window recomputed; no d(image)) */
+#define AOCR_PK_BN_FWD 4         /* conv5's BatchNorm + ReLU (cnn.lua:32-33): finalize + apply pass (the sums come from the conv epilogue) */
+#define AOCR_PK_BN_BWD 5         /* its backward: sums pass + apply pass */
+#define AOCR_PK_UNPOOL 6         /* conv6's (2,1) un-pool + ReLU backward (cnn.lua:37-38) */
+#define AOCR_PK_ATTN_DCTX 7      /* d(context) summed over the L decoder steps (model.lua:652-653) */
+#define AOCR_PK_SPLITK 8         /* sum of conv6's split-K filter-gradient slabs */
+#define AOCR_PK_LAST 8
 int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_per_launch, double* flops_per_launch);
 
 /* Per-family timing of the fused step with HIP events on the model's stream (measurement only).  After

@@ -267,7 +267,7 @@ int aocr_train_forward_backward(aocr_model* m, const float* images_dev, const in
   backward_all(m, images_dev, targets_dev, d);
   m->drop_on = false;
   prof_mark(m, -1);
-  m->last = d; m->last_valid = 1;
+  m->last = d; m->last_valid = 1; m->last_images = images_dev; m->last_train = true;
   return check_launch("aocr_train_forward_backward");
 }
 
@@ -319,7 +319,7 @@ int aocr_forward_logits(aocr_model* m, const float* images_dev, const int32_t* t
   decoder_tf_forward(m, d, targets_dev, 1, L, false);
   if (targets_eval_dev) loss_and_dlogits(m, d, targets_eval_dev, 1, L, 0.f, false, loss_dev);
   if (logits_dev) copy2d(m->s, m->logits, LOGIT_LD, logits_dev, m->V, L * B, m->V);
-  m->last = d; m->last_valid = 1;
+  m->last = d; m->last_valid = 1; m->last_train = false;
   return check_launch("aocr_forward_logits");
 }
 
@@ -367,7 +367,7 @@ int aocr_decode_dict(aocr_model* m, const float* images_dev, const int32_t* targ
   loss_and_dlogits(m, d, m->tge_pad, 1, Lt, 0.f, false, loss_dev);
   if (gold_scores_dev) gold_scores(m->s, m->nll_rows, gold_scores_dev, d.L, B);
   prof_mark(m, -1);
-  m->last = d; m->last_valid = 1;
+  m->last = d; m->last_valid = 1; m->last_train = false;
   return check_launch(trie ? "aocr_decode_dict" : "aocr_decode");
 }
 
@@ -421,16 +421,61 @@ int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32
 int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_per_launch, double* flops_per_launch) {
   REQUIRE(m && ms_per_launch && flops_per_launch, "NULL argument");
   REQUIRE(m->last_valid, "run a step first");
-  REQUIRE(which == 0 || which == 1, "unknown kernel id %d", which);
+  REQUIRE(which >= 0 && which <= AOCR_PK_LAST, "unknown kernel id %d", which);
   REQUIRE(iters >= 1, "iters must be >= 1");
+  REQUIRE(which < 2 || (m->bf16 && m->last_images && m->last_train), "the HBM-bound kernel ids replay the bf16 TRAINING step: run aocr_train_forward_backward in bf16 mode first");
   const Dims& d = m->last;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipStream_t s = m->s; const int B = d.B;
+  const int64_t n5 = (int64_t)B * d.H4 * d.W2;              // pixels of the conv5 / conv6 maps (512 channels)
+  constexpr size_t SLAB = (size_t)4 << 20;
+  double bytes = 0.0;
+  // ids >= 2: the bandwidth-bound kernels, each replayed on the buffers the last TRAINING step left, with the arguments cnn_forward /
+  // cnn_backward / decoder_backward pass (bf16 mode).  Outputs land where the step puts them (activations, gradient maps, gradient
+  // vector): the model's taps and gradients are UNDEFINED afterwards until the next step.  flops_per_launch returns ALGORITHMIC BYTES.
   auto run = [&]() {
-    if (which == 0)
+    switch (which) {
+    case 0:
       conv_forward(m->s, m->bf16, m->A5, m->conv[6].w, m->conv[6].b, m->bf16 ? nullptr : m->A6, m->idx6, d.B, d.H4, d.W2, 512, 512, 3, 1, 1, 2, m->A5b, m->wb[6],
                    m->A6b, 1);                              // exactly the launch cnn_forward makes for conv6 (distinct symbol: TAG = 1)
-    else                                                    // conv6 filter gradient as backward_all launches it (split-K slabs + their sum), summed into scratch
+      break;
+    case 1:                                                 // conv6 filter gradient as backward_all launches it (split-K slabs + their sum), summed into scratch
       conv_backward_filter(m->s, m->bf16, m->A5, m->G0, m->G1, nullptr, d.B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, m->G0b, m->wg_part, m->wg_part_floats, 1);
+      break;
+    case AOCR_PK_CONV1_FWD:                                 // R1 + R2: reads the image (fp32), writes the pooled 64-channel map as bf16
+      conv1_forward(s, m->last_images, m->conv[1].w, m->conv[1].b, nullptr, B, d.H, d.W, m->A1b);
+      bytes = (double)B * d.H * d.W * 4 + (double)B * d.H1 * d.W1 * 64 * 2;
+      break;
+    case AOCR_PK_CONV1_BWD:                                 // reads the image and d(pooled map) (fp32, conv2's data gradient); writes 640 numbers
+      conv1_backward(s, m->last_images, m->conv[1].w, m->conv[1].b, m->G1, m->conv[1].dw, m->conv[1].db, B, d.H, d.W,
+                     (size_t)B * d.H1 * d.W1 * 128 >= (size_t)4096 * 640 ? m->G0 + 6 * SLAB : nullptr, nullptr);
+      bytes = (double)B * d.H * d.W * 4 + (double)B * d.H1 * d.W1 * 64 * 4;
+      break;
+    case AOCR_PK_BN_FWD:                                    // conv5's BatchNorm + ReLU as the step runs it: statistics from the conv epilogue -> finalize + ONE pass: fp32 y in, bf16 out
+      bn_relu_forward(s, m->Y5, nullptr, m->bn[5].w, m->bn[5].b, m->bn[5].rm, m->bn[5].rv, m->bn[5].save, m->bn_scratch, n5, 512, 1, 0, 0, m->A5b, nullptr, (int)(n5 / 256));
+      bytes = (double)n5 * 512 * (4 + 2);
+      break;
+    case AOCR_PK_BN_BWD:                                    // conv5's BatchNorm backward: sums pass (x fp32, d A fp32, mask bf16) + apply pass (the same + bf16 d x out)
+      bn_relu_backward(s, m->Y5, m->A5, m->G1, m->bn[5].w, m->bn[5].save, nullptr, m->bn[5].dw, m->bn[5].db, m->bn_scratch, n5, 512, 0, m->G0b, m->A5b,
+                       m->conv[5].db, m->G0 + 2 * SLAB, nullptr, nullptr);
+      bytes = (double)n5 * 512 * ((4 + 4 + 2) + (4 + 4 + 2 + 2));
+      break;
+    case AOCR_PK_UNPOOL:                                    // (2,1) un-pool + ReLU backward of conv6: d(pooled) fp32 + arg-max (1 B) + pooled mask (bf16) in, bf16 gradient of the un-pooled map out
+      unpool_relu_backward(s, m->G1, m->A6, m->idx6, nullptr, B, d.H4, d.W2, 512, 2, m->G0b, m->conv[6].db, m->G0 + 1 * SLAB, m->A6b, nullptr);
+      bytes = (double)B * d.H6 * d.W2 * 512 * (4 + 1 + 2) + (double)n5 * 512 * 2;
+      break;
+    case AOCR_PK_ATTN_DCTX:                                 // d(context) of all L steps in one pass (model.lua:652-653): a, d s (L,B,T), d c, q (L,B,Hd) in; (B,T,Hd) fp32 out
+      attention_dctx(s, m->a_all, m->ds_all, m->dcat_all, 2 * m->Hd, m->q_all, m->dctx, d.L, B, d.T, m->Hd);
+      bytes = (double)d.L * B * (2.0 * d.T + 2.0 * m->Hd) * 4 + (double)B * d.T * m->Hd * 4;
+      break;
+    case AOCR_PK_SPLITK:                                    // the sum of conv6's seven split-K slabs (512 x 4608 fp32 each) into the gradient
+      {
+        const int ksl = (int)std::min<size_t>(7, m->wg_part_floats / ((size_t)512 * 4608));       // 36 tiles of 256 x 256 on 256 units: 7 k ranges (conv_backward_filter)
+        if (ksl >= 1) splitk_reduce(s, m->wg_part, ksl, (size_t)512 * 4608, m->G1);
+        bytes = (double)512 * 4608 * 4 * (ksl + 2);
+      }
+      break;
+    }
   };
   run();
   hipEventRecord(e0, m->s);
@@ -444,7 +489,7 @@ int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_p
     unsigned long long pr[8] = {0}; kprobe_read(pr);
     for (int k = 0; k < 2; ++k) if (pr[4 * k + 1]) fprintf(stderr, "[aocr] probe (%s halo kernel, conv6 forward): K loop of one workgroup %llu shader cycles in %.1f us = %.2f GHz\n", k ? "4-wave" : "8-wave", pr[4 * k], pr[4 * k + 1] / 100.0, pr[4 * k] / (pr[4 * k + 1] * 10.0)), fprintf(stderr, "[aocr]   prologue %.1f us, whole workgroup %.1f us (stores acknowledged)\n", pr[4 * k + 2] / 100.0, pr[4 * k + 3] / 100.0);
   }
-  *flops_per_launch = 2.0 * (double)d.B * d.H4 * d.W2 * 512.0 * (9.0 * 512.0);
+  *flops_per_launch = which < 2 ? 2.0 * (double)d.B * d.H4 * d.W2 * 512.0 * (9.0 * 512.0) : bytes;
   return check_launch("aocr_profile_kernel");
 }
 

@@ -1666,6 +1666,107 @@ void gemm_dma_narrow_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16
 }
 
 // ---------------------------------------------------------------------------
+// 128 x 128 tiles on the LDS-DMA ring (round 4): the kernel for grids that do NOT fill the chip with 256 x 256 / 256 x 128 tiles -- the
+// conv forward / data-gradient launches at 32-64 lines per GPU (BASELINE configs[3], the strong-scaling slice of C3) and ragged M.
+// There gemm_lds_bf16_kernel -- global -> VGPR -> ds_write staging, ONE tile in flight, one workgroup per CU when the grid is <= 256 tiles --
+// ran at 0.62 us per 128 x 128 x 32 step against 0.12 us of MFMA (conv6 at 32 lines: 90 us for 38.6 GFLOP): the step is the L2 round trip.
+// Four waves of 64 x 64 (2 x 2 accumulator tiles), NS ring slots of 16 KB filled by LDS-DMA with NS - 1 tiles in flight (NS = 4: two
+// workgroups per CU; NS = 8: one, for grids of <= one workgroup per CU), one barrier per tile, the same source-side swizzle, zero page and
+// k order as the other LDS-DMA kernels (bit-identical to gemm_lds_bf16_kernel: the parity tests compare them under AOCR_NO_DMA128=1).
+// ---------------------------------------------------------------------------
+template <class AL, class BL, class EP, int NS, int NW>
+__global__ __launch_bounds__(64 * NW, (NS == 4 && NW == 4) ? 2 : 1)
+void gemm_dma128_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t* zero) {
+  // NW = 4: waves 2 (M) x 2 (N), 64 x 64 each.  NW = 8: 2 x 4, 64 x 32 each -- for grids of <= one workgroup per CU: with ONE wave per SIMD the
+  // wave's own LDS-DMA issue (4 pieces, ~80 cycles each), fragment reads and 8 MFMAs (256 cycles) serialise (measured 0.51 us per step, conv6 at
+  // 32 lines 74 us); two waves per SIMD issue half the pieces each and multiply under each other's issue stalls.
+  constexpr int SLOT = 16384, NI = NW == 4 ? 2 : 1, PPW = 16 / NW;      // N tiles per wave; DMA pieces per wave, tile and operand... (A and B: 8 pieces each)
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * SLOT];            // the ONLY LDS object
+  const int nwg = gx * gy, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int m_blk = (bid / gx) * 128, n_blk = (bid % gx) * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5, wm = NW == 4 ? wave >> 1 : wave >> 2, wn = NW == 4 ? wave & 1 : wave & 3;
+
+  // staging: rows (tid >> 2) + 16 NW j of both operands (j < PPW / 2 ... i.e. 128 rows over NW waves), position tid & 3 holds k-chunk (tid & 3) ^ ((tid >> 4) & 3)
+  constexpr int NJ = 8 / NW;                            // pieces per wave and operand (a piece = 16 rows x 64 B)
+  const int srow = tid >> 2, chunk = (tid & 3) ^ ((tid >> 4) & 3);
+  typename AL::DRow ra[NJ]; typename BL::DRow rb[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { ra[j] = a.drow(m_blk + 16 * NW * j + srow, chunk); rb[j] = b.drow(n_blk + 16 * NW * j + srow, chunk); }
+  typename AL::DCur ca = a.dseek(0); typename BL::DCur cb = b.dseek(0);
+  const int nk = K >> 5;
+  unsigned char* const wbase = lds + wave * 1024;
+  int slot = 0;
+  auto issue = [&]() {                                  // (past the end of K the loaders select the zero page: never consumed)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) dma16(a.dsrc(ra[j], ca, zero), wbase + slot * SLOT + j * (1024 * NW));
+    a.dadvance(ca);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) dma16(b.dsrc(rb[j], cb, zero), wbase + slot * SLOT + 8192 + j * (1024 * NW));
+    b.dadvance(cb);
+    slot = slot == NS - 1 ? 0 : slot + 1;
+  };
+  (void)PPW;
+
+  f32x16 acc[2][NI];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int swz = (r >> 2) & 3;
+  unsigned aoff[2], boff[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    aoff[s] = (wm * 64 + r) * 64 + (((2 * s + h) ^ swz) << 4);
+    boff[s] = 8192 + (wn * 32 * NI + r) * 64 + (((2 * s + h) ^ swz) << 4);
+  }
+
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i) issue();
+  int rslot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ * (NS - 2)) : "memory");   // this wave's pieces of tile kt have landed (NS - 2 tiles stay in flight)
+    __builtin_amdgcn_s_barrier();                       // ... everyone's have, and everyone is done reading tile kt-1
+    const unsigned char* L = lds + rslot * SLOT;
+    rslot = rslot == NS - 1 ? 0 : rslot + 1;
+    bf16x8 af[2][2], bf[2][NI];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) af[s2][mi] = *reinterpret_cast<const bf16x8*>(L + aoff[s2] + mi * 2048);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[s2][ni] = *reinterpret_cast<const bf16x8*>(L + boff[s2] + ni * 2048);
+    }
+    issue();                                            // tile kt + NS - 1 -> the slot of tile kt-1
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s2][mi], bf[s2][ni], acc[mi][ni], 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (zero-page) tiles must land before the LDS is released
+  const int m0 = m_blk + wm * 64, n0 = n_blk + wn * 32 * NI;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[NI][4];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * q + i];
+      ep.template quad<NI>(m0 + 32 * mi + 8 * q + 4 * h, n0 + r, 32, v);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Filter-gradient kernel with hardware-transposed LDS reads.
 // Both operands of dW = dY^T . Xcol are contiguous along M/N (channels) and strided along K (pixels).  Instead of
 // transposing 8x4 micro-blocks in registers, the tiles are copied into LDS as they are -- [32 k][128 channels] bf16, one

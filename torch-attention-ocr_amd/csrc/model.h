@@ -99,6 +99,7 @@ struct aocr_model {
   int64_t conv5_off;              // offset of cnn.conv5.w in the flat vectors: the CNN group is split there
   aocr::Dims last;                // dims of the last step (for the parity taps)
   int last_valid;
+  const float* last_images = nullptr; bool last_train = false;   // the caller's image buffer of the last aocr_train_forward_backward (aocr_profile_kernel replays conv1 on it)
   // cluster encoder kernels (rnn_cluster.hip): exchange buffers, error flag, launch epoch (tags = epoch * 4096 + step)
   unsigned long long *cl_xbuf = nullptr, *cl_pbuf = nullptr, *cl_xtab = nullptr; int* cl_err = nullptr; size_t cl_xbytes = 0, cl_pbytes = 0, cl_tbytes = 0; unsigned cl_epoch = 0;
   unsigned long long *dc_xbuf = nullptr, *dc_xtab = nullptr; size_t dc_xbytes = 0, dc_tbytes = 0; aocr::bf16_t* ctxa_b = nullptr; bool ctxa_fresh = false; /* ctxa_b holds ctx W_a of the CURRENT context (set by the beam pass, consumed by the gold pass of the same decode call) */ bool dgates_il = false; unsigned long long* dc_bxbuf = nullptr; size_t dc_bxbytes = 0; float* dc_pbuf = nullptr;

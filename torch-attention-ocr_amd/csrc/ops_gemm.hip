@@ -45,6 +45,23 @@ static void launch_dma_narrow(hipStream_t s, const AL& a, const BL& b, const EP&
   if (N % 128 == 0) { const int gx = N / 128; hipLaunchKernelGGL((gemm_dma_narrow_kernel<AL, BL, EP, 2>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page()); }   // (N > 128: column blocks of 128)
   else          hipLaunchKernelGGL((gemm_dma_narrow_kernel<AL, BL, EP, 1>), dim3(gy), dim3(512), 0, s, a, b, ep, K, 1, gy, zero_page());
 }
+// 128 x 128 tiles on the LDS-DMA ring (gemm_dma128_kernel): every bf16 K-contiguous pair the larger LDS-DMA kernels do not take (small / ragged M).
+// AOCR_NO_DMA128=1: the register-staged 128 x 128 kernel (the parity reference: same k order, bit-identical)
+static bool dma128_eligible(int M, int N, int K, int C) {
+  if (N % 128 || K % 32 || C % 32 || M < 1 || dma_disabled()) return false;
+  const char* e = getenv("AOCR_NO_DMA128");
+  return !(e && e[0] == '1');
+}
+template <class AL, class BL, class EP>
+static void launch_dma128(hipStream_t s, const AL& a, const BL& b, const EP& ep, int M, int N, int K) {
+  const int gx = N / 128, gy = cdiv(M, 128);
+  // <= one workgroup per compute unit: a deep ring (7 tiles in flight) is all the latency hiding that workgroup has; otherwise two workgroups of 3 tiles in flight
+  static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+  const char* const w4 = getenv("AOCR_DMA128_W4");         // A/B: the 4-wave form at every grid size
+  if (gx * gy <= cus && !(w4 && w4[0] == '1')) hipLaunchKernelGGL((gemm_dma128_kernel<AL, BL, EP, 8, 8>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page());
+  else if (gx * gy <= cus) hipLaunchKernelGGL((gemm_dma128_kernel<AL, BL, EP, 8, 4>), dim3(gx * gy), dim3(256), 0, s, a, b, ep, K, gx, gy, zero_page());
+  else hipLaunchKernelGGL((gemm_dma128_kernel<AL, BL, EP, 4, 4>), dim3(gx * gy), dim3(256), 0, s, a, b, ep, K, gx, gy, zero_page());
+}
 // 256 x 128 tiles of the narrow kernel for a WIDE product whose 256 x 256 grid would leave half the chip idle (conv7 forward: 63 x 2 tiles)
 static bool dma_mid_eligible(int M, int N, int K, int C) {
   if (N % 128 || K % 32 || C % 32 || M < 256 || dma_disabled() || getenv("AOCR_NO_NARROW_WIDE")) return false;       // conv forward 0.846 -> 0.825 ms per C3 step (conv7: 74.6 us on 128 x 128 tiles)
@@ -299,6 +316,7 @@ void gemm_hh(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64
   // hoisted bf16 GEMMs with full 256 x 128 tiles that fill the chip: the narrow LDS-DMA kernel (two workgroups per CU: one's epilogue under the other's 16-step K loop):
   // hoisted GEMMs 0.739 -> 0.713 ms per C3 step (AOCR_NO_HH_NARROW=1: the 128 x 128 kernel)
   if (!getenv("AOCR_NO_HH_NARROW") && !dma_disabled() && M % 256 == 0 && N % 128 == 0 && K % 32 == 0 && (M / 256) * (N / 128) >= 200) { launch_dma_narrow(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K); return; }
+  if (dma128_eligible(M, N, K, 32)) { launch_dma128(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K); return; }       // small / ragged M (32-64 lines per GPU)
   launch_lds(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K, 1);
 }
 
@@ -308,6 +326,7 @@ void gemm_hh_shadow(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B
   LoadKh b; b.p = B; b.ld = ldb; b.rows = N; b.K = K;
   EpStore e = make_store(C, ldc, M, N, nullptr, nullptr, 0); e.Cb = Cb; e.ldcb = ldcb;
   if (!getenv("AOCR_NO_HH_NARROW") && !dma_disabled() && M % 256 == 0 && N % 128 == 0 && K % 32 == 0 && (M / 256) * (N / 128) >= 200) { launch_dma_narrow(s, a, b, e, M, N, K); return; }
+  if (dma128_eligible(M, N, K, 32)) { launch_dma128(s, a, b, e, M, N, K); return; }
   launch_lds(s, a, b, e, M, N, K, 1);
 }
 
@@ -396,6 +415,7 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
     if (dma_eligible(a.rows, Cout, a.K, Cin) && pad == 1 && halo_eligible(a, Cout, 256, 256)) launch_halo<1, 256, 256>(s, ah, bh, ep, a.rows, Cout, profile_tag);
     else if (dma_eligible(a.rows, Cout, a.K, Cin)) launch_dma(s, ah, bh, ep, a.rows, Cout, a.K, profile_tag);
     else if (dma_narrow_eligible(a.rows, Cout, a.K, Cin) || dma_mid_eligible(a.rows, Cout, a.K, Cin)) launch_dma_narrow(s, ah, bh, ep, a.rows, Cout, a.K);
+    else if (dma128_eligible(a.rows, Cout, a.K, Cin)) launch_dma128(s, ah, bh, ep, a.rows, Cout, a.K);
     else launch_lds(s, ah, bh, ep, a.rows, Cout, a.K, 1);       // (BK = 64 variant measured no faster: launch_lds64)
   } else {
     launch_conv_fwd(s, bf16, a, make_loadk(w, a.K, Cout, a.K), ep, a.rows, Cout, a.K);
@@ -413,6 +433,7 @@ void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* 
     if (dma_eligible(a.rows, Cin, a.K, Cout) && pad == 1 && halo_eligible(a, Cin, 256, 256)) launch_halo<-1, 256, 256>(s, ah, bh, ep, a.rows, Cin);
     else if (dma_eligible(a.rows, Cin, a.K, Cout)) launch_dma(s, ah, bh, ep, a.rows, Cin, a.K);
     else if (dma_narrow_eligible(a.rows, Cin, a.K, Cout)) launch_dma_narrow(s, ah, bh, ep, a.rows, Cin, a.K);
+    else if (dma128_eligible(a.rows, Cin, a.K, Cout)) launch_dma128(s, ah, bh, ep, a.rows, Cin, a.K);
     else launch_lds(s, ah, bh, ep, a.rows, Cin, a.K, 1);
   } else if (wtf) {                                          // fp32 taps re-laid [Cin][tap][Cout]: K-contiguous dwordx4 loads
     launch_big(s, bf16, a, make_loadk(wtf, a.K, Cin, a.K), ep, a.rows, Cin, a.K, 1);
