@@ -999,3 +999,28 @@ def test_dma128_kernel_matches_tiled_kernel(cuda, monkeypatch, B, W):
         else:
             assert torch.allclose(a["grads"][k], b["grads"][k], rtol=1e-5, atol=1e-7), k
     print(f"[parity] dma128 vs register-staged 128 x 128 kernel, B={B} W={W}: conv6 / feats / logits bit-identical, loss {a['loss']:.6f}")
+
+
+def test_narrow_staged_epilogue_matches_quad(cuda, monkeypatch):
+    """Round 4: the fp32 output tile of gemm_dma_narrow_kernel leaves through LDS as 16-byte row stores (narrow_store_staged: the hoisted
+    encoder projections / ctx W_a / d X products and the narrow data gradients) instead of 64 four-byte stores per wave.  The values are
+    the same values: against AOCR_NO_NARROW_STAGED=1 (the quad epilogue) context, logits and loss must be BIT-identical.  B = 128, W = 260
+    (T = 64): M = B T = 8192 rows, the smallest shape at He = 256 whose hoisted products take that kernel (AOCR_FORCE_DMA=1 for the convs)."""
+    cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
+    monkeypatch.setenv("AOCR_FORCE_DMA", "1")
+    out = {}
+    for off in ("1", "0"):
+        monkeypatch.setenv("AOCR_NO_NARROW_STAGED", off)
+        m, O, ocfg, P, st, batch = make(cfg, B=128, W=260, maxlen=6, compute="bf16", max_decoder_l=8, max_beam=1)
+        loss = m.train_forward_backward(batch)
+        out[off] = dict(loss=loss, ctx=m.get_tensor("context").clone(), logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(),
+                        dfeats=m.get_tensor("dfeats").clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.shutdown()
+    a, b = out["1"], out["0"]
+    assert torch.equal(a["ctx"], b["ctx"]) and torch.equal(a["logits"], b["logits"]) and a["loss"] == b["loss"]
+    assert torch.equal(a["dfeats"], b["dfeats"])
+    for k in a["grads"]:
+        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):          # bias in front of a BatchNorm: exact gradient 0, only rounding noise
+            continue
+        assert relerr(b["grads"][k], a["grads"][k]) < 1e-5, k          # split-K atomics: summation order only
+    print(f"[parity] staged vs quad epilogue of the narrow LDS-DMA kernel: context / logits / d(feats) bit-identical, loss {a['loss']:.5f}")

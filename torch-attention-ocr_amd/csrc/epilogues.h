@@ -97,6 +97,54 @@ struct EpStore {
   }
 };
 
+// The fp32 tile of gemm_dma_narrow_kernel (256 x 64 NT, 8 waves as 4 (M) x 2 (N), wave tile 64 x 32 NT) through LDS, two passes of 128 rows.
+// Round 4: the hoisted bf16 GEMMs (K = 512 / 1024: 16-32 steps, 2 us of MFMA per workgroup) are epilogue-bound -- the quad epilogue issues 64
+// 4-byte store instructions per wave for a 128 KB tile; staged, the tile leaves as 16-byte stores of whole 512-byte rows (and its bf16 shadow, when
+// asked for, as 8-byte stores from the same image).  Plain stores only (bias / ReLU / tanh applied on the way in); anything else -> quad epilogue.
+template <int NT, class EPT>
+__device__ __forceinline__ bool narrow_store_staged(const EPT& ep, const f32x16 (&acc)[2][NT], unsigned char* lds, int m_blk, int n_blk, int wm, int wn, int r, int h, int tid) {
+  constexpr int BN = 64 * NT, PITCH = BN * 4;
+  if ((ep.flags & (EP_ATOMIC | EP_ACCUM)) || ep.C1 || ep.dg || n_blk + BN > ep.N) return false;
+  float bb[NT];
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) { const int col = n_blk + wn * 32 * NT + ni * 32 + r; bb[ni] = (ep.bias ? ep.bias[col] : 0.f) + (ep.bias2 ? ep.bias2[col] : 0.f); }
+  __syncthreads();                                        // every wave is out of the K loop (the ring is free)
+  for (int p = 0; p < 2; ++p) {
+    if ((wm >> 1) == p) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float x = acc[mi][ni][4 * q + i] + bb[ni];
+              if (ep.flags & EP_RELU) x = fmaxf(x, 0.f);
+              if (ep.flags & EP_TANH) x = tanhf_(x);
+              *reinterpret_cast<float*>(lds + ((wm & 1) * 64 + mi * 32 + 8 * q + 4 * h + i) * PITCH + (wn * 32 * NT + ni * 32 + r) * 4) = x;
+            }
+    }
+    __syncthreads();
+    const int row_base = m_blk + p * 128;
+#pragma unroll 4
+    for (int it = 0; it < (128 * BN / 4) / 512; ++it) {
+      const int idx = it * 512 + tid, row = idx / (BN / 4), c = idx % (BN / 4);
+      if (row_base + row < ep.M) {
+        const float4 v = *reinterpret_cast<const float4*>(lds + row * PITCH + c * 16);
+        *reinterpret_cast<float4*>(ep.C + (int64_t)(row_base + row) * ep.ldc + n_blk + c * 4) = v;
+        if (ep.Cb) {
+          typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+          bf16x4_ o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+          *reinterpret_cast<bf16x4_*>(ep.Cb + (int64_t)(row_base + row) * ep.ldcb + n_blk + c * 4) = o;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  return true;
+}
+
 // conv epilogue: bias, optional ReLU, optional fused max-pool (window = consecutive rows).
 struct EpConv {
   float* y; uint8_t* idx; const float* bias; int Cout; int rows; int pmode; int relu;   // y may be null when yb is given (bf16 mode keeps only the shadow)

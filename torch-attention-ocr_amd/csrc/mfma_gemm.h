@@ -992,6 +992,10 @@ __device__ __forceinline__ bool tile256_store_staged(const EP& ep, const f32x16 
   } else return false;
 }
 
+// (defined in epilogues.h, behind EpStore: the staged fp32 tile of gemm_dma_narrow_kernel)
+template <int NT, class EPT>
+__device__ __forceinline__ bool narrow_store_staged(const EPT& ep, const f32x16 (&acc)[2][NT], unsigned char* lds, int m_blk, int n_blk, int wm, int wn, int r, int h, int tid);
+
 __device__ __forceinline__ void dma16(const void* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
@@ -1580,7 +1584,7 @@ void gemm_halo4_bf16_kernel(LoadConvKh a, LoadKh b, EP ep, int gx, int gy, const
 // ---------------------------------------------------------------------------
 template <class AL, class BL, class EP, int NT>
 __global__ __launch_bounds__(512, 2)
-void gemm_dma_narrow_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t* zero) {
+void gemm_dma_narrow_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16_t* zero, int staged) {
   constexpr int BN = 64 * NT, SLOT = 16384 + BN * 64;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * SLOT];             // the ONLY LDS object
   const int nwg = gx * gy, orig = blockIdx.x;
@@ -1651,6 +1655,9 @@ void gemm_dma_narrow_kernel(AL a, BL b, EP ep, int K, int gx, int gy, const bf16
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s2][mi], bf[s2][ni], acc[mi][ni], 0, 0, 0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (zero-page) tiles must land before the LDS is released
+  if constexpr (std::is_same<EP, EpStore>::value) {
+    if (staged && narrow_store_staged<NT, EP>(ep, acc, lds, m_blk, n_blk, wm, wn, r, h, tid)) return;
+  }
   const int m0 = m_blk + wm * 64, n0 = n_blk + wn * 32 * NT;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)

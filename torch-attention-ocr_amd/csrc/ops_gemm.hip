@@ -42,8 +42,10 @@ static bool dma_narrow_eligible(int M, int N, int K, int C) {
 template <class AL, class BL, class EP>
 static void launch_dma_narrow(hipStream_t s, const AL& a, const BL& b, const EP& ep, int M, int N, int K) {
   const int gy = cdiv(M, 256);
-  if (N % 128 == 0) { const int gx = N / 128; hipLaunchKernelGGL((gemm_dma_narrow_kernel<AL, BL, EP, 2>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page()); }   // (N > 128: column blocks of 128)
-  else          hipLaunchKernelGGL((gemm_dma_narrow_kernel<AL, BL, EP, 1>), dim3(gy), dim3(512), 0, s, a, b, ep, K, 1, gy, zero_page());
+  const char* const ns = getenv("AOCR_NO_NARROW_STAGED");  // A/B and parity: the quad epilogue (read per call)
+  const int staged = !(ns && ns[0] == '1');
+  if (N % 128 == 0) { const int gx = N / 128; hipLaunchKernelGGL((gemm_dma_narrow_kernel<AL, BL, EP, 2>), dim3(gx * gy), dim3(512), 0, s, a, b, ep, K, gx, gy, zero_page(), staged); }   // (N > 128: column blocks of 128)
+  else          hipLaunchKernelGGL((gemm_dma_narrow_kernel<AL, BL, EP, 1>), dim3(gy), dim3(512), 0, s, a, b, ep, K, 1, gy, zero_page(), staged);
 }
 // 128 x 128 tiles on the LDS-DMA ring (gemm_dma128_kernel): every bf16 K-contiguous pair the larger LDS-DMA kernels do not take (small / ragged M).
 // AOCR_NO_DMA128=1: the register-staged 128 x 128 kernel (the parity reference: same k order, bit-identical)
