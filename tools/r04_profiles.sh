@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-4 profile artefacts (run via gpurun from the repo root): everything lands in gpurun_out/prof4/; copy the summaries into profiles/r04_*.
+# Every pass is bounded by its own `timeout`; the program follows `--` directly (python3 bench.py ...), counters are collected in passes of their own.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof4; rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py"
+SHORT="--steps 2 --warmup 1 --no-cpu-baseline --decode-steps 0 --no-secondary --sustain-seconds 0"
+timeout 600 $B > $O/bench_c3_bf16.json 2> $O/bench.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --sustain-seconds 1 > $O/bench_stats.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B $SHORT > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $B $SHORT > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -- $B $SHORT > /dev/null 2>&1
+for w in c2 c3s c4 c5 ref; do
+  st=10; wu=3; [ $w = c4 ] && st=48 && wu=24; [ $w = c5 ] && st=5 && wu=2
+  timeout 300 $B --workload $w --steps $st --warmup $wu --no-cpu-baseline --no-secondary --sustain-seconds 1 > $O/bench_$w.json 2> $O/bench_$w.err
+done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3s -- $B --workload c3s --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --decode-steps 0 --sustain-seconds 0 > /dev/null 2>&1
+cd $R
+f=$(ls $O/pmc_fetch/*/*counter_collection.csv | head -1); w=$(ls $O/pmc_write/*/*counter_collection.csv | head -1); mf=$(ls $O/pmc_mfma/*/*counter_collection.csv | head -1)
+python3 tools/pmc_traffic.py $f $w $O > $O/pmc_traffic.txt 2>&1
+python3 tools/pmc_hbm_kernels.py $f $w $(ls $O/pmc_fetch/*/*kernel_trace.csv | head -1) > $O/hbm_pmc.txt 2>&1
+python3 tools/pmc_mfma_summary.py $mf > $O/mfma_busy.txt 2>&1
+cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/c3_bf16_kernel_stats.csv
+cp $(ls $O/stats_c3s/*/*kernel_stats.csv | head -1) $O/c3s_bf16_kernel_stats.csv
+rm -rf $O/stats $O/stats_c3s $O/pmc_fetch $O/pmc_write $O/pmc_mfma
+tail -1 $O/bench_c3_bf16.json | cut -c1-300; cat $O/hbm_pmc.txt; head -20 $O/mfma_busy.txt
