@@ -439,7 +439,7 @@ def main():
                  5: ("bn_partial4_kernel<1> + bn_bwd_finalize_kernel + bn_bwd_apply_kernel", "conv5 BatchNorm backward: sums pass (10 B / element) + apply pass (12 B / element)"),
                  6: ("unpool8_kernel", "conv6 (2,1) un-pool + ReLU backward: fp32 d(pooled), arg-max, bf16 mask in; bf16 gradient map out"),
                  7: ("attn_dctx_kernel", "d(context) over the L decoder steps: (L,B,T) weights and score gradients + (L,B,Hd) vectors in, (B,T,Hd) fp32 out; the L x re-reads are served by L2"),
-                 8: ("splitk_reduce_kernel", "sum of conv6's 7 split-K filter-gradient slabs (fp32) into the gradient")}
+                 8: ("splitk_reduce_kernel", "sum of conv6's 8 split-K filter-gradient slabs (fp32) into the gradient")}
         hbm_kernels = {}
         for kid, (kname, what) in names.items():
             ms_k, by = m.profile_kernel(kid, 20)

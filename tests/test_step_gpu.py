@@ -1024,3 +1024,33 @@ def test_narrow_staged_epilogue_matches_quad(cuda, monkeypatch):
             continue
         assert relerr(b["grads"][k], a["grads"][k]) < 1e-5, k          # split-K atomics: summation order only
     print(f"[parity] staged vs quad epilogue of the narrow LDS-DMA kernel: context / logits / d(feats) bit-identical, loss {a['loss']:.5f}")
+
+
+@pytest.mark.parametrize("B,W", [(8, 256), (3, 128), (2, 384)])
+def test_halo_wgrad_kernel_matches_tap_tiled_kernel(cuda, monkeypatch, B, W):
+    """Round 4: conv_wgrad_halo_kernel (filter gradient with N tiles of nine taps x 32 input channels, the input map's halo staged once per
+    32-pixel row segment) against the one-tap-per-tile kernels it replaces (AOCR_NO_WGRAD_HALO=1) on the same bf16 operands.  Only the fp32
+    summation order over pixels differs (different split-K ranges), so every conv filter gradient must agree to accumulation noise; the
+    forward pass and every other gradient do not involve the kernel and must be bit-identical.  W = 256 / 128 / 384 -> feature-map rows of
+    64 / 32 / 96 pixels (2 / 1 / 3 segments per row; image borders inside and between the segments); AOCR_FORCE_DMA=1 selects it at these
+    batch sizes."""
+    cfg = dict(enc_hidden=64, enc_layers=1, dec_layers=2, input_feed=True)
+    monkeypatch.setenv("AOCR_FORCE_DMA", "1")
+    out = {}
+    for off in ("1", "0"):
+        if off == "1": monkeypatch.setenv("AOCR_NO_WGRAD_HALO", "1")
+        else: monkeypatch.delenv("AOCR_NO_WGRAD_HALO", raising=False)
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=6, compute="bf16")
+        loss = m.train_forward_backward(batch)
+        out[off] = dict(loss=loss, logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.shutdown()
+    a, b = out["1"], out["0"]
+    assert torch.equal(a["logits"], b["logits"]) and a["loss"] == b["loss"]
+    worst = ("", 0.0)
+    for k in a["grads"]:
+        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):
+            continue
+        e = relerr(b["grads"][k], a["grads"][k])
+        if e > worst[1]: worst = (k, e)
+        assert e < (2e-5 if k.startswith("cnn.conv") and k.endswith(".w") else 1e-6), (k, e)
+    print(f"[parity] halo-resident filter gradient vs tap-tiled kernels, B={B} W={W}: worst relative difference {worst[1]:.2e} ({worst[0]})")

@@ -5,6 +5,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../torch-attention-ocr_amd/csrc gemm4w.hip -o gemm4w
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "ops.h"
 #include "mfma_gemm.h"
@@ -12,6 +13,7 @@ using namespace aocr;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 __device__ unsigned long long g_probe[2];
+static int g_warm = 3;             // launches before every timed loop (argv[1]; ~5000 = 1.5 s of sustained load: steady-state clock)
 __global__ void fill(bf16_t* p, size_t n, unsigned seed) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16_t* __restrict
 template <int MODE, int HALFBAR> static int run(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K, const char* name, int lda = 4608, int kwrap = 8192) {
   const int gx = N / 256, gy = M / 256;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm4w_kernel<MODE, HALFBAR>), dim3(gx * gy), dim3(256), 0, 0, A, B, C, M, N, K, gx, gy, lda, kwrap);
+  for (int i = 0; i < g_warm; ++i) hipLaunchKernelGGL((gemm4w_kernel<MODE, HALFBAR>), dim3(gx * gy), dim3(256), 0, 0, A, B, C, M, N, K, gx, gy, lda, kwrap);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   const int it = 20;
@@ -344,8 +346,11 @@ template <int ABL> static int run8(const LoadKh& a, const LoadKh& b, const EpSto
   return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
   setvbuf(stdout, nullptr, _IONBF, 0);
+  if (argc > 1) g_warm = atoi(argv[1]);
+  const bool quick = argc > 2;                          // argv[2]: only the spread-schedule comparison of the two MFMA shapes
+  printf("warm-up launches before every timed loop: %d\n", g_warm);
   const int M = 65536, N = 512, K = 4608;
   bf16_t *A, *B, *zero; float* C;
   CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 4)); CK(hipMalloc(&zero, 64)); CK(hipMemset(zero, 0, 64));
@@ -356,6 +361,17 @@ int main() {
   LoadKh a; a.p = A; a.ld = K; a.rows = M; a.K = K;
   LoadKh b; b.p = B; b.ld = K; b.rows = N; b.K = K;
   EpStore ep = make_store(C, N, M, N, nullptr, nullptr, 0);
+  if (quick) {
+    for (int rep = 0; rep < 2; ++rep) {
+      run<0, 3>(A, B, C, M, N, K, "32x32x16: 4 waves x 128x128, reads + DMA spread between MFMAs", 512, 512);
+      run<0, 4>(A, B, C, M, N, K, "16x16x32: 4 waves x 128x128, reads + DMA spread between MFMAs", 512, 512);
+      run<16, 3>(A, B, C, M, N, K, "  32x32x16, halo-like DMA volume", 512, 512);
+      run<16, 4>(A, B, C, M, N, K, "  16x16x32, halo-like DMA volume", 512, 512);
+      run<9, 2>(A, B, C, M, N, K, "  32x32x16: MFMA on resident random fragments + barrier", 512, 512);
+      run<9, 4>(A, B, C, M, N, K, "  16x16x32: MFMA on resident random fragments + barrier", 512, 512);
+    }
+    return 0;
+  }
   for (int rep = 0; rep < 2; ++rep) {
     run8<0>(a, b, ep, M, N, K, zero, "8 waves x 128x64 (gemm_dma_bf16_kernel, plain reads)");
     run<0, 0>(A, B, C, M, N, K, "4 waves x 128x128, barrier per tile");

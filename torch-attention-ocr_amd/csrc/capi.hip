@@ -470,7 +470,7 @@ int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_p
       break;
     case AOCR_PK_SPLITK:                                    // the sum of conv6's seven split-K slabs (512 x 4608 fp32 each) into the gradient
       {
-        const int ksl = (int)std::min<size_t>(7, m->wg_part_floats / ((size_t)512 * 4608));       // 36 tiles of 256 x 256 on 256 units: 7 k ranges (conv_backward_filter)
+        const int ksl = (int)std::min<size_t>(8, m->wg_part_floats / ((size_t)512 * 4608));       // 32 tiles of 256 x 288 on 256 units: 8 k ranges (conv_backward_filter, conv_wgrad_halo_kernel)
         if (ksl >= 1) splitk_reduce(s, m->wg_part, ksl, (size_t)512 * 4608, m->G1);
         bytes = (double)512 * 4608 * 4 * (ksl + 2);
       }

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <utility>
 
 namespace aocr {
 
@@ -2035,6 +2036,166 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_dma_kernel(LoadMNh a, LoadC
         for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * qq + i];
       ep.template quad<2>(m0 + 32 * mi + 8 * qq + 4 * h, n0 + r, 32, v);
     }
+}
+
+// ---------------------------------------------------------------------------
+// Filter gradient of a 3 x 3 / pad 1 layer with the INPUT MAP HALO-RESIDENT (round 4; priced in round 3).
+//   dW[co][tap][ci] = sum over pixels p of  dy[p][co] . x[p + off(tap)][ci]
+// conv_wgrad_dma_kernel tiles N as ONE tap x 256 input channels, so every K step (32 pixels) moves 16 KB of d y AND 16 KB of tap-shifted x through
+// L2 -> LDS, and nine workgroups re-fetch the same x pixels for the nine taps.  Here an N tile is ALL NINE TAPS x 32 input channels (N = 288):
+// a K step = one row segment of 32 pixels stages d y as before (16 KB) plus the 3 x 34-pixel halo of the segment for the 32 channels (6.4 KB), and
+// a tap is an OFFSET of the transposed fragment read inside that halo -- 22.4 KB instead of 32 KB per step, for 12 % more MFMA work per step.
+// Four waves, each 64 output channels x 288 (2 x 9 accumulator tiles of 32 x 32 = 288 AGPRs), one wave per SIMD.
+//   LDS slot (24 KB): [32 pixel rows][256 co] d y image as in conv_wgrad_dma_kernel (512 B per pixel row, 64-byte segment index ^ (row & 3)), then the
+//   halo [3 rows][34 pixels][32 ci] = 64 B per pixel, LINEAR: the transposed read of a 16-lane group takes 4 consecutive pixels x 32 channels = 256
+//   contiguous bytes -- conflict-free at every tap shift without a swizzle.  The halo is filled by 7 LDS-DMA pieces whose lanes address
+//   (halo row, pixel, 16-byte chunk) slots in image order (outside the map / past slot 407: zero page); the source offset is LINEAR in the segment
+//   index (raster pixels), so a piece's pointer advances by a constant and only the two bounds compares change per step.
+// Grid: (Cout / 256) x (Cin / 32) tiles x split-K over whole segments, k-range-major XCD order (the workgroups of an XCD share pixel ranges in its L2);
+// every k range writes its 256 x 288 partial tile with plain stores into its slab (dW layout [Cout][9 Cin]); splitk_reduce sums the slabs.
+// Requires W % 32 == 0 (a K step never straddles an image row), Cout % 256 == 0, Cin % 32 == 0.
+// ---------------------------------------------------------------------------
+template <int... I, class F> __device__ __forceinline__ void aocr_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void aocr_static_for(F&& f) { aocr_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+template <int TAG = 0>
+__global__ __launch_bounds__(512, 1)
+void conv_wgrad_halo_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ part, long long pstride,
+                            int nimg, int H, int W, int Cin, int Cout, int gx, int gy, int gz, int segs_per, const bf16_t* zero) {
+  // EIGHT waves as 4 (output-channel groups of 64) x 2 (tap groups: taps 0-4 / taps 5-8): a wave holds 2 x 5 or 2 x 4 accumulator tiles (160 / 128
+  // registers), and since waves w and w + 4 share a SIMD every SIMD carries 18 MFMAs per k-half.  History of the shape (tools/ubench/wgrad_halo.hip,
+  // conv6, random operands, conv_wgrad_dma_kernel 293-327 us in the same harness):
+  //   four waves of 64 x 288: 288 accumulator registers exceed the 256 AGPRs hipcc gives a kernel, and it moves the two tiles it keeps in VGPRs through
+  //     AGPRs around every MFMA (200 v_accvgpr_mov per half step): 380 us compiler-scheduled, 491 us with hand-placed reads / DMA pieces;
+  //   eight waves of 32 x 288 (every wave re-reads all nine taps' fragments: 2.2 transposed reads per MFMA): 276 us isolated -- but only 5 % faster than
+  //     conv_wgrad_dma_kernel back to back on the real gradients and no faster inside the step: the LDS -> register bytes it adds cost what the L2 -> LDS
+  //     bytes it saves;
+  //   this form: 1.4 transposed reads per MFMA (conv_wgrad_dma_kernel: 1.5) AND 22.4 instead of 32 KB per step through L2 -> LDS.
+  constexpr int SLOT = 24576, NS = 6, BOFF = 16384, PW = 34;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[163840];             // the ONLY LDS object: ring of NS slots (147456 B); epilogue: 8 waves x 32 rows x 160 fp32
+  const int nwg = gx * gy * gz, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int zsp = lin / (gx * gy), bid = lin - zsp * (gx * gy);
+  const int m_blk = (bid / gx) * 256, cchunk = bid % gx;                           // 256 output channels x input channels [32 cchunk, +32)
+  const int spr = W >> 5, S = nimg * H * spr;                                      // segments per row, in all
+  const int s_beg = zsp * segs_per, s_end = min(S, s_beg + segs_per);
+  const int nk = s_end > s_beg ? s_end - s_beg : 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, mg = wave & 3, tg = wave >> 2;
+
+  // ---- d y staging: pieces 2 wave, 2 wave + 1; piece pi = pixel rows 2 pi, 2 pi + 1; lane -> row 2 pi + (lane >> 5), 16-byte position lane & 31 of the
+  // row, which holds logical chunk ((pos >> 2) ^ (row & 3)) << 2 | (pos & 3)   (as conv_wgrad_dma_kernel)
+  const bf16_t* pa[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int krow = 2 * (2 * wave + j) + (lane >> 5), pos = lane & 31;
+    const int chunk = ((((pos >> 2) ^ (krow & 3)) << 2) | (pos & 3));
+    pa[j] = dy + ((int64_t)s_beg * 32 + krow) * Cout + m_blk + 8 * chunk;
+  }
+  const int64_t astep = (int64_t)32 * Cout;
+  // ---- halo staging: piece `wave` (piece 7 is all padding); slot sl = 64 piece + lane -> (halo row ry, pixel cx, chunk c) in image order
+  const int sl = 64 * wave + lane;
+  const bool bin = sl < 3 * PW * 4;
+  const int hry = sl / (PW * 4), hrem = sl - hry * (PW * 4), hcx = hrem >> 2, hc = hrem & 3;
+  const int bry = hry - 1, bcx = hcx - 1;
+  const bf16_t* pb = x + ((int64_t)s_beg * 32 + (int64_t)(hry - 1) * W + (hcx - 1)) * Cin + cchunk * 32 + hc * 8;       // never dereferenced while outside the map
+  const int64_t bstep = (int64_t)32 * Cin;
+  int is = s_beg, ixs = s_beg % spr, iy = (s_beg / spr) % H;                       // the issue stream's segment: index, position in its row, image row
+  unsigned char* const wA = lds + (2 * wave) * 1024;
+  unsigned char* const wB = lds + BOFF + wave * 1024;
+  int islot = 0;
+  auto issue = [&]() {
+    const bool live = is < s_end;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { dma16(dma_select(live, pa[j], zero), wA + islot * SLOT + j * 1024); pa[j] += astep; }
+    const int x0 = ixs << 5;
+    const bool ok = live && bin && (unsigned)(iy + bry) < (unsigned)H && (unsigned)(x0 + bcx) < (unsigned)W;
+    dma16(dma_select(ok, pb, zero), wB + islot * SLOT); pb += bstep;
+    ++is; if (++ixs == spr) { ixs = 0; if (++iy == H) iy = 0; }
+    islot = islot == NS - 1 ? 0 : islot + 1;
+  };
+
+  // transposed-read addressing: lane = 16 g + 4 q + p supplies pixel row 8 h + q (+ 4), channels 16 (g & 1) + 4 p .. + 3
+  const int g = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
+  const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
+  const unsigned rowoff = lbase + (8 * h + q) * 512 + (16 * (g & 1) + 4 * p4) * 2;
+  const unsigned aseg0 = rowoff + (((2 * mg) ^ q) << 6), aseg1 = rowoff + (((2 * mg + 1) ^ q) << 6);
+  const unsigned brd = lbase + BOFF + (8 * h + q) * 64 + (16 * (g & 1) + 4 * p4) * 2;
+  typedef unsigned long long u64;
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  const int r = lane & 31;
+  float* const slab = part + (size_t)zsp * pstride;
+  const int64_t ldw = (int64_t)9 * Cin;
+#define AOCR_TRH(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+
+  issue(); issue(); issue();
+  auto body = [&](auto tgc) {                           // TG = 0: taps 0 .. 4, TG = 1: taps 5 .. 8
+    constexpr int TG = decltype(tgc)::value, T0 = TG ? 5 : 0, NTP = TG ? 4 : 5;
+    f32x16 acc[2][NTP];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NTP; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int rslot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // this wave's pieces of segment kt have landed (two later segments in flight)
+      __builtin_amdgcn_s_barrier();                     // ... everyone's have, and everyone is done reading segment kt-1
+      const unsigned so = rslot * SLOT;
+      rslot = rslot == NS - 1 ? 0 : rslot + 1;
+      u64 fa[2][2][2], fb[2][NTP][2];                   // [k half][tile / tap][low / high four k]
+      const unsigned a0 = aseg0 + so, a1 = aseg1 + so, bd = brd + so;
+      AOCR_TRH(fa[0][0][0], a0, 0); AOCR_TRH(fa[0][0][1], a0, 2048); AOCR_TRH(fa[0][1][0], a1, 0); AOCR_TRH(fa[0][1][1], a1, 2048);
+#define AOCR_TAPH(S2, T) do { AOCR_TRH(fb[S2][T][0], bd, (((T0 + T) / 3) * PW + (T0 + T) % 3) * 64 + S2 * 1024); AOCR_TRH(fb[S2][T][1], bd, (((T0 + T) / 3) * PW + (T0 + T) % 3) * 64 + S2 * 1024 + 256); } while (0)
+      AOCR_TAPH(0, 0); AOCR_TAPH(0, 1); AOCR_TAPH(0, 2); AOCR_TAPH(0, 3); if constexpr (NTP == 5) AOCR_TAPH(0, NTP - 1);
+      AOCR_TRH(fa[1][0][0], a0, 8192); AOCR_TRH(fa[1][0][1], a0, 10240); AOCR_TRH(fa[1][1][0], a1, 8192); AOCR_TRH(fa[1][1][1], a1, 10240);
+      AOCR_TAPH(1, 0); AOCR_TAPH(1, 1); AOCR_TAPH(1, 2); AOCR_TAPH(1, 3); if constexpr (NTP == 5) AOCR_TAPH(1, NTP - 1);
+#undef AOCR_TAPH
+      issue();                                          // segment kt + 3 -> a slot last read three steps ago
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]), "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]) :: "memory");
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) asm volatile("" : "+v"(fb[s2][t][0]), "+v"(fb[s2][t][1]));
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int t = 0; t < NTP; ++t) {
+            const u64x2 av = {fa[s2][mi][0], fa[s2][mi][1]}, bv = {fb[s2][t][0], fb[s2][t][1]};
+            acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[mi][t], 0, 0, 0);
+          }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                    // every wave is out of the K loop: the ring is free
+    // ---- epilogue: the wave's 64 x (32 NTP) partial tile into its slab, 32 rows at a time through the wave's own 20 KB of LDS, as 16-byte stores of
+    // 128-byte runs (the 32 input channels of one tap of one output channel)
+    unsigned char* const wl = lds + wave * 20480;
+    constexpr int RP = NTP * 128;                       // bytes per staged row
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int t = 0; t < NTP; ++t)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float*>(wl + (8 * qq + 4 * h + i) * RP + (t * 32 + r) * 4) = acc[mi][t][4 * qq + i];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the wave reads back only what it wrote itself)
+      const int co0 = m_blk + mg * 64 + mi * 32;
+#pragma unroll 4
+      for (int it = 0; it < 4 * NTP; ++it) {            // 32 rows x 8 NTP float4
+        const int idx = it * 64 + lane, row = idx / (8 * NTP), c4 = idx - row * (8 * NTP), t = c4 >> 3, j = c4 & 7;
+        const float4 v = *reinterpret_cast<const float4*>(wl + row * RP + c4 * 16);
+        *reinterpret_cast<float4*>(slab + (int64_t)(co0 + row) * ldw + (int64_t)(T0 + t) * Cin + cchunk * 32 + j * 4) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
+  if (tg == 0) body(std::integral_constant<int, 0>{}); else body(std::integral_constant<int, 1>{});
+#undef AOCR_TRH
 }
 
 // Grouped form: up to 8 independent contractions of the same operand kinds in ONE launch (the hoisted weight gradients

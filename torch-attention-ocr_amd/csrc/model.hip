@@ -161,7 +161,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
   m->trie_loc[0] = a.get<int32_t>(R); m->trie_loc[1] = a.get<int32_t>(R);
   m->sgd_scratch = a.get<char>(sgd_scratch_bytes());
   // split-K slabs of the filter gradients (bf16 mode): one resident round of workgroups x one fp32 tile each = 64 MiB at most
-  m->wg_part_floats = m->bf16 ? (size_t)16 << 20 : 0; m->wg_part = m->wg_part_floats ? a.get<float>(m->wg_part_floats) : nullptr;
+  m->wg_part_floats = m->bf16 ? (size_t)20 << 20 : 0;      /* 80 MiB: eight k ranges of conv6's 512 x 4608 filter gradient (conv_wgrad_halo_kernel: 32 tiles x 8 = 256 workgroups) */ m->wg_part = m->wg_part_floats ? a.get<float>(m->wg_part_floats) : nullptr;
   if (m->bf16 && He % 64 == 0 && He <= 512) {                    // exchange buffers of the cluster encoder kernels
     // one set of group slots per layer: the layers of a stacked encoder run concurrently (layer wavefront, encoder_forward)
     m->cl_xbytes = m->Le * enc_cluster_xbuf_bytes((int)B, (int)He); m->cl_pbytes = m->Le * enc_cluster_pbuf_bytes((int)B, (int)He);

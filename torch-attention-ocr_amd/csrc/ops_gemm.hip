@@ -26,6 +26,7 @@ static const bf16_t* zero_page() {
   static const bf16_t* z = [] { void* p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_page)); return (const bf16_t*)p; }();
   return z;
 }
+static bool env_is_1(const char* name) { const char* e = getenv(name); return e && e[0] == '1'; }      // switches are read per call; "0" means off
 static bool dma_forced() { const char* e = getenv("AOCR_FORCE_DMA"); return e && e[0] == '1'; }     // read per call: tests toggle it
 static bool dma_disabled() { const char* e = getenv("AOCR_NO_DMA"); return e && e[0] == '1'; }       // tests: compare against the 128 x 128 kernels
 static bool dma_eligible(int M, int N, int K, int C) {
@@ -458,6 +459,24 @@ void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float*
     // 256 x 256 LDS-DMA kernel when Cout and N fill its tiles (measured on workload C3: conv4/5/6 249/239/427 -> 220/223/380 us;
     // conv7 (N = 2048) and conv3 (N = 1152) are no faster and stay on the 128 x 128 kernel)
     const int tiles = cdiv(N, 256) * (Cout / 256);
+    // halo-resident kernel (conv_wgrad_halo_kernel, round 4): N tiles of nine taps x 32 input channels, the input map's halo staged once per 32-pixel row
+    // segment -- 22.4 instead of 32 KB per K step through L2 -> LDS.  3 x 3 / pad 1 layers whose rows are whole 32-pixel segments; needs the slab scratch.
+    // Same-box, same harness (tools/ubench/wgrad_halo.hip) at the C3 shapes: conv4 193 -> 166 us, conv5 180 -> 151 us, conv6 327 -> 276 us.
+    // AOCR_NO_WGRAD_HALO=1: the one-tap-per-tile kernels below (the parity reference).
+    if (ks == 3 && pad == 1 && W % 32 == 0 && Cout % 256 == 0 && Cin % 32 == 0 && part && !dma_disabled() && !env_is_1("AOCR_NO_WGRAD_HALO") && !getenv("AOCR_WGRAD_ATOMIC") &&
+        (dma_forced() || (P >= 8192 && N >= 2304))) {
+      const int htiles = (Cin / 32) * (Cout / 256), S = B * H * (W / 32);
+      int ksh = htiles >= 256 ? 1 : 256 / htiles; if (ksh > S) ksh = S;                   // one round of the 256 CUs
+      const int per = cdiv(S, ksh); ksh = cdiv(S, per);
+      const size_t mn = (size_t)Cout * N;
+      if (mn * ksh <= part_floats) {
+        if (profile_tag) hipLaunchKernelGGL((conv_wgrad_halo_kernel<1>), dim3(htiles * ksh), dim3(512), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 256, ksh, per, zero_page());
+        else hipLaunchKernelGGL((conv_wgrad_halo_kernel<0>), dim3(htiles * ksh), dim3(512), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 256, ksh, per, zero_page());
+        splitk_reduce(s, part, ksh, mn, dw);
+        if (dbias) colsum_accum(s, dy, Cout, P, Cout, dbias);
+        return;
+      }
+    }
     if (Cout % 256 == 0 && Cin % 8 == 0 && !dma_disabled() && (dma_forced() || (P >= 8192 && tiles <= 256 && N % 256 == 0 && N >= 2304))) {
       int ks2 = tiles >= 128 ? (tiles >= 200 ? 1 : 2) : 256 / tiles, kper2; split_k(P, 32, ks2, kper2);      // one round of the 256 CUs
       const size_t mn = (size_t)Cout * N;
