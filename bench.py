@@ -458,15 +458,15 @@ def main():
         msw, kflw = m.profile_kernel(1, 20)
         achw = kflw / (msw * 1e-3) / 1e12
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "r03_wgrad_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r04_wgrad_pmc.json")
         if bf16 and args.workload == "c3" and world == 1 and args.scaling == "weak" and os.path.exists(pmc):
             traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
-            traffic_source = ("profiles/r03_wgrad_pmc.json: rocprofv3 --pmc passes of this command on the tagged conv6 filter-gradient launch "
+            traffic_source = ("profiles/r04_wgrad_pmc.json: rocprofv3 --pmc passes of this command on the tagged conv6 filter-gradient launch "
                               "(tools/pmc_traffic.py); PMC counters cannot be read from inside the timed process, so this field is NOT measured in this run")
         step_frac = 3 * fl["total"] * lines_per_s / 1e12 / (peak * world)
         wg_share = (families or {}).get("conv_wgrad", {}).get("ms_per_step", 0.0) / max(1e-9, (families or {}).get("_sum_ms", 1.0))
-        roof = {"bound": "mfma", "kernel": "conv6 filter gradient (512x4608 over 65536 pixels): conv_wgrad_dma_kernel + splitk_reduce -- the dominant "
-                                           "kernel family of the step by time",
+        roof = {"bound": "mfma", "kernel": "conv6 filter gradient (512x4608 over 65536 pixels): conv_wgrad_halo_kernel + splitk_reduce -- the largest launch of the "
+                                           "dominant kernel family of the step by time (the filter gradients)",
                 "achieved": achw, "peak": peak, "unit": "TFLOP/s", "frac": achw / peak, "traffic": traffic, "traffic_source": traffic_source,
                 "ms_per_launch": msw, "algorithmic_gflop_per_launch": kflw / 1e9, "family_share_of_step": wg_share,
                 "step_frac": step_frac, "step_frac_what": "SURVEY.md 8(d): train GFLOP per image x image-lines/s / bf16 MFMA peak over the WHOLE step (north-star target 0.40)"}

@@ -1,6 +1,6 @@
 """HBM-side traffic per launch of the two kernels bench.py's roofline fields name, from two rocprofv3 --pmc passes (FETCH_SIZE,
 WRITE_SIZE) of the bench command: the tagged launches of aocr_profile_kernel -- id 0 = conv6 forward (gemm_halo4_bf16_kernel<EpConv, 1, TAG 1>; under AOCR_HALO8=1 the 8-wave gemm_halo_bf16_kernel<..., 1>),
-id 1 = conv6 filter gradient (conv_wgrad_dma_kernel<EpStore, 256> + the splitk_reduce_kernel launch behind each of them).
+id 1 = conv6 filter gradient (round 4: conv_wgrad_halo_kernel<1>; round 3: conv_wgrad_dma_kernel<EpStore, 256>; + the splitk_reduce_kernel launch behind each of them).
 Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KB; FETCH_SIZE reports
 exactly half the bytes of a wide (16 B/lane) coalesced read stream -> doubled.  Writes JSON next to the text summary when asked:
     python tools/pmc_traffic.py fetch.csv write.csv [out_dir]"""
@@ -10,7 +10,7 @@ import os
 import sys
 
 FWD = "gemm_halo4_bf16_kernel<aocr::EpConv, 1, 1>"
-WG = "conv_wgrad_dma_kernel<aocr::EpStore, 256>"
+WG = "conv_wgrad_halo_kernel<1>"          # round 4 (round 3: "conv_wgrad_dma_kernel<aocr::EpStore, 256>")
 RED = "splitk_reduce_kernel"
 
 
@@ -53,11 +53,11 @@ def main():
                    "fetch_bytes_corrected_x2": fb, "write_bytes": wb, "traffic_bytes_per_launch": fb + wb,
                    "algorithmic_bytes_per_launch": {"read_A5_bf16": 67108864, "read_w_bf16": 4718592, "write_idx_u8": 16777216, "write_A6_bf16": 33554432},
                    "note": note}, open(os.path.join(out_dir, "conv6_fwd_pmc.json"), "w"), indent=1)
-        json.dump({"kernel": WG + " + splitk_reduce_kernel (conv6 filter gradient, C3 shape: 512 x 4608 over 65536 pixels, split-K 7 over 252 workgroups)",
+        json.dump({"kernel": WG + " + splitk_reduce_kernel (conv6 filter gradient, C3 shape: 512 x 4608 over 65536 pixels, split-K 8 over 256 workgroups of 256 x 288)",
                    "command": cmd, "kernel_fetch_bytes_corrected_x2": gfb, "kernel_write_bytes": gwb, "reduce_fetch_bytes_corrected_x2": rfb,
                    "reduce_write_bytes": rwb, "traffic_bytes_per_launch": gfb + gwb + rfb + rwb,
                    "algorithmic_bytes_per_launch": {"read_A5_bf16": 67108864, "read_dY6_bf16": 67108864, "write_dW_f32": 9437184},
-                   "split_k_bytes": {"slab_writes_f32": 7 * 9437184, "slab_reads_f32": 7 * 9437184, "dW_read_modify_write": 2 * 9437184},
+                   "split_k_bytes": {"slab_writes_f32": 8 * 9437184, "slab_reads_f32": 8 * 9437184, "dW_read_modify_write": 2 * 9437184},
                    "note": note + ".  The split-K partial tiles (7 k-ranges x 9.4 MB) are written once as plain stores and read once by the slab sum; "
                                   "in round 2 they were 66 MB of fp32 atomics executed at the memory side"},
                   open(os.path.join(out_dir, "wgrad_pmc.json"), "w"), indent=1)

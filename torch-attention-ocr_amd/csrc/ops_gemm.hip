@@ -27,6 +27,7 @@ static const bf16_t* zero_page() {
   return z;
 }
 static bool env_is_1(const char* name) { const char* e = getenv(name); return e && e[0] == '1'; }      // switches are read per call; "0" means off
+static int wgrad_halo_min_n() { const char* e = getenv("AOCR_WGRAD_HALO_MINN"); return e ? atoi(e) : 1152; }      // smallest N = 9 Cin that takes conv_wgrad_halo_kernel: conv3 (128 -> 256) upwards; A/B at C3: 2304 -> 1152 = 5.505 -> 5.455 ms per step (AOCR_WGRAD_HALO_MINN)
 static bool dma_forced() { const char* e = getenv("AOCR_FORCE_DMA"); return e && e[0] == '1'; }     // read per call: tests toggle it
 static bool dma_disabled() { const char* e = getenv("AOCR_NO_DMA"); return e && e[0] == '1'; }       // tests: compare against the 128 x 128 kernels
 static bool dma_eligible(int M, int N, int K, int C) {
@@ -464,7 +465,7 @@ void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float*
     // Same-box, same harness (tools/ubench/wgrad_halo.hip) at the C3 shapes: conv4 193 -> 166 us, conv5 180 -> 151 us, conv6 327 -> 276 us.
     // AOCR_NO_WGRAD_HALO=1: the one-tap-per-tile kernels below (the parity reference).
     if (ks == 3 && pad == 1 && W % 32 == 0 && Cout % 256 == 0 && Cin % 32 == 0 && part && !dma_disabled() && !env_is_1("AOCR_NO_WGRAD_HALO") && !getenv("AOCR_WGRAD_ATOMIC") &&
-        (dma_forced() || (P >= 8192 && N >= 2304))) {
+        (dma_forced() || (P >= 8192 && N >= wgrad_halo_min_n()))) {
       const int htiles = (Cin / 32) * (Cout / 256), S = B * H * (W / 32);
       int ksh = htiles >= 256 ? 1 : 256 / htiles; if (ksh > S) ksh = S;                   // one round of the 256 CUs
       const int per = cdiv(S, ksh); ksh = cdiv(S, per);
