@@ -1054,3 +1054,28 @@ def test_halo_wgrad_kernel_matches_tap_tiled_kernel(cuda, monkeypatch, B, W):
         if e > worst[1]: worst = (k, e)
         assert e < (2e-5 if k.startswith("cnn.conv") and k.endswith(".w") else 1e-6), (k, e)
     print(f"[parity] halo-resident filter gradient vs tap-tiled kernels, B={B} W={W}: worst relative difference {worst[1]:.2e} ({worst[0]})")
+
+
+def test_encoder_dx_single_product_matches_two_products(cuda, monkeypatch):
+    """Round 4: the encoder's input gradient d X = d z_fw W_i2h_fw + d z_bw W_i2h_bw (model.lua:675 copy, :689 add) as ONE product over the
+    concatenated K range (gemm_hh_cat, LoadKhCat) against the two products it replaces (AOCR_NO_HH_CAT=1: the second adds to the first's
+    output).  Same bf16 operands; only the fp32 summation order differs (one accumulator over 2 x 4He instead of two rounded sums), so
+    d(feats) agrees to accumulation noise, and everything upstream of it (forward pass, decoder / encoder recurrent gradients) is
+    bit-identical.  B = 256, W = 204 (T = 50): the smallest C3-like shape whose B T x 512 product fills the narrow LDS-DMA kernel's grid."""
+    cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for off in ("1", "0"):
+        monkeypatch.setenv("AOCR_NO_HH_CAT", off)
+        m, O, ocfg, P, st, batch = make(cfg, B=256, W=204, maxlen=6, compute="bf16", max_decoder_l=8, max_beam=1)
+        loss = m.train_forward_backward(batch)
+        out[off] = dict(loss=loss, dfeats=m.get_tensor("dfeats").clone(), dctx=m.get_tensor("dcontext").clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.shutdown()
+    a, b = out["1"], out["0"]
+    assert a["loss"] == b["loss"] and torch.equal(a["dctx"], b["dctx"])
+    e = relerr(b["dfeats"], a["dfeats"])
+    print(f"[parity] d X as one product over [d z_fw | d z_bw]: d(feats) relative difference {e:.2e} against the two-product form")
+    assert 0 < e < 1e-5                                      # (> 0: the single-product path really ran)
+    for k in ("enc_fw.l1.i2h.w", "enc_bw.l1.h2h.w", "dec.attn.wa"):
+        assert relerr(b["grads"][k], a["grads"][k]) < 1e-5, k
+    for k in ("cnn.conv7.w", "cnn.conv6.w", "cnn.conv2.w"):
+        assert cosine(b["grads"][k], a["grads"][k]) > 0.9999, k

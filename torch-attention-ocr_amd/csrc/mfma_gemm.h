@@ -359,6 +359,24 @@ struct LoadKh {
     return dma_select(d.b != nullptr && u.k < K, d.b + u.k, zero);
   }
 };
+// K-contiguous bf16 whose K range is the CONCATENATION of two buffers with the same rows (LDS-DMA staging only): element(r, k) = k < K0 ? p0[r ld0 + k] :
+// p1[r ld1 + k - K0], K0 % 32 == 0 (a 32-k tile never straddles).  One product over [d z_fw | d z_bw] x [W_fw ; W_bw] instead of two launches whose
+// second re-reads and adds to the first's output (encoder_backward: d X = d z_fw W_i2h_fw + d z_bw W_i2h_bw, model.lua:675,689).
+struct LoadKhCat {
+  const bf16_t* p0; const bf16_t* p1; int64_t ld0, ld1; int rows; int K0, K;
+  struct DRow { const bf16_t* b0; const bf16_t* b1; };
+  struct DCur { int k; };
+  __device__ __forceinline__ DRow drow(int r, int chunk) const {
+    DRow d; const bool ok = r < rows;
+    d.b0 = ok ? p0 + (int64_t)r * ld0 + 8 * chunk : nullptr; d.b1 = ok ? p1 + (int64_t)r * ld1 + 8 * chunk : nullptr; return d;
+  }
+  __device__ __forceinline__ DCur dseek(int k) const { DCur c; c.k = k; return c; }
+  __device__ __forceinline__ void dadvance(DCur& c) const { c.k += 32; }
+  __device__ __forceinline__ const bf16_t* dsrc(const DRow& d, const DCur& u, const bf16_t* zero) const {
+    const bf16_t* b = u.k >= K0 ? d.b1 + (u.k - K0) : d.b0 + u.k;           // (u.k is wave-uniform)
+    return dma_select(d.b0 != nullptr && u.k < K, b, zero);
+  }
+};
 // implicit im2col over a bf16 channels-last tensor (same geometry as LoadConvK); cursor = (kh, kw, first channel) of the tile
 struct LoadConvKh {
   const bf16_t* src; LoadConvK g;          // g.src unused

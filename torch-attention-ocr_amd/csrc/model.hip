@@ -770,6 +770,11 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
     }
     prof_mark(m, AOCR_PROF_RNN_GEMM);
     WGradProblem wg[4]; int nwg = 0;
+    // layer 0: d X = d z_fw W_i2h_fw + d z_bw W_i2h_bw (model.lua:675 copy, :689 add) as ONE product over K = 2 x 4He (round 4: one launch instead of two,
+    // the second of which re-read the first's 33 MB output to add to it)
+    bool dx_cat = false;
+    if (l == 0 && bf && !m->drop_on && m->edz_b[0][0] && m->edz_b[1][0] && m->enc[0][0].swi.wtb && m->enc[1][0].swi.wtb)
+      dx_cat = gemm_hh_cat(s, m->edz_b[0][0], m->edz_b[1][0], 4 * He, m->enc[0][0].swi.wtb, m->enc[1][0].swi.wtb, 4 * He, m->dX, m->enc[0][0].in, T * B, m->enc[0][0].in, 4 * He, 4 * He);
     for (int dir = 0; dir < 2; ++dir) {
       const LstmP& p = m->enc[dir][l];
       const float* xin = l == 0 ? m->X : m->ehs[dir][l - 1] + slot;
@@ -784,7 +789,8 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       if (!cluster) colsum_accum(s, dz, 4 * He, (int64_t)T * B, 4 * He, p.dbi, p.dbh);        // both biases see the same d z (LSTM.lua:79-88); the cluster kernel sums them itself
       float* dxo = l == 0 ? m->dX : m->edxl[dir];
       const int dxf = (l == 0 && dir == 1) ? EP_ACCUM : 0;                          // model.lua:675 copy, :689 add
-      if (bf && dzb && p.swi.wtb) gemm_hh(s, dzb, 4 * He, p.swi.wtb, 4 * He, dxo, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dxf);
+      if (dx_cat) { /* done above */ }
+      else if (bf && dzb && p.swi.wtb) gemm_hh(s, dzb, 4 * He, p.swi.wtb, 4 * He, dxo, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dxf);
       else if (p.swi.wtf) gemm(s, bf, dz, 4 * He, true, p.swi.wtf, 4 * He, true, dxo, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dxf);
       else gemm(s, bf, dz, 4 * He, true, p.wi, p.in, false, dxo, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dxf);
       if (l > 0 && m->drop_on) dropout_apply(s, dxo, dxo, nullptr, (int64_t)T * B * He, drop_site(m, (dir ? 48 : 32) + l + 1, 0));     // Dropout backward

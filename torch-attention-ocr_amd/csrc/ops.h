@@ -88,6 +88,7 @@ void grouped_wgrad(hipStream_t s, bool bf16, const WGradProblem* p, int n);
 void kprobe_read(unsigned long long out[8]);   // debugging probe of the tagged halo kernels (mfma_gemm.h: g_kprobe)
 
 // C = A B^T (+bias) with both operands read from K-contiguous bf16 shadows (A [M][K], B [N][K])
+bool gemm_hh_cat(hipStream_t s, const bf16_t* A0, const bf16_t* A1, int64_t lda, const bf16_t* B0, const bf16_t* B1, int64_t ldb, float* C, int64_t ldc, int M, int N, int K0, int K1);   // C = [A0 | A1] . [B0 | B1]^T, one launch; false: shape not taken
 void gemm_hh(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
              const float* bias, const float* bias2, int flags);
 // the same with a bf16 copy of C written beside it (plain stores)

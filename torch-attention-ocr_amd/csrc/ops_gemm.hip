@@ -324,6 +324,16 @@ void gemm_hh(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64
   launch_lds(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K, 1);
 }
 
+// C = [A0 | A1] . [B0 | B1]^T  (K = K0 + K1 over two buffer pairs; bf16, K-contiguous), one launch of the narrow LDS-DMA kernel.  Returns false when the
+// shape does not take that kernel (the caller then runs two products).
+bool gemm_hh_cat(hipStream_t s, const bf16_t* A0, const bf16_t* A1, int64_t lda, const bf16_t* B0, const bf16_t* B1, int64_t ldb, float* C, int64_t ldc, int M, int N, int K0, int K1) {
+  if (getenv("AOCR_NO_HH_NARROW") || env_is_1("AOCR_NO_HH_CAT") || dma_disabled() || M % 256 || N % 128 || K0 % 32 || K1 % 32 || (M / 256) * (N / 128) < 200) return false;
+  LoadKhCat a; a.p0 = A0; a.p1 = A1; a.ld0 = a.ld1 = lda; a.rows = M; a.K0 = K0; a.K = K0 + K1;
+  LoadKhCat b; b.p0 = B0; b.p1 = B1; b.ld0 = b.ld1 = ldb; b.rows = N; b.K0 = K0; b.K = K0 + K1;
+  launch_dma_narrow(s, a, b, make_store(C, ldc, M, N, nullptr, nullptr, 0), M, N, K0 + K1);
+  return true;
+}
+
 void gemm_hh_shadow(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, bf16_t* Cb, int64_t ldcb,
                     int M, int N, int K) {
   LoadKh a; a.p = A; a.ld = lda; a.rows = M; a.K = K;
