@@ -430,6 +430,11 @@ int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_p
   const int64_t n5 = (int64_t)B * d.H4 * d.W2;              // pixels of the conv5 / conv6 maps (512 channels)
   constexpr size_t SLAB = (size_t)4 << 20;
   double bytes = 0.0;
+  // bf16 data-gradient maps (conv_backward_data's dx16, round 4): what the step's BatchNorm backward / un-pool passes read when the switch is on
+  const char* const nd = getenv("AOCR_DX16");
+  const bool dx16 = (nd && nd[0] == '1') && !getenv("AOCR_BN_PARTIAL_OLD") && !getenv("AOCR_UNPOOL4") && !getenv("AOCR_HALO8") && B * d.H4 * d.W2 % 256 == 0;
+  const bf16_t* const g1h = dx16 ? reinterpret_cast<const bf16_t*>(m->G1) : nullptr;
+  const double dab = dx16 ? 2.0 : 4.0;                    // bytes per element of d A / d(pooled)
   // ids >= 2: the bandwidth-bound kernels, each replayed on the buffers the last TRAINING step left, with the arguments cnn_forward /
   // cnn_backward / decoder_backward pass (bf16 mode).  Outputs land where the step puts them (activations, gradient maps, gradient
   // vector): the model's taps and gradients are UNDEFINED afterwards until the next step.  flops_per_launch returns ALGORITHMIC BYTES.
@@ -457,12 +462,12 @@ int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_p
       break;
     case AOCR_PK_BN_BWD:                                    // conv5's BatchNorm backward: sums pass (x fp32, d A fp32, mask bf16) + apply pass (the same + bf16 d x out)
       bn_relu_backward(s, m->Y5, m->A5, m->G1, m->bn[5].w, m->bn[5].save, nullptr, m->bn[5].dw, m->bn[5].db, m->bn_scratch, n5, 512, 0, m->G0b, m->A5b,
-                       m->conv[5].db, m->G0 + 2 * SLAB, nullptr, nullptr);
-      bytes = (double)n5 * 512 * ((4 + 4 + 2) + (4 + 4 + 2 + 2));
+                       m->conv[5].db, m->G0 + 2 * SLAB, nullptr, nullptr, nullptr, g1h);
+      bytes = (double)n5 * 512 * ((4 + dab + 2) + (4 + dab + 2 + 2));
       break;
     case AOCR_PK_UNPOOL:                                    // (2,1) un-pool + ReLU backward of conv6: d(pooled) fp32 + arg-max (1 B) + pooled mask (bf16) in, bf16 gradient of the un-pooled map out
-      unpool_relu_backward(s, m->G1, m->A6, m->idx6, nullptr, B, d.H4, d.W2, 512, 2, m->G0b, m->conv[6].db, m->G0 + 1 * SLAB, m->A6b, nullptr);
-      bytes = (double)B * d.H6 * d.W2 * 512 * (4 + 1 + 2) + (double)n5 * 512 * 2;
+      unpool_relu_backward(s, m->G1, m->A6, m->idx6, nullptr, B, d.H4, d.W2, 512, 2, m->G0b, m->conv[6].db, m->G0 + 1 * SLAB, m->A6b, nullptr, g1h);
+      bytes = (double)B * d.H6 * d.W2 * 512 * (dab + 1 + 2) + (double)n5 * 512 * 2;
       break;
     case AOCR_PK_ATTN_DCTX:                                 // d(context) of all L steps in one pass (model.lua:652-653): a, d s (L,B,T), d c, q (L,B,Hd) in; (B,T,Hd) fp32 out
       attention_dctx(s, m->a_all, m->ds_all, m->dcat_all, 2 * m->Hd, m->q_all, m->dctx, d.L, B, d.T, m->Hd);

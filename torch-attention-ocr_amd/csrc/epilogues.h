@@ -132,7 +132,7 @@ __device__ __forceinline__ bool narrow_store_staged(const EPT& ep, const f32x16 
       const int idx = it * 512 + tid, row = idx / (BN / 4), c = idx % (BN / 4);
       if (row_base + row < ep.M) {
         const float4 v = *reinterpret_cast<const float4*>(lds + row * PITCH + c * 16);
-        *reinterpret_cast<float4*>(ep.C + (int64_t)(row_base + row) * ep.ldc + n_blk + c * 4) = v;
+        if (ep.C) *reinterpret_cast<float4*>(ep.C + (int64_t)(row_base + row) * ep.ldc + n_blk + c * 4) = v;      // (C == nullptr: only the bf16 shadow is wanted -- gemm_hh_shadow)
         if (ep.Cb) {
           typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
           bf16x4_ o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;

@@ -1005,6 +1005,8 @@ __device__ __forceinline__ bool tile256_store_staged(const EP& ep, const f32x16 
     if (ep.pmode == 0 && ep.y && !ep.yb && (opt & 2)) { tile256_store_f32<NI, NTH>(ep.y, ep.Cout, ep.bias, ep.relu != 0, acc, lds, m_blk, n_blk, wm, wn, r, h, tid, ep.bn_part, ep.Cout); return true; }
     return false;
   } else if constexpr (std::is_same<EP, EpStore>::value) {
+    if (!ep.C && ep.Cb && !ep.flags && !ep.bias && !ep.bias2 && !ep.C1 && !ep.dg) {       // bf16-only data gradient (conv_backward_data's dx16: full tiles guaranteed by the caller)
+      tile256_store_bf16<NI, NTH>(ep.Cb, (int)ep.ldcb, nullptr, false, nullptr, nullptr, nullptr, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
     if (ep.flags || ep.bias || ep.bias2 || ep.C1 || ep.Cb || ep.dg || !(opt & 1) || m_blk + 256 > ep.M || n_blk + 256 > ep.N) return false;
     tile256_store_f32<NI, NTH>(ep.C, ep.ldc, nullptr, false, acc, lds, m_blk, n_blk, wm, wn, r, h, tid);      // (taking the biases here too cost the data-gradient kernel 157 -> 190 us: register pressure in its K loop)
     return true;

@@ -110,7 +110,8 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
 void bn_eval_prepare(hipStream_t s, const float* rm, const float* rv, float* save, int C);
 // profile_tag != 0: the same kernel under a distinct symbol (aocr_profile_kernel), so profilers list these launches separately
 void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* w, float* dx, int B, int H, int W, int Cin,
-                        int Cout, int ks, int pad, const bf16_t* dyb = nullptr, const bf16_t* wtb = nullptr, const float* wtf = nullptr);
+                        int Cout, int ks, int pad, const bf16_t* dyb = nullptr, const bf16_t* wtb = nullptr, const float* wtf = nullptr,
+                        int* dx16 = nullptr /* the caller accepts dx written as bf16 into the first half of the same buffer; *dx16 = 1 when that happened */);
 void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float* dy, float* dw, float* dbias, int B, int H,
                           int W, int Cin, int Cout, int ks, int pad, const bf16_t* xb = nullptr, const bf16_t* dyb = nullptr,
                           float* part = nullptr, size_t part_floats = 0, int profile_tag = 0);   // part: scratch for the split-K slabs (else fp32 atomics)
@@ -125,7 +126,8 @@ void conv1_backward(hipStream_t s, const float* x, const float* w, const float* 
                     int B, int H, int W, float* scratch = nullptr, ColsumJobs* defer = nullptr);
 void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pooled, const uint8_t* idx, float* dy, int B,
                           int Ho, int Wo, int C, int pool, bf16_t* dyb = nullptr, float* dbias = nullptr,
-                          float* partial = nullptr, const bf16_t* pooledb = nullptr, ColsumJobs* defer = nullptr);
+                          float* partial = nullptr, const bf16_t* pooledb = nullptr, ColsumJobs* defer = nullptr,
+                          const bf16_t* dpooled16 = nullptr /* d(pooled) as bf16 instead of fp32 (bf16-mode 8-channel kernel only: conv_backward_data's dx16) */);
 // defer: the column sum that finishes a partial slab is queued (colsum_flush) instead of launched -- the slab must then stay untouched until the flush
 // dbias + partial (>= 2048*C floats scratch): fused bias gradient, dy may then be null; pooledb: bf16 shadow of pooled (mask source)
 void bf16_to_f32(hipStream_t s, const bf16_t* src, float* dst, int64_t n);
@@ -139,7 +141,8 @@ void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, co
 void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
                       float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb = nullptr,
                       const bf16_t* yb = nullptr, float* conv_dbias = nullptr, float* partial = nullptr, const BnSync* sync = nullptr,
-                      ColsumJobs* defer = nullptr, const bf16_t* xh = nullptr /* x as bf16 */);
+                      ColsumJobs* defer = nullptr, const bf16_t* xh = nullptr /* x as bf16 */,
+                      const bf16_t* dAh = nullptr /* d A as bf16 instead of fp32 (bn_partial4 path only) */);
 // yb: bf16 shadow of y (ReLU mask source); conv_dbias + partial (>= 4096*256 floats): fused bias gradient of the preceding conv, dx may then be null
 // ctx_div: rows r share context row r / ctx_div (beam search keeps one context per image, model.lua:373)
 void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a, float* c, int64_t ldc, int B, int T, int Hd,

@@ -339,7 +339,10 @@ void gemm_hh_shadow(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B
   LoadKh a; a.p = A; a.ld = lda; a.rows = M; a.K = K;
   LoadKh b; b.p = B; b.ld = ldb; b.rows = N; b.K = K;
   EpStore e = make_store(C, ldc, M, N, nullptr, nullptr, 0); e.Cb = Cb; e.ldcb = ldcb;
-  if (!getenv("AOCR_NO_HH_NARROW") && !dma_disabled() && M % 256 == 0 && N % 128 == 0 && K % 32 == 0 && (M / 256) * (N / 128) >= 200) { launch_dma_narrow(s, a, b, e, M, N, K); return; }
+  if (!getenv("AOCR_NO_HH_NARROW") && !dma_disabled() && M % 256 == 0 && N % 128 == 0 && K % 32 == 0 && (M / 256) * (N / 128) >= 200) {
+    if (!env_is_1("AOCR_NO_NARROW_STAGED")) e.C = nullptr;      // every reader takes the bf16 copy (ctx W_a of the decoder kernels): the staged tile skips the fp32 store (33 MB per C3 step)
+    launch_dma_narrow(s, a, b, e, M, N, K); return;
+  }
   if (dma128_eligible(M, N, K, 32)) { launch_dma128(s, a, b, e, M, N, K); return; }
   launch_lds(s, a, b, e, M, N, K, 1);
 }
@@ -437,13 +440,25 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
 }
 
 void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* w, float* dx, int B, int H, int W, int Cin,
-                        int Cout, int ks, int pad, const bf16_t* dyb, const bf16_t* wtb, const float* wtf) {
+                        int Cout, int ks, int pad, const bf16_t* dyb, const bf16_t* wtb, const float* wtf, int* dx16) {
   const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
   LoadConvK a = make_convk(dy, B, Ho, Wo, Cout, ks, -1, pad, H, W, 0);
   EpStore ep = make_store(dx, Cin, a.rows, Cin);
+  if (dx16) *dx16 = 0;
   if (bf16 && dyb && wtb) {
     LoadConvKh ah; ah.src = dyb; ah.g = a;
     LoadKh bh; bh.p = wtb; bh.ld = a.K; bh.rows = Cin; bh.K = a.K;          // wtb [Cin][tap][Cout]: K-contiguous over (tap, co)
+    // Round 4: the data gradient as bf16 INTO THE SAME BUFFER (half of it) when the caller accepts that (dx16) -- its only readers are the BatchNorm backward /
+    // un-pool passes, which round their own output to bf16 for the next contraction anyway, and the map is 2 of the 10-12 bytes per element those
+    // HBM-bound passes move.  Only where the staged 256 x 256 tile exists (4-wave halo kernel / gemm_dma_bf16_kernel, full tiles).
+    // OPT-IN (AOCR_DX16=1), not the default -- measured at C3: 5.463 -> 5.407 ms per step (BatchNorm 0.50 -> 0.48, data gradients 0.79 -> 0.77), but it is one more
+    // rounding than "bf16 contraction operands", the model the parity tests hold the product to: with the GPU's decisions imposed on the bf16-operand oracle the
+    // lowest gradient cosine falls from 0.99998 to 0.99983 (conv2.b; tests/test_configs_gpu.py requires 0.9999).  Parity first -- as for AOCR_BN_Y16.
+    if (dx16 && dma_eligible(a.rows, Cin, a.K, Cout) && a.rows % 256 == 0 && Cin % 256 == 0 && env_is_1("AOCR_DX16") && !getenv("AOCR_BN_PARTIAL_OLD") && !getenv("AOCR_UNPOOL4")) {   // (the generic forms of the two reader kernels take fp32 only)
+      const char* const so = getenv("AOCR_HALO4_STAGED");
+      const bool halo = pad == 1 && halo_eligible(a, Cin, 256, 256);
+      if (((so ? atoi(so) : 7) & 1) && !(halo && getenv("AOCR_HALO8"))) { ep.C = nullptr; ep.Cb = reinterpret_cast<bf16_t*>(dx); ep.ldcb = Cin; *dx16 = 1; }
+    }
     if (dma_eligible(a.rows, Cin, a.K, Cout) && pad == 1 && halo_eligible(a, Cin, 256, 256)) launch_halo<-1, 256, 256>(s, ah, bh, ep, a.rows, Cin);
     else if (dma_eligible(a.rows, Cin, a.K, Cout)) launch_dma(s, ah, bh, ep, a.rows, Cin, a.K);
     else if (dma_narrow_eligible(a.rows, Cin, a.K, Cout)) launch_dma_narrow(s, ah, bh, ep, a.rows, Cin, a.K);

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void unpool_kernel(const float* __restrict__ d
 // the bf16-mode form (shadow only + bias partials) with EIGHT channels per thread: 16-byte bf16 stores and loads, two 16-byte gradient loads
 // (the 4-channel form moves 8-byte pieces: 3.4 TB/s on the 126 MB of conv6's pass)
 __global__ __launch_bounds__(256) void unpool8_kernel(const float* __restrict__ dp, const uint8_t* __restrict__ idx, bf16_t* __restrict__ dyb, float* __restrict__ dbias,
-                                                      int B, int Ho, int Wo, int C, int pool, int Hp, int Wp, const bf16_t* __restrict__ pooledb) {
+                                                      int B, int Ho, int Wo, int C, int pool, int Hp, int Wp, const bf16_t* __restrict__ pooledb, const bf16_t* __restrict__ dph = nullptr /* d(pooled) as bf16 */) {
   const int C8 = C >> 3;
   const int64_t total = (int64_t)B * Hp * Wp * C8;
   float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // the grid stride is a multiple of C8: a thread keeps its eight channels
@@ -458,10 +458,14 @@ __global__ __launch_bounds__(256) void unpool8_kernel(const float* __restrict__ 
     const int c8 = (int)(id % C8); const int64_t win = id / C8;
     const int px = (int)(win % Wp); const int64_t t = win / Wp; const int py = (int)(t % Hp), b = (int)(t / Hp);
     const int64_t wo = win * C + c8 * 8;
-    const float4 g0 = *reinterpret_cast<const float4*>(dp + wo), g1 = *reinterpret_cast<const float4*>(dp + wo + 4);
+    float g[8];
+    if (dph) { const bf16x8 gh = *reinterpret_cast<const bf16x8*>(dph + wo);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[k] = (float)gh[k]; }
+    else { const float4 g0 = *reinterpret_cast<const float4*>(dp + wo), g1 = *reinterpret_cast<const float4*>(dp + wo + 4);
+      g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w; }
     const bf16x8 pv = *reinterpret_cast<const bf16x8*>(pooledb + wo);
     const uint2 ii = *reinterpret_cast<const uint2*>(idx + wo);
-    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
     float gv[8]; int iv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(256) void unpool8_kernel(const float* __restrict__ 
   }
 }
 void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pooled, const uint8_t* idx, float* dy, int B, int Ho,
-                          int Wo, int C, int pool, bf16_t* dyb, float* dbias, float* partial, const bf16_t* pooledb, ColsumJobs* defer) {
+                          int Wo, int C, int pool, bf16_t* dyb, float* dbias, float* partial, const bf16_t* pooledb, ColsumJobs* defer, const bf16_t* dpooled16) {
   int Hp = Ho / 2, Wp = pool == 1 ? Wo / 2 : Wo;
   if ((Ho & 1) || (pool == 1 && (Wo & 1))) {                                      // floor-mode leftovers
     if (dy) hipMemsetAsync(dy, 0, (size_t)B * Ho * Wo * C * sizeof(float), s);
@@ -504,7 +508,7 @@ void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pool
     int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);             // grid stride 2048*256 is a multiple of every C4 | 256
     if (!dy && pooledb && C % 8 == 0 && 256 % (C / 8) == 0 && !getenv("AOCR_UNPOOL4")) {
       const int64_t total8 = total / 2; const int blocks8 = (int)std::min<int64_t>((total8 + 255) / 256, 2048);
-      hipLaunchKernelGGL(unpool8_kernel, dim3(blocks8), dim3(256), 0, s, dpooled, idx, dyb, partial, B, Ho, Wo, C, pool, Hp, Wp, pooledb);
+      hipLaunchKernelGGL(unpool8_kernel, dim3(blocks8), dim3(256), 0, s, dpooled, idx, dyb, partial, B, Ho, Wo, C, pool, Hp, Wp, pooledb, dpooled16);
       if (defer) colsum_defer(*defer, partial, C, blocks8, C, dbias); else colsum_accum(s, partial, C, blocks8, C, dbias);
       return;
     }
@@ -580,7 +584,8 @@ template <int MODE>
 __global__ __launch_bounds__(1024) void bn_partial4_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dA, const float* __restrict__ save,
                                                            double* __restrict__ part, int64_t rows, int C, int tb_rows, int T,
-                                                           const bf16_t* __restrict__ yb, const bf16_t* __restrict__ xh = nullptr) {
+                                                           const bf16_t* __restrict__ yb, const bf16_t* __restrict__ xh = nullptr,
+                                                           const bf16_t* __restrict__ dAh = nullptr /* d A as bf16 (conv_backward_data wrote it so: round 4) */) {
   __shared__ double sh[1024];
   const int C4 = C >> 2, q = threadIdx.x & (C4 - 1), rl = threadIdx.x / C4, RP = 1024 / C4, c = q * 4;
   const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
@@ -613,7 +618,7 @@ __global__ __launch_bounds__(1024) void bn_partial4_kernel(const float* __restri
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       xv[u] = bn_ldx4(x, xh, (r + u * RP) * C + c);
-      if (MODE == 1) { const int64_t ro = orow(r + u * RP); dv[u] = *reinterpret_cast<const float4*>(dA + ro * C + c); loady(ro, yy[u]); }
+      if (MODE == 1) { const int64_t ro = orow(r + u * RP); dv[u] = bn_ldx4(dA, dAh, ro * C + c); loady(ro, yy[u]); }
       else dv[u] = xv[u];
     }
 #pragma unroll
@@ -621,7 +626,7 @@ __global__ __launch_bounds__(1024) void bn_partial4_kernel(const float* __restri
   }
   for (; r < r1; r += RP) {
     const float4 xv = bn_ldx4(x, xh, r * C + c); float4 dv = xv; float yy[4] = {0.f, 0.f, 0.f, 0.f};
-    if (MODE == 1) { const int64_t ro = orow(r); dv = *reinterpret_cast<const float4*>(dA + ro * C + c); loady(ro, yy); }
+    if (MODE == 1) { const int64_t ro = orow(r); dv = bn_ldx4(dA, dAh, ro * C + c); loady(ro, yy); }
     accum(xv, dv, yy);
   }
 #pragma unroll
@@ -747,7 +752,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ save, const double* __restrict__ fin,
                                                            float* __restrict__ dx, int64_t rows, int C, int tb_rows, int T,
                                                            bf16_t* __restrict__ dxb, const bf16_t* __restrict__ yb,
-                                                           float* __restrict__ partial, const bf16_t* __restrict__ xh = nullptr) {
+                                                           float* __restrict__ partial, const bf16_t* __restrict__ xh = nullptr, const bf16_t* __restrict__ dAh = nullptr) {
   const int C4 = C >> 2;                                // one channel quad per thread and iteration (16-byte accesses)
   const int64_t total = rows * C4;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -763,7 +768,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     float yy[4];
     if (yb) { bf16x4 t4 = *reinterpret_cast<const bf16x4*>(yb + ro * C + c); yy[0] = (float)t4[0]; yy[1] = (float)t4[1]; yy[2] = (float)t4[2]; yy[3] = (float)t4[3]; }
     else { float4 t4 = *reinterpret_cast<const float4*>(y + ro * C + c); yy[0] = t4.x; yy[1] = t4.y; yy[2] = t4.z; yy[3] = t4.w; }
-    const float4 da4 = *reinterpret_cast<const float4*>(dA + ro * C + c);
+    const float4 da4 = bn_ldx4(dA, dAh, ro * C + c);
     const float4 x4 = bn_ldx4(x, xh, r * C + c);
     const float da[4] = {da4.x, da4.y, da4.z, da4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
     float gx[4];
@@ -810,12 +815,12 @@ void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, co
 }
 void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
                       float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb,
-                      const bf16_t* yb, float* conv_dbias, float* partial, const BnSync* sync, ColsumJobs* defer, const bf16_t* xh) {
+                      const bf16_t* yb, float* conv_dbias, float* partial, const BnSync* sync, ColsumJobs* defer, const bf16_t* xh, const bf16_t* dAh) {
   int T = tb_rows > 0 ? (int)(rows / tb_rows) : 0;
   double* part = (double*)scratch;
   double* fin = part + (size_t)BN_CHUNKS * C * 2;
   int nchunk = (int)std::min<int64_t>(BN_CHUNKS, (rows + 63) / 64);
-  if (bn_partial4_ok(C)) hipLaunchKernelGGL(bn_partial4_kernel<1>, dim3(nchunk), dim3(1024), 0, s, x, y, dA, save, part, rows, C, tb_rows, T, yb, xh);
+  if (bn_partial4_ok(C)) hipLaunchKernelGGL(bn_partial4_kernel<1>, dim3(nchunk), dim3(1024), 0, s, x, y, dA, save, part, rows, C, tb_rows, T, yb, xh, dAh);
   else hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, x, y, dA, save, part, rows, C, 1, tb_rows, T, yb);
   if (sync) {                                             // mean(dy), mean(dy * xhat) over the GLOBAL batch
     hipLaunchKernelGGL(bn_sums_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, part, nchunk, rows, C, fin, dw, db);
@@ -830,12 +835,12 @@ void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float
     // the grid stride (blocks * 256 quads) is a multiple of C4, so a thread keeps its channel quad: the flat partial slab
     // [blocks * 256][4] is a [blocks * 256 / C4][C] matrix whose column sums are the bias gradient
     int fb = (int)std::min<int64_t>((total + 255) / 256, 2048);
-    if (dx) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), dim3(fb), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, partial, xh);
-    else    hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), dim3(fb), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, partial, xh);
+    if (dx) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), dim3(fb), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, partial, xh, dAh);
+    else    hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), dim3(fb), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, partial, xh, dAh);
     if (defer) colsum_defer(*defer, partial, C, (int64_t)fb * 256 / C4, C, conv_dbias); else colsum_accum(s, partial, C, (int64_t)fb * 256 / C4, C, conv_dbias);
     return;
   }
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), dim3(blocks), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, nullptr, xh);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), dim3(blocks), dim3(256), 0, s, x, y, dA, w, save, fin, dx, rows, C, tb_rows, T, dxb, yb, nullptr, xh, dAh);
 }
 
 // =============================================================================================
