@@ -2077,8 +2077,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_dma_kernel(LoadMNh a, LoadC
 // ---------------------------------------------------------------------------
 template <int... I, class F> __device__ __forceinline__ void aocr_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void aocr_static_for(F&& f) { aocr_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
-template <int TAG = 0>
-__global__ __launch_bounds__(512, 1)
+template <int TAG = 0, int MG = 4>
+__global__ __launch_bounds__(128 * MG, 1)
 void conv_wgrad_halo_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ part, long long pstride,
                             int nimg, int H, int W, int Cin, int Cout, int gx, int gy, int gz, int segs_per, const bf16_t* zero) {
   // EIGHT waves as 4 (output-channel groups of 64) x 2 (tap groups: taps 0-4 / taps 5-8): a wave holds 2 x 5 or 2 x 4 accumulator tiles (160 / 128
@@ -2090,47 +2090,56 @@ void conv_wgrad_halo_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restr
   //     conv_wgrad_dma_kernel back to back on the real gradients and no faster inside the step: the LDS -> register bytes it adds cost what the L2 -> LDS
   //     bytes it saves;
   //   this form: 1.4 transposed reads per MFMA (conv_wgrad_dma_kernel: 1.5) AND 22.4 instead of 32 KB per step through L2 -> LDS.
-  constexpr int SLOT = 24576, NS = 6, BOFF = 16384, PW = 34;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[163840];             // the ONLY LDS object: ring of NS slots (147456 B); epilogue: 8 waves x 32 rows x 160 fp32
+  // MG = 4: tiles of 256 output channels, eight waves.  MG = 2 (layers with 128 output channels: conv2): tiles of 128, four waves as 2 x 2, one per SIMD.
+  constexpr int MT = 64 * MG, NWV = 2 * MG, AROW = MT * 2, RPP = 1024 / AROW, LPR = 64 / RPP;   // tile rows (output channels), waves, bytes per pixel row of the d y image, pixel rows / lanes per row of a 1 KB piece
+  constexpr int BOFF = 32 * AROW, SLOT = BOFF + 8192, NS = 6, PW = 34, HPW = 8 / NWV;          // halo pieces per wave
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NWV * 20480 > NS * SLOT ? NWV * 20480 : NS * SLOT];   // the ONLY LDS object: ring of NS slots; epilogue: NWV waves x 32 rows x 160 fp32
   const int nwg = gx * gy * gz, orig = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
   const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   const int zsp = lin / (gx * gy), bid = lin - zsp * (gx * gy);
-  const int m_blk = (bid / gx) * 256, cchunk = bid % gx;                           // 256 output channels x input channels [32 cchunk, +32)
+  const int m_blk = (bid / gx) * MT, cchunk = bid % gx;                            // MT output channels x input channels [32 cchunk, +32)
   const int spr = W >> 5, S = nimg * H * spr;                                      // segments per row, in all
   const int s_beg = zsp * segs_per, s_end = min(S, s_beg + segs_per);
   const int nk = s_end > s_beg ? s_end - s_beg : 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, mg = wave & 3, tg = wave >> 2;
+  const int h = lane >> 5, mg = wave & (MG - 1), tg = wave / MG;
 
   // ---- d y staging: pieces 2 wave, 2 wave + 1; piece pi = pixel rows 2 pi, 2 pi + 1; lane -> row 2 pi + (lane >> 5), 16-byte position lane & 31 of the
   // row, which holds logical chunk ((pos >> 2) ^ (row & 3)) << 2 | (pos & 3)   (as conv_wgrad_dma_kernel)
   const bf16_t* pa[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int krow = 2 * (2 * wave + j) + (lane >> 5), pos = lane & 31;
+    const int krow = RPP * (2 * wave + j) + lane / LPR, pos = lane & (LPR - 1);
     const int chunk = ((((pos >> 2) ^ (krow & 3)) << 2) | (pos & 3));
     pa[j] = dy + ((int64_t)s_beg * 32 + krow) * Cout + m_blk + 8 * chunk;
   }
   const int64_t astep = (int64_t)32 * Cout;
   // ---- halo staging: piece `wave` (piece 7 is all padding); slot sl = 64 piece + lane -> (halo row ry, pixel cx, chunk c) in image order
-  const int sl = 64 * wave + lane;
-  const bool bin = sl < 3 * PW * 4;
-  const int hry = sl / (PW * 4), hrem = sl - hry * (PW * 4), hcx = hrem >> 2, hc = hrem & 3;
-  const int bry = hry - 1, bcx = hcx - 1;
-  const bf16_t* pb = x + ((int64_t)s_beg * 32 + (int64_t)(hry - 1) * W + (hcx - 1)) * Cin + cchunk * 32 + hc * 8;       // never dereferenced while outside the map
+  bool bin[HPW]; int bry[HPW], bcx[HPW]; const bf16_t* pb[HPW];
+#pragma unroll
+  for (int j = 0; j < HPW; ++j) {
+    const int sl = 64 * (HPW * wave + j) + lane;
+    bin[j] = sl < 3 * PW * 4;
+    const int hry = sl / (PW * 4), hrem = sl - hry * (PW * 4), hcx = hrem >> 2, hc = hrem & 3;
+    bry[j] = hry - 1; bcx[j] = hcx - 1;
+    pb[j] = x + ((int64_t)s_beg * 32 + (int64_t)(hry - 1) * W + (hcx - 1)) * Cin + cchunk * 32 + hc * 8;       // never dereferenced while outside the map
+  }
   const int64_t bstep = (int64_t)32 * Cin;
   int is = s_beg, ixs = s_beg % spr, iy = (s_beg / spr) % H;                       // the issue stream's segment: index, position in its row, image row
   unsigned char* const wA = lds + (2 * wave) * 1024;
-  unsigned char* const wB = lds + BOFF + wave * 1024;
+  unsigned char* const wB = lds + BOFF + (HPW * wave) * 1024;
   int islot = 0;
   auto issue = [&]() {
     const bool live = is < s_end;
 #pragma unroll
     for (int j = 0; j < 2; ++j) { dma16(dma_select(live, pa[j], zero), wA + islot * SLOT + j * 1024); pa[j] += astep; }
     const int x0 = ixs << 5;
-    const bool ok = live && bin && (unsigned)(iy + bry) < (unsigned)H && (unsigned)(x0 + bcx) < (unsigned)W;
-    dma16(dma_select(ok, pb, zero), wB + islot * SLOT); pb += bstep;
+#pragma unroll
+    for (int j = 0; j < HPW; ++j) {
+      const bool ok = live && bin[j] && (unsigned)(iy + bry[j]) < (unsigned)H && (unsigned)(x0 + bcx[j]) < (unsigned)W;
+      dma16(dma_select(ok, pb[j], zero), wB + islot * SLOT + j * 1024); pb[j] += bstep;
+    }
     ++is; if (++ixs == spr) { ixs = 0; if (++iy == H) iy = 0; }
     islot = islot == NS - 1 ? 0 : islot + 1;
   };
@@ -2138,7 +2147,7 @@ void conv_wgrad_halo_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restr
   // transposed-read addressing: lane = 16 g + 4 q + p supplies pixel row 8 h + q (+ 4), channels 16 (g & 1) + 4 p .. + 3
   const int g = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
   const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
-  const unsigned rowoff = lbase + (8 * h + q) * 512 + (16 * (g & 1) + 4 * p4) * 2;
+  const unsigned rowoff = lbase + (8 * h + q) * AROW + (16 * (g & 1) + 4 * p4) * 2;
   const unsigned aseg0 = rowoff + (((2 * mg) ^ q) << 6), aseg1 = rowoff + (((2 * mg + 1) ^ q) << 6);
   const unsigned brd = lbase + BOFF + (8 * h + q) * 64 + (16 * (g & 1) + 4 * p4) * 2;
   typedef unsigned long long u64;
@@ -2160,16 +2169,16 @@ void conv_wgrad_halo_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restr
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     int rslot = 0;
     for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // this wave's pieces of segment kt have landed (two later segments in flight)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (2 + HPW)) : "memory");  // this wave's pieces of segment kt have landed (two later segments in flight)
       __builtin_amdgcn_s_barrier();                     // ... everyone's have, and everyone is done reading segment kt-1
       const unsigned so = rslot * SLOT;
       rslot = rslot == NS - 1 ? 0 : rslot + 1;
       u64 fa[2][2][2], fb[2][NTP][2];                   // [k half][tile / tap][low / high four k]
       const unsigned a0 = aseg0 + so, a1 = aseg1 + so, bd = brd + so;
-      AOCR_TRH(fa[0][0][0], a0, 0); AOCR_TRH(fa[0][0][1], a0, 2048); AOCR_TRH(fa[0][1][0], a1, 0); AOCR_TRH(fa[0][1][1], a1, 2048);
+      AOCR_TRH(fa[0][0][0], a0, 0); AOCR_TRH(fa[0][0][1], a0, 4 * AROW); AOCR_TRH(fa[0][1][0], a1, 0); AOCR_TRH(fa[0][1][1], a1, 4 * AROW);
 #define AOCR_TAPH(S2, T) do { AOCR_TRH(fb[S2][T][0], bd, (((T0 + T) / 3) * PW + (T0 + T) % 3) * 64 + S2 * 1024); AOCR_TRH(fb[S2][T][1], bd, (((T0 + T) / 3) * PW + (T0 + T) % 3) * 64 + S2 * 1024 + 256); } while (0)
       AOCR_TAPH(0, 0); AOCR_TAPH(0, 1); AOCR_TAPH(0, 2); AOCR_TAPH(0, 3); if constexpr (NTP == 5) AOCR_TAPH(0, NTP - 1);
-      AOCR_TRH(fa[1][0][0], a0, 8192); AOCR_TRH(fa[1][0][1], a0, 10240); AOCR_TRH(fa[1][1][0], a1, 8192); AOCR_TRH(fa[1][1][1], a1, 10240);
+      AOCR_TRH(fa[1][0][0], a0, 16 * AROW); AOCR_TRH(fa[1][0][1], a0, 20 * AROW); AOCR_TRH(fa[1][1][0], a1, 16 * AROW); AOCR_TRH(fa[1][1][1], a1, 20 * AROW);
       AOCR_TAPH(1, 0); AOCR_TAPH(1, 1); AOCR_TAPH(1, 2); AOCR_TAPH(1, 3); if constexpr (NTP == 5) AOCR_TAPH(1, NTP - 1);
 #undef AOCR_TAPH
       issue();                                          // segment kt + 3 -> a slot last read three steps ago

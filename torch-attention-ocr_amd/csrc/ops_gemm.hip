@@ -27,7 +27,7 @@ static const bf16_t* zero_page() {
   return z;
 }
 static bool env_is_1(const char* name) { const char* e = getenv(name); return e && e[0] == '1'; }      // switches are read per call; "0" means off
-static int wgrad_halo_min_n() { const char* e = getenv("AOCR_WGRAD_HALO_MINN"); return e ? atoi(e) : 1152; }      // smallest N = 9 Cin that takes conv_wgrad_halo_kernel: conv3 (128 -> 256) upwards; A/B at C3: 2304 -> 1152 = 5.505 -> 5.455 ms per step (AOCR_WGRAD_HALO_MINN)
+static int wgrad_halo_min_n() { const char* e = getenv("AOCR_WGRAD_HALO_MINN"); return e ? atoi(e) : 576; }       // smallest N = 9 Cin that takes conv_wgrad_halo_kernel: conv2 (64 -> 128) upwards; A/B at C3: 2304 -> 1152 (conv3 too) = 5.505 -> 5.455 ms per step, 1152 -> 576 (conv2 too, 128-channel tiles): see DESIGN.md (AOCR_WGRAD_HALO_MINN)
 static bool dma_forced() { const char* e = getenv("AOCR_FORCE_DMA"); return e && e[0] == '1'; }     // read per call: tests toggle it
 static bool dma_disabled() { const char* e = getenv("AOCR_NO_DMA"); return e && e[0] == '1'; }       // tests: compare against the 128 x 128 kernels
 static bool dma_eligible(int M, int N, int K, int C) {
@@ -489,15 +489,17 @@ void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float*
     // segment -- 22.4 instead of 32 KB per K step through L2 -> LDS.  3 x 3 / pad 1 layers whose rows are whole 32-pixel segments; needs the slab scratch.
     // Same-box, same harness (tools/ubench/wgrad_halo.hip) at the C3 shapes: conv4 193 -> 166 us, conv5 180 -> 151 us, conv6 327 -> 276 us.
     // AOCR_NO_WGRAD_HALO=1: the one-tap-per-tile kernels below (the parity reference).
-    if (ks == 3 && pad == 1 && W % 32 == 0 && Cout % 256 == 0 && Cin % 32 == 0 && part && !dma_disabled() && !env_is_1("AOCR_NO_WGRAD_HALO") && !getenv("AOCR_WGRAD_ATOMIC") &&
+    const int hmt = Cout % 256 == 0 ? 256 : 128;            // tile rows: 256 output channels (eight waves), or 128 for conv2 (four waves)
+    if (ks == 3 && pad == 1 && W % 32 == 0 && Cout % hmt == 0 && Cin % 32 == 0 && part && !dma_disabled() && !env_is_1("AOCR_NO_WGRAD_HALO") && !getenv("AOCR_WGRAD_ATOMIC") &&
         (dma_forced() || (P >= 8192 && N >= wgrad_halo_min_n()))) {
-      const int htiles = (Cin / 32) * (Cout / 256), S = B * H * (W / 32);
+      const int htiles = (Cin / 32) * (Cout / hmt), S = B * H * (W / 32);
       int ksh = htiles >= 256 ? 1 : 256 / htiles; if (ksh > S) ksh = S;                   // one round of the 256 CUs
       const int per = cdiv(S, ksh); ksh = cdiv(S, per);
       const size_t mn = (size_t)Cout * N;
       if (mn * ksh <= part_floats) {
-        if (profile_tag) hipLaunchKernelGGL((conv_wgrad_halo_kernel<1>), dim3(htiles * ksh), dim3(512), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 256, ksh, per, zero_page());
-        else hipLaunchKernelGGL((conv_wgrad_halo_kernel<0>), dim3(htiles * ksh), dim3(512), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 256, ksh, per, zero_page());
+        if (hmt == 128) hipLaunchKernelGGL((conv_wgrad_halo_kernel<0, 2>), dim3(htiles * ksh), dim3(256), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 128, ksh, per, zero_page());
+        else if (profile_tag) hipLaunchKernelGGL((conv_wgrad_halo_kernel<1, 4>), dim3(htiles * ksh), dim3(512), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 256, ksh, per, zero_page());
+        else hipLaunchKernelGGL((conv_wgrad_halo_kernel<0, 4>), dim3(htiles * ksh), dim3(512), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 256, ksh, per, zero_page());
         splitk_reduce(s, part, ksh, mn, dw);
         if (dbias) colsum_accum(s, dy, Cout, P, Cout, dbias);
         return;
