@@ -205,7 +205,8 @@ void launch_small_gates_bwd(hipStream_t s, bool bf16, int nz, const GatesBwdArgs
 static bool half_gate_tiles(int H, int M, int nz) {
   const char* e = getenv("AOCR_NO_HALF_TILES");
   if (e && e[0] == '1') return false;
-  return H % 16 == 0 && (H / 32) * cdiv(M, 32) * nz < 200;
+  const char* g = getenv("AOCR_HALF_TILES_MAXGRID");       // A/B: the 32-unit grid size below which the half tiles are taken
+  return H % 16 == 0 && (H / 32) * cdiv(M, 32) * nz < (g ? atoi(g) : 200);
 }
 template <int NT, bool GATES, class ARGS>
 static void launch_small_bf16(hipStream_t s, int nz, const ARGS* z, int M, int ncols, int gate_stride) {
