@@ -10,7 +10,7 @@ import os
 import sys
 
 FWD = "gemm_halo4_bf16_kernel<aocr::EpConv, 1, 1>"
-WG = "conv_wgrad_halo_kernel<1>"          # round 4 (round 3: "conv_wgrad_dma_kernel<aocr::EpStore, 256>")
+WG = "conv_wgrad_halo_kernel<1,"          # round 4 (round 3: "conv_wgrad_dma_kernel<aocr::EpStore, 256>")
 RED = "splitk_reduce_kernel"
 
 
@@ -53,7 +53,7 @@ def main():
                    "fetch_bytes_corrected_x2": fb, "write_bytes": wb, "traffic_bytes_per_launch": fb + wb,
                    "algorithmic_bytes_per_launch": {"read_A5_bf16": 67108864, "read_w_bf16": 4718592, "write_idx_u8": 16777216, "write_A6_bf16": 33554432},
                    "note": note}, open(os.path.join(out_dir, "conv6_fwd_pmc.json"), "w"), indent=1)
-        json.dump({"kernel": WG + " + splitk_reduce_kernel (conv6 filter gradient, C3 shape: 512 x 4608 over 65536 pixels, split-K 8 over 256 workgroups of 256 x 288)",
+        json.dump({"kernel": "conv_wgrad_halo_kernel<1, 4> + splitk_reduce_kernel (conv6 filter gradient, C3 shape: 512 x 4608 over 65536 pixels, split-K 8 over 256 workgroups of 256 x 288)",
                    "command": cmd, "kernel_fetch_bytes_corrected_x2": gfb, "kernel_write_bytes": gwb, "reduce_fetch_bytes_corrected_x2": rfb,
                    "reduce_write_bytes": rwb, "traffic_bytes_per_launch": gfb + gwb + rfb + rwb,
                    "algorithmic_bytes_per_launch": {"read_A5_bf16": 67108864, "read_dY6_bf16": 67108864, "write_dW_f32": 9437184},
