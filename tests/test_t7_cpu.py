@@ -180,6 +180,11 @@ def test_reference_layout_writer_round_trip(tmp_path, He, Le, Ld, feed, pre):
     kinds = [m.typename for m in nets[1]["modules"].array_part()]
     assert kinds[:5] == ["nn.AddConstant", "nn.MulConstant", "cudnn.SpatialConvolution", "cudnn.ReLU", "cudnn.SpatialMaxPooling"]   # cnn.lua:9-15
     assert kinds.count("cudnn.SpatialConvolution") == 7 and kinds.count("nn.SpatialBatchNormalization") == 3 and kinds[-2:] == ["nn.View", "nn.Transpose"]
+    # nn.View keeps its size as a torch.LongStorage (not a tensor): a bare storage object in the byte stream
+    view = [m for m in nets[1]["modules"].array_part() if m.typename == "nn.View"][0]
+    assert np.array_equal(np.asarray(view["size"]), np.array([512, -1])) and np.asarray(view["size"]).dtype == np.int64
+    blob = open(path, "rb").read()
+    assert b"torch.LongStorage" in blob
     pools = [m for m in nets[1]["modules"].array_part() if m.typename == "cudnn.SpatialMaxPooling"]
     assert [(p["kW"], p["kH"]) for p in pools] == [(2, 2), (2, 2), (1, 2), (1, 2)]                          # cnn.lua:15,20,29,38
     # gModule inputs: x [, context [, input feed]] + 2 per layer (LSTM.lua:30-45); the decoder ends in Dropout(attention) (:116-118)
