@@ -84,6 +84,10 @@ int aocr_model_set_stream(aocr_model* m, void* stream);
  * finishes, and the step's results are invalid: aocr_sgd_step / aocr_adadelta_step then leave the parameters untouched (device-side
  * predicate on the same flag, no host sync), so a host that polls this call only every N steps loses steps, never its weights.
  * *code = 0: healthy; a non-zero code is cleared by the call (read and clear).
+ * Under data parallelism the code is a GLOBAL decision (round 4): aocr_allreduce_grads sums a time-out flag with the exchange, and a rank whose own
+ * kernels were healthy while a peer's were not reads 0x7e -- so every rank's optimizer skips the update and every host repeats the step together.
+ * After a non-zero code the NEXT aocr_train_forward_backward (the repeat of the skipped step) leaves the BatchNorm running statistics alone: the
+ * skipped step's CNN forward -- untouched by the time-out -- has already moved them once.
  * Synchronises the model's stream.  No reference counterpart.
  * These kernels need the device to themselves: a launch occupies every compute unit, so the steps of two models (or two processes)
  * must not run concurrently on ONE device -- AOCR_NO_CLUSTER=1 AOCR_NO_DEC_CLUSTER=1 selects the per-step launch chains for that case. */
@@ -133,7 +137,10 @@ int aocr_stream_wait_grads(aocr_model* m, int32_t bucket, void* stream);
  * does (ncclCommSplit), or bucket 0 queues behind the last BatchNorm-backward sum and the overlap with the backward pass is lost.
  * aocr_allreduce_grads: after aocr_train_forward_backward and before aocr_sgd_step; the buckets of aocr_grad_buckets are summed on a
  * second stream as the backward pass completes them (overlap), loss_dev (optional, 1 float) is summed too, and the model's stream
- * waits for the last bucket.  Pass grad_scale = 1 / GLOBAL batch to aocr_train_forward_backward. */
+ * waits for the last bucket.  Pass grad_scale = 1 / GLOBAL batch to aocr_train_forward_backward.
+ * Exchange policy (round 4): no collective is in flight while a whole-sequence kernel runs -- with a communicator attached bucket 0 (decoder + projector)
+ * is released behind the encoder BPTT (AOCR_COMM_EARLY_BUCKET0=1: as soon as it is complete; the encoder kernels then leave AOCR_COMM_RESERVE_CUS,
+ * default 32, compute units free).  aocr_comm_init_rank fails if ncclCommSplit fails (AOCR_ONE_COMM=1 on every rank shares one communicator). */
 #define AOCR_COMM_CHANNEL_BN 0x100
 typedef int (*aocr_allreduce_fn)(void* user, void* buf_dev, int64_t count, int32_t dtype, void* stream);
 int aocr_comm_unique_id(char id[128]);

@@ -342,6 +342,9 @@ function model:step(batch, forward_only, beam_size, trie)
         local loss = A.read_scalar(self.scal_dev, 0)                          -- = loss * batch_size of model.lua:701
         -- health of the whole-sequence kernels (include/aocr.h: aocr_cluster_status).  A timed-out wait invalidates the step; the
         -- library then skips the update itself (aocr_sgd_step's device-side predicate), so the weights are intact: report and redo.
+        -- With AOCR_WORLD_SIZE > 1 the code is the same decision on every rank (the flag is summed with the gradient exchange; a rank whose own
+        -- kernels were healthy reads 0x7e), so all ranks repeat together and their collectives pair up; the library keeps the BatchNorm running
+        -- statistics as they are during the repeat (include/aocr.h: aocr_cluster_status).
         local code = ffi.new('int32_t[1]')
         A.check(L.aocr_cluster_status(self.handle, code), 'aocr_cluster_status')
         if code[0] ~= 0 then
