@@ -48,6 +48,10 @@ struct EpStore {
   bf16_t* Cb = nullptr; int64_t ldcb = 0; // optional bf16 shadow of C (plain stores only)
   // optional tanh-backward fusion (decoder BPTT, model.lua:649,654-657): x <- (x + dg[m][n]) * (1 - dout[m][n]^2)
   const float* dg = nullptr; const float* dout = nullptr; int64_t ldd = 0;
+  // optional (round 4; data gradient in front of a BatchNorm backward, staged 256 x 256 fp32 tiles only: tile256_store_f32): the per-tile partial sums of the
+  // BatchNorm backward pass -- (sum d, sum d xhat) per column with d = C[m][n] (y[m][n] > 0), xhat = (x[m][n] - mean[n]) invstd[n] -- in the chunk layout
+  // bn_bwd_finalize_kernel / bn_sums_kernel read ([row tile][N][2] doubles), so bn_relu_backward skips its sums pass (a re-read of this output, x and the mask)
+  const float* bnb_x = nullptr; const bf16_t* bnb_yb = nullptr; const float* bnb_save = nullptr; double* bnb_part = nullptr;
   template <int NT> __device__ __forceinline__ void quad(int m, int n, int nstep, const float (&v)[NT][4]) const {
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {

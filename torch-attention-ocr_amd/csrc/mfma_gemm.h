@@ -845,8 +845,16 @@ struct EpConv; struct EpStore;
 // NI = 32-column accumulator tiles per wave (wave tile 128 x 32 NI), NTH = threads of the workgroup.
 template <int NI, int NTH>
 __device__ __forceinline__ void tile256_store_f32(float* dst, int64_t ldc, const float* bias, bool relu, const f32x16 (&acc)[4][NI], unsigned char* lds,
-                                                  int m_blk, int n_blk, int wm, int wn, int r, int h, int tid, double* part = nullptr, int C = 0, const float* bias2 = nullptr) {
+                                                  int m_blk, int n_blk, int wm, int wn, int r, int h, int tid, double* part = nullptr, int C = 0, const float* bias2 = nullptr,
+                                                  const float* bnb_x = nullptr, const bf16_t* bnb_yb = nullptr, const float* bnb_save = nullptr) {
+  // bnb_x (with part): the sums are those of the BatchNorm BACKWARD pass -- (sum d, sum d xhat), d = stored value where the bf16 activation bnb_yb is positive,
+  // xhat = (bnb_x - mean) invstd (bnb_save = {mean[C], invstd[C]}): EpStore::bnb_*
   constexpr int PITCH = 1024;                             // lanes r = consecutive dwords, the two row groups h are separate LDS cycles: no padding needed
+  float bmean[4] = {0.f, 0.f, 0.f, 0.f}, binv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bnb_x) {
+    const float4 m4 = *reinterpret_cast<const float4*>(bnb_save + n_blk + (tid & 63) * 4), i4 = *reinterpret_cast<const float4*>(bnb_save + C + n_blk + (tid & 63) * 4);
+    bmean[0] = m4.x; bmean[1] = m4.y; bmean[2] = m4.z; bmean[3] = m4.w; binv[0] = i4.x; binv[1] = i4.y; binv[2] = i4.z; binv[3] = i4.w;
+  }
   float bb[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) bb[ni] = (bias ? bias[n_blk + wn * 32 * NI + ni * 32 + r] : 0.f) + (bias2 ? bias2[n_blk + wn * 32 * NI + ni * 32 + r] : 0.f);
@@ -874,7 +882,16 @@ __device__ __forceinline__ void tile256_store_f32(float* dst, int64_t ldc, const
       const int idx = it * NTH + tid, row = idx >> 6, c = idx & 63;
       const float4 v = *reinterpret_cast<const float4*>(lds + row * PITCH + c * 16);
       *reinterpret_cast<float4*>(d0 + (int64_t)row * ldc + c * 4) = v;
-      if (part) {                                         // a thread keeps its four columns (c = tid & 63): column sums of exactly the stored values
+      if (part && bnb_x) {                                // BatchNorm backward sums of the thread's four columns
+        const int64_t gofs = (int64_t)(m_blk + p * 128 + row) * C + n_blk + c * 4;
+        const float4 x4 = *reinterpret_cast<const float4*>(bnb_x + gofs);
+        typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+        const bf16x4_ y4 = *reinterpret_cast<const bf16x4_*>(bnb_yb + gofs);
+        const float dv[4] = {(float)y4[0] > 0.f ? v.x : 0.f, (float)y4[1] > 0.f ? v.y : 0.f, (float)y4[2] > 0.f ? v.z : 0.f, (float)y4[3] > 0.f ? v.w : 0.f};
+        const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ps[k] += dv[k]; ps[4 + k] = fmaf(dv[k], (xs[k] - bmean[k]) * binv[k], ps[4 + k]); }
+      } else if (part) {                                  // a thread keeps its four columns (c = tid & 63): column sums of exactly the stored values
         ps[0] += v.x; ps[1] += v.y; ps[2] += v.z; ps[3] += v.w;
         ps[4] = fmaf(v.x, v.x, ps[4]); ps[5] = fmaf(v.y, v.y, ps[5]); ps[6] = fmaf(v.z, v.z, ps[6]); ps[7] = fmaf(v.w, v.w, ps[7]);
       }
@@ -1008,7 +1025,8 @@ __device__ __forceinline__ bool tile256_store_staged(const EP& ep, const f32x16 
     if (!ep.C && ep.Cb && !ep.flags && !ep.bias && !ep.bias2 && !ep.C1 && !ep.dg) {       // bf16-only data gradient (conv_backward_data's dx16: full tiles guaranteed by the caller)
       tile256_store_bf16<NI, NTH>(ep.Cb, (int)ep.ldcb, nullptr, false, nullptr, nullptr, nullptr, acc, lds, m_blk, n_blk, wm, wn, r, h, tid); return true; }
     if (ep.flags || ep.bias || ep.bias2 || ep.C1 || ep.Cb || ep.dg || !(opt & 1) || m_blk + 256 > ep.M || n_blk + 256 > ep.N) return false;
-    tile256_store_f32<NI, NTH>(ep.C, ep.ldc, nullptr, false, acc, lds, m_blk, n_blk, wm, wn, r, h, tid);      // (taking the biases here too cost the data-gradient kernel 157 -> 190 us: register pressure in its K loop)
+    if (ep.bnb_part) tile256_store_f32<NI, NTH>(ep.C, ep.ldc, nullptr, false, acc, lds, m_blk, n_blk, wm, wn, r, h, tid, ep.bnb_part, ep.N, nullptr, ep.bnb_x, ep.bnb_yb, ep.bnb_save);
+    else tile256_store_f32<NI, NTH>(ep.C, ep.ldc, nullptr, false, acc, lds, m_blk, n_blk, wm, wn, r, h, tid);      // (taking the biases here too cost the data-gradient kernel 157 -> 190 us: register pressure in its K loop)
     return true;
   } else return false;
 }

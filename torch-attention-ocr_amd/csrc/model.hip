@@ -362,6 +362,7 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
   const BnSync bsync_v{bn_sync_allreduce, m}; const BnSync* bsync = sync_bn_on(m) ? &bsync_v : nullptr;
   float *G0 = m->G0, *G1 = m->G1; bf16_t* G0b = m->G0b;
+  int bnbc = 0;                                                  // > 0: the data gradient's epilogue left the BatchNorm backward's partial sums in bn_scratch (conv_backward_data: bnb_chunks)
   int g16 = 0; const bf16_t* const G1h = reinterpret_cast<const bf16_t*>(G1);      // conv_backward_data left G1 as bf16 (its dx16): the BatchNorm backward / un-pool pass that follows reads it so
   // bf16 mode: fp32 G0 is free for the whole pass (every gradient map lives in its bf16 shadow), so the eight partial slabs of the fused bias /
   // conv1 gradients get regions of their own and their column sums are finished by TWO launches (before the bucket event, at the end)
@@ -383,18 +384,20 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A6, m->idx6, bf ? nullptr : G0, B, d.H4, d.W2, 512, 2, G0b, bf ? m->conv[6].db : nullptr, bf ? slab(1) : nullptr, bf ? m->A6b : nullptr, defer, g16 ? G1h : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
   if (stop == 2) { if (defer) colsum_flush(s, cj); return; }
   prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, bf ? nullptr : m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, G0b, m->wg_part, m->wg_part_floats);
-  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, G0b, m->wtb[6], m->wtf[6], bf ? &g16 : nullptr);
+  prof_mark(m, AOCR_PROF_CONV_DGRAD); { const BnBwdFuse bf5{m->Y5, m->A5b, m->bn[5].save, (double*)m->bn_scratch};
+    conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, G0b, m->wtb[6], m->wtf[6], bf ? &g16 : nullptr, (bf && !m->y16[1]) ? &bf5 : nullptr, &bnbc); }
   prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, bf ? nullptr : G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
-                   (int64_t)B * d.H4 * d.W2, 512, 0, G0b, bf ? m->A5b : nullptr, bf ? m->conv[5].db : nullptr, bf ? slab(2) : nullptr, bsync, defer, m->y16[1] ? reinterpret_cast<const bf16_t*>(m->Y5) : nullptr, g16 ? G1h : nullptr);
+                   (int64_t)B * d.H4 * d.W2, 512, 0, G0b, bf ? m->A5b : nullptr, bf ? m->conv[5].db : nullptr, bf ? slab(2) : nullptr, bsync, defer, m->y16[1] ? reinterpret_cast<const bf16_t*>(m->Y5) : nullptr, g16 ? G1h : nullptr, bnbc); bnbc = 0;
   prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, bf ? nullptr : m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, G0b, m->wg_part, m->wg_part_floats);
   if (defer) colsum_flush(s, cj);                               // conv7.b, conv6.b, conv5.b
   hipEventRecord(m->grad_ev[2], s);                             // every CNN gradient from conv5.w upwards is complete
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1, G0b, m->wtb[5], m->wtf[5], bf ? &g16 : nullptr);
   prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A4, m->idx4, bf ? nullptr : G0, B, d.H2, d.W2, 256, 2, G0b, bf ? m->conv[4].db : nullptr, bf ? slab(3) : nullptr, bf ? m->A4b : nullptr, defer, g16 ? G1h : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
   prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, bf ? nullptr : m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, G0b, m->wg_part, m->wg_part_floats);
-  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, G0b, m->wtb[4], m->wtf[4], bf ? &g16 : nullptr);
+  prof_mark(m, AOCR_PROF_CONV_DGRAD); { const BnBwdFuse bf3{m->Y3, m->A3b, m->bn[3].save, (double*)m->bn_scratch};
+    conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, G0b, m->wtb[4], m->wtf[4], bf ? &g16 : nullptr, (bf && !m->y16[0]) ? &bf3 : nullptr, &bnbc); }
   prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y3, m->A3, G1, m->bn[3].w, m->bn[3].save, bf ? nullptr : G0, m->bn[3].dw, m->bn[3].db, m->bn_scratch,
-                   (int64_t)B * d.H2 * d.W2, 256, 0, G0b, bf ? m->A3b : nullptr, bf ? m->conv[3].db : nullptr, bf ? slab(4) : nullptr, bsync, defer, m->y16[0] ? reinterpret_cast<const bf16_t*>(m->Y3) : nullptr, g16 ? G1h : nullptr);
+                   (int64_t)B * d.H2 * d.W2, 256, 0, G0b, bf ? m->A3b : nullptr, bf ? m->conv[3].db : nullptr, bf ? slab(4) : nullptr, bsync, defer, m->y16[0] ? reinterpret_cast<const bf16_t*>(m->Y3) : nullptr, g16 ? G1h : nullptr, bnbc); bnbc = 0;
   prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A2, G0, m->conv[3].dw, bf ? nullptr : m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, G0b, m->wg_part, m->wg_part_floats);
   prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1, G0b, m->wtb[3], m->wtf[3]);
   prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A2, m->idx2, bf ? nullptr : G0, B, d.H1, d.W1, 128, 1, G0b, bf ? m->conv[2].db : nullptr, bf ? slab(5) : nullptr, bf ? m->A2b : nullptr, defer);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)

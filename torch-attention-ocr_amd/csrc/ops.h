@@ -109,9 +109,11 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
 // bn_save != nullptr: evaluation-mode BatchNorm + ReLU folded into the conv epilogue (bn_save from bn_eval_prepare)
 void bn_eval_prepare(hipStream_t s, const float* rm, const float* rv, float* save, int C);
 // profile_tag != 0: the same kernel under a distinct symbol (aocr_profile_kernel), so profilers list these launches separately
+struct BnBwdFuse { const float* x; const bf16_t* yb; const float* save; double* part; };   // pre-BatchNorm map (fp32), post-ReLU bf16 shadow (mask), {mean, invstd}, bn_relu_backward's scratch
 void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* w, float* dx, int B, int H, int W, int Cin,
                         int Cout, int ks, int pad, const bf16_t* dyb = nullptr, const bf16_t* wtb = nullptr, const float* wtf = nullptr,
-                        int* dx16 = nullptr /* the caller accepts dx written as bf16 into the first half of the same buffer; *dx16 = 1 when that happened */);
+                        int* dx16 = nullptr /* the caller accepts dx written as bf16 into the first half of the same buffer; *dx16 = 1 when that happened */,
+                        const struct BnBwdFuse* bnb = nullptr, int* bnb_chunks = nullptr /* the BatchNorm backward behind this data gradient: its partial sums from the conv epilogue; *bnb_chunks = row tiles written (pass to bn_relu_backward as sums_chunks), 0 = not taken */);
 void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float* dy, float* dw, float* dbias, int B, int H,
                           int W, int Cin, int Cout, int ks, int pad, const bf16_t* xb = nullptr, const bf16_t* dyb = nullptr,
                           float* part = nullptr, size_t part_floats = 0, int profile_tag = 0);   // part: scratch for the split-K slabs (else fp32 atomics)
@@ -142,7 +144,8 @@ void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float
                       float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb = nullptr,
                       const bf16_t* yb = nullptr, float* conv_dbias = nullptr, float* partial = nullptr, const BnSync* sync = nullptr,
                       ColsumJobs* defer = nullptr, const bf16_t* xh = nullptr /* x as bf16 */,
-                      const bf16_t* dAh = nullptr /* d A as bf16 instead of fp32 (bn_partial4 path only) */);
+                      const bf16_t* dAh = nullptr /* d A as bf16 instead of fp32 (bn_partial4 path only) */,
+                      int sums_chunks = 0 /* > 0: scratch already holds that many chunks of (sum d, sum d xhat) (conv_backward_data's bnb_chunks) */);
 // yb: bf16 shadow of y (ReLU mask source); conv_dbias + partial (>= 4096*256 floats): fused bias gradient of the preceding conv, dx may then be null
 // ctx_div: rows r share context row r / ctx_div (beam search keeps one context per image, model.lua:373)
 void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a, float* c, int64_t ldc, int B, int T, int Hd,

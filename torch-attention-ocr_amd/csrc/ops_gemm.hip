@@ -441,11 +441,12 @@ void conv_forward(hipStream_t s, bool bf16, const float* x, const float* w, cons
 }
 
 void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* w, float* dx, int B, int H, int W, int Cin,
-                        int Cout, int ks, int pad, const bf16_t* dyb, const bf16_t* wtb, const float* wtf, int* dx16) {
+                        int Cout, int ks, int pad, const bf16_t* dyb, const bf16_t* wtb, const float* wtf, int* dx16, const BnBwdFuse* bnb, int* bnb_chunks) {
   const int Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
   LoadConvK a = make_convk(dy, B, Ho, Wo, Cout, ks, -1, pad, H, W, 0);
   EpStore ep = make_store(dx, Cin, a.rows, Cin);
   if (dx16) *dx16 = 0;
+  if (bnb_chunks) *bnb_chunks = 0;
   if (bf16 && dyb && wtb) {
     LoadConvKh ah; ah.src = dyb; ah.g = a;
     LoadKh bh; bh.p = wtb; bh.ld = a.K; bh.rows = Cin; bh.K = a.K;          // wtb [Cin][tap][Cout]: K-contiguous over (tap, co)
@@ -459,6 +460,20 @@ void conv_backward_data(hipStream_t s, bool bf16, const float* dy, const float* 
       const char* const so = getenv("AOCR_HALO4_STAGED");
       const bool halo = pad == 1 && halo_eligible(a, Cin, 256, 256);
       if (((so ? atoi(so) : 7) & 1) && !(halo && getenv("AOCR_HALO8"))) { ep.C = nullptr; ep.Cb = reinterpret_cast<bf16_t*>(dx); ep.ldcb = Cin; *dx16 = 1; }
+    }
+    // Round 4: the sums pass of the BatchNorm backward that follows -- (sum d, sum d xhat) per channel, a re-read of this output (4 B), x (4 B) and the mask
+    // (2 B) per element -- from the staged fp32 tile of the 256 x 256 kernels: the output values pass through a thread that keeps four fixed columns anyway
+    // (as for the forward statistics, EpConv::bn_part), so only x and the mask are read, by the workgroup that has the tile's output in LDS.
+    // Only where EVERY tile of the launch takes tile256_store_f32 (full tiles, staged fp32 tile on).
+    // MEASURED, NOT THE DEFAULT (AOCR_BNB_FUSE=1 turns it on): at C3 the BatchNorm family drops 0.50 -> 0.365 ms per step, but the data gradients rise 0.767 -> 0.931 ms
+    // -- the 201 MB of x / mask reads per layer land in an epilogue that nothing overlaps (one workgroup per CU, all of a round finishing together) -- net
+    // 5.262 -> 5.280 ms per step, same box, two runs each.  The separate sums pass runs at 5.1 TB/s; it stays.
+    if (bnb && bnb_chunks && ep.C && dma_eligible(a.rows, Cin, a.K, Cout) && a.rows % 256 == 0 && Cin % 256 == 0 && a.rows / 256 <= 512 && env_is_1("AOCR_BNB_FUSE")) {
+      const char* const so = getenv("AOCR_HALO4_STAGED");
+      const bool halo = pad == 1 && halo_eligible(a, Cin, 256, 256);
+      if (((so ? atoi(so) : 7) & 1) && !(halo && getenv("AOCR_HALO8"))) {
+        ep.bnb_x = bnb->x; ep.bnb_yb = bnb->yb; ep.bnb_save = bnb->save; ep.bnb_part = bnb->part; *bnb_chunks = a.rows / 256;
+      }
     }
     if (dma_eligible(a.rows, Cin, a.K, Cout) && pad == 1 && halo_eligible(a, Cin, 256, 256)) launch_halo<-1, 256, 256>(s, ah, bh, ep, a.rows, Cin);
     else if (dma_eligible(a.rows, Cin, a.K, Cout)) launch_dma(s, ah, bh, ep, a.rows, Cin, a.K);

@@ -815,11 +815,13 @@ void bn_relu_forward(hipStream_t s, const float* x, float* y, const float* w, co
 }
 void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float* dA, const float* w, const float* save,
                       float* dx, float* dw, float* db, void* scratch, int64_t rows, int C, int tb_rows, bf16_t* dxb,
-                      const bf16_t* yb, float* conv_dbias, float* partial, const BnSync* sync, ColsumJobs* defer, const bf16_t* xh, const bf16_t* dAh) {
+                      const bf16_t* yb, float* conv_dbias, float* partial, const BnSync* sync, ColsumJobs* defer, const bf16_t* xh, const bf16_t* dAh, int sums_chunks) {
   int T = tb_rows > 0 ? (int)(rows / tb_rows) : 0;
   double* part = (double*)scratch;
   double* fin = part + (size_t)BN_CHUNKS * C * 2;
   int nchunk = (int)std::min<int64_t>(BN_CHUNKS, (rows + 63) / 64);
+  if (sums_chunks > 0 && sums_chunks <= BN_CHUNKS) nchunk = sums_chunks;       // the producing data gradient's epilogue wrote the partial sums (EpStore::bnb_part)
+  else
   if (bn_partial4_ok(C)) hipLaunchKernelGGL(bn_partial4_kernel<1>, dim3(nchunk), dim3(1024), 0, s, x, y, dA, save, part, rows, C, tb_rows, T, yb, xh, dAh);
   else hipLaunchKernelGGL(bn_partial_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, x, y, dA, save, part, rows, C, 1, tb_rows, T, yb);
   if (sync) {                                             // mean(dy), mean(dy * xhat) over the GLOBAL batch
