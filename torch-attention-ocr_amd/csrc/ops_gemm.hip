@@ -510,6 +510,8 @@ void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float*
         (dma_forced() || (P >= 8192 && N >= wgrad_halo_min_n()))) {
       const int htiles = (Cin / 32) * (Cout / hmt), S = B * H * (W / 32);
       int ksh = htiles >= 256 ? 1 : 256 / htiles; if (ksh > S) ksh = S;                   // one round of the 256 CUs
+      { const char* ms = getenv("AOCR_WGRAD_HALO_MINSTEPS"); const int minsteps = ms ? atoi(ms) : 0;       // A/B: at small P fewer, longer k ranges (less slab traffic) instead of a full round
+        if (minsteps > 0 && S / ksh < minsteps) ksh = std::max(1, S / minsteps); }
       const int per = cdiv(S, ksh); ksh = cdiv(S, per);
       const size_t mn = (size_t)Cout * N;
       if (mn * ksh <= part_floats) {
