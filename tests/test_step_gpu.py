@@ -1147,3 +1147,32 @@ def test_bn_backward_sums_from_dgrad_epilogue(cuda, monkeypatch, B, W):
         if k.startswith("cnn."): assert cosine(b["grads"][k], a["grads"][k]) > 0.999999, k
     assert differs, "the fused sums were not taken"
     print(f"[parity] BatchNorm backward sums from the data-gradient epilogue vs the separate pass, B={B} W={W}: worst relative difference {worst[1]:.2e} ({worst[0]})")
+
+
+@pytest.mark.parametrize("B,W,tile", [(6, 72, ""), (64, 100, ""), (64, 100, "1"), (64, 100, "2"), (5, 200, "3")])
+def test_f32t_kernel_matches_lds_f32_kernel(cuda, monkeypatch, B, W, tile):
+    """Round 4: gemm_f32t_kernel (exact-fp32 conv forward / data gradient / nn.Linear products: branch-free staging, tile shape by grid size:
+    128 x 128, 64 x 128, 64 x 64) against gemm_lds_f32_kernel (AOCR_NO_F32T=1).  Same LDS image and the same k order per output element, so
+    feature maps, logits, loss and every gradient that does not pass through split-K atomics must be BIT-identical -- with the tile chosen
+    by the dispatch ("" : (64, 100) is BASELINE configs[1], where the 3x3 layers take 64 x 64 tiles) and with each shape forced."""
+    cfg = dict(enc_hidden=256 if B == 64 else 64, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for off in ("1", "0"):
+        monkeypatch.setenv("AOCR_NO_F32T", off)
+        if tile and off == "0":
+            monkeypatch.setenv("AOCR_F32T_TILE", tile)
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=6, compute="f32")
+        loss = m.train_forward_backward(batch)
+        out[off] = dict(loss=loss, feats=m.get_tensor("feats").clone(), conv6=m.get_tensor("conv6").clone(), dfeats=m.get_tensor("dfeats").clone(),
+                        logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.shutdown()
+    monkeypatch.delenv("AOCR_F32T_TILE", raising=False)
+    a, b = out["1"], out["0"]
+    assert torch.equal(a["conv6"], b["conv6"]) and torch.equal(a["feats"], b["feats"]) and torch.equal(a["logits"], b["logits"])
+    assert a["loss"] == b["loss"] and torch.equal(a["dfeats"], b["dfeats"])
+    for k in a["grads"]:
+        if k.endswith(".w") and (k.startswith("cnn.conv") or "lstm" in k or k.startswith("enc") or k.startswith("dec")):
+            assert relerr(b["grads"][k], a["grads"][k]) < 1e-5, k            # split-K atomics: not bit-stable between two runs of one path
+        else:
+            assert torch.allclose(a["grads"][k], b["grads"][k], rtol=1e-5, atol=1e-7), k
+    print(f"[parity] f32t (tile '{tile or 'auto'}') vs gemm_lds_f32_kernel, B={B} W={W}: conv6 / feats / logits / dfeats bit-identical, loss {a['loss']:.6f}")

@@ -73,6 +73,16 @@ struct LoadK {
       f.v[j] = t.x; f.v[j + 1] = t.y; f.v[j + 2] = t.z; f.v[j + 3] = t.w;
     }
   }
+  // branch-free 8-k chunk interface of gemm_f32t_kernel (host guarantees vec, K % 8 == 0, K0 % 8 == 0): the address of a chunk that is
+  // not there is the base pointer (a valid 32 bytes) and `ok` tells the stager to keep zeros instead of what was loaded
+  typedef int KCur;
+  __device__ __forceinline__ KCur kseek(int k) const { return k; }
+  __device__ __forceinline__ void kadvance(KCur& k, int dk) const { k += dk; }
+  __device__ __forceinline__ const float* ptr8(const Ctx& c, const KCur& k, bool& ok) const {
+    ok = c.ok && k + 8 <= K;
+    const float* s = (k < K0) ? c.b0 + k : c.b1 + (k - K0);
+    return ok ? s : p0;
+  }
 };
 
 // MN-contiguous: element(r,k) = p[k*ld + r]
@@ -146,6 +156,21 @@ struct LoadConvK {
 #pragma unroll
       for (int j = 0; j < NV; ++j) f.v[j] = 0.f;
     }
+  }
+  // branch-free 8-k chunk interface (gemm_f32t_kernel; C % 8 == 0, so a chunk stays inside one tap): the (tap, channel) of the cursor advance
+  // by addition instead of two integer divisions per load
+  struct KCur { int k, ch, kh, kw; };
+  __device__ __forceinline__ KCur kseek(int k) const { KCur q; q.k = k; const int tap = k / C; q.ch = k - tap * C; q.kh = tap / KW; q.kw = tap - q.kh * KW; return q; }
+  __device__ __forceinline__ void kadvance(KCur& q, int dk) const {
+    q.k += dk; q.ch += dk;                       // dk <= C (host: C >= 32): at most one tap boundary per advance, as selects (no divergent loop)
+    const bool wrap = q.ch >= C; q.ch -= wrap ? C : 0;
+    const int kw1 = q.kw + (wrap ? 1 : 0); const bool row = kw1 == KW;
+    q.kw = row ? 0 : kw1; q.kh += row ? 1 : 0;
+  }
+  __device__ __forceinline__ const float* ptr8(const Ctx& c, const KCur& q, bool& ok) const {
+    const int sy = c.y + sgn * q.kh + off, sx = c.x + sgn * q.kw + off;
+    ok = c.ok && q.k < K && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+    return ok ? src + (((int64_t)c.b * H + sy) * W + sx) * C + q.ch : src;
   }
 };
 
@@ -811,6 +836,119 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_f32_kernel(AL a, BL b, EP ep,
   const int kbeg = blockIdx.z * kper;
   lds_tile_f32(a, b, ep, (bid / gx) * 128, (bid % gx) * 128, kbeg, min(K, kbeg + kper), lds);
 }
+
+// ---------------------------------------------------------------------------
+// Round 4: gemm_f32t_kernel -- the exact-fp32 LDS-tiled kernel again, for K-contiguous operand pairs whose 8-k chunks are whole (conv
+// forward / data gradient with C % 8 == 0, nn.Linear with K % 8 == 0), written around what the ISA of gemm_lds_f32_kernel showed at C2
+// (batch 64: 48-400 workgroups of 128 x 128, one wave per SIMD, 0.19-0.42 of the fp32 MFMA peak per layer):
+//  * the stager's `if (ok) load else zero` became divergent branches, and the compiler's waitcnt pass put `s_waitcnt vmcnt(0/1)` INSIDE
+//    the load phase -- every K tile paid a full global-load latency in front of its 64 MFMAs.  Here a chunk's address is always valid
+//    (ptr8: the base pointer when the chunk is padding), all loads are unconditional, and validity is a select at the LDS store, so the
+//    only vmcnt wait of a tile sits behind its MFMAs;
+//  * the (tap, channel) of the im2col cursor advance by addition (KCur) instead of two integer divisions per load;
+//  * the fragments of chunk c+1 are read from LDS while chunk c is multiplied (two register sets);
+//  * the tile is a template parameter: 128 x 128, 64 x 128 or 64 x 64 (4 waves as 2 x 2, wave tile BM/2 x BN/2), chosen by the host so
+//    that every CU holds 2-4 workgroups: at batch 64 the 3x3 layers run as 400-800 workgroups of 64 x 64 instead of 100-200 of 128 x 128.
+// Same LDS image (144-byte rows), same k order per output element (chunk c, MFMA s: k = 8c + s and 8c + 4 + s) as gemm_lds_f32_kernel
+// and gemm_big_kernel<false>: bit-identical results (tests/test_step_gpu.py::test_f32t_kernel_matches_lds_f32_kernel).
+// ---------------------------------------------------------------------------
+template <class LD, int ROWS> struct StagerF32 {
+  static constexpr int NI = ROWS / 64;
+  typename LD::Ctx ctx[NI]; typename LD::KCur cur; float4 reg[NI][2]; bool ok[NI]; int row0, chunk;
+  __device__ __forceinline__ void init(const LD& l, int base, int tid, int kbeg) {
+    chunk = tid & 3; row0 = tid >> 2; cur = l.kseek(kbeg + 8 * chunk);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) ctx[i] = l.row(base + row0 + 64 * i);
+  }
+  __device__ __forceinline__ void load(const LD& l) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float* p = l.ptr8(ctx[i], cur, ok[i]);
+      reg[i][0] = *reinterpret_cast<const float4*>(p); reg[i][1] = *reinterpret_cast<const float4*>(p + 4);
+    }
+    l.kadvance(cur, 32);
+  }
+  __device__ __forceinline__ void store(unsigned char* tile) const {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float4* d = reinterpret_cast<float4*>(tile + (row0 + 64 * i) * LDS_PITCH32 + chunk * 32);
+      const float4 u = reg[i][0], w = reg[i][1]; const bool k = ok[i];      // (component selects: a select between the two float4 OBJECTS sends the stager to scratch)
+      d[0] = make_float4(k ? u.x : 0.f, k ? u.y : 0.f, k ? u.z : 0.f, k ? u.w : 0.f);
+      d[1] = make_float4(k ? w.x : 0.f, k ? w.y : 0.f, k ? w.z : 0.f, k ? w.w : 0.f);
+    }
+  }
+};
+template <int BM, int BN, class AL, class BL, class EP>
+__global__ __launch_bounds__(256, (BM + BN <= 128) ? 4 : 2) void gemm_f32t_kernel(AL a, BL b, EP ep, int K, int kper, int gx, int gy) {
+  constexpr int PITCH = LDS_PITCH32, MI = BM / 64, NI = BN / 64, SLOT = (BM + BN) * PITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][SLOT];      // 128 x 128: 73.7 KB (2 per CU), 64 x 128: 55.3 KB (2), 64 x 64: 36.9 KB (4)
+  const int nwg = gx * gy, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);      // consecutive ids share an XCD
+  const int m_blk = (bid / gx) * BM, n_blk = (bid % gx) * BN;
+  const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = (kend - kbeg + 31) / 32;
+  StagerF32<AL, BM> sa; StagerF32<BL, BN> sb;
+  sa.init(a, m_blk, tid, kbeg); sb.init(b, n_blk, tid, kbeg);
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  if (nk > 0) { sa.load(a); sb.load(b); sa.store(&lds[0][0]); sb.store(&lds[0][BM * PITCH]); }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) { sa.load(a); sb.load(b); }            // tile kt+1: global -> registers; consumed behind this tile's MFMAs
+    const unsigned char* la = &lds[buf][(wm * (BM / 2) + r) * PITCH + 16 * h];
+    const unsigned char* lb = &lds[buf][(BM + wn * (BN / 2) + r) * PITCH + 16 * h];
+    float4 af[2][MI], bf[2][NI];
+    auto rd = [&](int set, int c) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[set][i] = *reinterpret_cast<const float4*>(la + i * 32 * PITCH + 32 * c);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) bf[set][i] = *reinterpret_cast<const float4*>(lb + i * 32 * PITCH + 32 * c);
+    };
+    rd(0, 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < 3) rd((c + 1) & 1, c + 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const float4& A = af[c & 1][mi]; const float4& B = bf[c & 1][ni];
+            const float x = s == 0 ? A.x : s == 1 ? A.y : s == 2 ? A.z : A.w;
+            const float y = s == 0 ? B.x : s == 1 ? B.y : s == 2 ? B.z : B.w;
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[mi][ni], 0, 0, 0);
+          }
+    }
+    if (kt + 1 < nk) { sa.store(&lds[buf ^ 1][0]); sb.store(&lds[buf ^ 1][BM * PITCH]); }
+    __syncthreads();
+  }
+  const int m0 = m_blk + wm * (BM / 2), n0 = n_blk + wn * (BN / 2);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[NI][4];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * q + i];
+      ep.template quad<NI>(m0 + 32 * mi + 8 * q + 4 * h, n0 + r, 32, v);
+    }
+}
+template <class L> struct HasPtr8 { static constexpr bool v = false; };
+template <> struct HasPtr8<LoadK> { static constexpr bool v = true; };
+template <> struct HasPtr8<LoadConvK> { static constexpr bool v = true; };
 
 template <class AL, class BL, class EP, int BK = 32>
 __global__ __launch_bounds__(256, (SrcBf16<AL>::v && SrcBf16<BL>::v) ? 4 : 1)      // bf16-source pairs fit 128 VGPRs: 4 workgroups per CU

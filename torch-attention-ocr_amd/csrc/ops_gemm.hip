@@ -117,6 +117,9 @@ template <class AL, class BL, class EP>
   const int gx = cdiv(N, 128), gy = cdiv(M, 128);
   hipLaunchKernelGGL((gemm_lds_bf16_kernel<AL, BL, EP, 64>), dim3(gx * gy, 1, 1), dim3(256), 0, s, a, b, ep, K, cdiv(K, 64) * 64, gx, gy);
 }
+static bool f32t_ok(const LoadK& l) { return l.vec && l.K % 8 == 0 && (!l.p1 || l.K0 % 8 == 0); }
+static bool f32t_ok(const LoadConvK& l) { return l.C % 8 == 0 && l.C >= 32 && l.K % 8 == 0 && (reinterpret_cast<uintptr_t>(l.src) & 15) == 0; }
+template <class L> static bool f32t_ok(const L&) { return false; }
 template <class AL, class BL, class EP>
 static void launch_big(hipStream_t s, bool bf16, const AL& a, const BL& b, const EP& ep, int M, int N, int K, int ksplit) {
   if (M <= 0 || N <= 0) return;
@@ -126,6 +129,27 @@ static void launch_big(hipStream_t s, bool bf16, const AL& a, const BL& b, const
   // The M/N-contiguous pairs (filter / weight gradients: transposing stagers, split-K) measured SLOWER on it (1.67 -> 1.85 ms) and keep
   // the fragment-from-global kernel.  AOCR_NO_LDS_F32=1 restores that kernel everywhere (bit-identical results).
   const bool no_lds32 = getenv("AOCR_NO_LDS_F32") != nullptr;          // read per call: tests toggle it
+  if constexpr (HasPtr8<AL>::v && HasPtr8<BL>::v) {
+    // round 4: branch-free staging + tile shape by grid size (gemm_f32t_kernel); AOCR_NO_F32T=1 restores gemm_lds_f32_kernel (bit-identical)
+    if (!no_lds32 && !env_is_1("AOCR_NO_F32T") && M >= 96 && N >= 64 && K >= 32 && f32t_ok(a) && f32t_ok(b)) {
+      int kp; split_k(K, 32, ksplit, kp);
+      const char* ft = getenv("AOCR_F32T_TILE");                       // A/B: 1 = 128 x 128, 2 = 64 x 128, 3 = 64 x 64
+      const int force = ft ? atoi(ft) : 0;
+      auto wgs = [&](int bm, int bn) { return (long long)cdiv(M, bm) * cdiv(N, bn) * ksplit; };
+      const int pick = force ? force : (N > 64 && wgs(128, 128) >= 512) ? 1 : (N > 64 && wgs(64, 128) >= 512) ? 2 : 3;
+      if (pick == 1) {
+        const int gx = cdiv(N, 128), gy = cdiv(M, 128);
+        hipLaunchKernelGGL((gemm_f32t_kernel<128, 128, AL, BL, EP>), dim3(gx * gy, 1, ksplit), dim3(256), 0, s, a, b, ep, K, kp, gx, gy);
+      } else if (pick == 2) {
+        const int gx = cdiv(N, 128), gy = cdiv(M, 64);
+        hipLaunchKernelGGL((gemm_f32t_kernel<64, 128, AL, BL, EP>), dim3(gx * gy, 1, ksplit), dim3(256), 0, s, a, b, ep, K, kp, gx, gy);
+      } else {
+        const int gx = cdiv(N, 64), gy = cdiv(M, 64);
+        hipLaunchKernelGGL((gemm_f32t_kernel<64, 64, AL, BL, EP>), dim3(gx * gy, 1, ksplit), dim3(256), 0, s, a, b, ep, K, kp, gx, gy);
+      }
+      return;
+    }
+  }
   if (KContig<AL>::v && KContig<BL>::v && !no_lds32 && M >= 96 && N >= 64 && K >= 32) {
     int kp; split_k(K, 32, ksplit, kp);
     const int gx = cdiv(N, 128), gy = cdiv(M, 128);
