@@ -2678,4 +2678,126 @@ __global__ __launch_bounds__(64 * NW) void gemm_step_kernel(SmallArgs2<AL, LoadK
   }
 }
 
+// ---------------------------------------------------------------------------
+// Round 4: the EXACT-fp32 recurrent-step kernel with wave-private LDS staging (the fp32 sibling of gemm_step_kernel).  In fp32 mode
+// (BASELINE configs[1]) the recurrent steps ran on gemm_small_kernel<false>, whose lanes load their MFMA fragments straight from global
+// memory -- 16 bytes of 32 different rows per wave instruction, ~37 GB/s per CU: 13-30 us per launch at batch 64, 4.2 of the step's
+// 9.5 ms.  Here each of the NW waves streams its contiguous share of K in 32-deep chunks with whole 128-byte lines (8 rows x 128 B per
+// load instruction, two chunks in flight), parks them in its own fp32 LDS image (144-byte pitch: conflict-free ds_read_b128) and feeds
+// v_mfma_f32_32x32x2_f32 from there; no workgroup barrier inside the K loop.  One 32 x 32 output tile per workgroup (NT = 1):
+//   QG = true : gate tiles -- tile column j = gate j >> 3 of hidden unit n0 + (j & 7) (8 units per workgroup, as gemm_small_kernel's QG)
+//   QG = false: 32 plain columns.
+// Requires K % 32 == 0, K0 % 32 == 0 for a two-segment operand (a chunk never straddles the segments), 16-byte aligned rows, N % 32 == 0 (plain) / H % 8 == 0 (QG).
+// ---------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct StepfSrc { const float* p0; const float* p1; int64_t ld0, ld1; int K0; };      // one operand: a buffer or two K segments ([x0 ; x1]); scalars (SGPRs)
+__device__ __forceinline__ void stepf_gload(const StepfSrc& a, const StepfSrc& b, int kc, const int (&arow)[4], const int (&brow)[4], int sp, f32x4 (&xa)[4], f32x4 (&xb)[4]) {
+  const bool sa1 = kc >= a.K0, sb1 = kc >= b.K0;                 // kc is wave-uniform: scalar selects
+  const float* pa = sa1 ? a.p1 : a.p0; const int64_t lda = sa1 ? a.ld1 : a.ld0;
+  const float* pb = sb1 ? b.p1 : b.p0; const int64_t ldb = sb1 ? b.ld1 : b.ld0;
+  const int ka = (sa1 ? kc - a.K0 : kc) + 4 * sp, kb = (sb1 ? kc - b.K0 : kc) + 4 * sp;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xa[i] = *reinterpret_cast<const f32x4*>(pa + (int64_t)arow[i] * lda + ka);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xb[i] = *reinterpret_cast<const f32x4*>(pb + (int64_t)brow[i] * ldb + kb);
+}
+__device__ __forceinline__ void stepf_lwrite(unsigned char* la, unsigned char* lb, int sr, int sp, const f32x4 (&xa)[4], const f32x4 (&xb)[4]) {
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(la + (sr + 8 * i) * STEP_PITCH + sp * 16) = xa[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(lb + (sr + 8 * i) * STEP_PITCH + sp * 16) = xb[i];
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void stepf_mma(const unsigned char* la, const unsigned char* lb, int r, int h, f32x16& acc) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const f32x4 af = *reinterpret_cast<const f32x4*>(la + r * STEP_PITCH + 32 * c + 16 * h);
+    const f32x4 bf = *reinterpret_cast<const f32x4*>(lb + r * STEP_PITCH + 32 * c + 16 * h);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
+  }
+}
+template <bool QG, class EP, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void gemm_step_f32_kernel(SmallArgs2<LoadK, LoadK, EP> zz, int gate_stride) {
+  constexpr int E = 16 / NW, PITCH = STEP_PITCH, WBYTES = 2 * 32 * PITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NW * WBYTES];      // 8 waves: 73.7 KB
+  const SmallArgs<LoadK, LoadK, EP>& g = zz.z[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: the K range and the segment selects stay in SGPRs)
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 32;
+  const int n0 = QG ? blockIdx.x * 8 : blockIdx.x * 32;
+  const int K = g.K;
+  unsigned char* const la = lds + wave * WBYTES;
+  unsigned char* const lb = la + 32 * PITCH;
+  const int kw = ((K / 32 + NW - 1) / NW) * 32;                  // this wave's K range (multiple of 32)
+  const int kbeg = wave * kw, kend = min(K, kbeg + kw);
+  const int sr = lane >> 3, sp = lane & 7;                       // staging: tile rows sr + 8 i, 16-byte piece sp of the 128-byte chunk row
+  int arow[4], brow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    arow[i] = min(m0 + sr + 8 * i, g.a.rows - 1);                // rows past the end: any valid row, result dropped by the epilogue
+    brow[i] = min(QG ? i * gate_stride + n0 + sr : n0 + sr + 8 * i, g.b.rows - 1);
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int orow = m0 + 8 * ((E * wave) >> 2) + 4 * h + ((E * wave) & 3);
+  typename EP::Pre pre[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) pre[e] = g.ep.prefetch(orow + e, QG ? n0 + (r & 7) : n0 + r);
+
+  // (free functions over flat arrays of native vector types: float4 arrays handed to lambdas were demoted to scratch.)  Every chunk's loads are
+  // issued UNCONDITIONALLY -- past the wave's range they re-read its last chunk -- so that the number of loads in flight is the same on every
+  // path into the loop: with conditional prefetches the compiler's vmcnt at the loop head assumed the shortest path and waited for everything.
+  if (kbeg < kend) {
+    const StepfSrc A = {g.a.p0, g.a.p1 ? g.a.p1 : g.a.p0, g.a.ld0, g.a.ld1, g.a.K0}, B = {g.b.p0, g.b.p1 ? g.b.p1 : g.b.p0, g.b.ld0, g.b.ld1, g.b.K0};
+    const int klast = kend - 32;
+    f32x4 a0[4], b0[4], a1[4], b1[4];
+    stepf_gload(A, B, kbeg, arow, brow, sp, a0, b0);
+    stepf_gload(A, B, min(kbeg + 32, klast), arow, brow, sp, a1, b1);
+    int kc = kbeg;
+    for (; kc + 64 <= kend; kc += 64) {                                       // pairs of chunks: no condition inside, so the counts at the loop head are exact
+      stepf_lwrite(la, lb, sr, sp, a0, b0);
+      stepf_gload(A, B, min(kc + 64, klast), arow, brow, sp, a0, b0);        // two chunks ahead: lands during this chunk's and the next chunk's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      stepf_mma(la, lb, r, h, acc);
+      stepf_lwrite(la, lb, sr, sp, a1, b1);
+      stepf_gload(A, B, min(kc + 96, klast), arow, brow, sp, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      stepf_mma(la, lb, r, h, acc);
+    }
+    if (kc < kend) {                                                          // odd chunk count: the last chunk is in a0 / b0
+      stepf_lwrite(la, lb, sr, sp, a0, b0);
+      stepf_mma(la, lb, r, h, acc);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                       // vmcnt(0): the re-read tail chunks are not left in flight across the reduction
+  }
+  // cross-wave reduction: every wave parks its accumulators in its own (now idle) LDS region
+  __builtin_amdgcn_wave_barrier();
+  float* red = reinterpret_cast<float*>(la);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[e * 64 + lane] = acc[e];
+  __syncthreads();
+  const float* r0 = reinterpret_cast<const float*>(lds);
+  constexpr int WSTRIDE = WBYTES / 4;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int idx = (E * wave + e) * 64 + lane;
+    float v = (r0[idx] + r0[idx + WSTRIDE]) + (r0[idx + 2 * WSTRIDE] + r0[idx + 3 * WSTRIDE]);
+#pragma unroll
+    for (int q = 4; q < NW; q += 4)
+      v += (r0[idx + q * WSTRIDE] + r0[idx + (q + 1) * WSTRIDE]) + (r0[idx + (q + 2) * WSTRIDE] + r0[idx + (q + 3) * WSTRIDE]);
+    if constexpr (QG) {                                           // lane r < 8 gathers the four gates of unit n0 + r from lanes r, r + 8, r + 16, r + 24
+      float v4[4];
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt) v4[gt] = __shfl(v, (lane & 32) + 8 * gt + (r & 7), 64);
+      if (r < 8) g.ep.template elem<4>(orow + e, n0 + r, 32, v4, pre[e]);
+    } else {
+      const float v1[1] = {v};
+      g.ep.template elem<1>(orow + e, n0 + r, 32, v1, pre[e]);
+    }
+  }
+}
+
 }  // namespace aocr

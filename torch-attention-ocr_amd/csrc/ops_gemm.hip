@@ -195,6 +195,21 @@ static void launch_small(hipStream_t s, bool bf16, int nz, const ARGS* z, int M,
                        gate_stride);
     return;
   }
+  if constexpr (std::is_same<typename std::decay<decltype(z[0].a)>::type, LoadK>::value && std::is_same<typename std::decay<decltype(z[0].b)>::type, LoadK>::value &&
+                ((GATES && NT == 4) || (!GATES && NT == 1))) {
+    // round 4: wave-private LDS staging with whole-line loads for the exact-fp32 steps too (gemm_step_f32_kernel); AOCR_NO_STEP_F32=1: the
+    // fragment-from-global kernels below
+    bool ok = !env_is_1("AOCR_NO_STEP_F32") && (GATES ? ncols % 8 == 0 : ncols % 32 == 0);
+    for (int i = 0; i < nz && ok; ++i)
+      ok = z[i].K > 0 && z[i].K % 32 == 0 && z[i].a.vec && z[i].b.vec && z[i].a.K == z[i].K && z[i].b.K == z[i].K &&
+           (z[i].a.p1 ? z[i].a.K0 % 32 == 0 : z[i].a.K0 >= z[i].K) && (z[i].b.p1 ? z[i].b.K0 % 32 == 0 : z[i].b.K0 >= z[i].K);
+    if (ok) {
+      typedef typename std::decay<decltype(z[0].ep)>::type EPT;
+      if constexpr (GATES) hipLaunchKernelGGL((gemm_step_f32_kernel<true, EPT>), dim3(ncols / 8, cdiv(M, 32), nz), dim3(512), 0, s, zz, gate_stride);
+      else hipLaunchKernelGGL((gemm_step_f32_kernel<false, EPT>), dim3(ncols / 32, cdiv(M, 32), nz), dim3(512), 0, s, zz, gate_stride);
+      return;
+    }
+  }
   if constexpr (GATES && NT == 4) {
     if (quarter_gate_tiles(ncols, M, nz)) {
       // small batch: 8 hidden units x 4 gates per workgroup (the A and B tiles are loaded straight from global memory here, so
