@@ -23,6 +23,7 @@
 namespace aocr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // one operand fragment of a 32-row tile for one k-chunk: 4 floats (f32 mode, chunk 8)
@@ -946,6 +947,124 @@ __global__ __launch_bounds__(256, (BM + BN <= 128) ? 4 : 2) void gemm_f32t_kerne
       ep.template quad<NI>(m0 + 32 * mi + 8 * q + 4 * h, n0 + r, 32, v);
     }
 }
+// ---------------------------------------------------------------------------
+// Round 4: gemm_f32w_kernel -- exact-fp32 products of two M/N-CONTIGUOUS operands (conv filter gradients: A = dY^T (LoadMN), B = im2col
+// columns (LoadConvXcol); the recurrent weight gradients: LoadMN x LoadMN), K = pixels / time steps.  They ran on gemm_big_kernel<false>
+// (every lane loads its own MFMA fragments from global memory, 0.30-0.33 of the fp32 MFMA peak at C2) because the LDS-tiled kernel's
+// transposing stagers measured slower.  No transpose is needed for v_mfma_f32_32x32x2_f32: a lane supplies ONE A value (row r, k = h) and
+// one B value per MFMA, so the LDS image can stay [k][m] -- exactly how the operands lie in memory.  A tile is 32 k x 128 floats per
+// operand: staged with 16-byte loads along m (512 contiguous bytes per k, branch-free: the address of a piece that is padding / halo is
+// the base pointer and zeros are selected at the LDS store) and read back as ds_read_b32 (32 consecutive dwords per half-wave; the k-row
+// pitch of 136 dwords puts the two halves, 1 k apart, on disjoint banks).  4 waves as 2 x 2, wave tile 64 x 64, double-buffered LDS
+// (69.6 KB: two workgroups per CU), split-K over blockIdx.z as before.  k order per output: steps j = 0..15 of a tile, MFMA j takes k = 2j, 2j+1.
+// ---------------------------------------------------------------------------
+constexpr int F32W_PITCH = 136 * 4;
+template <class LD> struct StagerW;
+// (addresses advance by ADDITION: a 64-bit k * ld product per load made the compiler guard each address computation with a branch)
+template <> struct StagerW<LoadMN> {
+  const float* pk; int64_t ld8; bool mok; int k; f32x4 reg[4]; bool ok[4];
+  __device__ __forceinline__ void init(const LoadMN& l, int mbase, int tid, int kbeg) {
+    const int m = mbase + 4 * (tid & 31); mok = m + 3 < l.rows; k = kbeg + (tid >> 5);
+    pk = l.p + (mok ? m : 0) + (int64_t)k * l.ld; ld8 = 8 * l.ld;
+  }
+  __device__ __forceinline__ void load(const LoadMN& l) {
+    const float* q = pk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ok[i] = mok && k + 8 * i < l.K;
+      reg[i] = *reinterpret_cast<const f32x4*>(ok[i] ? q : l.p);
+      q += ld8;
+    }
+    pk = q; k += 32;
+  }
+};
+// im2col columns: element(n = (tap, ci), k = output pixel (b, py, px)) = x[b][py + kh - pad][px + kw - pad][ci].  The cursor keeps the linear
+// offset of the un-shifted pixel times Cin (host: the tensor has fewer than 2^31 elements) and moves it by additions: +8 pixels per item,
+// + (W - Wo) at the end of an output row, + (H - Ho) W at the end of an image (host: Wo >= 8, so one wrap at most per item).
+template <> struct StagerW<LoadConvXcol> {
+  LoadConvXcol::Ctx4 c; int px, py, k, linc, cbase, dxc, dyc; f32x4 reg[4]; bool ok[4];
+  __device__ __forceinline__ void init(const LoadConvXcol& l, int nbase, int tid, int kbeg) {
+    c = l.row4(nbase + 4 * (tid & 31)); k = kbeg + (tid >> 5);
+    px = k % l.Wo; const int t = k / l.Wo; py = t % l.Ho; const int b = t / l.Ho;
+    linc = ((b * l.H + py) * l.W + px) * l.Cin; cbase = ((c.kh - l.pad) * l.W + (c.kw - l.pad)) * l.Cin + c.ci;
+    dxc = (l.W - l.Wo) * l.Cin; dyc = (l.H - l.Ho) * l.W * l.Cin;
+  }
+  __device__ __forceinline__ void load(const LoadConvXcol& l) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int sy = py + c.kh - l.pad, sx = px + c.kw - l.pad;
+      ok[i] = c.ok && k < l.K && (unsigned)sy < (unsigned)l.H && (unsigned)sx < (unsigned)l.W;
+      reg[i] = *reinterpret_cast<const f32x4*>(l.x + (ok[i] ? linc + cbase : 0));
+      k += 8; px += 8; linc += 8 * l.Cin;
+      const bool wx = px >= l.Wo; px -= wx ? l.Wo : 0; py += wx ? 1 : 0; linc += wx ? dxc : 0;
+      const bool wy = py >= l.Ho; py = wy ? 0 : py; linc += wy ? dyc : 0;
+    }
+  }
+};
+template <class ST> __device__ __forceinline__ void stagerw_store(const ST& st, unsigned char* tile, int tid) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(tile + ((tid >> 5) + 8 * i) * F32W_PITCH + (tid & 31) * 16) = st.ok[i] ? st.reg[i] : z;
+}
+template <class AL, class BL, class EP>
+__global__ __launch_bounds__(256, 2) void gemm_f32w_kernel(AL a, BL b, EP ep, int K, int kper, int gx, int gy) {
+  constexpr int PK = F32W_PITCH, OPB = 32 * PK;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2 * OPB];
+  const int nwg = gx * gy, orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int m_blk = (bid / gx) * 128, n_blk = (bid % gx) * 128;
+  const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = (kend - kbeg + 31) / 32;
+  StagerW<AL> sa; StagerW<BL> sb;
+  sa.init(a, m_blk, tid, kbeg); sb.init(b, n_blk, tid, kbeg);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  if (nk > 0) { sa.load(a); sb.load(b); stagerw_store(sa, &lds[0][0], tid); stagerw_store(sb, &lds[0][OPB], tid); }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) { sa.load(a); sb.load(b); }
+    const unsigned char* la = &lds[buf][h * PK + (wm * 64 + r) * 4];
+    const unsigned char* lb = &lds[buf][OPB + h * PK + (wn * 64 + r) * 4];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { av[i] = *reinterpret_cast<const float*>(la + 2 * j * PK + i * 128); bv[i] = *reinterpret_cast<const float*>(lb + 2 * j * PK + i * 128); }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (kt + 1 < nk) { stagerw_store(sa, &lds[buf ^ 1][0], tid); stagerw_store(sb, &lds[buf ^ 1][OPB], tid); }
+    __syncthreads();
+  }
+  const int m0 = m_blk + wm * 64, n0 = n_blk + wn * 64;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[2][4];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[ni][i] = acc[mi][ni][4 * q + i];
+      ep.template quad<2>(m0 + 32 * mi + 8 * q + 4 * h, n0 + r, 32, v);
+    }
+}
+template <class L> struct HasStagerW { static constexpr bool v = false; };
+template <> struct HasStagerW<LoadMN> { static constexpr bool v = true; };
+template <> struct HasStagerW<LoadConvXcol> { static constexpr bool v = true; };
+
 template <class L> struct HasPtr8 { static constexpr bool v = false; };
 template <> struct HasPtr8<LoadK> { static constexpr bool v = true; };
 template <> struct HasPtr8<LoadConvK> { static constexpr bool v = true; };
@@ -2689,7 +2808,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_step_kernel(SmallArgs2<AL, LoadK
 //   QG = false: 32 plain columns.
 // Requires K % 32 == 0, K0 % 32 == 0 for a two-segment operand (a chunk never straddles the segments), 16-byte aligned rows, N % 32 == 0 (plain) / H % 8 == 0 (QG).
 // ---------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct StepfSrc { const float* p0; const float* p1; int64_t ld0, ld1; int K0; };      // one operand: a buffer or two K segments ([x0 ; x1]); scalars (SGPRs)
 __device__ __forceinline__ void stepf_gload(const StepfSrc& a, const StepfSrc& b, int kc, const int (&arow)[4], const int (&brow)[4], int sp, f32x4 (&xa)[4], f32x4 (&xb)[4]) {
   const bool sa1 = kc >= a.K0, sb1 = kc >= b.K0;                 // kc is wave-uniform: scalar selects

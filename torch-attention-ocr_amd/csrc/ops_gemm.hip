@@ -120,6 +120,12 @@ template <class AL, class BL, class EP>
 static bool f32t_ok(const LoadK& l) { return l.vec && l.K % 8 == 0 && (!l.p1 || l.K0 % 8 == 0); }
 static bool f32t_ok(const LoadConvK& l) { return l.C % 8 == 0 && l.C >= 32 && l.K % 8 == 0 && (reinterpret_cast<uintptr_t>(l.src) & 15) == 0; }
 template <class L> static bool f32t_ok(const L&) { return false; }
+static bool f32w_ok(const LoadMN& l) { return l.vec && l.rows % 4 == 0; }
+static bool f32w_ok(const LoadConvXcol& l) {
+  const long long pixels = ((long long)l.K / ((long long)l.Ho * l.Wo) + 1) * l.H * l.W;          // K = B Ho Wo output pixels
+  return l.Cin % 4 == 0 && l.N % 4 == 0 && l.Wo >= 8 && (reinterpret_cast<uintptr_t>(l.x) & 15) == 0 && pixels * l.Cin < (1ll << 31);
+}
+template <class L> static bool f32w_ok(const L&) { return false; }
 template <class AL, class BL, class EP>
 static void launch_big(hipStream_t s, bool bf16, const AL& a, const BL& b, const EP& ep, int M, int N, int K, int ksplit) {
   if (M <= 0 || N <= 0) return;
@@ -155,6 +161,16 @@ static void launch_big(hipStream_t s, bool bf16, const AL& a, const BL& b, const
     const int gx = cdiv(N, 128), gy = cdiv(M, 128);
     hipLaunchKernelGGL((gemm_lds_f32_kernel<AL, BL, EP>), dim3(gx * gy, 1, ksplit), dim3(256), 0, s, a, b, ep, K, kp, gx, gy);
     return;
+  }
+  if constexpr (HasStagerW<AL>::v && HasStagerW<BL>::v) {
+    // round 4: M/N-contiguous pairs (filter gradients, recurrent weight gradients) through a [k][m] LDS image (gemm_f32w_kernel);
+    // AOCR_NO_F32W=1 restores the fragment-from-global kernel
+    if (!env_is_1("AOCR_NO_F32W") && M >= 64 && N >= 64 && K >= 64 && f32w_ok(a) && f32w_ok(b)) {
+      int kp; split_k(K, 32, ksplit, kp);
+      const int gx = cdiv(N, 128), gy = cdiv(M, 128);
+      hipLaunchKernelGGL((gemm_f32w_kernel<AL, BL, EP>), dim3(gx * gy, 1, ksplit), dim3(256), 0, s, a, b, ep, K, kp, gx, gy);
+      return;
+    }
   }
   int kper; split_k(K, 8, ksplit, kper);
   hipLaunchKernelGGL((gemm_big_kernel<false, 2, 2, AL, BL, EP>), dim3(cdiv(N, 128), cdiv(M, 128), ksplit), dim3(256), 0, s, a, b, ep, K, kper);
