@@ -137,7 +137,7 @@ static void launch_big(hipStream_t s, bool bf16, const AL& a, const BL& b, const
   const bool no_lds32 = getenv("AOCR_NO_LDS_F32") != nullptr;          // read per call: tests toggle it
   if constexpr (HasPtr8<AL>::v && HasPtr8<BL>::v) {
     // round 4: branch-free staging + tile shape by grid size (gemm_f32t_kernel); AOCR_NO_F32T=1 restores gemm_lds_f32_kernel (bit-identical)
-    if (!no_lds32 && !env_is_1("AOCR_NO_F32T") && M >= 96 && N >= 64 && K >= 32 && f32t_ok(a) && f32t_ok(b)) {
+    if (!no_lds32 && !env_is_1("AOCR_NO_F32T") && M >= 96 && N >= 16 && K >= 32 && f32t_ok(a) && f32t_ok(b)) {      // (N < 64: the projector, 39 columns: rows past N stage zeros)
       int kp; split_k(K, 32, ksplit, kp);
       const char* ft = getenv("AOCR_F32T_TILE");                       // A/B: 1 = 128 x 128, 2 = 64 x 128, 3 = 64 x 64
       const int force = ft ? atoi(ft) : 0;
@@ -221,7 +221,13 @@ static void launch_small(hipStream_t s, bool bf16, int nz, const ARGS* z, int M,
            (z[i].a.p1 ? z[i].a.K0 % 32 == 0 : z[i].a.K0 >= z[i].K) && (z[i].b.p1 ? z[i].b.K0 % 32 == 0 : z[i].b.K0 >= z[i].K);
     if (ok) {
       typedef typename std::decay<decltype(z[0].ep)>::type EPT;
+      // AOCR_STEP_F32_W16=1: 16 waves (147 KB of LDS, one workgroup per CU) where K is deep and the launch covers less than half the chip (K = 4 Hd = 2048
+      // of the decoder's d h products at batch 64: 32-96 workgroups x 8 chunks per wave).  Measured SLOWER (those launches 15.5-16.6 -> 17.5-18.2 us,
+      // C2 7.67 -> 7.81 ms per step: the 1024-thread workgroup's launch and 16-way reduction cost more than the shorter K loop saves): opt-in.
+      const int wgs = (GATES ? ncols / 8 : ncols / 32) * cdiv(M, 32) * nz;
+      const bool deep = env_is_1("AOCR_STEP_F32_W16") && z[0].K >= 2048 && wgs <= 128;
       if constexpr (GATES) hipLaunchKernelGGL((gemm_step_f32_kernel<true, EPT>), dim3(ncols / 8, cdiv(M, 32), nz), dim3(512), 0, s, zz, gate_stride);
+      else if (deep) hipLaunchKernelGGL((gemm_step_f32_kernel<false, EPT, 16>), dim3(ncols / 32, cdiv(M, 32), nz), dim3(1024), 0, s, zz, gate_stride);
       else hipLaunchKernelGGL((gemm_step_f32_kernel<false, EPT>), dim3(ncols / 32, cdiv(M, 32), nz), dim3(512), 0, s, zz, gate_stride);
       return;
     }
