@@ -1176,3 +1176,34 @@ def test_f32t_kernel_matches_lds_f32_kernel(cuda, monkeypatch, B, W, tile):
         else:
             assert torch.allclose(a["grads"][k], b["grads"][k], rtol=1e-5, atol=1e-7), k
     print(f"[parity] f32t (tile '{tile or 'auto'}') vs gemm_lds_f32_kernel, B={B} W={W}: conv6 / feats / logits / dfeats bit-identical, loss {a['loss']:.6f}")
+
+
+@pytest.mark.parametrize("B,W", [(6, 72), (64, 100), (256, 256)])
+def test_embedding_token_table_matches_tensor_path(cuda, monkeypatch, B, W):
+    """Round 4: with the whole-sequence decoder kernels the embedding part of the first layer's gate input is read from the per-token table
+    [V][4 Hd] (lookup W_i2h[:, :E]^T + biases) and the backward pass sums d z by token (segsum_by_token) instead of gathering a (L B, E)
+    tensor, multiplying it, and scattering its gradient back.  Against AOCR_NO_EMB_TABLE=1: the forward values are the same dot products --
+    logits and loss BIT-identical; the three gradients it touches (lookup, the embedding columns of W_i2h, both biases of layer 1) are sums
+    in a different order and with the V-sized products in exact fp32 instead of bf16 operands."""
+    cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for off in ("1", "0"):
+        if off == "1":
+            monkeypatch.setenv("AOCR_NO_EMB_TABLE", "1")
+        else:
+            monkeypatch.delenv("AOCR_NO_EMB_TABLE", raising=False)
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=9, compute="bf16", max_decoder_l=10, max_beam=1)
+        loss = m.train_forward_backward(batch)
+        out[off] = dict(loss=loss, logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        assert m.cluster_status() == 0
+        m.shutdown()
+    a, b = out["1"], out["0"]
+    assert torch.equal(a["logits"], b["logits"]) and a["loss"] == b["loss"]
+    worst = 0.0
+    for k in a["grads"]:
+        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):
+            continue                                             # bias in front of a BatchNorm: exact gradient 0, rounding noise only
+        e = relerr(b["grads"][k], a["grads"][k]); worst = max(worst, e)
+        # lookup / w_i embedding columns / layer-1 biases: bf16-operand products replaced by exact fp32 sums; everything else: the same kernels (split-K atomics only)
+        assert e < (6e-3 if ("lookup" in k or k.startswith("dec.l1.")) else 1e-4), (k, e)
+    print(f"[parity] embedding token table vs tensor path, B={B} W={W}: logits / loss bit-identical, worst gradient difference {worst:.2e}")

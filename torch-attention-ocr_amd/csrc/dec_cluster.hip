@@ -289,9 +289,17 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
   for (int rt = 0; rt < 2; ++rt) {
     const int row = min(row0 + 16 * rt + c16, B - 1);
     c1[rt] = p.cs[0][(size_t)row * HD + unit]; c2[rt] = p.cs[1][(size_t)row * HD + unit];
-    const size_t zrow = DEC ? (size_t)(p.tok0[(size_t)row * p.tok0_stride] - 1) : (size_t)row;      // DEC: the per-token table row of the GO token
+    const size_t zrow = DEC ? (size_t)(p.tok0[(size_t)row * p.tok0_stride] - 1)                      // DEC: the per-token table row of the GO token
+                            : (p.zx_tok ? (size_t)(min(max(p.zx_tok[(int64_t)row * p.zx_sb], 1), p.V) - 1) : (size_t)row);   // teacher-forced with the table: the token of step 0
 #pragma unroll
     for (int i = 0; i < 4; ++i) zxr[rt][i] = p.zx1[zrow * 4 * HD + i * HD + unit];
+  }
+  int ntok[2] = {1, 1};                                               // teacher-forced with the table: the tokens of the NEXT step (loaded a step ahead: no dependent load on the step's path)
+  if constexpr (!DEC) {
+    if (p.zx_tok) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) ntok[rt] = p.zx_tok[(int64_t)min(1, L - 1) * p.zx_st + (int64_t)min(row0 + 16 * rt + c16, B - 1) * p.zx_sb];
+    }
   }
   if constexpr (DEC) {
     for (int i = tid; i < 640; i += 256) { const int v = i >> 4, u = i & 15; wos[i] = v < p.V ? p.wo[(size_t)v * HD + 16 * member + u] : 0.f; }
@@ -495,8 +503,10 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
           const int row = min(row0 + 16 * rt + oc16, B - 1);
+          const size_t zr = p.zx_tok ? (size_t)(min(max(ntok[rt], 1), p.V) - 1) : (size_t)tn * B + row;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) zxr[rt][i] = p.zx1[((size_t)tn * B + row) * 4 * HD + i * HD + ounit];
+          for (int i = 0; i < 4; ++i) zxr[rt][i] = p.zx1[zr * 4 * HD + i * HD + ounit];
+          if (p.zx_tok) ntok[rt] = p.zx_tok[(int64_t)min(t + 2, L - 1) * p.zx_st + (int64_t)row * p.zx_sb];
         }
       }
       const unsigned char* hrow = H2 + (size_t)member * PA + 16 * q;

@@ -136,7 +136,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     for (int l = 0; l < m->Ld; ++l) { m->dhs_b[l] = hb((L + 1) * B * Hd); m->ddz_b[l] = hb(L * B * 4 * Hd); }
     m->out_b = hb((L + 1) * B * Hd); m->cat_b = hb(L * B * 2 * Hd); m->dpre_b = hb(L * B * Hd); m->dq_b = hb(L * B * Hd);
   }
-  m->emb_all = a.get<float>(L * B * E); m->zx1_all = a.get<float>(L * B * 4 * Hd);
+  m->emb_all = a.get<float>(L * B * E); m->zx1_all = a.get<float>(L * B * 4 * Hd); m->emb_seg = a.get<float>((size_t)m->V * 4 * Hd); m->emb_index = a.get<int>(segsum_index_ints((size_t)L * B, m->V));
   for (int l = 0; l < m->Ld; ++l) {
     m->dhs[l] = a.get<float>((L + 1) * B * Hd); m->dcs[l] = a.get<float>((L + 1) * B * Hd);
     m->dgates[l] = a.get<float>(L * B * 4 * Hd); m->ddz[l] = a.get<float>(L * B * 4 * Hd);
@@ -916,24 +916,34 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
   const int B = d.B, T = d.T, L = d.L, Hd = m->Hd, E = m->E;
   const size_t slot = (size_t)B * Hd;
   prof_mark(m, AOCR_PROF_RNN_GEMM);
-  embedding_gather(s, m->lookup, tgt, st, sb, m->emb_all, L, B, E);
   const LstmP& p1 = m->dec[0];
-  gemm(s, bf, m->emb_all, E, true, p1.wi, p1.in, true, m->zx1_all, 4 * Hd, L * B, 4 * Hd, E, p1.bi, p1.bh, 0);
+  const bool sh = m->bf16 && m->out_b != nullptr;
+  const bool drop = keep_gates && m->drop_on;                       // training only
+  const bool drop_cl = drop && m->dhm_b[0] && !getenv("AOCR_NO_DEC_CLUSTER_DROP");     // round 3: the cluster kernels evaluate the masks themselves
+  const bool use_cl = sh && (!drop || drop_cl) && dec_cluster_ok(m, T, L);
+  // Round 4: the embedding part of the first layer's gate input depends on the token only (nn.LookupTable -> W_i2h[:, :E], LSTM.lua:55-56,79-80).
+  // The whole-sequence kernel reads it from the per-token table [V][4 Hd] (what the decode path already does) instead of a (L B, 4 Hd) tensor
+  // produced by a gather + a K = E product: the same dot products (same kernel, same k order: bit-identical rows), 39 rows instead of 6144 at C3,
+  // and 50 MB less written and read per step.  The backward pass follows (decoder_backward: sums of d z by token).  AOCR_NO_EMB_TABLE=1: the tensor.
+  m->emb_table = use_cl && segsum_supported(4 * Hd, m->V, E) && !getenv("AOCR_NO_EMB_TABLE");
+  if (m->emb_table) gemm(s, bf, m->lookup, E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * Hd, m->V, 4 * Hd, E, p1.bi, p1.bh, 0);
+  else {
+    embedding_gather(s, m->lookup, tgt, st, sb, m->emb_all, L, B, E);
+    gemm(s, bf, m->emb_all, E, true, p1.wi, p1.in, true, m->zx1_all, 4 * Hd, L * B, 4 * Hd, E, p1.bi, p1.bh, 0);
+  }
   float* c0[MAXL]; float* h0[MAXL];
   for (int l = 0; l < m->Ld; ++l) { c0[l] = m->dcs[l]; h0[l] = m->dhs[l]; }
-  const bool sh = m->bf16 && m->out_b != nullptr;
   prof_mark(m, AOCR_PROF_DEC_FWD);
   dec_init_state(m, d, c0, h0, m->out_all, B, sh);
   m->dgates_il = false;
-  const bool drop = keep_gates && m->drop_on;                       // training only
-  const bool drop_cl = drop && m->dhm_b[0] && !getenv("AOCR_NO_DEC_CLUSTER_DROP");     // round 3: the cluster kernels evaluate the masks themselves
-  if (sh && (!drop || drop_cl) && dec_cluster_ok(m, T, L)) {
+  if (use_cl) {
     // scores against the pre-multiplied context: ctx[t] . (W_a h) = (ctx W_a)[t] . h, LSTM.lua:131-137
     if (!m->ctxa_fresh) gemm_hh_shadow(s, m->context_b, Hd, m->swa.wtb, Hd, m->dctx, Hd, m->ctxa_b, Hd, B * T, Hd, Hd);
     m->ctxa_fresh = false;
     DecClFwdArgs a; a.B = B; a.T = T; a.L = L; a.epoch = next_epoch(m);
     a.w1i = m->dec[0].swi.wb; a.w1h = m->dec[0].swh.wb; a.w2i = m->dec[1].swi.wb; a.w2h = m->dec[1].swh.wb; a.wc = m->swc.wb;
     a.b2i = m->dec[1].bi; a.b2h = m->dec[1].bh; a.zx1 = m->zx1_all; a.ctxb = m->context_b; a.ctxa = m->ctxa_b;
+    if (m->emb_table) { a.zx1 = m->bzx_tab; a.zx_tok = tgt; a.zx_st = st; a.zx_sb = sb; a.V = m->V; }
     for (int l = 0; l < 2; ++l) { a.cs[l] = m->dcs[l]; a.hsb[l] = m->dhs_b[l]; a.gates[l] = keep_gates ? m->dgates[l] : nullptr; }
     a.a_all = m->a_all; a.out = m->out_all; a.cat_b = m->cat_b; a.out_b = m->out_b;
     a.xbuf = m->dc_xbuf; a.xtab = m->dc_xtab; a.err = m->cl_err;
@@ -1121,6 +1131,13 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
     const bf16_t* dzb = sh ? m->ddz_b[l] : nullptr;
     wg[nwg++] = WGradProblem{dz, 4 * Hd, m->dhs[l], Hd, p.dwh, Hd, 4 * Hd, Hd, rows, dzb, sh ? m->dhs_b[l] : nullptr};
     if (cj.n >= 8) colsum_flush(s, cj);
+    if (l == 0 && m->emb_table) {
+      // the embedding side through the sums of d z by token (ops_misc.hip: segsum_by_token): S [V][4 Hd] in one pass over d z, which also yields
+      // the layer's bias gradients; then d lookup += S W_i2h[:, :E] and d W_i2h[:, :E] = S^T lookup -- two V-sized products in exact fp32
+      segsum_by_token(s, dz, 4 * Hd, tgt, 1, L, L, B, 4 * Hd, V, m->emb_seg, m->emb_index, p.dbi, p.dbh, p.wi, p.in, m->lookup, E, m->dlookup, p.dwi);
+      if (m->cfg.input_feed) wg[nwg++] = WGradProblem{dz, 4 * Hd, m->out_all, Hd, p.dwi + E, p.in, 4 * Hd, Hd, rows, dzb, sh ? m->out_b : nullptr};
+      continue;
+    }
     colsum_defer(cj, dz, 4 * Hd, rows, 4 * Hd, p.dbi, p.dbh);
     if (l == 0) {
       wg[nwg++] = WGradProblem{dz, 4 * Hd, m->emb_all, E, p.dwi, p.in, 4 * Hd, E, rows};

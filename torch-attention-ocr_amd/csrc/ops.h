@@ -172,6 +172,12 @@ void colsum_defer(ColsumJobs& g, const float* A, int64_t ld, int64_t rows, int N
 void colsum_flush(hipStream_t s, ColsumJobs& g);
 void embedding_gather(hipStream_t s, const float* table, const int32_t* tok, int64_t stride_t, int64_t stride_b, float* out,
                       int L, int B, int E);
+// S [V][ncols] = rows of dz summed by their token (zeroed here; index: segsum_index_ints(rows, V) ints of scratch); then db1 / db2 += the column
+// totals, dlookup [V][E] += S W[:, :E] (W [ncols][ldw]) and dW [ncols][ldw] (first E columns) += S^T lookup
+bool segsum_supported(int ncols, int V, int E);
+size_t segsum_index_ints(int rows, int V);
+void segsum_by_token(hipStream_t s, const float* dz, int64_t ld, const int32_t* tok, int64_t st, int64_t sb, int L, int B, int ncols, int V, float* S, int* index,
+                     float* db1, float* db2, const float* W, int64_t ldw, const float* lookup, int E, float* dlookup, float* dW);
 void embedding_scatter_accum(hipStream_t s, const float* demb, const int32_t* tok, int64_t stride_t, int64_t stride_b,
                              float* dtable, int L, int B, int E, int V);
 void dpre_tanh(hipStream_t s, const float* g1, const float* g2, const float* out, float* dpre, int64_t n, bf16_t* dpreb = nullptr, const DropSpec* drop = nullptr);
@@ -261,6 +267,9 @@ struct DecClFwdArgs {
   // nn.Dropout(p) (training, LSTM.lua:68-69,116-118): masks of layer 2's input (site 2) and of the attention output (site 16), flat index
   // = step * B * Hd + row * Hd + unit added to .off = 0; hm_b [L][B][Hd]: the masked bf16 copy of h1 (operand of layer 2 and of its weight gradient)
   DropSpec drop_h, drop_out; bf16_t* hm_b = nullptr;
+  // round 4, teacher-forced loop: zx1 as the per-token table [V][4 Hd] too (zx_tok = the input tokens, token of (step t, row b) = zx_tok[t zx_st + b zx_sb]):
+  // no (L B, 4 Hd) gate-input tensor is written or read; V must be set
+  const int32_t* zx_tok = nullptr; int64_t zx_st = 0, zx_sb = 0;
 };
 // decoder BPTT in one launch (dec_cluster.hip); reads what the forward cluster kernel saved (interleaved gates)
 struct DecClBwdArgs {

@@ -1507,6 +1507,128 @@ void embedding_scatter_accum(hipStream_t s, const float* demb, const int32_t* to
   hipLaunchKernelGGL(emb_scatter_kernel, dim3(V, slices), dim3(256), (size_t)256 * sizeof(float), s, demb, tok, st, sb, dtable, L, B, E);
 }
 
+// Round 4: the embedding side of the first decoder layer without the (rows, E) detour.  Every row's embedding is one of V table rows, so
+//   d lookup[v] = (sum of d z over the rows whose token is v) . W_i2h[:, :E],   d W_i2h[:, :E] = (those sums)^T . lookup,   d b = their total:
+// one pass over d z that sums rows BY TOKEN (S [V][ncols]) replaces the K = 4 Hd product into d emb, its scatter, the (d z, emb) weight-gradient
+// problem and the bias column-sum pass over the same 50 MB (LSTM.lua:55-56 nn.LookupTable accGradParameters; model.lua:643-661).
+// The rows are first grouped by token (one small workgroup: counting sort of the L B tokens into an index list + a list of work items of at
+// most SEG_CHUNK rows of ONE token), then every work item sums its rows in registers -- whole 4 KB row pieces, eight rows in flight -- and adds
+// its float4 to S with one atomic per component.  (First version: every workgroup kept [V][256] LDS accumulators over a slice of rows and
+// issued one global atomic per (token seen, column): 3.9 M device-scope atomics, 49 us for the 50 MB at C3.)
+constexpr int SEG_CHUNK = 48;
+__global__ __launch_bounds__(1024) void token_sort_kernel(const int32_t* __restrict__ tok, int64_t st, int64_t sb, int rows, int B, int V,
+                                                          int* __restrict__ order, int* __restrict__ items /* [n][3] = token, begin, end */, int* __restrict__ nitems) {
+  __shared__ int cnt[64], pos[64], start[64], ifirst[64];
+  const int tid = threadIdx.x;
+  if (tid < 64) cnt[tid] = 0;
+  __syncthreads();
+  int mine[8];                                                  // this thread's rows (rows <= 8192 per call; more rows loop again below)
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int r = tid + 1024 * u; mine[u] = -1;
+    if (r < rows) { const int t = r / B, b = r - t * B; mine[u] = min(max(tok[t * st + b * sb], 1), V) - 1; atomicAdd(&cnt[mine[u]], 1); }
+  }
+  for (int r = tid + 8192; r < rows; r += 1024) { const int t = r / B, b = r - t * B; atomicAdd(&cnt[min(max(tok[t * st + b * sb], 1), V) - 1], 1); }
+  __syncthreads();
+  if (tid == 0) {
+    int a = 0, n = 0;
+    for (int v = 0; v < V; ++v) { start[v] = a; pos[v] = a; ifirst[v] = n; a += cnt[v]; n += (cnt[v] + SEG_CHUNK - 1) / SEG_CHUNK; }
+    *nitems = n;
+  }
+  __syncthreads();
+  if (tid < V) {                                                // every token emits its own work items
+    int n = ifirst[tid];
+    for (int b0 = start[tid]; b0 < start[tid] + cnt[tid]; b0 += SEG_CHUNK, ++n) { items[3 * n] = tid; items[3 * n + 1] = b0; items[3 * n + 2] = min(start[tid] + cnt[tid], b0 + SEG_CHUNK); }
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) if (mine[u] >= 0) order[atomicAdd(&pos[mine[u]], 1)] = tid + 1024 * u;
+  for (int r = tid + 8192; r < rows; r += 1024) { const int t = r / B, b = r - t * B; order[atomicAdd(&pos[min(max(tok[t * st + b * sb], 1), V) - 1], 1)] = r; }
+}
+__global__ __launch_bounds__(256) void segsum_sorted_kernel(const float* __restrict__ dz, int64_t ld, const int* __restrict__ order, const int* __restrict__ items,
+                                                            const int* __restrict__ nitems, int ncols, float* __restrict__ S) {
+  __shared__ int idx[SEG_CHUNK];
+  if ((int)blockIdx.x >= *nitems) return;
+  const int v = items[3 * blockIdx.x], r0 = items[3 * blockIdx.x + 1], n = items[3 * blockIdx.x + 2] - r0;
+  if ((int)threadIdx.x < n) idx[threadIdx.x] = order[r0 + threadIdx.x];      // the item's row list once, through LDS: the row loads below do not wait for an index load each
+  __syncthreads();
+  const int col = (blockIdx.y * 256 + threadIdx.x) * 4;
+  if (col >= ncols) return;                                      // (ncols % 4 == 0)
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+  int r = 0;
+  for (; r + 16 <= n; r += 16) {                                 // sixteen rows in flight
+    float4 x[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) x[u] = *reinterpret_cast<const float4*>(dz + (int64_t)idx[r + u] * ld + col);
+#pragma unroll
+    for (int u = 0; u < 16; u += 2) { a.x += x[u].x; a.y += x[u].y; a.z += x[u].z; a.w += x[u].w; c.x += x[u + 1].x; c.y += x[u + 1].y; c.z += x[u + 1].z; c.w += x[u + 1].w; }
+  }
+  for (; r < n; ++r) { const float4 x = *reinterpret_cast<const float4*>(dz + (int64_t)idx[r] * ld + col); a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; }
+  float* o = S + (int64_t)v * ncols + col;
+  atomicAdd(o, a.x + c.x); atomicAdd(o + 1, a.y + c.y); atomicAdd(o + 2, a.z + c.z); atomicAdd(o + 3, a.w + c.w);
+}
+// what hangs off S [V][ncols] (ncols = 4 Hd): the bias gradients (column totals), d lookup [V][E] += S W[:, :E] (W [ncols][ldw]) and
+// d W[:, :E] += S^T lookup -- V-sized products in exact fp32
+__global__ __launch_bounds__(256) void segsum_bias_kernel(const float* __restrict__ S, int V, int ncols, float* __restrict__ db1, float* __restrict__ db2) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= ncols) return;
+  float s = 0.f;
+  for (int v0 = 0; v0 < V; v0 += 8) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = v0 + u < V ? S[(int64_t)(v0 + u) * ncols + col] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += x[u];
+  }
+  db1[col] += s; if (db2) db2[col] += s;
+}
+__global__ __launch_bounds__(256) void segsum_dlookup_kernel(const float* __restrict__ S, int V, int ncols, const float* __restrict__ W, int64_t ldw, int E, float* __restrict__ dlookup) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // one wave per output (v, e)
+  if (o >= V * E) return;
+  const int v = o / E, e = o - v * E;
+  float acc = 0.f;
+  for (int j0 = lane; j0 < ncols; j0 += 64 * 8) {
+    float sv[8], w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int j = j0 + 64 * u; const bool ok = j < ncols; sv[u] = ok ? S[(int64_t)v * ncols + j] : 0.f; w[u] = ok ? W[(int64_t)j * ldw + e] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = fmaf(sv[u], w[u], acc);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if (lane == 0) dlookup[o] += acc;
+}
+__global__ __launch_bounds__(256) void segsum_dw_kernel(const float* __restrict__ S, int V, int ncols, const float* __restrict__ lookup, int E, float* __restrict__ dW, int64_t ldw) {
+  extern __shared__ float lk[];                                 // [V][E]
+  for (int i = threadIdx.x; i < V * E; i += 256) lk[i] = lookup[i];
+  __syncthreads();
+  const int o = blockIdx.x * 256 + threadIdx.x;                 // one thread per output (j, e)
+  if (o >= ncols * E) return;
+  const int j = o / E, e = o - j * E;
+  float acc = 0.f;
+  for (int v0 = 0; v0 < V; v0 += 8) {
+    float sv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sv[u] = v0 + u < V ? S[(int64_t)(v0 + u) * ncols + j] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (v0 + u < V) acc = fmaf(sv[u], lk[(v0 + u) * E + e], acc);
+  }
+  dW[(int64_t)j * ldw + e] += acc;
+}
+bool segsum_supported(int ncols, int V, int E) { return ncols % 4 == 0 && V <= 64 && V * E <= 8192; }
+size_t segsum_index_ints(int rows, int V) { return (size_t)rows + 3 * ((size_t)rows / SEG_CHUNK + V + 8) + 8; }
+void segsum_by_token(hipStream_t s, const float* dz, int64_t ld, const int32_t* tok, int64_t st, int64_t sb, int L, int B, int ncols, int V, float* S, int* index,
+                     float* db1, float* db2, const float* W, int64_t ldw, const float* lookup, int E, float* dlookup, float* dW) {
+  const int rows = L * B;
+  int* order = index; int* nitems = index + rows; int* items = nitems + 8;
+  const int max_items = rows / SEG_CHUNK + V + 1;
+  (void)hipMemsetAsync(S, 0, (size_t)V * ncols * sizeof(float), s);
+  hipLaunchKernelGGL(token_sort_kernel, dim3(1), dim3(1024), 0, s, tok, st, sb, rows, B, V, order, items, nitems);
+  hipLaunchKernelGGL(segsum_sorted_kernel, dim3(max_items, cdiv(ncols, 1024)), dim3(256), 0, s, dz, ld, order, items, nitems, ncols, S);
+  hipLaunchKernelGGL(segsum_bias_kernel, dim3(cdiv(ncols, 256)), dim3(256), 0, s, S, V, ncols, db1, db2);
+  hipLaunchKernelGGL(segsum_dlookup_kernel, dim3(cdiv(V * E, 4)), dim3(256), 0, s, S, V, ncols, W, ldw, E, dlookup);
+  hipLaunchKernelGGL(segsum_dw_kernel, dim3(cdiv((int64_t)ncols * E, 256)), dim3(256), (size_t)V * E * sizeof(float), s, S, V, ncols, lookup, E, dW, ldw);
+}
+
 __global__ __launch_bounds__(256) void dpre_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
                                                    const float* __restrict__ out, float* __restrict__ dpre, int64_t n, bf16_t* __restrict__ dpreb, DropSpec drop) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
