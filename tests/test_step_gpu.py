@@ -1207,3 +1207,32 @@ def test_embedding_token_table_matches_tensor_path(cuda, monkeypatch, B, W):
         # lookup / w_i embedding columns / layer-1 biases: bf16-operand products replaced by exact fp32 sums; everything else: the same kernels (split-K atomics only)
         assert e < (6e-3 if ("lookup" in k or k.startswith("dec.l1.")) else 1e-4), (k, e)
     print(f"[parity] embedding token table vs tensor path, B={B} W={W}: logits / loss bit-identical, worst gradient difference {worst:.2e}")
+
+
+def test_grouped_dma_weight_gradients_match_transposed_read_kernel(cuda, monkeypatch):
+    """Round 4: the hoisted recurrent weight gradients (dW = dz^T x over all time steps) with full 256 x 256 tiles and K >= 2048 run on
+    wgrad_dma_grouped_kernel (LDS-DMA ring, slabs per k range + wgrad_slab_reduce_kernel), the encoder's on the side stream beside the
+    decoder's.  Against AOCR_NO_WGRAD_DMA_GROUPED=1 + AOCR_NO_ENC_WGRAD_SIDE=1 (wgrad_tr_grouped_kernel, 128 x 128 tiles, atomics): the
+    same bf16 products summed in a different order -- every gradient within 2e-5 of the other path's, everything upstream bit-identical.
+    B = 128, W = 260: K = L B = 1280 ... the decoder problems need K >= 2048, so L = 17 (max_decoder_l 18) and the encoder's K = T B = 8192."""
+    cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for off in ("1", "0"):
+        if off == "1":
+            monkeypatch.setenv("AOCR_NO_WGRAD_DMA_GROUPED", "1"); monkeypatch.setenv("AOCR_NO_ENC_WGRAD_SIDE", "1")
+        else:
+            monkeypatch.delenv("AOCR_NO_WGRAD_DMA_GROUPED", raising=False); monkeypatch.delenv("AOCR_NO_ENC_WGRAD_SIDE", raising=False)
+        m, O, ocfg, P, st, batch = make(cfg, B=128, W=260, maxlen=16, compute="bf16", max_decoder_l=18, max_beam=1)
+        loss = m.train_forward_backward(batch)
+        out[off] = dict(loss=loss, logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        assert m.cluster_status() == 0
+        m.shutdown()
+    a, b = out["1"], out["0"]
+    assert torch.equal(a["logits"], b["logits"]) and a["loss"] == b["loss"]
+    worst = 0.0
+    for k in a["grads"]:
+        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):
+            continue
+        e = relerr(b["grads"][k], a["grads"][k]); worst = max(worst, e)
+        assert e < 2e-5, (k, e)
+    print(f"[parity] grouped LDS-DMA weight gradients vs transposed-read kernel: worst gradient difference {worst:.2e}")

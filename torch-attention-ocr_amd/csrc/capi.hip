@@ -156,6 +156,10 @@ int aocr_model_destroy(aocr_model* m) {
   if (m && m->side) { hipStreamSynchronize(m->side); hipStreamDestroy(m->side); }
   if (m && m->side_go) hipEventDestroy(m->side_go);
   if (m && m->side_done) hipEventDestroy(m->side_done);
+  if (m && m->side2_done) hipEventDestroy(m->side2_done);
+  if (m && m->side2) hipStreamDestroy(m->side2);
+  if (m && m->tab_done) hipEventDestroy(m->tab_done);
+  if (m && m->enc_ev) hipEventDestroy(m->enc_ev);
   if (m) for (hipEvent_t e : m->prof_ev) hipEventDestroy(e);
   if (m) for (hipStream_t ls : m->lay_s) if (ls) { hipStreamSynchronize(ls); hipStreamDestroy(ls); }
   if (m) for (hipEvent_t e : m->lay_ev) hipEventDestroy(e);
@@ -259,6 +263,7 @@ int aocr_train_forward_backward(aocr_model* m, const float* images_dev, const in
   prof_mark(m, AOCR_PROF_OTHER);
   hipMemsetAsync(m->grads, 0, (size_t)m->layout.group_off[AOCR_NUM_GROUPS] * sizeof(float), m->s);      // model.lua:637-639
   m->drop_on = m->drop_thr != 0;                                          // nn.Dropout is active in training() mode only (model.lua:284)
+  token_table_prefetch(m);
   cnn_forward(m, images_dev, d, 1, m->skip_running_once ? 0 : 1);
   m->skip_running_once = false;
   encoder_forward(m, d);

@@ -2334,6 +2334,128 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_dma_kernel(LoadMNh a, LoadC
 }
 
 // ---------------------------------------------------------------------------
+// Round 4: the hoisted RECURRENT weight gradients (dW = dz^T x over all time steps: K = L B or T B rows, M, N = 256 .. 2048) on the same
+// LDS-DMA skeleton, several problems per launch.  They ran on wgrad_tr_grouped_kernel (128 x 128 tiles, register staging, one tile in
+// flight: 111 GFLOP in 377 us = 0.12 of the bf16 peak at C3) on the side stream beside the encoder BPTT -- and that stream had become the
+// critical path: the main stream idled 121 us at the join in front of the CNN backward pass (tools/ktrace_step.sh c3).
+// Both operands are plain [K][M] / [K][N] bf16 matrices (row strides lda / ldb), so the B side loses conv_wgrad_dma_kernel's tap / pixel
+// cursor; a work item is (problem, 256 x 256 tile, k range) and writes its fp32 tile into the problem's slab of that k range (whole 1 KB
+// rows through LDS); wgrad_slab_reduce_kernel adds the slabs into the (strided) gradient matrices.  M, N multiples of 256, K of 32.
+// ---------------------------------------------------------------------------
+struct WgDmaProblem { const bf16_t* A; const bf16_t* B; long long lda, ldb; int M, N, K, gx, tiles, ks, kper, first; float* part; float* C; long long ldc; long long f4first; };
+struct WgDmaArgs { int n, total; long long f4total; WgDmaProblem p[8]; };
+template <int UNUSED = 0>      // (a template only so that the header may be included by several translation units)
+__global__ __launch_bounds__(512, 1) void wgrad_dma_grouped_kernel(WgDmaArgs g, const bf16_t* zero) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 32768];          // the ONLY LDS object
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) if (i < g.n && (int)blockIdx.x >= g.p[i].first) pi = i;
+  const WgDmaProblem& P = g.p[pi];
+  const int local = blockIdx.x - P.first;                     // k-range-major inside a problem: co-resident workgroups share a row range of both operands
+  const int zsp = local / P.tiles, bid = local - zsp * P.tiles;
+  const int m_blk = (bid / P.gx) * 256, n_blk = (bid % P.gx) * 256;
+  const int kbeg = zsp * P.kper, kend = min(P.K, kbeg + P.kper);
+  const int nk = kend > kbeg ? (kend - kbeg + 31) >> 5 : 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, wm = wave >> 2, wn = wave & 3;
+  // staging role (as conv_wgrad_dma_kernel): pieces 2 wave, 2 wave + 1 of each operand; piece pi = k rows 2pi, 2pi+1; lane -> row 2pi + (lane>>5),
+  // 16-byte position lane & 31 of the row, which holds logical chunk ((pos>>2) ^ (row & 3)) << 2 | (pos & 3)
+  const bf16_t* pa[2]; const bf16_t* pb[2]; int ka[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int krow = 2 * (2 * wave + j) + (lane >> 5), pos = lane & 31;
+    const int chunk = ((((pos >> 2) ^ (krow & 3)) << 2) | (pos & 3));
+    ka[j] = kbeg + krow;
+    pa[j] = P.A + (long long)ka[j] * P.lda + m_blk + 8 * chunk; pb[j] = P.B + (long long)ka[j] * P.ldb + n_blk + 8 * chunk;
+  }
+  const long long astep = 32 * P.lda, bstep = 32 * P.ldb;
+  unsigned char* const wbase = lds + (2 * wave) * 1024;
+  int slot = 0;
+  auto issue = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { dma16(dma_select(ka[j] < kend, pa[j], zero), wbase + slot * 32768 + j * 1024); pa[j] += astep; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { dma16(dma_select(ka[j] < kend, pb[j], zero), wbase + slot * 32768 + 16384 + j * 1024); pb[j] += bstep; ka[j] += 32; }
+    slot = (slot + 1) & 3;
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int gq = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
+  const unsigned rowoff = (8 * h + q) * 512 + (16 * (gq & 1) + 4 * p4) * 2;
+  unsigned aseg[4], bseg[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aseg[i] = rowoff + (((wm * 4 + i) ^ q) << 6);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) bseg[i] = 16384 + rowoff + (((wn * 2 + i) ^ q) << 6);
+  typedef unsigned long long u64;
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
+#define AOCR_TRR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+#pragma unroll
+  for (int t = 0; t < 3; ++t) issue();
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // this wave's pieces of tile kt have landed (two later tiles in flight)
+    __builtin_amdgcn_s_barrier();
+    const unsigned sl = lbase + (kt & 3) * 32768;
+    u64 fa[2][4][2], fb[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned ad = sl + aseg[i];
+      AOCR_TRR(fa[0][i][0], ad, 0); AOCR_TRR(fa[0][i][1], ad, 2048); AOCR_TRR(fa[1][i][0], ad, 8192); AOCR_TRR(fa[1][i][1], ad, 10240);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned ad = sl + bseg[i];
+      AOCR_TRR(fb[0][i][0], ad, 0); AOCR_TRR(fb[0][i][1], ad, 2048); AOCR_TRR(fb[1][i][0], ad, 8192); AOCR_TRR(fb[1][i][1], ad, 10240);
+    }
+    issue();                                            // tile kt+3 -> the slot of tile kt-1
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]), "+v"(fa[0][2][0]), "+v"(fa[0][2][1]),
+                   "+v"(fa[0][3][0]), "+v"(fa[0][3][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][1][0]), "+v"(fb[0][1][1])
+                 :: "memory");
+    asm volatile(""
+                 : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]), "+v"(fa[1][2][0]), "+v"(fa[1][2][1]),
+                   "+v"(fa[1][3][0]), "+v"(fa[1][3][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][1][0]), "+v"(fb[1][1][1])
+                 :: "memory");
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const u64x2 av = {fa[s2][mi][0], fa[s2][mi][1]}, bv = {fb[s2][ni][0], fb[s2][ni][1]};
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[mi][ni], 0, 0, 0);
+        }
+  }
+#undef AOCR_TRR
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  tile256_store_f32<2, 512>(P.part + (size_t)zsp * P.M * P.N, P.N, nullptr, false, acc, lds, m_blk, n_blk, wm, wn, lane & 31, h, tid);
+}
+// C[m][n] (row stride ldc) += sum over the k ranges of the problem's slabs; one launch for all problems of a group (float4 items)
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(WgDmaArgs g) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.f4total) return;
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) if (k < g.n && i >= g.p[k].f4first) pi = k;
+  const WgDmaProblem& P = g.p[pi];
+  const long long li = i - P.f4first; const int n4 = P.N >> 2; const long long m = li / n4; const int c = (int)(li - m * n4) * 4;
+  const size_t mn = (size_t)P.M * P.N;
+  const float* src = P.part + (size_t)m * P.N + c;
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < P.ks; ++z) acc += __builtin_nontemporal_load(reinterpret_cast<const f4*>(src + (size_t)z * mn));
+  float* o = P.C + m * P.ldc + c;                               // (ldc need not be a multiple of 4: dW_i2h[:, E:] starts at column E)
+  o[0] += acc[0]; o[1] += acc[1]; o[2] += acc[2]; o[3] += acc[3];
+}
+
+// ---------------------------------------------------------------------------
 // Filter gradient of a 3 x 3 / pad 1 layer with the INPUT MAP HALO-RESIDENT (round 4; priced in round 3).
 //   dW[co][tap][ci] = sum over pixels p of  dy[p][co] . x[p + off(tap)][ci]
 // conv_wgrad_dma_kernel tiles N as ONE tap x 256 input channels, so every K step (32 pixels) moves 16 KB of d y AND 16 KB of tap-shifted x through

@@ -773,6 +773,13 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       run_gates_bwd(m, 2, la, ww, ee, B, He, lah);
     }
     prof_mark(m, AOCR_PROF_RNN_GEMM);
+    // round 4: the layer's weight gradients join the decoder's on the side stream (nothing reads them before the optimizer), behind an event that
+    // marks the end of this layer's BPTT: 0.11 ms off the main stream at C3, where they ran between d X and the CNN backward pass
+    bool wg_side = false;
+    if (m->side_busy && m->side && !getenv("AOCR_NO_ENC_WGRAD_SIDE")) {
+      if (!m->enc_ev && hipEventCreateWithFlags(&m->enc_ev, hipEventDisableTiming) != hipSuccess) m->enc_ev = nullptr;
+      if (m->enc_ev) { hipEventRecord(m->enc_ev, s); wg_side = true; }
+    }
     WGradProblem wg[4]; int nwg = 0;
     // layer 0: d X = d z_fw W_i2h_fw + d z_bw W_i2h_bw (model.lua:675 copy, :689 add) as ONE product over K = 2 x 4He (round 4: one launch instead of two,
     // the second of which re-read the first's 33 MB output to add to it)
@@ -799,7 +806,8 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
       else gemm(s, bf, dz, 4 * He, true, p.wi, p.in, false, dxo, p.in, T * B, p.in, 4 * He, nullptr, nullptr, dxf);
       if (l > 0 && m->drop_on) dropout_apply(s, dxo, dxo, nullptr, (int64_t)T * B * He, drop_site(m, (dir ? 48 : 32) + l + 1, 0));     // Dropout backward
     }
-    grouped_wgrad(s, bf, wg, nwg);
+    if (wg_side) { hipStreamWaitEvent(m->side, m->enc_ev, 0); grouped_wgrad(m->side, bf, wg, nwg, m->wg_part, m->wg_part_floats); }
+    else grouped_wgrad(s, bf, wg, nwg, m->side_busy ? nullptr : m->wg_part, m->wg_part_floats);      // (the side stream may be using the slab scratch: the decoder's weight gradients)
   }
 }
 
@@ -926,7 +934,9 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
   // produced by a gather + a K = E product: the same dot products (same kernel, same k order: bit-identical rows), 39 rows instead of 6144 at C3,
   // and 50 MB less written and read per step.  The backward pass follows (decoder_backward: sums of d z by token).  AOCR_NO_EMB_TABLE=1: the tensor.
   m->emb_table = use_cl && segsum_supported(4 * Hd, m->V, E) && !getenv("AOCR_NO_EMB_TABLE");
-  if (m->emb_table) gemm(s, bf, m->lookup, E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * Hd, m->V, 4 * Hd, E, p1.bi, p1.bh, 0);
+  const bool tab_there = m->tab_ready;
+  if (m->tab_ready) { hipStreamWaitEvent(s, m->tab_done, 0); m->tab_ready = false; }       // token_table_prefetch of this step (joined even when unused: the decode path writes the same buffer)
+  if (m->emb_table) { if (!tab_there) gemm(s, bf, m->lookup, E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * Hd, m->V, 4 * Hd, E, p1.bi, p1.bh, 0); }
   else {
     embedding_gather(s, m->lookup, tgt, st, sb, m->emb_all, L, B, E);
     gemm(s, bf, m->emb_all, E, true, p1.wi, p1.in, true, m->zx1_all, 4 * Hd, L * B, 4 * Hd, E, p1.bi, p1.bh, 0);
@@ -989,6 +999,7 @@ void loss_and_dlogits(aocr_model* m, const Dims& d, const int32_t* tge, int64_t 
   if (loss_dev) sum_to_scalar(m->s, m->nll_rows, rows, loss_dev);
 }
 
+static bool side_create(aocr_model* m);
 // the side stream of the backward pass (created on first use, lowest priority) -- AOCR_NO_SIDE_WGRAD=1 keeps everything on one stream
 static bool side_stream_on(aocr_model* m, int B, int T) {
   if (m->prof_on || !m->bf16 || getenv("AOCR_NO_SIDE_WGRAD")) return false;
@@ -1006,13 +1017,31 @@ static bool side_stream_on(aocr_model* m, int B, int T) {
       if (layer_pipe_chunks(m, T, G, groups) > 0) return false;
     }
   }
+  return side_create(m);
+}
+static bool side_create(aocr_model* m) {
   if (!m->side) {
     int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);            // lo = numerically greatest = lowest priority
     const hipError_t e = getenv("AOCR_SIDE_PLAIN") ? hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) : hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, lo);
     if (e != hipSuccess) { m->side = nullptr; return false; }
     if (hipEventCreateWithFlags(&m->side_go, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&m->side_done, hipEventDisableTiming) != hipSuccess) return false;
+    if (hipStreamCreateWithPriority(&m->side2, hipStreamNonBlocking, lo) != hipSuccess) m->side2 = nullptr;      // optional (decoder_backward)
+    if (m->side2 && hipEventCreateWithFlags(&m->side2_done, hipEventDisableTiming) != hipSuccess) m->side2_done = nullptr;
   }
   return m->side_go && m->side_done;
+}
+// The per-token gate-input table of the first decoder layer (decoder_tf_forward) depends on the parameters only: a training step computes it
+// on the side stream while the CNN runs (20 us off the main stream between the encoder and the decoder kernels at C3).
+void token_table_prefetch(aocr_model* m) {
+  m->tab_ready = false;
+  if (!m->bf16 || m->prof_on || !m->bzx_tab || getenv("AOCR_NO_EMB_TABLE") || getenv("AOCR_NO_SIDE_WGRAD") || !segsum_supported(4 * m->Hd, m->V, m->E)) return;
+  if (!side_create(m)) return;
+  if (!m->tab_done && hipEventCreateWithFlags(&m->tab_done, hipEventDisableTiming) != hipSuccess) { m->tab_done = nullptr; return; }
+  hipEventRecord(m->side_go, m->s); hipStreamWaitEvent(m->side, m->side_go, 0);       // behind whatever wrote the parameters on the model's stream
+  const LstmP& p1 = m->dec[0];
+  gemm(m->side, true, m->lookup, m->E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * m->Hd, m->V, 4 * m->Hd, m->E, p1.bi, p1.bh, 0);
+  hipEventRecord(m->tab_done, m->side);
+  m->tab_ready = true;
 }
 
 // decoder BPTT, model.lua:643-661, t = L..1.
@@ -1024,7 +1053,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   // projector backward for all steps at once (model.lua:648): d(out) part, gradWeight, gradBias
   prof_mark(m, AOCR_PROF_RNN_GEMM);
   gemm(s, bf, m->dlogits, LOGIT_LD, true, m->wo, Hd, false, m->dout_proj, Hd, rows, Hd, V, nullptr, nullptr, 0);
-  gemm(s, bf, m->dlogits, LOGIT_LD, false, m->out_all + slot, Hd, false, m->dwo, Hd, V, Hd, rows, nullptr, nullptr, EP_ATOMIC);
+  // (gradWeight of the projector: nothing in this pass reads it -- with the hoisted parameter gradients below, beside the encoder BPTT: 41 us off the main stream at C3)
   ColsumJobs cj; cj.n = 0; cj.total = 0;                          // projector bias + the LSTM biases of every layer: one launch at the end of this pass
   colsum_defer(cj, m->dlogits, LOGIT_LD, rows, V, m->dbo);
   prof_mark(m, AOCR_PROF_DEC_BWD);
@@ -1121,6 +1150,13 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   if (side_stream_on(m, B, T)) {
     hipEventRecord(m->side_go, ms); s = m->side; hipStreamWaitEvent(s, m->side_go, 0); m->side_busy = true;
   }
+  // round 4: a SECOND side stream for the latency- / HBM-bound part of this section (projector gradWeight: a 24-way split-K product of 96 workgroups;
+  // the bias column sums: 67 us over 180 MB) so that it runs beside the weight-gradient GEMMs instead of in front of them -- with the encoder's weight
+  // gradients on the side stream too, that stream had become the critical path (the main stream idled ~120 us at the join).  It rejoins the first side
+  // stream at the end of this function, so "the side stream is done" still means "every hoisted gradient is done".
+  hipStream_t s2 = s;
+  if (m->side_busy && m->side2 && m->side2_done && !getenv("AOCR_NO_SIDE2")) { s2 = m->side2; hipStreamWaitEvent(s2, m->side_go, 0); }
+  gemm(s2, bf, m->dlogits, LOGIT_LD, false, m->out_all + slot, Hd, false, m->dwo, Hd, V, Hd, rows, nullptr, nullptr, EP_ATOMIC);
   const float* h_top_all = m->dhs[Ld - 1] + slot;
   WGradProblem wg[16]; int nwg = 0;
   const bool sh = m->bf16 && m->dpre_b != nullptr;
@@ -1130,10 +1166,12 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
     const LstmP& p = m->dec[l]; const float* dz = m->ddz[l];
     const bf16_t* dzb = sh ? m->ddz_b[l] : nullptr;
     wg[nwg++] = WGradProblem{dz, 4 * Hd, m->dhs[l], Hd, p.dwh, Hd, 4 * Hd, Hd, rows, dzb, sh ? m->dhs_b[l] : nullptr};
-    if (cj.n >= 8) colsum_flush(s, cj);
+    if (cj.n >= 8) colsum_flush(s2, cj);
     if (l == 0 && m->emb_table) {
       // the embedding side through the sums of d z by token (ops_misc.hip: segsum_by_token): S [V][4 Hd] in one pass over d z, which also yields
       // the layer's bias gradients; then d lookup += S W_i2h[:, :E] and d W_i2h[:, :E] = S^T lookup -- two V-sized products in exact fp32
+      // (on the FIRST side stream, in front of the weight-gradient GEMMs: with the sums on the second stream the GEMM's 228 workgroups were dispatched ahead of the
+      //  encoder BPTT kernel's groups and delayed them -- enc_cl_bwd 246 -> 314 us, step 5.28 -> 5.32 ms)
       segsum_by_token(s, dz, 4 * Hd, tgt, 1, L, L, B, 4 * Hd, V, m->emb_seg, m->emb_index, p.dbi, p.dbh, p.wi, p.in, m->lookup, E, m->dlookup, p.dwi);
       if (m->cfg.input_feed) wg[nwg++] = WGradProblem{dz, 4 * Hd, m->out_all, Hd, p.dwi + E, p.in, 4 * Hd, Hd, rows, dzb, sh ? m->out_b : nullptr};
       continue;
@@ -1151,8 +1189,9 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
       else wg[nwg++] = WGradProblem{dz, 4 * Hd, m->dhs[l - 1] + slot, Hd, p.dwi, Hd, 4 * Hd, Hd, rows, dzb, sh ? m->dhs_b[l - 1] + slot : nullptr};
     }
   }
-  colsum_flush(s, cj);
-  grouped_wgrad(s, bf, wg, nwg);
+  colsum_flush(s2, cj);
+  grouped_wgrad(s, bf, wg, nwg, m->wg_part, m->wg_part_floats);
+  if (s2 != s) { hipEventRecord(m->side2_done, s2); hipStreamWaitEvent(s, m->side2_done, 0); }
 }
 
 // The flat gradient vector completes back to front: decoder + projector groups, then both encoder groups, then the CNN from conv7

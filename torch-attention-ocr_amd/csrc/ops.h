@@ -84,7 +84,7 @@ int gemm(hipStream_t s, bool bf16, const float* A, int64_t lda, bool a_kmajor, c
 // one launch for up to 8 problems; K is split only as far as needed to fill the chip once.
 struct WGradProblem { const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int M, N, K;
                       const bf16_t* Ab = nullptr; const bf16_t* Bb = nullptr; };     // optional bf16 shadows of A and B (same lda/ldb)
-void grouped_wgrad(hipStream_t s, bool bf16, const WGradProblem* p, int n);
+void grouped_wgrad(hipStream_t s, bool bf16, const WGradProblem* p, int n, float* part = nullptr, size_t part_floats = 0);     // part: split-K slab scratch (enables the LDS-DMA kernel for deep problems)
 void kprobe_read(unsigned long long out[8]);   // debugging probe of the tagged halo kernels (mfma_gemm.h: g_kprobe)
 
 // C = A B^T (+bias) with both operands read from K-contiguous bf16 shadows (A [M][K], B [N][K])

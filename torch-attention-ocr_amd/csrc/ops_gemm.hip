@@ -432,18 +432,48 @@ static void grouped_launch(hipStream_t s, const WGradProblem* const* q, int cnt,
   hipLaunchKernelGGL(kernel, dim3(first), dim3(256), 0, s, g);
 }
 
-void grouped_wgrad(hipStream_t s, bool bf16, const WGradProblem* p, int n) {
+// round 4: deep problems with full 256 x 256 tiles on the LDS-DMA skeleton (wgrad_dma_grouped_kernel), slabs in `part`; returns how many it took (the first `cnt` of q)
+static int grouped_launch_dma(hipStream_t s, const WGradProblem* const* q, int cnt, float* part, size_t part_floats) {
+  if (cnt <= 0 || !part) return 0;
+  if (cnt > 8) cnt = 8;
+  long long tiles = 0; int kmin = 1 << 30;
+  for (int i = 0; i < cnt; ++i) { tiles += (long long)(q[i]->M / 256) * (q[i]->N / 256); kmin = std::min(kmin, q[i]->K); }
+  const char* tg = getenv("AOCR_WGRAD_DMA_WGS");                           // A/B: workgroups aimed at per launch
+  int ks = (int)((tg ? atoi(tg) : 256) / tiles); if (ks < 1) ks = 1;           // never more than one round of the 256 CUs (312 workgroups = a second round of 56: 120 instead of 75 us for the encoder's four problems)
+  ks = std::min(ks, std::max(1, kmin / 768));                                 // at least 24 K steps per workgroup
+  while (ks > 1 && (size_t)tiles * 65536 * ks > part_floats) --ks;
+  if ((size_t)tiles * 65536 * ks > part_floats) return 0;
+  WgDmaArgs g; g.n = cnt; int first = 0; long long f4 = 0; size_t off = 0;
+  for (int i = 0; i < cnt; ++i) {
+    WgDmaProblem& P = g.p[i];
+    int ksplit = ks, kper; split_k(q[i]->K, 32, ksplit, kper);
+    P.A = q[i]->Ab; P.B = q[i]->Bb; P.lda = q[i]->lda; P.ldb = q[i]->ldb; P.M = q[i]->M; P.N = q[i]->N; P.K = q[i]->K;
+    P.gx = q[i]->N / 256; P.tiles = (q[i]->M / 256) * P.gx; P.ks = ksplit; P.kper = kper; P.first = first; first += P.tiles * ksplit;
+    P.part = part + off; off += (size_t)P.M * P.N * ksplit;
+    P.C = q[i]->C; P.ldc = q[i]->ldc; P.f4first = f4; f4 += (long long)P.M * (P.N / 4);
+  }
+  g.total = first; g.f4total = f4;
+  hipLaunchKernelGGL((wgrad_dma_grouped_kernel<0>), dim3(first), dim3(512), 0, s, g, zero_page());
+  hipLaunchKernelGGL((wgrad_slab_reduce_kernel<0>), dim3((unsigned)((f4 + 255) / 256)), dim3(256), 0, s, g);
+  return cnt;
+}
+void grouped_wgrad(hipStream_t s, bool bf16, const WGradProblem* p, int n, float* part, size_t part_floats) {
   if (!bf16) {                                                // fp32 mode: one launch per problem
     for (int i = 0; i < n; ++i)
       gemm(s, false, p[i].A, p[i].lda, false, p[i].B, p[i].ldb, false, p[i].C, p[i].ldc, p[i].M, p[i].N, p[i].K, nullptr, nullptr, EP_ATOMIC);
     return;
   }
   // problems whose operands both have bf16 shadows (16-byte pieces: M, N, lda, ldb multiples of 8) take the transposed-read kernel
-  const WGradProblem* hs[16]; const WGradProblem* fs[16]; int nh = 0, nf = 0;
+  const WGradProblem* hs[16]; const WGradProblem* fs[16]; const WGradProblem* ds[16]; int nh = 0, nf = 0, nd = 0;
+  const bool dma_ok = part && !dma_disabled() && !env_is_1("AOCR_NO_WGRAD_DMA_GROUPED");
   for (int i = 0; i < n && i < 16; ++i) {
     const bool ok = p[i].Ab && p[i].Bb && p[i].M % 8 == 0 && p[i].N % 8 == 0 && p[i].lda % 8 == 0 && p[i].ldb % 8 == 0;
-    if (ok) hs[nh++] = &p[i]; else fs[nf++] = &p[i];
+    const bool deep = ok && dma_ok && p[i].M % 256 == 0 && p[i].N % 256 == 0 && p[i].K % 32 == 0 && p[i].K >= 2048 &&
+                      ((reinterpret_cast<uintptr_t>(p[i].Ab) | reinterpret_cast<uintptr_t>(p[i].Bb)) & 15) == 0;
+    if (deep && nd < 8) ds[nd++] = &p[i]; else if (ok) hs[nh++] = &p[i]; else fs[nf++] = &p[i];
   }
+  if (nd > 0 && grouped_launch_dma(s, ds, nd, part, part_floats) != nd)
+    for (int i = 0; i < nd; ++i) hs[nh++] = ds[i];                             // no room for the slabs: the transposed-read kernel
   for (int base = 0; base < nh; base += 8)
     grouped_launch<LoadMNh>(s, hs + base, std::min(8, nh - base), 1024, true, wgrad_tr_grouped_kernel<EpStore>);
   for (int base = 0; base < nf; base += 8)
