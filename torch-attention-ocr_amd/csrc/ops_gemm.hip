@@ -166,6 +166,11 @@ static void launch_big(hipStream_t s, bool bf16, const AL& a, const BL& b, const
     // round 4: M/N-contiguous pairs (filter gradients, recurrent weight gradients) through a [k][m] LDS image (gemm_f32w_kernel);
     // AOCR_NO_F32W=1 restores the fragment-from-global kernel
     if (!env_is_1("AOCR_NO_F32W") && M >= 64 && N >= 64 && K >= 64 && f32w_ok(a) && f32w_ok(b)) {
+      // at least AOCR_F32W_MINK (default 192) of K per k range: the callers' split (pick_ksplit: 768 workgroups) gave the recurrent weight gradients at batch 64
+      // (K = L B = 1536) 12-24 ranges of 64-128 rows -- 2-4 tiles of MFMA work under a 128 x 128 tile of memory-side atomics each (88 us, MFMA-busy 0.17).
+      // Measured at C2 (ms per step, same box): 32 (the callers' split) 7.70, 128 7.62, 160 7.56, 192 7.51-7.57, 256 7.59, 384 7.66, 768 8.08.
+      const char* mk = getenv("AOCR_F32W_MINK"); const int mink = mk ? std::max(32, atoi(mk)) : 192;
+      ksplit = std::min(ksplit, std::max(1, K / mink));
       int kp; split_k(K, 32, ksplit, kp);
       const int gx = cdiv(N, 128), gy = cdiv(M, 128);
       hipLaunchKernelGGL((gemm_f32w_kernel<AL, BL, EP>), dim3(gx * gy, 1, ksplit), dim3(256), 0, s, a, b, ep, K, kp, gx, gy);
