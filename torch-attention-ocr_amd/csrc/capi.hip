@@ -159,6 +159,8 @@ int aocr_model_destroy(aocr_model* m) {
   if (m && m->side2_done) hipEventDestroy(m->side2_done);
   if (m && m->side2) hipStreamDestroy(m->side2);
   if (m && m->tab_done) hipEventDestroy(m->tab_done);
+  if (m && m->zero_done) hipEventDestroy(m->zero_done);
+  if (m && m->shadow_done) hipEventDestroy(m->shadow_done);
   if (m && m->enc_ev) hipEventDestroy(m->enc_ev);
   if (m) for (hipEvent_t e : m->prof_ev) hipEventDestroy(e);
   if (m) for (hipStream_t ls : m->lay_s) if (ls) { hipStreamSynchronize(ls); hipStreamDestroy(ls); }
@@ -261,9 +263,8 @@ int aocr_train_forward_backward(aocr_model* m, const float* images_dev, const in
   Dims d; if (step_dims(m, B, W, L, d)) return 1;
   REQUIRE(images_dev && targets_dev && targets_eval_dev, "NULL input");
   prof_mark(m, AOCR_PROF_OTHER);
-  hipMemsetAsync(m->grads, 0, (size_t)m->layout.group_off[AOCR_NUM_GROUPS] * sizeof(float), m->s);      // model.lua:637-639
+  step_prologue(m, (size_t)m->layout.group_off[AOCR_NUM_GROUPS] * sizeof(float));      // model.lua:637-639 (zeroGradParameters) + the step's parameter-only work
   m->drop_on = m->drop_thr != 0;                                          // nn.Dropout is active in training() mode only (model.lua:284)
-  token_table_prefetch(m);
   cnn_forward(m, images_dev, d, 1, m->skip_running_once ? 0 : 1);
   m->skip_running_once = false;
   encoder_forward(m, d);

@@ -79,7 +79,7 @@ struct aocr_model {
   float *context, *dctx;
   aocr::bf16_t* context_b;        // bf16 shadow of the context for the attention kernels (bf16 mode)
   // decoder, teacher-forced (rows = B, time-major)
-  float* emb_seg = nullptr; int* emb_index = nullptr; bool emb_table = false; hipEvent_t tab_done = nullptr, enc_ev = nullptr; bool tab_ready = false;   // tab_*: the table was enqueued on the side stream by this step (token_table_prefetch)   // round 4: sums of the first decoder layer's d z by token [V][4 Hd]; the last teacher-forced forward read zx1 from the per-token table
+  float* emb_seg = nullptr; int* emb_index = nullptr; bool emb_table = false; hipEvent_t tab_done = nullptr, enc_ev = nullptr, zero_done = nullptr, shadow_done = nullptr; bool tab_ready = false, zero_pending = false, shadow_pending = false;   // (step_prologue)   // tab_*: the table was enqueued on the side stream by this step (token_table_prefetch)   // round 4: sums of the first decoder layer's d z by token [V][4 Hd]; the last teacher-forced forward read zx1 from the per-token table
   float *emb_all, *zx1_all, *dhs[aocr::MAXL], *dcs[aocr::MAXL], *dgates[aocr::MAXL], *ddz[aocr::MAXL];
   float *out_all, *cat_all, *q_all, *a_all, *logits, *dlogits, *nll_rows;
   float *dout_proj, *dpre_all, *dcat_all, *ds_all, *dq_all, *demb_all;
@@ -138,7 +138,7 @@ inline int comm_reserved_cus(const aocr_model* m) {
 }
 void prof_mark_slow(aocr_model* m, int tag);
 inline void prof_mark(aocr_model* m, int tag) { if (m->prof_on) prof_mark_slow(m, tag); }
-void token_table_prefetch(aocr_model* m);                           // start of a training step (capi.hip)
+void step_prologue(aocr_model* m, size_t grad_bytes);              // start of a training step (capi.hip): gradient zeroing, weight shadows, token table
 void build_shadow_jobs(aocr_model* m);                              // after bind_params + model_carve
 int model_carve(aocr_model* m, void* base, size_t bytes);          // returns 0 / -1 (too small); base==nullptr: size only
 void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training, int update_running);

@@ -314,7 +314,7 @@ void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training
   m->y16[0] = m->y16[1] = 0;                                     // only a training conv_forward below sets them again: the evaluation / folded branch leaves Y3 / Y5 untouched, never "bf16 from an older step"
   const BnSync bsync_v{bn_sync_allreduce, m}; const BnSync* bsync = (training && sync_bn_on(m)) ? &bsync_v : nullptr;
   if (bf && !m->shadow_host.empty()) {                          // every bf16 shadow of the step in one launch
-    shadow_jobs(s, m->shadow_dev, (int)m->shadow_host.size(), m->shadow_tiles);
+    if (!m->shadow_pending) shadow_jobs(s, m->shadow_dev, (int)m->shadow_host.size(), m->shadow_tiles);      // (pending: step_prologue put it on the side stream)
   } else {
     refresh_rnn_shadows(m);
     for (int i = 2; i <= 7; ++i) {                              // refresh the re-laid weight copies (weights change every step)
@@ -325,6 +325,7 @@ void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training
   // bf16 mode: the pooled conv outputs exist only as bf16 shadows (every consumer -- next conv, filter gradient, ReLU mask of the
   // un-pool -- reads the shadow; aocr_get_tensor materialises fp32 on demand)
   prof_mark(m, AOCR_PROF_POOL_CONV1); conv1_forward(s, images, m->conv[1].w, m->conv[1].b, bf ? nullptr : m->A1, B, d.H, d.W, m->A1b);
+  if (m->shadow_pending) { hipStreamWaitEvent(s, m->shadow_done, 0); m->shadow_pending = false; }       // conv1 reads no shadow; everything below does
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A1, m->conv[2].w, m->conv[2].b, bf ? nullptr : m->A2, m->idx2, B, d.H1, d.W1, 64, 128, 3, 1, 1, 1, m->A1b, m->wb[2], m->A2b);
   // evaluation mode, bf16: BatchNorm + ReLU of conv3 / conv5 are a per-channel affine map -> folded into the conv epilogue, which then writes only
   // the bf16 shadow (no fp32 map, no apply pass); conv7's BatchNorm also transposes to (T, B) and stays a pass of its own
@@ -1032,16 +1033,26 @@ static bool side_create(aocr_model* m) {
 }
 // The per-token gate-input table of the first decoder layer (decoder_tf_forward) depends on the parameters only: a training step computes it
 // on the side stream while the CNN runs (20 us off the main stream between the encoder and the decoder kernels at C3).
-void token_table_prefetch(aocr_model* m) {
-  m->tab_ready = false;
-  if (!m->bf16 || m->prof_on || !m->bzx_tab || getenv("AOCR_NO_EMB_TABLE") || getenv("AOCR_NO_SIDE_WGRAD") || !segsum_supported(4 * m->Hd, m->V, m->E)) return;
-  if (!side_create(m)) return;
-  if (!m->tab_done && hipEventCreateWithFlags(&m->tab_done, hipEventDisableTiming) != hipSuccess) { m->tab_done = nullptr; return; }
+// Start of a training step (aocr_train_forward_backward): what depends on nothing but the parameters -- zeroing the gradient vector (49 MB), the
+// bf16 weight shadows (100 MB of traffic), the token table -- goes to the side stream and runs under conv1 (VALU-bound, 40 us) instead of in front
+// of it; cnn_forward waits for the shadows behind conv1, backward_all for the zeroed gradients.  AOCR_NO_SIDE_PROLOGUE=1: everything in line.
+void step_prologue(aocr_model* m, size_t grad_bytes) {
+  m->tab_ready = m->zero_pending = m->shadow_pending = false;
+  auto ev = [](hipEvent_t& e) { return e || hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
+  const bool side = m->bf16 && !m->prof_on && !getenv("AOCR_NO_SIDE_WGRAD") && !getenv("AOCR_NO_SIDE_PROLOGUE") && side_create(m) && ev(m->zero_done) && ev(m->shadow_done) && ev(m->tab_done);
+  if (!side) { hipMemsetAsync(m->grads, 0, grad_bytes, m->s); return; }
   hipEventRecord(m->side_go, m->s); hipStreamWaitEvent(m->side, m->side_go, 0);       // behind whatever wrote the parameters on the model's stream
-  const LstmP& p1 = m->dec[0];
-  gemm(m->side, true, m->lookup, m->E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * m->Hd, m->V, 4 * m->Hd, m->E, p1.bi, p1.bh, 0);
-  hipEventRecord(m->tab_done, m->side);
-  m->tab_ready = true;
+  if (!m->shadow_host.empty()) {
+    shadow_jobs(m->side, m->shadow_dev, (int)m->shadow_host.size(), m->shadow_tiles);
+    hipEventRecord(m->shadow_done, m->side); m->shadow_pending = true;
+  }
+  hipMemsetAsync(m->grads, 0, grad_bytes, m->side); hipEventRecord(m->zero_done, m->side); m->zero_pending = true;
+  if (m->bzx_tab && !getenv("AOCR_NO_EMB_TABLE") && segsum_supported(4 * m->Hd, m->V, m->E)) {
+    const LstmP& p1 = m->dec[0];
+    gemm(m->side, true, m->lookup, m->E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * m->Hd, m->V, 4 * m->Hd, m->E, p1.bi, p1.bh, 0);
+    hipEventRecord(m->tab_done, m->side);
+    m->tab_ready = true;
+  }
 }
 
 // decoder BPTT, model.lua:643-661, t = L..1.
@@ -1199,6 +1210,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
 // still runs (aocr_grad_buckets / aocr_stream_wait_grads).
 void backward_all(aocr_model* m, const float* images, const int32_t* tgt, const Dims& d) {
   m->side_busy = false;
+  if (m->zero_pending) { hipStreamWaitEvent(m->s, m->zero_done, 0); m->zero_pending = false; }          // step_prologue zeroed the gradient vector on the side stream
   decoder_backward(m, d, tgt);
   // Exchange policy: NO collective is in flight while a whole-sequence kernel runs.  A collective's kernel stays
   // resident until every peer has joined it; a cluster kernel needs all members of a group resident at once and bounds its spins.  With
