@@ -158,6 +158,7 @@ int aocr_model_destroy(aocr_model* m) {
   if (m && m->side_done) hipEventDestroy(m->side_done);
   if (m && m->side2_done) hipEventDestroy(m->side2_done);
   if (m && m->side2) hipStreamDestroy(m->side2);
+  if (m) for (hipEvent_t e : {m->cw_map[0], m->cw_map[1], m->cw_done[0], m->cw_done[1], m->cw_main}) if (e) hipEventDestroy(e);
   if (m && m->tab_done) hipEventDestroy(m->tab_done);
   if (m && m->zero_done) hipEventDestroy(m->zero_done);
   if (m && m->shadow_done) hipEventDestroy(m->shadow_done);

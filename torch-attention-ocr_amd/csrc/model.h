@@ -66,7 +66,8 @@ struct aocr_model {
   uint8_t *idx2, *idx4, *idx6;
   float *G0, *G1, *dX; size_t gmax = 0;   // gmax: floats in G0 / G1
   // bf16 shadows of the contraction operands (bf16 compute mode only; nullptr otherwise)
-  aocr::bf16_t *A1b, *A2b, *A3b, *A4b, *A5b, *A6b, *G0b;
+  aocr::bf16_t *A1b, *A2b, *A3b, *A4b, *A5b, *A6b, *G0b, *G2b = nullptr;
+  hipEvent_t cw_map[2] = {nullptr, nullptr}, cw_done[2] = {nullptr, nullptr}, cw_main = nullptr;   // cnn_backward: gradient map ready / filter gradient done per map buffer
   aocr::bf16_t *wb[8], *wtb[8];
   float* wtf[8];                  // fp32 mode: conv taps re-laid as [Cin][tap][Cout] (K-contiguous B operand of the data gradient)
   // bf16 shadows of the recurrent activations / gradients (written by the producing epilogues)

@@ -94,7 +94,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
   m->Y7 = a.get<float>(B * T * 512); m->X = a.get<float>(T * B * 512); m->dX = a.get<float>(T * B * 512);
   size_t gmax = B * d.H1 * d.W1 * 128;                                      // d(conv2 pre-pool output): the largest gradient map
   m->G0 = a.get<float>(gmax); m->G1 = a.get<float>(gmax); m->gmax = gmax;
-  m->A1b = m->A2b = m->A3b = m->A4b = m->A5b = m->A6b = m->G0b = nullptr;
+  m->A1b = m->A2b = m->A3b = m->A4b = m->A5b = m->A6b = m->G0b = m->G2b = nullptr;
   for (int i = 0; i < 8; ++i) { m->wb[i] = nullptr; m->wtb[i] = nullptr; m->wtf[i] = nullptr; }
   if (!m->bf16) {
     static const int wsz32[8] = {0, 0, 128 * 9 * 64, 256 * 9 * 128, 256 * 9 * 256, 512 * 9 * 256, 512 * 9 * 512, 512 * 4 * 512};
@@ -104,7 +104,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     m->A1b = a.get<bf16_t>(B * d.H1 * d.W1 * 64); m->A2b = a.get<bf16_t>(B * d.H2 * d.W2 * 128);
     m->A3b = a.get<bf16_t>(B * d.H2 * d.W2 * 256); m->A4b = a.get<bf16_t>(B * d.H4 * d.W2 * 256);
     m->A5b = a.get<bf16_t>(B * d.H4 * d.W2 * 512); m->A6b = a.get<bf16_t>(B * d.H6 * d.W2 * 512);
-    m->G0b = a.get<bf16_t>(gmax);
+    m->G0b = a.get<bf16_t>(gmax); m->G2b = a.get<bf16_t>(gmax);      // G2b: second gradient-map shadow (cnn_backward: filter gradients on the side stream)
     static const int wsz[8] = {0, 0, 128 * 9 * 64, 256 * 9 * 128, 256 * 9 * 256, 512 * 9 * 256, 512 * 9 * 512, 512 * 4 * 512};
     for (int i = 2; i <= 7; ++i) { m->wb[i] = a.get<bf16_t>(wsz[i]); m->wtb[i] = a.get<bf16_t>(wsz[i]); }
   }
@@ -362,7 +362,23 @@ void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training
 static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
   const BnSync bsync_v{bn_sync_allreduce, m}; const BnSync* bsync = sync_bn_on(m) ? &bsync_v : nullptr;
-  float *G0 = m->G0, *G1 = m->G1; bf16_t* G0b = m->G0b;
+  float *G0 = m->G0, *G1 = m->G1;
+  // Round 4: the filter gradients on the side stream.  A stage is E_k (BatchNorm backward / un-pool: HBM-bound, writes the gradient map d Y_k) ->
+  // { filter gradient k, data gradient k } (both MFMA-bound, both read d Y_k) -> E_(k-1).  On one stream the elementwise passes (0.5 ms of the
+  // backward pass at C3) run with the MFMA pipes idle; with the filter gradient of stage k on the (low-priority) side stream it runs beside the data
+  // gradient k and E_(k-1).  d Y alternates between two bf16 buffers so that E_(k-1) can write the next map while the filter gradient k still reads
+  // its own; an event per buffer keeps E_(k-2) from overwriting it before that filter gradient is done.  AOCR_NO_CNN_WGRAD_SIDE=1: one stream.
+  bf16_t* Gb[2] = {m->G0b, m->G2b}; int gp = 0;
+  const char* dbg_stop = getenv("AOCR_DBG_STOP");          // debugging aid: leave the gradient map of a stage in place (tap "g0")
+  const int stop = dbg_stop ? atoi(dbg_stop) : 0;
+  auto evok = [](hipEvent_t& e) { return e || hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
+  const bool ws = bf && m->G2b && !stop && !m->prof_on && m->side && m->side_done && !getenv("AOCR_NO_SIDE_WGRAD") && !getenv("AOCR_NO_CNN_WGRAD_SIDE") &&
+                  evok(m->cw_map[0]) && evok(m->cw_map[1]) && evok(m->cw_done[0]) && evok(m->cw_done[1]) && evok(m->cw_main);
+  hipStream_t sw = ws ? m->side : s;
+  if (!ws) Gb[1] = Gb[0];
+  auto map_ready = [&]() { if (ws) { hipEventRecord(m->cw_map[gp], s); hipStreamWaitEvent(sw, m->cw_map[gp], 0); } };        // d Y_k (Gb[gp]) is complete: the side stream may read it
+  auto wgrad_done = [&]() { if (ws) hipEventRecord(m->cw_done[gp], sw); };
+  auto next_map = [&]() { if (ws) { gp ^= 1; hipStreamWaitEvent(s, m->cw_done[gp], 0); } };                                    // the next E writes Gb[gp]: the filter gradient that read it two stages ago is done
   int bnbc = 0;                                                  // > 0: the data gradient's epilogue left the BatchNorm backward's partial sums in bn_scratch (conv_backward_data: bnb_chunks)
   int g16 = 0; const bf16_t* const G1h = reinterpret_cast<const bf16_t*>(G1);      // conv_backward_data left G1 as bf16 (its dx16): the BatchNorm backward / un-pool pass that follows reads it so
   // bf16 mode: fp32 G0 is free for the whole pass (every gradient map lives in its bf16 shadow), so the eight partial slabs of the fused bias /
@@ -376,37 +392,37 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   // bf16 mode: the BatchNorm backward writes only the bf16 shadow of its gradient, takes the ReLU mask from the bf16 output
   // shadow and accumulates the preceding conv's bias gradient (fp32 G0 is free there: partial slab)
   prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y7, m->X, m->dX, m->bn[7].w, m->bn[7].save, bf ? nullptr : G0, m->bn[7].dw, m->bn[7].db, m->bn_scratch,
-                   (int64_t)B * d.T, 512, B, G0b, bf ? m->Xb : nullptr, bf ? m->conv[7].db : nullptr, bf ? slab(0) : nullptr, bsync, defer);
-  const char* dbg_stop = getenv("AOCR_DBG_STOP");          // debugging aid: leave the gradient map of a stage in place (tap "g0")
-  const int stop = dbg_stop ? atoi(dbg_stop) : 0;
+                   (int64_t)B * d.T, 512, B, Gb[gp], bf ? m->Xb : nullptr, bf ? m->conv[7].db : nullptr, bf ? slab(0) : nullptr, bsync, defer);
   if (stop == 1) { if (defer) colsum_flush(s, cj); return; }
-  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A6, G0, m->conv[7].dw, bf ? nullptr : m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0, m->A6b, G0b, m->wg_part, m->wg_part_floats);
-  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0, G0b, m->wtb[7], m->wtf[7], bf ? &g16 : nullptr);
-  prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A6, m->idx6, bf ? nullptr : G0, B, d.H4, d.W2, 512, 2, G0b, bf ? m->conv[6].db : nullptr, bf ? slab(1) : nullptr, bf ? m->A6b : nullptr, defer, g16 ? G1h : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
+  map_ready(); prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A6, G0, m->conv[7].dw, bf ? nullptr : m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0, m->A6b, Gb[gp], m->wg_part, m->wg_part_floats); wgrad_done();
+  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0, Gb[gp], m->wtb[7], m->wtf[7], bf ? &g16 : nullptr);
+  next_map(); prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A6, m->idx6, bf ? nullptr : G0, B, d.H4, d.W2, 512, 2, Gb[gp], bf ? m->conv[6].db : nullptr, bf ? slab(1) : nullptr, bf ? m->A6b : nullptr, defer, g16 ? G1h : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
   if (stop == 2) { if (defer) colsum_flush(s, cj); return; }
-  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A5, G0, m->conv[6].dw, bf ? nullptr : m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, G0b, m->wg_part, m->wg_part_floats);
+  map_ready(); prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A5, G0, m->conv[6].dw, bf ? nullptr : m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, Gb[gp], m->wg_part, m->wg_part_floats); wgrad_done();
   prof_mark(m, AOCR_PROF_CONV_DGRAD); { const BnBwdFuse bf5{m->Y5, m->A5b, m->bn[5].save, (double*)m->bn_scratch};
-    conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, G0b, m->wtb[6], m->wtf[6], bf ? &g16 : nullptr, (bf && !m->y16[1]) ? &bf5 : nullptr, &bnbc); }
-  prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, bf ? nullptr : G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
-                   (int64_t)B * d.H4 * d.W2, 512, 0, G0b, bf ? m->A5b : nullptr, bf ? m->conv[5].db : nullptr, bf ? slab(2) : nullptr, bsync, defer, m->y16[1] ? reinterpret_cast<const bf16_t*>(m->Y5) : nullptr, g16 ? G1h : nullptr, bnbc); bnbc = 0;
-  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A4, G0, m->conv[5].dw, bf ? nullptr : m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, G0b, m->wg_part, m->wg_part_floats);
+    conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, Gb[gp], m->wtb[6], m->wtf[6], bf ? &g16 : nullptr, (bf && !m->y16[1]) ? &bf5 : nullptr, &bnbc); }
+  next_map(); prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, bf ? nullptr : G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
+                   (int64_t)B * d.H4 * d.W2, 512, 0, Gb[gp], bf ? m->A5b : nullptr, bf ? m->conv[5].db : nullptr, bf ? slab(2) : nullptr, bsync, defer, m->y16[1] ? reinterpret_cast<const bf16_t*>(m->Y5) : nullptr, g16 ? G1h : nullptr, bnbc); bnbc = 0;
+  map_ready(); prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A4, G0, m->conv[5].dw, bf ? nullptr : m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, Gb[gp], m->wg_part, m->wg_part_floats); wgrad_done();
   if (defer) colsum_flush(s, cj);                               // conv7.b, conv6.b, conv5.b
-  hipEventRecord(m->grad_ev[2], s);                             // every CNN gradient from conv5.w upwards is complete
-  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1, G0b, m->wtb[5], m->wtf[5], bf ? &g16 : nullptr);
-  prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A4, m->idx4, bf ? nullptr : G0, B, d.H2, d.W2, 256, 2, G0b, bf ? m->conv[4].db : nullptr, bf ? slab(3) : nullptr, bf ? m->A4b : nullptr, defer, g16 ? G1h : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
-  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A3, G0, m->conv[4].dw, bf ? nullptr : m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, G0b, m->wg_part, m->wg_part_floats);
+  if (ws) { hipEventRecord(m->cw_main, s); hipStreamWaitEvent(sw, m->cw_main, 0); hipEventRecord(m->grad_ev[2], sw); }      // (behind the filter gradient of conv5 on the side stream AND the bias sums on this one)
+  else hipEventRecord(m->grad_ev[2], s);                        // every CNN gradient from conv5.w upwards is complete
+  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1, Gb[gp], m->wtb[5], m->wtf[5], bf ? &g16 : nullptr);
+  next_map(); prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A4, m->idx4, bf ? nullptr : G0, B, d.H2, d.W2, 256, 2, Gb[gp], bf ? m->conv[4].db : nullptr, bf ? slab(3) : nullptr, bf ? m->A4b : nullptr, defer, g16 ? G1h : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
+  map_ready(); prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A3, G0, m->conv[4].dw, bf ? nullptr : m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, Gb[gp], m->wg_part, m->wg_part_floats); wgrad_done();
   prof_mark(m, AOCR_PROF_CONV_DGRAD); { const BnBwdFuse bf3{m->Y3, m->A3b, m->bn[3].save, (double*)m->bn_scratch};
-    conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, G0b, m->wtb[4], m->wtf[4], bf ? &g16 : nullptr, (bf && !m->y16[0]) ? &bf3 : nullptr, &bnbc); }
-  prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y3, m->A3, G1, m->bn[3].w, m->bn[3].save, bf ? nullptr : G0, m->bn[3].dw, m->bn[3].db, m->bn_scratch,
-                   (int64_t)B * d.H2 * d.W2, 256, 0, G0b, bf ? m->A3b : nullptr, bf ? m->conv[3].db : nullptr, bf ? slab(4) : nullptr, bsync, defer, m->y16[0] ? reinterpret_cast<const bf16_t*>(m->Y3) : nullptr, g16 ? G1h : nullptr, bnbc); bnbc = 0;
-  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A2, G0, m->conv[3].dw, bf ? nullptr : m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, G0b, m->wg_part, m->wg_part_floats);
-  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1, G0b, m->wtb[3], m->wtf[3]);
-  prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A2, m->idx2, bf ? nullptr : G0, B, d.H1, d.W1, 128, 1, G0b, bf ? m->conv[2].db : nullptr, bf ? slab(5) : nullptr, bf ? m->A2b : nullptr, defer);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
-  prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(s, bf, m->A1, G0, m->conv[2].dw, bf ? nullptr : m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1, m->A1b, G0b, m->wg_part, m->wg_part_floats);
-  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1, G0b, m->wtb[2], m->wtf[2]);
+    conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, Gb[gp], m->wtb[4], m->wtf[4], bf ? &g16 : nullptr, (bf && !m->y16[0]) ? &bf3 : nullptr, &bnbc); }
+  next_map(); prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y3, m->A3, G1, m->bn[3].w, m->bn[3].save, bf ? nullptr : G0, m->bn[3].dw, m->bn[3].db, m->bn_scratch,
+                   (int64_t)B * d.H2 * d.W2, 256, 0, Gb[gp], bf ? m->A3b : nullptr, bf ? m->conv[3].db : nullptr, bf ? slab(4) : nullptr, bsync, defer, m->y16[0] ? reinterpret_cast<const bf16_t*>(m->Y3) : nullptr, g16 ? G1h : nullptr, bnbc); bnbc = 0;
+  map_ready(); prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A2, G0, m->conv[3].dw, bf ? nullptr : m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, Gb[gp], m->wg_part, m->wg_part_floats); wgrad_done();
+  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1, Gb[gp], m->wtb[3], m->wtf[3]);
+  next_map(); prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A2, m->idx2, bf ? nullptr : G0, B, d.H1, d.W1, 128, 1, Gb[gp], bf ? m->conv[2].db : nullptr, bf ? slab(5) : nullptr, bf ? m->A2b : nullptr, defer);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
+  map_ready(); prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A1, G0, m->conv[2].dw, bf ? nullptr : m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1, m->A1b, Gb[gp], m->wg_part, m->wg_part_floats); wgrad_done();
+  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1, Gb[gp], m->wtb[2], m->wtf[2]);
   prof_mark(m, AOCR_PROF_POOL_CONV1); conv1_backward(s, images, m->conv[1].w, m->conv[1].b, G1, m->conv[1].dw, m->conv[1].db, B, d.H, d.W,
                  (size_t)B * d.H1 * d.W1 * 128 >= (size_t)4096 * 640 ? slab(6) : nullptr, defer);      // G0 is free here: use it as the partial slab
   if (defer) colsum_flush(s, cj);                               // conv4.b, conv3.b, conv2.b, conv1.w, conv1.b
+  if (ws) { hipEventRecord(m->side_done, sw); hipStreamWaitEvent(s, m->side_done, 0); }
 }
 
 // ------------------------------------------------------------------------------------------------
