@@ -375,6 +375,7 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   const bool ws = bf && m->G2b && !stop && !m->prof_on && m->side && m->side_done && !getenv("AOCR_NO_SIDE_WGRAD") && !getenv("AOCR_NO_CNN_WGRAD_SIDE") &&
                   evok(m->cw_map[0]) && evok(m->cw_map[1]) && evok(m->cw_done[0]) && evok(m->cw_done[1]) && evok(m->cw_main);
   hipStream_t sw = ws ? m->side : s;
+  const bool wg_after = ws && getenv("AOCR_CNN_WGRAD_AFTER_DGRAD") != nullptr;      // A/B: start the filter gradient of a stage behind its data gradient (beside the next elementwise pass only)
   if (!ws) Gb[1] = Gb[0];
   auto map_ready = [&]() { if (ws) { hipEventRecord(m->cw_map[gp], s); hipStreamWaitEvent(sw, m->cw_map[gp], 0); } };        // d Y_k (Gb[gp]) is complete: the side stream may read it
   auto wgrad_done = [&]() { if (ws) hipEventRecord(m->cw_done[gp], sw); };
@@ -394,31 +395,36 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y7, m->X, m->dX, m->bn[7].w, m->bn[7].save, bf ? nullptr : G0, m->bn[7].dw, m->bn[7].db, m->bn_scratch,
                    (int64_t)B * d.T, 512, B, Gb[gp], bf ? m->Xb : nullptr, bf ? m->conv[7].db : nullptr, bf ? slab(0) : nullptr, bsync, defer);
   if (stop == 1) { if (defer) colsum_flush(s, cj); return; }
-  map_ready(); prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A6, G0, m->conv[7].dw, bf ? nullptr : m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0, m->A6b, Gb[gp], m->wg_part, m->wg_part_floats); wgrad_done();
-  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0, Gb[gp], m->wtb[7], m->wtf[7], bf ? &g16 : nullptr);
+  { auto W = [&]() { prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A6, G0, m->conv[7].dw, bf ? nullptr : m->conv[7].db, B, d.H6, d.W2, 512, 512, 2, 0, m->A6b, Gb[gp], m->wg_part, m->wg_part_floats); };
+    auto D = [&]() { prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[7].w, G1, B, d.H6, d.W2, 512, 512, 2, 0, Gb[gp], m->wtb[7], m->wtf[7], bf ? &g16 : nullptr); };
+    if (wg_after) { D(); map_ready(); W(); wgrad_done(); } else { map_ready(); W(); wgrad_done(); D(); } }
   next_map(); prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A6, m->idx6, bf ? nullptr : G0, B, d.H4, d.W2, 512, 2, Gb[gp], bf ? m->conv[6].db : nullptr, bf ? slab(1) : nullptr, bf ? m->A6b : nullptr, defer, g16 ? G1h : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
   if (stop == 2) { if (defer) colsum_flush(s, cj); return; }
-  map_ready(); prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A5, G0, m->conv[6].dw, bf ? nullptr : m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, Gb[gp], m->wg_part, m->wg_part_floats); wgrad_done();
-  prof_mark(m, AOCR_PROF_CONV_DGRAD); { const BnBwdFuse bf5{m->Y5, m->A5b, m->bn[5].save, (double*)m->bn_scratch};
-    conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, Gb[gp], m->wtb[6], m->wtf[6], bf ? &g16 : nullptr, (bf && !m->y16[1]) ? &bf5 : nullptr, &bnbc); }
+  { auto W = [&]() { prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A5, G0, m->conv[6].dw, bf ? nullptr : m->conv[6].db, B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, Gb[gp], m->wg_part, m->wg_part_floats); };
+    auto D = [&]() { prof_mark(m, AOCR_PROF_CONV_DGRAD); { const BnBwdFuse bf5{m->Y5, m->A5b, m->bn[5].save, (double*)m->bn_scratch}; conv_backward_data(s, bf, G0, m->conv[6].w, G1, B, d.H4, d.W2, 512, 512, 3, 1, Gb[gp], m->wtb[6], m->wtf[6], bf ? &g16 : nullptr, (bf && !m->y16[1]) ? &bf5 : nullptr, &bnbc); } };
+    if (wg_after) { D(); map_ready(); W(); wgrad_done(); } else { map_ready(); W(); wgrad_done(); D(); } }
   next_map(); prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y5, m->A5, G1, m->bn[5].w, m->bn[5].save, bf ? nullptr : G0, m->bn[5].dw, m->bn[5].db, m->bn_scratch,
                    (int64_t)B * d.H4 * d.W2, 512, 0, Gb[gp], bf ? m->A5b : nullptr, bf ? m->conv[5].db : nullptr, bf ? slab(2) : nullptr, bsync, defer, m->y16[1] ? reinterpret_cast<const bf16_t*>(m->Y5) : nullptr, g16 ? G1h : nullptr, bnbc); bnbc = 0;
-  map_ready(); prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A4, G0, m->conv[5].dw, bf ? nullptr : m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, Gb[gp], m->wg_part, m->wg_part_floats); wgrad_done();
+  { auto W = [&]() { prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A4, G0, m->conv[5].dw, bf ? nullptr : m->conv[5].db, B, d.H4, d.W2, 256, 512, 3, 1, m->A4b, Gb[gp], m->wg_part, m->wg_part_floats); };
+    auto D = [&]() { prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1, Gb[gp], m->wtb[5], m->wtf[5], bf ? &g16 : nullptr); };
+    if (wg_after) { D(); map_ready(); W(); wgrad_done(); } else { map_ready(); W(); wgrad_done(); }
   if (defer) colsum_flush(s, cj);                               // conv7.b, conv6.b, conv5.b
   if (ws) { hipEventRecord(m->cw_main, s); hipStreamWaitEvent(sw, m->cw_main, 0); hipEventRecord(m->grad_ev[2], sw); }      // (behind the filter gradient of conv5 on the side stream AND the bias sums on this one)
   else hipEventRecord(m->grad_ev[2], s);                        // every CNN gradient from conv5.w upwards is complete
-  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[5].w, G1, B, d.H4, d.W2, 256, 512, 3, 1, Gb[gp], m->wtb[5], m->wtf[5], bf ? &g16 : nullptr);
+    if (!wg_after) D(); }
   next_map(); prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A4, m->idx4, bf ? nullptr : G0, B, d.H2, d.W2, 256, 2, Gb[gp], bf ? m->conv[4].db : nullptr, bf ? slab(3) : nullptr, bf ? m->A4b : nullptr, defer, g16 ? G1h : nullptr);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
-  map_ready(); prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A3, G0, m->conv[4].dw, bf ? nullptr : m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, Gb[gp], m->wg_part, m->wg_part_floats); wgrad_done();
-  prof_mark(m, AOCR_PROF_CONV_DGRAD); { const BnBwdFuse bf3{m->Y3, m->A3b, m->bn[3].save, (double*)m->bn_scratch};
-    conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, Gb[gp], m->wtb[4], m->wtf[4], bf ? &g16 : nullptr, (bf && !m->y16[0]) ? &bf3 : nullptr, &bnbc); }
+  { auto W = [&]() { prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A3, G0, m->conv[4].dw, bf ? nullptr : m->conv[4].db, B, d.H2, d.W2, 256, 256, 3, 1, m->A3b, Gb[gp], m->wg_part, m->wg_part_floats); };
+    auto D = [&]() { prof_mark(m, AOCR_PROF_CONV_DGRAD); { const BnBwdFuse bf3{m->Y3, m->A3b, m->bn[3].save, (double*)m->bn_scratch}; conv_backward_data(s, bf, G0, m->conv[4].w, G1, B, d.H2, d.W2, 256, 256, 3, 1, Gb[gp], m->wtb[4], m->wtf[4], bf ? &g16 : nullptr, (bf && !m->y16[0]) ? &bf3 : nullptr, &bnbc); } };
+    if (wg_after) { D(); map_ready(); W(); wgrad_done(); } else { map_ready(); W(); wgrad_done(); D(); } }
   next_map(); prof_mark(m, AOCR_PROF_BN); bn_relu_backward(s, m->Y3, m->A3, G1, m->bn[3].w, m->bn[3].save, bf ? nullptr : G0, m->bn[3].dw, m->bn[3].db, m->bn_scratch,
                    (int64_t)B * d.H2 * d.W2, 256, 0, Gb[gp], bf ? m->A3b : nullptr, bf ? m->conv[3].db : nullptr, bf ? slab(4) : nullptr, bsync, defer, m->y16[0] ? reinterpret_cast<const bf16_t*>(m->Y3) : nullptr, g16 ? G1h : nullptr, bnbc); bnbc = 0;
-  map_ready(); prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A2, G0, m->conv[3].dw, bf ? nullptr : m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, Gb[gp], m->wg_part, m->wg_part_floats); wgrad_done();
-  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1, Gb[gp], m->wtb[3], m->wtf[3]);
+  { auto W = [&]() { prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A2, G0, m->conv[3].dw, bf ? nullptr : m->conv[3].db, B, d.H2, d.W2, 128, 256, 3, 1, m->A2b, Gb[gp], m->wg_part, m->wg_part_floats); };
+    auto D = [&]() { prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[3].w, G1, B, d.H2, d.W2, 128, 256, 3, 1, Gb[gp], m->wtb[3], m->wtf[3]); };
+    if (wg_after) { D(); map_ready(); W(); wgrad_done(); } else { map_ready(); W(); wgrad_done(); D(); } }
   next_map(); prof_mark(m, AOCR_PROF_POOL_CONV1); unpool_relu_backward(s, G1, m->A2, m->idx2, bf ? nullptr : G0, B, d.H1, d.W1, 128, 1, Gb[gp], bf ? m->conv[2].db : nullptr, bf ? slab(5) : nullptr, bf ? m->A2b : nullptr, defer);   // bf16: shadow only + fused bias gradient (fp32 G0 is free: partial slab)
-  map_ready(); prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A1, G0, m->conv[2].dw, bf ? nullptr : m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1, m->A1b, Gb[gp], m->wg_part, m->wg_part_floats); wgrad_done();
-  prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1, Gb[gp], m->wtb[2], m->wtf[2]);
+  { auto W = [&]() { prof_mark(m, AOCR_PROF_CONV_WGRAD); conv_backward_filter(sw, bf, m->A1, G0, m->conv[2].dw, bf ? nullptr : m->conv[2].db, B, d.H1, d.W1, 64, 128, 3, 1, m->A1b, Gb[gp], m->wg_part, m->wg_part_floats); };
+    auto D = [&]() { prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1, Gb[gp], m->wtb[2], m->wtf[2]); };
+    if (wg_after) { D(); map_ready(); W(); wgrad_done(); } else { map_ready(); W(); wgrad_done(); D(); } }
   prof_mark(m, AOCR_PROF_POOL_CONV1); conv1_backward(s, images, m->conv[1].w, m->conv[1].b, G1, m->conv[1].dw, m->conv[1].db, B, d.H, d.W,
                  (size_t)B * d.H1 * d.W1 * 128 >= (size_t)4096 * 640 ? slab(6) : nullptr, defer);      // G0 is free here: use it as the partial slab
   if (defer) colsum_flush(s, cj);                               // conv4.b, conv3.b, conv2.b, conv1.w, conv1.b
