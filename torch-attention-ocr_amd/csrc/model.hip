@@ -958,9 +958,8 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
   // produced by a gather + a K = E product: the same dot products (same kernel, same k order: bit-identical rows), 39 rows instead of 6144 at C3,
   // and 50 MB less written and read per step.  The backward pass follows (decoder_backward: sums of d z by token).  AOCR_NO_EMB_TABLE=1: the tensor.
   m->emb_table = use_cl && segsum_supported(4 * Hd, m->V, E) && !getenv("AOCR_NO_EMB_TABLE");
-  const bool tab_there = m->tab_ready;
-  if (m->tab_ready) { hipStreamWaitEvent(s, m->tab_done, 0); m->tab_ready = false; }       // token_table_prefetch of this step (joined even when unused: the decode path writes the same buffer)
-  if (m->emb_table) { if (!tab_there) gemm(s, bf, m->lookup, E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * Hd, m->V, 4 * Hd, E, p1.bi, p1.bh, 0); }
+  if (m->tab_ready) { hipStreamWaitEvent(s, m->tab_done, 0); m->tab_ready = false; m->tab_valid = true; }       // step_prologue of this call (joined even when unused: the decode path writes the same buffer)
+  if (m->emb_table) { if (!m->tab_valid) { gemm(s, bf, m->lookup, E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * Hd, m->V, 4 * Hd, E, p1.bi, p1.bh, 0); m->tab_valid = true; } }      // (tab_valid: this API call already has the table -- the beam pass in front of a gold pass)
   else {
     embedding_gather(s, m->lookup, tgt, st, sb, m->emb_all, L, B, E);
     gemm(s, bf, m->emb_all, E, true, p1.wi, p1.in, true, m->zx1_all, 4 * Hd, L * B, 4 * Hd, E, p1.bi, p1.bh, 0);
@@ -1059,20 +1058,20 @@ static bool side_create(aocr_model* m) {
 // Start of a training step (aocr_train_forward_backward): what depends on nothing but the parameters -- zeroing the gradient vector (49 MB), the
 // bf16 weight shadows (100 MB of traffic), the token table -- goes to the side stream and runs under conv1 (VALU-bound, 40 us) instead of in front
 // of it; cnn_forward waits for the shadows behind conv1, backward_all for the zeroed gradients.  AOCR_NO_SIDE_PROLOGUE=1: everything in line.
-void step_prologue(aocr_model* m, size_t grad_bytes) {
-  m->tab_ready = m->zero_pending = m->shadow_pending = false;
+void step_prologue(aocr_model* m, size_t grad_bytes) {             // grad_bytes = 0: a decode call (no gradient vector to zero)
+  m->tab_ready = m->zero_pending = m->shadow_pending = m->tab_valid = false;
   auto ev = [](hipEvent_t& e) { return e || hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
   m->tr_pending = false;
   // (bf16 mode only: in exact-fp32 mode the same move -- gradient zeroing and the 16 per-step weight transposes beside the forward pass -- measured SLOWER, C2 7.52 -> 7.74 ms:
   //  the forward pass there is a chain of ~150 small dependent launches, and the side stream's launches get in their way)
   const bool side = m->bf16 && !m->prof_on && !getenv("AOCR_NO_SIDE_WGRAD") && !getenv("AOCR_NO_SIDE_PROLOGUE") && side_create(m) && ev(m->zero_done) && ev(m->shadow_done) && ev(m->tab_done);
-  if (!side) { hipMemsetAsync(m->grads, 0, grad_bytes, m->s); return; }
+  if (!side) { if (grad_bytes) hipMemsetAsync(m->grads, 0, grad_bytes, m->s); return; }
   hipEventRecord(m->side_go, m->s); hipStreamWaitEvent(m->side, m->side_go, 0);       // behind whatever wrote the parameters on the model's stream
   if (!m->shadow_host.empty()) {
     shadow_jobs(m->side, m->shadow_dev, (int)m->shadow_host.size(), m->shadow_tiles);
     hipEventRecord(m->shadow_done, m->side); m->shadow_pending = true;
   }
-  hipMemsetAsync(m->grads, 0, grad_bytes, m->side); hipEventRecord(m->zero_done, m->side); m->zero_pending = true;
+  if (grad_bytes) { hipMemsetAsync(m->grads, 0, grad_bytes, m->side); hipEventRecord(m->zero_done, m->side); m->zero_pending = true; }
   if (m->bzx_tab && !getenv("AOCR_NO_EMB_TABLE") && segsum_supported(4 * m->Hd, m->V, m->E)) {
     const LstmP& p1 = m->dec[0];
     gemm(m->side, true, m->lookup, m->E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * m->Hd, m->V, 4 * m->Hd, m->E, p1.bi, p1.bh, 0);
@@ -1267,7 +1266,8 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
   dec_init_state(m, d, c0, h0, m->bfeed[0], B);
   // The embedding part of the first layer's gate input depends on the token only: one table row per vocabulary entry
   // (lookup W_i2h[:, :E]^T + both biases, LSTM.lua:55-56,79-80), gathered per step instead of a K = 20 GEMM per step.
-  gemm(s, bf, m->lookup, E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * Hd, V, 4 * Hd, E, p1.bi, p1.bh, 0);
+  if (m->tab_ready) { hipStreamWaitEvent(s, m->tab_done, 0); m->tab_ready = false; m->tab_valid = true; }       // step_prologue of this decode call computed it on the side stream
+  if (!m->tab_valid) { gemm(s, bf, m->lookup, E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * Hd, V, 4 * Hd, E, p1.bi, p1.bh, 0); m->tab_valid = true; }
   if (k == 1 && V <= 40 && m->out_b && m->dc_pbuf && !getenv("AOCR_NO_DEC_GREEDY") && dec_cluster_ok(m, T, Lt)) {
     // greedy decode: the whole loop (cell, attention, projector, LogSoftMax, selection) as one launch of the decoder cluster kernel
     float* tc0[MAXL]; float* th0[MAXL];
