@@ -129,6 +129,7 @@ inline bool sync_bn_on(const aocr_model* m) { return m->comm.provider != 0 && m-
 // held behind the encoder BPTT, so no collective kernel is ever co-resident with a cluster kernel.  AOCR_COMM_EARLY_BUCKET0=1 releases it
 // as soon as the decoder's gradients are complete; the encoder cluster launches then keep comm_reserved_cus() compute units free for the
 // collective's workgroups (AOCR_COMM_RESERVE_CUS, default 32 = RCCL's channel count on an 8-GPU xGMI node).
+inline bool env_on(const char* name) { const char* e = getenv(name); return e && e[0] == '1'; }      // round-4 switches test the VALUE ("0" = off)
 inline bool comm_early_bucket0() { return getenv("AOCR_COMM_EARLY_BUCKET0") != nullptr; }      // read per call, like every dispatch switch
 inline bool comm_holds_bucket0(const aocr_model* m) { return m->comm.provider != 0 && !comm_early_bucket0(); }
 inline int comm_reserved_cus(const aocr_model* m) {

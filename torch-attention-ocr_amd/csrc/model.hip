@@ -373,10 +373,10 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   const char* dbg_stop = getenv("AOCR_DBG_STOP");          // debugging aid: leave the gradient map of a stage in place (tap "g0")
   const int stop = dbg_stop ? atoi(dbg_stop) : 0;
   auto evok = [](hipEvent_t& e) { return e || hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
-  const bool ws = bf && m->G2b && !stop && !m->prof_on && m->side && m->side_done && !getenv("AOCR_NO_SIDE_WGRAD") && !getenv("AOCR_NO_CNN_WGRAD_SIDE") &&
+  const bool ws = bf && m->G2b && !stop && !m->prof_on && m->side && m->side_done && !getenv("AOCR_NO_SIDE_WGRAD") && !env_on("AOCR_NO_CNN_WGRAD_SIDE") &&
                   evok(m->cw_map[0]) && evok(m->cw_map[1]) && evok(m->cw_done[0]) && evok(m->cw_done[1]) && evok(m->cw_main);
   hipStream_t sw = ws ? m->side : s;
-  const bool wg_after = ws && getenv("AOCR_CNN_WGRAD_AFTER_DGRAD") != nullptr;      // A/B: start the filter gradient of a stage behind its data gradient (beside the next elementwise pass only)
+  const bool wg_after = ws && env_on("AOCR_CNN_WGRAD_AFTER_DGRAD");      // A/B: start the filter gradient of a stage behind its data gradient (beside the next elementwise pass only)
   if (!ws) Gb[1] = Gb[0];
   auto map_ready = [&]() { if (ws) { hipEventRecord(m->cw_map[gp], s); hipStreamWaitEvent(sw, m->cw_map[gp], 0); } };        // d Y_k (Gb[gp]) is complete: the side stream may read it
   auto wgrad_done = [&]() { if (ws) hipEventRecord(m->cw_done[gp], sw); };
@@ -800,7 +800,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
     // round 4: the layer's weight gradients join the decoder's on the side stream (nothing reads them before the optimizer), behind an event that
     // marks the end of this layer's BPTT: 0.11 ms off the main stream at C3, where they ran between d X and the CNN backward pass
     bool wg_side = false;
-    if (m->side_busy && m->side && !getenv("AOCR_NO_ENC_WGRAD_SIDE")) {
+    if (m->side_busy && m->side && !env_on("AOCR_NO_ENC_WGRAD_SIDE")) {
       if (!m->enc_ev && hipEventCreateWithFlags(&m->enc_ev, hipEventDisableTiming) != hipSuccess) m->enc_ev = nullptr;
       if (m->enc_ev) { hipEventRecord(m->enc_ev, s); wg_side = true; }
     }
@@ -957,7 +957,7 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
   // The whole-sequence kernel reads it from the per-token table [V][4 Hd] (what the decode path already does) instead of a (L B, 4 Hd) tensor
   // produced by a gather + a K = E product: the same dot products (same kernel, same k order: bit-identical rows), 39 rows instead of 6144 at C3,
   // and 50 MB less written and read per step.  The backward pass follows (decoder_backward: sums of d z by token).  AOCR_NO_EMB_TABLE=1: the tensor.
-  m->emb_table = use_cl && segsum_supported(4 * Hd, m->V, E) && !getenv("AOCR_NO_EMB_TABLE");
+  m->emb_table = use_cl && segsum_supported(4 * Hd, m->V, E) && !env_on("AOCR_NO_EMB_TABLE");
   if (m->tab_ready) { hipStreamWaitEvent(s, m->tab_done, 0); m->tab_ready = false; m->tab_valid = true; }       // step_prologue of this call (joined even when unused: the decode path writes the same buffer)
   if (m->emb_table) { if (!m->tab_valid) { gemm(s, bf, m->lookup, E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * Hd, m->V, 4 * Hd, E, p1.bi, p1.bh, 0); m->tab_valid = true; } }      // (tab_valid: this API call already has the table -- the beam pass in front of a gold pass)
   else {
@@ -1064,7 +1064,7 @@ void step_prologue(aocr_model* m, size_t grad_bytes) {             // grad_bytes
   m->tr_pending = false;
   // (bf16 mode only: in exact-fp32 mode the same move -- gradient zeroing and the 16 per-step weight transposes beside the forward pass -- measured SLOWER, C2 7.52 -> 7.74 ms:
   //  the forward pass there is a chain of ~150 small dependent launches, and the side stream's launches get in their way)
-  const bool side = m->bf16 && !m->prof_on && !getenv("AOCR_NO_SIDE_WGRAD") && !getenv("AOCR_NO_SIDE_PROLOGUE") && side_create(m) && ev(m->zero_done) && ev(m->shadow_done) && ev(m->tab_done);
+  const bool side = m->bf16 && !m->prof_on && !getenv("AOCR_NO_SIDE_WGRAD") && !env_on("AOCR_NO_SIDE_PROLOGUE") && side_create(m) && ev(m->zero_done) && ev(m->shadow_done) && ev(m->tab_done);
   if (!side) { if (grad_bytes) hipMemsetAsync(m->grads, 0, grad_bytes, m->s); return; }
   hipEventRecord(m->side_go, m->s); hipStreamWaitEvent(m->side, m->side_go, 0);       // behind whatever wrote the parameters on the model's stream
   if (!m->shadow_host.empty()) {
@@ -1072,7 +1072,7 @@ void step_prologue(aocr_model* m, size_t grad_bytes) {             // grad_bytes
     hipEventRecord(m->shadow_done, m->side); m->shadow_pending = true;
   }
   if (grad_bytes) { hipMemsetAsync(m->grads, 0, grad_bytes, m->side); hipEventRecord(m->zero_done, m->side); m->zero_pending = true; }
-  if (m->bzx_tab && !getenv("AOCR_NO_EMB_TABLE") && segsum_supported(4 * m->Hd, m->V, m->E)) {
+  if (m->bzx_tab && !env_on("AOCR_NO_EMB_TABLE") && segsum_supported(4 * m->Hd, m->V, m->E)) {
     const LstmP& p1 = m->dec[0];
     gemm(m->side, true, m->lookup, m->E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * m->Hd, m->V, 4 * m->Hd, m->E, p1.bi, p1.bh, 0);
     hipEventRecord(m->tab_done, m->side);
@@ -1191,7 +1191,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   // gradients on the side stream too, that stream had become the critical path (the main stream idled ~120 us at the join).  It rejoins the first side
   // stream at the end of this function, so "the side stream is done" still means "every hoisted gradient is done".
   hipStream_t s2 = s;
-  if (m->side_busy && m->side2 && m->side2_done && !getenv("AOCR_NO_SIDE2")) { s2 = m->side2; hipStreamWaitEvent(s2, m->side_go, 0); }
+  if (m->side_busy && m->side2 && m->side2_done && !env_on("AOCR_NO_SIDE2")) { s2 = m->side2; hipStreamWaitEvent(s2, m->side_go, 0); }
   gemm(s2, bf, m->dlogits, LOGIT_LD, false, m->out_all + slot, Hd, false, m->dwo, Hd, V, Hd, rows, nullptr, nullptr, EP_ATOMIC);
   const float* h_top_all = m->dhs[Ld - 1] + slot;
   WGradProblem wg[16]; int nwg = 0;
