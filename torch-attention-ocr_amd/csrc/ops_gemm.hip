@@ -471,9 +471,10 @@ void grouped_wgrad(hipStream_t s, bool bf16, const WGradProblem* p, int n, float
   // problems whose operands both have bf16 shadows (16-byte pieces: M, N, lda, ldb multiples of 8) take the transposed-read kernel
   const WGradProblem* hs[16]; const WGradProblem* fs[16]; const WGradProblem* ds[16]; int nh = 0, nf = 0, nd = 0;
   const bool dma_ok = part && !dma_disabled() && !env_is_1("AOCR_NO_WGRAD_DMA_GROUPED");
+  const char* dmk = getenv("AOCR_WGRAD_DMA_MINK"); const int dma_mink = dmk ? atoi(dmk) : 2048;      // smallest K (rows L B / T B) that takes the LDS-DMA kernel
   for (int i = 0; i < n && i < 16; ++i) {
     const bool ok = p[i].Ab && p[i].Bb && p[i].M % 8 == 0 && p[i].N % 8 == 0 && p[i].lda % 8 == 0 && p[i].ldb % 8 == 0;
-    const bool deep = ok && dma_ok && p[i].M % 256 == 0 && p[i].N % 256 == 0 && p[i].K % 32 == 0 && p[i].K >= 2048 &&
+    const bool deep = ok && dma_ok && p[i].M % 256 == 0 && p[i].N % 256 == 0 && p[i].K % 32 == 0 && p[i].K >= dma_mink &&
                       ((reinterpret_cast<uintptr_t>(p[i].Ab) | reinterpret_cast<uintptr_t>(p[i].Bb)) & 15) == 0;
     if (deep && nd < 8) ds[nd++] = &p[i]; else if (ok) hs[nh++] = &p[i]; else fs[nf++] = &p[i];
   }
