@@ -80,7 +80,12 @@ struct aocr_model {
   float *context, *dctx;
   aocr::bf16_t* context_b;        // bf16 shadow of the context for the attention kernels (bf16 mode)
   // decoder, teacher-forced (rows = B, time-major)
-  float* emb_seg = nullptr; int* emb_index = nullptr; bool emb_table = false; hipEvent_t tab_done = nullptr, enc_ev = nullptr, zero_done = nullptr, shadow_done = nullptr; bool tab_ready = false, tab_valid = false, zero_pending = false, shadow_pending = false, tr_pending = false;   // (step_prologue)   // tab_*: the table was enqueued on the side stream by this step (token_table_prefetch)   // round 4: sums of the first decoder layer's d z by token [V][4 Hd]; the last teacher-forced forward read zx1 from the per-token table
+  // round 4: the embedding side of the first decoder layer through the per-token table (decoder_tf_forward / decoder_backward): sums of d z by token [V][4 Hd], index scratch of the
+  // token sort, "the last teacher-forced forward read zx1 from the table", "this API call already has an up-to-date table"
+  float* emb_seg = nullptr; int* emb_index = nullptr; bool emb_table = false, tab_valid = false;
+  // step_prologue (start of a training step): table / gradient zeroing / weight shadows enqueued on the side stream, and the events the model's stream waits for
+  hipEvent_t tab_done = nullptr, zero_done = nullptr, shadow_done = nullptr; bool tab_ready = false, zero_pending = false, shadow_pending = false;
+  hipEvent_t enc_ev = nullptr;   // end of an encoder layer's BPTT: its weight gradients start behind it on the side stream (encoder_backward)
   float *emb_all, *zx1_all, *dhs[aocr::MAXL], *dcs[aocr::MAXL], *dgates[aocr::MAXL], *ddz[aocr::MAXL];
   float *out_all, *cat_all, *q_all, *a_all, *logits, *dlogits, *nll_rows;
   float *dout_proj, *dpre_all, *dcat_all, *ds_all, *dq_all, *demb_all;

@@ -316,7 +316,7 @@ void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training
   const BnSync bsync_v{bn_sync_allreduce, m}; const BnSync* bsync = (training && sync_bn_on(m)) ? &bsync_v : nullptr;
   if (bf && !m->shadow_host.empty()) {                          // every bf16 shadow of the step in one launch
     if (!m->shadow_pending) shadow_jobs(s, m->shadow_dev, (int)m->shadow_host.size(), m->shadow_tiles);      // (pending: step_prologue put it on the side stream)
-  } else if (!m->tr_pending) {                                  // (tr_pending: step_prologue put the fp32 transposes on the side stream)
+  } else {
     refresh_rnn_shadows(m);
     for (int i = 2; i <= 7; ++i) {                              // refresh the re-laid weight copies (weights change every step)
       if (bf) conv_weight_shadows(s, m->conv[i].w, m->wb[i], m->wtb[i], m->conv[i].cout, m->conv[i].ks * m->conv[i].ks, m->conv[i].cin);
@@ -1061,7 +1061,6 @@ static bool side_create(aocr_model* m) {
 void step_prologue(aocr_model* m, size_t grad_bytes) {             // grad_bytes = 0: a decode call (no gradient vector to zero)
   m->tab_ready = m->zero_pending = m->shadow_pending = m->tab_valid = false;
   auto ev = [](hipEvent_t& e) { return e || hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
-  m->tr_pending = false;
   // (bf16 mode only: in exact-fp32 mode the same move -- gradient zeroing and the 16 per-step weight transposes beside the forward pass -- measured SLOWER, C2 7.52 -> 7.74 ms:
   //  the forward pass there is a chain of ~150 small dependent launches, and the side stream's launches get in their way)
   const bool side = m->bf16 && !m->prof_on && !getenv("AOCR_NO_SIDE_WGRAD") && !env_on("AOCR_NO_SIDE_PROLOGUE") && side_create(m) && ev(m->zero_done) && ev(m->shadow_done) && ev(m->tab_done);
@@ -1235,7 +1234,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
 // still runs (aocr_grad_buckets / aocr_stream_wait_grads).
 void backward_all(aocr_model* m, const float* images, const int32_t* tgt, const Dims& d) {
   m->side_busy = false;
-  if (m->zero_pending) { hipStreamWaitEvent(m->s, m->zero_done, 0); m->zero_pending = false; m->tr_pending = false; }          // step_prologue zeroed the gradient vector (fp32 mode: and re-laid the weights) on the side stream
+  if (m->zero_pending) { hipStreamWaitEvent(m->s, m->zero_done, 0); m->zero_pending = false; }          // step_prologue zeroed the gradient vector on the side stream
   decoder_backward(m, d, tgt);
   // Exchange policy: NO collective is in flight while a whole-sequence kernel runs.  A collective's kernel stays
   // resident until every peer has joined it; a cluster kernel needs all members of a group resident at once and bounds its spins.  With
