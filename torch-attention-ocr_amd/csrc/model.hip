@@ -898,29 +898,17 @@ static void dec_step_forward(aocr_model* m, const DecStepIO& io, int T) {
 
 // initial decoder state from the encoder's final states, model.lua:539-552 (+ quirk S5)
 static void dec_init_state(aocr_model* m, const Dims& d, float* const* c0, float* const* h0, float* feed0, int R, bool shadows = false) {
-  hipStream_t s = m->s; const int B = d.B, T = d.T, He = m->He, Hd = m->Hd; const size_t slot = (size_t)B * He;
+  const int B = d.B, T = d.T, He = m->He, Hd = m->Hd; const size_t slot = (size_t)B * He;
   (void)R;
   const int lt = m->Le - 1;
-  ZeroList zl;                                          // MAXL = 4 layers: at most 4*3 + 2 = 14 regions
-  for (int l = 0; l < m->Ld; ++l) { zl.add(c0[l], (size_t)B * Hd * sizeof(float)); zl.add(h0[l], (size_t)B * Hd * sizeof(float)); }
-  if (feed0) zl.add(feed0, (size_t)B * Hd * sizeof(float));
-  if (shadows) {
-    for (int l = 0; l < m->Ld; ++l) zl.add(m->dhs_b[l], (size_t)B * Hd * sizeof(bf16_t));
-    zl.add(m->out_b, (size_t)B * Hd * sizeof(bf16_t));
-  }
-  zero_many(s, zl);
-  // c1(0) = [c_fw(T) ; c_bw(1)]
-  copy2d(s, m->ecs[0][lt] + (size_t)T * slot, He, c0[0], Hd, B, He);
-  copy2d(s, m->ecs[1][lt] + (size_t)1 * slot, He, c0[0] + He, Hd, B, He);
-  const bool quirk_s5 = m->cfg.input_feed && m->Ld >= 2;     // model.lua:549-552 zeroes h1(0) instead of h2(0)
-  if (!quirk_s5) {
-    copy2d(s, m->ehs[0][lt] + (size_t)T * slot, He, h0[0], Hd, B, He);
-    copy2d(s, m->ehs[1][lt] + (size_t)1 * slot, He, h0[0] + He, Hd, B, He);
-    if (shadows) {
-      copy2d_bf16(s, m->ehs[0][lt] + (size_t)T * slot, He, m->dhs_b[0], Hd, B, He);
-      copy2d_bf16(s, m->ehs[1][lt] + (size_t)1 * slot, He, m->dhs_b[0] + He, Hd, B, He);
-    }
-  }
+  DecInitArgs a{};
+  for (int l = 0; l < m->Ld && l < 4; ++l) { a.c0[l] = c0[l]; a.h0[l] = h0[l]; a.hb[l] = shadows ? m->dhs_b[l] : nullptr; }
+  a.feed0 = feed0; a.outb = shadows ? m->out_b : nullptr;
+  // c1(0) = [c_fw(T) ; c_bw(1)]; model.lua:549-552 (quirk S5) zeroes h1(0) instead of h2(0) with input feed and two or more layers
+  a.cfw = m->ecs[0][lt] + (size_t)T * slot; a.cbw = m->ecs[1][lt] + (size_t)1 * slot;
+  a.hfw = m->ehs[0][lt] + (size_t)T * slot; a.hbw = m->ehs[1][lt] + (size_t)1 * slot;
+  a.B = B; a.He = He; a.Hd = Hd; a.Ld = m->Ld; a.copy_h = (m->cfg.input_feed && m->Ld >= 2) ? 0 : 1;
+  dec_init(m->s, a);
 }
 
 // The decoder cluster kernel (dec_cluster.hip): bf16 mode, Hd = 512, two layers, input feed (the reference's defaults at
@@ -1262,7 +1250,6 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
   const LstmP& p1 = m->dec[0];
   float* c0[MAXL]; float* h0[MAXL];
   for (int l = 0; l < Ld; ++l) { c0[l] = m->bc[0][l]; h0[l] = m->bh[0][l]; }
-  dec_init_state(m, d, c0, h0, m->bfeed[0], B);
   // The embedding part of the first layer's gate input depends on the token only: one table row per vocabulary entry
   // (lookup W_i2h[:, :E]^T + both biases, LSTM.lua:55-56,79-80), gathered per step instead of a K = 20 GEMM per step.
   if (m->tab_ready) { hipStreamWaitEvent(s, m->tab_done, 0); m->tab_ready = false; m->tab_valid = true; }       // step_prologue of this decode call computed it on the side stream
@@ -1286,6 +1273,7 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
     dec_cluster_forward(s, a, true);
     return;
   }
+  dec_init_state(m, d, c0, h0, m->bfeed[0], B);                    // the launch chain's beam buffers (the greedy cluster kernel above has its own: not initialised for nothing)
   int cur = 0;
   for (int t = 0; t < Lt; ++t) {
     const int kin = t == 0 ? 1 : k, R = B * kin;

@@ -1721,6 +1721,28 @@ void copy2d_bf16(hipStream_t s, const float* src, int64_t lds, bf16_t* dst, int6
   }
   hipLaunchKernelGGL(copy2d_bf16_kernel, dim3(cdiv((int64_t)rows * cols, 256)), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
 }
+// Initial decoder state in ONE launch (model.lua:541-552): c_1(0) = [c_fw(T) ; c_bw(1)] (and h_1(0) likewise unless quirk S5 zeroes it), every other
+// state, the first input feed and their bf16 shadows zero.  Was a zero-list launch + 2-4 strided copies, 3-5 dependent ~6 us dispatches per call.
+__global__ __launch_bounds__(256) void dec_init_kernel(DecInitArgs a) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)a.B * a.Hd) return;
+  const int r = (int)(idx / a.Hd), j = (int)(idx - (int64_t)r * a.Hd);
+  const bool fw = j < a.He, in = j < 2 * a.He;
+  const int64_t e = (int64_t)r * a.He + (fw ? j : j - a.He);
+  const float c = in ? (fw ? a.cfw[e] : a.cbw[e]) : 0.f;
+  const float h = (in && a.copy_h) ? (fw ? a.hfw[e] : a.hbw[e]) : 0.f;
+  for (int l = 0; l < a.Ld; ++l) {
+    a.c0[l][idx] = l == 0 ? c : 0.f;
+    const float hv = l == 0 ? h : 0.f;
+    a.h0[l][idx] = hv;
+    if (a.hb[l]) a.hb[l][idx] = (bf16_t)hv;
+  }
+  if (a.feed0) a.feed0[idx] = 0.f;
+  if (a.outb) a.outb[idx] = (bf16_t)0.f;
+}
+void dec_init(hipStream_t s, const DecInitArgs& a) {
+  hipLaunchKernelGGL(dec_init_kernel, dim3(cdiv((int64_t)a.B * a.Hd, 256)), dim3(256), 0, s, a);
+}
 void copy2d(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols) {
   hipLaunchKernelGGL(copy2d_kernel, dim3(cdiv((int64_t)rows * cols, 256)), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
 }
