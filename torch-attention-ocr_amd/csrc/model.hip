@@ -739,10 +739,8 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
   for (int l = m->Le - 1; l >= 0; --l) {
     const bool top = l == m->Le - 1;
     prof_mark(m, AOCR_PROF_ENC_SEQ);
-    for (int dir = 0; dir < 2; ++dir) {
-      if (top) copy2d(s, m->dc_st[0] + dir * He, Hd, m->edc[dir][l], He, B, He);        // model.lua:666,680
-      else hipMemsetAsync(m->edc[dir][l], 0, slot * sizeof(float), s);
-    }
+    if (top) copy2d_pair(s, m->dc_st[0], m->dc_st[0] + He, Hd, m->edc[0][l], m->edc[1][l], He, B, He);        // model.lua:666,680 (both directions in one launch)
+    else for (int dir = 0; dir < 2; ++dir) hipMemsetAsync(m->edc[dir][l], 0, slot * sizeof(float), s);
     int clG = 0, clRT = 0, clGroups = 0;
     const bool cluster = cluster_ok(m, B, T, clG, clRT, clGroups) && m->edz_b[0][l] && m->enc[0][l].swh.wtb;
     const bool seq = cluster || (seq_kernels_ok(m, B) && m->edz_b[0][l] && m->enc[0][l].swh.wtb);
@@ -1080,9 +1078,11 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   ColsumJobs cj; cj.n = 0; cj.total = 0;                          // projector bias + the LSTM biases of every layer: one launch at the end of this pass
   colsum_defer(cj, m->dlogits, LOGIT_LD, rows, V, m->dbo);
   prof_mark(m, AOCR_PROF_DEC_BWD);
-  { ZeroList zl; for (int l = 0; l < Ld; ++l) { zl.add(m->dh_rec[l], slot * sizeof(float)); zl.add(m->dc_st[l], slot * sizeof(float)); } zero_many(s, zl); }
+  const bool cl_bwd = m->dgates_il && dec_cluster_bwd_ok(m, T, L);
+  // (the launch chain accumulates into the initial-state gradients; the whole-sequence kernel writes every element of them at its end -- no zeroing launch in front of it)
+  if (!cl_bwd) { ZeroList zl; for (int l = 0; l < Ld; ++l) { zl.add(m->dh_rec[l], slot * sizeof(float)); zl.add(m->dc_st[l], slot * sizeof(float)); } zero_many(s, zl); }
   const bool feed_fused = m->cfg.input_feed && Ld <= 2 && !m->drop_on;  // the feed product joins the grouped launch and carries the tanh backward (dropout: the separate d pre kernel knows the mask)
-  if (m->dgates_il && dec_cluster_bwd_ok(m, T, L)) {     // the whole loop as one launch (dec_cluster.hip); needs the forward cluster kernel's saved state
+  if (cl_bwd) {     // the whole loop as one launch (dec_cluster.hip); needs the forward cluster kernel's saved state
     DecClBwdArgs a; a.B = B; a.T = T; a.L = L; a.epoch = next_epoch(m);
     a.w2i_t = m->dec[1].swi.wtb; a.w2h_t = m->dec[1].swh.wtb; a.w1h_t = m->dec[0].swh.wtb; a.w1f_t = m->dec[0].swi.wtb;
     a.wc_t = m->swc.wtb; a.wa_t = m->swa.wtb; a.dout_proj = m->dout_proj; a.out = m->out_all; a.a_all = m->a_all; a.ctxb = m->context_b;

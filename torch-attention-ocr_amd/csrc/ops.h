@@ -187,6 +187,7 @@ void dropout_apply(hipStream_t s, const float* src, float* dst, bf16_t* dstb, in
 void dropout_apply_b(hipStream_t s, const bf16_t* src, float* dst, bf16_t* dstb, int64_t n, const DropSpec& drop);  // (g1+g2)*(1-out^2)
 void copy2d_bf16(hipStream_t s, const float* src, int64_t lds, bf16_t* dst, int64_t ldd, int rows, int cols);
 void copy2d(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols);
+void copy2d_pair(hipStream_t s, const float* s0, const float* s1, int64_t lds, float* d0, float* d1, int64_t ldd, int rows, int cols);
 struct DecInitArgs { float* c0[4]; float* h0[4]; bf16_t* hb[4]; float* feed0; bf16_t* outb; const float *cfw, *cbw, *hfw, *hbw; int B, He, Hd, Ld, copy_h; };
 void dec_init(hipStream_t s, const DecInitArgs& a);              // the decoder's initial state in one launch (ops_misc.hip)
 void sgd_clip_update(hipStream_t s, float* params, float* grads, const int64_t* group_off /*6 host values*/, float lr,

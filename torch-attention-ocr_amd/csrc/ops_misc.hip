@@ -1743,6 +1743,17 @@ __global__ __launch_bounds__(256) void dec_init_kernel(DecInitArgs a) {
 void dec_init(hipStream_t s, const DecInitArgs& a) {
   hipLaunchKernelGGL(dec_init_kernel, dim3(cdiv((int64_t)a.B * a.Hd, 256)), dim3(256), 0, s, a);
 }
+// two strided copies of the same shape in one launch (blockIdx.y picks the pair): the two halves of the decoder's initial-cell gradient -> the two encoder directions
+__global__ __launch_bounds__(256) void copy2d_pair_kernel(const float* __restrict__ s0, const float* __restrict__ s1, int64_t lds, float* __restrict__ d0, float* __restrict__ d1, int64_t ldd, int rows, int cols) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+  const float* src = blockIdx.y ? s1 : s0; float* dst = blockIdx.y ? d1 : d0;
+  dst[(int64_t)r * ldd + c] = src[(int64_t)r * lds + c];
+}
+void copy2d_pair(hipStream_t s, const float* s0, const float* s1, int64_t lds, float* d0, float* d1, int64_t ldd, int rows, int cols) {
+  hipLaunchKernelGGL(copy2d_pair_kernel, dim3(cdiv((int64_t)rows * cols, 256), 2), dim3(256), 0, s, s0, s1, lds, d0, d1, ldd, rows, cols);
+}
 void copy2d(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols) {
   hipLaunchKernelGGL(copy2d_kernel, dim3(cdiv((int64_t)rows * cols, 256)), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
 }
