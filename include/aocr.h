@@ -86,8 +86,10 @@ int aocr_model_set_stream(aocr_model* m, void* stream);
  * *code = 0: healthy; a non-zero code is cleared by the call (read and clear).
  * Under data parallelism the code is a GLOBAL decision (round 4): aocr_allreduce_grads sums a time-out flag with the exchange, and a rank whose own
  * kernels were healthy while a peer's were not reads 0x7e -- so every rank's optimizer skips the update and every host repeats the step together.
- * After a non-zero code the NEXT aocr_train_forward_backward (the repeat of the skipped step) leaves the BatchNorm running statistics alone: the
- * skipped step's CNN forward -- untouched by the time-out -- has already moved them once.
+ * The optimizer call that skips an update also restores the BatchNorm running statistics to their values at the start of that step (device side, round 5):
+ * a skipped step leaves NO trace, so the host may repeat the batch at once, later (polling every N steps) or never.
+ * A caller that sums the gradient buckets itself (aocr_stream_wait_grads) must also take the MAX over ranks of the status word (tap "cl_err"[0]) before
+ * aocr_sgd_step, as aocr_allreduce_grads does inside the library; the Python mirror does (Model._exchange_timeout_flag).
  * Synchronises the model's stream.  No reference counterpart.
  * These kernels need the device to themselves: a launch occupies every compute unit, so the steps of two models (or two processes)
  * must not run concurrently on ONE device -- AOCR_NO_CLUSTER=1 AOCR_NO_DEC_CLUSTER=1 selects the per-step launch chains for that case. */

@@ -186,15 +186,15 @@ def _worker_timeout(rank, world, port, q):
     m.train_step_device(images, targets, targets_eval, 8)           # feval + exchange (the flag travels with it) + clip + update
     torch.cuda.synchronize()
     skipped = bool(torch.equal(m.params, p0))
-    code = m.cluster_status()                                       # read and clear; the repeat must not move the running statistics again
+    code = m.cluster_status()                                       # read and clear
     bn_mid = {k: v.clone() for k, v in m.get_bn_state().items()}
     m.train_step_device(images, targets, targets_eval, 8)           # the repeat, on every rank together
     torch.cuda.synchronize()
     code2 = m.cluster_status()
     params = {k: v.numpy() for k, v in m.get_parameters().items()}
     bn = {k: v.numpy() for k, v in m.get_bn_state().items()}
-    same_bn = all(torch.equal(bn_mid[k], torch.from_numpy(bn[k])) for k in bn)
-    moved_bn = any(not torch.equal(bn_mid[k], bn0[k]) for k in bn0)
+    same_bn = all(torch.equal(bn_mid[k], bn0[k]) for k in bn0)       # the skipped step's move was taken back by the optimizer call that skipped (round 5)
+    moved_bn = any(not torch.equal(bn_mid[k], torch.from_numpy(bn[k])) for k in bn)      # ... and the repeat moved them (once: compared with the clean step below)
     q.put((rank, skipped, code, code2, params, bn, same_bn, moved_bn))
     dist.barrier()
     m.shutdown()
@@ -227,7 +227,7 @@ def test_dp2_cluster_timeout_is_a_global_decision(cuda, monkeypatch):
     print(f"[dp] injected time-out on rank 1: update skipped on rank 0 / 1: {sk0} / {sk1}; status codes {c0:#x} / {c1:#x}, after the repeat {c0b} / {c1b}")
     assert sk0 and sk1, "a rank applied an update computed from gradients another rank flagged invalid"
     assert c0 == 0x7e and c1 == 23 and c0b == 0 and c1b == 0
-    assert same0 and same1 and moved0 and moved1, "the repeated step moved the BatchNorm running statistics a second time"
+    assert same0 and same1 and moved0 and moved1, "the skipped step left its move of the BatchNorm running statistics behind, or the repeat did not move them"
     for k in pa0:
         assert np.array_equal(pa0[k], pa1[k]), k                    # the replicas did not diverge
     dp = max(float(np.abs(pa0[k] - p1[k]).max()) for k in p1)

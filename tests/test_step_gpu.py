@@ -960,12 +960,25 @@ def test_update_is_skipped_when_a_cluster_kernel_timed_out(cuda):
     off = p.value - m.workspace.data_ptr()
     flag = m.workspace[off:off + 4].view(torch.int32)
     before = m.params.clone()
+    bn0 = m.bn_state.clone()
+    m.train_forward_backward(batch)                                 # a step whose kernels "time out": its CNN forward moves the running statistics
+    bn_moved = m.bn_state.clone()
+    assert not torch.equal(bn_moved, bn0)
     flag.fill_(23)                                                  # "dq raise/wait timed out"
     m.sgd_step(lr=0.1)
-    m.adadelta_step()
     torch.cuda.synchronize()
     assert torch.equal(m.params, before), "the update ran on gradients flagged invalid"
+    # the optimizer call that skips the update also takes the step's move of the running statistics back (device side),
+    # so a repeat of the batch moves them exactly once whenever the host polls the status -- and a host that never repeats loses nothing else
+    assert torch.equal(m.bn_state, bn0), "the skipped step's move of the BatchNorm running statistics was not taken back"
+    m.train_forward_backward(batch)                                 # the host has not polled yet: the next step is skipped as well, and restored as well
+    m.adadelta_step()
+    torch.cuda.synchronize()
+    assert torch.equal(m.params, before) and torch.equal(m.bn_state, bn0)
     assert m.cluster_status() == 23 and m.cluster_status() == 0     # read and clear
+    m.train_forward_backward(batch)                                 # the repeat: a clean step moves them once
+    torch.cuda.synchronize()
+    assert torch.equal(m.bn_state, bn_moved)
     m.sgd_step(lr=0.1)
     torch.cuda.synchronize()
     assert not torch.equal(m.params, before)

@@ -329,10 +329,22 @@ class Model:
                 self._comm_stream = torch.cuda.Stream(device=self.device)
                 self._buckets = dist.bucket_ranges(self.ccfg)
             dist.exchange_overlapped(self.grad_params, loss_dev, self._buckets, self._wait_bucket, self._comm_stream)
+        if dist.world_size() > 1 and getattr(self, "_comm_cb", None) is None and not getattr(self, "_comm_rccl", False):
+            self._exchange_timeout_flag()
         norms = self._scal[2:12]
         check(lib.aocr_sgd_step(self._h, float(self.optim_state["learningRate"]), 5.0, ptr(norms)), "aocr_sgd_step")
         self.last_norms = norms
         return loss_dev
+
+    def _exchange_timeout_flag(self):
+        """Host-side exchange paths (AOCR_PY_EXCHANGE): a caller that sums the gradient buckets itself must also make the cluster
+        kernels' time-out code a GLOBAL decision, as aocr_allreduce_grads does inside the library (include/aocr.h, aocr_cluster_status):
+        MAX over ranks of the status word, so every rank's optimizer skips (or applies) the update together."""
+        try:
+            flag = self.get_tensor_view("cl_err")[0:1]
+        except RuntimeError:
+            return                                                # configuration without whole-sequence kernels: nothing can time out
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
 
     def _wait_bucket(self, k, stream):
         check(lib.aocr_stream_wait_grads(self._h, k, C.c_void_p(stream.cuda_stream)), "aocr_stream_wait_grads")
@@ -522,6 +534,10 @@ class Model:
         running statistics are rank-local -- every rank calls `sync_bn_state()` before rank 0 saves."""
         if str(model_path).endswith(".t7") or layout in ("reference", "flat"):
             from .checkpoint import write_flat_checkpoint, write_reference_checkpoint
+            if layout is None:                                    # ADVICE round 4: the .t7 default is NOT what upstream model:load reads -- say so once per call
+                import warnings
+                warnings.warn(f"Model.save({str(model_path)!r}): writing the flat 'aocr-flat-1' table; the reference's model:load "
+                              "(src/model/model.lua:52-60) reads layout='reference' (or the Lua glue of INTEGRATION.md)", stacklevel=2)
             writer = write_reference_checkpoint if layout == "reference" else write_flat_checkpoint
             writer(model_path, {k: v.numpy() for k, v in self.get_parameters().items()},
                    {k: v.numpy() for k, v in self.get_bn_state().items()}, self.config, self.global_step, self.optim_state)

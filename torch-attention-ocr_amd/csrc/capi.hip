@@ -244,9 +244,9 @@ int aocr_cluster_status(aocr_model* m, int32_t* code) {
     return fail("aocr_cluster_status: %s", hipGetErrorString(hipGetLastError()));
   if (*code != 0) {
     hipMemsetAsync(m->cl_err, 0, sizeof(int32_t), m->s);      // read and clear: the next call reports the steps after this one
-    // the host repeats the step whose update was skipped (lua/model.lua, include/aocr.h): that step's CNN forward -- untouched by the
-    // time-out -- has already moved the BatchNorm running statistics once, so the repeat must not move them again
-    m->skip_running_once = true;
+    // (the skipped step's move of the BatchNorm running statistics was taken back by the optimizer call that skipped the update --
+    //  sgd_update_kernel / adadelta_kernel restore the snapshot of step_prologue -- so a repeat of the batch moves them exactly once,
+    //  whenever the host polls)
   }
   return 0;
 }
@@ -266,8 +266,7 @@ int aocr_train_forward_backward(aocr_model* m, const float* images_dev, const in
   prof_mark(m, AOCR_PROF_OTHER);
   step_prologue(m, (size_t)m->layout.group_off[AOCR_NUM_GROUPS] * sizeof(float));      // model.lua:637-639 (zeroGradParameters) + the step's parameter-only work
   m->drop_on = m->drop_thr != 0;                                          // nn.Dropout is active in training() mode only (model.lua:284)
-  cnn_forward(m, images_dev, d, 1, m->skip_running_once ? 0 : 1);
-  m->skip_running_once = false;
+  cnn_forward(m, images_dev, d, 1, 1);
   encoder_forward(m, d);
   decoder_tf_forward(m, d, targets_dev, 1, L, true);
   loss_and_dlogits(m, d, targets_eval_dev, 1, L, grad_scale, true, loss_dev);
@@ -304,7 +303,7 @@ int aocr_stream_wait_grads(aocr_model* m, int32_t bucket, void* stream) {
 int aocr_sgd_step(aocr_model* m, float lr, float clip, float* norms_dev) {
   REQUIRE(m, "NULL model");
   prof_mark(m, AOCR_PROF_SGD);
-  sgd_clip_update(m->s, m->params, m->grads, m->layout.group_off, lr, clip, norms_dev, m->sgd_scratch, m->cl_err);
+  sgd_clip_update(m->s, m->params, m->grads, m->layout.group_off, lr, clip, norms_dev, m->sgd_scratch, m->cl_err, m->bn_snap ? m->bn_state : nullptr, m->bn_snap, (int)aocr_bn_state_count());
   prof_mark(m, -1);
   return check_launch("aocr_sgd_step");
 }
@@ -313,7 +312,7 @@ int aocr_adadelta_step(aocr_model* m, float rho, float eps, float weight_decay, 
   REQUIRE(m && state_dev, "NULL argument");
   REQUIRE(rho >= 0.f && rho < 1.f && eps > 0.f, "rho=%g eps=%g out of range", rho, eps);
   const int64_t n = m->layout.group_off[AOCR_NUM_GROUPS];
-  adadelta_update(m->s, m->params, m->grads, state_dev, state_dev + n, n, rho, eps, weight_decay, m->cl_err);
+  adadelta_update(m->s, m->params, m->grads, state_dev, state_dev + n, n, rho, eps, weight_decay, m->cl_err, m->bn_snap ? m->bn_state : nullptr, m->bn_snap, (int)aocr_bn_state_count());
   return check_launch("aocr_adadelta_step");
 }
 
@@ -434,9 +433,12 @@ int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_p
   REQUIRE(iters >= 1, "iters must be >= 1");
   REQUIRE(which < 2 || (m->bf16 && m->last_images && m->last_train), "the HBM-bound kernel ids replay the bf16 TRAINING step: run aocr_train_forward_backward in bf16 mode first");
   const Dims& d = m->last;
+  const int64_t n5 = (int64_t)d.B * d.H4 * d.W2;            // pixels of the conv5 / conv6 maps (512 channels)
+  // the replays write where the step writes: guard the buffers they assume
+  REQUIRE((which != 1 && which != AOCR_PK_SPLITK) || (size_t)512 * 4608 <= m->gmax, "kernel id %d sums conv6's filter gradient (512 x 4608 floats) into the gradient-map scratch, which holds %zu floats in this configuration", which, m->gmax);
+  REQUIRE((which != AOCR_PK_BN_FWD && which != AOCR_PK_BN_BWD && which != AOCR_PK_UNPOOL) || (n5 % 256 == 0 && n5 / 256 <= 512), "kernel id %d replays conv5's BatchNorm with the epilogue's 256-pixel statistics chunks: %lld pixels are not a multiple of 256 / more than 512 chunks", which, (long long)n5);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipStream_t s = m->s; const int B = d.B;
-  const int64_t n5 = (int64_t)B * d.H4 * d.W2;              // pixels of the conv5 / conv6 maps (512 channels)
   constexpr size_t SLAB = (size_t)4 << 20;
   double bytes = 0.0;
   // bf16 data-gradient maps (conv_backward_data's dx16, round 4): what the step's BatchNorm backward / un-pool passes read when the switch is on

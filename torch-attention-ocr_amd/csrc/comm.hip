@@ -128,7 +128,7 @@ int comm_allreduce_grads(aocr_model* m, float* loss_dev) {
     if (k == 0 && loss_dev && comm_allreduce(m, loss_dev, 1, 0, cs, 0) != 0) return 2;      // the loss is final before the backward pass starts
     if (k == 1 && m->cl_err) {
       // every whole-sequence kernel of the step has completed (grad_ev[1] is recorded behind the encoder BPTT): agree on the time-out flag
-      float* flag = reinterpret_cast<float*>(m->cl_err + 4);                               // ints 4..7 of the flag block: exchange scratch
+      float* flag = reinterpret_cast<float*>(m->cl_err + 8);                               // ints 8..11 of the flag block: exchange scratch (1..4 hold the encoder kernel's time-out diagnostics, the trash slots start at 16)
       hipLaunchKernelGGL(cl_flag_pack_kernel, dim3(1), dim3(1), 0, cs, m->cl_err, flag);
       if (comm_allreduce(m, flag, 1, 0, cs, 0) != 0) return 2;
       hipLaunchKernelGGL(cl_flag_merge_kernel, dim3(1), dim3(1), 0, cs, m->cl_err, flag);

@@ -116,7 +116,7 @@ struct aocr_model {
   double drop_p = 0.0; unsigned long long drop_thr = 0, drop_seed = 0, drop_step = 0; bool drop_on = false;
   float* dhm[aocr::MAXL] = {}; aocr::bf16_t* dhm_b[aocr::MAXL] = {}; float* ehm[2][aocr::MAXL] = {}; aocr::bf16_t* ehm_b[2][aocr::MAXL] = {};   // decoder cluster kernel (dec_cluster.hip)
   aocr::CommState comm;
-  bool skip_running_once = false;  // set by aocr_cluster_status when it reports a time-out: the next training forward is the repeat of a skipped step
+  float* bn_snap = nullptr;        // the BatchNorm running statistics as they were at the start of the current training step (step_prologue); restored on the device by the optimizer call that skips a timed-out step's update
   // per-family HIP-event profile (aocr_profile_enable): a mark = "family `tag` runs from here to the next mark"
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev; std::vector<int> prof_tag; size_t prof_n = 0;
@@ -135,7 +135,7 @@ inline bool sync_bn_on(const aocr_model* m) { return m->comm.provider != 0 && m-
 // as soon as the decoder's gradients are complete; the encoder cluster launches then keep comm_reserved_cus() compute units free for the
 // collective's workgroups (AOCR_COMM_RESERVE_CUS, default 32 = RCCL's channel count on an 8-GPU xGMI node).
 inline bool env_on(const char* name) { const char* e = getenv(name); return e && e[0] == '1'; }      // round-4 switches test the VALUE ("0" = off)
-inline bool comm_early_bucket0() { return getenv("AOCR_COMM_EARLY_BUCKET0") != nullptr; }      // read per call, like every dispatch switch
+inline bool comm_early_bucket0() { return env_on("AOCR_COMM_EARLY_BUCKET0"); }      // read per call, like every dispatch switch
 inline bool comm_holds_bucket0(const aocr_model* m) { return m->comm.provider != 0 && !comm_early_bucket0(); }
 inline int comm_reserved_cus(const aocr_model* m) {
   if (m->comm.provider == 0 || !comm_early_bucket0()) return 0;

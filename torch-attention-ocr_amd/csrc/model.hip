@@ -169,6 +169,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     m->cl_tbytes = ((size_t)m->Le * 2 * ((B + 15) / 16) * 8 + 64) * 8;
     m->cl_xtab = a.get<unsigned long long>(m->cl_tbytes / 8);      // XCC ids of the members of every group
     m->cl_err = a.get<int>(16 + 256 * 8 + 4096);                 // error flag + the trash slots rows >= B store to + a debugging timeline
+    m->bn_snap = a.get<float>(2 * (256 + 512 + 512));            // aocr_bn_state_count() floats
     if (Hd == 512 && m->Ld == 2 && m->cfg.input_feed) {          // the decoder loop as one launch (dec_cluster.hip)
       m->dc_xbytes = dec_cluster_xbuf_bytes((int)B); m->dc_tbytes = dec_cluster_xtab_bytes((int)B);
       m->dc_xbuf = a.get<unsigned long long>(m->dc_xbytes / 8); m->dc_xtab = a.get<unsigned long long>(m->dc_tbytes / 8);
@@ -1049,9 +1050,15 @@ void step_prologue(aocr_model* m, size_t grad_bytes) {             // grad_bytes
   auto ev = [](hipEvent_t& e) { return e || hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
   // (bf16 mode only: in exact-fp32 mode the same move -- gradient zeroing and the 16 per-step weight transposes beside the forward pass -- measured SLOWER, C2 7.52 -> 7.74 ms:
   //  the forward pass there is a chain of ~150 small dependent launches, and the side stream's launches get in their way)
+  const size_t bn_bytes = (size_t)2 * (256 + 512 + 512) * sizeof(float);
   const bool side = m->bf16 && !m->prof_on && !getenv("AOCR_NO_SIDE_WGRAD") && !env_on("AOCR_NO_SIDE_PROLOGUE") && side_create(m) && ev(m->zero_done) && ev(m->shadow_done) && ev(m->tab_done);
-  if (!side) { if (grad_bytes) hipMemsetAsync(m->grads, 0, grad_bytes, m->s); return; }
+  if (!side) {
+    if (grad_bytes) { hipMemsetAsync(m->grads, 0, grad_bytes, m->s); if (m->bn_snap) hipMemcpyAsync(m->bn_snap, m->bn_state, bn_bytes, hipMemcpyDeviceToDevice, m->s); }
+    return;
+  }
   hipEventRecord(m->side_go, m->s); hipStreamWaitEvent(m->side, m->side_go, 0);       // behind whatever wrote the parameters on the model's stream
+  // snapshot of the running statistics (10 KB): in front of the shadows, which cnn_forward joins before its first BatchNorm layer
+  if (grad_bytes && m->bn_snap) hipMemcpyAsync(m->bn_snap, m->bn_state, bn_bytes, hipMemcpyDeviceToDevice, m->shadow_host.empty() ? m->s : m->side);
   if (!m->shadow_host.empty()) {
     shadow_jobs(m->side, m->shadow_dev, (int)m->shadow_host.size(), m->shadow_tiles);
     hipEventRecord(m->shadow_done, m->side); m->shadow_pending = true;

@@ -1801,8 +1801,15 @@ __global__ void sgd_scale_kernel(const double* __restrict__ part, float clip, fl
   if (norms) { norms[grp * 2] = (float)pn; norms[grp * 2 + 1] = (float)gn; }
 }
 __global__ __launch_bounds__(256) void sgd_update_kernel(float* __restrict__ p, const float* __restrict__ g, GroupOff go,
-                                                         const float* __restrict__ scale, float lr, const int* __restrict__ skip) {
-  if (skip && *skip != 0) return;      // a whole-sequence kernel of this step gave up waiting for its group (aocr_cluster_status): its gradients are invalid, keep the parameters
+                                                         const float* __restrict__ scale, float lr, const int* __restrict__ skip,
+                                                         float* __restrict__ bn_state, const float* __restrict__ bn_snap, int bn_n) {
+  if (skip && *skip != 0) {            // a whole-sequence kernel of this step gave up waiting for its group (aocr_cluster_status): its gradients are invalid, keep the parameters
+    // ... and take back the step's move of the BatchNorm running statistics (snapshot from the start of the step): the host repeats the
+    // batch, and the repeat moves them once -- whenever the host happens to poll the status
+    if (bn_state && blockIdx.y == 0)
+      for (int i = blockIdx.x * 256 + threadIdx.x; i < bn_n; i += gridDim.x * 256) bn_state[i] = bn_snap[i];
+    return;
+  }
   const int grp = blockIdx.y;
   const int64_t beg = go.o[grp], end = go.o[grp + 1];
   const float sc = scale[grp];
@@ -1818,12 +1825,12 @@ __global__ __launch_bounds__(256) void sgd_update_kernel(float* __restrict__ p, 
   }
 }
 void sgd_clip_update(hipStream_t s, float* params, float* grads, const int64_t* group_off, float lr, float clip, float* norms_out,
-                     void* scratch, const int* skip) {
+                     void* scratch, const int* skip, float* bn_state, const float* bn_snap, int bn_n) {
   GroupOff go; for (int i = 0; i < 6; ++i) go.o[i] = group_off[i];
   double* part = (double*)scratch; float* scale = (float*)(part + 5 * 2 * SGD_BLOCKS);
   hipLaunchKernelGGL(sgd_sumsq_kernel, dim3(SGD_BLOCKS, 5), dim3(256), 0, s, params, grads, go, part);
   hipLaunchKernelGGL(sgd_scale_kernel, dim3(5), dim3(64), 0, s, part, clip, scale, norms_out);
-  hipLaunchKernelGGL(sgd_update_kernel, dim3(512, 5), dim3(256), 0, s, params, grads, go, scale, lr, skip);
+  hipLaunchKernelGGL(sgd_update_kernel, dim3(512, 5), dim3(256), 0, s, params, grads, go, scale, lr, skip, bn_state, bn_snap, bn_n);
 }
 
 // optim.adadelta_list, src/optim/optim_adadelta.lua:19-62, fused into one pass over the flat vectors (the reference walks the 5
@@ -1831,8 +1838,13 @@ void sgd_clip_update(hipStream_t s, float* params, float* grads, const int64_t* 
 // acc = rho*acc + (1-rho) delta^2.  Weight decay is what line 37 means (g += wd*x; the line itself indexes the table of
 // gradients and would raise).  HBM-bound: 4 reads + 3 writes of 4 bytes per parameter.
 __global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ x, float* __restrict__ g, float* __restrict__ var,
-                                                       float* __restrict__ acc, int64_t n, float rho, float eps, float wd, const int* __restrict__ skip) {
-  if (skip && *skip != 0) return;      // see sgd_update_kernel
+                                                       float* __restrict__ acc, int64_t n, float rho, float eps, float wd, const int* __restrict__ skip,
+                                                       float* __restrict__ bn_state, const float* __restrict__ bn_snap, int bn_n) {
+  if (skip && *skip != 0) {            // see sgd_update_kernel
+    if (bn_state)
+      for (int i = blockIdx.x * 256 + threadIdx.x; i < bn_n; i += gridDim.x * 256) bn_state[i] = bn_snap[i];
+    return;
+  }
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const float xv = x[i];
@@ -1845,8 +1857,9 @@ __global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ x, fl
     var[i] = v;
   }
 }
-void adadelta_update(hipStream_t s, float* params, float* grads, float* var, float* acc, int64_t n, float rho, float eps, float wd, const int* skip) {
-  hipLaunchKernelGGL(adadelta_kernel, dim3(2048), dim3(256), 0, s, params, grads, var, acc, n, rho, eps, wd, skip);
+void adadelta_update(hipStream_t s, float* params, float* grads, float* var, float* acc, int64_t n, float rho, float eps, float wd, const int* skip,
+                     float* bn_state, const float* bn_snap, int bn_n) {
+  hipLaunchKernelGGL(adadelta_kernel, dim3(2048), dim3(256), 0, s, params, grads, var, acc, n, rho, eps, wd, skip, bn_state, bn_snap, bn_n);
 }
 
 // =============================================================================================
