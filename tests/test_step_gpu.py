@@ -468,6 +468,42 @@ def test_decoder_cluster_kernel_matches_launch_chain(cuda, monkeypatch, B, W, ma
         assert abs(x - y) < 2e-2 * max(1.0, abs(x)), (x, y)
 
 
+@pytest.mark.parametrize("B,W,maxlen", [(32, 72, 6), (16, 100, 9), (45, 52, 5), (7, 72, 3), (256, 256, 23), (70, 416, 12)])
+def test_decoder_chain_kernels_match_cluster_kernels_bitwise(cuda, monkeypatch, B, W, maxlen):
+    """Round 5 (dec_chain.hip): the decoder loop and its BPTT with TWO interleaved 16-row chains per group and the tag-free exchange
+    (pre-filled destinations, no acknowledgement wait, no flags) against dec_cluster.hip's kernels (AOCR_NO_DEC_CHAINS=1).  Same layouts,
+    same K split, same reduction order: every output must be BIT-identical -- logits, every gradient, d(context), the gold-pass scores.
+    Ragged batches (rows beyond B inside a chain, a whole chain beyond B), several groups, T up to 103, the C3 shape."""
+    cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("AOCR_NO_DEC_CHAINS", knob)
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=maxlen, compute="bf16", max_decoder_l=maxlen + 1, max_beam=1)
+        loss = m.train_forward_backward(batch)
+        loss2 = m.train_forward_backward(batch)
+        assert loss2 == loss
+        assert int(m.get_tensor("cl_err").view(torch.int32)[0]) == 0, "a whole-sequence kernel timed out waiting for its group"
+        out[knob] = dict(loss=loss, logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), outs=m.get_tensor("outs").clone(),
+                         taps={k: m.get_tensor(k).clone() for k in ("ds_all", "dq_all", "dpre_all")},
+                         dctx=m.get_tensor("dcontext").clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        dloss, _ = m.step(batch, True, 1)
+        out[knob]["gold"] = [float(x) for x in m._dec_out.gold_scores] + [float(dloss)]
+        m.shutdown()
+    a, b = out["1"], out["0"]
+    assert a["loss"] == b["loss"]
+    assert torch.equal(a["logits"], b["logits"]), (a["logits"] - b["logits"]).abs().max().item()
+    assert torch.equal(a["outs"], b["outs"])
+    for k in a["taps"]:                                          # what the BPTT kernel itself writes, step by step
+        assert torch.equal(a["taps"][k], b["taps"][k]), (k, relerr(b["taps"][k], a["taps"][k]))
+    # (everything downstream of the kernels' outputs goes through split-K products whose partial sums meet in arrival order: norm-relative)
+    assert relerr(b["dctx"], a["dctx"]) < 1e-5
+    for k in a["grads"]:
+        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):      # analytically zero (a bias in front of a BatchNorm): rounding noise only
+            continue
+        assert relerr(b["grads"][k], a["grads"][k]) < 1e-5, k
+    assert a["gold"] == b["gold"]
+
+
 @pytest.mark.parametrize("B,W,maxdec", [(32, 72, 10), (45, 100, 12), (256, 256, 50), (8, 800, 6)])
 def test_greedy_decode_cluster_kernel_matches_launch_chain(cuda, monkeypatch, B, W, maxdec):
     """Greedy decode (model.lua:376-536 at beam 1) through the decoder cluster kernel's DEC variant -- cell, attention, projector on fp32
