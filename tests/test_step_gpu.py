@@ -485,6 +485,7 @@ def test_decoder_chain_kernels_match_cluster_kernels_bitwise(cuda, monkeypatch, 
         assert int(m.get_tensor("cl_err").view(torch.int32)[0]) == 0, "a whole-sequence kernel timed out waiting for its group"
         out[knob] = dict(loss=loss, logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), outs=m.get_tensor("outs").clone(),
                          taps={k: m.get_tensor(k).clone() for k in ("ds_all", "dq_all", "dpre_all")},
+                         init={k: m.get_tensor(k).clone() for k in ("dh_rec0", "dh_rec1", "dc_st0", "dc_st1", "dfeed0")},
                          dctx=m.get_tensor("dcontext").clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
         dloss, _ = m.step(batch, True, 1)
         out[knob]["gold"] = [float(x) for x in m._dec_out.gold_scores] + [float(dloss)]
@@ -495,12 +496,19 @@ def test_decoder_chain_kernels_match_cluster_kernels_bitwise(cuda, monkeypatch, 
     assert torch.equal(a["outs"], b["outs"])
     for k in a["taps"]:                                          # what the BPTT kernel itself writes, step by step
         assert torch.equal(a["taps"][k], b["taps"][k]), (k, relerr(b["taps"][k], a["taps"][k]))
-    # (everything downstream of the kernels' outputs goes through split-K products whose partial sums meet in arrival order: norm-relative)
+    # the gradients of the initial decoder state (what the encoder's BPTT starts from): the two kernels are different compilations of the same fp32
+    # cell-backward expressions and may contract a multiply-add differently -- an ulp in the running d c, invisible in everything that goes on
+    # through bf16 (the taps above), visible here
+    for k in a["init"]:
+        assert relerr(b["init"][k], a["init"][k]) < 1e-6, k
     assert relerr(b["dctx"], a["dctx"]) < 1e-5
     for k in a["grads"]:
         if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):      # analytically zero (a bias in front of a BatchNorm): rounding noise only
             continue
-        assert relerr(b["grads"][k], a["grads"][k]) < 1e-5, k
+        # decoder / projector / embedding: straight from the kernels' outputs.  Encoder and CNN: an ulp in the initial-state gradient is amplified by
+        # bf16 operand rounding and ReLU / arg-max decisions on the way down (test_c2_gradient_residual_is_decision_flips): the cluster-vs-chain bound
+        tol = 1e-5 if k.startswith(("dec.", "proj", "lookup", "emb")) else 3e-2
+        assert relerr(b["grads"][k], a["grads"][k]) < tol, (k, relerr(b["grads"][k], a["grads"][k]))
     assert a["gold"] == b["gold"]
 
 

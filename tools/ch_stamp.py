@@ -13,14 +13,18 @@ m, O, ocfg, P, st, batch = make(dict(enc_hidden=256, enc_layers=1, dec_layers=2,
 for _ in range(3):
     m.train_forward_backward(batch)
 torch.cuda.synchronize()
-for tap, names in (("dc_stamps", ["P1<0>", "P1<1>", "P2<0>", "P2<1>", "P3<0>", "P3<1>", "P4<0>", "P4<1>"]),
-                   ("dc_bstamps", ["B1<0>", "B1<1>", "B2<0>", "B2<1>", "B3<0>", "B3<1>", "B4<0>", "B4<1>", "B5<0>", "B5<1>", "B6<0>", "B6<1>"])):
-    s = m.get_tensor(tap).view(torch.int64).cpu().tolist()
-    tot = sum(s[:len(names)])
-    if tot == 0:
-        continue
-    print(tap, "workgroup 0 (member 0 of group 0), cycles per step (100 MHz ticks x ? -- s_memtime counts shader-clock-independent ticks)")
-    for n, v in zip(names, s):
-        print(f"  {n:8s} {v / L:9.0f}  {100.0 * v / tot:5.1f} %")
-    print(f"  total {tot / L:9.0f} per step;  aux {s[12:]}")
+s = m.get_tensor("dc_stamps").view(torch.int64).cpu().tolist()
+r = m.get_tensor("dc_times").view(torch.int32).cpu().tolist()
+names = ["P1<0>", "P1<1>", "P2<0>", "P2<1>", "P3<0>", "P3<1>", "P4<0>", "P4<1>"]
+tot = sum(s)
+print("forward, workgroup 0 (member 0 of group 0), shader cycles per step: wait for the operand (land) + the rest of the phase; poll retries per step")
+for k, n in enumerate(names):
+    print(f"  {n:6s} land {s[8 + k] / L:7.0f}  rest {s[k] / L:7.0f}  retries {r[k] / L:5.2f}")
+print(f"  total {tot / L:9.0f} per step")
+b = m.get_tensor("dc_bstamps").view(torch.int64).cpu().tolist()
+bn = ["B2<0>", "B2<1>", "B3<0>", "B3<1>", "B4<0>", "B4<1>", "B5<0>", "B5<1>", "B6<0>", "B6<1>"]
+print("backward, workgroup 0, shader cycles per step")
+for k, n in enumerate(bn):
+    print(f"  {n:6s} {b[k] / L:8.0f}")
+print(f"  total {sum(b[:10]) / L:9.0f} per step")
 m.shutdown()

@@ -413,6 +413,8 @@ int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32
   else if (n == "ds_all") { *ptr_dev = m->ds_all; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = d.T; }          // debugging aids: decoder BPTT intermediates
   else if (n == "dq_all") { *ptr_dev = m->dq_all; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = m->Hd; }
   else if (n == "dcat_all") { *ptr_dev = m->dcat_all; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = 2 * m->Hd; }
+  else if (n == "dh_rec0" || n == "dh_rec1" || n == "dc_st0" || n == "dc_st1" || n == "dfeed0") {      // debugging aids: gradients of the decoder's initial state
+    const int l = n.back() - '0'; *ptr_dev = n[1] == 'f' ? m->dfeed : (n[1] == 'h' ? m->dh_rec[l] : m->dc_st[l]); *ndim = 2; shape[0] = d.B; shape[1] = m->Hd; }
   else if (n == "dpre_all") { *ptr_dev = m->dpre_all; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = m->Hd; }
   else if (n == "dc_bstamps") { REQUIRE(m->dc_xtab, "no decoder cluster kernel in this configuration"); *ptr_dev = m->dc_xtab + (size_t)((d.B + 31) / 32) * 32 + 16; *ndim = 1; shape[0] = 32; }
   else if (n == "dc_times") { REQUIRE(m->cl_err, "no cluster kernels in this configuration"); *ptr_dev = m->cl_err + 16 + 2048; *ndim = 1; shape[0] = 32 * 4 * 16 * 2; }   // 32 members x 4 gathers x 16 x u64 (10 ns ticks)

@@ -73,7 +73,7 @@ __device__ __forceinline__ void pend_issue(const void* src, int stride_bytes, in
 // lane fetched -- for dwords nobody has written yet, fetch the rows that have some again until none is left; then the workgroup barrier.
 template <int NST>
 __device__ __forceinline__ void pend_land(const void* src, int stride_bytes, int rbase, int B, unsigned char* dst, int pitch, int lane, int wave, int member, bool local,
-                                          int* err, int code, int* dead_flag, int chunk0 = 0) {
+                                          int* err, int code, int* dead_flag, int chunk0 = 0, [[maybe_unused]] int* retries = nullptr) {
   wait_vm<NST>();
   u32x4 g[4];
 #pragma unroll
@@ -99,6 +99,9 @@ __device__ __forceinline__ void pend_land(const void* src, int stride_bytes, int
       mx = max(max(umax4(g[0]), umax4(g[1])), max(umax4(g[2]), umax4(g[3])));
       if (!__any(mx == SENT)) break;
     }
+#ifdef DC_DEBUG_STAMPS
+    if (retries) *retries += spins;
+#endif
   }
   lds_barrier();
 }
@@ -109,6 +112,16 @@ __device__ __forceinline__ void load_rows16(const bf16_t* src, int rbase, int B,
     const int idx = tid + 256 * j, row = idx >> 6, ch = idx & 63;
     *reinterpret_cast<u32x4*>(dst + (size_t)row * PA + ch * 16) = *reinterpret_cast<const u32x4*>(src + (size_t)min(rbase + row, B - 1) * HD + ch * 8);
   }
+}
+// Eight B fragments (16 bytes each, 64 bytes apart) in ONE asm statement: the reads are issued back to back and waited for once -- hipcc
+// otherwise emits read / wait / 4 MFMAs per k-step (~170 cycles each instead of 64).  One statement, so every output is valid when it ends.
+struct Frag8 { bf16x8 v[8]; };
+__device__ __forceinline__ void lds_read8(Frag8& f, const unsigned char* p) {
+  const unsigned a = lds_addr(p);
+  asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:64\n\tds_read_b128 %2, %8 offset:128\n\tds_read_b128 %3, %8 offset:192\n\t"
+               "ds_read_b128 %4, %8 offset:256\n\tds_read_b128 %5, %8 offset:320\n\tds_read_b128 %6, %8 offset:384\n\tds_read_b128 %7, %8 offset:448\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(f.v[0]), "=&v"(f.v[1]), "=&v"(f.v[2]), "=&v"(f.v[3]), "=&v"(f.v[4]), "=&v"(f.v[5]), "=&v"(f.v[6]), "=&v"(f.v[7]) : "v"(a) : "memory");
 }
 template <int C> struct IC { static constexpr int value = C; };
 }  // namespace
@@ -151,7 +164,8 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       const int row = row0 + (ln >> 1);
       dst = (s < L && row < B) ? (void*)(base + (size_t)(s + 1) * slot + (size_t)row * HD + 16 * member + 8 * (ln & 1)) : (void*)trash;
     } else dst = (s < L && rvalid) ? (void*)(p.cat_b + ((size_t)s * B + arow) * 2 * HD + 8 * ln) : (void*)trash;
-    pst16(dst, u32x4{SENT, SENT, SENT, SENT}, loc);
+    unsigned sv = SENT; asm volatile("" : "+v"(sv));                 // (re-materialised per call: a loop-carried constant was spilled to scratch and re-loaded behind an s_waitcnt vmcnt(0))
+    pst16(dst, u32x4{sv, sv, sv, sv}, loc);
   };
   prefill(0, tid, false); prefill(1, tid, false);
   wait_vm<0>();
@@ -227,12 +241,11 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    Frag8 bf; lds_read8(bf, src);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const bf16x8 bv = *reinterpret_cast<const bf16x8*>(src + 64 * s);
+    for (int s = 0; s < 8; ++s)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(j < 2 ? wa[j * 8 + s] : wb[(j - 2) * 8 + s], bv, acc[j], 0, 0, 0);
-    }
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(j < 2 ? wa[j * 8 + s] : wb[(j - 2) * 8 + s], bf.v[s], acc[j], 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(red + ((size_t)(wave * 4 + j) * 64 + lane) * 4) = acc[j];
     mid();                                                          // the next phase's operand fetch: its producers published a phase ago, ~half a phase before its use
@@ -251,6 +264,7 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
     hp = u32x2{sane(hb | (h1v << 16)), sane(h2v | (h3v << 16))};
   };
   bool dead = false;
+  [[maybe_unused]] int nretry[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
   for (int t = 0; t < L && !dead; ++t) {
     int ot = tid; asm volatile("" : "+v"(ot));                     // opaque per-step copy of the thread id: the address arithmetic stays inside the step
@@ -263,9 +277,10 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       unsigned char* const F = lds + (size_t)(c * 3 + 0) * OPB; unsigned char* const H1 = lds + (size_t)(c * 3 + 1) * OPB;
       const int rb = row0 + RC * c;
       if (t > 0) {
-        if constexpr (c == 0) pend_land<3>(p.out_b + (size_t)t * slot, HD * 2, rb, B, F, PA, olane, wave, member, local, p.err, 11, &s_dead);      // P4<1> of step t-1: 2 stores + the pre-fill
-        else pend_land<3>(p.out_b + (size_t)t * slot, HD * 2, rb, B, F, PA, olane, wave, member, local, p.err, 11, &s_dead);                       // P1<0>: 3 stores
+        if constexpr (c == 0) pend_land<3>(p.out_b + (size_t)t * slot, HD * 2, rb, B, F, PA, olane, wave, member, local, p.err, 11, &s_dead, 0, &nretry[0 + c]);      // P4<1> of step t-1: 2 stores + the pre-fill
+        else pend_land<3>(p.out_b + (size_t)t * slot, HD * 2, rb, B, F, PA, olane, wave, member, local, p.err, 11, &s_dead, 0, &nretry[0 + c]);                       // P1<0>: 3 stores
       } else lds_barrier();
+      CH_STAMP(8 + c);
       f32x4 z, g; u32x2 hp;
       product(w1a, w1b, F, H1, z, [&] {
         if constexpr (c == 0) { if (t > 0) pend_issue(p.out_b + (size_t)t * slot, HD * 2, row0 + RC, B, lds + (size_t)(1 * 3 + 0) * OPB, PA, olane, wave, member, local); }
@@ -284,8 +299,9 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       constexpr int c = decltype(cc)::value;
       unsigned char* const H1 = lds + (size_t)(c * 3 + 1) * OPB; unsigned char* const H2 = lds + (size_t)(c * 3 + 2) * OPB;
       const int rb = row0 + RC * c;
-      if constexpr (c == 0) pend_land<3>(p.hsb[0] + (size_t)(t + 1) * slot, HD * 2, rb, B, H1, PA, olane, wave, member, local, p.err, 12, &s_dead);     // behind P1<1>
-      else pend_land<4>(p.hsb[0] + (size_t)(t + 1) * slot, HD * 2, rb, B, H1, PA, olane, wave, member, local, p.err, 12, &s_dead);                       // behind P2<0>
+      if constexpr (c == 0) pend_land<3>(p.hsb[0] + (size_t)(t + 1) * slot, HD * 2, rb, B, H1, PA, olane, wave, member, local, p.err, 12, &s_dead, 0, &nretry[2 + c]);     // behind P1<1>
+      else pend_land<4>(p.hsb[0] + (size_t)(t + 1) * slot, HD * 2, rb, B, H1, PA, olane, wave, member, local, p.err, 12, &s_dead, 0, &nretry[2 + c]);                       // behind P2<0>
+      CH_STAMP(10 + c);
       f32x4 z, g; u32x2 hp;
       product(w2a, w2b, H1, H2, z, [&] {
         if constexpr (c == 0) pend_issue(p.hsb[0] + (size_t)(t + 1) * slot, HD * 2, row0 + RC, B, lds + (size_t)(1 * 3 + 1) * OPB, PA, olane, wave, member, local);
@@ -305,9 +321,10 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       constexpr int c = decltype(cc)::value;
       unsigned char* const H2 = lds + (size_t)(c * 3 + 2) * OPB;
       const int rb = row0 + RC * c;
-      if constexpr (c == 0) pend_land<4>(p.hsb[1] + (size_t)(t + 1) * slot, HD * 2, rb, B, H2, PA, olane, wave, member, local, p.err, 13, &s_dead);      // behind P2<1>
-      else { if (mych == 0) pend_land<2>(p.hsb[1] + (size_t)(t + 1) * slot, HD * 2, rb, B, H2, PA, olane, wave, member, local, p.err, 13, &s_dead);      // behind P3<0>
-             else pend_land<0>(p.hsb[1] + (size_t)(t + 1) * slot, HD * 2, rb, B, H2, PA, olane, wave, member, local, p.err, 13, &s_dead); }
+      if constexpr (c == 0) pend_land<4>(p.hsb[1] + (size_t)(t + 1) * slot, HD * 2, rb, B, H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]);      // behind P2<1>
+      else { if (mych == 0) pend_land<2>(p.hsb[1] + (size_t)(t + 1) * slot, HD * 2, rb, B, H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]);      // behind P3<0>
+             else pend_land<0>(p.hsb[1] + (size_t)(t + 1) * slot, HD * 2, rb, B, H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]); }
+      CH_STAMP(12 + c);
       {                                                             // zx1 of the next step (LDS-DMA, older than the prefetch below: complete by the next counted wait)
         const int tn = min(t + 1, L - 1);
         const int row = min(rb + oc16, B - 1);
@@ -328,7 +345,11 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
         if (wave < ntile) {
           f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cavr[s], *reinterpret_cast<const bf16x8*>(hrow + 64 * s), acc, 0, 0, 0);
+          for (int hh = 0; hh < 2; ++hh) {
+            Frag8 bf; lds_read8(bf, hrow + 512 * hh);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cavr[8 * hh + s], bf.v[s], acc, 0, 0, 0);
+          }
           if (c16 == 0) *reinterpret_cast<f32x4*>(sc + 16 * wave + 4 * q) = acc;
         }
       } else {
@@ -346,14 +367,18 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
           }
           f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cav[s], *reinterpret_cast<const bf16x8*>(hrow + 64 * s), acc, 0, 0, 0);
+          for (int hh = 0; hh < 2; ++hh) {
+            Frag8 bf; lds_read8(bf, hrow + 512 * hh);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cav[8 * hh + s], bf.v[s], acc, 0, 0, 0);
+          }
           if (c16 == 0) *reinterpret_cast<f32x4*>(sc + 16 * tile + 4 * q) = acc;
         }
       }
+      fetch_next();
       bf16x8 cv[16];                                                // the first 64 context rows of the weighted sum: in flight across the softmax
 #pragma unroll
       for (int i = 0; i < 16; ++i) cv[i] = *reinterpret_cast<const bf16x8*>(cx + (size_t)min(4 * i + wave, T - 1) * HD + 8 * olane);
-      fetch_next();
       lds_barrier();
       float aj[4];
       {
@@ -401,13 +426,15 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       constexpr int c = decltype(cc)::value;
       unsigned char* const F = lds + (size_t)(c * 3 + 0) * OPB; unsigned char* const H2 = lds + (size_t)(c * 3 + 2) * OPB;
       const int rb = row0 + RC * c;
-      if constexpr (c == 0) { if (mych == 1) pend_land<2>(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, rb, B, F, PA, olane, wave, member, local, p.err, 14, &s_dead);      // behind P3<1>
-                              else pend_land<0>(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, rb, B, F, PA, olane, wave, member, local, p.err, 14, &s_dead); }
-      else pend_land<2>(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, rb, B, F, PA, olane, wave, member, local, p.err, 14, &s_dead);                                          // behind P4<0>
+      if constexpr (c == 0) { if (mych == 1) pend_land<2>(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, rb, B, F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]);      // behind P3<1>
+                              else pend_land<0>(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, rb, B, F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]); }
+      else pend_land<2>(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, rb, B, F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]);                                          // behind P4<0>
+      CH_STAMP(14 + c);
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       const unsigned char* src = (wave < 2 ? F : H2) + (256 * (wave & 1) + 8 * q) * 2 + (size_t)c16 * PA;   // k = 256 wave + 32 s: waves 0, 1 read c, waves 2, 3 read h2
+      Frag8 bf; lds_read8(bf, src);
 #pragma unroll
-      for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcr[s], *reinterpret_cast<const bf16x8*>(src + 64 * s), acc, 0, 0, 0);
+      for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcr[s], bf.v[s], acc, 0, 0, 0);
       *reinterpret_cast<f32x4*>(red + ((size_t)wave * 64 + lane) * 4) = acc;
       if constexpr (c == 0) pend_issue(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, row0 + RC, B, lds + (size_t)(1 * 3 + 0) * OPB, PA, olane, wave, member, local);
       else { if (t + 1 < L) pend_issue(p.out_b + (size_t)(t + 1) * slot, HD * 2, row0, B, lds + (size_t)(0 * 3 + 0) * OPB, PA, olane, wave, member, local); }
@@ -434,7 +461,449 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
   }
   wait_vm<0>();
 #ifdef DC_DEBUG_STAMPS
-  if (p.stamps && wid == 0 && tid == 0) { stamp[15] = local ? 1 : 0; for (int k = 0; k < 16; ++k) p.stamps[k] = stamp[k]; }
+  if (p.stamps && wid == 0 && tid == 0) { for (int k = 0; k < 16; ++k) p.stamps[k] = stamp[k]; for (int k = 0; k < 8; ++k) p.err[16 + 2048 + k] = nretry[k]; }
+#endif
+}
+
+// =============================================================================================================================
+// Backward (model.lua:643-661; dec_cluster.hip's dec_cl_bwd_kernel: same weight slices in registers, same products, same layouts).  Phases of
+// step t (t = L-1 .. 0), each for chain 0 then chain 1; every operand was published one phase of the SAME chain earlier:
+//   B2  [d c ; d h2a] = d pre W_c                               d pre <- B6 of step t+1 (the prologue for t = L-1)      publishes d c (fp32, to the rows' owners)
+//   B3  attention backward of row r on member r (its chain's phase only)      the row's d c <- B2                          publishes d q (bf16 row)
+//   B4  d h2 = d q W_a + d h2a + d h2rec; cell backward 2       d q <- B3                                                publishes d z2 (4 KB rows)
+//   B5  [d h1 ; d h2rec] = d z2 [W2_i2h | W2_h2h]; cell backward 1            d z2 <- B4                                  publishes d z1
+//   B6  [d h1rec ; d feed] = d z1 [W1_h2h | W1_i2h[:, E:]]; d pre(t-1) = (d out_proj + d feed)(1 - out^2)     d z1 <- B5       publishes d pre(t-1)
+// The 4 KB d z rows are fetched by the wave that reads them (wave w: bytes 1024 w .. of every row = its quarter of K): no barrier between
+// landing and use, and the look for unwritten dwords rides on the fragment reads.  What the elementwise parts read from global memory (saved gates
+// and cell states, d out_proj, out) is fetched by LDS-DMA one phase ahead into small staging areas (wave 0 does the elementwise work of a chain).
+constexpr int XC = RC * PZ;                                          // operand buffer of a chain: 16 rows x 4 KB (+ pad); d pre / d q rows use its start, pitch PA
+constexpr int CH_BWD_LDS = NCH * XC + 8192 + 1024 + 2048 + NCH * 2048 + 2 * 6144 + NCH * 2048;
+struct Frag4 { bf16x8 v[4]; };
+__device__ __forceinline__ void lds_read4(Frag4& f, const unsigned char* p) {
+  const unsigned a = lds_addr(p);
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\tds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(f.v[0]), "=&v"(f.v[1]), "=&v"(f.v[2]), "=&v"(f.v[3]) : "v"(a) : "memory");
+}
+__device__ __forceinline__ unsigned fmax8(const Frag8& f) {
+  unsigned m = 0;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) m = max(m, umax4(__builtin_bit_cast(u32x4, f.v[s])));
+  return m;
+}
+
+__global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* const red = reinterpret_cast<float*>(lds + NCH * XC);                 // [4 waves][2 tiles][64 lanes][4] partial tiles; attention: [4 waves][512] partial d q
+  float* const part = red;
+  float* const da = reinterpret_cast<float*>(lds + NCH * XC + 8192);           // [256] d a
+  bf16_t* const dchl = reinterpret_cast<bf16_t*>(lds + NCH * XC + 8192 + 1024);        // [2][512]: the row's d c as hi + lo bf16
+  unsigned char* const stin = lds + NCH * XC + 8192 + 1024 + 2048;                     // [chain][2][64 lanes][16 B]: d out_proj, out of the chain's next step (fetched in B5, read in B6)
+  float* const dcs = reinterpret_cast<float*>(stin);                                    // [512]: the row's d c (fp32) as fetched (in B2 / B3, read in B3: stin is dead then)
+  unsigned char* const cellb = stin + NCH * 2048;                                       // [2 buffers][6][64 lanes][16 B]: c(t), c(t-1), the four units' gates
+  f32x4* const keep = reinterpret_cast<f32x4*>(cellb + 2 * 6144);                       // [chain][2][64 lanes]: wave 0's d h2a (B2 -> B4) and d h1rec (B6 -> B5 of the next step): LDS instead of 16 VGPRs
+  __shared__ int s_local, s_dead;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q = lane >> 4;
+  const int wid = blockIdx.x, xcd = wid & 7, i8 = wid >> 3;
+  const int member = i8 % NM, gl = (i8 / NM) * 8 + xcd;
+  if (gl >= p.ngroups) return;
+  const int group = p.group0 + gl;
+  const int B = p.B, T = p.T, L = p.L, row0 = group * R;
+  const size_t slot = (size_t)B * HD;
+  const int arow = row0 + member; const bool rvalid = arow < B;
+  const int mych = member >> 4;
+  unsigned char* const trash0 = reinterpret_cast<unsigned char*>(p.err + 16);
+
+  // ---- pre-fill of this member's pieces of step s (3 stores per wave): d z2 / d z1 gate `wave`; wave 0 d pre, waves 1, 2 the halves of d c, wave 3 the row's d q
+  auto prefill = [&](int s, int ot, bool loc) {
+    const int ln = ot & 63; unsigned char* const trash = trash0 + ot * 16;
+    unsigned sv = SENT; asm volatile("" : "+v"(sv));
+    const u32x4 sent = u32x4{sv, sv, sv, sv};
+    const bool on = s >= 0 && s < L;
+    const int row = row0 + (ln >> 1); const bool rok = on && row < B;
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+      pst16(rok ? (void*)(p.dzb[l] + ((size_t)s * B + row) * 4 * HD + wave * HD + 16 * member + 8 * (ln & 1)) : (void*)trash, sent, loc);
+    void* dst;
+    if (wave == 0) dst = rok ? (void*)(p.dpre_b + (size_t)s * slot + (size_t)row * HD + 16 * member + 8 * (ln & 1)) : (void*)trash;
+    else if (wave == 3) dst = (on && rvalid) ? (void*)(p.dq_b + (size_t)s * slot + (size_t)arow * HD + 8 * ln) : (void*)trash;
+    else { const int id = ln + 64 * (wave - 1), r2 = row0 + (id >> 2); dst = (on && r2 < B) ? (void*)(p.dcat + ((size_t)s * B + r2) * 2 * HD + 16 * member + 4 * (id & 3)) : (void*)trash; }
+    pst16(dst, sent, loc);
+  };
+  prefill(L - 1, tid, false); prefill(L - 2, tid, false);
+  wait_vm<0>();
+  __syncthreads();
+  u64* const xt = p.xtab + (size_t)group * NM;
+  if (tid == 0) {
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); xcc &= 15u;
+    stg64(xt + member, ((u64)p.epoch << 32) | (u64)(xcc + 1u));
+    int same = 1;
+    for (int m = 0; m < NM; ++m) {
+      u64 v; int spins = 0;
+      while ((unsigned)((v = ldg64(xt + m)) >> 32) != p.epoch) { if (++spins > DC_SPIN_LIMIT) { atomicExch(p.err, 25); same = 0; break; } __builtin_amdgcn_s_sleep(2); }
+      if ((unsigned)v != xcc + 1u) same = 0;
+    }
+    s_local = same && !p.force_remote; s_dead = 0;
+  }
+  __syncthreads();
+  const bool local = __builtin_amdgcn_readfirstlane(s_local) != 0;
+
+  // ---- resident weights: rows 16m + c16 of the transposed matrices (A fragments), this wave's quarter of K
+  bf16x8 wz[4][16], wct[2][4], wat[4];
+  {
+    const bf16_t* wsrc[4] = {p.w2i_t, p.w2h_t, p.w1h_t, p.w1f_t};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) wz[k][s] = *reinterpret_cast<const bf16x8*>(wsrc[k] + (size_t)(16 * member + c16) * 4 * HD + 512 * wave + 32 * s + 8 * q);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      wct[0][s] = *reinterpret_cast<const bf16x8*>(p.wc_t + (size_t)(16 * member + c16) * HD + 128 * wave + 32 * s + 8 * q);
+      wct[1][s] = *reinterpret_cast<const bf16x8*>(p.wc_t + (size_t)(HD + 16 * member + c16) * HD + 128 * wave + 32 * s + 8 * q);
+      wat[s] = *reinterpret_cast<const bf16x8*>(p.wa_t + (size_t)(16 * member + c16) * HD + 128 * wave + 32 * s + 8 * q);
+    }
+  }
+  const bf16_t* const cx = p.ctxb + (size_t)min(arow, B - 1) * T * HD;
+  const int ntile = (T + 15) >> 4;
+  // per chain, in wave 0 (lane -> row 16 c + c16 of the group, units 16 member + 4 q .. + 3): running cell-state gradients and what a step hands to the next one
+  f32x4 dc1[NCH], dc2[NCH], dh2rec[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) { dc1[c] = dc2[c] = dh2rec[c] = f32x4{0.f, 0.f, 0.f, 0.f}; if (wave == 0) keep[(c * 2 + 1) * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+
+  // ---- operand fetches.  1 KB rows (d pre, d q): pend_issue / pend_land as in the forward kernel.  4 KB rows (d z): wave w fetches its own quarter of every row.
+  auto xbuf = [&](int c) { return lds + (size_t)c * XC; };
+  auto dz_issue = [&](const bf16_t* src, int rb, unsigned char* X, int ln) {
+#pragma unroll
+    for (int r = 0; r < RC; ++r)
+      dma16x(reinterpret_cast<const unsigned char*>(src) + (size_t)min(rb + r, B - 1) * (HD * 8) + 1024 * wave + ln * 16, __builtin_amdgcn_readfirstlane(lds_addr(X) + r * PZ + 1024 * wave), local);
+  };
+  // wave 0's elementwise inputs of (chain c, step t): d out_proj(t), out(t)
+  auto stin_issue = [&](int c, int t, int oc16, int oq, int ln) {
+    if (wave != 0) return;
+    const size_t eo = (size_t)min(row0 + RC * c + oc16, B - 1) * HD + 16 * member + 4 * oq;
+    const unsigned b = __builtin_amdgcn_readfirstlane(lds_addr(stin) + c * 2048);
+    (void)ln;
+    dma16x(p.dout_proj + (size_t)t * slot + eo, b, true); dma16x(p.out + (size_t)(t + 1) * slot + eo, b + 1024, true);
+  };
+  // ... and the saved state of layer l: c(t), c(t-1), gates of the lane's four units
+  auto cell_issue = [&](int buf, int c, int l, int t, int oc16, int oq) {
+    if (wave != 0) return;
+    const int row = min(row0 + RC * c + oc16, B - 1), u0 = 16 * member + 4 * oq;
+    const unsigned b = __builtin_amdgcn_readfirstlane(lds_addr(cellb) + buf * 6144);
+    dma16x(p.cs[l] + (size_t)(t + 1) * slot + (size_t)row * HD + u0, b, true);
+    dma16x(p.cs[l] + (size_t)t * slot + (size_t)row * HD + u0, b + 1024, true);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16x(p.gates[l] + (((size_t)t * B + row) * HD + u0 + i) * 4, b + 2048 + 1024 * i, true);
+  };
+  auto reduce2 = [&](const f32x4 (&acc)[2], f32x4 (&v)[2], auto&& mid) {      // two K-split tiles of a chain -> wave 0 (dec_cluster.hip's order)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) *reinterpret_cast<f32x4*>(red + ((size_t)(wave * 2 + n) * 64 + lane) * 4) = acc[n];
+    mid();
+    lds_barrier();
+    if (wave == 0) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        v[n] = *reinterpret_cast<const f32x4*>(red + ((size_t)(0 * 2 + n) * 64 + lane) * 4);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v[n] += *reinterpret_cast<const f32x4*>(red + ((size_t)(w * 2 + n) * 64 + lane) * 4);
+      }
+    }
+  };
+  // cell backward of one layer on this lane's 4 units (EpGatesBwd), inputs from the staging buffer
+  auto cell_bwd = [&](int buf, const f32x4& dh, f32x4& dcs_, f32x4 (&dz)[4]) {
+    const unsigned char* b = cellb + buf * 6144 + lane * 16;
+    const f32x4 cn = *reinterpret_cast<const f32x4*>(b), cp = *reinterpret_cast<const f32x4*>(b + 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(b + 2048 + 1024 * i);
+      const float ig = g[0], fg = g[1], og = g[2], gg = g[3];
+      const float tc = tanhf_(cn[i]);
+      const float dcv = dh[i] * og * (1.f - tc * tc) + dcs_[i];
+      const float d_o = dh[i] * tc, di = dcv * gg, dg = dcv * ig, df = dcv * cp[i];
+      dz[0][i] = di * ig * (1.f - ig); dz[1][i] = df * fg * (1.f - fg); dz[2][i] = d_o * og * (1.f - og); dz[3][i] = dg * (1.f - gg * gg);
+      dcs_[i] = dcv * fg;
+    }
+  };
+  // K = 2048 products against a chain's d z (this wave's quarter of K, two tiles); the fragments are looked at for unwritten dwords on the way
+  auto zprod = [&](const bf16x8 (&wa_)[16], const bf16x8 (&wb_)[16], const bf16_t* src, int rb, unsigned char* X, f32x4 (&v)[2], int code, auto&& mid) {
+    const unsigned char* base = X + (size_t)c16 * PZ + 1024 * wave + 16 * q;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {                                 // (two halves: 32 instead of 64 fragment registers live beside the 304 of the weights)
+      Frag8 f;
+      lds_read8(f, base + 512 * hh);
+      if (__any(fmax8(f) == SENT)) {
+        int spins = 0;
+#pragma nounroll
+        while (true) {
+          asm volatile("" : "+v"(spins));
+          if (++spins > DC_SPIN_LIMIT) { if (lane == 0) { atomicExch(p.err, code); s_dead = 1; } break; }
+          __builtin_amdgcn_s_sleep(1);
+          dz_issue(src, rb, X, lane);
+          wait_vm<0>();
+          lds_read8(f, base + 512 * hh);
+          if (!__any(fmax8(f) == SENT)) break;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa_[8 * hh + s], f.v[s], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb_[8 * hh + s], f.v[s], acc[1], 0, 0, 0);
+      }
+    }
+    reduce2(acc, v, mid);
+  };
+  // d pre of (chain c, step t) from d feed and the staged d out_proj / out: published (bf16) + stored (fp32) by wave 0 -- 2 stores per wave
+  auto dpre_publish = [&](int c, int t, int ot, bool from_lds, const f32x4& dpn_, const f32x4& on_, const f32x4& dfeed) {
+    const int oc16 = ot & 15, oq = (ot >> 4) & 3;
+    f32x4 dpn = dpn_, on = on_;
+    if (from_lds) { dpn = *reinterpret_cast<const f32x4*>(stin + c * 2048 + (ot & 63) * 16); on = *reinterpret_cast<const f32x4*>(stin + c * 2048 + 1024 + (ot & 63) * 16); }
+    f32x4 dpre;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dpre[i] = (dpn[i] + dfeed[i]) * (1.f - on[i] * on[i]);
+    const int erow = row0 + RC * c + oc16; const bool eok = wave == 0 && t >= 0 && erow < B;
+    const size_t eoff = (size_t)min(erow, B - 1) * HD + 16 * member + 4 * oq;
+    unsigned char* const otrash = trash0 + ot * 16;
+    pst8(eok ? (void*)(p.dpre_b + (size_t)t * slot + eoff) : (void*)otrash, u32x2{sane(bfpair(dpre[0], dpre[1])), sane(bfpair(dpre[2], dpre[3]))}, local);
+    st16f(eok ? (void*)(p.dpre + (size_t)t * slot + eoff) : (void*)otrash, dpre);
+  };
+  // ---- step L-1's d pre (d feed = 0) from direct loads
+  {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const size_t eo = (size_t)min(row0 + RC * c + c16, B - 1) * HD + 16 * member + 4 * q;
+      const f32x4 dpn = *reinterpret_cast<const f32x4*>(p.dout_proj + (size_t)(L - 1) * slot + eo), on = *reinterpret_cast<const f32x4*>(p.out + (size_t)L * slot + eo);
+      dpre_publish(c, L - 1, tid, false, dpn, on, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    pend_issue(p.dpre_b + (size_t)(L - 1) * slot, HD * 2, row0, B, xbuf(0), PA, lane, wave, member, local);
+  }
+  [[maybe_unused]] u64 stamp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+  bool dead = false;
+  bool first = true;
+
+  for (int t = L - 1; t >= 0 && !dead; --t) {
+    int ot = tid; asm volatile("" : "+v"(ot));
+    const int olane = ot & 63, oc16 = ot & 15, oq = (ot >> 4) & 3;
+    unsigned char* const otrash = trash0 + ot * 16;
+
+    // =================== B2: [d c ; d h2a] = d pre W_c.  stores: the d c half (fp32) = 1
+    auto B2 = [&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      unsigned char* const X = xbuf(c); const int rb = row0 + RC * c;
+      if constexpr (c == 0) { if (first) pend_land<0>(p.dpre_b + (size_t)t * slot, HD * 2, rb, B, X, PA, olane, wave, member, local, p.err, 21, &s_dead);
+                              else pend_land<5>(p.dpre_b + (size_t)t * slot, HD * 2, rb, B, X, PA, olane, wave, member, local, p.err, 21, &s_dead); }       // behind B6<1>: 2 stores + the pre-fill's 3
+      else pend_land<1>(p.dpre_b + (size_t)t * slot, HD * 2, rb, B, X, PA, olane, wave, member, local, p.err, 21, &s_dead);                                    // behind B2<0>
+      Frag4 f; lds_read4(f, X + (size_t)c16 * PA + (128 * wave + 8 * q) * 2);
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dcat[2];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wct[0][s], f.v[s], acc[0], 0, 0, 0); acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wct[1][s], f.v[s], acc[1], 0, 0, 0); }
+      reduce2(acc, dcat, [&] {
+        if constexpr (c == 0) pend_issue(p.dpre_b + (size_t)t * slot, HD * 2, row0 + RC, B, xbuf(1), PA, olane, wave, member, local);
+        else { if (mych == 0 && wave < 2)                           // the d c row of a chain-0 owner (published in B2<0>)
+                 dma16x(reinterpret_cast<const unsigned char*>(p.dcat + ((size_t)t * B + min(arow, B - 1)) * 2 * HD) + 1024 * wave + olane * 16, __builtin_amdgcn_readfirstlane(lds_addr(dcs) + 1024 * wave), local); }
+      });
+      if (wave == 0) keep[(c * 2 + 0) * 64 + lane] = dcat[1];
+      const int erow = rb + oc16; const bool eok = wave == 0 && erow < B;
+      u32x4 dv = __builtin_bit_cast(u32x4, dcat[0]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dv[i] = sane(dv[i]);
+      pst16(eok ? (void*)(p.dcat + ((size_t)t * B + erow) * 2 * HD + 16 * member + 4 * oq) : (void*)otrash, dv, local);
+    };
+    // =================== B3: attention backward of row `member` (its chain's phase only).  stores: owners d q (bf16) + d s + d q (fp32) = 3
+    auto B3 = [&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      auto fetch_next = [&] {
+        if constexpr (c == 0) { if (mych == 1 && wave < 2)           // the d c row of a chain-1 owner (published in B2<1>)
+                                  dma16x(reinterpret_cast<const unsigned char*>(p.dcat + ((size_t)t * B + min(arow, B - 1)) * 2 * HD) + 1024 * wave + olane * 16, __builtin_amdgcn_readfirstlane(lds_addr(dcs) + 1024 * wave), local); }
+        else { cell_issue(0, 0, 1, t, oc16, oq); pend_issue(p.dq_b + (size_t)t * slot, HD * 2, row0, B, xbuf(0), PA, olane, wave, member, local); }
+      };
+      if (mych != c) { fetch_next(); return; }
+      // ---- the row's d c: 512 floats as staged by waves 0, 1 -> hi + lo bf16 in LDS
+      if constexpr (c == 0) wait_vm<1>(); else wait_vm<0>();         // behind B2<1> (1 store) / an empty B3<0>
+      lds_barrier();
+      {
+        f32x2 x = *reinterpret_cast<const f32x2*>(dcs + 2 * ot);
+        if (__any(max(__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1])) == SENT)) {      // (this wave's half of the row: waves 0, 1 the first KB, 2, 3 the second)
+          int spins = 0;
+#pragma nounroll
+          while (true) {
+            asm volatile("" : "+v"(spins));
+            if (++spins > DC_SPIN_LIMIT) { if (olane == 0) { atomicExch(p.err, 22); s_dead = 1; } break; }
+            __builtin_amdgcn_s_sleep(1);
+            u64 v; asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(v) : "v"((unsigned)(ot * 8)), "s"(p.dcat + ((size_t)t * B + min(arow, B - 1)) * 2 * HD) : "memory");
+            wait_vm<0>();
+            asm volatile("" : "+v"(v));
+            x = f32x2{__builtin_bit_cast(float, (unsigned)v), __builtin_bit_cast(float, (unsigned)(v >> 32))};
+            if (!__any(max((unsigned)v, (unsigned)(v >> 32)) == SENT)) break;
+          }
+        }
+        const float h0 = (float)(bf16_t)x[0], h1 = (float)(bf16_t)x[1];
+        reinterpret_cast<unsigned*>(dchl)[ot] = bfpair(h0, h1); reinterpret_cast<unsigned*>(dchl + HD)[ot] = bfpair(x[0] - h0, x[1] - h1);
+      }
+      // a(t) and the d a tile of ctx: issued before the barrier
+      float aj[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) aj[j] = (olane + 64 * j < T) ? p.a_all[((size_t)t * B + min(arow, B - 1)) * T + olane + 64 * j] : 0.f;
+      bf16x8 cxv[16];
+      {
+        const bf16_t* r1 = cx + (size_t)min(16 * wave + oc16, T - 1) * HD + 8 * oq;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) cxv[s] = *reinterpret_cast<const bf16x8*>(r1 + 32 * s);
+      }
+      lds_barrier();
+      const unsigned char* hrow = reinterpret_cast<const unsigned char*>(dchl) + 16 * q;
+      for (int tile = wave; tile < ntile; tile += 4) {
+        if (tile != wave) {
+          const bf16_t* r2 = cx + (size_t)min(16 * tile + oc16, T - 1) * HD + 8 * oq;
+#pragma unroll
+          for (int s = 0; s < 16; ++s) cxv[s] = *reinterpret_cast<const bf16x8*>(r2 + 32 * s);
+        }
+        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cxv[s], *reinterpret_cast<const bf16x8*>(hrow + 64 * s), a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cxv[s], *reinterpret_cast<const bf16x8*>(hrow + HD * 2 + 64 * s), a1, 0, 0, 0);
+        }
+        if (c16 == 0) *reinterpret_cast<f32x4*>(da + 16 * tile + 4 * q) = a0 + a1;
+      }
+      fetch_next();
+      bf16x8 cv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cv[i] = *reinterpret_cast<const bf16x8*>(cx + (size_t)min(4 * i + wave, T - 1) * HD + 8 * olane);
+      lds_barrier();
+      float dsj[4];
+      {
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dsj[j] = lane + 64 * j < T ? da[lane + 64 * j] : 0.f; dot += aj[j] * dsj[j]; }
+        dot = wave_reduce(dot, 0.f, [](float a, float b) { return a + b; });
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dsj[j] = aj[j] * (dsj[j] - dot);          // SoftMax backward (LSTM.lua:139)
+      }
+      const float dsv_own = wave == 0 ? dsj[0] : wave == 1 ? dsj[1] : wave == 2 ? dsj[2] : dsj[3];      // d s[tid]
+      float cacc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cacc[e] = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        if (64 * ch >= T) break;
+        if (ch > 0) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) cv[i] = *reinterpret_cast<const bf16x8*>(cx + (size_t)min(64 * ch + 4 * i + wave, T - 1) * HD + 8 * olane);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dsj[ch]), 4 * i + wave));     // 0 beyond T
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cacc[e] = fmaf(d, (float)cv[i][e], cacc[e]);
+        }
+      }
+      *reinterpret_cast<f32x4*>(part + wave * HD + lane * 8) = f32x4{cacc[0], cacc[1], cacc[2], cacc[3]};
+      *reinterpret_cast<f32x4*>(part + wave * HD + lane * 8 + 4) = f32x4{cacc[4], cacc[5], cacc[6], cacc[7]};
+      lds_barrier();
+      float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { v0 += part[w * HD + 2 * tid]; v1 += part[w * HD + 2 * tid + 1]; }
+      pst4(rvalid ? (void*)(p.dq_b + (size_t)t * slot + (size_t)arow * HD + 2 * ot) : (void*)otrash, sane(bfpair(v0, v1)), local);
+      st4f(rvalid && ot < T ? (void*)(p.ds_all + ((size_t)t * B + arow) * T + ot) : (void*)otrash, dsv_own);
+      asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" ::"v"(rvalid ? (void*)(p.dq + (size_t)t * slot + (size_t)arow * HD + 2 * ot) : (void*)otrash), "v"(f32x2{v0, v1}) : "memory");
+    };
+    // d z of (row, 4 units) x 4 gates of wave 0: bf16 [row][gate * 512 + unit] published, fp32 stored = 8 stores per wave
+    auto dz_store = [&](int l, int rb, const f32x4 (&dz)[4]) {
+      const int erow = rb + oc16; const bool eok = wave == 0 && erow < B;
+      const size_t o = ((size_t)t * B + min(erow, B - 1)) * 4 * HD + 16 * member + 4 * oq;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pst8(eok ? (void*)(p.dzb[l] + o + g * HD) : (void*)otrash, u32x2{sane(bfpair(dz[g][0], dz[g][1])), sane(bfpair(dz[g][2], dz[g][3]))}, local);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) st16f(eok ? (void*)(p.dz[l] + o + g * HD) : (void*)otrash, dz[g]);
+    };
+    // =================== B4: d h2 = d q W_a + d h2a + d h2rec; cell backward of layer 2.  stores: 8
+    auto B4 = [&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      unsigned char* const X = xbuf(c); const int rb = row0 + RC * c;
+      if constexpr (c == 0) { if (mych == 1) pend_land<3>(p.dq_b + (size_t)t * slot, HD * 2, rb, B, X, PA, olane, wave, member, local, p.err, 23, &s_dead);     // behind B3<1>
+                              else pend_land<0>(p.dq_b + (size_t)t * slot, HD * 2, rb, B, X, PA, olane, wave, member, local, p.err, 23, &s_dead); }
+      else pend_land<8>(p.dq_b + (size_t)t * slot, HD * 2, rb, B, X, PA, olane, wave, member, local, p.err, 23, &s_dead);                                          // behind B4<0>
+      Frag4 f; lds_read4(f, X + (size_t)c16 * PA + (128 * wave + 8 * q) * 2);
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, v[2];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wat[s], f.v[s], acc[0], 0, 0, 0);
+      *reinterpret_cast<f32x4*>(red + ((size_t)wave * 64 + lane) * 4) = acc[0];
+      if constexpr (c == 0) { cell_issue(1, 1, 1, t, oc16, oq); pend_issue(p.dq_b + (size_t)t * slot, HD * 2, row0 + RC, B, xbuf(1), PA, olane, wave, member, local); }
+      else { cell_issue(0, 0, 0, t, oc16, oq); dz_issue(p.dzb[1] + (size_t)t * B * 4 * HD, row0, xbuf(0), olane); }
+      lds_barrier();
+      f32x4 dz[4] = {acc[0], acc[0], acc[0], acc[0]};
+      if (wave == 0) {
+        v[0] = *reinterpret_cast<const f32x4*>(red + ((size_t)0 * 64 + lane) * 4);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v[0] += *reinterpret_cast<const f32x4*>(red + ((size_t)w * 64 + lane) * 4);
+        const f32x4 dh2 = v[0] + keep[(c * 2 + 0) * 64 + lane] + dh2rec[c];
+        cell_bwd(c, dh2, dc2[c], dz);
+      }
+      dz_store(1, rb, dz);
+    };
+    // =================== B5: [d h1 ; d h2rec] from d z2; cell backward of layer 1.  stores: 8
+    auto B5 = [&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      unsigned char* const X = xbuf(c); const int rb = row0 + RC * c;
+      wait_vm<8>();                                                  // behind B4<1> / B5<0>: 8 stores
+      f32x4 v[2], dz[4];
+      zprod(wz[0], wz[1], p.dzb[1] + (size_t)t * B * 4 * HD, rb, X, v, 24, [&] {
+        if constexpr (c == 0) { cell_issue(1, 1, 0, t, oc16, oq); if (t > 0) stin_issue(0, t - 1, oc16, oq, olane); dz_issue(p.dzb[1] + (size_t)t * B * 4 * HD, row0 + RC, xbuf(1), olane); }
+        else { if (t > 0) stin_issue(1, t - 1, oc16, oq, olane); dz_issue(p.dzb[0] + (size_t)t * B * 4 * HD, row0, xbuf(0), olane); }
+      });
+      dz[0] = dz[1] = dz[2] = dz[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (wave == 0) {
+        dh2rec[c] = v[1];
+        const f32x4 dh1 = v[0] + keep[(c * 2 + 1) * 64 + lane];
+        cell_bwd(c, dh1, dc1[c], dz);
+      }
+      dz_store(0, rb, dz);
+    };
+    // =================== B6: [d h1rec ; d feed] from d z1; d pre of step t-1.  stores: 2
+    auto B6 = [&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      unsigned char* const X = xbuf(c); const int rb = row0 + RC * c;
+      if constexpr (c == 0) wait_vm<8>(); else wait_vm<2>();         // behind B5<1> (8 stores) / B6<0> (2)
+      f32x4 v[2];
+      zprod(wz[2], wz[3], p.dzb[0] + (size_t)t * B * 4 * HD, rb, X, v, 26, [&] {
+        if constexpr (c == 0) dz_issue(p.dzb[0] + (size_t)t * B * 4 * HD, row0 + RC, xbuf(1), olane);
+        else { if (t > 0) pend_issue(p.dpre_b + (size_t)(t - 1) * slot, HD * 2, row0, B, xbuf(0), PA, olane, wave, member, local); }
+      });
+      if (wave == 0) {
+        keep[(c * 2 + 1) * 64 + lane] = v[0];                        // d h1rec
+        if (t == 0) {                                                // the gradients of the initial state that leave through the last step: d h1rec, d feed
+          const int erow = rb + oc16;
+          if (erow < B) { const size_t o = (size_t)erow * HD + 16 * member + 4 * oq; *reinterpret_cast<f32x4*>(p.dh_rec[0] + o) = v[0]; *reinterpret_cast<f32x4*>(p.dfeed + o) = v[1]; }
+        }
+      }
+      dpre_publish(c, t - 1, ot, true, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, v[1]);
+    };
+
+    B2(IC<0>{}); CH_STAMP(0); B2(IC<1>{}); CH_STAMP(1); if (s_dead) { dead = true; break; }
+    B3(IC<0>{}); CH_STAMP(2); B3(IC<1>{}); CH_STAMP(3); if (s_dead) { dead = true; break; }
+    B4(IC<0>{}); CH_STAMP(4); B4(IC<1>{}); CH_STAMP(5); if (s_dead) { dead = true; break; }
+    B5(IC<0>{}); CH_STAMP(6); B5(IC<1>{}); CH_STAMP(7); if (s_dead) { dead = true; break; }
+    B6(IC<0>{}); CH_STAMP(8); B6(IC<1>{}); CH_STAMP(9); if (s_dead) { dead = true; break; }
+    prefill(t - 2, ot, local);
+    first = false;
+  }
+  // d c / d h of the initial decoder state, for the encoder's backward pass (model.lua:662-690)
+  if (!s_dead && wave == 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int erow = row0 + RC * c + c16;
+      if (erow < B) {
+        const size_t o = (size_t)erow * HD + 16 * member + 4 * q;
+        *reinterpret_cast<f32x4*>(p.dc_st[0] + o) = dc1[c]; *reinterpret_cast<f32x4*>(p.dc_st[1] + o) = dc2[c];
+        *reinterpret_cast<f32x4*>(p.dh_rec[1] + o) = dh2rec[c];                // (d h1rec and d feed: stored by B6 of step 0)
+      }
+    }
+  }
+  wait_vm<0>();
+#ifdef DC_DEBUG_STAMPS
+  if (p.stamps && wid == 0 && tid == 0) for (int k = 0; k < 16; ++k) p.stamps[k] = stamp[k];
 #endif
 }
 
@@ -452,6 +921,17 @@ void dec_chain_forward(hipStream_t s, const DecClFwdArgs& a0) {
     a.stamps = getenv("AOCR_DC_STAMPS") ? a.xtab + (size_t)groups * NM : nullptr;
     if (res) hipLaunchKernelGGL((dec_ch_fwd_kernel<false, true>), dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), (size_t)CH_FWD_LDS, s, a);
     else hipLaunchKernelGGL((dec_ch_fwd_kernel<false, false>), dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), (size_t)CH_FWD_LDS, s, a);
+  }
+}
+
+void dec_chain_backward(hipStream_t s, const DecClBwdArgs& a0) {
+  static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int groups = (a0.B + R - 1) / R, per_pass = std::max(8, cus / (8 * NM) * 8);
+  (void)hipFuncSetAttribute((const void*)dec_ch_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_BWD_LDS);
+  for (int g0 = 0; g0 < groups; g0 += per_pass) {
+    DecClBwdArgs a = a0; a.group0 = g0; a.ngroups = std::min(per_pass, groups - g0); a.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;
+    a.stamps = getenv("AOCR_DC_STAMPS") ? a.xtab + (size_t)groups * NM + 16 : nullptr;
+    hipLaunchKernelGGL(dec_ch_bwd_kernel, dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), (size_t)CH_BWD_LDS, s, a);
   }
 }
 

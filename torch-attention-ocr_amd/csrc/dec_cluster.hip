@@ -630,7 +630,6 @@ __global__ __launch_bounds__(256, 1) void dec_cl_fwd_kernel(DecClFwdArgs p) {
 // The four K = 2048 weight slices (rows 16m .. 16m+15 of the TRANSPOSED matrices, K split over the four waves) stay in registers:
 // 256 VGPRs per lane; W_c^T / W_a^T slices (48) too.  Everything the hoisted weight-gradient GEMMs and attention_dctx read is
 // written in the launch chain's layouts: d pre, d c (in d cat), d s, d q, d z (fp32 + bf16), plus the final d c / d h of both layers.
-constexpr int PZ = 4096 + 16;                                      // LDS pitch of a d z operand row (2048 bf16)
 constexpr int BWD_LDS_BYTES = R * PZ + 16384 + 4096;               // operand (d pre / d q alias its start) + partial tiles + attention scratch
 
 template <bool DROP = false>                                        // DROP: the forward kernel ran with nn.Dropout(p > 0) (masked attention output, masked layer-2 input)
@@ -980,6 +979,7 @@ bool dec_cluster_supported(int Hd, int Ld, int input_feed, int T, int L, int cus
 size_t dec_cluster_bwd_xbuf_bytes(int B) { return (size_t)((B + R - 1) / R) * 5 * NM * 128 * sizeof(unsigned) + 256; }
 bool dec_cluster_bwd_supported(int Hd, int Ld, int input_feed, int T, int L, int cus) { return dec_cluster_supported(Hd, Ld, input_feed, T, L, cus) && L + 2 < 512; }
 void dec_cluster_backward(hipStream_t s, const DecClBwdArgs& a0) {
+  if (a0.drop_h.thr == 0 && a0.drop_out.thr == 0 && dec_chain_enabled() && !getenv("AOCR_NO_DEC_CHAINS_BWD")) { dec_chain_backward(s, a0); return; }      // round 5: two chains per group, tag-free exchange
   static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
   const int groups = (a0.B + R - 1) / R, per_pass = std::max(8, cus / (8 * NM) * 8);
   (void)hipFuncSetAttribute((const void*)dec_cl_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES);

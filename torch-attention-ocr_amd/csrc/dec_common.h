@@ -8,6 +8,7 @@ namespace aocr {
 // two-chain, tag-free-exchange form of the decoder kernels (dec_chain.hip); AOCR_NO_DEC_CHAINS=1 keeps dec_cluster.hip's kernels
 bool dec_chain_enabled();
 void dec_chain_forward(hipStream_t s, const DecClFwdArgs& a);
+void dec_chain_backward(hipStream_t s, const DecClBwdArgs& a);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -18,6 +19,7 @@ typedef unsigned long long u64;
 namespace {
 constexpr int DC_SPIN_LIMIT = 1 << 18;
 constexpr int HD = 512, NM = 32, R = 32, PA = HD * 2 + 16;      // hidden size, members per group, rows per group, LDS operand pitch
+constexpr int PZ = 4096 + 16;                                      // LDS pitch of a d z operand row (2048 bf16)
 constexpr int LDS_BYTES = 3 * R * PA + 32768 + 4736 + 10240;     // three operand buffers + the reduction scratch + the decode scratch (+ its gate-input table slice)
 
 // ---- VMEM in program order: polls first, the previous phase's output stores behind them, then `s_waitcnt vmcnt(#stores)` -- the
