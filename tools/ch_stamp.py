@@ -25,6 +25,6 @@ b = m.get_tensor("dc_bstamps").view(torch.int64).cpu().tolist()
 bn = ["B2<0>", "B2<1>", "B3<0>", "B3<1>", "B4<0>", "B4<1>", "B5<0>", "B5<1>", "B6<0>", "B6<1>"]
 print("backward, workgroup 0, shader cycles per step")
 for k, n in enumerate(bn):
-    print(f"  {n:6s} {b[k] / L:8.0f}")
-print(f"  total {sum(b[:10]) / L:9.0f} per step")
+    print(f"  {n:6s} {b[k] / L:8.0f}" + (f"   + operand wait {b[10 + k - 4] / L:7.0f}" if k >= 4 else ""))
+print(f"  total {sum(b[:16]) / L:9.0f} per step; d z poll retries per step (wave 0 of workgroup 0) {m.get_tensor('dc_times').view(torch.int32)[8].item() / L:.2f}")
 m.shutdown()

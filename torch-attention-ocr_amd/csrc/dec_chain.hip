@@ -596,11 +596,12 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma16x(p.gates[l] + (((size_t)t * B + row) * HD + u0 + i) * 4, b + 2048 + 1024 * i, true);
   };
-  auto reduce2 = [&](const f32x4 (&acc)[2], f32x4 (&v)[2], auto&& mid) {      // two K-split tiles of a chain -> wave 0 (dec_cluster.hip's order)
+  auto reduce2 = [&](const f32x4 (&acc)[2], f32x4 (&v)[2], auto&& mid, auto&& post) {      // two K-split tiles of a chain -> wave 0 (dec_cluster.hip's order)
 #pragma unroll
     for (int n = 0; n < 2; ++n) *reinterpret_cast<f32x4*>(red + ((size_t)(wave * 2 + n) * 64 + lane) * 4) = acc[n];
     mid();
     lds_barrier();
+    post();                                                          // fetches of 4 KB-row operands: as late as the phase allows for every wave (their producers published a phase ago; an early fetch finds unwritten dwords)
     if (wave == 0) {
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
@@ -625,8 +626,9 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
       dcs_[i] = dcv * fg;
     }
   };
+  [[maybe_unused]] int zretry = 0;
   // K = 2048 products against a chain's d z (this wave's quarter of K, two tiles); the fragments are looked at for unwritten dwords on the way
-  auto zprod = [&](const bf16x8 (&wa_)[16], const bf16x8 (&wb_)[16], const bf16_t* src, int rb, unsigned char* X, f32x4 (&v)[2], int code, auto&& mid) {
+  auto zprod = [&](const bf16x8 (&wa_)[16], const bf16x8 (&wb_)[16], const bf16_t* src, int rb, unsigned char* X, f32x4 (&v)[2], int code, auto&& mid, auto&& post) {
     const unsigned char* base = X + (size_t)c16 * PZ + 1024 * wave + 16 * q;
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -640,11 +642,21 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
           asm volatile("" : "+v"(spins));
           if (++spins > DC_SPIN_LIMIT) { if (lane == 0) { atomicExch(p.err, code); s_dead = 1; } break; }
           __builtin_amdgcn_s_sleep(1);
-          dz_issue(src, rb, X, lane);
+          {                                                          // lane (c16, q) holds row c16's fragments: re-fetch this wave's quarter of the rows that have unwritten dwords
+            const unsigned long long bm = __ballot(fmax8(f) == SENT);
+            unsigned rows = (unsigned)((bm | (bm >> 16) | (bm >> 32) | (bm >> 48)) & 0xFFFFull);
+            while (rows) {
+              const int r = __builtin_ctz(rows); rows &= rows - 1;
+              dma16x(reinterpret_cast<const unsigned char*>(src) + (size_t)min(rb + r, B - 1) * (HD * 8) + 1024 * wave + lane * 16, __builtin_amdgcn_readfirstlane(lds_addr(X) + r * PZ + 1024 * wave), local);
+            }
+          }
           wait_vm<0>();
           lds_read8(f, base + 512 * hh);
           if (!__any(fmax8(f) == SENT)) break;
         }
+#ifdef DC_DEBUG_STAMPS
+        zretry += spins;
+#endif
       }
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
@@ -652,7 +664,7 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb_[8 * hh + s], f.v[s], acc[1], 0, 0, 0);
       }
     }
-    reduce2(acc, v, mid);
+    reduce2(acc, v, mid, post);
   };
   // d pre of (chain c, step t) from d feed and the staged d out_proj / out: published (bf16) + stored (fp32) by wave 0 -- 2 stores per wave
   auto dpre_publish = [&](int c, int t, int ot, bool from_lds, const f32x4& dpn_, const f32x4& on_, const f32x4& dfeed) {
@@ -702,7 +714,7 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
         if constexpr (c == 0) pend_issue(p.dpre_b + (size_t)t * slot, HD * 2, row0 + RC, B, xbuf(1), PA, olane, wave, member, local);
         else { if (mych == 0 && wave < 2)                           // the d c row of a chain-0 owner (published in B2<0>)
                  dma16x(reinterpret_cast<const unsigned char*>(p.dcat + ((size_t)t * B + min(arow, B - 1)) * 2 * HD) + 1024 * wave + olane * 16, __builtin_amdgcn_readfirstlane(lds_addr(dcs) + 1024 * wave), local); }
-      });
+      }, [] {});
       if (wave == 0) keep[(c * 2 + 0) * 64 + lane] = dcat[1];
       const int erow = rb + oc16; const bool eok = wave == 0 && erow < B;
       u32x4 dv = __builtin_bit_cast(u32x4, dcat[0]);
@@ -825,14 +837,17 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
       if constexpr (c == 0) { if (mych == 1) pend_land<3>(p.dq_b + (size_t)t * slot, HD * 2, rb, B, X, PA, olane, wave, member, local, p.err, 23, &s_dead);     // behind B3<1>
                               else pend_land<0>(p.dq_b + (size_t)t * slot, HD * 2, rb, B, X, PA, olane, wave, member, local, p.err, 23, &s_dead); }
       else pend_land<8>(p.dq_b + (size_t)t * slot, HD * 2, rb, B, X, PA, olane, wave, member, local, p.err, 23, &s_dead);                                          // behind B4<0>
+      CH_STAMP(10 + c);
       Frag4 f; lds_read4(f, X + (size_t)c16 * PA + (128 * wave + 8 * q) * 2);
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, v[2];
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wat[s], f.v[s], acc[0], 0, 0, 0);
       *reinterpret_cast<f32x4*>(red + ((size_t)wave * 64 + lane) * 4) = acc[0];
       if constexpr (c == 0) { cell_issue(1, 1, 1, t, oc16, oq); pend_issue(p.dq_b + (size_t)t * slot, HD * 2, row0 + RC, B, xbuf(1), PA, olane, wave, member, local); }
-      else { cell_issue(0, 0, 0, t, oc16, oq); dz_issue(p.dzb[1] + (size_t)t * B * 4 * HD, row0, xbuf(0), olane); }
+      else cell_issue(0, 0, 0, t, oc16, oq);
       lds_barrier();
+      // (d z2 of chain 0 left its producers at the end of B4<0>, a short phase ago: the idle waves hold their fetch back a little, wave 0 issues its own behind the cell arithmetic)
+      if constexpr (c == 1) { if (wave != 0) { __builtin_amdgcn_s_sleep(14); dz_issue(p.dzb[1] + (size_t)t * B * 4 * HD, row0, xbuf(0), olane); } }
       f32x4 dz[4] = {acc[0], acc[0], acc[0], acc[0]};
       if (wave == 0) {
         v[0] = *reinterpret_cast<const f32x4*>(red + ((size_t)0 * 64 + lane) * 4);
@@ -840,6 +855,7 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
         for (int w = 1; w < 4; ++w) v[0] += *reinterpret_cast<const f32x4*>(red + ((size_t)w * 64 + lane) * 4);
         const f32x4 dh2 = v[0] + keep[(c * 2 + 0) * 64 + lane] + dh2rec[c];
         cell_bwd(c, dh2, dc2[c], dz);
+        if constexpr (c == 1) dz_issue(p.dzb[1] + (size_t)t * B * 4 * HD, row0, xbuf(0), olane);
       }
       dz_store(1, rb, dz);
     };
@@ -848,10 +864,14 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
       constexpr int c = decltype(cc)::value;
       unsigned char* const X = xbuf(c); const int rb = row0 + RC * c;
       wait_vm<8>();                                                  // behind B4<1> / B5<0>: 8 stores
+      CH_STAMP(12 + c);
       f32x4 v[2], dz[4];
       zprod(wz[0], wz[1], p.dzb[1] + (size_t)t * B * 4 * HD, rb, X, v, 24, [&] {
-        if constexpr (c == 0) { cell_issue(1, 1, 0, t, oc16, oq); if (t > 0) stin_issue(0, t - 1, oc16, oq, olane); dz_issue(p.dzb[1] + (size_t)t * B * 4 * HD, row0 + RC, xbuf(1), olane); }
-        else { if (t > 0) stin_issue(1, t - 1, oc16, oq, olane); dz_issue(p.dzb[0] + (size_t)t * B * 4 * HD, row0, xbuf(0), olane); }
+        if constexpr (c == 0) { cell_issue(1, 1, 0, t, oc16, oq); if (t > 0) stin_issue(0, t - 1, oc16, oq, olane); }
+        else { if (t > 0) stin_issue(1, t - 1, oc16, oq, olane); }
+      }, [&] {
+        if constexpr (c == 0) dz_issue(p.dzb[1] + (size_t)t * B * 4 * HD, row0 + RC, xbuf(1), olane);
+        else dz_issue(p.dzb[0] + (size_t)t * B * 4 * HD, row0, xbuf(0), olane);
       });
       dz[0] = dz[1] = dz[2] = dz[3] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (wave == 0) {
@@ -866,10 +886,12 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
       constexpr int c = decltype(cc)::value;
       unsigned char* const X = xbuf(c); const int rb = row0 + RC * c;
       if constexpr (c == 0) wait_vm<8>(); else wait_vm<2>();         // behind B5<1> (8 stores) / B6<0> (2)
+      CH_STAMP(14 + c);
       f32x4 v[2];
       zprod(wz[2], wz[3], p.dzb[0] + (size_t)t * B * 4 * HD, rb, X, v, 26, [&] {
+        if constexpr (c == 1) { if (t > 0) pend_issue(p.dpre_b + (size_t)(t - 1) * slot, HD * 2, row0, B, xbuf(0), PA, olane, wave, member, local); }
+      }, [&] {
         if constexpr (c == 0) dz_issue(p.dzb[0] + (size_t)t * B * 4 * HD, row0 + RC, xbuf(1), olane);
-        else { if (t > 0) pend_issue(p.dpre_b + (size_t)(t - 1) * slot, HD * 2, row0, B, xbuf(0), PA, olane, wave, member, local); }
       });
       if (wave == 0) {
         keep[(c * 2 + 1) * 64 + lane] = v[0];                        // d h1rec
@@ -903,7 +925,7 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
   }
   wait_vm<0>();
 #ifdef DC_DEBUG_STAMPS
-  if (p.stamps && wid == 0 && tid == 0) for (int k = 0; k < 16; ++k) p.stamps[k] = stamp[k];
+  if (p.stamps && wid == 0 && tid == 0) { for (int k = 0; k < 16; ++k) p.stamps[k] = stamp[k]; p.err[16 + 2048 + 8] = zretry; }
 #endif
 }
 
