@@ -196,6 +196,7 @@ def main():
         rccl_ranks = int(probe.item())
     img, tgt, tge, nnz = aocr.synth.synth_batch(B, W, seed=1234 + rank, max_len=L - 1, H=IMG_H)
     dev = m.device
+    params0, bn0 = m.params.clone(), m.bn_state.clone()      # the replica the decode legs run on (decode must not depend on how long the training loop ran)
     images = torch.from_numpy(img).to(device=dev, dtype=torch.float32)
     targets = torch.from_numpy(tgt).to(dev); targets_eval = torch.from_numpy(tge).to(dev)
     assert targets.shape[1] == L
@@ -307,37 +308,70 @@ def main():
             families[k] = e
         families["_sum_ms"] = float(sum(fam.values()))
 
-    # ---- decode throughput (greedy, max_decoder_l = 50 steps + gold pass = the reference's -phase test step), no exchange across ranks
+    # ---- decode throughput (greedy, max_decoder_l = 50 steps + gold pass = the reference's -phase test step), no exchange across ranks.
+    # Run on a FRESH replica of the parameters (the ones the training loop started from): after ~1500 steps on one fixed batch the model
+    # emits EOS early and the greedy kernel's early exit (every row of a 32-row group at EOS / PAD) skips half the loop -- the number would
+    # depend on --sustain-seconds.  Two timings: the kernel as shipped (early exit on) and AOCR_NO_DEC_EARLY=1 = the literal 50 steps of
+    # model.lua:376; both with the steps actually executed.
     dec = None; dec_dict = None
+
+    def executed_steps(lab):
+        """Decoder steps the greedy kernel ran for these labels: a 32-row group leaves its loop at the first step at which every row has
+        emitted EOS / PAD = 1 + the last position with a live token + the EOS step, at most the label width."""
+        live = ((lab != 1) & (lab != 3)).cpu().numpy()
+        last = np.where(live.any(axis=1), live.shape[1] - np.argmax(live[:, ::-1], axis=1), 0)
+        grp = [int(min(lab.shape[1], last[g:g + 32].max() + 2)) for g in range(0, B, 32)]
+        return int(sum(min(32, B - g) * grp[g // 32] for g in range(0, B, 32))), max(grp)
+
     if args.decode_steps > 0:
-        m.decode_device(images, targets, targets_eval, BEAM); sync()
-        t0 = time.perf_counter()
-        for _ in range(args.decode_steps):
-            m.decode_device(images, targets, targets_eval, BEAM)
-        sync()
-        eld = (time.perf_counter() - t0) / args.decode_steps
+        trained = (m.params.clone(), m.bn_state.clone())
+        m.params.copy_(params0); m.bn_state.copy_(bn0)
         Hd, T = 2 * wl["He"], (IMG_H // 16 - 1) * (W // 4 - 1)
-        dec = {"chars_per_s": world * B * 50 / eld, "what": "decoder steps/s: B*50 per call = one -phase test call of the reference, beam pass over max_decoder_l = 50 steps + gold pass (model.lua:376-627; the gold pass runs the steps the targets span -- its all-PAD steps add nothing to any output)",
-               "emitted_chars_per_s": world * nnz / eld, "ms_per_call": 1e3 * eld, "beam": BEAM}
-        if rank == 0:
-            fam = m.profile_families(lambda: m.decode_device(images, targets, targets_eval, BEAM), repeats=2)
-            chain = fam["decode_chain"]; gold = fam["decoder_fwd"] + fam["rnn_gemm"]
-            wbytes = 2 * (sum((Hd + Hd) * 4 * Hd for _ in range(wl["Ld"])) + Hd * Hd + 2 * Hd * Hd) + 4 * 39 * Hd   # bf16 recurrent weights + fp32 projector
-            sbytes = B * T * Hd * 2 + B * Hd * 4 * (4 * wl["Ld"] + 6)                                                # context (bf16) + state rows
-            if wl["compute"] != "bf16":
-                wbytes *= 2; sbytes = B * T * Hd * 4 + B * Hd * 4 * (4 * wl["Ld"] + 6)
-            dec.update({"beam_only_chars_per_s": B * 50 / (chain * 1e-3) if chain > 0 else None, "beam_ms": chain, "gold_pass_ms": gold,
-                        "cnn_encoder_ms": sum(fam[k] for k in ("conv_fwd", "bn", "pool_conv1", "encoder_seq", "other"))})
-            dec["decode_roofline"] = {
-                "bound": "hbm", "unit": "GB/s", "algorithmic_bytes_per_step": wbytes + sbytes,
-                "launches_per_step": (1.0 / 50 if (wl["compute"] == "bf16" and Hd == 512 and not os.environ.get("AOCR_NO_DEC_CLUSTER")) else 6),
-                "achieved": (wbytes + sbytes) / (chain / 50 * 1e-3) / 1e9 if chain > 0 else None, "peak": HBM_PEAK_GBPS,
-                "frac": (wbytes + sbytes) / (chain / 50 * 1e-3) / 1e9 / HBM_PEAK_GBPS if chain > 0 else None,
-                "us_per_step": 1e3 * chain / 50,
-                "note": "algorithmic bytes = every recurrent weight once + the batch's context once per step.  bf16 / Hd = 512: the whole greedy loop is "
-                        "ONE launch of the decoder cluster kernel (weights resident in registers, so these bytes are not streamed at all); a step is "
-                        "bound by its five in-XCD exchanges (~1.7 us each) and the context stream.  Otherwise: 6 dependent launches per step"}
-        # the same step under -use_dictionary: a synthetic 90 k-word lexicon as a device-resident flat trie
+        cluster = wl["compute"] == "bf16" and Hd == 512 and BEAM == 1 and not os.environ.get("AOCR_NO_DEC_CLUSTER")
+
+        def time_decode(no_early):
+            if no_early:
+                os.environ["AOCR_NO_DEC_EARLY"] = "1"
+            try:
+                lab = m.decode_device(images, targets, targets_eval, BEAM)[0]; sync()
+                t0 = time.perf_counter()
+                for _ in range(args.decode_steps):
+                    m.decode_device(images, targets, targets_eval, BEAM)
+                sync()
+                el_ = (time.perf_counter() - t0) / args.decode_steps
+                ex, exg = (B * 50, 50) if (no_early or not cluster) else executed_steps(lab)
+                r = {"ms_per_call": 1e3 * el_, "chars_per_s": world * B * 50 / el_, "executed_steps_per_call": ex, "executed_steps_per_s": world * ex / el_,
+                     "longest_group_steps": exg}
+                if rank == 0:
+                    fam = m.profile_families(lambda: m.decode_device(images, targets, targets_eval, BEAM), repeats=2)
+                    r.update({"beam_ms": fam["decode_chain"], "gold_pass_ms": fam["decoder_fwd"] + fam["rnn_gemm"],
+                              "cnn_encoder_ms": sum(fam[k] for k in ("conv_fwd", "bn", "pool_conv1", "encoder_seq", "other")),
+                              "beam_us_per_executed_step": 1e3 * fam["decode_chain"] / max(1, exg)})
+                return r
+            finally:
+                os.environ.pop("AOCR_NO_DEC_EARLY", None)
+
+        d_early, d_full = time_decode(False), time_decode(True)
+        dec = dict(d_early)
+        dec.update({"what": "one -phase test call of the reference = beam pass over max_decoder_l = 50 steps + gold pass (model.lua:376-627), on the parameters the "
+                            "training loop STARTED from.  chars_per_s = the nominal B*50 decoder steps / time; executed_steps_* = the steps the greedy kernel "
+                            "ran (a 32-row group leaves once every row has emitted EOS / PAD: the outputs are those of the 50-step loop); `no_early_exit` = the "
+                            "same call with AOCR_NO_DEC_EARLY=1 (all 50 steps executed)",
+                    "emitted_chars_per_s": world * nnz / (d_early["ms_per_call"] * 1e-3), "beam": BEAM, "no_early_exit": d_full})
+        if rank == 0 and d_full.get("beam_ms"):
+            us = d_full["beam_us_per_executed_step"]
+            # what bounds a step of the whole-sequence greedy kernel: five dependent all-gathers inside a 32-CU group (out, h1, h2, attention context,
+            # partial logits) -- nothing is streamed from HBM (weights in registers, context in L2).  Floor = 5 x the idle one-hop hand-off price of
+            # MI355X_MICROARCH.md ("handoff-1to1", 0.8-1.0 us).  The launch chain instead: 6 dependent launches per step.
+            floor = 5 * 1.0 if cluster else 6 * 1.45
+            dec["decode_roofline"] = {"bound": "exchange-latency" if cluster else "launch-latency", "unit": "us per executed decoder step (all rows of the batch advance one step)",
+                                      "achieved": us, "floor": floor, "frac": floor / us if us > 0 else None, "launches_per_step": 1.0 / 50 if cluster else 6,
+                                      "note": "floor: MI355X_MICROARCH.md price list (handoff-1to1 idle 0.8-1.0 us per dependent hop; boundary 1.45 us per dependent launch); "
+                                              "measured with every step executed (AOCR_NO_DEC_EARLY=1): beam_ms / 50"}
+        m.params.copy_(trained[0]); m.bn_state.copy_(trained[1])
+    if args.decode_steps > 0:
+        # the same step under -use_dictionary (SURVEY.md 8(f) row 2): a synthetic 90 k-word lexicon as a device-resident flat trie (trained parameters: the
+        # early exit is the point of this leg)
         if not args.no_secondary and BEAM == 1:
             rng = np.random.default_rng(1234)
             lens = rng.integers(3, 11, size=90000)
@@ -431,7 +465,7 @@ def main():
         # ---- the BANDWIDTH-bound kernels ("report HBM GB/s for those kernels separately"): each replayed by the library on the
         # buffers of a training step with the arguments the step passes (aocr_profile_kernel ids >= 2), HIP events on the model's stream;
         # algorithmic bytes = what the kernel must read and write once.  `frac` is against the 8 TB/s spec; ~6.3 TB/s is what a float4 copy
-        # reaches on this chip (MI355X_MICROARCH.md), so 0.79 is the practical ceiling.  PMC cross-check: profiles/r04_hbm_pmc.txt.
+        # reaches on this chip (MI355X_MICROARCH.md), so 0.79 is the practical ceiling.  PMC cross-check: profiles/r05_hbm_pmc.txt.
         step(); torch.cuda.synchronize()
         names = {2: ("conv1_fwd_kernel", "normalise + conv1 + ReLU + 2x2 pool: fp32 image in, pooled bf16 map out"),
                  3: ("conv1_bwd_pk_kernel", "conv1 filter gradient: image + fp32 d(pooled map) in; VALU-bound (~110 instructions per window and lane), not byte-bound"),
@@ -458,10 +492,10 @@ def main():
         msw, kflw = m.profile_kernel(1, 20)
         achw = kflw / (msw * 1e-3) / 1e12
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "r04_wgrad_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r05_wgrad_pmc.json")
         if bf16 and args.workload == "c3" and world == 1 and args.scaling == "weak" and os.path.exists(pmc):
             traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
-            traffic_source = ("profiles/r04_wgrad_pmc.json: rocprofv3 --pmc passes of this command on the tagged conv6 filter-gradient launch "
+            traffic_source = ("profiles/r05_wgrad_pmc.json: rocprofv3 --pmc passes of this command on the tagged conv6 filter-gradient launch "
                               "(tools/pmc_traffic.py); PMC counters cannot be read from inside the timed process, so this field is NOT measured in this run")
         step_frac = 3 * fl["total"] * lines_per_s / 1e12 / (peak * world)
         wg_share = (families or {}).get("conv_wgrad", {}).get("ms_per_step", 0.0) / max(1e-9, (families or {}).get("_sum_ms", 1.0))
@@ -473,10 +507,15 @@ def main():
         if bf16:
             # context for `peak` (not a replacement for it): what a K loop that does nothing but v_mfma_f32_32x32x16_bf16 on register-resident RANDOM bf16
             # operands sustains on this chip -- the shader clock falls from 2.4 to ~1.7 GHz under it (power); profiles/r03_gemm4w_ubench.txt, tools/ubench/gemm4w.hip
+            mo, mo_src = None, os.path.join("profiles", "r05_gemm4w_steady.txt")
+            try:                                          # tools/ubench/gemm4w after 5000 warm-up launches: the "MFMA on resident random fragments" rows, best of the file
+                mo = max(float(l.split("TFLOP/s")[0].split()[-1]) for l in open(os.path.join(ROOT, mo_src)) if "MFMA on resident random fragments" in l)
+            except Exception:
+                pass
             for r_ in (roof, best):
-                r_["mfma_only_sustained_TFLOPs"] = 1550.0
-                r_["frac_of_mfma_only_sustained"] = r_["achieved"] / 1550.0
-                r_["mfma_only_source"] = "profiles/r03_gemm4w_ubench.txt (a constant from that measurement, NOT measured in this run)"
+                r_["mfma_only_sustained_TFLOPs"] = mo
+                r_["frac_of_mfma_only_sustained"] = r_["achieved"] / mo if mo else None
+                r_["mfma_only_source"] = mo_src + " (tools/ubench/gemm4w.hip, measured this round on the pool; a file constant, NOT measured in this run)"
         out = {
             "metric": "image-lines/sec (train step)", "value": lines_per_s, "unit": "image-lines/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,

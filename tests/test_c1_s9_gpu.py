@@ -22,8 +22,7 @@ def _gen():
     return m
 
 
-@pytest.mark.parametrize("compute", ["f32", "bf16"])
-@pytest.mark.parametrize("He", [256, 512])
+@pytest.mark.parametrize("He,compute", [(256, "f32"), (512, "bf16"), pytest.param(256, "bf16", marks=pytest.mark.slow), pytest.param(512, "f32", marks=pytest.mark.slow)])
 def test_c1_batch1_greedy_decode(cuda, compute, He):
     """C1: B = 1, 32x100, beam 1, max_decoder_l = 50 steps + the gold pass (model.lua:321-627) -- every `B % 16` / `B % 32`
     fallback of the dispatch.  BatchNorm statistics calibrated on a batch of 8 crops of the same generator so that the
@@ -87,8 +86,7 @@ def test_c1_batch1_train_step(cuda, compute):
     m.shutdown()
 
 
-@pytest.mark.parametrize("beam", [1, 5])
-@pytest.mark.parametrize("compute", ["f32", "bf16"])
+@pytest.mark.parametrize("compute,beam", [("f32", 1), ("bf16", 5), pytest.param("f32", 5, marks=pytest.mark.slow), pytest.param("bf16", 1, marks=pytest.mark.slow)])
 def test_s9_first_token_39(cuda, beam, compute):
     """tests/golden/s9_first39.npz: the projector bias of id 39 is raised so that some rows emit id 39 (= V) at the first step.  The
     reference computes that step's parent as floor(39 / 39) + 1 = 2: harmless with beam > 1 (identical replicas), the NEXT image's

@@ -241,6 +241,7 @@ def test_halo_conv_kernel_matches_im2col_kernel(cuda, monkeypatch, B, W):
     assert_grads_agree_up_to_decisions(a["grads"], b["grads"], "halo-vs-im2col")
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("B,W", [(8, 128), (6, 256), (4, 512)])
 def test_halo_four_wave_kernel_matches_eight_wave_kernel(cuda, monkeypatch, B, W):
     """gemm_halo4_bf16_kernel (four waves of 128 x 128, fragment reads / LDS-DMA pieces pinned between the MFMAs, output tiles staged
@@ -1058,6 +1059,7 @@ def test_dma128_kernel_matches_tiled_kernel(cuda, monkeypatch, B, W):
     print(f"[parity] dma128 vs register-staged 128 x 128 kernel, B={B} W={W}: conv6 / feats / logits bit-identical, loss {a['loss']:.6f}")
 
 
+@pytest.mark.slow
 def test_narrow_staged_epilogue_matches_quad(cuda, monkeypatch):
     """Round 4: the fp32 output tile of gemm_dma_narrow_kernel leaves through LDS as 16-byte row stores (narrow_store_staged: the hoisted
     encoder projections / ctx W_a / d X products and the narrow data gradients) instead of 64 four-byte stores per wave.  The values are
@@ -1113,6 +1115,7 @@ def test_halo_wgrad_kernel_matches_tap_tiled_kernel(cuda, monkeypatch, B, W):
     print(f"[parity] halo-resident filter gradient vs tap-tiled kernels, B={B} W={W}: worst relative difference {worst[1]:.2e} ({worst[0]})")
 
 
+@pytest.mark.slow
 def test_encoder_dx_single_product_matches_two_products(cuda, monkeypatch):
     """Round 4: the encoder's input gradient d X = d z_fw W_i2h_fw + d z_bw W_i2h_bw (model.lua:675 copy, :689 add) as ONE product over the
     concatenated K range (gemm_hh_cat, LoadKhCat) against the two products it replaces (AOCR_NO_HH_CAT=1: the second adds to the first's
@@ -1138,6 +1141,7 @@ def test_encoder_dx_single_product_matches_two_products(cuda, monkeypatch):
         assert cosine(b["grads"][k], a["grads"][k]) > 0.9999, k
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("B,W", [(8, 256), (16, 128)])
 def test_bf16_data_gradient_maps_match_fp32_maps(cuda, monkeypatch, B, W):
     """Round 4, OPT-IN path (AOCR_DX16=1; measured -0.055 ms per C3 step, NOT the default): the data gradients of conv4-conv7 leave their
@@ -1173,6 +1177,7 @@ def test_bf16_data_gradient_maps_match_fp32_maps(cuda, monkeypatch, B, W):
     print(f"[parity] bf16 data-gradient maps (opt-in) vs fp32 maps, B={B} W={W}: lowest cosine {worst[1]:.7f} ({worst[0]}, max-norm {worst[2]:.2e})")
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("B,W", [(8, 256), (16, 128)])
 def test_bn_backward_sums_from_dgrad_epilogue(cuda, monkeypatch, B, W):
     """Round 4, OPT-IN path (AOCR_BNB_FUSE=1; measured SLOWER at C3 -- BatchNorm 0.50 -> 0.365 ms but data gradients 0.767 -> 0.931 ms per step --
@@ -1206,6 +1211,7 @@ def test_bn_backward_sums_from_dgrad_epilogue(cuda, monkeypatch, B, W):
     print(f"[parity] BatchNorm backward sums from the data-gradient epilogue vs the separate pass, B={B} W={W}: worst relative difference {worst[1]:.2e} ({worst[0]})")
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("B,W,tile", [(6, 72, ""), (64, 100, ""), (64, 100, "1"), (64, 100, "2"), (5, 200, "3")])
 def test_f32t_kernel_matches_lds_f32_kernel(cuda, monkeypatch, B, W, tile):
     """Round 4: gemm_f32t_kernel (exact-fp32 conv forward / data gradient / nn.Linear products: branch-free staging, tile shape by grid size:
@@ -1266,6 +1272,7 @@ def test_embedding_token_table_matches_tensor_path(cuda, monkeypatch, B, W):
     print(f"[parity] embedding token table vs tensor path, B={B} W={W}: logits / loss bit-identical, worst gradient difference {worst:.2e}")
 
 
+@pytest.mark.slow
 def test_grouped_dma_weight_gradients_match_transposed_read_kernel(cuda, monkeypatch):
     """Round 4: the hoisted recurrent weight gradients (dW = dz^T x over all time steps) with full 256 x 256 tiles and K >= 2048 run on
     wgrad_dma_grouped_kernel (LDS-DMA ring, slabs per k range + wgrad_slab_reduce_kernel), the encoder's on the side stream beside the
@@ -1293,3 +1300,34 @@ def test_grouped_dma_weight_gradients_match_transposed_read_kernel(cuda, monkeyp
         e = relerr(b["grads"][k], a["grads"][k]); worst = max(worst, e)
         assert e < 2e-5, (k, e)
     print(f"[parity] grouped LDS-DMA weight gradients vs transposed-read kernel: worst gradient difference {worst:.2e}")
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("switch", ["AOCR_NO_CNN_WGRAD_SIDE", "AOCR_NO_SIDE_PROLOGUE", "AOCR_NO_SIDE2"])
+def test_side_stream_overlaps_match_in_line_order(cuda, monkeypatch, switch):
+    """the round-4 stream-level overlaps -- CNN filter gradients on the side stream over double-buffered gradient maps, the step prologue
+    (gradient zeroing, weight shadows, token table) beside conv1, the second side stream -- each against the same steps with the switch that puts the
+    work back in line.  Three optimisation steps on one batch: a missing event dependency (a kernel reading a buffer the other stream has not finished, or
+    has already overwritten) shows up as a different gradient vector / different parameters; what may differ is the order in which split-K partial sums meet."""
+    cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for knob in ("", "1"):
+        monkeypatch.delenv(switch, raising=False)
+        if knob:
+            monkeypatch.setenv(switch, knob)
+        m, O, ocfg, P, st, batch = make(cfg, B=32, W=256, maxlen=11, compute="bf16", max_decoder_l=12, max_beam=1)
+        images, targets, targets_eval = m._upload(batch)
+        grads = []
+        for i in range(3):
+            m.train_step_device(images, targets, targets_eval, 32)
+            grads.append(m.grad_params.clone())
+        torch.cuda.synchronize()
+        assert m.cluster_status() == 0
+        out[knob] = (grads, m.params.clone(), m.bn_state.clone())
+        m.shutdown()
+    (g0, p0, b0), (g1, p1, b1) = out[""], out["1"]
+    for i, (a, b) in enumerate(zip(g0, g1)):
+        rel = ((a - b).norm() / b.norm()).item()
+        assert rel < 2e-3, (switch, i, rel)                       # step 0: ~1e-6 (summation order); later steps: the same, amplified through bf16 operand rounding
+    assert ((g0[0] - g1[0]).norm() / g1[0].norm()).item() < 1e-4
+    assert (p0 - p1).abs().max().item() < 5e-3 and (b0 - b1).abs().max().item() < 1e-3

@@ -28,7 +28,8 @@ namespace {
 constexpr unsigned SENT = 0xFFFFFFFFu;
 constexpr int NCH = 2, RC = 16;                                     // chains per group, rows per chain
 constexpr int OPB = RC * PA;                                        // one operand buffer of a chain: 16 rows x 1 KB (+ pad)
-constexpr int CH_FWD_LDS = NCH * 3 * OPB + 16384 + 8192 + 1024 + NCH * 5 * 1024;     // operands + K-split partial tiles + attention partial context + scores + the next step's gate inputs / tokens
+constexpr int CH_FWD_LDS = NCH * 3 * OPB + 16384 + 8192 + 1024 + NCH * 5 * 1024;
+constexpr int CH_DEC_LDS = CH_FWD_LDS + 2560 + NCH * 1024 + NCH * 1024 + 10240;      // greedy decode: + W_o slice, out(t) of the member's units, token staging, the per-token gate-input table slice     // operands + K-split partial tiles + attention partial context + scores + the next step's gate inputs / tokens
 
 __device__ __forceinline__ unsigned sane(unsigned x) { return x == SENT ? 0xFFFEFFFFu : x; }
 __device__ __forceinline__ unsigned umax4(const u32x4& v) { return max(max(v[0], v[1]), max(v[2], v[3])); }
@@ -134,12 +135,15 @@ template <int C> struct IC { static constexpr int value = C; };
 //   P4  out(t) = tanh(W_c [c(t) ; h2(t)])                              c(t)     <- P3                    publishes out(t)
 template <bool DEC, bool RES>     // RES: T <= 64 -- the 16-step tile of ctx . W_a a wave multiplies stays in its registers for the whole loop (64 VGPRs)
 __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
-  static_assert(!DEC, "the greedy variant is not on the two-chain kernel yet");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* const red = reinterpret_cast<float*>(lds + NCH * 3 * OPB);            // [4 waves][4 tiles][64 lanes][4]: K-split partial tiles of one chain
   float* const part = reinterpret_cast<float*>(lds + NCH * 3 * OPB + 16384);   // attention: [4 waves][512] partial context
   float* const sc = part + 4 * HD;                                             //            [256] scores
   float* const zxs = sc + 256;                                                 // [chain][4 gates + token][256 threads]: zx1 of the next step, the token after it (LDS-DMA)
+  float* const wos = zxs + NCH * 5 * 256;                                      // DEC: [40][16] this member's slice of W_o (fp32)
+  float* const outs = wos + 640;                                               //      [chain][16 rows][16] out(t) of this member's units (fp32)
+  unsigned* const tokst = reinterpret_cast<unsigned*>(outs + NCH * 256);       //      [chain][4 waves][64] the tokens chosen a step ago, as fetched (tag << 8 | token)
+  float* const ztab = reinterpret_cast<float*>(tokst + NCH * 256);             //      [40 tokens][4 gates][16] this member's columns of the per-token gate-input table
   __shared__ int s_local, s_dead;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
@@ -168,6 +172,13 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
     pst16(dst, u32x4{sv, sv, sv, sv}, loc);
   };
   prefill(0, tid, false); prefill(1, tid, false);
+  constexpr int PSZ = 32 * 32 * 40;                                  // partial logits of a group and step parity: [row][source member][40]
+  float* const pown = DEC ? p.pbuf + ((size_t)group * 32 + member) * 32 * 40 : nullptr;      // ... this member's row (+ parity * ngroups_all * PSZ)
+  const size_t ppar = (size_t)p.pgroups * PSZ;
+  if constexpr (DEC) {                                               // this member's row of both parities: unwritten; its token slot: no token
+    for (int i = tid; i < 2 * 320; i += 256) pst16(pown + (i / 320) * ppar + (i % 320) * 4, u32x4{SENT, SENT, SENT, SENT}, false);
+    if (tid == 0) pst4(p.tokx + (size_t)group * 32 + member, 0u, false);
+  }
   wait_vm<0>();
   __syncthreads();
   // ---- co-location check (rnn_cluster.hip); it is also the point after which every member's pre-fill of steps 0 and 1 is in memory
@@ -206,15 +217,28 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
   // zx1 (gate input of layer 1: embedding part + biases) of the NEXT step and, with the per-token table, the token after it: fetched by LDS-DMA in P3
   // (a compiler-tracked load would put an s_waitcnt vmcnt(0) -- which also waits for the phase's young stores -- in front of its first use)
   float c1[NCH], c2[NCH];
+  int tokc[NCH] = {1, 1};                                            // DEC: the token this lane's row (of each chain) feeds to the current step
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int row = min(row0 + RC * c + c16, B - 1);
     c1[c] = p.cs[0][(size_t)row * HD + unit]; c2[c] = p.cs[1][(size_t)row * HD + unit];
-    const size_t zrow = p.zx_tok ? (size_t)(min(max(p.zx_tok[(int64_t)row * p.zx_sb], 1), p.V) - 1) : (size_t)row;
+    if constexpr (DEC) tokc[c] = p.tok0[(size_t)row * p.tok0_stride];                  // the GO tokens
+    else {
+      const size_t zrow = p.zx_tok ? (size_t)(min(max(p.zx_tok[(int64_t)row * p.zx_sb], 1), p.V) - 1) : (size_t)row;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) zxs[(c * 5 + i) * 256 + tid] = p.zx1[zrow * 4 * HD + i * HD + unit];
-    reinterpret_cast<int*>(zxs)[(c * 5 + 4) * 256 + tid] = p.zx_tok ? p.zx_tok[(int64_t)min(1, L - 1) * p.zx_st + (int64_t)row * p.zx_sb] : 1;
+      for (int i = 0; i < 4; ++i) zxs[(c * 5 + i) * 256 + tid] = p.zx1[zrow * 4 * HD + i * HD + unit];
+      reinterpret_cast<int*>(zxs)[(c * 5 + 4) * 256 + tid] = p.zx_tok ? p.zx_tok[(int64_t)min(1, L - 1) * p.zx_st + (int64_t)row * p.zx_sb] : 1;
+    }
   }
+  if constexpr (DEC) {
+    for (int i = tid; i < 640; i += 256) { const int v = i >> 4, u = i & 15; wos[i] = v < p.V ? p.wo[(size_t)v * HD + 16 * member + u] : 0.f; }
+    for (int i = tid; i < 2560; i += 256) {
+      const int v = i >> 6, g = (i >> 4) & 3, u = i & 15;
+      ztab[i] = v < p.V ? p.zx1[(size_t)v * 4 * HD + g * HD + 16 * member + u] : 0.f;
+    }
+  }
+  int t_exit = -1; bool fin0 = false;                                // DEC: the step at which every row of the group had finished (early exit)
+  float score = 0.f; int prev_tok = 0, node = 0;                     // DEC, wave 0 of the row's owner: running log-probability, last token, trie node (-use_dictionary)
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     load_rows16(p.out_b, row0 + RC * c, B, lds + (size_t)(c * 3 + 0) * OPB, tid);
@@ -277,17 +301,50 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       unsigned char* const F = lds + (size_t)(c * 3 + 0) * OPB; unsigned char* const H1 = lds + (size_t)(c * 3 + 1) * OPB;
       const int rb = row0 + RC * c;
       if (t > 0) {
-        if constexpr (c == 0) pend_land<3>(p.out_b + (size_t)t * slot, HD * 2, rb, B, F, PA, olane, wave, member, local, p.err, 11, &s_dead, 0, &nretry[0 + c]);      // P4<1> of step t-1: 2 stores + the pre-fill
+        if constexpr (c == 0) pend_land<(DEC ? 6 : 3)>(p.out_b + (size_t)t * slot, HD * 2, rb, B, F, PA, olane, wave, member, local, p.err, 11, &s_dead, 0, &nretry[0 + c]);      // P4<1> of step t-1: 2 stores (DEC: 5) + the pre-fill (P5's stores, wave 0 of an owner only, come on top)
         else pend_land<3>(p.out_b + (size_t)t * slot, HD * 2, rb, B, F, PA, olane, wave, member, local, p.err, 11, &s_dead, 0, &nretry[0 + c]);                       // P1<0>: 3 stores
       } else lds_barrier();
       CH_STAMP(8 + c);
+      if constexpr (DEC) {                                           // the tokens chosen at step t-1 (published by the rows' owners in P5): fetched beside the products, read behind them
+        if (t > 0) dma4(p.tokx + (size_t)group * 32 + RC * c + (olane & 15), __builtin_amdgcn_readfirstlane(lds_addr(tokst) + ((c * 4 + wave) * 64) * 4));
+      }
       f32x4 z, g; u32x2 hp;
       product(w1a, w1b, F, H1, z, [&] {
         if constexpr (c == 0) { if (t > 0) pend_issue(p.out_b + (size_t)t * slot, HD * 2, row0 + RC, B, lds + (size_t)(1 * 3 + 0) * OPB, PA, olane, wave, member, local); }
         else pend_issue(p.hsb[0] + (size_t)(t + 1) * slot, HD * 2, row0, B, lds + (size_t)(0 * 3 + 1) * OPB, PA, olane, wave, member, local);
       });
+      if constexpr (DEC) {
+        if (t > 0) {
+          wait_vm<4>();                                              // everything older than the four operand fetches above: the token fetch among it
+          const unsigned want = (p.epoch * 4096u + (unsigned)t) & 0xFFFFFFu;
+          unsigned tk = tokst[(c * 4 + wave) * 64 + olane];
+          if (__any((tk >> 8) != want)) {
+            int spins = 0;
+#pragma nounroll
+            while (true) {
+              asm volatile("" : "+v"(spins));
+              if (++spins > DC_SPIN_LIMIT) { if (olane == 0) { atomicExch(p.err, 17); s_dead = 1; } break; }
+              __builtin_amdgcn_s_sleep(1);
+              ld4_sc1(tk, (unsigned)((RC * c + (olane & 15)) * 4), p.tokx + (size_t)group * 32, local);
+              wait_vm<0>();
+              asm volatile("" : "+v"(tk));
+              if (!__any((tk >> 8) != want)) break;
+            }
+          }
+          tokc[c] = (int)(tk & 0xFFu);
+          // Every row of the group has emitted EOS (or PAD): from here on each step selects PAD at no cost (model.lua:448-449), so the labels of
+          // the remaining steps are PAD and the scores final.  Every wave of every member sees the same 32 tokens: all leave together (behind P1<1>).
+          const bool done = tokc[c] == 1 || tokc[c] == 3 || rb + (olane & 15) >= B;
+          const bool fin = __ballot(done) == ~0ull;
+          if constexpr (c == 0) fin0 = fin; else { if (fin0 && fin && !p.no_early) t_exit = t; }
+        }
+        const int zrow = min(max(tokc[c], 1), p.V) - 1;             // (clamped: a corrupted token must not become a wild address)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) z[i] += zxs[(c * 5 + i) * 256 + ot];
+        for (int i = 0; i < 4; ++i) z[i] += ztab[zrow * 64 + i * 16 + 4 * wave + oq];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] += zxs[(c * 5 + i) * 256 + ot];
+      }
       cell(z, c1[c], g, hp);
       const int row = rb + oc16; const bool ok = row < B;
       pst8(oq == 0 && ok ? (void*)(p.hsb[0] + (size_t)(t + 1) * slot + (size_t)row * HD + 16 * member + 4 * wave) : (void*)otrash, hp, local);
@@ -325,7 +382,7 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       else { if (mych == 0) pend_land<2>(p.hsb[1] + (size_t)(t + 1) * slot, HD * 2, rb, B, H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]);      // behind P3<0>
              else pend_land<0>(p.hsb[1] + (size_t)(t + 1) * slot, HD * 2, rb, B, H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]); }
       CH_STAMP(12 + c);
-      {                                                             // zx1 of the next step (LDS-DMA, older than the prefetch below: complete by the next counted wait)
+      if constexpr (!DEC) {                                         // zx1 of the next step (LDS-DMA, older than the prefetch below: complete by the next counted wait)
         const int tn = min(t + 1, L - 1);
         const int row = min(rb + oc16, B - 1);
         const int ntok = reinterpret_cast<const int*>(zxs)[(c * 5 + 4) * 256 + ot];
@@ -428,7 +485,7 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       const int rb = row0 + RC * c;
       if constexpr (c == 0) { if (mych == 1) pend_land<2>(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, rb, B, F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]);      // behind P3<1>
                               else pend_land<0>(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, rb, B, F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]); }
-      else pend_land<2>(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, rb, B, F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]);                                          // behind P4<0>
+      else pend_land<(DEC ? 5 : 2)>(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, rb, B, F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]);                              // behind P4<0> (DEC: + 3 partial logits)
       CH_STAMP(14 + c);
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       const unsigned char* src = (wave < 2 ? F : H2) + (256 * (wave & 1) + 8 * q) * 2 + (size_t)c16 * PA;   // k = 256 wave + 32 s: waves 0, 1 read c, waves 2, 3 read h2
@@ -451,13 +508,94 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       const size_t o = (size_t)(t + 1) * slot + (size_t)row * HD + 16 * member + 4 * oq;
       pst8(ok ? (void*)(p.out_b + o) : (void*)otrash, u32x2{sane(bfpair(v[0], v[1])), sane(bfpair(v[2], v[3]))}, local);
       st16f(ok ? (void*)(p.out + o) : (void*)otrash, v);
+      if constexpr (DEC) {
+        // projector (output_projector.lua:3-8) on fp32 out: this member's 16 units against its slice of W_o -> 16 rows x V partial logits, to the rows' owners
+        if (wave == 0) *reinterpret_cast<f32x4*>(outs + c * 256 + c16 * 16 + 4 * q) = v;
+        lds_barrier();
+        const int r = ot >> 4, j = ot & 15;
+        float o16[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) o16[u] = outs[c * 256 + r * 16 + u];
+        float* const pp = p.pbuf + (size_t)(t & 1) * ppar + ((size_t)group * 32 + RC * c + r) * 32 * 40 + (size_t)member * 40;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int vv = j + 16 * k;
+          float a = 0.f;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) a = fmaf(wos[min(vv, 39) * 16 + u], o16[u], a);
+          pst4(vv < 40 ? (void*)(pp + vv) : (void*)otrash, sane(__builtin_bit_cast(unsigned, a)), local);
+        }
+      }
+    };
+    // =================== P5 (greedy decode): LogSoftMax + selection of row `member` by wave 0 of its owner (project_select_kernel at beam 1; model.lua:376-536)
+    auto P5 = [&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      if (mych != c || wave != 0) return;
+      const int V = p.V;
+      float* const base = pown + (size_t)(t & 1) * ppar; const unsigned lo = (unsigned)(olane < V ? olane : 0) * 4u;
+      float pv[32];
+      int spins = 0;
+#pragma nounroll
+      while (true) {
+#pragma unroll
+        for (int sm = 0; sm < 32; ++sm) { unsigned u_; ld4_sc1(u_, (unsigned)(sm * 160) + lo, base, local); pv[sm] = __builtin_bit_cast(float, u_); }
+        wait_vm<0>();
+        unsigned mx = 0;
+#pragma unroll
+        for (int sm = 0; sm < 32; ++sm) { asm volatile("" : "+v"(pv[sm])); mx = max(mx, __builtin_bit_cast(unsigned, pv[sm])); }
+        if (!__any(mx == SENT)) break;
+        asm volatile("" : "+v"(spins));
+        if (++spins > DC_SPIN_LIMIT) { if (olane == 0) { atomicExch(p.err, 16); s_dead = 1; } break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      float x = -INFINITY;
+      if (olane < V) {
+        x = p.bo[olane];
+#pragma unroll
+        for (int sm = 0; sm < 32; ++sm) x += pv[sm];
+      }
+      const float mxv = wave_reduce(x, -INFINITY, [](float a, float b) { return fmaxf(a, b); });
+      const float sum = wave_reduce(olane < V ? expf(x - mxv) : 0.f, 0.f, [](float a, float b) { return a + b; });
+      float lp = olane < V ? x - (mxv + logf(sum)) : -INFINITY;
+      if (t > 0) {
+        if (olane == 0 && (prev_tok == 1 || prev_tok == 3)) lp = 0.f;          // model.lua:448-449: after PAD / EOS only PAD, at no cost
+        lp += score;                                                          // model.lua:450
+      }
+      unsigned long long tmask = 0;                                            // -use_dictionary: only tokens that continue the row's trie node (model.lua:413,469)
+      if (p.trie_mask) {
+        tmask = p.trie_mask[node];
+        const bool okt = (t > 0 && olane == 0) || ((tmask >> olane) & 1ull);    // PAD is always admissible after the first step
+        if (olane < V && !okt) lp = -INFINITY;
+      }
+      const float best = wave_reduce(lp, -INFINITY, [](float a, float b) { return fmaxf(a, b); });
+      const unsigned long long tie = __ballot(lp == best && olane < V);        // descending score, ties -> lowest index
+      const int bi = tie ? __ffsll((long long)tie) - 1 : 0;
+      score = best; prev_tok = bi + 1;
+      if (p.trie_mask && !(t > 0 && bi == 0) && ((tmask >> bi) & 1ull))        // trie_next: PAD keeps the node (model.lua:502-503)
+        node = p.trie_child[p.trie_base[node] + __popcll(tmask & ((1ull << bi) - 1ull))];
+      if (olane == 0) {
+        if (rvalid) { p.labels[(size_t)arow * p.tok0_stride + t] = bi + 1; if (t == L - 1) p.scores[arow] = best; }
+        pst4(p.tokx + (size_t)group * 32 + member, (((p.epoch * 4096u + (unsigned)(t + 1)) & 0xFFFFFFu) << 8) | (unsigned)(bi + 1), local);
+      }
+      // this parity's row is read: unwritten again for step t + 2 (in memory long before its writers get there: they need this step's token first)
+      unsigned sv = SENT; asm volatile("" : "+v"(sv));
+#pragma unroll
+      for (int k = 0; k < 5; ++k) pst16(pown + (size_t)(t & 1) * ppar + (k * 64 + olane) * 4, u32x4{sv, sv, sv, sv}, local);
     };
 
     P1(IC<0>{}); CH_STAMP(0); P1(IC<1>{}); CH_STAMP(1); if (s_dead) { dead = true; break; }
+    if constexpr (DEC) { if (t_exit >= 0) break; }                   // (the PAD labels / final scores are written behind the loop)
     P2(IC<0>{}); CH_STAMP(2); P2(IC<1>{}); CH_STAMP(3); if (s_dead) { dead = true; break; }
     P3(IC<0>{}); CH_STAMP(4); P3(IC<1>{}); CH_STAMP(5); if (s_dead) { dead = true; break; }
     P4(IC<0>{}); CH_STAMP(6); P4(IC<1>{}); CH_STAMP(7); if (s_dead) { dead = true; break; }
     prefill(t + 2, ot, local);
+    if constexpr (DEC) { P5(IC<0>{}); P5(IC<1>{}); }
+  }
+  if constexpr (DEC) {
+    if (t_exit >= 0 && wave == 0 && lane == 0 && rvalid) {
+      for (int tt = t_exit; tt < L; ++tt) p.labels[(size_t)arow * p.tok0_stride + tt] = 1;
+      p.scores[arow] = score;
+    }
   }
   wait_vm<0>();
 #ifdef DC_DEBUG_STAMPS
@@ -932,17 +1070,24 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
 // ---------------------------------------------------------------------------------------------
 bool dec_chain_enabled() { const char* e = getenv("AOCR_NO_DEC_CHAINS"); return !(e && e[0] == '1'); }
 
-void dec_chain_forward(hipStream_t s, const DecClFwdArgs& a0) {
+void dec_chain_forward(hipStream_t s, const DecClFwdArgs& a0, bool greedy_decode) {
   static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
   const int groups = (a0.B + R - 1) / R, per_pass = std::max(8, cus / (8 * NM) * 8);
   (void)hipFuncSetAttribute((const void*)dec_ch_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_FWD_LDS);
   (void)hipFuncSetAttribute((const void*)dec_ch_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_FWD_LDS);
+  (void)hipFuncSetAttribute((const void*)dec_ch_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_DEC_LDS);
+  (void)hipFuncSetAttribute((const void*)dec_ch_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_DEC_LDS);
   const bool res = a0.T <= 64 && !getenv("AOCR_CH_NO_RES");
   for (int g0 = 0; g0 < groups; g0 += per_pass) {
     DecClFwdArgs a = a0; a.group0 = g0; a.ngroups = std::min(per_pass, groups - g0); a.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;
     a.stamps = getenv("AOCR_DC_STAMPS") ? a.xtab + (size_t)groups * NM : nullptr;
-    if (res) hipLaunchKernelGGL((dec_ch_fwd_kernel<false, true>), dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), (size_t)CH_FWD_LDS, s, a);
-    else hipLaunchKernelGGL((dec_ch_fwd_kernel<false, false>), dim3(8 * NM * ((a.ngroups + 7) / 8)), dim3(256), (size_t)CH_FWD_LDS, s, a);
+    const dim3 grid(8 * NM * ((a.ngroups + 7) / 8));
+    if (greedy_decode) {
+      a.pgroups = groups; a.tokx = reinterpret_cast<unsigned*>(a.pbuf + (size_t)2 * groups * 32 * 32 * 40); a.no_early = getenv("AOCR_NO_DEC_EARLY") != nullptr;
+      if (res) hipLaunchKernelGGL((dec_ch_fwd_kernel<true, true>), grid, dim3(256), (size_t)CH_DEC_LDS, s, a);
+      else hipLaunchKernelGGL((dec_ch_fwd_kernel<true, false>), grid, dim3(256), (size_t)CH_DEC_LDS, s, a);
+    } else if (res) hipLaunchKernelGGL((dec_ch_fwd_kernel<false, true>), grid, dim3(256), (size_t)CH_FWD_LDS, s, a);
+    else hipLaunchKernelGGL((dec_ch_fwd_kernel<false, false>), grid, dim3(256), (size_t)CH_FWD_LDS, s, a);
   }
 }
 

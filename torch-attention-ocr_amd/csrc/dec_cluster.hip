@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256, 1) void dec_cl_bwd_kernel(DecClBwdArgs p) {
 
 // ---------------------------------------------------------------------------------------------
 size_t dec_cluster_xbuf_bytes(int B) { return (size_t)((B + R - 1) / R) * 5 * NM * 128 * sizeof(unsigned) + 256; }
-size_t dec_cluster_pbuf_bytes(int B) { return (size_t)((B + R - 1) / R) * (32 * 32 * 40 + 32) * sizeof(float) + 256; }   // partial logits + tokens (greedy decode)
+size_t dec_cluster_pbuf_bytes(int B) { return (size_t)((B + R - 1) / R) * (2 * 32 * 32 * 40 + 32) * sizeof(float) + 256; }   // (two step parities for dec_chain.hip)   // partial logits + tokens (greedy decode)
 size_t dec_cluster_xtab_bytes(int B) { return (size_t)((B + R - 1) / R) * NM * sizeof(u64) + 512; }   // + two debugging stamp areas
 bool dec_cluster_supported(int Hd, int Ld, int input_feed, int T, int L, int cus) { return Hd == HD && Ld == 2 && input_feed && T >= 1 && T <= 256 && L + 2 < 1024 && cus >= 8 * NM; }
 
@@ -993,7 +993,7 @@ void dec_cluster_backward(hipStream_t s, const DecClBwdArgs& a0) {
 }
 
 void dec_cluster_forward(hipStream_t s, const DecClFwdArgs& a0, bool greedy_decode) {
-  if (!greedy_decode && a0.drop_h.thr == 0 && a0.drop_out.thr == 0 && dec_chain_enabled()) { dec_chain_forward(s, a0); return; }      // round 5: two chains per group, tag-free exchange
+  if (a0.drop_h.thr == 0 && a0.drop_out.thr == 0 && dec_chain_enabled() && !(greedy_decode && getenv("AOCR_NO_DEC_CHAINS_GREEDY"))) { dec_chain_forward(s, a0, greedy_decode); return; }      // round 5: two chains per group, tag-free exchange
   static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
   const int groups = (a0.B + R - 1) / R, per_pass = std::max(8, cus / (8 * NM) * 8);
   const size_t lds = LDS_BYTES;

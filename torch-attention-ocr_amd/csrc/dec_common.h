@@ -7,7 +7,7 @@ namespace aocr {
 
 // two-chain, tag-free-exchange form of the decoder kernels (dec_chain.hip); AOCR_NO_DEC_CHAINS=1 keeps dec_cluster.hip's kernels
 bool dec_chain_enabled();
-void dec_chain_forward(hipStream_t s, const DecClFwdArgs& a);
+void dec_chain_forward(hipStream_t s, const DecClFwdArgs& a, bool greedy_decode = false);
 void dec_chain_backward(hipStream_t s, const DecClBwdArgs& a);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

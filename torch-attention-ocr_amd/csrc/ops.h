@@ -267,7 +267,7 @@ struct DecClFwdArgs {
   unsigned long long *xbuf, *xtab; int* err; unsigned long long* stamps = nullptr;
   // greedy decode (the kernel's DEC variant): zx1 is the per-token table [V][4 Hd]; tok0 = the GO tokens (row stride tok0_stride = the label width)
   const int32_t* tok0 = nullptr; int tok0_stride = 0; const float *wo = nullptr, *bo = nullptr; int V = 0;
-  float* pbuf = nullptr; unsigned* tokx = nullptr; int32_t* labels = nullptr; float* scores = nullptr;
+  float* pbuf = nullptr; unsigned* tokx = nullptr; int32_t* labels = nullptr; float* scores = nullptr; int pgroups = 0;   /* dec_chain.hip: groups of the whole batch (the partial logits are kept per step parity) */
   const unsigned long long* trie_mask = nullptr; const int32_t* trie_base = nullptr; const int32_t* trie_child = nullptr;   // -use_dictionary (flat trie of include/aocr.h) or null
   // nn.Dropout(p) (training, LSTM.lua:68-69,116-118): masks of layer 2's input (site 2) and of the attention output (site 16), flat index
   // = step * B * Hd + row * Hd + unit added to .off = 0; hm_b [L][B][Hd]: the masked bf16 copy of h1 (operand of layer 2 and of its weight gradient)
