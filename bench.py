@@ -476,7 +476,11 @@ def main():
                  8: ("splitk_reduce_kernel", "sum of conv6's 8 split-K filter-gradient slabs (fp32) into the gradient")}
         hbm_kernels = {}
         for kid, (kname, what) in names.items():
-            ms_k, by = m.profile_kernel(kid, 20)
+            try:
+                ms_k, by = m.profile_kernel(kid, 20)
+            except Exception as e_:                       # a replay that does not exist at this workload's shape (aocr_profile_kernel refuses it): say so, keep the line
+                hbm_kernels[kname] = {"skipped": str(e_)[:200]}
+                continue
             gbps = by / (ms_k * 1e-3) / 1e9
             hbm_kernels[kname] = {"us_per_launch": 1e3 * ms_k, "algorithmic_MB": by / 1e6, "GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS,
                                   "frac_of_6.3TBps_achievable": gbps / 6300.0, "what": what}

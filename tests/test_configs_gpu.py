@@ -78,9 +78,13 @@ def test_reference_default_he512_fp32_vs_oracle(cuda):
     m.shutdown()
 
 
-@pytest.mark.parametrize("B", [16, 48])
-def test_reference_default_he512_bf16_vs_oracle(cuda, B):
-    """The same shape through the production bf16 dispatch (whole-sequence encoder kernels at He = 512, B % 16 == 0)."""
+@pytest.mark.parametrize("B,big", [(16, False), (48, False), (48, True)])
+def test_reference_default_he512_bf16_vs_oracle(cuda, monkeypatch, B, big):
+    """The same shape through the production bf16 dispatch (whole-sequence encoder kernels at He = 512, B % 16 == 0).
+    big: the large-batch route of the decoder's step products (round 5: 128 x 128 LDS-DMA tiles over [x0 | x1] x [W0 | W1] + an elementwise cell pass --
+    an opt-in route, AOCR_BIG_STEP=1: measured slower than the step kernels at the reference's default batch of 400, see ops_gemm.hip) forced at this batch, against the same oracle bounds."""
+    if big:
+        monkeypatch.setenv("AOCR_BIG_STEP", "1"); monkeypatch.setenv("AOCR_BIG_STEP_MIN_ROWS", "16")
     m, O, ocfg, P, st, batch = make(REF_DEFAULT, B=B, W=100, maxlen=9, compute="bf16", max_decoder_l=12, max_beam=1)
     img, tgt, tge = tensors(batch)
     loss_ref, G, aux, _ = O.train_step_manual(P, st, ocfg, img, tgt, tge)

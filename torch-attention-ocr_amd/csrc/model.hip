@@ -236,6 +236,9 @@ static bool hh_ok(const LoadKh2* ah, int nz, int ncols) {        // staged kerne
 static void run_gates_fwd(aocr_model* m, int nz, const LoadK* a, const ShW* const* w0, const ShW* const* w1, const EpGatesFwd* ep,
                           int M, int H, const LoadKh2* ah = nullptr) {
   if (m->bf16 && hh_ok(ah, nz, H)) {
+    // large batch (the reference's default shape): tiled GEMM into a scratch z + elementwise cell pass (ops_gemm.hip: big_step_gates_fwd); scratch = the
+    // d z buffer of layer 0, which only the backward pass uses
+    if (nz == 1 && big_step_gates_fwd(m->s, ah[0], bnt_h(w0[0], w1[0]), ep[0], M, H, m->ddz[0], (size_t)m->cfg.max_decoder_l * m->cfg.batch_size * 4 * m->Hd)) return;
     GatesFwdArgsHH z[2];
     for (int i = 0; i < nz; ++i) { z[i].a = ah[i]; z[i].b = bnt_h(w0[i], w1[i]); z[i].ep = ep[i]; z[i].K = ah[i].K; }
     launch_small_gates_fwd_hh(m->s, nz, z, M, H);
@@ -251,13 +254,13 @@ static void run_gates_fwd(aocr_model* m, int nz, const LoadK* a, const ShW* cons
 }
 // y = x W^T through an EpStore
 static void run_store_nt(aocr_model* m, const LoadK& a, const ShW& w, const EpStore& ep, int M, const LoadKh2* ah = nullptr) {
-  if (m->bf16 && hh_ok(ah, 1, w.R)) { SmallArgsHH z; z.a = *ah; z.b = bnt_h(&w, nullptr); z.ep = ep; z.K = ah->K; launch_small_hh(m->s, 1, &z, M, w.R); }
+  if (m->bf16 && hh_ok(ah, 1, w.R)) { if (big_step_store(m->s, *ah, bnt_h(&w, nullptr), ep, M, w.R)) return; SmallArgsHH z; z.a = *ah; z.b = bnt_h(&w, nullptr); z.ep = ep; z.K = ah->K; launch_small_hh(m->s, 1, &z, M, w.R); }
   else if (m->bf16) { SmallArgsH z; z.a = a; z.b = bnt_h(&w, nullptr); z.ep = ep; z.K = a.K; launch_small_h(m->s, 1, &z, M, w.R); }
   else { SmallKKArgs z; z.a = a; z.b = bnt_f(&w, nullptr); z.ep = ep; z.K = a.K; launch_small_kk(m->s, false, 1, &z, M, w.R); }
 }
 // y = x W through an EpStore (x is [M][R], y is [M][C])
 static void run_store_nn(aocr_model* m, const LoadK& a, const ShW& w, const EpStore& ep, int M, const LoadKh2* ah = nullptr) {
-  if (m->bf16 && hh_ok(ah, 1, w.C)) { SmallArgsHH z; z.a = *ah; z.b = make_loadkh(w.wtb, w.R, w.C, w.R); z.ep = ep; z.K = ah->K; launch_small_hh(m->s, 1, &z, M, w.C); }
+  if (m->bf16 && hh_ok(ah, 1, w.C)) { if (big_step_store(m->s, *ah, make_loadkh(w.wtb, w.R, w.C, w.R), ep, M, w.C)) return; SmallArgsHH z; z.a = *ah; z.b = make_loadkh(w.wtb, w.R, w.C, w.R); z.ep = ep; z.K = ah->K; launch_small_hh(m->s, 1, &z, M, w.C); }
   else if (m->bf16) { SmallArgsH z; z.a = a; z.b = make_loadkh(w.wtb, w.R, w.C, w.R); z.ep = ep; z.K = a.K; launch_small_h(m->s, 1, &z, M, w.C); }
   else if (w.wtf) { SmallKKArgs z; z.a = a; z.b = make_loadk(w.wtf, w.R, w.C, w.R); z.ep = ep; z.K = a.K; launch_small_kk(m->s, false, 1, &z, M, w.C); }
   else { SmallKMNArgs z; z.a = a; z.b = make_loadmn(w.w, w.ld, w.C, a.K); z.ep = ep; z.K = a.K; launch_small_kmn(m->s, false, 1, &z, M, w.C); }

@@ -60,6 +60,9 @@ typedef SmallArgs<LoadKh2, LoadKh2, EpGatesFwd> GatesFwdArgsHH;    // A read fro
 typedef SmallArgs<LoadKh2, LoadKh2, EpStore> SmallArgsHH;
 typedef SmallArgs<LoadKh2, LoadKh2, EpGatesBwd> GatesBwdArgsHH;
 void launch_small_gates_fwd_hh(hipStream_t s, int nz, const GatesFwdArgsHH* z, int M, int H);
+// recurrent-step products at large batch (>= 320 rows, >= 1024 columns): 128 x 128 LDS-DMA tiles + an elementwise cell pass; false: shape not taken (ops_gemm.hip)
+bool big_step_store(hipStream_t s, const LoadKh2& a, const LoadKh2& b, const EpStore& ep, int M, int N);
+bool big_step_gates_fwd(hipStream_t s, const LoadKh2& a, const LoadKh2& b, const EpGatesFwd& ep, int M, int H, float* zbuf, size_t zbuf_floats);
 void launch_small_hh(hipStream_t s, int nz, const SmallArgsHH* z, int M, int N);
 void launch_small_gates_bwd_hh(hipStream_t s, int nz, const GatesBwdArgsHH* z, int M, int H);
 void launch_small_gates_fwd_h(hipStream_t s, int nz, const GatesFwdArgsH* z, int M, int H);

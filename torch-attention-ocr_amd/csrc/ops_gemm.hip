@@ -340,6 +340,42 @@ static void launch_small_bf16_hh(hipStream_t s, int nz, const ARGS* z, int M, in
   }
   hipLaunchKernelGGL((gemm_step_kernel<NT, GATES ? 1 : 0, decltype(z[0].a), decltype(z[0].ep)>), grid, dim3(256), 0, s, zz, gate_stride);
 }
+// ---- recurrent-step products at LARGE batch (round 5; the reference's default shape: 400 rows, Hd = 1024).  The step kernels above are built for latency at 32-256
+// rows: 32-row tiles, every workgroup streams its own weight slice -- at 400 rows a gate launch re-reads its 16 MB of weights 13 times (41.5 us for 6.7 GFLOP =
+// 0.06 of the MFMA peak, 18 % of that workload's step).  Here: 128 x 128 tiles on the LDS-DMA ring over the concatenated K range [x0 | x1] x [W0 | W1], fp32 tile
+// out; the LSTM cell then runs as its own elementwise pass (gates_elem_fwd_kernel) on the SAME epilogue object (EpGatesFwd::elem), so every option of the
+// fused epilogue (token table, dropout, shadows, saved gates) is the one code path.
+static LoadKhCat cat_of(const LoadKh2& a) {
+  LoadKhCat c; c.p0 = a.p0; c.ld0 = a.ld0; c.rows = a.rows; c.K = a.K;
+  if (a.p1) { c.p1 = a.p1; c.ld1 = a.ld1; c.K0 = a.K0; } else { c.p1 = a.p0; c.ld1 = a.ld0; c.K0 = a.K; }
+  return c;
+}
+bool big_step_eligible(int M, int N, int K) {
+  const char* const e = getenv("AOCR_BIG_STEP_MIN_ROWS"); const int min_rows = e ? atoi(e) : 320;       // (read per call, like every dispatch switch) C3 / C4 launch-chain fallbacks (<= 256 rows) stay on the step kernels
+  // MEASURED SLOWER, so opt-in (AOCR_BIG_STEP=1; tests/test_configs_gpu.py keeps its oracle test): at 400 rows x Hd = 1024 the 128 x 128 grid is 128 workgroups of 64 K steps, and
+  // a workgroup's L2 -> LDS stream sustains ~32 GB/s (1 MB of operands in 32 us): gate product 32 us + 7 us for the cell pass against 41.5 us fused in the step kernel, the
+  // N = 1024 products 19-25 us against 17 -- decoder 5.06 -> 5.82 ms per step of the reference-default workload.  Both forms are bound by what one compute unit pulls from L2.
+  return env_is_1("AOCR_BIG_STEP") && M >= min_rows && N >= 1024 && dma128_eligible(M, N, K, 32);
+}
+bool big_step_store(hipStream_t s, const LoadKh2& a, const LoadKh2& b, const EpStore& ep, int M, int N) {
+  if (!big_step_eligible(M, N, a.K) || (a.p1 && a.K0 % 32) || (b.p1 && b.K0 % 32) || (a.p1 != nullptr) != (b.p1 != nullptr) || (a.p1 && a.K0 != b.K0)) return false;
+  launch_dma128(s, cat_of(a), cat_of(b), ep, M, N, a.K);
+  return true;
+}
+__global__ __launch_bounds__(256) void gates_elem_fwd_kernel(const float* __restrict__ z, int64_t ldz, EpGatesFwd ep) {
+  const int j = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+  if (j >= ep.H) return;
+  const EpGatesFwd::Pre pre = ep.prefetch(row, j);
+  float v[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) v[g] = z[(int64_t)row * ldz + (int64_t)g * ep.H + j];
+  ep.elem<4>(row, j, 0, v, pre);
+}
+bool big_step_gates_fwd(hipStream_t s, const LoadKh2& a, const LoadKh2& b, const EpGatesFwd& ep, int M, int H, float* zbuf, size_t zbuf_floats) {
+  if (!zbuf || zbuf_floats < (size_t)M * 4 * H || !big_step_store(s, a, b, make_store(zbuf, 4 * H, M, 4 * H, nullptr, nullptr, 0), M, 4 * H)) return false;
+  hipLaunchKernelGGL(gates_elem_fwd_kernel, dim3(cdiv(H, 256), M), dim3(256), 0, s, zbuf, (int64_t)4 * H, ep);
+  return true;
+}
 void launch_small_gates_fwd_hh(hipStream_t s, int nz, const GatesFwdArgsHH* z, int M, int H) { launch_small_bf16_hh<4, true>(s, nz, z, M, H, H); }
 void launch_small_hh(hipStream_t s, int nz, const SmallArgsHH* z, int M, int N) { launch_small_bf16_hh<1, false>(s, nz, z, M, N, 0); }
 void launch_small_gates_bwd_hh(hipStream_t s, int nz, const GatesBwdArgsHH* z, int M, int H) { launch_small_bf16_hh<1, false>(s, nz, z, M, H, 0); }
