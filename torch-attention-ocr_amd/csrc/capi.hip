@@ -162,6 +162,9 @@ int aocr_model_destroy(aocr_model* m) {
   if (m && m->tab_done) hipEventDestroy(m->tab_done);
   if (m && m->zero_done) hipEventDestroy(m->zero_done);
   if (m && m->shadow_done) hipEventDestroy(m->shadow_done);
+  if (m && m->shadow2_done) hipEventDestroy(m->shadow2_done);
+  if (m && m->q_go) hipEventDestroy(m->q_go);
+  if (m && m->q_done) hipEventDestroy(m->q_done);
   if (m && m->enc_ev) hipEventDestroy(m->enc_ev);
   if (m) for (hipEvent_t e : m->prof_ev) hipEventDestroy(e);
   if (m) for (hipStream_t ls : m->lay_s) if (ls) { hipStreamSynchronize(ls); hipStreamDestroy(ls); }

@@ -84,7 +84,9 @@ struct aocr_model {
   // token sort, "the last teacher-forced forward read zx1 from the table", "this API call already has an up-to-date table"
   float* emb_seg = nullptr; int* emb_index = nullptr; bool emb_table = false, tab_valid = false;
   // step_prologue (start of a training step): table / gradient zeroing / weight shadows enqueued on the side stream, and the events the model's stream waits for
-  hipEvent_t tab_done = nullptr, zero_done = nullptr, shadow_done = nullptr; bool tab_ready = false, zero_pending = false, shadow_pending = false;
+  hipEvent_t tab_done = nullptr, zero_done = nullptr, shadow_done = nullptr, shadow2_done = nullptr; bool tab_ready = false, zero_pending = false, shadow_pending = false, shadow2_pending = false;   // shadow2: conv2's taps (the head of the job table), an event of their own
+  int shadow_tiles_conv2 = 0;
+  hipEvent_t q_go = nullptr, q_done = nullptr; bool q_pending = false;     // q = W_a h_top of all steps on the side stream (decoder_tf_forward -> decoder_backward)
   hipEvent_t enc_ev = nullptr;   // end of an encoder layer's BPTT: its weight gradients start behind it on the side stream (encoder_backward)
   float *emb_all, *zx1_all, *dhs[aocr::MAXL], *dcs[aocr::MAXL], *dgates[aocr::MAXL], *ddz[aocr::MAXL];
   float *out_all, *cat_all, *q_all, *a_all, *logits, *dlogits, *nll_rows;

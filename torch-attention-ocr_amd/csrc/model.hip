@@ -200,16 +200,19 @@ void build_shadow_jobs(aocr_model* m) {
     m->shadow_host.push_back(j);
   };
   auto up = [&](const ShW& w) { if (w.wb) add(w.w, w.wb, w.wtb, w.ld, w.C, w.R, w.R, w.C); };
-  for (int dir = 0; dir < 2; ++dir) for (int l = 0; l < m->Le; ++l) { up(m->enc[dir][l].swh); up(m->enc[dir][l].swi); }
-  for (int l = 0; l < m->Ld; ++l) { if (l > 0 || m->cfg.input_feed) up(m->dec[l].swi); up(m->dec[l].swh); }
-  up(m->swa); up(m->swc);
-  for (int i = 2; i <= 7; ++i) {
+  auto conv_jobs = [&](int i) {
     const ConvP& c = m->conv[i]; const int KK = c.ks * c.ks;
     for (int tap = 0; tap < KK; ++tap)
       add(c.w + (size_t)tap * c.cin, m->wb[i] + (size_t)tap * c.cin, m->wtb[i] + (size_t)tap * c.cout, (int64_t)KK * c.cin,
           (int64_t)KK * c.cin, (int64_t)KK * c.cout, c.cout, c.cin);
-  }
-  if (m->shadow_host.size() > 128) { m->shadow_host.clear(); m->shadow_tiles = 0; }      // table too small: per-matrix launches
+  };
+  conv_jobs(2);                                                  // conv2's taps FIRST: the step launches them on their own (step_prologue) so that conv2 can start behind conv1
+  m->shadow_tiles_conv2 = m->shadow_tiles;
+  for (int dir = 0; dir < 2; ++dir) for (int l = 0; l < m->Le; ++l) { up(m->enc[dir][l].swh); up(m->enc[dir][l].swi); }
+  for (int l = 0; l < m->Ld; ++l) { if (l > 0 || m->cfg.input_feed) up(m->dec[l].swi); up(m->dec[l].swh); }
+  up(m->swa); up(m->swc);
+  for (int i = 3; i <= 7; ++i) conv_jobs(i);
+  if (m->shadow_host.size() > 128) { m->shadow_host.clear(); m->shadow_tiles = 0; m->shadow_tiles_conv2 = 0; }      // table too small: per-matrix launches
 }
 static void refresh_rnn_shadows(aocr_model* m, hipStream_t st = nullptr) {
   if (!st) st = m->s;
@@ -330,8 +333,10 @@ void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training
   // bf16 mode: the pooled conv outputs exist only as bf16 shadows (every consumer -- next conv, filter gradient, ReLU mask of the
   // un-pool -- reads the shadow; aocr_get_tensor materialises fp32 on demand)
   prof_mark(m, AOCR_PROF_POOL_CONV1); conv1_forward(s, images, m->conv[1].w, m->conv[1].b, bf ? nullptr : m->A1, B, d.H, d.W, m->A1b);
-  if (m->shadow_pending) { hipStreamWaitEvent(s, m->shadow_done, 0); m->shadow_pending = false; }       // conv1 reads no shadow; everything below does
+  if (m->shadow_pending && m->shadow2_pending) { hipStreamWaitEvent(s, m->shadow2_done, 0); m->shadow2_pending = false; }       // conv1 reads no shadow; conv2 reads its own taps (the first part of the table)
+  else if (m->shadow_pending) { hipStreamWaitEvent(s, m->shadow_done, 0); m->shadow_pending = false; }
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A1, m->conv[2].w, m->conv[2].b, bf ? nullptr : m->A2, m->idx2, B, d.H1, d.W1, 64, 128, 3, 1, 1, 1, m->A1b, m->wb[2], m->A2b);
+  if (m->shadow_pending) { hipStreamWaitEvent(s, m->shadow_done, 0); m->shadow_pending = false; }       // the rest of the table (conv3 .. conv7, the recurrent matrices): refreshed under conv2
   // evaluation mode, bf16: BatchNorm + ReLU of conv3 / conv5 are a per-channel affine map -> folded into the conv epilogue, which then writes only
   // the bf16 shadow (no fp32 map, no apply pass); conv7's BatchNorm also transposes to (T, B) and stays a pass of its own
   const bool fold = bf && !training && !getenv("AOCR_NO_BN_FOLD");
@@ -931,6 +936,7 @@ static bool dec_cluster_bwd_ok(const aocr_model* m, int T, int L) {
   return dec_cluster_bwd_supported(m->Hd, m->Ld, m->cfg.input_feed, T, L, cus);
 }
 
+static bool side_create(aocr_model* m);
 // teacher-forced decoder loop, model.lua:553-568 (train) / :604-627 (gold pass); the projector (model.lua:560)
 // is hoisted out of the loop: logits for all L steps in one contraction.
 void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_t st, int64_t sb, bool keep_gates) {
@@ -973,8 +979,16 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
     if (drop) { a.drop_h = drop_site(m, 2, 0); a.drop_out = drop_site(m, 16, 0); a.hm_b = m->dhm_b[0]; }     // (.off = the step's offset, added in the kernel)
     dec_cluster_forward(s, a);
     m->dgates_il = true;
-    if (keep_gates)                                                // q = W_a h_top for all L steps: only the backward pass reads it
-      gemm_hh(s, m->dhs_b[1] + slot, Hd, m->swa.wb, Hd, m->q_all, Hd, L * B, Hd, Hd, nullptr, nullptr, 0);
+    if (keep_gates) {                                              // q = W_a h_top for all L steps: only the backward pass reads it (attention_dctx, behind the decoder BPTT)
+      // round 5: on the side stream, beside the projector / loss / d logits launches that follow (small grids: 85 us of mostly idle chip between the two
+      // whole-sequence kernels at C3), joined in front of attention_dctx -- 21 us off the main stream
+      auto ev = [](hipEvent_t& e) { return e || hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
+      if (!m->prof_on && !getenv("AOCR_NO_SIDE_WGRAD") && !env_on("AOCR_NO_Q_SIDE") && side_create(m) && ev(m->q_go) && ev(m->q_done)) {
+        hipEventRecord(m->q_go, s); hipStreamWaitEvent(m->side, m->q_go, 0);
+        gemm_hh(m->side, m->dhs_b[1] + slot, Hd, m->swa.wb, Hd, m->q_all, Hd, L * B, Hd, Hd, nullptr, nullptr, 0);
+        hipEventRecord(m->q_done, m->side); m->q_pending = true;
+      } else gemm_hh(s, m->dhs_b[1] + slot, Hd, m->swa.wb, Hd, m->q_all, Hd, L * B, Hd, Hd, nullptr, nullptr, 0);
+    }
   } else
   for (int t = 0; t < L; ++t) {
     DecStepIO io; io.R = B; io.ctx_div = 1;
@@ -1049,7 +1063,7 @@ static bool side_create(aocr_model* m) {
 // bf16 weight shadows (100 MB of traffic), the token table -- goes to the side stream and runs under conv1 (VALU-bound, 40 us) instead of in front
 // of it; cnn_forward waits for the shadows behind conv1, backward_all for the zeroed gradients.  AOCR_NO_SIDE_PROLOGUE=1: everything in line.
 void step_prologue(aocr_model* m, size_t grad_bytes) {             // grad_bytes = 0: a decode call (no gradient vector to zero)
-  m->tab_ready = m->zero_pending = m->shadow_pending = m->tab_valid = false;
+  m->tab_ready = m->zero_pending = m->shadow_pending = m->shadow2_pending = m->tab_valid = false;
   auto ev = [](hipEvent_t& e) { return e || hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
   // (bf16 mode only: in exact-fp32 mode the same move -- gradient zeroing and the 16 per-step weight transposes beside the forward pass -- measured SLOWER, C2 7.52 -> 7.74 ms:
   //  the forward pass there is a chain of ~150 small dependent launches, and the side stream's launches get in their way)
@@ -1060,11 +1074,19 @@ void step_prologue(aocr_model* m, size_t grad_bytes) {             // grad_bytes
     return;
   }
   hipEventRecord(m->side_go, m->s); hipStreamWaitEvent(m->side, m->side_go, 0);       // behind whatever wrote the parameters on the model's stream
-  // snapshot of the running statistics (10 KB): in front of the shadows, which cnn_forward joins before its first BatchNorm layer
-  if (grad_bytes && m->bn_snap) hipMemcpyAsync(m->bn_snap, m->bn_state, bn_bytes, hipMemcpyDeviceToDevice, m->shadow_host.empty() ? m->s : m->side);
+  if (grad_bytes && m->bn_snap && m->shadow_host.empty()) hipMemcpyAsync(m->bn_snap, m->bn_state, bn_bytes, hipMemcpyDeviceToDevice, m->s);
   if (!m->shadow_host.empty()) {
-    shadow_jobs(m->side, m->shadow_dev, (int)m->shadow_host.size(), m->shadow_tiles);
-    hipEventRecord(m->shadow_done, m->side); m->shadow_pending = true;
+    // conv2's taps first, with an event of their own: conv2 starts as soon as conv1 is done (the rest of the table -- 100 MB of traffic -- runs under conv2
+    // and is joined in front of conv3): 25 us off the head of the step at C3, where conv2 waited for the whole table and the cross-stream hand-over
+    const bool split = m->shadow_tiles_conv2 > 0 && ev(m->shadow2_done) && !env_on("AOCR_NO_SHADOW_SPLIT");
+    if (split) {
+      shadow_jobs(m->side, m->shadow_dev, (int)m->shadow_host.size(), m->shadow_tiles_conv2, 0);
+      hipEventRecord(m->shadow2_done, m->side);
+      shadow_jobs(m->side, m->shadow_dev, (int)m->shadow_host.size(), m->shadow_tiles - m->shadow_tiles_conv2, m->shadow_tiles_conv2);
+    } else shadow_jobs(m->side, m->shadow_dev, (int)m->shadow_host.size(), m->shadow_tiles);
+    // snapshot of the running statistics (10 KB; joined with the shadows in front of the first BatchNorm layer, behind conv2's taps so that it delays nothing)
+    if (grad_bytes && m->bn_snap) hipMemcpyAsync(m->bn_snap, m->bn_state, bn_bytes, hipMemcpyDeviceToDevice, m->side);
+    hipEventRecord(m->shadow_done, m->side); m->shadow_pending = true; m->shadow2_pending = split;
   }
   if (grad_bytes) { hipMemsetAsync(m->grads, 0, grad_bytes, m->side); hipEventRecord(m->zero_done, m->side); m->zero_pending = true; }
   if (m->bzx_tab && !env_on("AOCR_NO_EMB_TABLE") && segsum_supported(4 * m->Hd, m->V, m->E)) {
@@ -1092,6 +1114,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   // (the launch chain accumulates into the initial-state gradients; the whole-sequence kernel writes every element of them at its end -- no zeroing launch in front of it)
   if (!cl_bwd) { ZeroList zl; for (int l = 0; l < Ld; ++l) { zl.add(m->dh_rec[l], slot * sizeof(float)); zl.add(m->dc_st[l], slot * sizeof(float)); } zero_many(s, zl); }
   const bool feed_fused = m->cfg.input_feed && Ld <= 2 && !m->drop_on;  // the feed product joins the grouped launch and carries the tanh backward (dropout: the separate d pre kernel knows the mask)
+  if (!cl_bwd && m->q_pending) { hipStreamWaitEvent(s, m->q_done, 0); m->q_pending = false; }      // the launch chain's attention backward reads q step by step
   if (cl_bwd) {     // the whole loop as one launch (dec_cluster.hip); needs the forward cluster kernel's saved state
     DecClBwdArgs a; a.B = B; a.T = T; a.L = L; a.epoch = next_epoch(m);
     a.w2i_t = m->dec[1].swi.wtb; a.w2h_t = m->dec[1].swh.wtb; a.w1h_t = m->dec[0].swh.wtb; a.w1f_t = m->dec[0].swi.wtb;
@@ -1174,6 +1197,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   }
   // d(context), model.lua:652-653 summed over the loop: the ONE result of this pass the encoder BPTT waits for
   prof_mark(m, AOCR_PROF_RNN_GEMM);
+  if (m->q_pending) { hipStreamWaitEvent(s, m->q_done, 0); m->q_pending = false; }          // q of all steps (decoder_tf_forward put the product on the side stream)
   attention_dctx(s, m->a_all, m->ds_all, m->dcat_all, 2 * Hd, m->q_all, m->dctx, L, B, T, Hd);
   // ---- hoisted parameter gradients (accGradParameters of every clone summed over time).  Nothing downstream of them but the
   // optimizer: they run on the side stream beside the encoder BPTT, whose whole-sequence kernel occupies HALF the compute units

@@ -201,7 +201,7 @@ void adadelta_update(hipStream_t s, float* params, float* grads, float* var, flo
                      float* bn_state = nullptr, const float* bn_snap = nullptr, int bn_n = 0);
 // one 2-D piece of the per-step bf16 weight shadow refresh (shadow_jobs_kernel); tile0 = first 32x32 tile of the piece, tx = tiles per row
 struct ShadowJob { const float* w; bf16_t* wb; bf16_t* wtb; int64_t ld, ldb, ldt; int R, C, tile0, tx; };
-void shadow_jobs(hipStream_t s, const ShadowJob* jobs_dev, int njobs, int total_tiles);
+void shadow_jobs(hipStream_t s, const ShadowJob* jobs_dev, int njobs, int total_tiles, int tile_off = 0);      // tiles [tile_off, tile_off + total_tiles) of the table
 // flat dictionary trie + the per-beam node ids of one decode step (mask == nullptr: unconstrained); needs V <= 64
 struct TrieView { const unsigned long long* mask; const int32_t* base; const int32_t* child; const int32_t* loc_in; int32_t* loc_out; };
 void beam_select(hipStream_t s, const float* logp, const int32_t* prev_tok, float* beam_scores, int32_t* tokens,

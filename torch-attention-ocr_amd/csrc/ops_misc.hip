@@ -324,12 +324,13 @@ __global__ __launch_bounds__(256) void weight_shadow_kernel(const float* __restr
 // All bf16 weight shadows of a step in ONE launch: a device-resident job table (built once: the pointers never change) lists
 // 2-D pieces w [R][C] (leading dimension ld) -> wb [R][C] (ldb) and its transpose wtb [C][R] (ldt); a conv weight [Cout][tap][Cin]
 // is one piece per tap (wtb is [Cin][tap][Cout]).  16 separate launches cost ~100 us of dispatch latency for ~20 us of traffic.
-__global__ __launch_bounds__(256) void shadow_jobs_kernel(const ShadowJob* __restrict__ jobs, int njobs) {
+__global__ __launch_bounds__(256) void shadow_jobs_kernel(const ShadowJob* __restrict__ jobs, int njobs, int tile_off) {
   __shared__ float tile[32][33];
+  const int bid = (int)blockIdx.x + tile_off;              // (a step launches the table in two parts: the pieces conv2 needs first, on an event of their own)
   int j = 0, hi = njobs;                                // uniform binary search: last job whose first tile is <= this workgroup's (tile0 ascends)
-  while (hi - j > 1) { const int mid = (j + hi) >> 1; if ((int)blockIdx.x >= jobs[mid].tile0) j = mid; else hi = mid; }
+  while (hi - j > 1) { const int mid = (j + hi) >> 1; if (bid >= jobs[mid].tile0) j = mid; else hi = mid; }
   const ShadowJob J = jobs[j];
-  const int t = blockIdx.x - J.tile0;
+  const int t = bid - J.tile0;
   const int c0 = (t % J.tx) * 32, r0 = (t / J.tx) * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   // 16-byte loads / 8-byte stores when the piece allows it (every matrix of the model does): one load and two stores per thread
   const bool vec = ((J.C | J.R | (int)J.ld | (int)J.ldb | (int)J.ldt) & 3) == 0 && ((reinterpret_cast<uintptr_t>(J.w) & 15) == 0) &&
@@ -368,8 +369,8 @@ __global__ __launch_bounds__(256) void shadow_jobs_kernel(const ShadowJob* __res
     if (r < J.R && c < J.C) J.wtb[(int64_t)c * J.ldt + r] = (bf16_t)tile[tx][i];
   }
 }
-void shadow_jobs(hipStream_t s, const ShadowJob* jobs_dev, int njobs, int total_tiles) {
-  if (njobs > 0) hipLaunchKernelGGL(shadow_jobs_kernel, dim3(total_tiles), dim3(256), 0, s, jobs_dev, njobs);
+void shadow_jobs(hipStream_t s, const ShadowJob* jobs_dev, int njobs, int total_tiles, int tile_off) {
+  if (njobs > 0 && total_tiles > 0) hipLaunchKernelGGL(shadow_jobs_kernel, dim3(total_tiles), dim3(256), 0, s, jobs_dev, njobs, tile_off);
 }
 __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ w, int64_t ld, int R, int C, float* __restrict__ wt) {
   __shared__ float tile[32][33];
