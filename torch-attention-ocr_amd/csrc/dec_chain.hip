@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma16x(p.gates[l] + (((size_t)t * B + row) * HD + u0 + i) * 4, b + 2048 + 1024 * i, true);
   };
-  auto reduce2 = [&](const f32x4 (&acc)[2], f32x4 (&v)[2], auto&& mid, auto&& post) {      // two K-split tiles of a chain -> wave 0 (dec_cluster.hip's order)
+  auto reduce2 = [&](const f32x4 (&acc)[2], f32x4 (&v)[2], auto&& mid, auto&& post, bool release = false) {      // two K-split tiles of a chain -> wave 0 (dec_cluster.hip's order)
 #pragma unroll
     for (int n = 0; n < 2; ++n) *reinterpret_cast<f32x4*>(red + ((size_t)(wave * 2 + n) * 64 + lane) * 4) = acc[n];
     mid();
@@ -748,6 +748,8 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
         for (int w = 1; w < 4; ++w) v[n] += *reinterpret_cast<const f32x4*>(red + ((size_t)(w * 2 + n) * 64 + lane) * 4);
       }
     }
+    // release: the NEXT phase has no landing barrier in front of its products (the d z phases), so its partial tiles could overwrite these before wave 0 has read them
+    if (release) lds_barrier();
   };
   // cell backward of one layer on this lane's 4 units (EpGatesBwd), inputs from the staging buffer
   auto cell_bwd = [&](int buf, const f32x4& dh, f32x4& dcs_, f32x4 (&dz)[4]) {
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb_[8 * hh + s], f.v[s], acc[1], 0, 0, 0);
       }
     }
-    reduce2(acc, v, mid, post);
+    reduce2(acc, v, mid, post, true);
   };
   // d pre of (chain c, step t) from d feed and the staged d out_proj / out: published (bf16) + stored (fp32) by wave 0 -- 2 stores per wave
   auto dpre_publish = [&](int c, int t, int ot, bool from_lds, const f32x4& dpn_, const f32x4& on_, const f32x4& dfeed) {
@@ -911,9 +913,13 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
         }
         f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cxv[s], *reinterpret_cast<const bf16x8*>(hrow + 64 * s), a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cxv[s], *reinterpret_cast<const bf16x8*>(hrow + HD * 2 + 64 * s), a1, 0, 0, 0);
+        for (int hh = 0; hh < 4; ++hh) {                           // (fragment reads in blocks of four -- eight spill beside the 304 weight registers and the ctx tile: same products, same order per accumulator)
+          { Frag4 f; lds_read4(f, hrow + 256 * hh);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cxv[4 * hh + s], f.v[s], a0, 0, 0, 0); }
+          { Frag4 f; lds_read4(f, hrow + HD * 2 + 256 * hh);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cxv[4 * hh + s], f.v[s], a1, 0, 0, 0); }
         }
         if (c16 == 0) *reinterpret_cast<f32x4*>(da + 16 * tile + 4 * q) = a0 + a1;
       }
