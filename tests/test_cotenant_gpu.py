@@ -158,6 +158,38 @@ def test_cotenant_across_cnn_backward(cuda, WGS):
     assert t1_ < t0_ + USEC * 1e-3 + 1.0                         # never longer than the tenant's own stay
 
 
+@pytest.mark.parametrize("WGS,USEC", [(32, 4000.0), (96, 1500.0)])
+def test_cotenant_across_decoder_chain_kernels(cuda, WGS, USEC):
+    """The tag-free exchange of dec_chain.hip under UNEVEN load (MI355X_MICROARCH.md: hand-offs must be tested with part of the chip busy): a co-tenant that
+    holds 32 (96) compute units for 4 (1.5) ms is started on another stream right in front of a C3-shape step, so the whole-sequence kernels -- which need every
+    compute unit -- run with some members placed late: their peers poll the unwritten pattern for as long as that takes.  The step must end with
+    cluster status 0 and with EXACTLY the outputs of the undisturbed step (every exchanged dword either is the pattern or is final: nothing else may be read)."""
+    co = _cotenant()
+    cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
+    m, O, ocfg, P, st, batch = make(cfg, B=256, W=256, maxlen=23, compute="bf16", max_decoder_l=24, max_beam=1)
+    taps = ("logits", "outs", "ds_all", "dq_all", "dpre_all")
+    m.train_forward_backward(batch)
+    ref = {k: m.get_tensor(k).clone() for k in taps}
+    scratch = torch.zeros(64 << 20, dtype=torch.uint8, device=m.device)
+    stamps = torch.zeros(2 * WGS, dtype=torch.int64, device=m.device)
+    side = torch.cuda.Stream(device=m.device)
+    for rep in range(3):
+        torch.cuda.synchronize()
+        assert co.cotenant_launch(side.cuda_stream, scratch.data_ptr(), scratch.numel(), WGS, float(USEC), stamps.data_ptr()) == 0
+        m.train_forward_backward(batch)
+        torch.cuda.synchronize()
+        assert m.cluster_status() == 0
+        for k in taps:
+            assert torch.equal(m.get_tensor(k), ref[k]), (rep, k)
+        lab_ref = m.decode_device(*m._upload(batch), 1)[0].clone()      # (evaluation-mode BatchNorm: the running statistics moved with the training forward above)
+        torch.cuda.synchronize()
+        assert co.cotenant_launch(side.cuda_stream, scratch.data_ptr(), scratch.numel(), WGS, float(USEC), stamps.data_ptr()) == 0
+        lab = m.decode_device(*m._upload(batch), 1)[0]
+        torch.cuda.synchronize()
+        assert m.cluster_status() == 0 and torch.equal(lab, lab_ref), rep
+    m.shutdown()
+
+
 def test_rccl_provider_through_model_step(cuda):
     """The library's own RCCL binding (ncclCommInitRank + ncclCommSplit for the BatchNorm sums + ncclAllReduce on the exchange stream)
     under Model.step for three optimisation steps on a 1-rank communicator: the sums are identities, so losses and parameters must follow
