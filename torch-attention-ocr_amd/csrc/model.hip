@@ -1021,9 +1021,12 @@ void loss_and_dlogits(aocr_model* m, const Dims& d, const int32_t* tge, int64_t 
                       float* loss_dev) {
   const int64_t rows = (int64_t)d.L * d.B;
   prof_mark(m, AOCR_PROF_OTHER);
-  logsoftmax_nll(m->s, m->logits, LOGIT_LD, tge, st, sb, d.B, nullptr, want_grad ? m->dlogits : nullptr, m->nll_rows, rows, m->V,
-                 grad_scale);
-  if (loss_dev) sum_to_scalar(m->s, m->nll_rows, rows, loss_dev);
+  // (round 5, measured and dropped: d logits and the projector's data gradient d out_proj = d logits W_o in this pass -- d logits kept in the wave, W_o (80 KB, fp32) in LDS,
+  //  exact fp32 FMAs instead of the K = 39 bf16 product behind it: 9 + 27 us of launches became one of ~60 us: 39 x 8 dependent LDS reads per row and lane)
+  logsoftmax_nll(m->s, m->logits, LOGIT_LD, tge, st, sb, d.B, nullptr, want_grad ? m->dlogits : nullptr, m->nll_rows, rows, m->V, grad_scale);
+  // the step's loss (sum of the rows' NLL, fp64 in one workgroup: deterministic): nothing on the device reads it, so a training step sums it behind the decoder BPTT kernel
+  // (decoder_backward) instead of between the two whole-sequence kernels (12 us of launch + latency on a mostly idle chip)
+  if (loss_dev) { if (want_grad && !m->prof_on) m->loss_pending = loss_dev; else sum_to_scalar(m->s, m->nll_rows, rows, loss_dev); }
 }
 
 static bool side_create(aocr_model* m);
@@ -1197,6 +1200,7 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   }
   // d(context), model.lua:652-653 summed over the loop: the ONE result of this pass the encoder BPTT waits for
   prof_mark(m, AOCR_PROF_RNN_GEMM);
+  if (m->loss_pending) { sum_to_scalar(s, m->nll_rows, (int64_t)L * B, m->loss_pending); m->loss_pending = nullptr; }      // the step's loss (loss_and_dlogits): behind the BPTT, in front of every event the exchange waits for
   if (m->q_pending) { hipStreamWaitEvent(s, m->q_done, 0); m->q_pending = false; }          // q of all steps (decoder_tf_forward put the product on the side stream)
   attention_dctx(s, m->a_all, m->ds_all, m->dcat_all, 2 * Hd, m->q_all, m->dctx, L, B, T, Hd);
   // ---- hoisted parameter gradients (accGradParameters of every clone summed over time).  Nothing downstream of them but the
