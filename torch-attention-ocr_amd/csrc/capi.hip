@@ -464,13 +464,13 @@ int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_p
       conv_backward_filter(m->s, m->bf16, m->A5, m->G0, m->G1, nullptr, d.B, d.H4, d.W2, 512, 512, 3, 1, m->A5b, m->G0b, m->wg_part, m->wg_part_floats, 1);
       break;
     case AOCR_PK_CONV1_FWD:                                 // R1 + R2: reads the image (fp32), writes the pooled 64-channel map as bf16
-      conv1_forward(s, m->last_images, m->conv[1].w, m->conv[1].b, nullptr, B, d.H, d.W, m->A1b);
-      bytes = (double)B * d.H * d.W * 4 + (double)B * d.H1 * d.W1 * 64 * 2;
+      conv1_forward(s, m->last_images, m->conv[1].w, m->conv[1].b, nullptr, B, d.H, d.W, m->A1b, m->route1_valid ? m->route1 : nullptr);
+      bytes = (double)B * d.H * d.W * 4 + (double)B * d.H1 * d.W1 * 64 * 2 + (m->route1_valid ? (double)conv1_route_elems(B, d.H, d.W) * 2 : 0.0);
       break;
     case AOCR_PK_CONV1_BWD:                                 // reads the image and d(pooled map) (fp32, conv2's data gradient); writes 640 numbers
       conv1_backward(s, m->last_images, m->conv[1].w, m->conv[1].b, m->G1, m->conv[1].dw, m->conv[1].db, B, d.H, d.W,
-                     (size_t)B * d.H1 * d.W1 * 128 >= (size_t)4096 * 640 ? m->G0 + 6 * SLAB : nullptr, nullptr);
-      bytes = (double)B * d.H * d.W * 4 + (double)B * d.H1 * d.W1 * 64 * 4;
+                     (size_t)B * d.H1 * d.W1 * 128 >= (size_t)4096 * 640 ? m->G0 + 6 * SLAB : nullptr, nullptr, m->route1_valid ? m->route1 : nullptr);
+      bytes = (double)B * d.H * d.W * 4 + (double)B * d.H1 * d.W1 * 64 * 4 + (m->route1_valid ? (double)conv1_route_elems(B, d.H, d.W) * 2 : 0.0);
       break;
     case AOCR_PK_BN_FWD:                                    // conv5's BatchNorm + ReLU as the step runs it: statistics from the conv epilogue -> finalize + ONE pass: fp32 y in, bf16 out
       bn_relu_forward(s, m->Y5, nullptr, m->bn[5].w, m->bn[5].b, m->bn[5].rm, m->bn[5].rv, m->bn[5].save, m->bn_scratch, n5, 512, 1, 0, 0, m->A5b, nullptr, (int)(n5 / 256));

@@ -64,6 +64,7 @@ struct aocr_model {
   // CNN
   float *A1, *A2, *Y3, *A3, *A4, *Y5, *A5, *A6, *Y7, *X;
   uint8_t *idx2, *idx4, *idx6;
+  uint16_t* route1 = nullptr; bool route1_valid = false;       // conv1's pooling/ReLU decisions of the last training forward (conv1_forward's route)
   float *G0, *G1, *dX; size_t gmax = 0;   // gmax: floats in G0 / G1
   // bf16 shadows of the contraction operands (bf16 compute mode only; nullptr otherwise)
   aocr::bf16_t *A1b, *A2b, *A3b, *A4b, *A5b, *A6b, *G0b, *G2b = nullptr;

@@ -95,6 +95,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
   size_t gmax = B * d.H1 * d.W1 * 128;                                      // d(conv2 pre-pool output): the largest gradient map
   m->G0 = a.get<float>(gmax); m->G1 = a.get<float>(gmax); m->gmax = gmax;
   m->A1b = m->A2b = m->A3b = m->A4b = m->A5b = m->A6b = m->G0b = m->G2b = nullptr;
+  m->route1 = a.get<uint16_t>(conv1_route_elems((int)B, d.H, d.W)); m->route1_valid = false;
   for (int i = 0; i < 8; ++i) { m->wb[i] = nullptr; m->wtb[i] = nullptr; m->wtf[i] = nullptr; }
   if (!m->bf16) {
     static const int wsz32[8] = {0, 0, 128 * 9 * 64, 256 * 9 * 128, 256 * 9 * 256, 512 * 9 * 256, 512 * 9 * 512, 512 * 4 * 512};
@@ -332,7 +333,8 @@ void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training
   }
   // bf16 mode: the pooled conv outputs exist only as bf16 shadows (every consumer -- next conv, filter gradient, ReLU mask of the
   // un-pool -- reads the shadow; aocr_get_tensor materialises fp32 on demand)
-  prof_mark(m, AOCR_PROF_POOL_CONV1); conv1_forward(s, images, m->conv[1].w, m->conv[1].b, bf ? nullptr : m->A1, B, d.H, d.W, m->A1b);
+  prof_mark(m, AOCR_PROF_POOL_CONV1); conv1_forward(s, images, m->conv[1].w, m->conv[1].b, bf ? nullptr : m->A1, B, d.H, d.W, m->A1b, training ? m->route1 : nullptr);
+  m->route1_valid = training;                                   // conv1_backward takes the pooling/ReLU decisions from here instead of re-evaluating the layer
   if (m->shadow_pending && m->shadow2_pending) { hipStreamWaitEvent(s, m->shadow2_done, 0); m->shadow2_pending = false; }       // conv1 reads no shadow; conv2 reads its own taps (the first part of the table)
   else if (m->shadow_pending) { hipStreamWaitEvent(s, m->shadow_done, 0); m->shadow_pending = false; }
   prof_mark(m, AOCR_PROF_CONV_FWD); conv_forward(s, bf, m->A1, m->conv[2].w, m->conv[2].b, bf ? nullptr : m->A2, m->idx2, B, d.H1, d.W1, 64, 128, 3, 1, 1, 1, m->A1b, m->wb[2], m->A2b);
@@ -436,7 +438,8 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
     auto D = [&]() { prof_mark(m, AOCR_PROF_CONV_DGRAD); conv_backward_data(s, bf, G0, m->conv[2].w, G1, B, d.H1, d.W1, 64, 128, 3, 1, Gb[gp], m->wtb[2], m->wtf[2]); };
     if (wg_after) { D(); map_ready(); W(); wgrad_done(); } else { map_ready(); W(); wgrad_done(); D(); } }
   prof_mark(m, AOCR_PROF_POOL_CONV1); conv1_backward(s, images, m->conv[1].w, m->conv[1].b, G1, m->conv[1].dw, m->conv[1].db, B, d.H, d.W,
-                 (size_t)B * d.H1 * d.W1 * 128 >= (size_t)4096 * 640 ? slab(6) : nullptr, defer);      // G0 is free here: use it as the partial slab
+                 (size_t)B * d.H1 * d.W1 * 128 >= (size_t)4096 * 640 ? slab(6) : nullptr, defer,      // G0 is free here: use it as the partial slab
+                 m->route1_valid && !getenv("AOCR_CONV1_RECOMPUTE") ? m->route1 : nullptr);
   if (defer) colsum_flush(s, cj);                               // conv4.b, conv3.b, conv2.b, conv1.w, conv1.b
   if (ws) { hipEventRecord(m->side_done, sw); hipStreamWaitEvent(s, m->side_done, 0); }
 }

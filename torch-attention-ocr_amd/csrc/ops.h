@@ -123,12 +123,15 @@ void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float*
 void splitk_reduce(hipStream_t s, const float* part, int ks, size_t n, float* out);   // out[i] += sum_z part[z * n + i]  (n % 4 == 0)
 
 // ---- everything that is not a contraction (ops_misc.hip)
+// route (conv1_route_elems() uint16): the pooling/ReLU decision of every window, four 4-bit codes per word, for conv1_backward
 void conv1_forward(hipStream_t s, const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
-                   bf16_t* yb = nullptr);
+                   bf16_t* yb = nullptr, uint16_t* route = nullptr);
+size_t conv1_route_elems(int B, int H, int W);
 void conv_weight_shadows(hipStream_t s, const float* w, bf16_t* wb, bf16_t* wtb, int Cout, int KK, int Cin);
 struct ColsumJobs;
 void conv1_backward(hipStream_t s, const float* x, const float* w, const float* bias, const float* dyp, float* dw, float* db,
-                    int B, int H, int W, float* scratch = nullptr, ColsumJobs* defer = nullptr);
+                    int B, int H, int W, float* scratch = nullptr, ColsumJobs* defer = nullptr,
+                    const uint16_t* route = nullptr /* conv1_forward's decisions for the SAME x, w, bias; null: re-evaluated here */);
 void unpool_relu_backward(hipStream_t s, const float* dpooled, const float* pooled, const uint8_t* idx, float* dy, int B,
                           int Ho, int Wo, int C, int pool, bf16_t* dyb = nullptr, float* dbias = nullptr,
                           float* partial = nullptr, const bf16_t* pooledb = nullptr, ColsumJobs* defer = nullptr,

@@ -41,9 +41,10 @@ __device__ __forceinline__ void conv1_stage(const float* __restrict__ xb, int py
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+template <bool ROUTE>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, bf16_t* __restrict__ yb,
-                                                        int B, int H, int W, int Hp, int Wp) {
+                                                        int B, int H, int W, int Hp, int Wp, uint16_t* __restrict__ route) {
   __shared__ float sx[4][4][2 * C1S + 4];                       // [wave][row][col]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float wk[9];
@@ -67,9 +68,11 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
           const float2 v = *reinterpret_cast<const float2*>(&sx[wave][i][2 * w0 + j]);
           p[i][j] = v.x; p[i][j + 1] = v.y;
         }
+      unsigned code = 0;                                        // four 4-bit routes: 0 = below the ReLU floor, 1 + (2 dy + dx) = the window's first strict maximum
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         float best = 0.f;                                       // relu floor
+        unsigned bi = 0;
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -79,13 +82,16 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
               for (int kw = 0; kw < 3; ++kw) s2 = fmaf(wk[kh * 3 + kw], p[dy + kh][2 * u + dx + kw], s2);
+            if (ROUTE) bi = s2 > best ? (unsigned)(1 + 2 * dy + dx) << (4 * u) : bi;
             best = fmaxf(best, s2);
           }
+        if (ROUTE) code |= bi;
         if (w0 + u < nw) {
           if (y) y[o0 + (int64_t)(w0 + u) * 64] = best;
           if (yb) yb[o0 + (int64_t)(w0 + u) * 64] = (bf16_t)best;
         }
       }
+      if (ROUTE) route[(st * (C1S / 4) + (w0 >> 2)) * 64 + lane] = (uint16_t)code;
     }
     __builtin_amdgcn_wave_barrier();                            // the next strip overwrites this wave's block
   }
@@ -181,10 +187,12 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
 // neighbours.  Per window and lane 18 + 18 packed FMAs instead of 36 + 36; every conv value still sums its nine taps in the forward
 // pass's order, so the arg-max / ReLU routing is unchanged; the tap accumulators are kept per column parity and added at the end.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool ROUTE>
 __global__ __launch_bounds__(256) void conv1_bwd_pk_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, const float* __restrict__ dyp,
                                                            float* __restrict__ dw, float* __restrict__ db, int B, int H, int W,
-                                                           int Hp, int Wp, float* __restrict__ partial) {
+                                                           int Hp, int Wp, float* __restrict__ partial,
+                                                           const uint16_t* __restrict__ route) {
   __shared__ float sx[4][4][2 * C1S + 4];                       // [wave][row][col]
   __shared__ float swave[4][640];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -207,6 +215,8 @@ __global__ __launch_bounds__(256) void conv1_bwd_pk_kernel(const float* __restri
       float g[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) g[u] = (w0 + u < nw) ? gp[(int64_t)(w0 + u) * 64] : 0.f;
+      unsigned code = 0;
+      if (ROUTE) code = route[(st * (C1S / 4) + (w0 >> 2)) * 64 + lane];
       f32x2 pe[4][5], po[4][4];                                 // even pairs (columns 2k, 2k+1 of the 10-column slice), odd pairs (2k+1, 2k+2)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -217,24 +227,28 @@ __global__ __launch_bounds__(256) void conv1_bwd_pk_kernel(const float* __restri
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        f32x2 sv[2];                                            // sv[dy] = conv outputs (dx = 0, dx = 1) of window row dy
+        int bi = -1;
+        if (ROUTE) bi = (int)((code >> (4 * u)) & 7) - 1;       // the forward pass's own decision (conv1_fwd_kernel<true>)
+        else {
+          f32x2 sv[2];                                          // sv[dy] = conv outputs (dx = 0, dx = 1) of window row dy
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-          f32x2 s2 = f32x2{bb, bb};
+          for (int dy = 0; dy < 2; ++dy) {
+            f32x2 s2 = f32x2{bb, bb};
 #pragma unroll
-          for (int kh = 0; kh < 3; ++kh) {
-            s2 = __builtin_elementwise_fma(wk[kh * 3 + 0], pe[dy + kh][u], s2);
-            s2 = __builtin_elementwise_fma(wk[kh * 3 + 1], po[dy + kh][u], s2);
-            s2 = __builtin_elementwise_fma(wk[kh * 3 + 2], pe[dy + kh][u + 1], s2);
+            for (int kh = 0; kh < 3; ++kh) {
+              s2 = __builtin_elementwise_fma(wk[kh * 3 + 0], pe[dy + kh][u], s2);
+              s2 = __builtin_elementwise_fma(wk[kh * 3 + 1], po[dy + kh][u], s2);
+              s2 = __builtin_elementwise_fma(wk[kh * 3 + 2], pe[dy + kh][u + 1], s2);
+            }
+            sv[dy] = s2;
           }
-          sv[dy] = s2;
+          // first strict maximum above the ReLU floor, in the order (0,0),(0,1),(1,0),(1,1) -- the forward's fmaxf chain
+          float best = 0.f;
+          if (sv[0][0] > best) { best = sv[0][0]; bi = 0; }
+          if (sv[0][1] > best) { best = sv[0][1]; bi = 1; }
+          if (sv[1][0] > best) { best = sv[1][0]; bi = 2; }
+          if (sv[1][1] > best) { best = sv[1][1]; bi = 3; }
         }
-        // first strict maximum above the ReLU floor, in the order (0,0),(0,1),(1,0),(1,1) -- the forward's fmaxf chain
-        float best = 0.f; int bi = -1;
-        if (sv[0][0] > best) { best = sv[0][0]; bi = 0; }
-        if (sv[0][1] > best) { best = sv[0][1]; bi = 1; }
-        if (sv[1][0] > best) { best = sv[1][0]; bi = 2; }
-        if (sv[1][1] > best) { best = sv[1][1]; bi = 3; }
         const float gg = g[u];
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
@@ -263,21 +277,25 @@ __global__ __launch_bounds__(256) void conv1_bwd_pk_kernel(const float* __restri
   }
 }
 
-void conv1_forward(hipStream_t s, const float* x, const float* w, const float* bias, float* y, int B, int H, int W, bf16_t* yb) {
+size_t conv1_route_elems(int B, int H, int W) { return (size_t)B * (H / 2) * ((W / 2 + C1S - 1) / C1S) * (C1S / 4) * 64; }
+void conv1_forward(hipStream_t s, const float* x, const float* w, const float* bias, float* y, int B, int H, int W, bf16_t* yb,
+                   uint16_t* route) {
   int Hp = H / 2, Wp = W / 2;
   int64_t strips = (int64_t)B * Hp * ((Wp + C1S - 1) / C1S);
   int blocks = (int)std::min<int64_t>((strips + 3) / 4, 4096);
-  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, y, yb, B, H, W, Hp, Wp);
+  if (route) hipLaunchKernelGGL(conv1_fwd_kernel<true>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, yb, B, H, W, Hp, Wp, route);
+  else hipLaunchKernelGGL(conv1_fwd_kernel<false>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, yb, B, H, W, Hp, Wp, route);
 }
 void conv1_backward(hipStream_t s, const float* x, const float* w, const float* bias, const float* dyp, float* dw, float* db,
-                    int B, int H, int W, float* scratch, ColsumJobs* defer) {
+                    int B, int H, int W, float* scratch, ColsumJobs* defer, const uint16_t* route) {
   int Hp = H / 2, Wp = W / 2;
   int64_t strips = (int64_t)B * Hp * ((Wp + C1S - 1) / C1S);
   // with a scratch slab (>= 4096*640 floats) every workgroup writes its partial sums and two column sums finish the job:
   // no contended global atomics, more workgroups
   int blocks = (int)std::min<int64_t>((strips + 3) / 4, scratch ? 2048 : 1024);
   if (getenv("AOCR_CONV1_SCALAR")) hipLaunchKernelGGL(conv1_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, dyp, dw, db, B, H, W, Hp, Wp, scratch);
-  else hipLaunchKernelGGL(conv1_bwd_pk_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, dyp, dw, db, B, H, W, Hp, Wp, scratch);
+  else if (route) hipLaunchKernelGGL(conv1_bwd_pk_kernel<true>, dim3(blocks), dim3(256), 0, s, x, w, bias, dyp, dw, db, B, H, W, Hp, Wp, scratch, route);
+  else hipLaunchKernelGGL(conv1_bwd_pk_kernel<false>, dim3(blocks), dim3(256), 0, s, x, w, bias, dyp, dw, db, B, H, W, Hp, Wp, scratch, route);
   if (scratch && defer) { colsum_defer(*defer, scratch, 640, blocks, 576, dw); colsum_defer(*defer, scratch + 576, 640, blocks, 64, db); }
   else if (scratch) {
     colsum_accum(s, scratch, 640, blocks, 576, dw);
