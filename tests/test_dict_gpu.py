@@ -212,3 +212,36 @@ def test_greedy_dictionary_decode_cluster_kernel(cuda, monkeypatch):
     print(f"[parity] greedy dictionary decode, cluster vs chain: identical rows {same.mean():.3f}")
     assert same.mean() >= 0.9
     assert np.abs(out["0"][1] - out["1"][1])[same].max() < 2e-2 * max(1.0, np.abs(out["1"][1]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beam", [3, 5])
+def test_beam_dictionary_decode_chain_kernel(cuda, monkeypatch, beam):
+    """Beam search with -use_dictionary inside the decoder chain kernel's BEAM variant (trie test per candidate, node of every surviving hypothesis,
+    the repeat-the-best rule when fewer candidates than beams are admissible: model.lua:405-445,460-513) against the launch chain with
+    project_select_kernel: same labels, every row on a trie path."""
+    import aocr
+    from test_step_gpu import make
+    rng = random.Random(11)
+    words = _words(rng, 5000, "abcdefghijklmnopqrstuvwxyz", 3, 9)
+    out = {}
+    for knob in ("0", "1"):
+        if knob == "1":
+            monkeypatch.setenv("AOCR_NO_DEC_CHAINS_BEAM", "1")
+        else:
+            monkeypatch.delenv("AOCR_NO_DEC_CHAINS_BEAM", raising=False)
+        m, O, ocfg, P, st, batch = make(dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True), B=64, W=128, maxlen=8,
+                                        compute="bf16", max_decoder_l=16, max_beam=beam)
+        P = dict(P); P["proj.w"] = P["proj.w"] * 40.0; P["proj.b"] = P["proj.b"].clone(); P["proj.b"][:3] -= 4.0
+        m.set_parameters(P, st)
+        trie = aocr.build_trie(words).to(cuda)
+        m.step(batch, True, beam, trie)
+        assert int(m.get_tensor("cl_err").view(torch.int32)[0]) == 0
+        out[knob] = (np.array(m._dec_out.labels), np.array(m._dec_out.scores))
+        for row in out[knob][0]:
+            assert trie.walk([int(v) for v in row if v != 1]) is not None
+        m.shutdown()
+    same = (out["0"][0] == out["1"][0]).all(axis=1)
+    print(f"[parity] beam-{beam} dictionary decode, chain kernel vs launch chain: identical rows {same.mean():.3f}")
+    assert same.mean() >= 0.9
+    assert np.abs(out["0"][1] - out["1"][1])[same].max() < 2e-2 * max(1.0, np.abs(out["1"][1]).max())

@@ -543,6 +543,36 @@ def test_greedy_decode_cluster_kernel_matches_launch_chain(cuda, monkeypatch, B,
     assert np.abs(a["gold"] - b["gold"]).max() < 2e-2 * max(1.0, np.abs(a["gold"]).max())
 
 
+@pytest.mark.parametrize("B,W,maxdec,beam", [(32, 72, 10, 5), (45, 100, 12, 3), (256, 256, 50, 5), (16, 800, 30, 5), (7, 100, 40, 2), (40, 160, 16, 8)])
+def test_beam_decode_chain_kernel_matches_launch_chain(cuda, monkeypatch, B, W, maxdec, beam):
+    """Beam search (model.lua:360-536) inside the decoder chain kernel's BEAM variant -- the k hypotheses of an image are rows of one chain,
+    the state gather by parent beam is a lane permutation of the old-state products and cell states, the image's owner runs LogSoftMax and
+    project_select_kernel's k-best selection, tokens + parents go to the history beam_backtrace reads -- against the per-step launch chain
+    (AOCR_NO_DEC_CHAINS_BEAM=1).  As for greedy decode the two paths' logits differ by bf16 noise, so labels agree except at near-ties."""
+    cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for knob in ("0", "1"):
+        if knob == "1":
+            monkeypatch.setenv("AOCR_NO_DEC_CHAINS_BEAM", "1")
+        else:
+            monkeypatch.delenv("AOCR_NO_DEC_CHAINS_BEAM", raising=False)
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=min(5, maxdec - 1), compute="bf16", max_decoder_l=maxdec, max_beam=beam)
+        P2 = dict(P); P2["proj.w"] = P["proj.w"] * 40.0; m.set_parameters(P2, st)
+        loss, stats = m.step(batch, True, beam)
+        assert int(m.get_tensor("cl_err").view(torch.int32)[0]) == 0
+        o = m._dec_out
+        out[knob] = dict(labels=np.array(o.labels), scores=np.array(o.scores), gold=np.array(o.gold_scores), loss=loss)
+        m.shutdown()
+    a, b = out["1"], out["0"]
+    same_rows = (a["labels"] == b["labels"]).all(axis=1)
+    agree = (a["labels"] == b["labels"]).mean()
+    print(f"[parity] beam-{beam} decode chain kernel B={B} W={W} Lt={maxdec}: label agreement {agree:.4f}, identical rows {same_rows.mean():.3f}, "
+          f"score max-abs on identical rows {np.abs(a['scores'] - b['scores'])[same_rows].max() if same_rows.any() else float('nan'):.3e}")
+    assert agree >= 0.95 and same_rows.mean() >= 0.8
+    assert np.abs(a["scores"] - b["scores"])[same_rows].max() < 2e-2 * max(1.0, np.abs(a["scores"]).max())
+    assert np.abs(a["gold"] - b["gold"]).max() < 2e-2 * max(1.0, np.abs(a["gold"]).max())
+
+
 @pytest.mark.parametrize("boost", [60.0, 0.45, 0.3])
 def test_greedy_decode_early_exit(cuda, monkeypatch, boost):
     """The greedy cluster kernel leaves its loop once every row of a 32-row group has emitted EOS / PAD (all later steps select PAD at no
@@ -1317,10 +1347,17 @@ def test_side_stream_overlaps_match_in_line_order(cuda, monkeypatch, switch):
             monkeypatch.setenv(switch, knob)
         m, O, ocfg, P, st, batch = make(cfg, B=32, W=256, maxlen=11, compute="bf16", max_decoder_l=12, max_beam=1)
         images, targets, targets_eval = m._upload(batch)
+        # Three steps at learning rate 0 (the parameters stay put, everything else -- gradient zeroing, shadows, double-buffered maps, the update kernel --
+        # runs): every step must reproduce the same gradient vector.  With a real learning rate the run-to-run noise of step 0 (2.7e-8: the order in
+        # which split-K partial sums meet) grows to 4e-3 .. 6e-2 by step 2 with or without a switch (bf16 operand rounding, ReLU / arg-max decisions,
+        # learning rate 0.1 on a random-init model): that comparison says nothing.  A fourth step at learning rate 0.1 then compares the update.
+        m.optim_state["learningRate"] = 0.0
         grads = []
         for i in range(3):
             m.train_step_device(images, targets, targets_eval, 32)
             grads.append(m.grad_params.clone())
+        m.optim_state["learningRate"] = 0.1
+        m.train_step_device(images, targets, targets_eval, 32)
         torch.cuda.synchronize()
         assert m.cluster_status() == 0
         out[knob] = (grads, m.params.clone(), m.bn_state.clone())
@@ -1328,5 +1365,6 @@ def test_side_stream_overlaps_match_in_line_order(cuda, monkeypatch, switch):
     (g0, p0, b0), (g1, p1, b1) = out[""], out["1"]
     for i, (a, b) in enumerate(zip(g0, g1)):
         rel = ((a - b).norm() / b.norm()).item()
-        assert rel < (1e-4 if i == 0 else 3e-2), (switch, i, rel)   # step 0: ~1e-6 (summation order); later steps: the same, amplified through bf16 operand rounding and ReLU / arg-max decisions (4e-3 measured, with or without a switch)
-    assert (p0 - p1).abs().max().item() < 5e-3 and (b0 - b1).abs().max().item() < 1e-3
+        own = ((a - g0[0]).norm() / g0[0].norm()).item()
+        assert rel < 1e-5 and own < 1e-5, (switch, i, rel, own)
+    assert (p0 - p1).abs().max().item() < 1e-5 and (b0 - b1).abs().max().item() < 1e-5

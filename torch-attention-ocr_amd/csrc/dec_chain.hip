@@ -29,6 +29,7 @@ constexpr unsigned SENT = 0xFFFFFFFFu;
 constexpr int NCH = 2, RC = 16;                                     // chains per group, rows per chain
 constexpr int OPB = RC * PA;                                        // one operand buffer of a chain: 16 rows x 1 KB (+ pad)
 constexpr int CH_FWD_LDS = NCH * 3 * OPB + 16384 + 8192 + 1024 + NCH * 5 * 1024;
+constexpr int CH_BEAM_EXTRA = 2048;                                 // beam search: candidate scores of the member's image + per-beam score / token / trie node
 constexpr int CH_DEC_LDS = CH_FWD_LDS + 2560 + NCH * 1024 + NCH * 1024 + 10240;      // greedy decode: + W_o slice, out(t) of the member's units, token staging, the per-token gate-input table slice     // operands + K-split partial tiles + attention partial context + scores + the next step's gate inputs / tokens
 
 __device__ __forceinline__ unsigned sane(unsigned x) { return x == SENT ? 0xFFFEFFFFu : x; }
@@ -42,8 +43,10 @@ __device__ __forceinline__ void pst16(void* p, u32x4 v, bool local) {
 
 #ifdef DC_DEBUG_STAMPS
 #define CH_STAMP(k) do { if (p.stamps) { const u64 now_ = __builtin_readcyclecounter(); stamp[k] += now_ - tprev; tprev = now_; } } while (0)
+#define CH_STAMP2(k) do { if (p.stamps) { const u64 now_ = __builtin_readcyclecounter(); stamp2[k] += now_ - tprev2; tprev2 = now_; } } while (0)
 #else
 #define CH_STAMP(k) do { } while (0)
+#define CH_STAMP2(k) do { } while (0)
 #endif
 
 // LDS-DMA (global_load_lds): the load writes LDS directly -- 64 lanes x 16 (4) bytes lane-linearly at the wave-uniform byte address in M0 -- and
@@ -133,9 +136,18 @@ template <int C> struct IC { static constexpr int value = C; };
 //   P2  z2 = [h1(t) ; h2(t-1)] W2^T + b         -> c2, h2(t)          h1(t)    <- P1                    publishes h2(t)
 //   P3  attention of row r on member r (members 16 c .. 16 c + 15 work for chain c, the others pass)     h2(t) <- P2      publishes c(t) of the row
 //   P4  out(t) = tanh(W_c [c(t) ; h2(t)])                              c(t)     <- P3                    publishes out(t)
-template <bool DEC, bool RES>     // RES: T <= 64 -- the 16-step tile of ctx . W_a a wave multiplies stays in its registers for the whole loop (64 VGPRs)
+// BEAM (with DEC): beam search, model.lua:360-536.  A chain carries 16 / k images x k hypotheses (row = image * k + beam); the step slots of the
+// exchange buffers are a rolling window of four (rows of this launch's groups only); the state gather by parent beam (model.lua:516-535) is
+// a lane permutation of the OLD-state partial products and of the cell states (nothing moves in memory); the image's owner (member of its first
+// row) runs project_select_kernel's selection over the k rows and publishes token + parent of every new row; history for beam_backtrace.
+template <bool DEC, bool RES, bool BEAM = false>     // RES: T <= 64 -- the 16-step tile of ctx . W_a a wave multiplies stays in its registers for the whole loop (64 VGPRs)
 __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  [[maybe_unused]] const u64 t_kernel0 = __builtin_readcyclecounter();
+  [[maybe_unused]] u64 t_real0 = 0;
+#ifdef DC_DEBUG_STAMPS
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_real0));
+#endif
   float* const red = reinterpret_cast<float*>(lds + NCH * 3 * OPB);            // [4 waves][4 tiles][64 lanes][4]: K-split partial tiles of one chain
   float* const part = reinterpret_cast<float*>(lds + NCH * 3 * OPB + 16384);   // attention: [4 waves][512] partial context
   float* const sc = part + 4 * HD;                                             //            [256] scores
@@ -144,6 +156,9 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
   float* const outs = wos + 640;                                               //      [chain][16 rows][16] out(t) of this member's units (fp32)
   unsigned* const tokst = reinterpret_cast<unsigned*>(outs + NCH * 256);       //      [chain][4 waves][64] the tokens chosen a step ago, as fetched (tag << 8 | token)
   float* const ztab = reinterpret_cast<float*>(tokst + NCH * 256);             //      [40 tokens][4 gates][16] this member's columns of the per-token gate-input table
+  float* const cand = ztab + 2560;                                             // BEAM: [8 beams][40] candidate scores of this member's image
+  float* const bsc = cand + 320;                                               //       [2 parities][8] running scores, then last tokens, then trie nodes
+  int* const bpt = reinterpret_cast<int*>(bsc + 16); int* const bnd = bpt + 16;
   __shared__ int s_local, s_dead;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
@@ -151,11 +166,26 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
   const int member = i8 % NM, gl = (i8 / NM) * 8 + xcd;
   if (gl >= p.ngroups) return;
   const int group = p.group0 + gl;
-  const int B = p.B, T = p.T, L = p.L, row0 = group * R;
+  const int B = p.B, T = p.T, L = p.L;
+  const int kb = BEAM ? p.beam : 1, ipc = RC / kb;                  // BEAM: hypotheses per image, images per chain
+  const int gx = BEAM ? gl : group;                                 // index of the group in the exchange buffers (BEAM: of this launch)
+  const int row0 = gx * R;                                          // its first row there
+  const int Rs = BEAM ? p.rows_slot : B;                            // rows of one step slot
   const int unit = 16 * member + 4 * wave + q;
-  const size_t slot = (size_t)B * HD;
-  const int arow = row0 + member; const bool rvalid = arow < B;     // the row whose attention this workgroup computes
-  const int mych = member >> 4;                                     // ... and its chain
+  const size_t slot = (size_t)Rs * HD;
+  // element offsets of step slots: h / out [slot s1 = step + 1] and [c ; h2] [step]; BEAM: four rolling slots (behind the B rows of the initial state)
+  auto hof = [&](int s1) { return BEAM ? ((size_t)B + (size_t)(s1 & 3) * Rs) * HD : (size_t)s1 * slot; };
+  auto cof = [&](int s_) { return (size_t)(BEAM ? (s_ & 3) : s_) * Rs * 2 * HD; };
+  const int mych = member >> 4;                                     // the chain of the row whose attention this workgroup computes
+  int nvc[NCH], rlim[NCH];                                          // valid rows of a chain; row limit of its operand fetches (rows beyond repeat the last valid one)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) nvc[c] = BEAM ? max(0, min(B - (group * NCH + c) * ipc, ipc)) * kb : max(0, min(B - (row0 + RC * c), RC));
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) rlim[c] = BEAM ? (nvc[c] > 0 ? row0 + RC * c + nvc[c] : row0 + nvc[0]) : B;
+  auto imgof = [&](int c, int lr) { return BEAM ? (group * NCH + c) * ipc + lr / kb : row0 + RC * c + lr; };      // image (context / label row) of local row lr of chain c
+  const int arow = row0 + member; const bool rvalid = (member & (RC - 1)) < nvc[mych];     // the row whose attention this workgroup computes
+  const int aimg = imgof(mych, member & (RC - 1));
+  const bool bown = BEAM && rvalid && (member & (RC - 1)) % kb == 0;                       // BEAM: this member selects for its image
   unsigned char* const trash0 = reinterpret_cast<unsigned char*>(p.err + 16);
 
   // ---- pre-fill of this member's pieces of step s: wave 0 out(s) [slot s + 1], wave 1 / 2 h1(s) / h2(s) [slot s + 1], wave 3 the c half of
@@ -166,23 +196,23 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
     if (wave < 3) {
       bf16_t* const base = wave == 0 ? p.out_b : p.hsb[wave - 1];
       const int row = row0 + (ln >> 1);
-      dst = (s < L && row < B) ? (void*)(base + (size_t)(s + 1) * slot + (size_t)row * HD + 16 * member + 8 * (ln & 1)) : (void*)trash;
-    } else dst = (s < L && rvalid) ? (void*)(p.cat_b + ((size_t)s * B + arow) * 2 * HD + 8 * ln) : (void*)trash;
+      dst = (s < L && (BEAM || row < B)) ? (void*)(base + hof(s + 1) + (size_t)row * HD + 16 * member + 8 * (ln & 1)) : (void*)trash;
+    } else dst = (s < L && rvalid) ? (void*)(p.cat_b + cof(s) + (size_t)arow * 2 * HD + 8 * ln) : (void*)trash;
     unsigned sv = SENT; asm volatile("" : "+v"(sv));                 // (re-materialised per call: a loop-carried constant was spilled to scratch and re-loaded behind an s_waitcnt vmcnt(0))
     pst16(dst, u32x4{sv, sv, sv, sv}, loc);
   };
   prefill(0, tid, false); prefill(1, tid, false);
   constexpr int PSZ = 32 * 32 * 40;                                  // partial logits of a group and step parity: [row][source member][40]
-  float* const pown = DEC ? p.pbuf + ((size_t)group * 32 + member) * 32 * 40 : nullptr;      // ... this member's row (+ parity * ngroups_all * PSZ)
+  float* const pown = DEC ? p.pbuf + ((size_t)gx * 32 + member) * 32 * 40 : nullptr;      // ... this member's row (+ parity * ngroups_all * PSZ)
   const size_t ppar = (size_t)p.pgroups * PSZ;
   if constexpr (DEC) {                                               // this member's row of both parities: unwritten; its token slot: no token
     for (int i = tid; i < 2 * 320; i += 256) pst16(pown + (i / 320) * ppar + (i % 320) * 4, u32x4{SENT, SENT, SENT, SENT}, false);
-    if (tid == 0) pst4(p.tokx + (size_t)group * 32 + member, 0u, false);
+    if (tid == 0) pst4(p.tokx + (size_t)gx * 32 + member, 0u, false);
   }
   wait_vm<0>();
   __syncthreads();
   // ---- co-location check (rnn_cluster.hip); it is also the point after which every member's pre-fill of steps 0 and 1 is in memory
-  u64* const xt = p.xtab + (size_t)group * NM;
+  u64* const xt = p.xtab + (size_t)gx * NM;
   if (tid == 0) {
     unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); xcc &= 15u;
     stg64(xt + member, ((u64)p.epoch << 32) | (u64)(xcc + 1u));
@@ -218,9 +248,10 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
   // (a compiler-tracked load would put an s_waitcnt vmcnt(0) -- which also waits for the phase's young stores -- in front of its first use)
   float c1[NCH], c2[NCH];
   int tokc[NCH] = {1, 1};                                            // DEC: the token this lane's row (of each chain) feeds to the current step
+  [[maybe_unused]] int plane[NCH] = {lane, lane};                    // BEAM: the lane that holds this lane's unit of the row's parent hypothesis
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    const int row = min(row0 + RC * c + c16, B - 1);
+    const int row = min(imgof(c, c16), B - 1);
     c1[c] = p.cs[0][(size_t)row * HD + unit]; c2[c] = p.cs[1][(size_t)row * HD + unit];
     if constexpr (DEC) tokc[c] = p.tok0[(size_t)row * p.tok0_stride];                  // the GO tokens
     else {
@@ -237,20 +268,38 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       ztab[i] = v < p.V ? p.zx1[(size_t)v * 4 * HD + g * HD + 16 * member + u] : 0.f;
     }
   }
+  [[maybe_unused]] float bo_lane = 0.f;                              // BEAM: the projector bias of class `lane`
+  if constexpr (BEAM) bo_lane = lane < p.V ? p.bo[lane] : 0.f;
   int t_exit = -1; bool fin0 = false;                                // DEC: the step at which every row of the group had finished (early exit)
   float score = 0.f; int prev_tok = 0, node = 0;                     // DEC, wave 0 of the row's owner: running log-probability, last token, trie node (-use_dictionary)
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    load_rows16(p.out_b, row0 + RC * c, B, lds + (size_t)(c * 3 + 0) * OPB, tid);
-    load_rows16(p.hsb[0], row0 + RC * c, B, lds + (size_t)(c * 3 + 1) * OPB, tid);
-    load_rows16(p.hsb[1], row0 + RC * c, B, lds + (size_t)(c * 3 + 2) * OPB, tid);
+    if constexpr (BEAM) {                                            // every hypothesis of an image starts from the image's state (model.lua:388-398)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = tid + 256 * j, row = idx >> 6, ch = idx & 63; const size_t so = (size_t)min(imgof(c, row), B - 1) * HD + ch * 8;
+        *reinterpret_cast<u32x4*>(lds + (size_t)(c * 3 + 0) * OPB + (size_t)row * PA + ch * 16) = *reinterpret_cast<const u32x4*>(p.out_b + so);
+        *reinterpret_cast<u32x4*>(lds + (size_t)(c * 3 + 1) * OPB + (size_t)row * PA + ch * 16) = *reinterpret_cast<const u32x4*>(p.hsb[0] + so);
+        *reinterpret_cast<u32x4*>(lds + (size_t)(c * 3 + 2) * OPB + (size_t)row * PA + ch * 16) = *reinterpret_cast<const u32x4*>(p.hsb[1] + so);
+      }
+    } else {
+      load_rows16(p.out_b, row0 + RC * c, B, lds + (size_t)(c * 3 + 0) * OPB, tid);
+      load_rows16(p.hsb[0], row0 + RC * c, B, lds + (size_t)(c * 3 + 1) * OPB, tid);
+      load_rows16(p.hsb[1], row0 + RC * c, B, lds + (size_t)(c * 3 + 2) * OPB, tid);
+    }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): nothing of the prologue is in flight inside the loop
   __syncthreads();
   [[maybe_unused]] u64 stamp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+  [[maybe_unused]] const u64 t_loop0 = tprev;
+  [[maybe_unused]] u64 stamp2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev2 = 0;
+  [[maybe_unused]] u64 t_real1 = 0;
+#ifdef DC_DEBUG_STAMPS
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_real1));
+#endif
 
-  const bf16_t* const ca = p.ctxa + (size_t)min(arow, B - 1) * T * HD;
-  const bf16_t* const cx = p.ctxb + (size_t)min(arow, B - 1) * T * HD;
+  const bf16_t* const ca = p.ctxa + (size_t)min(aimg, B - 1) * T * HD;      // (BEAM: the context is not replicated, model.lua:373)
+  const bf16_t* const cx = p.ctxb + (size_t)min(aimg, B - 1) * T * HD;
   const int ntile = (T + 15) >> 4;
   bf16x8 cavr[RES ? 16 : 1];
   if constexpr (RES) {
@@ -260,6 +309,27 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
   }
 
   // one K-split product of a chain: acc tiles -> LDS -> this wave's tile summed over the four waves (dec_cluster.hip's order)
+  auto product_sum = [&](f32x4& v, int la, int lb) {                // la / lb: the lane whose column is read from the partial tiles of waves 0, 1 / 2, 3 (BEAM: the parent row)
+    v = *reinterpret_cast<const f32x4*>(red + ((size_t)(0 * 4 + wave) * 64 + la) * 4);
+    v += *reinterpret_cast<const f32x4*>(red + ((size_t)(1 * 4 + wave) * 64 + la) * 4);
+    v += *reinterpret_cast<const f32x4*>(red + ((size_t)(2 * 4 + wave) * 64 + lb) * 4);
+    v += *reinterpret_cast<const f32x4*>(red + ((size_t)(3 * 4 + wave) * 64 + lb) * 4);
+  };
+  auto product_mma = [&](const bf16x8 (&wa)[16], const bf16x8 (&wb)[16], const unsigned char* x0, const unsigned char* x1, auto&& mid) {
+    const unsigned char* src = (wave < 2 ? x0 : x1) + (256 * (wave & 1) + 8 * q) * 2 + (size_t)c16 * PA;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    Frag8 bf; lds_read8(bf, src);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(j < 2 ? wa[j * 8 + s] : wb[(j - 2) * 8 + s], bf.v[s], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(red + ((size_t)(wave * 4 + j) * 64 + lane) * 4) = acc[j];
+    mid();
+    lds_barrier();
+  };
   auto product = [&](const bf16x8 (&wa)[16], const bf16x8 (&wb)[16], const unsigned char* x0, const unsigned char* x1, f32x4& v, auto&& mid) {
     const unsigned char* src = (wave < 2 ? x0 : x1) + (256 * (wave & 1) + 8 * q) * 2 + (size_t)c16 * PA;
     f32x4 acc[4];
@@ -301,37 +371,50 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       unsigned char* const F = lds + (size_t)(c * 3 + 0) * OPB; unsigned char* const H1 = lds + (size_t)(c * 3 + 1) * OPB;
       const int rb = row0 + RC * c;
       if (t > 0) {
-        if constexpr (c == 0) pend_land<(DEC ? 6 : 3)>(p.out_b + (size_t)t * slot, HD * 2, rb, B, F, PA, olane, wave, member, local, p.err, 11, &s_dead, 0, &nretry[0 + c]);      // P4<1> of step t-1: 2 stores (DEC: 5) + the pre-fill (P5's stores, wave 0 of an owner only, come on top)
-        else pend_land<3>(p.out_b + (size_t)t * slot, HD * 2, rb, B, F, PA, olane, wave, member, local, p.err, 11, &s_dead, 0, &nretry[0 + c]);                       // P1<0>: 3 stores
+        if constexpr (c == 0) pend_land<(DEC ? 6 : 3)>(p.out_b + hof(t), HD * 2, rb, rlim[c], F, PA, olane, wave, member, local, p.err, 11, &s_dead, 0, &nretry[0 + c]);      // P4<1> of step t-1: 2 stores (DEC: 5) + the pre-fill (P5's stores, wave 0 of an owner only, come on top)
+        else pend_land<3>(p.out_b + hof(t), HD * 2, rb, rlim[c], F, PA, olane, wave, member, local, p.err, 11, &s_dead, 0, &nretry[0 + c]);                       // P1<0>: 3 stores
       } else lds_barrier();
       CH_STAMP(8 + c);
       if constexpr (DEC) {                                           // the tokens chosen at step t-1 (published by the rows' owners in P5): fetched beside the products, read behind them
-        if (t > 0) dma4(p.tokx + (size_t)group * 32 + RC * c + (olane & 15), __builtin_amdgcn_readfirstlane(lds_addr(tokst) + ((c * 4 + wave) * 64) * 4));
+        if (t > 0) dma4(p.tokx + (size_t)gx * 32 + RC * c + (olane & 15), __builtin_amdgcn_readfirstlane(lds_addr(tokst) + ((c * 4 + wave) * 64) * 4));
       }
       f32x4 z, g; u32x2 hp;
-      product(w1a, w1b, F, H1, z, [&] {
-        if constexpr (c == 0) { if (t > 0) pend_issue(p.out_b + (size_t)t * slot, HD * 2, row0 + RC, B, lds + (size_t)(1 * 3 + 0) * OPB, PA, olane, wave, member, local); }
-        else pend_issue(p.hsb[0] + (size_t)(t + 1) * slot, HD * 2, row0, B, lds + (size_t)(0 * 3 + 1) * OPB, PA, olane, wave, member, local);
-      });
+      auto mid1 = [&] {
+        if constexpr (c == 0) { if (t > 0) pend_issue(p.out_b + hof(t), HD * 2, row0 + RC, rlim[1], lds + (size_t)(1 * 3 + 0) * OPB, PA, olane, wave, member, local); }
+        else pend_issue(p.hsb[0] + hof(t + 1), HD * 2, row0, rlim[0], lds + (size_t)(0 * 3 + 1) * OPB, PA, olane, wave, member, local);
+      };
+      if constexpr (BEAM) product_mma(w1a, w1b, F, H1, mid1); else product(w1a, w1b, F, H1, z, mid1);
+      constexpr int TSH = BEAM ? 9 : 8;                              // a token word: tag << TSH | (BEAM: parent beam << 6) | token
       if constexpr (DEC) {
         if (t > 0) {
           wait_vm<4>();                                              // everything older than the four operand fetches above: the token fetch among it
-          const unsigned want = (p.epoch * 4096u + (unsigned)t) & 0xFFFFFFu;
+          const unsigned want = (p.epoch * 4096u + (unsigned)t) & (0xFFFFFFFFu >> TSH);
+          const bool need = !BEAM || (olane & 15) < nvc[c];          // (BEAM: nobody selects for the unused rows of a chain)
           unsigned tk = tokst[(c * 4 + wave) * 64 + olane];
-          if (__any((tk >> 8) != want)) {
+          if (__any(need && (tk >> TSH) != want)) {
             int spins = 0;
 #pragma nounroll
             while (true) {
               asm volatile("" : "+v"(spins));
               if (++spins > DC_SPIN_LIMIT) { if (olane == 0) { atomicExch(p.err, 17); s_dead = 1; } break; }
               __builtin_amdgcn_s_sleep(1);
-              ld4_sc1(tk, (unsigned)((RC * c + (olane & 15)) * 4), p.tokx + (size_t)group * 32, local);
+              ld4_sc1(tk, (unsigned)((RC * c + (olane & 15)) * 4), p.tokx + (size_t)gx * 32, local);
               wait_vm<0>();
               asm volatile("" : "+v"(tk));
-              if (!__any((tk >> 8) != want)) break;
+              if (!__any(need && (tk >> TSH) != want)) break;
             }
           }
-          tokc[c] = (int)(tk & 0xFFu);
+          if constexpr (BEAM) {
+            // model.lua:516-535: row r continues hypothesis `parent` of its image -- z1 and c1 (here), the h2(t-1) half of z2 and c2 (P2) are taken
+            // from the parent's column / lane
+            tokc[c] = need ? (int)(tk & 63u) : 1;
+            const int pr = (oc16 / kb) * kb + (int)((tk >> 6) & 7u);
+            plane[c] = need ? (olane & 48) | min(pr, RC - 1) : olane;
+            c1[c] = __shfl(c1[c], plane[c], 64);
+          } else tokc[c] = (int)(tk & 0xFFu);
+        }
+        if constexpr (BEAM) product_sum(z, plane[c], plane[c]);
+        if constexpr (!BEAM) if (t > 0) {
           // Every row of the group has emitted EOS (or PAD): from here on each step selects PAD at no cost (model.lua:448-449), so the labels of
           // the remaining steps are PAD and the scores final.  Every wave of every member sees the same 32 tokens: all leave together (behind P1<1>).
           const bool done = tokc[c] == 1 || tokc[c] == 3 || rb + (olane & 15) >= B;
@@ -346,41 +429,46 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
         for (int i = 0; i < 4; ++i) z[i] += zxs[(c * 5 + i) * 256 + ot];
       }
       cell(z, c1[c], g, hp);
-      const int row = rb + oc16; const bool ok = row < B;
-      pst8(oq == 0 && ok ? (void*)(p.hsb[0] + (size_t)(t + 1) * slot + (size_t)row * HD + 16 * member + 4 * wave) : (void*)otrash, hp, local);
-      st16f(ok && p.gates[0] ? (void*)(p.gates[0] + (((size_t)t * B + row) * HD + ounit) * 4) : (void*)otrash, g);
-      st4f(ok ? (void*)(p.cs[0] + (size_t)(t + 1) * slot + (size_t)row * HD + ounit) : (void*)otrash, c1[c]);
+      const int row = rb + oc16; const bool ok = oc16 < nvc[c];
+      pst8(oq == 0 && ok ? (void*)(p.hsb[0] + hof(t + 1) + (size_t)row * HD + 16 * member + 4 * wave) : (void*)otrash, hp, local);
+      st16f(ok && !BEAM && p.gates[0] ? (void*)(p.gates[0] + (((size_t)t * B + row) * HD + ounit) * 4) : (void*)otrash, g);
+      st4f(ok && !BEAM ? (void*)(p.cs[0] + (size_t)(t + 1) * slot + (size_t)row * HD + ounit) : (void*)otrash, c1[c]);
     };
     // =================== P2: layer 2.  stores: publish + gates + cell state + the h half of [c ; h2] = 4
     auto P2 = [&](auto cc) {
       constexpr int c = decltype(cc)::value;
       unsigned char* const H1 = lds + (size_t)(c * 3 + 1) * OPB; unsigned char* const H2 = lds + (size_t)(c * 3 + 2) * OPB;
       const int rb = row0 + RC * c;
-      if constexpr (c == 0) pend_land<3>(p.hsb[0] + (size_t)(t + 1) * slot, HD * 2, rb, B, H1, PA, olane, wave, member, local, p.err, 12, &s_dead, 0, &nretry[2 + c]);     // behind P1<1>
-      else pend_land<4>(p.hsb[0] + (size_t)(t + 1) * slot, HD * 2, rb, B, H1, PA, olane, wave, member, local, p.err, 12, &s_dead, 0, &nretry[2 + c]);                       // behind P2<0>
+      if constexpr (c == 0) pend_land<3>(p.hsb[0] + hof(t + 1), HD * 2, rb, rlim[c], H1, PA, olane, wave, member, local, p.err, 12, &s_dead, 0, &nretry[2 + c]);     // behind P1<1>
+      else pend_land<4>(p.hsb[0] + hof(t + 1), HD * 2, rb, rlim[c], H1, PA, olane, wave, member, local, p.err, 12, &s_dead, 0, &nretry[2 + c]);                       // behind P2<0>
       CH_STAMP(10 + c);
       f32x4 z, g; u32x2 hp;
-      product(w2a, w2b, H1, H2, z, [&] {
-        if constexpr (c == 0) pend_issue(p.hsb[0] + (size_t)(t + 1) * slot, HD * 2, row0 + RC, B, lds + (size_t)(1 * 3 + 1) * OPB, PA, olane, wave, member, local);
-        else pend_issue(p.hsb[1] + (size_t)(t + 1) * slot, HD * 2, row0, B, lds + (size_t)(0 * 3 + 2) * OPB, PA, olane, wave, member, local);
-      });
+      auto mid2 = [&] {
+        if constexpr (c == 0) pend_issue(p.hsb[0] + hof(t + 1), HD * 2, row0 + RC, rlim[1], lds + (size_t)(1 * 3 + 1) * OPB, PA, olane, wave, member, local);
+        else pend_issue(p.hsb[1] + hof(t + 1), HD * 2, row0, rlim[0], lds + (size_t)(0 * 3 + 2) * OPB, PA, olane, wave, member, local);
+      };
+      if constexpr (BEAM) {                                          // h1(t) belongs to the new rows, h2(t-1) and c2 to their parents
+        product_mma(w2a, w2b, H1, H2, mid2);
+        product_sum(z, olane, plane[c]);
+        c2[c] = __shfl(c2[c], plane[c], 64);
+      } else product(w2a, w2b, H1, H2, z, mid2);
 #pragma unroll
       for (int i = 0; i < 4; ++i) z[i] += b2[i];
       cell(z, c2[c], g, hp);
-      const int row = rb + oc16; const bool ok = row < B;
-      pst8(oq == 0 && ok ? (void*)(p.hsb[1] + (size_t)(t + 1) * slot + (size_t)row * HD + 16 * member + 4 * wave) : (void*)otrash, hp, local);
-      st16f(ok && p.gates[1] ? (void*)(p.gates[1] + (((size_t)t * B + row) * HD + ounit) * 4) : (void*)otrash, g);
-      st4f(ok ? (void*)(p.cs[1] + (size_t)(t + 1) * slot + (size_t)row * HD + ounit) : (void*)otrash, c2[c]);
-      st8(oq == 0 && ok ? (void*)(p.cat_b + ((size_t)t * B + row) * 2 * HD + HD + 16 * member + 4 * wave) : (void*)otrash, hp);               // JoinTable [c ; h_top], LSTM.lua:153
+      const int row = rb + oc16; const bool ok = oc16 < nvc[c];
+      pst8(oq == 0 && ok ? (void*)(p.hsb[1] + hof(t + 1) + (size_t)row * HD + 16 * member + 4 * wave) : (void*)otrash, hp, local);
+      st16f(ok && !BEAM && p.gates[1] ? (void*)(p.gates[1] + (((size_t)t * B + row) * HD + ounit) * 4) : (void*)otrash, g);
+      st4f(ok && !BEAM ? (void*)(p.cs[1] + (size_t)(t + 1) * slot + (size_t)row * HD + ounit) : (void*)otrash, c2[c]);
+      st8(oq == 0 && ok ? (void*)(p.cat_b + cof(t) + (size_t)row * 2 * HD + HD + 16 * member + 4 * wave) : (void*)otrash, hp);               // JoinTable [c ; h_top], LSTM.lua:153
     };
     // =================== P3: attention of row `member` (its chain's phase only).  stores: owners publish c + a = 2, the others none
     auto P3 = [&](auto cc) {
       constexpr int c = decltype(cc)::value;
       unsigned char* const H2 = lds + (size_t)(c * 3 + 2) * OPB;
       const int rb = row0 + RC * c;
-      if constexpr (c == 0) pend_land<4>(p.hsb[1] + (size_t)(t + 1) * slot, HD * 2, rb, B, H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]);      // behind P2<1>
-      else { if (mych == 0) pend_land<2>(p.hsb[1] + (size_t)(t + 1) * slot, HD * 2, rb, B, H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]);      // behind P3<0>
-             else pend_land<0>(p.hsb[1] + (size_t)(t + 1) * slot, HD * 2, rb, B, H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]); }
+      if constexpr (c == 0) pend_land<4>(p.hsb[1] + hof(t + 1), HD * 2, rb, rlim[c], H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]);      // behind P2<1>
+      else { if (mych == 0) pend_land<2>(p.hsb[1] + hof(t + 1), HD * 2, rb, rlim[c], H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]);      // behind P3<0>
+             else pend_land<0>(p.hsb[1] + hof(t + 1), HD * 2, rb, rlim[c], H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]); }
       CH_STAMP(12 + c);
       if constexpr (!DEC) {                                         // zx1 of the next step (LDS-DMA, older than the prefetch below: complete by the next counted wait)
         const int tn = min(t + 1, L - 1);
@@ -393,8 +481,8 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
         if (p.zx_tok) dma4(p.zx_tok + (int64_t)min(t + 2, L - 1) * p.zx_st + (int64_t)row * p.zx_sb, zb + 4 * 1024);
       }
       auto fetch_next = [&] {
-        if constexpr (c == 0) pend_issue(p.hsb[1] + (size_t)(t + 1) * slot, HD * 2, row0 + RC, B, lds + (size_t)(1 * 3 + 2) * OPB, PA, olane, wave, member, local);
-        else pend_issue(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, row0, B, lds + (size_t)(0 * 3 + 0) * OPB, PA, olane, wave, member, local);
+        if constexpr (c == 0) pend_issue(p.hsb[1] + hof(t + 1), HD * 2, row0 + RC, rlim[1], lds + (size_t)(1 * 3 + 2) * OPB, PA, olane, wave, member, local);
+        else pend_issue(p.cat_b + cof(t), HD * 4, row0, rlim[0], lds + (size_t)(0 * 3 + 0) * OPB, PA, olane, wave, member, local);
       };
       if (mych != c) { fetch_next(); return; }
       const unsigned char* hrow = H2 + (size_t)(member & (RC - 1)) * PA + 16 * q;
@@ -475,17 +563,17 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       float v0 = 0.f, v1 = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { v0 += part[w * HD + 2 * tid]; v1 += part[w * HD + 2 * tid + 1]; }
-      pst4(rvalid ? (void*)(p.cat_b + ((size_t)t * B + arow) * 2 * HD + 2 * ot) : (void*)otrash, sane(bfpair(v0, v1)), local);      // c of row `member`: units 2 tid, 2 tid + 1
-      st4f(rvalid && ot < T ? (void*)(p.a_all + ((size_t)t * B + arow) * T + ot) : (void*)otrash, av);
+      pst4(rvalid ? (void*)(p.cat_b + cof(t) + (size_t)arow * 2 * HD + 2 * ot) : (void*)otrash, sane(bfpair(v0, v1)), local);      // c of row `member`: units 2 tid, 2 tid + 1
+      st4f(rvalid && !BEAM && ot < T ? (void*)(p.a_all + ((size_t)t * B + arow) * T + ot) : (void*)otrash, av);
     };
     // =================== P4: out = tanh(W_c [c ; h2]), LSTM.lua:153-157.  stores: publish + the fp32 copy = 2 (+ the pre-fill behind chain 1)
     auto P4 = [&](auto cc) {
       constexpr int c = decltype(cc)::value;
       unsigned char* const F = lds + (size_t)(c * 3 + 0) * OPB; unsigned char* const H2 = lds + (size_t)(c * 3 + 2) * OPB;
       const int rb = row0 + RC * c;
-      if constexpr (c == 0) { if (mych == 1) pend_land<2>(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, rb, B, F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]);      // behind P3<1>
-                              else pend_land<0>(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, rb, B, F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]); }
-      else pend_land<(DEC ? 5 : 2)>(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, rb, B, F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]);                              // behind P4<0> (DEC: + 3 partial logits)
+      if constexpr (c == 0) { if (mych == 1) pend_land<2>(p.cat_b + cof(t), HD * 4, rb, rlim[c], F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]);      // behind P3<1>
+                              else pend_land<0>(p.cat_b + cof(t), HD * 4, rb, rlim[c], F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]); }
+      else pend_land<(DEC ? 5 : 2)>(p.cat_b + cof(t), HD * 4, rb, rlim[c], F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]);                              // behind P4<0> (DEC: + 3 partial logits)
       CH_STAMP(14 + c);
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       const unsigned char* src = (wave < 2 ? F : H2) + (256 * (wave & 1) + 8 * q) * 2 + (size_t)c16 * PA;   // k = 256 wave + 32 s: waves 0, 1 read c, waves 2, 3 read h2
@@ -493,8 +581,8 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcr[s], bf.v[s], acc, 0, 0, 0);
       *reinterpret_cast<f32x4*>(red + ((size_t)wave * 64 + lane) * 4) = acc;
-      if constexpr (c == 0) pend_issue(p.cat_b + (size_t)t * B * 2 * HD, HD * 4, row0 + RC, B, lds + (size_t)(1 * 3 + 0) * OPB, PA, olane, wave, member, local);
-      else { if (t + 1 < L) pend_issue(p.out_b + (size_t)(t + 1) * slot, HD * 2, row0, B, lds + (size_t)(0 * 3 + 0) * OPB, PA, olane, wave, member, local); }
+      if constexpr (c == 0) pend_issue(p.cat_b + cof(t), HD * 4, row0 + RC, rlim[1], lds + (size_t)(1 * 3 + 0) * OPB, PA, olane, wave, member, local);
+      else { if (t + 1 < L) pend_issue(p.out_b + hof(t + 1), HD * 2, row0, rlim[0], lds + (size_t)(0 * 3 + 0) * OPB, PA, olane, wave, member, local); }
       lds_barrier();
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
       if (wave == 0) {
@@ -504,10 +592,10 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = tanhf_(v[i]);
       }
-      const int row = rb + oc16; const bool ok = wave == 0 && row < B;
-      const size_t o = (size_t)(t + 1) * slot + (size_t)row * HD + 16 * member + 4 * oq;
+      const int row = rb + oc16; const bool ok = wave == 0 && oc16 < nvc[c];
+      const size_t o = hof(t + 1) + (size_t)row * HD + 16 * member + 4 * oq;
       pst8(ok ? (void*)(p.out_b + o) : (void*)otrash, u32x2{sane(bfpair(v[0], v[1])), sane(bfpair(v[2], v[3]))}, local);
-      st16f(ok ? (void*)(p.out + o) : (void*)otrash, v);
+      st16f(ok && !BEAM ? (void*)(p.out + o) : (void*)otrash, v);
       if constexpr (DEC) {
         // projector (output_projector.lua:3-8) on fp32 out: this member's 16 units against its slice of W_o -> 16 rows x V partial logits, to the rows' owners
         if (wave == 0) *reinterpret_cast<f32x4*>(outs + c * 256 + c16 * 16 + 4 * q) = v;
@@ -516,7 +604,7 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
         float o16[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) o16[u] = outs[c * 256 + r * 16 + u];
-        float* const pp = p.pbuf + (size_t)(t & 1) * ppar + ((size_t)group * 32 + RC * c + r) * 32 * 40 + (size_t)member * 40;
+        float* const pp = p.pbuf + (size_t)(t & 1) * ppar + ((size_t)gx * 32 + RC * c + r) * 32 * 40 + (size_t)member * 40;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const int vv = j + 16 * k;
@@ -575,12 +663,130 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
         node = p.trie_child[p.trie_base[node] + __popcll(tmask & ((1ull << bi) - 1ull))];
       if (olane == 0) {
         if (rvalid) { p.labels[(size_t)arow * p.tok0_stride + t] = bi + 1; if (t == L - 1) p.scores[arow] = best; }
-        pst4(p.tokx + (size_t)group * 32 + member, (((p.epoch * 4096u + (unsigned)(t + 1)) & 0xFFFFFFu) << 8) | (unsigned)(bi + 1), local);
+        pst4(p.tokx + (size_t)gx * 32 + member, (((p.epoch * 4096u + (unsigned)(t + 1)) & 0xFFFFFFu) << 8) | (unsigned)(bi + 1), local);
       }
       // this parity's row is read: unwritten again for step t + 2 (in memory long before its writers get there: they need this step's token first)
       unsigned sv = SENT; asm volatile("" : "+v"(sv));
 #pragma unroll
       for (int k = 0; k < 5; ++k) pst16(pown + (size_t)(t & 1) * ppar + (k * 64 + olane) * 4, u32x4{sv, sv, sv, sv}, local);
+    };
+    // =================== P5 (beam search): the owner of an image -- LogSoftMax of its k rows (wave j & 3 takes row j), then wave 0 selects the k best of the
+    // k x V candidates exactly as project_select_kernel does (descending score, ties -> lowest index; model.lua:399-458) and publishes, for every new
+    // row, token + parent beam; tokens and parents also go to the history beam_backtrace reads (model.lua:573-585)
+    auto P5B = [&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      if (mych != c || !bown) return;
+#ifdef DC_DEBUG_STAMPS
+      tprev2 = __builtin_readcyclecounter();
+#endif
+      const int V = p.V, cur = t & 1, nxt = cur ^ 1;
+      const bool first = t == 0;
+      // partial logits of the image's k rows: [row][source member][40]; wave w sums source members 8 w .. 8 w + 7 of every row (lane = class; one batch of
+      // up to 64 loads per wave), the four partial sums meet in LDS (`part`: idle outside P3)
+      {
+        const unsigned lo = (unsigned)(olane < V ? olane : 0) * 4u + (unsigned)wave * 8u * 160u;
+        float* const base = pown + (size_t)(t & 1) * ppar;
+        float pv[8][8];
+        int spins = 0;
+#pragma nounroll
+        while (true) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < kb) {
+#pragma unroll
+              for (int sm = 0; sm < 8; ++sm) { unsigned u_; ld4_sc1(u_, (unsigned)(j * 32 * 160 + sm * 160) + lo, base, local); pv[j][sm] = __builtin_bit_cast(float, u_); }
+            }
+          wait_vm<0>();
+          unsigned mx = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < kb) {
+#pragma unroll
+              for (int sm = 0; sm < 8; ++sm) { asm volatile("" : "+v"(pv[j][sm])); mx = max(mx, __builtin_bit_cast(unsigned, pv[j][sm])); }
+            }
+          if (!__any(mx == SENT)) break;
+          asm volatile("" : "+v"(spins));
+          if (++spins > DC_SPIN_LIMIT) { if (olane == 0) { atomicExch(p.err, 16); s_dead = 1; } break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < kb) {
+            float a = pv[j][0];
+#pragma unroll
+            for (int sm = 1; sm < 8; ++sm) a += pv[j][sm];
+            part[(wave * 8 + j) * 64 + olane] = a;
+          }
+      }
+      CH_STAMP2(0);
+      lds_barrier();
+      CH_STAMP2(1);
+      for (int j = wave; j < kb; j += 4) {
+        float x = -INFINITY;
+        if (olane < V) x = bo_lane + (((part[(0 * 8 + j) * 64 + olane] + part[(1 * 8 + j) * 64 + olane]) + part[(2 * 8 + j) * 64 + olane]) + part[(3 * 8 + j) * 64 + olane]);
+        const float mxv = wave_reduce(x, -INFINITY, [](float a, float b) { return fmaxf(a, b); });
+        const float sum = wave_reduce(olane < V ? expf(x - mxv) : 0.f, 0.f, [](float a, float b) { return a + b; });
+        float lp = olane < V ? x - (mxv + logf(sum)) : -INFINITY;
+        if (!first) {
+          const int pt = bpt[cur * 8 + j];
+          if (olane == 0 && (pt == 1 || pt == 3)) lp = 0.f;                     // model.lua:448-449: finished beams continue with PAD at zero cost
+          lp += bsc[cur * 8 + j];                                               // model.lua:450
+        }
+        if (p.trie_mask) {                                                      // -use_dictionary (model.lua:413,469)
+          const unsigned long long tm = p.trie_mask[first ? 0 : bnd[cur * 8 + j]];
+          const bool okt = (!first && olane == 0) || ((tm >> olane) & 1ull);
+          if (olane < V && !okt) lp = -INFINITY;
+        }
+        if (olane < V) cand[j * V + olane] = lp;
+        unsigned sv = SENT; asm volatile("" : "+v"(sv));                        // this parity's row is read (by every wave: the barrier above): unwritten again for step t + 2
+        float* const rowb = pown + (size_t)j * 32 * 40 + (size_t)(t & 1) * ppar;
+#pragma unroll
+        for (int k5 = 0; k5 < 5; ++k5) pst16(rowb + (k5 * 64 + olane) * 4, u32x4{sv, sv, sv, sv}, local);
+      }
+      CH_STAMP2(2);
+      lds_barrier();
+      CH_STAMP2(3);
+      if (wave != 0) return;
+      const int n = (first ? 1 : kb) * V;                                       // t = 0: one hypothesis per image (model.lua:388-398)
+      // candidates c = lane + 64 i in registers; per pick: wave maximum (DPP), then the lowest index among the ties = lowest i first, lowest lane within it
+      // (project_select_kernel's order: descending score, ties -> lowest index) -- no LDS traffic, no cross-lane permutes in the loop
+      float cv[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) cv[i] = olane + 64 * i < n ? cand[olane + 64 * i] : -INFINITY;
+      float first_best = -INFINITY; int first_bi = 0;
+      float mysc = 0.f; int mybi = 0;
+      for (int kk = 0; kk < kb; ++kk) {
+        float lm = fmaxf(fmaxf(fmaxf(cv[0], cv[1]), fmaxf(cv[2], cv[3])), cv[4]);
+        float best = wave_reduce(lm, -INFINITY, [](float a, float b) { return fmaxf(a, b); });
+        int bi = 0x7fffffff;
+        if (best > -INFINITY) {                                                  // (a NaN or -inf row leaves bi unset: the fallback below)
+#pragma unroll
+          for (int i = 4; i >= 0; --i) { const unsigned long long tie = __ballot(cv[i] == best); if (tie) bi = 64 * i + __ffsll((long long)tie) - 1; }
+        }
+        if (bi == 0x7fffffff) { best = first_best; bi = first_bi; }             // model.lua:419-433 (see project_select_kernel)
+        else {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) if (bi == olane + 64 * i) cv[i] = -INFINITY;
+        }
+        if (kk == 0) { first_best = best; first_bi = bi; }
+        if (olane == kk) { mysc = best; mybi = bi; }
+      }
+      CH_STAMP2(4);
+      if (olane < kb) {
+        const int tokv = mybi % V + 1, par = mybi / V;
+        int node = 0;
+        if (p.trie_mask) {                                                      // trie_next (model.lua:434-439,499-507)
+          node = first ? 0 : bnd[cur * 8 + par];
+          const int v0 = tokv - 1; const unsigned long long tm = p.trie_mask[node];
+          if (!(!first && v0 == 0) && ((tm >> v0) & 1ull)) node = p.trie_child[p.trie_base[node] + __popcll(tm & ((1ull << v0) - 1ull))];
+        }
+        bsc[nxt * 8 + olane] = mysc; bpt[nxt * 8 + olane] = tokv; bnd[nxt * 8 + olane] = node;
+        const size_t ho = ((size_t)t * B + aimg) * kb + olane;
+        p.hist_tok[ho] = tokv; p.hist_par[ho] = par;
+        if (t == L - 1) p.beam_scores[(size_t)aimg * kb + olane] = mysc;
+        pst4(p.tokx + (size_t)gx * 32 + member + olane, (((p.epoch * 4096u + (unsigned)(t + 1)) & (0xFFFFFFFFu >> 9)) << 9) | ((unsigned)par << 6) | (unsigned)tokv, local);
+      }
+      CH_STAMP2(5);
     };
 
     P1(IC<0>{}); CH_STAMP(0); P1(IC<1>{}); CH_STAMP(1); if (s_dead) { dead = true; break; }
@@ -589,7 +795,8 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
     P3(IC<0>{}); CH_STAMP(4); P3(IC<1>{}); CH_STAMP(5); if (s_dead) { dead = true; break; }
     P4(IC<0>{}); CH_STAMP(6); P4(IC<1>{}); CH_STAMP(7); if (s_dead) { dead = true; break; }
     prefill(t + 2, ot, local);
-    if constexpr (DEC) { P5(IC<0>{}); P5(IC<1>{}); }
+    if constexpr (BEAM) { P5B(IC<0>{}); P5B(IC<1>{}); }
+    else if constexpr (DEC) { P5(IC<0>{}); P5(IC<1>{}); }
   }
   if constexpr (DEC) {
     if (t_exit >= 0 && wave == 0 && lane == 0 && rvalid) {
@@ -599,7 +806,17 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
   }
   wait_vm<0>();
 #ifdef DC_DEBUG_STAMPS
-  if (p.stamps && wid == 0 && tid == 0) { for (int k = 0; k < 16; ++k) p.stamps[k] = stamp[k]; for (int k = 0; k < 8; ++k) p.err[16 + 2048 + k] = nretry[k]; }
+  if (p.stamps && tid == 0) {      // per workgroup: start, loop start, end in 100 MHz ticks (low 31 bits)
+    u64 rt; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt));
+    p.err[16 + 2048 + 32 + wid] = (int)(t_real0 & 0x7FFFFFFF); p.err[16 + 2048 + 288 + wid] = (int)(t_real1 & 0x7FFFFFFF); p.err[16 + 2048 + 544 + wid] = (int)(rt & 0x7FFFFFFF);
+  }
+  if (p.stamps && wid == 0 && tid == 0) {
+    for (int k = 0; k < 16; ++k) p.stamps[k] = stamp[k];
+    for (int k = 0; k < 8; ++k) p.err[16 + 2048 + k] = nretry[k];
+    for (int k = 0; k < 6; ++k) p.err[16 + 2048 + 12 + k] = (int)(stamp2[k] >> 4);
+    p.err[16 + 2048 + 9] = (int)((t_loop0 - t_kernel0) >> 4); p.err[16 + 2048 + 10] = (int)((__builtin_readcyclecounter() - t_kernel0) >> 4);      // prologue, whole kernel (cycles / 16)
+    u64 rt; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)); p.err[16 + 2048 + 11] = (int)(rt - t_real0);                       // whole kernel in 100 MHz ticks
+  }
 #endif
 }
 
@@ -1086,7 +1303,7 @@ void dec_chain_forward(hipStream_t s, const DecClFwdArgs& a0, bool greedy_decode
   const bool res = a0.T <= 64 && !getenv("AOCR_CH_NO_RES");
   for (int g0 = 0; g0 < groups; g0 += per_pass) {
     DecClFwdArgs a = a0; a.group0 = g0; a.ngroups = std::min(per_pass, groups - g0); a.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;
-    a.stamps = getenv("AOCR_DC_STAMPS") ? a.xtab + (size_t)groups * NM : nullptr;
+    { const char* e = getenv("AOCR_DC_STAMPS"); a.stamps = (e && e[0] != 'b') ? a.xtab + (size_t)groups * NM : nullptr; }      // ("beam": only the beam-search launches)
     const dim3 grid(8 * NM * ((a.ngroups + 7) / 8));
     if (greedy_decode) {
       a.pgroups = groups; a.tokx = reinterpret_cast<unsigned*>(a.pbuf + (size_t)2 * groups * 32 * 32 * 40); a.no_early = getenv("AOCR_NO_DEC_EARLY") != nullptr;
@@ -1094,6 +1311,39 @@ void dec_chain_forward(hipStream_t s, const DecClFwdArgs& a0, bool greedy_decode
       else hipLaunchKernelGGL((dec_ch_fwd_kernel<true, false>), grid, dim3(256), (size_t)CH_DEC_LDS, s, a);
     } else if (res) hipLaunchKernelGGL((dec_ch_fwd_kernel<false, true>), grid, dim3(256), (size_t)CH_FWD_LDS, s, a);
     else hipLaunchKernelGGL((dec_ch_fwd_kernel<false, false>), grid, dim3(256), (size_t)CH_FWD_LDS, s, a);
+  }
+}
+
+// ---- beam search on the chain kernel.  Groups hold 2 * (16 / k) images; a launch runs at most one group per XCD, and every launch needs its own
+// epoch (the exchange buffers are indexed by the group WITHIN the launch): a0.epoch is the first of dec_chain_beam_passes() consecutive ones.
+static int chain_per_pass() {
+  static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  return std::max(8, cus / (8 * NM) * 8);
+}
+static int beam_groups(int B, int k) { const int ipg = NCH * (RC / k); return (B + ipg - 1) / ipg; }
+// groups of one launch: one per XCD at most, and no more than fit four rolling step slots (32 rows each per group) into the [L + 1][B][Hd] / [L][B][2 Hd]
+// buffers behind the B rows of the initial state: 4 * 32 g <= L B
+static int beam_pass_groups(int B, int L, int k) { return (int)std::min<long>(std::min(chain_per_pass(), beam_groups(B, k)), (long)L * B / 128); }
+int dec_chain_beam_passes(int B, int L, int k) { const int g = beam_pass_groups(B, L, k); return g < 1 ? 0 : (beam_groups(B, k) + g - 1) / g; }
+int dec_chain_beam_group_cap() { return chain_per_pass(); }
+bool dec_chain_beam_supported(int B, int L, int k, int V) {
+  if (k < 2 || k > 8 || V > 40 || B < 1 || getenv("AOCR_NO_DEC_CHAINS_BEAM") || !dec_chain_enabled()) return false;
+  return beam_pass_groups(B, L, k) >= 1;
+}
+void dec_chain_beam_forward(hipStream_t s, const DecClFwdArgs& a0) {
+  const int groups = beam_groups(a0.B, a0.beam), per_pass = beam_pass_groups(a0.B, a0.L, a0.beam), cap = chain_per_pass();
+  (void)hipFuncSetAttribute((const void*)dec_ch_fwd_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_DEC_LDS + CH_BEAM_EXTRA));
+  (void)hipFuncSetAttribute((const void*)dec_ch_fwd_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_DEC_LDS + CH_BEAM_EXTRA));
+  const bool res = a0.T <= 64 && !getenv("AOCR_CH_NO_RES");
+  unsigned epoch = a0.epoch;
+  for (int g0 = 0; g0 < groups; g0 += per_pass, ++epoch) {
+    DecClFwdArgs a = a0; a.group0 = g0; a.ngroups = std::min(per_pass, groups - g0); a.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;
+    a.epoch = epoch; a.stamps = getenv("AOCR_DC_STAMPS") ? a.xtab + (size_t)cap * NM : nullptr; a.no_early = 1;
+    a.rows_slot = 32 * per_pass;
+    a.pgroups = cap; a.tokx = reinterpret_cast<unsigned*>(a.pbuf + (size_t)2 * cap * 32 * 32 * 40);
+    const dim3 grid(8 * NM * ((a.ngroups + 7) / 8));
+    if (res) hipLaunchKernelGGL((dec_ch_fwd_kernel<true, true, true>), grid, dim3(256), (size_t)(CH_DEC_LDS + CH_BEAM_EXTRA), s, a);
+    else hipLaunchKernelGGL((dec_ch_fwd_kernel<true, false, true>), grid, dim3(256), (size_t)(CH_DEC_LDS + CH_BEAM_EXTRA), s, a);
   }
 }
 

@@ -172,11 +172,11 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     m->cl_err = a.get<int>(16 + 256 * 8 + 4096);                 // error flag + the trash slots rows >= B store to + a debugging timeline
     m->bn_snap = a.get<float>(2 * (256 + 512 + 512));            // aocr_bn_state_count() floats
     if (Hd == 512 && m->Ld == 2 && m->cfg.input_feed) {          // the decoder loop as one launch (dec_cluster.hip)
-      m->dc_xbytes = dec_cluster_xbuf_bytes((int)B); m->dc_tbytes = dec_cluster_xtab_bytes((int)B);
+      m->dc_xbytes = dec_cluster_xbuf_bytes((int)B); m->dc_tbytes = dec_cluster_xtab_bytes((int)std::max<size_t>(B, 32 * (size_t)dec_chain_beam_group_cap()));      // (beam search on the chain kernel indexes by the group within a launch: up to one group per XCD)
       m->dc_xbuf = a.get<unsigned long long>(m->dc_xbytes / 8); m->dc_xtab = a.get<unsigned long long>(m->dc_tbytes / 8);
       m->ctxa_b = a.get<bf16_t>(B * T * Hd);
       m->dc_bxbytes = dec_cluster_bwd_xbuf_bytes((int)B); m->dc_bxbuf = a.get<unsigned long long>(m->dc_bxbytes / 8);
-      m->dc_pbuf = a.get<float>(dec_cluster_pbuf_bytes((int)B) / 4);
+      m->dc_pbuf = a.get<float>(dec_cluster_pbuf_bytes((int)std::max<size_t>(B, 32 * (size_t)dec_chain_beam_group_cap())) / 4);
     }
   }
   for (int l = 0; l + 1 < m->Ld; ++l) { m->dhm[l] = a.get<float>(L * B * Hd); m->dhm_b[l] = m->bf16 ? a.get<bf16_t>(L * B * Hd) : nullptr; }
@@ -1312,6 +1312,30 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
     a.tok0 = tgt; a.tok0_stride = Lt; a.wo = m->wo; a.bo = m->bo; a.V = V; a.pbuf = m->dc_pbuf; a.labels = labels; a.scores = scores;
     if (trie) { a.trie_mask = (const unsigned long long*)trie->child_mask_dev; a.trie_base = trie->child_base_dev; a.trie_child = trie->child_dev; }
     dec_cluster_forward(s, a, true);
+    return;
+  }
+  if (k > 1 && m->out_b && m->dc_pbuf && dec_cluster_ok(m, T, Lt) && dec_chain_beam_supported(B, Lt, k, V)) {
+    // beam search inside the decoder chain kernel: the k hypotheses of an image are rows of one chain; state gather by parent, LogSoftMax and the
+    // k-best selection happen in the kernel (dec_chain.hip, BEAM), the back-trace is the launch chain's
+    float* tc0[MAXL]; float* th0[MAXL];
+    for (int l = 0; l < Ld; ++l) { tc0[l] = m->dcs[l]; th0[l] = m->dhs[l]; }
+    dec_init_state(m, d, tc0, th0, m->out_all, B, true);
+    gemm_hh_shadow(s, m->context_b, Hd, m->swa.wtb, Hd, m->dctx, Hd, m->ctxa_b, Hd, B * T, Hd, Hd);
+    m->ctxa_fresh = true;
+    const int npass = dec_chain_beam_passes(B, Lt, k);
+    reserve_epochs(m, (unsigned)npass + 1);
+    DecClFwdArgs a; a.B = B; a.T = T; a.L = Lt; a.epoch = next_epoch(m);
+    for (int i = 1; i < npass; ++i) (void)next_epoch(m);
+    a.w1i = m->dec[0].swi.wb; a.w1h = m->dec[0].swh.wb; a.w2i = m->dec[1].swi.wb; a.w2h = m->dec[1].swh.wb; a.wc = m->swc.wb;
+    a.b2i = m->dec[1].bi; a.b2h = m->dec[1].bh; a.zx1 = m->bzx_tab; a.ctxb = m->context_b; a.ctxa = m->ctxa_b;
+    for (int l = 0; l < 2; ++l) { a.cs[l] = m->dcs[l]; a.hsb[l] = m->dhs_b[l]; a.gates[l] = nullptr; }
+    a.a_all = m->a_all; a.out = m->out_all; a.cat_b = m->cat_b; a.out_b = m->out_b;
+    a.xbuf = m->dc_xbuf; a.xtab = m->dc_xtab; a.err = m->cl_err;
+    a.tok0 = tgt; a.tok0_stride = Lt; a.wo = m->wo; a.bo = m->bo; a.V = V; a.pbuf = m->dc_pbuf; a.labels = labels; a.scores = scores;
+    a.beam = k; a.hist_tok = m->hist_tok; a.hist_par = m->hist_par; a.beam_scores = m->beam_scores;
+    if (trie) { a.trie_mask = (const unsigned long long*)trie->child_mask_dev; a.trie_base = trie->child_base_dev; a.trie_child = trie->child_dev; }
+    dec_chain_beam_forward(s, a);
+    beam_backtrace(s, m->hist_tok, m->hist_par, m->beam_scores, labels, scores, Lt, B, k);
     return;
   }
   dec_init_state(m, d, c0, h0, m->bfeed[0], B);                    // the launch chain's beam buffers (the greedy cluster kernel above has its own: not initialised for nothing)

@@ -275,6 +275,8 @@ struct DecClFwdArgs {
   const int32_t* tok0 = nullptr; int tok0_stride = 0; const float *wo = nullptr, *bo = nullptr; int V = 0;
   float* pbuf = nullptr; unsigned* tokx = nullptr; int32_t* labels = nullptr; float* scores = nullptr; int pgroups = 0;   /* dec_chain.hip: groups of the whole batch (the partial logits are kept per step parity) */
   const unsigned long long* trie_mask = nullptr; const int32_t* trie_base = nullptr; const int32_t* trie_child = nullptr;   // -use_dictionary (flat trie of include/aocr.h) or null
+  // beam search on the chain kernel (dec_chain.hip, BEAM variant): k hypotheses per image, history [L][B][k] + final scores [B][k] for beam_backtrace
+  int beam = 0, rows_slot = 0; int32_t *hist_tok = nullptr, *hist_par = nullptr; float* beam_scores = nullptr;
   // nn.Dropout(p) (training, LSTM.lua:68-69,116-118): masks of layer 2's input (site 2) and of the attention output (site 16), flat index
   // = step * B * Hd + row * Hd + unit added to .off = 0; hm_b [L][B][Hd]: the masked bf16 copy of h1 (operand of layer 2 and of its weight gradient)
   DropSpec drop_h, drop_out; bf16_t* hm_b = nullptr;
@@ -298,6 +300,12 @@ struct DecClBwdArgs {
   unsigned long long *xbuf, *xtab; int* err; unsigned long long* stamps = nullptr;
   DropSpec drop_h, drop_out;                           // as in DecClFwdArgs (the forward kernel stored the MASKED attention output)
 };
+// beam search (2 <= beam <= 8, V <= 40) as launches of dec_chain.hip's kernel: a.epoch = the first of dec_chain_beam_passes() consecutive epochs,
+// a.pbuf / a.xtab sized for dec_chain_beam_group_cap() groups; four rolling step slots inside the [L + 1][B][Hd] buffers bound the groups of a launch (..._supported: at least one fits)
+bool dec_chain_beam_supported(int B, int L, int beam, int V);
+int dec_chain_beam_passes(int B, int L, int beam);
+int dec_chain_beam_group_cap();
+void dec_chain_beam_forward(hipStream_t s, const DecClFwdArgs& a);
 bool dec_cluster_supported(int Hd, int Ld, int input_feed, int T, int L, int cus);
 bool dec_cluster_bwd_supported(int Hd, int Ld, int input_feed, int T, int L, int cus);
 size_t dec_cluster_bwd_xbuf_bytes(int B);
