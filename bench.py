@@ -420,19 +420,30 @@ def main():
               "unit": "image-lines/s", "step_mfma_frac": 3 * f2 * w2["B"] * 10 / e / 1e12 / PEAK["f32"]}
         m2.shutdown()
 
-    # ---- beam-5 decode of the same lines (N = 1 only; model.lua:376-536 with -beam_size 5): the per-step launch chain + one fused state gather
+    # ---- beam-5 decode of the same lines (N = 1 only; model.lua:376-536 with -beam_size 5).  bf16, Hd = 512: the decoder chain kernel's BEAM variant
+    # (dec_chain.hip: the 5 hypotheses of an image are rows of one chain, 6 images per 32-CU group, launches of <= 8 groups); the per-step launch chain
+    # (AOCR_NO_DEC_CHAINS_BEAM=1: one cell / attention / project_select / state-gather launch set per step) is timed beside it
     beam5 = None
     if world == 1 and args.workload == "c3" and not args.no_secondary and args.decode_steps > 0:
         m5 = aocr.Model().create(dict(encoder_num_hidden=wl["He"], encoder_num_layers=wl["Le"], decoder_num_layers=wl["Ld"], input_feed=True,
                                       batch_size=B, max_img_w=W, max_decoder_l=50, max_beam=5, compute=wl["compute"], learning_rate=0.1, seed=910820))
-        m5.decode_device(images, targets, targets_eval, 5); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.decode_steps):
-            m5.decode_device(images, targets, targets_eval, 5)
-        torch.cuda.synchronize()
-        e5 = (time.perf_counter() - t0) / args.decode_steps
+
+        def time_beam():
+            m5.decode_device(images, targets, targets_eval, 5); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.decode_steps):
+                lab = m5.decode_device(images, targets, targets_eval, 5)[0]
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / args.decode_steps, lab.clone()
+        e5, lab5 = time_beam()
+        os.environ["AOCR_NO_DEC_CHAINS_BEAM"] = "1"
+        e5c, lab5c = time_beam()
+        del os.environ["AOCR_NO_DEC_CHAINS_BEAM"]
         beam5 = {"beam": 5, "chars_per_s": B * 50 / e5, "ms_per_call": 1e3 * e5,
-                 "what": "B*50 decoder steps per -phase test call at beam 5 (5 hypotheses per line advance per step), beam pass + gold pass"}
+                 "launch_chain_ms_per_call": 1e3 * e5c, "launch_chain_chars_per_s": B * 50 / e5c,
+                 "labels_equal_to_launch_chain": float((lab5 == lab5c).float().mean().item()),
+                 "what": "B*50 decoder steps per -phase test call at beam 5 (5 hypotheses per line advance per step), beam pass + gold pass; every step "
+                         "executed (a finished hypothesis can still be overtaken: no early exit at beam > 1)"}
         m5.shutdown()
 
     # ---- data path, HBM-bound

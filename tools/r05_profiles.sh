@@ -31,4 +31,9 @@ bash tools/ktrace_step.sh c3; cp gpurun_out/ktrace_step_c3.txt $O/c3_step_trace.
 bash tools/ktrace_step.sh c2 --compute f32; cp gpurun_out/ktrace_step_c2.txt $O/c2_step_trace.txt
 bash tools/pmc_clock.sh c2 --compute f32; cp gpurun_out/pmc_clock_c2.txt $O/c2_pmc_clock.txt
 rm -rf $O/stats $O/stats_c3s $O/stats_c2 $O/pmc_fetch $O/pmc_write $O/pmc_mfma
+# cycles per phase of the decoder chain kernels (training forward / backward, beam-5 decode): stamps build of the library
+if [ -f $R/torch-attention-ocr_amd/aocr/libaocr_stamps.so ]; then
+  AOCR_LIB=$R/torch-attention-ocr_amd/aocr/libaocr_stamps.so timeout 120 python3 tools/ch_stamp.py > $O/chain_stamps.txt 2>&1
+  AOCR_LIB=$R/torch-attention-ocr_amd/aocr/libaocr_stamps.so timeout 120 python3 tools/debug/beam_stamp.py 5 2>&1 | grep -v "wid " >> $O/chain_stamps.txt
+fi
 tail -1 $O/bench_c3_bf16.json | cut -c1-300; cat $O/hbm_pmc.txt; head -20 $O/mfma_busy.txt
