@@ -15,12 +15,12 @@ _T0 = time.time()
 # `slow` = A/B comparisons of two kernel paths that add no oracle comparison of their own, and the second parameter variants of long oracle cases.
 # They are collected LAST and each one is skipped (never silently: the reason is printed) once the session has run longer than the budget, so that the
 # whole `-m gpu` suite stays inside the driver's step limit on a slow box instead of timing out and scoring "untested" (VERDICT round 4, item 7).
-SLOW_AFTER_S = float(os.environ.get("AOCR_TEST_SLOW_AFTER", "600"))
+SLOW_AFTER_S = float(os.environ.get("AOCR_TEST_SLOW_AFTER", "560"))
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "slow: runs at the end of the session and only while the session is younger than AOCR_TEST_SLOW_AFTER seconds (default 600)")
+    config.addinivalue_line("markers", "slow: runs at the end of the session and only while the session is younger than AOCR_TEST_SLOW_AFTER seconds (default 560)")
 
 
 def pytest_collection_modifyitems(config, items):
