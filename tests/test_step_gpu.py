@@ -573,6 +573,31 @@ def test_beam_decode_chain_kernel_matches_launch_chain(cuda, monkeypatch, B, W, 
     assert np.abs(a["gold"] - b["gold"]).max() < 2e-2 * max(1.0, np.abs(a["gold"]).max())
 
 
+@pytest.mark.parametrize("B,W,maxdec,beam", [(8, 100, 48, 5), (12, 72, 40, 3)])
+def test_beam_decode_chain_kernel_vs_oracle(cuda, B, W, maxdec, beam):
+    """The BEAM variant of the chain kernel against the oracle's own beam search (O.decode_beam: model.lua:360-585 in fp64), not only against the
+    launch chain: labels, beam scores, gold scores.  bf16 operands against fp64: rows whose two best candidates are closer than the bf16 noise of
+    the logits may differ (sharpened projector: few), everything else must be the reference's decode."""
+    cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
+    m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=min(5, maxdec - 1), compute="bf16", max_decoder_l=maxdec, max_beam=beam)
+    P2 = dict(P); P2["proj.w"] = P["proj.w"] * 40.0; m.set_parameters(P2, st)
+    img, tgt, tge = (torch.from_numpy(np.asarray(x)) for x in batch[:3])
+    ref = O.decode_beam(P2, st, ocfg, img, tgt, tge, beam=beam, max_decoder_l=maxdec)
+    loss, stats = m.step(batch, True, beam)
+    assert int(m.get_tensor("cl_err").view(torch.int32)[0]) == 0
+    out = m._dec_out
+    rl = ref["labels"].numpy().astype(np.int32)
+    same = (np.array(out.labels) == rl).all(axis=1)
+    agree = (np.array(out.labels) == rl).mean()
+    ds = np.abs(np.array(out.scores) - ref["scores"].numpy())
+    print(f"[parity] beam-{beam} chain kernel vs O.decode_beam B={B} Lt={maxdec}: label agreement {agree:.4f}, identical rows {same.mean():.3f}, "
+          f"score max-abs on identical rows {ds[same].max() if same.any() else float('nan'):.3e}")
+    assert agree >= 0.9 and same.mean() >= 0.7
+    assert ds[same].max() < 3e-2 * max(1.0, np.abs(ref["scores"].numpy()).max())
+    assert np.abs(np.array(out.gold_scores) - ref["gold_scores"].numpy()).max() < 3e-2 * max(1.0, np.abs(ref["gold_scores"].numpy()).max())
+    m.shutdown()
+
+
 @pytest.mark.parametrize("boost", [60.0, 0.45, 0.3])
 def test_greedy_decode_early_exit(cuda, monkeypatch, boost):
     """The greedy cluster kernel leaves its loop once every row of a 32-row group has emitted EOS / PAD (all later steps select PAD at no
