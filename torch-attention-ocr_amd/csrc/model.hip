@@ -751,10 +751,11 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
   for (int l = m->Le - 1; l >= 0; --l) {
     const bool top = l == m->Le - 1;
     prof_mark(m, AOCR_PROF_ENC_SEQ);
-    if (top) copy2d_pair(s, m->dc_st[0], m->dc_st[0] + He, Hd, m->edc[0][l], m->edc[1][l], He, B, He);        // model.lua:666,680 (both directions in one launch)
-    else for (int dir = 0; dir < 2; ++dir) hipMemsetAsync(m->edc[dir][l], 0, slot * sizeof(float), s);
     int clG = 0, clRT = 0, clGroups = 0;
     const bool cluster = cluster_ok(m, B, T, clG, clRT, clGroups) && m->edz_b[0][l] && m->enc[0][l].swh.wtb;
+    const bool dc_direct = top && cluster && !env_on("AOCR_ENC_DC_COPY");      // the cluster kernel reads the halves of the decoder's initial-state gradient in place (one 9 us launch off the main stream's critical chain)
+    if (top && !dc_direct) copy2d_pair(s, m->dc_st[0], m->dc_st[0] + He, Hd, m->edc[0][l], m->edc[1][l], He, B, He);        // model.lua:666,680 (both directions in one launch)
+    else if (!top) for (int dir = 0; dir < 2; ++dir) hipMemsetAsync(m->edc[dir][l], 0, slot * sizeof(float), s);
     const bool seq = cluster || (seq_kernels_ok(m, B) && m->edz_b[0][l] && m->enc[0][l].swh.wtb);
     if (getenv("AOCR_TRACE")) fprintf(stderr, "[aocr] encoder layer %d backward: %s kernels\n", l, cluster ? "cluster" : seq ? "whole-sequence" : "per-step");
     if (cluster) {
@@ -766,6 +767,7 @@ static void encoder_backward(aocr_model* m, const Dims& d) {
         else { e.dh1 = m->edxl[dir]; e.dh1_row = He; e.dh1_t = (int64_t)slot; }
         e.dh2 = top ? m->dh_rec[0] + dir * He : nullptr; e.dh2_row = Hd;                            // model.lua:667,681
         e.dc = m->edc[dir][l]; e.gates = m->egates[dir][l]; e.cs = m->ecs[dir][l];
+        if (dc_direct) { e.dc_in = m->dc_st[0] + dir * He; e.dc_in_row = Hd; }
         e.dz = m->edz[dir][l]; e.dzb = m->edz_b[dir][l]; e.forward_dir = dir == 0;
         e.dbi = m->enc[dir][l].dbi; e.dbh = m->enc[dir][l].dbh;
       }
@@ -1203,7 +1205,13 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   }
   // d(context), model.lua:652-653 summed over the loop: the ONE result of this pass the encoder BPTT waits for
   prof_mark(m, AOCR_PROF_RNN_GEMM);
-  if (m->loss_pending) { sum_to_scalar(s, m->nll_rows, (int64_t)L * B, m->loss_pending); m->loss_pending = nullptr; }      // the step's loss (loss_and_dlogits): behind the BPTT, in front of every event the exchange waits for
+  // The hoisted parameter gradients below need the BPTT's outputs only: their streams are released HERE, in front of the loss sum and d(context) (67 us
+  // during which the chip is mostly idle), not behind them -- the side streams were the critical path of this section (the main stream idled ~70 us at
+  // the join in front of the CNN backward pass).  The first side-stream kernels are small (token sums, the projector's 96-workgroup product): the encoder
+  // BPTT kernel still finds its compute units when it starts.  AOCR_SIDE_GO_LATE=1: the old place.
+  const bool side_on = side_stream_on(m, B, T), side_early = side_on && !env_on("AOCR_SIDE_GO_LATE");
+  if (side_early) hipEventRecord(m->side_go, s);
+  if (m->loss_pending && !side_early) { sum_to_scalar(s, m->nll_rows, (int64_t)L * B, m->loss_pending); m->loss_pending = nullptr; }      // the step's loss (loss_and_dlogits): behind the BPTT, in front of every event the exchange waits for (side streams released early: on the side stream below, off the chain the encoder BPTT waits for)
   if (m->q_pending) { hipStreamWaitEvent(s, m->q_done, 0); m->q_pending = false; }          // q of all steps (decoder_tf_forward put the product on the side stream)
   attention_dctx(s, m->a_all, m->ds_all, m->dcat_all, 2 * Hd, m->q_all, m->dctx, L, B, T, Hd);
   // ---- hoisted parameter gradients (accGradParameters of every clone summed over time).  Nothing downstream of them but the
@@ -1211,8 +1219,10 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   // (16 groups x 2 directions x 4 members at C3) for ~0.2 ms.  The side stream has the lowest priority, so the encoder kernel's
   // workgroups are placed first.  Off while the per-family profile marks are on (the marks live on the model's stream).
   hipStream_t ms = s;
-  if (side_stream_on(m, B, T)) {
-    hipEventRecord(m->side_go, ms); s = m->side; hipStreamWaitEvent(s, m->side_go, 0); m->side_busy = true;
+  if (side_on) {
+    if (!side_early) hipEventRecord(m->side_go, ms);
+    s = m->side; hipStreamWaitEvent(s, m->side_go, 0); m->side_busy = true;
+    if (m->loss_pending) { sum_to_scalar(s, m->nll_rows, (int64_t)L * B, m->loss_pending); m->loss_pending = nullptr; }
   }
   // round 4: a SECOND side stream for the latency- / HBM-bound part of this section (projector gradWeight: a 24-way split-K product of 96 workgroups;
   // the bias column sums: 67 us over 180 MB) so that it runs beside the weight-gradient GEMMs instead of in front of them -- with the encoder's weight

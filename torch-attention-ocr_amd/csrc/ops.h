@@ -244,6 +244,7 @@ struct EncSeqBwdDir {
   const float* dh2;        // extra d h for the FIRST processed step (decoder initial state), row stride dh2_row; or nullptr
   int64_t dh2_row;
   float* dc;               // [B][He]: in = d c entering the first processed step, out = d c leaving the last one
+  const float* dc_in = nullptr; int64_t dc_in_row = 0;   // cluster kernels, first chunk: d c entering the first step read from here (row stride dc_in_row) instead of dc -- the decoder's [B][2 He] initial-state gradient without a split copy
   const float* gates;      // saved gates [T][B][4He]
   const float* cs;         // cell-state slots [(T+2)][B][He]
   float* dz; bf16_t* dzb;  // out: d z [T][B][4He], fp32 and bf16

@@ -334,7 +334,10 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dbs[g][i] = 0.f;
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) { const int row = min(row0 + 16 * rt + c16, B - 1); dcr[rt] = *reinterpret_cast<const f32x4*>(d.dc + (size_t)row * He + u0); }
+  for (int rt = 0; rt < RT; ++rt) {
+    const int row = min(row0 + 16 * rt + c16, B - 1);
+    dcr[rt] = (d.dc_in && p.it0 == 0) ? *reinterpret_cast<const f32x4*>(d.dc_in + (size_t)row * d.dc_in_row + u0) : *reinterpret_cast<const f32x4*>(d.dc + (size_t)row * He + u0);
+  }
 
   struct Pre { f32x4 g[RT][4], cc[RT], cp[RT], dh[RT]; };
   auto prefetch = [&](int it) {                                  // RT * 7 LDS-DMA loads: saved gates, c(t), c(t-1), d h from above
