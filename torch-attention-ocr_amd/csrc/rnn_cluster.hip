@@ -63,8 +63,19 @@ __device__ __forceinline__ void st16_sc1(void* p, u32x4 v) { asm volatile("globa
 // result must stay untouched in a VGPR across an MFMA phase is not safe -- under register pressure the allocator splits the live range
 // (copies the not-yet-landed register to an AGPR) -- so everything prefetched across a phase goes through LDS and is read back behind
 // the wait that covers it (vmcnt counts LDS-DMA like any other load).
+// Inline asm (M0 written in the statement that reads it), NOT __builtin_amdgcn_global_load_lds: hipcc tracks the builtin as an LDS write and drains
+// vmcnt to 0 at the next workgroup barrier -- which also waits for the acknowledgement of the granule stores issued since.  The waits that cover
+// these loads are the explicit counted ones.
 __device__ __forceinline__ void cl_dma16(const void* g, unsigned char* lds_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+  const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) void*)lds_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(a) : "memory");
+}
+// workgroup barrier whose fences cover LDS only (no wait for outstanding global stores)
+__device__ __forceinline__ void cl_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 // Two granules to a consumer.  `local` (wave-uniform): every member of the group runs on ONE XCD (checked at kernel start), so a plain
 // store -- which stays in that XCD's L2 -- is visible to the members' sc1 (L1-bypassing) polls without the trip through the fabric that
@@ -99,6 +110,16 @@ template <int G> __device__ __forceinline__ bool group_is_local(u64* tab, int me
 // vector-memory instructions per wave and step; the first layout issued 56, and the wave (at most 63 in flight) stalled on its
 // own store acknowledgements.
 //
+#ifdef CL_TIMING_FINE
+#define CL_FINE(k) do { const u64 now_ = __builtin_readcyclecounter(); fin_[k] += now_ - cprev_; cprev_ = now_; } while (0)
+#else
+#define CL_FINE(k) do { } while (0)
+#endif
+#ifdef DC_DEBUG_STAMPS
+#define CL_STAMP(k) do { const u64 now_ = __builtin_readcyclecounter(); cst_[k] += now_ - cprev_; cprev_ = now_; } while (0)
+#else
+#define CL_STAMP(k) do { } while (0)
+#endif
 // forward.  Saved gates layout of the cluster kernels: [T][B][He][4] (16 bytes per cell).
 template <int G, int RT, bool CTX>
 __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
@@ -114,7 +135,10 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
   if (gl >= p.ngid) return;
   const int gid = p.gid0 + gl;
   const int dir = gid / p.groups, group = gid - dir * p.groups;
-  const EncSeqDir& d = p.d[dir];
+  // A COPY whose fields are pinned in scalar registers: through the reference hipcc re-loaded the pointers from the kernarg segment inside the step loop
+  // (s_load_dwordx2 + s_waitcnt lgkmcnt(0) in front of every output store: 3.4 k of the 7.2 k cycles of a step, tools/debug/enc_stamp.py)
+  EncSeqDir d = p.d[dir];
+  asm volatile("" : "+s"(d.zx), "+s"(d.hs), "+s"(d.cs), "+s"(d.hsb), "+s"(d.gates), "+s"(d.ctx), "+s"(d.reverse));
   const int B = p.B, T = p.T, row0 = group * R;
   const int u0 = 64 * member + 16 * wave + 4 * q;               // this lane's four hidden units u0 .. u0+3 (epilogue), batch row c16
   unsigned char* const zxl = hbuf + 2 * R * HP + wave * (RT * 4 * 1024);
@@ -160,24 +184,40 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
   wait_vm<0>();
   __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0) the compiler can see: no wait of its own for the prologue loads inside the loop
   f32x4 gat[RT][4], hh[RT], cc[RT];                              // outputs of the step before ([unit i] = {in, forget, out, g}), stored one step late
-  auto store_outputs = [&](int t) {                              // RT * (6 or 7) store instructions, none conditional
+  [[maybe_unused]] u64 fin_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cprev_ = 0;
+  // What a step costs (tools/debug/enc_stamp.py, stamps build, C3: 7.2 k cycles): these stores are 2.9 k of it -- 26 KB per CU and step through a write path
+  // that sustains ~16 bytes per clock and CU (1.7 k cycles even when every store goes to one fixed 4 KB), + ~1.2 k for the 64-byte-per-row pieces of the
+  // real layouts.  They overlap the exchange (polls answered after ~2.4 k cycles), so the net cost is ~1.7 k cycles per step.  Measured without gain:
+  // the gates behind the barrier (the stall moves to the next step's polls), lane-contiguous stores (-15 %), touching the pages one phase ahead (worse).
+  // The lever that is left is bytes per CU: 32 units per member (twice the CUs per group; the idle half of the chip at C3, 15/16 of it at C5).
+  auto store_outputs = [&](int t, int part) {                    // part 0: c, h, context = RT * (2 or 3) store instructions; part 1: the saved gates = RT * 4; none conditional
     const size_t so = (size_t)(t + 1) * B * He;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const int row = row0 + 16 * rt + c16;
       const bool ok = row < B;
       const size_t o = so + (size_t)row * He + u0;
+      if (part == 0) {
       st16(ok ? d.cs + o : trash, cc[rt]);
+      CL_FINE(0);
       const unsigned h01 = bf16_bits(hh[rt][0]) | (bf16_bits(hh[rt][1]) << 16), h23 = bf16_bits(hh[rt][2]) | (bf16_bits(hh[rt][3]) << 16);
       st8(ok ? reinterpret_cast<void*>(d.hsb + o) : reinterpret_cast<void*>(trash), h01, h23);
+      CL_FINE(1);
       if (CTX) st16(ok ? d.ctx + ((size_t)row * T + t) * p.Hd + u0 : trash, hh[rt]);
+      CL_FINE(2);
+      } else {
       float* gp = ok ? d.gates + (((size_t)t * B + row) * He + u0) * 4 : trash;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) st16(ok ? gp + 4 * i : trash, gat[rt][i]);
+      for (int i = 0; i < 4; ++i) { st16(ok ? gp + 4 * i : trash, gat[rt][i]); CL_FINE(3 + i); }
+      }
     }
   };
   bool dead = false;
+  __shared__ int s_dead;
+  if (threadIdx.x == 0) s_dead = 0;
+  __syncthreads();
 
+  [[maybe_unused]] u64 cst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; cprev_ = __builtin_readcyclecounter();
   for (int it = it0; it < it1 && !dead; ++it) {
     const int t = d.reverse ? T - 1 - it : it;
     const int tprev = d.reverse ? t + 1 : t - 1;
@@ -213,10 +253,14 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) pin(gr[j][rt][hf]);
       };
+      CL_STAMP(0);
       issue();
-      store_outputs(tprev);                                      // behind the polls: the outputs of the step before (NBULK store instructions)
+      CL_STAMP(7);
+      store_outputs(tprev, 0); store_outputs(tprev, 1);                                      // behind the polls: the outputs of the step before (NBULK store instructions)
+      CL_STAMP(1);
       wait_vm<NBULK>();                                          // the polls and everything older (this step's zx in LDS) have landed
       settle();
+      CL_STAMP(2);
       int spins = 0;
       while (true) {
         bool ok = true;
@@ -235,6 +279,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
         __builtin_amdgcn_s_sleep(1);
         issue(); wait_vm<0>(); settle();
       }
+      CL_STAMP(3);
 #pragma unroll
       for (int j = 0; j < NPW; ++j) {
         const int x = (wave + 4 * j) % (2 * G);
@@ -244,9 +289,13 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
           *reinterpret_cast<u32x4*>(hb + (size_t)(16 * rt + c16) * HP + (32 * x + 8 * q) * 2) = raw;
         }
       }
-      __syncthreads();
-      dead = __syncthreads_or(dead);                             // a timeout anywhere in the workgroup stops all of it
+      // ONE barrier, LDS-only fences: __syncthreads_or() expands to three more barriers, a scalar load of the dispatch packet and -- through its
+      // memory fences -- s_waitcnt vmcnt(0), i.e. the acknowledgement of this step's young stores, on the path every step takes
+      if (dead && lane == 0) s_dead = 1;                         // a timeout anywhere in the workgroup stops all of it (plain LDS accesses: a volatile generic access is a FLAT instruction, counted by vmcnt too)
+      cl_barrier();
+      dead = s_dead != 0;
       if (dead) break;
+      CL_STAMP(4);
     }
     if (it > 0) {                                                // (the first iteration of a later chunk: h(t-1) was put into LDS by the prologue)
       const unsigned char* const hb = hbuf + (size_t)(it & 1) * R * HP;
@@ -260,6 +309,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
         }
     }
     if (dead) break;
+    CL_STAMP(5);
     f32x4 zx[RT][4];                                             // this step's input part, prefetched into LDS one step ago
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -283,11 +333,18 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
       }
     }
     dma_zx(it + 1 < it1 ? (d.reverse ? t - 1 : t + 1) : t);        // the next step's input part: issued behind the granules, older than the next polls
+    CL_STAMP(6);
   }
   wait_vm<0>();
+#ifdef DC_DEBUG_STAMPS
+  if (wid == 0 && threadIdx.x == 0) for (int k = 0; k < 8; ++k) p.err[16 + 2048 + 1000 + k] = (int)(cst_[k] >> 4);
+#ifdef CL_TIMING_FINE
+  if (wid == 0 && threadIdx.x == 0) for (int k = 0; k < 8; ++k) p.err[16 + 2048 + 1010 + k] = (int)(fin_[k] >> 4);
+#endif
+#endif
   if (!dead) {                                                   // the last step's outputs + its fp32 h (the decoder's initial state reads it)
     const int tl = d.reverse ? T - it1 : it1 - 1;
-    store_outputs(tl);
+    store_outputs(tl, 0); store_outputs(tl, 1);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) { const int row = row0 + 16 * rt + c16; if (row < B) *reinterpret_cast<f32x4*>(d.hs + ((size_t)(tl + 1) * B + row) * He + u0) = hh[rt]; }
   }
@@ -314,7 +371,8 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
   if (gl >= p.ngid) return;
   const int gid = p.gid0 + gl;
   const int dir = gid / p.groups, group = gid - dir * p.groups;
-  const EncSeqBwdDir& d = p.d[dir];
+  EncSeqBwdDir d = p.d[dir];                                     // pinned copy: see the forward kernel
+  asm volatile("" : "+s"(d.dh1), "+s"(d.dh1_row), "+s"(d.dh1_t), "+s"(d.dh2), "+s"(d.dh2_row), "+s"(d.dc), "+s"(d.gates), "+s"(d.cs), "+s"(d.dz), "+s"(d.dzb), "+s"(d.forward_dir));
   const int B = p.B, T = p.T, row0 = group * R;
   const int ul = 16 * wave + 4 * q, u0 = 64 * member + ul;      // epilogue: this lane's four hidden units (local / global), batch row c16
   float* const trash = reinterpret_cast<float*>(p.err + 16) + (threadIdx.x & 255) * 4;
@@ -445,7 +503,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
         }
       }
     }
-    __syncthreads();                                             // own partials are in LDS; everyone is done with abuf[(it-1)&1]
+    cl_barrier();                                                // own partials are in LDS; everyone is done with abuf[(it-1)&1]  (LDS-only fences: __syncthreads() put s_waitcnt vmcnt(0) -- the acknowledgement of the granule stores above -- in front of the barrier, and the polls behind it)
     // ---- polls first (the other members' partial tiles, in batches of <= PB members), bulk stores behind the first batch
     constexpr int NO = G - 1, PB = (NO > 4 || (RT > 1 && NO > 2)) ? (RT > 1 ? 2 : 4) : (NO > 0 ? NO : 1);
     const bool live = it > 0 && !dead;
@@ -546,7 +604,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
         *reinterpret_cast<u32x2*>(an + (size_t)(16 * rt + c16) * AP + (g * 64 + ul) * 2) = zz;
       }
     }
-    __syncthreads();                                             // d z(t) complete in LDS
+    cl_barrier();                                                // d z(t) complete in LDS
   }
   store_dz(d.forward_dir ? T - it1 : it1 - 1);
 #pragma unroll
@@ -574,6 +632,7 @@ bool enc_cluster_plan(int B, int He, int T, int cus, int& G, int& RT, int& group
   G = He / 64;
   RT = 1; groups = (B + 15) / 16;
   if (2 * groups * G > cus && G <= 4) { RT = 2; groups = (B + 31) / 32; }
+  { static const char* e = getenv("AOCR_ENC_RT2"); if (e && e[0] == '1' && G <= 4 && B > 16) { RT = 2; groups = (B + 31) / 32; } }      // A/B: two row tiles per group although one fits the chip
   return true;
 }
 size_t enc_cluster_xbuf_bytes(int B, int He) {                   // forward exchange buffer for the largest plan (RT = 1 granularity covers RT = 2)
