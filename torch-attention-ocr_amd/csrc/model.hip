@@ -167,7 +167,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     // one set of group slots per layer: the layers of a stacked encoder run concurrently (layer wavefront, encoder_forward)
     m->cl_xbytes = m->Le * enc_cluster_xbuf_bytes((int)B, (int)He); m->cl_pbytes = m->Le * enc_cluster_pbuf_bytes((int)B, (int)He);
     m->cl_xbuf = a.get<unsigned long long>(m->cl_xbytes / 8); m->cl_pbuf = a.get<unsigned long long>(m->cl_pbytes / 8);
-    m->cl_tbytes = ((size_t)m->Le * 2 * ((B + 15) / 16) * 8 + 64) * 8;
+    m->cl_tbytes = ((size_t)m->Le * 2 * ((B + 7) / 8) * 8 + 64) * 8;      // (8-row groups of the forward kernel: twice the slots)
     m->cl_xtab = a.get<unsigned long long>(m->cl_tbytes / 8);      // XCC ids of the members of every group
     m->cl_err = a.get<int>(16 + 256 * 8 + 4096);                 // error flag + the trash slots rows >= B store to + a debugging timeline
     m->bn_snap = a.get<float>(2 * (256 + 512 + 512));            // aocr_bn_state_count() floats

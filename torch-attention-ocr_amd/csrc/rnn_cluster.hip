@@ -139,7 +139,12 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
   // (s_load_dwordx2 + s_waitcnt lgkmcnt(0) in front of every output store: 3.4 k of the 7.2 k cycles of a step, tools/debug/enc_stamp.py)
   EncSeqDir d = p.d[dir];
   asm volatile("" : "+s"(d.zx), "+s"(d.hs), "+s"(d.cs), "+s"(d.hsb), "+s"(d.gates), "+s"(d.ctx), "+s"(d.reverse));
-  const int B = p.B, T = p.T, row0 = group * R;
+  // RH = batch rows a 16-column tile carries (p.rh: 16, or 8 = HALF tiles: twice the groups on twice the compute units, half the output bytes per CU
+  // and step -- the output stores are what bounds a step, see store_outputs; columns RH..15 repeat column RH-1 and are never stored or published)
+  const int RH = p.rh == 8 ? 8 : 16;
+  const int B = p.B, T = p.T, row0 = group * (RH * RT);
+  const int cv = min(c16, RH - 1);                              // the tile column this lane READS (its own, or the last valid one)
+  const bool cok = c16 < RH;                                    // ... and whether it owns one
   const int u0 = 64 * member + 16 * wave + 4 * q;               // this lane's four hidden units u0 .. u0+3 (epilogue), batch row c16
   unsigned char* const zxl = hbuf + 2 * R * HP + wave * (RT * 4 * 1024);
 
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
   auto dma_zx = [&](int t) {                                     // RT * 4 LDS-DMA loads: the input part of step t for this lane's cells
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      const int row = min(row0 + 16 * rt + c16, B - 1);
+      const int row = min(row0 + RH * rt + cv, B - 1);
 #pragma unroll
       for (int g = 0; g < 4; ++g) cl_dma16(d.zx + ((size_t)t * B + row) * 4 * He + g * He + u0, zxl + (rt * 4 + g) * 1024);
     }
@@ -174,9 +179,9 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
     const int tp = d.reverse ? T - it0 : it0 - 1;               // the step of iteration it0 - 1: its state is in slot tp + 1
     unsigned char* const hb = hbuf + (size_t)(it0 & 1) * R * HP;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) { const int row = min(row0 + 16 * rt + c16, B - 1); cst[rt] = *reinterpret_cast<const f32x4*>(d.cs + ((size_t)(tp + 1) * B + row) * He + u0); }
+    for (int rt = 0; rt < RT; ++rt) { const int row = min(row0 + RH * rt + cv, B - 1); cst[rt] = *reinterpret_cast<const f32x4*>(d.cs + ((size_t)(tp + 1) * B + row) * He + u0); }
     for (int x = threadIdx.x; x < R * (He / 8); x += 256) {
-      const int rr = x / (He / 8), k8 = x - rr * (He / 8), row = min(row0 + rr, B - 1);
+      const int rr = x / (He / 8), k8 = x - rr * (He / 8), row = min(row0 + RH * (rr >> 4) + min(rr & 15, RH - 1), B - 1);
       *reinterpret_cast<u32x4*>(hb + (size_t)rr * HP + k8 * 16) = *reinterpret_cast<const u32x4*>(d.hsb + ((size_t)(tp + 1) * B + row) * He + k8 * 8);
     }
     __syncthreads();
@@ -194,9 +199,10 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
     const size_t so = (size_t)(t + 1) * B * He;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      const int row = row0 + 16 * rt + c16;
+      const int row = row0 + RH * rt + c16;
       const bool ok = row < B;
       const size_t o = so + (size_t)row * He + u0;
+      if (!cok) continue;                                        // (an exec mask, not a branch around the instructions: every wave has owners, the store count stays static)
       if (part == 0) {
       st16(ok ? d.cs + o : trash, cc[rt]);
       CL_FINE(0);
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[rt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned tag = p.epoch * 4096u + (unsigned)it;
-    const u64* xp = xg + (size_t)((it - 1) & 1) * G * R * 32 + c16 * 32 + 4 * q;
+    const u64* xp = xg + (size_t)((it - 1) & 1) * G * R * 32 + cv * 32 + 4 * q;
     if (it > it0) {
       // ---- all-gather of h(t-1), shared by the four waves: the 2G (member, k-step) pieces are dealt to the waves (piece x = wave + 4 j),
       // each wave polls its pieces (2 RT loads of 16 bytes per lane and piece), drops the bf16 payload into LDS as the B operand
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
       }
       if (it + 1 < it1) {
         const u32x4 gv = {bf16_bits(hh[rt][0]) | (bf16_bits(hh[rt][1]) << 16), tagn, bf16_bits(hh[rt][2]) | (bf16_bits(hh[rt][3]) << 16), tagn};
-        st_granules(xw + (size_t)(16 * rt + c16) * 32, gv, local);
+        if (cok) st_granules(xw + (size_t)(16 * rt + c16) * 32, gv, local);
       }
     }
     dma_zx(it + 1 < it1 ? (d.reverse ? t - 1 : t + 1) : t);        // the next step's input part: issued behind the granules, older than the next polls
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
     const int tl = d.reverse ? T - it1 : it1 - 1;
     store_outputs(tl, 0); store_outputs(tl, 1);
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) { const int row = row0 + 16 * rt + c16; if (row < B) *reinterpret_cast<f32x4*>(d.hs + ((size_t)(tl + 1) * B + row) * He + u0) = hh[rt]; }
+    for (int rt = 0; rt < RT; ++rt) { const int row = row0 + RH * rt + c16; if (cok && row < B) *reinterpret_cast<f32x4*>(d.hs + ((size_t)(tl + 1) * B + row) * He + u0) = hh[rt]; }
   }
 }
 
@@ -635,8 +641,8 @@ bool enc_cluster_plan(int B, int He, int T, int cus, int& G, int& RT, int& group
   { static const char* e = getenv("AOCR_ENC_RT2"); if (e && e[0] == '1' && G <= 4 && B > 16) { RT = 2; groups = (B + 31) / 32; } }      // A/B: two row tiles per group although one fits the chip
   return true;
 }
-size_t enc_cluster_xbuf_bytes(int B, int He) {                   // forward exchange buffer for the largest plan (RT = 1 granularity covers RT = 2)
-  const int G = He / 64, groups = (B + 15) / 16;
+size_t enc_cluster_xbuf_bytes(int B, int He) {                   // forward exchange buffer for the largest plan (RT = 1 granularity covers RT = 2; 8-row groups: twice the slots)
+  const int G = He / 64, groups = (B + 7) / 8;
   return (size_t)2 * groups * 2 * G * 32 * 32 * sizeof(u64);     // [gid][parity][member][<= 32 rows][32 granules]
 }
 size_t enc_cluster_pbuf_bytes(int B, int He) {
@@ -660,6 +666,12 @@ static int cluster_cus() {
 }
 void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a00, int G, int RT, int reserve_cus) {
   EncClFwdArgs a0 = a00; a0.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;    // testing aid: write-through granules even inside one XCD
+  // Half tiles (8 batch rows per group) whenever twice the groups still fit the chip in one launch: the step is bound by the output stores of a CU
+  // (store_outputs), and half the rows are half the bytes.  C3: 32 + 32 groups of 4 = all 256 CUs instead of 128; AOCR_ENC_RH16=1: 16-row groups.
+  a0.rh = 16;
+  { static const char* e = getenv("AOCR_ENC_RH16");
+    const int g8 = (a0.B + 7) / 8;
+    if (!(e && e[0] == '1') && RT == 1 && a0.B > 8 && 2 * g8 * G <= cluster_cus() - reserve_cus) { a0.rh = 8; a0.groups = g8; a0.gslot = a00.gslot * 2; } }
   const int per_pass = std::max(8, (cluster_cus() - reserve_cus) / (8 * G) * 8);          // groups (gids) one launch can keep resident; reserve_cus: compute units left to a co-resident collective (model.h: comm_reserved_cus)
   for (int g0 = 0; g0 < 2 * a0.groups; g0 += per_pass) {
     EncClFwdArgs a = a0; a.gid0 = g0; a.ngid = std::min(per_pass, 2 * a0.groups - g0);
