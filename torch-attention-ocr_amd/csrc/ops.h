@@ -255,7 +255,7 @@ struct EncSeqBwdArgs { EncSeqBwdDir d[2]; int B, T, He; };
 bool enc_seq_supported(int B, int He, int blocks_limit);
 // ---- the same recurrences on clusters of CUs with register-resident weights (rnn_cluster.hip)
 struct EncClFwdArgs { EncSeqDir d[2]; int B, T, He, Hd, groups; unsigned epoch; unsigned long long* xbuf; int* err; int gid0 = 0, ngid = 0; unsigned long long* xtab = nullptr; int force_remote = 0; int it0 = 0, it1 = 0 /* iterations [it0, it1) of the T in this launch; it1 = 0: all */, gslot = 0 /* group-slot offset into xbuf / xtab (one set of slots per layer) */; int rh = 16 /* batch rows per 16-column tile: 16, or 8 (half tiles; set by enc_cluster_forward) */; };
-struct EncClBwdArgs { EncSeqBwdDir d[2]; int B, T, He, groups; unsigned epoch; unsigned long long* pbuf; int* err; int gid0 = 0, ngid = 0; unsigned long long* xtab = nullptr; int force_remote = 0; int it0 = 0, it1 = 0, gslot = 0; };
+struct EncClBwdArgs { EncSeqBwdDir d[2]; int B, T, He, groups; unsigned epoch; unsigned long long* pbuf; int* err; int gid0 = 0, ngid = 0; unsigned long long* xtab = nullptr; int force_remote = 0; int it0 = 0, it1 = 0, gslot = 0; int rh = 16 /* as EncClFwdArgs::rh; set by enc_cluster_backward */; };
 bool enc_cluster_plan(int B, int He, int T, int cus, int& G, int& RT, int& groups);
 size_t enc_cluster_xbuf_bytes(int B, int He);
 size_t enc_cluster_pbuf_bytes(int B, int He);

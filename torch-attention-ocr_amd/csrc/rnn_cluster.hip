@@ -379,7 +379,10 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
   const int dir = gid / p.groups, group = gid - dir * p.groups;
   EncSeqBwdDir d = p.d[dir];                                     // pinned copy: see the forward kernel
   asm volatile("" : "+s"(d.dh1), "+s"(d.dh1_row), "+s"(d.dh1_t), "+s"(d.dh2), "+s"(d.dh2_row), "+s"(d.dc), "+s"(d.gates), "+s"(d.cs), "+s"(d.dz), "+s"(d.dzb), "+s"(d.forward_dir));
-  const int B = p.B, T = p.T, row0 = group * R;
+  const int RH = p.rh == 8 ? 8 : 16;                            // batch rows per 16-column tile (8: half tiles, see the forward kernel)
+  const int B = p.B, T = p.T, row0 = group * (RH * RT);
+  const int cv = min(c16, RH - 1); const bool cok = c16 < RH;   // the column this lane reads; whether it owns one
+  const int lane_v = (lane & 48) | cv;                          // ... as a lane index (granule slots of the columns nobody owns are never written)
   const int ul = 16 * wave + 4 * q, u0 = 64 * member + ul;      // epilogue: this lane's four hidden units (local / global), batch row c16
   float* const trash = reinterpret_cast<float*>(p.err + 16) + (threadIdx.x & 255) * 4;
 
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
     for (int i = 0; i < 4; ++i) dbs[g][i] = 0.f;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    const int row = min(row0 + 16 * rt + c16, B - 1);
+    const int row = min(row0 + RH * rt + cv, B - 1);
     dcr[rt] = (d.dc_in && p.it0 == 0) ? *reinterpret_cast<const f32x4*>(d.dc_in + (size_t)row * d.dc_in_row + u0) : *reinterpret_cast<const f32x4*>(d.dc + (size_t)row * He + u0);
   }
 
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
     const int t = d.forward_dir ? T - 1 - it : it, prev = d.forward_dir ? t : t + 2;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      const int row = min(row0 + 16 * rt + c16, B - 1);
+      const int row = min(row0 + RH * rt + cv, B - 1);
       unsigned char* pl = prel + rt * 7 * 1024;
 #pragma unroll
       for (int i = 0; i < 4; ++i) cl_dma16(d.gates + (((size_t)t * B + row) * He + u0 + i) * 4, pl + i * 1024);
@@ -438,8 +441,9 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
   auto store_dz = [&](int t) {                                   // RT * 4 store instructions, none conditional
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      const int row = row0 + 16 * rt + c16;
+      const int row = row0 + RH * rt + c16;
       const bool ok = row < B;
+      if (!cok) continue;                                        // (exec mask: the store count stays static)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const unsigned z01 = bf16_bits(zprev[rt][g][0]) | (bf16_bits(zprev[rt][g][1]) << 16), z23 = bf16_bits(zprev[rt][g][2]) | (bf16_bits(zprev[rt][g][3]) << 16);
@@ -454,12 +458,12 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
     const int tp = d.forward_dir ? T - it0 : it0 - 1;
     unsigned char* const ab = abuf + (size_t)((it0 - 1) & 1) * R * AP;
     for (int x = tid; x < R * 32; x += 256) {                    // 16 B pieces: [row][gate][8 pieces of 8 units]
-      const int rr = x >> 5, g = (x >> 3) & 3, k8 = x & 7, row = min(row0 + rr, B - 1);
+      const int rr = x >> 5, g = (x >> 3) & 3, k8 = x & 7, row = min(row0 + RH * (rr >> 4) + min(rr & 15, RH - 1), B - 1);
       *reinterpret_cast<u32x4*>(ab + (size_t)rr * AP + (g * 64 + k8 * 8) * 2) = *reinterpret_cast<const u32x4*>(d.dzb + ((size_t)tp * B + row) * KG + g * He + 64 * member + k8 * 8);
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      const int row = min(row0 + 16 * rt + c16, B - 1);
+      const int row = min(row0 + RH * rt + cv, B - 1);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
             u64* dst = pb + ((((size_t)(par * G + dm) * G + member) * 4 + e) * RT + rt) * 256 + lane * 4;
             const u32x4 g0 = {__float_as_uint(acc[rt][j][0]), tag, __float_as_uint(acc[rt][j][1]), tag};
             const u32x4 g1 = {__float_as_uint(acc[rt][j][2]), tag, __float_as_uint(acc[rt][j][3]), tag};
-            st_granules(dst, g0, local); st_granules(dst + 2, g1, local);
+            if (cok) { st_granules(dst, g0, local); st_granules(dst + 2, g1, local); }
           }
         }
       }
@@ -523,7 +527,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
 #pragma unroll
         for (int kk = 0; kk < PB; ++kk) {
           const int k = (k0 + kk) % (NO > 0 ? NO : 1), sm = k + (k >= member ? 1 : 0);   // the G-1 other members (straight-line: a tail batch repeats)
-          const u64* src = pb + ((((size_t)(par * G + member) * G + sm) * 4 + wave) * RT) * 256 + lane * 4;
+          const u64* src = pb + ((((size_t)(par * G + member) * G + sm) * 4 + wave) * RT) * 256 + lane_v * 4;
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
     if (it == 0 && d.dh2) {                                      // model.lua:667,681: d h of the decoder's initial state joins the first processed step
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        const int row = min(row0 + 16 * rt + c16, B - 1);
+        const int row = min(row0 + RH * rt + cv, B - 1);
         const f32x4 v = *reinterpret_cast<const f32x4*>(d.dh2 + (size_t)row * d.dh2_row + u0);
         dh[rt] += v;
       }
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
     unsigned char* an = abuf + (size_t)par * R * AP;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      const bool ok = row0 + 16 * rt + c16 < B;
+      const bool ok = cok && row0 + RH * rt + c16 < B;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float ig = cur.g[rt][i][0], fg = cur.g[rt][i][1], og = cur.g[rt][i][2], gg = cur.g[rt][i][3];
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
   }
   store_dz(d.forward_dir ? T - it1 : it1 - 1);
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) { const int row = row0 + 16 * rt + c16; if (row < B) *reinterpret_cast<f32x4*>(d.dc + (size_t)row * He + u0) = dcr[rt]; }
+  for (int rt = 0; rt < RT; ++rt) { const int row = row0 + RH * rt + c16; if (cok && row < B) *reinterpret_cast<f32x4*>(d.dc + (size_t)row * He + u0) = dcr[rt]; }
   // bias gradients: both Linear layers see the same d z (LSTM.lua:79-88); sum over this lane's steps, then over the 16 rows of the tile
 #pragma unroll
   for (int g = 0; g < 4; ++g)
@@ -646,7 +650,7 @@ size_t enc_cluster_xbuf_bytes(int B, int He) {                   // forward exch
   return (size_t)2 * groups * 2 * G * 32 * 32 * sizeof(u64);     // [gid][parity][member][<= 32 rows][32 granules]
 }
 size_t enc_cluster_pbuf_bytes(int B, int He) {
-  const int G = He / 64, groups = (B + 15) / 16;
+  const int G = He / 64, groups = (B + 7) / 8;                   // (8-row groups: twice the slots)
   return (size_t)2 * groups * 2 * G * G * 4 * 2 * 256 * sizeof(u64);
 }
 
@@ -683,6 +687,13 @@ void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a00, int G, int RT, 
 }
 void enc_cluster_backward(hipStream_t s, const EncClBwdArgs& a00, int G, int RT, int reserve_cus) {
   EncClBwdArgs a0 = a00; a0.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;
+  // Half tiles as in the forward launch, but only while they leave half the chip free: the hoisted weight-gradient GEMMs run beside this kernel on the
+  // side streams (C3: 128 + 128 CUs; 8-row groups there would take all 256).  AOCR_ENC_BWD_RH=8 / 16 forces one.
+  a0.rh = 16;
+  { static const char* e = getenv("AOCR_ENC_BWD_RH");
+    const int g8 = (a0.B + 7) / 8, cus = cluster_cus() - reserve_cus;
+    const bool fits = RT == 1 && a0.B > 8 && 2 * g8 * G <= cus;
+    if (fits && ((e && e[0] == '8') || (!(e && e[0] == '1') && 2 * g8 * G <= cus / 2))) { a0.rh = 8; a0.groups = g8; a0.gslot = a00.gslot * 2; } }
   const int per_pass = std::max(8, (cluster_cus() - reserve_cus) / (8 * G) * 8);
   for (int g0 = 0; g0 < 2 * a0.groups; g0 += per_pass) {
     EncClBwdArgs a = a0; a.gid0 = g0; a.ngid = std::min(per_pass, 2 * a0.groups - g0);
