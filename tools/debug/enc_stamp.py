@@ -22,3 +22,10 @@ print(f"  (of the second line: issuing the polls {r[1007] * 16 / T:.0f})")
 print(f"  total {tot + r[1007] * 16 / T:.0f} cycles / step over T = {T}")
 if any(r[1010:1018]):
     print("  per output store (cs, hsb, ctx, gates 0..3):", [int(r[1010 + k] * 16 / T) for k in range(7)])
+bn = ["barrier at the loop end + loop top", "prefetch DMA issue + MFMA", "partial tiles out (granule stores / LDS)", "barrier", "polls issued + d z stores", "wait for the polls + epilogue inputs from LDS", "tag check / spin + partial sums", "cell backward + d z to LDS"]
+print("backward kernel, workgroup 0:")
+tb = 0
+for k, n in enumerate(bn):
+    c = r[1020 + k] * 16 / T; tb += c
+    print(f"  {n:46s} {c:8.0f} cycles / step")
+print(f"  total {tb:.0f} cycles / step")

@@ -360,6 +360,10 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
   };
   bool dead = false;
   [[maybe_unused]] int nretry[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // one-instruction stores of a phase behind its operand prefetch (what the next landing's counted wait leaves in flight).  Decode (DEC) keeps the state in
+  // registers and reads nothing back: the saved gates, cell-state slots, attention weights and the fp32 out are not written at all -- a store instruction
+  // costs ~250-400 cycles of issue on this path whatever it carries (tools/debug/enc_stamp.py), six per chain and step
+  constexpr int S1 = DEC ? 1 : 3, S2 = DEC ? 2 : 4, S3 = DEC ? 1 : 2, S4 = DEC ? 4 : 2;
 
   for (int t = 0; t < L && !dead; ++t) {
     int ot = tid; asm volatile("" : "+v"(ot));                     // opaque per-step copy of the thread id: the address arithmetic stays inside the step
@@ -372,8 +376,8 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       unsigned char* const F = lds + (size_t)(c * 3 + 0) * OPB; unsigned char* const H1 = lds + (size_t)(c * 3 + 1) * OPB;
       const int rb = row0 + RC * c;
       if (t > 0) {
-        if constexpr (c == 0) pend_land<(DEC ? 6 : 3)>(p.out_b + hof(t), HD * 2, rb, rlim[c], F, PA, olane, wave, member, local, p.err, 11, &s_dead, 0, &nretry[0 + c]);      // P4<1> of step t-1: 2 stores (DEC: 5) + the pre-fill (P5's stores, wave 0 of an owner only, come on top)
-        else pend_land<3>(p.out_b + hof(t), HD * 2, rb, rlim[c], F, PA, olane, wave, member, local, p.err, 11, &s_dead, 0, &nretry[0 + c]);                       // P1<0>: 3 stores
+        if constexpr (c == 0) pend_land<S4 + 1>(p.out_b + hof(t), HD * 2, rb, rlim[c], F, PA, olane, wave, member, local, p.err, 11, &s_dead, 0, &nretry[0 + c]);      // P4<1> of step t-1: 2 stores (DEC: 5) + the pre-fill (P5's stores, wave 0 of an owner only, come on top)
+        else pend_land<S1>(p.out_b + hof(t), HD * 2, rb, rlim[c], F, PA, olane, wave, member, local, p.err, 11, &s_dead, 0, &nretry[0 + c]);                       // P1<0>: 3 stores
       } else lds_barrier();
       CH_STAMP(8 + c);
       if constexpr (DEC) {                                           // the tokens chosen at step t-1 (published by the rows' owners in P5): fetched beside the products, read behind them
@@ -432,16 +436,18 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       cell(z, c1[c], g, hp);
       const int row = rb + oc16; const bool ok = oc16 < nvc[c];
       pst8(oq == 0 && ok ? (void*)(p.hsb[0] + hof(t + 1) + (size_t)row * HD + 16 * member + 4 * wave) : (void*)otrash, hp, local);
-      st16f(ok && !BEAM && p.gates[0] ? (void*)(p.gates[0] + (((size_t)t * B + row) * HD + ounit) * 4) : (void*)otrash, g);
-      st4f(ok && !BEAM ? (void*)(p.cs[0] + (size_t)(t + 1) * slot + (size_t)row * HD + ounit) : (void*)otrash, c1[c]);
+      if constexpr (!DEC) {
+        st16f(ok && p.gates[0] ? (void*)(p.gates[0] + (((size_t)t * B + row) * HD + ounit) * 4) : (void*)otrash, g);
+        st4f(ok ? (void*)(p.cs[0] + (size_t)(t + 1) * slot + (size_t)row * HD + ounit) : (void*)otrash, c1[c]);
+      }
     };
     // =================== P2: layer 2.  stores: publish + gates + cell state + the h half of [c ; h2] = 4
     auto P2 = [&](auto cc) {
       constexpr int c = decltype(cc)::value;
       unsigned char* const H1 = lds + (size_t)(c * 3 + 1) * OPB; unsigned char* const H2 = lds + (size_t)(c * 3 + 2) * OPB;
       const int rb = row0 + RC * c;
-      if constexpr (c == 0) pend_land<3>(p.hsb[0] + hof(t + 1), HD * 2, rb, rlim[c], H1, PA, olane, wave, member, local, p.err, 12, &s_dead, 0, &nretry[2 + c]);     // behind P1<1>
-      else pend_land<4>(p.hsb[0] + hof(t + 1), HD * 2, rb, rlim[c], H1, PA, olane, wave, member, local, p.err, 12, &s_dead, 0, &nretry[2 + c]);                       // behind P2<0>
+      if constexpr (c == 0) pend_land<S1>(p.hsb[0] + hof(t + 1), HD * 2, rb, rlim[c], H1, PA, olane, wave, member, local, p.err, 12, &s_dead, 0, &nretry[2 + c]);     // behind P1<1>
+      else pend_land<S2>(p.hsb[0] + hof(t + 1), HD * 2, rb, rlim[c], H1, PA, olane, wave, member, local, p.err, 12, &s_dead, 0, &nretry[2 + c]);                       // behind P2<0>
       CH_STAMP(10 + c);
       f32x4 z, g; u32x2 hp;
       auto mid2 = [&] {
@@ -458,8 +464,10 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       cell(z, c2[c], g, hp);
       const int row = rb + oc16; const bool ok = oc16 < nvc[c];
       pst8(oq == 0 && ok ? (void*)(p.hsb[1] + hof(t + 1) + (size_t)row * HD + 16 * member + 4 * wave) : (void*)otrash, hp, local);
-      st16f(ok && !BEAM && p.gates[1] ? (void*)(p.gates[1] + (((size_t)t * B + row) * HD + ounit) * 4) : (void*)otrash, g);
-      st4f(ok && !BEAM ? (void*)(p.cs[1] + (size_t)(t + 1) * slot + (size_t)row * HD + ounit) : (void*)otrash, c2[c]);
+      if constexpr (!DEC) {
+        st16f(ok && p.gates[1] ? (void*)(p.gates[1] + (((size_t)t * B + row) * HD + ounit) * 4) : (void*)otrash, g);
+        st4f(ok ? (void*)(p.cs[1] + (size_t)(t + 1) * slot + (size_t)row * HD + ounit) : (void*)otrash, c2[c]);
+      }
       st8(oq == 0 && ok ? (void*)(p.cat_b + cof(t) + (size_t)row * 2 * HD + HD + 16 * member + 4 * wave) : (void*)otrash, hp);               // JoinTable [c ; h_top], LSTM.lua:153
     };
     // =================== P3: attention of row `member` (its chain's phase only).  stores: owners publish c + a = 2, the others none
@@ -467,8 +475,8 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       constexpr int c = decltype(cc)::value;
       unsigned char* const H2 = lds + (size_t)(c * 3 + 2) * OPB;
       const int rb = row0 + RC * c;
-      if constexpr (c == 0) pend_land<4>(p.hsb[1] + hof(t + 1), HD * 2, rb, rlim[c], H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]);      // behind P2<1>
-      else { if (mych == 0) pend_land<2>(p.hsb[1] + hof(t + 1), HD * 2, rb, rlim[c], H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]);      // behind P3<0>
+      if constexpr (c == 0) pend_land<S2>(p.hsb[1] + hof(t + 1), HD * 2, rb, rlim[c], H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]);      // behind P2<1>
+      else { if (mych == 0) pend_land<S3>(p.hsb[1] + hof(t + 1), HD * 2, rb, rlim[c], H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]);      // behind P3<0>
              else pend_land<0>(p.hsb[1] + hof(t + 1), HD * 2, rb, rlim[c], H2, PA, olane, wave, member, local, p.err, 13, &s_dead, 0, &nretry[4 + c]); }
       CH_STAMP(12 + c);
       if constexpr (!DEC) {                                         // zx1 of the next step (LDS-DMA, older than the prefetch below: complete by the next counted wait)
@@ -565,16 +573,16 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
 #pragma unroll
       for (int w = 0; w < 4; ++w) { v0 += part[w * HD + 2 * tid]; v1 += part[w * HD + 2 * tid + 1]; }
       pst4(rvalid ? (void*)(p.cat_b + cof(t) + (size_t)arow * 2 * HD + 2 * ot) : (void*)otrash, sane(bfpair(v0, v1)), local);      // c of row `member`: units 2 tid, 2 tid + 1
-      st4f(rvalid && !BEAM && ot < T ? (void*)(p.a_all + ((size_t)t * B + arow) * T + ot) : (void*)otrash, av);
+      if constexpr (!DEC) st4f(rvalid && ot < T ? (void*)(p.a_all + ((size_t)t * B + arow) * T + ot) : (void*)otrash, av);
     };
     // =================== P4: out = tanh(W_c [c ; h2]), LSTM.lua:153-157.  stores: publish + the fp32 copy = 2 (+ the pre-fill behind chain 1)
     auto P4 = [&](auto cc) {
       constexpr int c = decltype(cc)::value;
       unsigned char* const F = lds + (size_t)(c * 3 + 0) * OPB; unsigned char* const H2 = lds + (size_t)(c * 3 + 2) * OPB;
       const int rb = row0 + RC * c;
-      if constexpr (c == 0) { if (mych == 1) pend_land<2>(p.cat_b + cof(t), HD * 4, rb, rlim[c], F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]);      // behind P3<1>
+      if constexpr (c == 0) { if (mych == 1) pend_land<S3>(p.cat_b + cof(t), HD * 4, rb, rlim[c], F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]);      // behind P3<1>
                               else pend_land<0>(p.cat_b + cof(t), HD * 4, rb, rlim[c], F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]); }
-      else pend_land<(DEC ? 5 : 2)>(p.cat_b + cof(t), HD * 4, rb, rlim[c], F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]);                              // behind P4<0> (DEC: + 3 partial logits)
+      else pend_land<S4>(p.cat_b + cof(t), HD * 4, rb, rlim[c], F, PA, olane, wave, member, local, p.err, 14, &s_dead, 0, &nretry[6 + c]);                              // behind P4<0> (DEC: + 3 partial logits)
       CH_STAMP(14 + c);
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       const unsigned char* src = (wave < 2 ? F : H2) + (256 * (wave & 1) + 8 * q) * 2 + (size_t)c16 * PA;   // k = 256 wave + 32 s: waves 0, 1 read c, waves 2, 3 read h2
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
       const int row = rb + oc16; const bool ok = wave == 0 && oc16 < nvc[c];
       const size_t o = hof(t + 1) + (size_t)row * HD + 16 * member + 4 * oq;
       pst8(ok ? (void*)(p.out_b + o) : (void*)otrash, u32x2{sane(bfpair(v[0], v[1])), sane(bfpair(v[2], v[3]))}, local);
-      st16f(ok && !BEAM ? (void*)(p.out + o) : (void*)otrash, v);
+      if constexpr (!DEC) st16f(ok ? (void*)(p.out + o) : (void*)otrash, v);
       if constexpr (DEC) {
         // projector (output_projector.lua:3-8) on fp32 out: this member's 16 units against its slice of W_o -> 16 rows x V partial logits, to the rows' owners
         if (wave == 0) *reinterpret_cast<f32x4*>(outs + c * 256 + c16 * 16 + 4 * q) = v;

@@ -475,11 +475,13 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0) the compiler can see: no wait of its own for the prologue loads inside the loop
 
+  [[maybe_unused]] u64 cst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cprev_ = __builtin_readcyclecounter();
   for (int it = it0; it < it1; ++it) {
     const int t = d.forward_dir ? T - 1 - it : it;
     const int tprev = d.forward_dir ? t + 1 : t - 1;
     const unsigned tag = p.epoch * 4096u + (unsigned)it;
     const int par = it & 1;
+    CL_STAMP(0);
     prefetch(it);                                                // this step's epilogue inputs -> LDS: older than the polls, landed when they have
     if (it > 0 && !dead) {
       // ---- partial d h (transposed: units x rows) for ALL units from this workgroup's own d z of the step before
@@ -497,6 +499,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
 #pragma unroll
           for (int j = 0; j < G; ++j) acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres[j][s], zb, acc[rt][j], 0, 0, 0);
         }
+      CL_STAMP(1);
       // ---- reduce-scatter: tile (wave G + j) belongs to member (wave G + j) / 4
 #pragma unroll
       for (int j = 0; j < G; ++j) {
@@ -513,6 +516,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
         }
       }
     }
+    CL_STAMP(2);
     cl_barrier();                                                // own partials are in LDS; everyone is done with abuf[(it-1)&1]  (LDS-only fences: __syncthreads() put s_waitcnt vmcnt(0) -- the acknowledgement of the granule stores above -- in front of the barrier, and the polls behind it)
     // ---- polls first (the other members' partial tiles, in batches of <= PB members), bulk stores behind the first batch
     constexpr int NO = G - 1, PB = (NO > 4 || (RT > 1 && NO > 2)) ? (RT > 1 ? 2 : 4) : (NO > 0 ? NO : 1);
@@ -543,10 +547,12 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
             for (int hf = 0; hf < 2; ++hf) pin(gr[kk][rt][hf]);
       };
       if (!live) break;
+      CL_STAMP(3);
       issue();
-      if (k0 == 0) { store_dz(tprev); wait_vm<NBULK>(); read_pre(cur); }   // (step 0 stores zeros to the slot it rewrites one step later: handled above)
+      if (k0 == 0) { store_dz(tprev); CL_STAMP(4); wait_vm<NBULK>(); read_pre(cur); }   // (step 0 stores zeros to the slot it rewrites one step later: handled above)
       else wait_vm<0>();
       settle();
+      CL_STAMP(5);
       if (k0 == 0) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) dh[rt] = cur.dh[rt];
@@ -579,6 +585,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) dh[rt] = cur.dh[rt];
     }
+    CL_STAMP(6);
     if (it == 0 && d.dh2) {                                      // model.lua:667,681: d h of the decoder's initial state joins the first processed step
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
@@ -614,8 +621,12 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
         *reinterpret_cast<u32x2*>(an + (size_t)(16 * rt + c16) * AP + (g * 64 + ul) * 2) = zz;
       }
     }
+    CL_STAMP(7);
     cl_barrier();                                                // d z(t) complete in LDS
   }
+#ifdef DC_DEBUG_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) for (int k = 0; k < 8; ++k) p.err[16 + 2048 + 1020 + k] = (int)(cst_[k] >> 4);
+#endif
   store_dz(d.forward_dir ? T - it1 : it1 - 1);
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) { const int row = row0 + RH * rt + c16; if (cok && row < B) *reinterpret_cast<f32x4*>(d.dc + (size_t)row * He + u0) = dcr[rt]; }
