@@ -35,5 +35,6 @@ rm -rf $O/stats $O/stats_c3s $O/stats_c2 $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 if [ -f $R/torch-attention-ocr_amd/aocr/libaocr_stamps.so ]; then
   AOCR_LIB=$R/torch-attention-ocr_amd/aocr/libaocr_stamps.so timeout 120 python3 tools/ch_stamp.py > $O/chain_stamps.txt 2>&1
   AOCR_LIB=$R/torch-attention-ocr_amd/aocr/libaocr_stamps.so timeout 120 python3 tools/debug/beam_stamp.py 5 2>&1 | grep -v "wid " >> $O/chain_stamps.txt
+  for w in c3 c5; do echo "--- encoder cluster kernels, $w shape" >> $O/chain_stamps.txt; AOCR_LIB=$R/torch-attention-ocr_amd/aocr/libaocr_stamps.so timeout 120 python3 tools/debug/enc_stamp.py $w 2>&1 | grep -v amdgpu >> $O/chain_stamps.txt; done
 fi
 tail -1 $O/bench_c3_bf16.json | cut -c1-300; cat $O/hbm_pmc.txt; head -20 $O/mfma_busy.txt

@@ -71,6 +71,16 @@ __device__ __forceinline__ void cl_dma16(const void* g, unsigned char* lds_base)
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(a) : "memory");
 }
+// Eight B fragments (16 bytes each, 64 bytes apart) in ONE asm statement: issued back to back, waited for once (dec_chain.hip's lds_read8) -- hipcc otherwise emits
+// read / wait / MFMAs per k-step (C5, G = 8: 2.4 k cycles for the 64 MFMAs of a step instead of ~1.2 k)
+struct ClFrag8 { bf16x8 v[8]; };
+__device__ __forceinline__ void cl_read8(ClFrag8& f, const unsigned char* p) {
+  const unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+  asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:64\n\tds_read_b128 %2, %8 offset:128\n\tds_read_b128 %3, %8 offset:192\n\t"
+               "ds_read_b128 %4, %8 offset:256\n\tds_read_b128 %5, %8 offset:320\n\tds_read_b128 %6, %8 offset:384\n\tds_read_b128 %7, %8 offset:448\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(f.v[0]), "=&v"(f.v[1]), "=&v"(f.v[2]), "=&v"(f.v[3]), "=&v"(f.v[4]), "=&v"(f.v[5]), "=&v"(f.v[6]), "=&v"(f.v[7]) : "v"(a) : "memory");
+}
 // workgroup barrier whose fences cover LDS only (no wait for outstanding global stores)
 __device__ __forceinline__ void cl_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -308,10 +318,21 @@ __global__ __launch_bounds__(256, 1) void enc_cl_fwd_kernel(EncClFwdArgs p) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int s2 = 0; s2 < KS; ++s2) {
-          const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hb + (size_t)(16 * rt + c16) * HP + (32 * s2 + 8 * q) * 2);   // B operand: column = batch row c16
+        for (int s8 = 0; s8 < KS; s8 += 8) {
+          if constexpr (KS % 8 == 0) {
+            ClFrag8 hv; cl_read8(hv, hb + (size_t)(16 * rt + c16) * HP + (32 * s8 + 8 * q) * 2);                             // B operand: column = batch row c16
 #pragma unroll
-          for (int g = 0; g < 4; ++g) acc[rt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres[g][s2], hv, acc[rt][g], 0, 0, 0);
+            for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) acc[rt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres[g][s8 + s2], hv.v[s2], acc[rt][g], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int s2 = s8; s2 < KS; ++s2) {
+              const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hb + (size_t)(16 * rt + c16) * HP + (32 * s2 + 8 * q) * 2);
+#pragma unroll
+              for (int g = 0; g < 4; ++g) acc[rt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres[g][s2], hv, acc[rt][g], 0, 0, 0);
+            }
+          }
         }
     }
     if (dead) break;
@@ -492,13 +513,13 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
         for (int j = 0; j < G; ++j) acc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       const unsigned char* ab = abuf + (size_t)((it - 1) & 1) * R * AP;
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
+      for (int rt = 0; rt < RT; ++rt) {
+        ClFrag8 zb; cl_read8(zb, ab + (size_t)(16 * rt + c16) * AP + (8 * q) * 2);                                           // column = batch row c16
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const bf16x8 zb = *reinterpret_cast<const bf16x8*>(ab + (size_t)(16 * rt + c16) * AP + (32 * s + 8 * q) * 2);   // column = batch row c16
+        for (int s = 0; s < 8; ++s)
 #pragma unroll
-          for (int j = 0; j < G; ++j) acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres[j][s], zb, acc[rt][j], 0, 0, 0);
-        }
+          for (int j = 0; j < G; ++j) acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres[j][s], zb.v[s], acc[rt][j], 0, 0, 0);
+      }
       CL_STAMP(1);
       // ---- reduce-scatter: tile (wave G + j) belongs to member (wave G + j) / 4
 #pragma unroll
