@@ -407,14 +407,16 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
   const int ul = 16 * wave + 4 * q, u0 = 64 * member + ul;      // epilogue: this lane's four hidden units (local / global), batch row c16
   float* const trash = reinterpret_cast<float*>(p.err + 16) + (threadIdx.x & 255) * 4;
 
-  // resident A fragments: this wave's G output tiles (A row = unit 16 (wave G + j) + c16), K = the workgroup's own 256 gate columns
+  // resident A fragments: this wave's G output tiles -- tile 4 j + wave, i.e. ONE tile for every destination member j (A row = unit 16 (4 j + wave) + c16), so every
+  // wave sends G - 1 tiles and keeps one (round 5; with tiles wave G .. wave G + G - 1 the wave whose tiles were the workgroup's own sent nothing and waited at the
+  // barrier for the three that sent four each) --, K = the workgroup's own 256 gate columns
   // k = gate * 64 + local unit  <->  column gate * He + 64 member + local unit of W^T [He][4He]
   bf16x8 wres[G][8];
 #pragma unroll
   for (int j = 0; j < G; ++j)
 #pragma unroll
     for (int s = 0; s < 8; ++s)
-      wres[j][s] = *reinterpret_cast<const bf16x8*>(d.wt + (size_t)(16 * (wave * G + j) + c16) * KG + (s >> 1) * He + 64 * member + 32 * (s & 1) + 8 * q);
+      wres[j][s] = *reinterpret_cast<const bf16x8*>(d.wt + (size_t)(16 * (4 * j + wave) + c16) * KG + (s >> 1) * He + 64 * member + 32 * (s & 1) + 8 * q);
 
   f32x4 dcr[RT]; float dbs[4][4];
 #pragma unroll
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
       x.dh[rt] = *reinterpret_cast<const f32x4*>(pl + 6 * 1024);
     }
   };
-  u64* const pb = p.pbuf + (size_t)(gid + p.gslot) * 2 * G * G * 4 * RT * 256;            // [parity][dest][src][tile][rt][lane][4 granules]
+  u64* const pb = p.pbuf + (size_t)(gid + p.gslot) * 2 * G * G * 4 * RT * 256;            // [parity][dest][src][tile][rt][half][lane][2 granules]
   const bool local = group_is_local<G>(p.xtab + (size_t)(gid + p.gslot) * 8, member, p.epoch, p.err) && !p.force_remote;
   const int it0 = p.it0, it1 = p.it1 > 0 ? p.it1 : T;          // this launch's chunk of the T iterations (see the forward kernel)
   f32x4 zprev[RT][4];                                            // d z of the step before ([gate][unit i]): stored to HBM one step late
@@ -521,18 +523,18 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
           for (int j = 0; j < G; ++j) acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres[j][s], zb.v[s], acc[rt][j], 0, 0, 0);
       }
       CL_STAMP(1);
-      // ---- reduce-scatter: tile (wave G + j) belongs to member (wave G + j) / 4
+      // ---- reduce-scatter: tile 4 j + wave belongs to member j, and to its wave `wave`
 #pragma unroll
       for (int j = 0; j < G; ++j) {
-        const int nt = wave * G + j, dm = nt >> 2, e = nt & 3;
+        const int dm = j, e = wave;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           if (dm == member) own[(e * RT + rt) * 64 + lane] = acc[rt][j];
           else {
-            u64* dst = pb + ((((size_t)(par * G + dm) * G + member) * 4 + e) * RT + rt) * 256 + lane * 4;
+            u64* dst = pb + ((((size_t)(par * G + dm) * G + member) * 4 + e) * RT + rt) * 256 + lane * 2;      // tile = [half][lane][2 granules]: each store instruction writes 1 KB contiguous
             const u32x4 g0 = {__float_as_uint(acc[rt][j][0]), tag, __float_as_uint(acc[rt][j][1]), tag};
             const u32x4 g1 = {__float_as_uint(acc[rt][j][2]), tag, __float_as_uint(acc[rt][j][3]), tag};
-            if (cok) { st_granules(dst, g0, local); st_granules(dst + 2, g1, local); }
+            if (cok) { st_granules(dst, g0, local); st_granules(dst + 128, g1, local); }
           }
         }
       }
@@ -552,11 +554,11 @@ __global__ __launch_bounds__(256, 1) void enc_cl_bwd_kernel(EncClBwdArgs p) {
 #pragma unroll
         for (int kk = 0; kk < PB; ++kk) {
           const int k = (k0 + kk) % (NO > 0 ? NO : 1), sm = k + (k >= member ? 1 : 0);   // the G-1 other members (straight-line: a tail batch repeats)
-          const u64* src = pb + ((((size_t)(par * G + member) * G + sm) * 4 + wave) * RT) * 256 + lane_v * 4;
+          const u64* src = pb + ((((size_t)(par * G + member) * G + sm) * 4 + wave) * RT) * 256 + lane_v * 2;
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) poll16(gr[kk][rt][hf], src + rt * 256 + hf * 2);
+            for (int hf = 0; hf < 2; ++hf) poll16(gr[kk][rt][hf], src + rt * 256 + hf * 128);
         }
       };
       auto settle = [&]() {
