@@ -166,7 +166,7 @@ def test_cotenant_across_decoder_chain_kernels(cuda, WGS, USEC):
     cluster status 0 and with EXACTLY the outputs of the undisturbed step (every exchanged dword either is the pattern or is final: nothing else may be read)."""
     co = _cotenant()
     cfg = dict(enc_hidden=256, enc_layers=1, dec_layers=2, input_feed=True)
-    m, O, ocfg, P, st, batch = make(cfg, B=256, W=256, maxlen=23, compute="bf16", max_decoder_l=24, max_beam=1)
+    m, O, ocfg, P, st, batch = make(cfg, B=256, W=256, maxlen=23, compute="bf16", max_decoder_l=24, max_beam=5)
     taps = ("logits", "outs", "ds_all", "dq_all", "dpre_all")
     m.train_forward_backward(batch)
     ref = {k: m.get_tensor(k).clone() for k in taps}
@@ -187,6 +187,13 @@ def test_cotenant_across_decoder_chain_kernels(cuda, WGS, USEC):
         lab = m.decode_device(*m._upload(batch), 1)[0]
         torch.cuda.synchronize()
         assert m.cluster_status() == 0 and torch.equal(lab, lab_ref), rep
+        # beam search on the chain kernel (six launches of <= 8 groups, token + parent words polled by every member): the same under the co-tenant
+        lab5_ref, sc5_ref = (x.clone() for x in m.decode_device(*m._upload(batch), 5)[:2])
+        torch.cuda.synchronize()
+        assert co.cotenant_launch(side.cuda_stream, scratch.data_ptr(), scratch.numel(), WGS, float(USEC), stamps.data_ptr()) == 0
+        lab5, sc5 = m.decode_device(*m._upload(batch), 5)[:2]
+        torch.cuda.synchronize()
+        assert m.cluster_status() == 0 and torch.equal(lab5, lab5_ref) and torch.equal(sc5, sc5_ref), rep
     m.shutdown()
 
 

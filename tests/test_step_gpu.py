@@ -573,6 +573,37 @@ def test_beam_decode_chain_kernel_matches_launch_chain(cuda, monkeypatch, B, W, 
     assert np.abs(a["gold"] - b["gold"]).max() < 2e-2 * max(1.0, np.abs(a["gold"]).max())
 
 
+@pytest.mark.parametrize("B,W,He", [(48, 100, 256), (21, 72, 256), (24, 160, 512)])
+def test_encoder_half_tiles_match_full_tiles(cuda, monkeypatch, B, W, He):
+    """Round 5: the encoder cluster kernels give a group 8 batch rows instead of 16 when twice the groups fit the chip (half the output bytes per compute unit;
+    columns 8..15 of every MFMA tile repeat column 7 and are neither stored nor published).  Same arithmetic per row: against 16-row groups (AOCR_ENC_RH16=1,
+    AOCR_ENC_BWD_RH=16) the encoder output, the logits and the loss must be BIT-identical, the gradients equal up to the order in which the bias sums and the
+    split-K partial sums meet; ragged last groups (B = 21) and He = 512 (8 members per group) included."""
+    cfg = dict(enc_hidden=He, enc_layers=1, dec_layers=2, input_feed=True)
+    out = {}
+    for knob in ("half", "full"):
+        monkeypatch.delenv("AOCR_ENC_RH16", raising=False); monkeypatch.delenv("AOCR_ENC_BWD_RH", raising=False)
+        if knob == "full":
+            monkeypatch.setenv("AOCR_ENC_RH16", "1"); monkeypatch.setenv("AOCR_ENC_BWD_RH", "16")
+        else:
+            monkeypatch.setenv("AOCR_ENC_BWD_RH", "8")
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=7, compute="bf16", max_decoder_l=8, max_beam=1)
+        loss = m.train_forward_backward(batch)
+        assert m.cluster_status() == 0
+        out[knob] = dict(loss=loss, ctx=m.get_tensor("context").clone(), logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(),
+                         grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.shutdown()
+    a, b = out["half"], out["full"]
+    assert torch.equal(a["ctx"], b["ctx"]) and torch.equal(a["logits"], b["logits"]) and a["loss"] == b["loss"]
+    worst = 0.0
+    for k in a["grads"]:
+        if k in ("cnn.conv3.b", "cnn.conv5.b", "cnn.conv7.b"):
+            continue
+        e = relerr(a["grads"][k], b["grads"][k]); worst = max(worst, e)
+        assert e < 1e-5, (k, e)
+    print(f"[parity] encoder 8-row groups vs 16-row groups B={B} He={He}: context / logits / loss bit-identical, worst gradient difference {worst:.2e}")
+
+
 @pytest.mark.parametrize("B,W,maxdec,beam", [(8, 100, 48, 5), (12, 72, 40, 3)])
 def test_beam_decode_chain_kernel_vs_oracle(cuda, B, W, maxdec, beam):
     """The BEAM variant of the chain kernel against the oracle's own beam search (O.decode_beam: model.lua:360-585 in fp64), not only against the
