@@ -33,9 +33,9 @@ constexpr int CH_BEAM_EXTRA = 2048;                                 // beam sear
 constexpr int CH_DEC_LDS = CH_FWD_LDS + 2560 + NCH * 1024 + NCH * 1024 + 10240;      // greedy decode: + W_o slice, out(t) of the member's units, token staging, the per-token gate-input table slice     // operands + K-split partial tiles + attention partial context + scores + the next step's gate inputs / tokens
 
 __device__ __forceinline__ unsigned sane(unsigned x) { return x == SENT ? 0xFFFEFFFFu : x; }
-__device__ __forceinline__ unsigned umax4(const u32x4& v) { return max(max(v[0], v[1]), max(v[2], v[3])); }
-__device__ __forceinline__ void ld4g(unsigned& v, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory"); }
-__device__ __forceinline__ void dpin1(unsigned& v) { asm volatile("" : "+v"(v)); }
+// unsigned maximum spelled out: the pattern test must never become a signed comparison (0xFFFFFFFF is -1), whatever overload set `max` finds
+__device__ __forceinline__ unsigned umax(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned umax4(const u32x4& v) { return umax(umax(v[0], v[1]), umax(v[2], v[3])); }
 __device__ __forceinline__ void pst16(void* p, u32x4 v, bool local) {
   if (local) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
   else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
@@ -82,7 +82,7 @@ __device__ __forceinline__ void pend_land(const void* src, int stride_bytes, int
   u32x4 g[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) g[j] = *reinterpret_cast<const u32x4*>(dst + (size_t)((wave + 4 * j + member) & (RC - 1)) * pitch + chunk0 + lane * 16);
-  unsigned mx = max(max(umax4(g[0]), umax4(g[1])), max(umax4(g[2]), umax4(g[3])));
+  unsigned mx = umax(umax(umax4(g[0]), umax4(g[1])), umax(umax4(g[2]), umax4(g[3])));
   if (__any(mx == SENT)) {
     int spins = 0;
 #pragma nounroll
@@ -100,7 +100,7 @@ __device__ __forceinline__ void pend_land(const void* src, int stride_bytes, int
       wait_vm<0>();
 #pragma unroll
       for (int j = 0; j < 4; ++j) g[j] = *reinterpret_cast<const u32x4*>(dst + (size_t)((wave + 4 * j + member) & (RC - 1)) * pitch + chunk0 + lane * 16);
-      mx = max(max(umax4(g[0]), umax4(g[1])), max(umax4(g[2]), umax4(g[3])));
+      mx = umax(umax(umax4(g[0]), umax4(g[1])), umax(umax4(g[2]), umax4(g[3])));
       if (!__any(mx == SENT)) break;
     }
 #ifdef DC_DEBUG_STAMPS
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
         wait_vm<0>();
         unsigned mx = 0;
 #pragma unroll
-        for (int sm = 0; sm < 32; ++sm) { asm volatile("" : "+v"(pv[sm])); mx = max(mx, __builtin_bit_cast(unsigned, pv[sm])); }
+        for (int sm = 0; sm < 32; ++sm) { asm volatile("" : "+v"(pv[sm])); mx = umax(mx, __builtin_bit_cast(unsigned, pv[sm])); }
         if (!__any(mx == SENT)) break;
         asm volatile("" : "+v"(spins));
         if (++spins > DC_SPIN_LIMIT) { if (olane == 0) { atomicExch(p.err, 16); s_dead = 1; } break; }
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256, 1) void dec_ch_fwd_kernel(DecClFwdArgs p) {
           for (int j = 0; j < 8; ++j)
             if (j < kb) {
 #pragma unroll
-              for (int sm = 0; sm < 8; ++sm) { asm volatile("" : "+v"(pv[j][sm])); mx = max(mx, __builtin_bit_cast(unsigned, pv[j][sm])); }
+              for (int sm = 0; sm < 8; ++sm) { asm volatile("" : "+v"(pv[j][sm])); mx = umax(mx, __builtin_bit_cast(unsigned, pv[j][sm])); }
             }
           if (!__any(mx == SENT)) break;
           asm volatile("" : "+v"(spins));
@@ -851,7 +851,7 @@ __device__ __forceinline__ void lds_read4(Frag4& f, const unsigned char* p) {
 __device__ __forceinline__ unsigned fmax8(const Frag8& f) {
   unsigned m = 0;
 #pragma unroll
-  for (int s = 0; s < 8; ++s) m = max(m, umax4(__builtin_bit_cast(u32x4, f.v[s])));
+  for (int s = 0; s < 8; ++s) m = umax(m, umax4(__builtin_bit_cast(u32x4, f.v[s])));
   return m;
 }
 
@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
       lds_barrier();
       {
         f32x2 x = *reinterpret_cast<const f32x2*>(dcs + 2 * ot);
-        if (__any(max(__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1])) == SENT)) {      // (this wave's half of the row: waves 0, 1 the first KB, 2, 3 the second)
+        if (__any(umax(__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1])) == SENT)) {      // (this wave's half of the row: waves 0, 1 the first KB, 2, 3 the second)
           int spins = 0;
 #pragma nounroll
           while (true) {
@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(256, 1) void dec_ch_bwd_kernel(DecClBwdArgs p) {
             wait_vm<0>();
             asm volatile("" : "+v"(v));
             x = f32x2{__builtin_bit_cast(float, (unsigned)v), __builtin_bit_cast(float, (unsigned)(v >> 32))};
-            if (!__any(max((unsigned)v, (unsigned)(v >> 32)) == SENT)) break;
+            if (!__any(umax((unsigned)v, (unsigned)(v >> 32)) == SENT)) break;
           }
         }
         const float h0 = (float)(bf16_t)x[0], h1 = (float)(bf16_t)x[1];
