@@ -2770,7 +2770,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_small_kernel(SmallArgs2<AL, BL, 
 // ---------------------------------------------------------------------------
 constexpr int STEP_PITCH = 144;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-template <int NT, int NW = 4> constexpr int step_lds_bytes() { return NW * (1 + NT) * 32 * STEP_PITCH; }
+template <int NT, int NW = 4, int MT = 1> constexpr int step_lds_bytes() { return NW * (MT + NT) * 32 * STEP_PITCH; }
 
 // global -> registers for one 64-deep chunk (kept as free functions with flat, statically indexed arrays of native
 // vector types: arrays captured by reference in lambdas / HIP's uint4 struct were demoted to LDS or scratch)
@@ -2827,78 +2827,96 @@ __device__ __forceinline__ void step_lwrite_b(unsigned char* lb, int br, int bp,
 // the weights and twice as many workgroups share the step: 128 -> 256 at Hd = 512, B = 256; the epilogue pairs lanes l and l^16).
 // NW waves share K (4, or 8 where the LDS allows): one workgroup per CU means the waves of ONE workgroup are all the memory-level
 // parallelism a CU has, and these launches are a load -> MFMA -> reduce latency chain.
-template <int NT, int GATES, class AL, class EP, int NW = 4>
+// MT (round 5): row tiles of 32 per workgroup.  MT = 2 at large M (the reference-default decoder: M = 400 rows, N = 4 x 1024 gate columns, K = 2048): every B (weight)
+// fragment read from LDS feeds two MFMAs and the weight tile is streamed by 7 row blocks instead of 13 -- these launches run at the chip's L2 -> CU rate
+// (266 MB per launch at ~7 TB/s), so bytes per launch is what counts.
+template <int NT, int GATES, class AL, class EP, int NW = 4, int MT = 1>
 __global__ __launch_bounds__(64 * NW) void gemm_step_kernel(SmallArgs2<AL, LoadKh2, EP> zz, int gate_stride) {
   constexpr bool AH = SrcBf16<AL>::v;                           // A operand read from its bf16 shadow
   constexpr int NA = AH ? 4 : 8;
   constexpr int E = 16 / NW;                                    // accumulator rows finished per thread
-  __shared__ __attribute__((aligned(16))) unsigned char lds[step_lds_bytes<NT, NW>()];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[step_lds_bytes<NT, NW, MT>()];
   const SmallArgs<AL, LoadKh2, EP>& g = zz.z[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * 32;
+  const int m0 = blockIdx.y * 32 * MT;
   const int n0 = GATES == 2 ? blockIdx.x * 16 : (GATES ? blockIdx.x * 32 : blockIdx.x * 32 * NT);
   const int K = g.K;
-  unsigned char* la = lds + wave * ((1 + NT) * 32 * STEP_PITCH);
-  unsigned char* lb = la + 32 * STEP_PITCH;
+  unsigned char* la = lds + wave * ((MT + NT) * 32 * STEP_PITCH);
+  unsigned char* lb = la + MT * 32 * STEP_PITCH;
   const int kw = ((K / 64 + NW - 1) / NW) * 64;             // this wave's K range (multiple of 64)
   const int kbeg = wave * kw, kend = min(K, kbeg + kw);
 
   // staging roles.  fp32 rows: lane -> row (lane>>4) + 4i, 16-byte piece (lane&15) = 4 k;  bf16 rows: row (lane>>3) + 8i, piece (lane&7) = 8 k
   const int ar = AH ? (lane >> 3) : (lane >> 4), ap = AH ? (lane & 7) : (lane & 15), br = lane >> 3, bp = lane & 7;
-  int arow[NA];
+  int arow[MT][NA];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) arow[i] = min(m0 + ar + (AH ? 8 : 4) * i, g.a.rows - 1);   // rows past the end: any valid row, result dropped
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) arow[mt][i] = min(m0 + 32 * mt + ar + (AH ? 8 : 4) * i, g.a.rows - 1);   // rows past the end: any valid row, result dropped
   const int brow0 = n0 + br;                                  // N % 32 == 0 so always valid
 
-  f32x16 acc[NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mt][j][e] = 0.f;
 
   // the epilogue's own operands (zx, c_prev, gates, ...) are requested now so that they arrive during the K loop
   // accumulator index i = E*wave + e of a 32x32 tile sits in row 8*(i/4) + 4h + i%4
   const int orow = m0 + 8 * ((E * wave) >> 2) + 4 * h + ((E * wave) & 3);
-  typename EP::Pre pre[E];
+  typename EP::Pre pre[MT][E];
 #pragma unroll
-  for (int e = 0; e < E; ++e) pre[e] = g.ep.prefetch(orow + e, GATES == 2 ? n0 + (r & 15) : n0 + r);
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < E; ++e) pre[mt][e] = g.ep.prefetch(orow + 32 * mt + e, GATES == 2 ? n0 + (r & 15) : n0 + r);
 
   if (kbeg < kend) {
-    typename std::conditional<AH, u32x4, float4>::type ra[NA]; u32x4 rb[NT * 4];
-    step_gload_a(g.a, kbeg, arow, ap, ra);
+    typename std::conditional<AH, u32x4, float4>::type ra[MT][NA]; u32x4 rb[NT * 4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) step_gload_a(g.a, kbeg, arow[mt], ap, ra[mt]);
     step_gload_b<NT, GATES>(g.b, kbeg, g.a.K0, brow0, gate_stride, bp, rb);
     for (int kc = kbeg; kc < kend; kc += 64) {
       __builtin_amdgcn_wave_barrier();
-      step_lwrite_a(la, ar, ap, ra);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) step_lwrite_a(la + mt * 32 * STEP_PITCH, ar, ap, ra[mt]);
       step_lwrite_b<NT>(lb, br, bp, rb);
       __builtin_amdgcn_wave_barrier();
       if (kc + 64 < kend) {
-        step_gload_a(g.a, kc + 64, arow, ap, ra);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) step_gload_a(g.a, kc + 64, arow[mt], ap, ra[mt]);
         step_gload_b<NT, GATES>(g.b, kc + 64, g.a.K0, brow0, gate_stride, bp, rb);
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(la + r * STEP_PITCH + 32 * s + 16 * h);
+        bf16x8 af[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(la + (mt * 32 + r) * STEP_PITCH + 32 * s + 16 * h);
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
           const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(lb + (ni * 32 + r) * STEP_PITCH + 32 * s + 16 * h);
-          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[ni], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr, acc[mt][ni], 0, 0, 0);
         }
       }
     }
   }
-  // cross-wave reduction: every wave parks its accumulators in its own (now idle) LDS region
+  // cross-wave reduction: every wave parks its accumulators in its own (now idle) LDS region -- one row tile at a time (the region holds NT tiles of 4 KB)
+  constexpr int WSTRIDE = (MT + NT) * 32 * STEP_PITCH / 4;    // floats between two waves' regions
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+  if (mt > 0) __syncthreads();                                // every thread is done reading the tile before
   __builtin_amdgcn_wave_barrier();
   float* red = reinterpret_cast<float*>(la);
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) red[(ni * 16 + e) * 64 + lane] = acc[ni][e];
+    for (int e = 0; e < 16; ++e) red[(ni * 16 + e) * 64 + lane] = acc[mt][ni][e];
   __syncthreads();
   // each thread finishes E elements (rows orow + e of column r) straight from LDS
   const float* r0 = reinterpret_cast<const float*>(lds);
-  constexpr int WSTRIDE = (1 + NT) * 32 * STEP_PITCH / 4;     // floats between two waves' regions
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     float v[NT];
@@ -2912,10 +2930,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_step_kernel(SmallArgs2<AL, LoadK
     }
     if constexpr (GATES == 2) {                                 // lane l < 16 of each 32-lane half: [i, o] here, [f, g] in lane l + 16
       float v4[4] = {v[0], __shfl_xor(v[0], 16, 64), v[1], __shfl_xor(v[1], 16, 64)};
-      if (r < 16) g.ep.template elem<4>(orow + e, n0 + r, 32, v4, pre[e]);
+      if (r < 16) g.ep.template elem<4>(orow + 32 * mt + e, n0 + r, 32, v4, pre[mt][e]);
     } else {
-      g.ep.template elem<NT>(orow + e, n0 + r, 32, v, pre[e]);
+      g.ep.template elem<NT>(orow + 32 * mt + e, n0 + r, 32, v, pre[mt][e]);
     }
+  }
   }
 }
 

@@ -325,7 +325,16 @@ static void launch_small_bf16_hh(hipStream_t s, int nz, const ARGS* z, int M, in
         hipLaunchKernelGGL((gemm_step_kernel<2, 2, decltype(z[0].a), decltype(z[0].ep)>), dim3(ncols / 16, cdiv(M, 32), nz), dim3(256), 0, s, zz, gate_stride);
       return;
     }
+    // two row tiles per workgroup where the single-tile grid is more than a round of the chip anyway (reference default He = 512: M = 400, 32 x 13 workgroups):
+    // the weight tile is streamed by half as many row blocks and every weight fragment feeds two MFMAs.  AOCR_NO_STEP_MT2=1: off
+    { const char* e = getenv("AOCR_NO_STEP_MT2");
+      if (!(e && e[0] == '1') && cdiv(ncols, 32) * cdiv(M, 64) * nz >= 200) {
+        hipLaunchKernelGGL((gemm_step_kernel<NT, 1, decltype(z[0].a), decltype(z[0].ep), 4, 2>), dim3(cdiv(ncols, 32), cdiv(M, 64), nz), dim3(256), 0, s, zz, gate_stride);
+        return;
+      } }
   }
+  // (measured and dropped: 64 x 64 tiles -- NT = 2, MT = 2, eight waves -- for the plain step products of the backward pass at M = 400: 336 workgroups instead of
+  //  1248, 350 MB instead of 640 MB per launch, decoder backward 2.27 -> 2.34 ms: there the many small workgroups are what hides the latency)
   if constexpr (NT == 1) {
     if (step_waves8() && step_waves16() && z[0].K >= 1024) {
       hipLaunchKernelGGL((gemm_step_kernel<NT, GATES ? 1 : 0, decltype(z[0].a), decltype(z[0].ep), 16>), grid, dim3(1024), 0, s, zz, gate_stride);
