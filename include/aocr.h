@@ -82,12 +82,15 @@ int aocr_model_set_stream(aocr_model* m, void* stream);
 /* Health of the whole-sequence ("cluster") kernels: the compute units that share a block of batch rows wait for each other with BOUNDED
  * spins; if a wait ever times out (it cannot unless another kernel keeps part of the chip busy for ~0.3 s) the kernel records a code,
  * finishes, and the step's results are invalid: aocr_sgd_step / aocr_adadelta_step then leave the parameters untouched (device-side
- * predicate on the same flag, no host sync), so a host that polls this call only every N steps loses steps, never its weights.
- * *code = 0: healthy; a non-zero code is cleared by the call (read and clear).
+ * predicate on the same flag, no host sync).  The optimizer call CONSUMES the code (round 6): it moves it to a second word that waits for
+ * the host, so exactly the step that timed out is skipped -- a host that polls this call only every N steps loses that one step, never its
+ * weights and never the healthy steps behind it (before round 6 every step up to the poll was dropped).  A code raised by a call that has
+ * no optimizer behind it (aocr_decode*) is moved aside the same way by the next aocr_train_forward_backward, so it cannot cancel that step.
+ * *code = 0: healthy; otherwise the most recent code not yet reported; cleared by the call (read and clear).
  * Under data parallelism the code is a GLOBAL decision (round 4): aocr_allreduce_grads sums a time-out flag with the exchange, and a rank whose own
  * kernels were healthy while a peer's were not reads 0x7e -- so every rank's optimizer skips the update and every host repeats the step together.
  * The optimizer call that skips an update also restores the BatchNorm running statistics to their values at the start of that step (device side, round 5):
- * a skipped step leaves NO trace, so the host may repeat the batch at once, later (polling every N steps) or never.
+ * a skipped step leaves NO trace in the model, so the host may repeat the batch at once, later (whenever it polls) or never.
  * A caller that sums the gradient buckets itself (aocr_stream_wait_grads) must also take the MAX over ranks of the status word (tap "cl_err"[0]) before
  * aocr_sgd_step, as aocr_allreduce_grads does inside the library; the Python mirror does (Model._exchange_timeout_flag).
  * Synchronises the model's stream.  No reference counterpart.

@@ -13,33 +13,31 @@ local tds = require 'tds'
 
 local DataGen = torch.class('DataGen')
 
+-- list file: one "<image path> <label>" per line, looked for as given and then under data_base_dir (data_gen.lua:29-37)
+local function open_list(base_dir, path)
+    for _, candidate in ipairs({path, paths.concat(base_dir, path)}) do
+        local f = io.open(candidate, 'r')
+        if f then return f end
+    end
+    log(string.format('Error: Data file %s not found ', path))
+    os.exit()
+end
+
 function DataGen:__init(data_base_dir, data_path, max_aspect_ratio, max_encoder_l_h, max_encoder_l_w, max_decoder_l)
-    self.imgH = 32
-    self.data_base_dir = data_base_dir
-    self.data_path = data_path
+    self.imgH, self.min_aspect_ratio = 32, 0.5
+    self.data_base_dir, self.data_path = data_base_dir, data_path
     self.max_aspect_ratio = max_aspect_ratio or math.huge
-    self.max_encoder_l_h = max_encoder_l_h or math.huge
-    self.max_encoder_l_w = max_encoder_l_w or math.huge
+    self.max_encoder_l_h, self.max_encoder_l_w = max_encoder_l_h or math.huge, max_encoder_l_w or math.huge
     self.max_decoder_l = max_decoder_l or math.huge
-    self.min_aspect_ratio = 0.5
-    local file, err = io.open(self.data_path, "r")
-    if err then
-        file, err = io.open(paths.concat(self.data_base_dir, self.data_path), "r")
-        if err then
-            log(string.format('Error: Data file %s not found ', self.data_path))
-            os.exit()
-        end
+    self.lines = tds.Hash()                                            -- off the Lua heap, as in the reference (millions of lines)
+    local n = 0
+    for line in open_list(data_base_dir, data_path):lines() do
+        n = n + 1
+        local fields = split(line)
+        self.lines[n] = tds.Vec({fields[1], fields[2]})
+        if n % 1000000 == 0 then log(string.format('%d lines read', n)) end
     end
-    self.lines = tds.Hash()
-    local idx = 0
-    for line in file:lines() do
-        idx = idx + 1
-        if idx % 1000000 == 0 then log(string.format('%d lines read', idx)) end
-        local filename, label = unpack(split(line))
-        self.lines[idx] = tds.Vec({filename, label})
-    end
-    self.cursor = 1
-    self.buffer = {}
+    self.cursor, self.buffer = 1, {}
 end
 
 function DataGen:shuffle() shuffle(self.lines) end

@@ -16,20 +16,10 @@
 
      Unexecuted in the build container (no Lua / Torch7 there); tests/abi_harness.cc performs this file's call sequence against
      the C ABI with no host framework in the process. ]]
-require 'nn'
-require 'nngraph'
-require 'hdf5'
-require 'cudnn'
-require 'optim'
-require 'paths'
-
-package.path = package.path .. ';src/?.lua' .. ';src/utils/?.lua' .. ';src/model/?.lua' .. ';src/optim/?.lua'
-require 'cnn'
-require 'LSTM'
-require 'output_projector'
-require 'criterion'
-require 'model_utils'
-require 'memory'
+-- the packages train.lua expects its model file to have loaded (model.lua:2-16), then the reference's own builders of the five nets
+for _, pkg in ipairs({'nn', 'nngraph', 'hdf5', 'cudnn', 'optim', 'paths'}) do require(pkg) end
+package.path = package.path .. ';src/?.lua;src/utils/?.lua;src/model/?.lua;src/optim/?.lua'
+for _, pkg in ipairs({'cnn', 'LSTM', 'output_projector', 'criterion', 'model_utils', 'memory'}) do require(pkg) end
 
 local ffi = require 'ffi'
 local A = require 'aocr_ffi'
@@ -38,11 +28,8 @@ local Dict = require 'dictionary'
 local model = torch.class('Model')
 
 function model:__init()
-    if logging ~= nil then
-        log = function(msg) logging:info(msg) end
-    else
-        log = print
-    end
+    -- the global `log` of the reference (model.lua:19-25): the logger train.lua created, else print
+    log = (logging ~= nil) and function(msg) logging:info(msg) end or print
 end
 
 -- ------------------------------------------------------------------------------------------------ parameter containers
@@ -161,101 +148,79 @@ function model:_device_to_nets()
     end
 end
 
--- ------------------------------------------------------------------------------------------------ model.lua:45-112
+-- ------------------------------------------------------------------------------------------------ model.lua:45-142
+-- The reference spells the configuration out field by field three times (load, create, the log block + the `config` copy of
+-- _build, model.lua:63-80, 86-98, 115-142).  Here it is ONE table: which fields the saved parameters fix, which a caller may
+-- override at load time (model.lua:72-75), and the line each one logs.  Field names, the `config` table a checkpoint carries and the
+-- log strings (typo of model.lua:115 included: downstream log parsers see the same text) are the reference's.
+local STRUCTURAL = {'dropout', 'encoder_num_hidden', 'encoder_num_layers', 'decoder_num_layers', 'target_vocab_size',
+                    'target_embedding_size', 'input_feed'}
+local RUNTIME = {'max_encoder_l', 'max_decoder_l', 'batch_size'}
+local LOGGED = {      -- {field, format}; order of model.lua:115-127
+    {'cnn_feature_size', 'cnn_featuer_size: %d'}, {'dropout', 'dropout: %f'}, {'encoder_num_hidden', 'encoder_num_hidden: %d'},
+    {'encoder_num_layers', 'encoder_num_layers: %d'}, {'decoder_num_hidden', 'decoder_num_hidden: %d'},
+    {'decoder_num_layers', 'decoder_num_layers: %d'}, {'target_vocab_size', 'target_vocab_size: %d'},
+    {'target_embedding_size', 'target_embedding_size: %d'}, {'max_encoder_l', 'max_encoder_l: %d'},
+    {'max_decoder_l', 'max_decoder_l: %d'}, {'input_feed', 'input_feed: %s'}, {'batch_size', 'batch_size: %d'},
+    {'prealloc', 'prealloc: %s'},
+}
+local SAVED = {'dropout', 'encoder_num_hidden', 'encoder_num_layers', 'decoder_num_hidden', 'decoder_num_layers', 'target_vocab_size',
+               'target_embedding_size', 'max_encoder_l', 'max_decoder_l', 'input_feed', 'batch_size', 'prealloc'}   -- model.lua:130-142
+
+-- structural fields from `fixed`; run-time fields from `caller` first, then from `recorded` (nil for a fresh model)
+local function adopt_config(self, fixed, caller, recorded)
+    for _, k in ipairs(STRUCTURAL) do self[k] = fixed[k] end
+    for _, k in ipairs(RUNTIME) do
+        local v = caller[k]
+        if v == nil and recorded then v = recorded[k] end
+        self[k] = v
+    end
+    self.cnn_feature_size = 512                                   -- conv7's maps, cnn.lua:39
+    self.decoder_num_hidden = 2 * self.encoder_num_hidden         -- model.lua:66,88: the decoder state is [h_fw ; h_bw]
+    self.prealloc = caller.prealloc
+    self.seed = caller.seed or 910820
+    preallocateMemory(caller.prealloc)
+end
+
 function model:load(model_path, config)
     config = config or {}
     assert(paths.filep(model_path), string.format('Model %s does not exist!', model_path))
-    local checkpoint = torch.load(model_path)
-    local nets, model_config = checkpoint[1], checkpoint[2]
-    preallocateMemory(config.prealloc)
-    self.cnn_model = nets[1]:double()
-    self.encoder_fw = nets[2]:double()
-    self.encoder_bw = nets[3]:double()
-    self.decoder = nets[4]:double()
-    self.output_projector = nets[5]:double()
-    self.global_step = checkpoint[3]
-    self.optim_state = checkpoint[4]
-    if self.optim_state == nil or self.optim_state.learningRate == nil then
-        self.optim_state = self.optim_state or {}
-        self.optim_state.learningRate = config.learning_rate                  -- train.lua:87 falls back to opt.learning_rate
-    end
-    self.cnn_feature_size = 512
-    self.dropout = model_config.dropout
-    self.encoder_num_hidden = model_config.encoder_num_hidden
-    self.encoder_num_layers = model_config.encoder_num_layers
-    self.decoder_num_hidden = self.encoder_num_hidden * 2
-    self.decoder_num_layers = model_config.decoder_num_layers
-    self.target_vocab_size = model_config.target_vocab_size
-    self.target_embedding_size = model_config.target_embedding_size
-    self.input_feed = model_config.input_feed
-    self.max_encoder_l = config.max_encoder_l or model_config.max_encoder_l
-    self.max_decoder_l = config.max_decoder_l or model_config.max_decoder_l
-    self.batch_size = config.batch_size or model_config.batch_size
-    self.prealloc = config.prealloc
-    self.seed = config.seed or 910820
+    local nets, saved_config, step, optim_state = unpack(torch.load(model_path), 1, 4)     -- the tuple of model.lua:720-725
+    adopt_config(self, saved_config, config, saved_config)
+    self.layers = {}
+    for i = 1, 5 do self.layers[i] = nets[i]:double() end                                  -- parameter containers only, never run
+    self.global_step = step
+    self.optim_state = optim_state or {}
+    if self.optim_state.learningRate == nil then self.optim_state.learningRate = config.learning_rate end   -- train.lua:87
     self:_build()
 end
 
 function model:create(config)
-    self.cnn_feature_size = 512
-    self.dropout = config.dropout
-    self.encoder_num_hidden = config.encoder_num_hidden
-    self.encoder_num_layers = config.encoder_num_layers
-    self.decoder_num_hidden = config.encoder_num_hidden * 2
-    self.decoder_num_layers = config.decoder_num_layers
-    self.target_vocab_size = config.target_vocab_size
-    self.target_embedding_size = config.target_embedding_size
-    self.max_encoder_l = config.max_encoder_l
-    self.max_decoder_l = config.max_decoder_l
-    self.input_feed = config.input_feed
-    self.batch_size = config.batch_size
-    self.prealloc = config.prealloc
-    self.seed = config.seed or 910820
-    preallocateMemory(config.prealloc)
+    adopt_config(self, config, config, nil)
     -- the reference's own constructors: fresh parameters are Torch7's module initialisation (nn.Linear / SpatialConvolution reset(),
     -- LookupTable N(0,1), BatchNorm weight U(0,1))
-    self.cnn_model = createCNNModel()
-    self.encoder_fw = createLSTM(self.cnn_feature_size, self.encoder_num_hidden, self.encoder_num_layers, self.dropout, false, false, false, nil, self.batch_size, self.max_encoder_l, 'encoder-fw')
-    self.encoder_bw = createLSTM(self.cnn_feature_size, self.encoder_num_hidden, self.encoder_num_layers, self.dropout, false, false, false, nil, self.batch_size, self.max_encoder_l, 'encoder-bw')
-    self.decoder = createLSTM(self.target_embedding_size, self.decoder_num_hidden, self.decoder_num_layers, self.dropout, true, self.input_feed, true, self.target_vocab_size, self.batch_size, self.max_encoder_l, 'decoder')
-    self.output_projector = createOutputUnit(self.decoder_num_hidden, self.target_vocab_size)
+    local F, He, Hd = self.cnn_feature_size, self.encoder_num_hidden, self.decoder_num_hidden
+    local function encoder(name)                                   -- model.lua:101-102
+        return createLSTM(F, He, self.encoder_num_layers, self.dropout, false, false, false, nil, self.batch_size, self.max_encoder_l, name)
+    end
+    self.layers = {
+        createCNNModel(), encoder('encoder-fw'), encoder('encoder-bw'),
+        createLSTM(self.target_embedding_size, Hd, self.decoder_num_layers, self.dropout, true, self.input_feed, true,
+                   self.target_vocab_size, self.batch_size, self.max_encoder_l, 'decoder'),              -- model.lua:103
+        createOutputUnit(Hd, self.target_vocab_size),
+    }
     self.global_step = 0
-    self.optim_state = {}
-    self.optim_state.learningRate = config.learning_rate
+    self.optim_state = {learningRate = config.learning_rate}
     self:_build()
 end
 
 -- ------------------------------------------------------------------------------------------------ model.lua:115-223
 function model:_build()
-    log(string.format('cnn_featuer_size: %d', self.cnn_feature_size))
-    log(string.format('dropout: %f', self.dropout))
-    log(string.format('encoder_num_hidden: %d', self.encoder_num_hidden))
-    log(string.format('encoder_num_layers: %d', self.encoder_num_layers))
-    log(string.format('decoder_num_hidden: %d', self.decoder_num_hidden))
-    log(string.format('decoder_num_layers: %d', self.decoder_num_layers))
-    log(string.format('target_vocab_size: %d', self.target_vocab_size))
-    log(string.format('target_embedding_size: %d', self.target_embedding_size))
-    log(string.format('max_encoder_l: %d', self.max_encoder_l))
-    log(string.format('max_decoder_l: %d', self.max_decoder_l))
-    log(string.format('input_feed: %s', self.input_feed))
-    log(string.format('batch_size: %d', self.batch_size))
-    log(string.format('prealloc: %s', self.prealloc))
-
+    self.cnn_model, self.encoder_fw, self.encoder_bw, self.decoder, self.output_projector = unpack(self.layers, 1, 5)
     self.config = {}
-    self.config.dropout = self.dropout
-    self.config.encoder_num_hidden = self.encoder_num_hidden
-    self.config.encoder_num_layers = self.encoder_num_layers
-    self.config.decoder_num_hidden = self.decoder_num_hidden
-    self.config.decoder_num_layers = self.decoder_num_layers
-    self.config.target_vocab_size = self.target_vocab_size
-    self.config.target_embedding_size = self.target_embedding_size
-    self.config.max_encoder_l = self.max_encoder_l
-    self.config.max_decoder_l = self.max_decoder_l
-    self.config.input_feed = self.input_feed
-    self.config.batch_size = self.batch_size
-    self.config.prealloc = self.prealloc
-    if self.optim_state == nil then self.optim_state = {} end
-    self.layers = {self.cnn_model, self.encoder_fw, self.encoder_bw, self.decoder, self.output_projector}
+    for _, e in ipairs(LOGGED) do log(string.format(e[2], (e[2]:sub(-1) == 's') and tostring(self[e[1]]) or self[e[1]])) end
+    for _, k in ipairs(SAVED) do self.config[k] = self[k] end
+    self.optim_state = self.optim_state or {}
 
     -- the widest crop the workspace is sized for: T = W/4 - 1 <= max_encoder_l (the reference clones max_encoder_l cells, model.lua:172-173)
     self.max_img_w = 4 * (self.max_encoder_l + 1)
@@ -396,34 +361,24 @@ end
 
 -- ------------------------------------------------------------------------------------------------ model.lua:708-731
 function model:vis(output_dir)
-    self.visualize = true
-    self.visualize_path = paths.concat(output_dir, 'results.txt')
-    local file, err = io.open(self.visualize_path, "w")
-    self.visualize_file = file
-    if err then
-        log(string.format('Error: visualize file %s cannot be created', self.visualize_path))
-        self.visualize = false
-        self.visualize_file = nil
-    end
+    local path = paths.concat(output_dir, 'results.txt')
+    local file = io.open(path, 'w')
+    self.visualize_path, self.visualize_file, self.visualize = path, file, file ~= nil
+    if not file then log(string.format('Error: visualize file %s cannot be created', path)) end
 end
 
 function model:save(model_path)
     self:_device_to_nets()
-    for i = 1, #self.layers do
-        self.layers[i]:clearState()
-    end
-    torch.save(model_path, {{self.cnn_model, self.encoder_fw, self.encoder_bw, self.decoder, self.output_projector}, self.config, self.global_step, self.optim_state})
+    for _, net in ipairs(self.layers) do net:clearState() end
+    torch.save(model_path, {self.layers, self.config, self.global_step, self.optim_state})   -- {5 nets, config, step, optim state}: what model:load reads
 end
 
+local DEVICE_BUFFERS = {'params_dev', 'grads_dev', 'bn_dev', 'ws_dev', 'scal_dev', 'images_dev', 'targets_dev', 'targets_eval_dev', 'labels_dev',
+                        'scores_dev', 'gold_dev', 'dist_dev', 'tlen_dev', 'tge_pad_dev'}
 function model:shutdown()
-    if self.visualize_file then
-        self.visualize_file:close()
-    end
-    if self.handle ~= nil then
-        A.lib.aocr_model_destroy(self.handle); self.handle = nil
-    end
-    for _, k in ipairs({'params_dev', 'grads_dev', 'bn_dev', 'ws_dev', 'scal_dev', 'images_dev', 'targets_dev', 'targets_eval_dev', 'labels_dev',
-                        'scores_dev', 'gold_dev', 'dist_dev', 'tlen_dev', 'tge_pad_dev'}) do
+    if self.visualize_file then self.visualize_file:close(); self.visualize_file = nil end
+    if self.handle ~= nil then A.lib.aocr_model_destroy(self.handle); self.handle = nil end
+    for _, k in ipairs(DEVICE_BUFFERS) do
         if self[k] then self[k]:free(); self[k] = nil end
     end
 end

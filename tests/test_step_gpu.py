@@ -297,7 +297,8 @@ def test_halo_four_wave_kernel_matches_eight_wave_kernel(cuda, monkeypatch, B, W
 
 @pytest.mark.parametrize("He,B,W,Le", [(64, 16, 40, 1), (256, 32, 72, 1), (128, 16, 36, 1), (64, 16, 44, 2), (256, 16, 36, 2),
                                         (64, 16, 800, 1),           # W = 800: T = 199 steps (BASELINE C4 upper width)
-                                        (512, 16, 100, 1), (512, 40, 52, 2), (256, 21, 60, 1), (128, 70, 36, 1)])   # He = 512; ragged batches
+                                        (512, 16, 100, 1), (512, 40, 52, 2), (256, 21, 60, 1), (128, 70, 36, 1),   # He = 512; ragged batches
+                                        (128, 24, 36, 3)])          # B mod 16 in 1..8 with stacked layers: the 8-row launches' slot offsets (4 ceil(B/16) per layer) exceed 2 ceil(B/8)
 def test_seq_encoder_kernels_match_step_kernels(cuda, monkeypatch, He, B, W, Le):
     """The whole-sequence BiLSTM encoder kernels against the per-step kernels on the same bf16 operands (only fp32 summation order
     differs).  Two families: CLUSTER kernels (rnn_cluster.hip: He/64 CUs share 16 rows, recurrent weights resident in registers,
@@ -1079,7 +1080,7 @@ def test_cluster_kernels_remote_exchange_mode(cuda, monkeypatch, p):
 def test_update_is_skipped_when_a_cluster_kernel_timed_out(cuda):
     """include/aocr.h (aocr_cluster_status): a whole-sequence kernel whose bounded wait expired leaves a non-zero code; the step's
     gradients are invalid, and aocr_sgd_step / aocr_adadelta_step must then leave the parameters untouched (device-side predicate, no
-    host sync) until the host has read -- and thereby cleared -- the code.  The code is injected here (a real timeout needs a co-tenant)."""
+    host sync) for THAT step.  The code is injected here (a real timeout needs a co-tenant)."""
     import ctypes as C
     import aocr
     from aocr import check, lib
@@ -1102,17 +1103,36 @@ def test_update_is_skipped_when_a_cluster_kernel_timed_out(cuda):
     # the optimizer call that skips the update also takes the step's move of the running statistics back (device side),
     # so a repeat of the batch moves them exactly once whenever the host polls the status -- and a host that never repeats loses nothing else
     assert torch.equal(m.bn_state, bn0), "the skipped step's move of the BatchNorm running statistics was not taken back"
-    m.train_forward_backward(batch)                                 # the host has not polled yet: the next step is skipped as well, and restored as well
-    m.adadelta_step()
-    torch.cuda.synchronize()
-    assert torch.equal(m.params, before) and torch.equal(m.bn_state, bn0)
-    assert m.cluster_status() == 23 and m.cluster_status() == 0     # read and clear
-    m.train_forward_backward(batch)                                 # the repeat: a clean step moves them once
+    # round 6: the optimizer call CONSUMES the code -- only the step that timed out is skipped, however late the host polls
+    # (the code waits for the host in a sticky word); before, every step up to the poll was dropped
+    assert int(flag.item()) == 0, "the skipping optimizer call did not consume the step's code"
+    m.train_forward_backward(batch)                                 # the host has not polled yet: a healthy step
     torch.cuda.synchronize()
     assert torch.equal(m.bn_state, bn_moved)
     m.sgd_step(lr=0.1)
     torch.cuda.synchronize()
-    assert not torch.equal(m.params, before)
+    after1 = m.params.clone()
+    assert not torch.equal(after1, before), "a healthy step behind an unpolled time-out was dropped"
+    assert m.cluster_status() == 23 and m.cluster_status() == 0     # the late poll still reports the skipped step; read and clear
+    # the same through the fused Adadelta pass
+    m.train_forward_backward(batch); bn1 = m.bn_state.clone()
+    m.train_forward_backward(batch)
+    flag.fill_(24)
+    m.adadelta_step()
+    torch.cuda.synchronize()
+    assert torch.equal(m.params, after1) and torch.equal(m.bn_state, bn1)
+    m.train_forward_backward(batch); m.adadelta_step()
+    torch.cuda.synchronize()
+    assert not torch.equal(m.params, after1)
+    assert m.cluster_status() == 24 and m.cluster_status() == 0
+    # a code no optimizer call consumed (a decode call's time-out: decode never updates) must not cancel the NEXT training step: the step's
+    # prologue moves it to the sticky word
+    flag.fill_(31)
+    p0 = m.params.clone()
+    m.train_forward_backward(batch); m.sgd_step(lr=0.1)
+    torch.cuda.synchronize()
+    assert not torch.equal(m.params, p0), "a stale decode-call code cancelled a healthy training step"
+    assert m.cluster_status() == 31 and m.cluster_status() == 0
     with pytest.raises(RuntimeError):
         flag.fill_(11); m.check_health()
     m.shutdown()

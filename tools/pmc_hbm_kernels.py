@@ -1,5 +1,5 @@
 """HBM-side traffic per launch of the bandwidth-bound kernels bench.py lists under `hbm_kernels`, from the two rocprofv3 --pmc passes
-(FETCH_SIZE, WRITE_SIZE) of the bench command (tools/r04_profiles.sh).  Counters are in KB; FETCH_SIZE is doubled (gfx950 reports half the
+(FETCH_SIZE, WRITE_SIZE) of the bench command (tools/round_profiles.sh).  Counters are in KB; FETCH_SIZE is doubled (gfx950 reports half the
 bytes of a 16-B-per-lane coalesced read stream: /opt/skills/guides/MI355X_MICROARCH.md, HBM section) -- for the kernels here whose loads are
 narrower (conv1: 4-byte image loads) the doubling is an upper bound; Infinity-Cache hits are counted, so this is L2-miss traffic.
     python tools/pmc_hbm_kernels.py fetch_counter_collection.csv write_counter_collection.csv kernel_trace.csv"""

@@ -1,5 +1,5 @@
 """MFMA-busy fraction per kernel from one rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES pass of the bench command
-(tools/r04_profiles.sh): python tools/pmc_mfma_summary.py counter_collection.csv"""
+(tools/round_profiles.sh): python tools/pmc_mfma_summary.py counter_collection.csv"""
 import collections
 import csv
 import sys

@@ -1,7 +1,12 @@
 #!/bin/bash
-# Round-5 profile artefacts (run via gpurun from the repo root): everything lands in gpurun_out/prof5/; copy the summaries into profiles/r05_*.
+# Profile artefacts of a round (run via gpurun from the repo root: `bash tools/round_profiles.sh r06`): everything lands in gpurun_out/prof_<tag>/;
+# copy the summaries into profiles/<tag>_*.
 # Every pass is bounded by its own `timeout`; the program follows `--` directly (python3 bench.py ...), counters are collected in passes of their own.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof5; rm -rf $O; mkdir -p $O
+set -u
+TAG=${1:?usage: round_profiles.sh <round tag, e.g. r06>}
+R=${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (this script runs on the GPU box, through gpurun)}
+[ -f "$R/bench.py" ] || { echo "no bench.py under $R" >&2; exit 2; }
+O="$R/gpurun_out/prof_$TAG"; rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py"
 SHORT="--steps 2 --warmup 1 --no-cpu-baseline --decode-steps 0 --no-secondary --sustain-seconds 0"
@@ -16,7 +21,7 @@ for w in c2 c3s c4 c5 ref; do
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -- $B --workload c2 --compute f32 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --decode-steps 0 --sustain-seconds 0 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3s -- $B --workload c3s --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --decode-steps 0 --sustain-seconds 0 > /dev/null 2>&1
-cd $R
+cd "$R"
 # what the MFMA pipe sustains on resident random fragments, after 5000 warm-up launches (bench.py reads the best "MFMA on resident random fragments" row)
 (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../torch-attention-ocr_amd/csrc gemm4w.hip -o gemm4w 2>/dev/null; timeout 300 ./gemm4w 5000 quick > $O/gemm4w_steady.txt 2>&1)
 f=$(ls $O/pmc_fetch/*/*counter_collection.csv | head -1); w=$(ls $O/pmc_write/*/*counter_collection.csv | head -1); mf=$(ls $O/pmc_mfma/*/*counter_collection.csv | head -1)

@@ -243,10 +243,12 @@ int aocr_cluster_status(aocr_model* m, int32_t* code) {
   REQUIRE(m && code, "NULL argument");
   *code = 0;
   if (!m->cl_err) return 0;
-  if (hipMemcpyAsync(code, m->cl_err, sizeof(int32_t), hipMemcpyDeviceToHost, m->s) != hipSuccess || hipStreamSynchronize(m->s) != hipSuccess)
+  int32_t w[16] = {0};           // word 0: a code no optimizer call has consumed yet (a decode call's, or feval without an update); CL_ERR_STICKY: the last code an optimizer call skipped its update on
+  if (hipMemcpyAsync(w, m->cl_err, sizeof(w), hipMemcpyDeviceToHost, m->s) != hipSuccess || hipStreamSynchronize(m->s) != hipSuccess)
     return fail("aocr_cluster_status: %s", hipGetErrorString(hipGetLastError()));
+  *code = w[CL_ERR_STICKY] != 0 ? w[CL_ERR_STICKY] : w[0];
   if (*code != 0) {
-    hipMemsetAsync(m->cl_err, 0, sizeof(int32_t), m->s);      // read and clear: the next call reports the steps after this one
+    hipMemsetAsync(m->cl_err, 0, sizeof(int32_t), m->s); hipMemsetAsync(m->cl_err + CL_ERR_LATCH, 0, 2 * sizeof(int32_t), m->s);      // read and clear: the next call reports the steps after this one
     // (the skipped step's move of the BatchNorm running statistics was taken back by the optimizer call that skipped the update --
     //  sgd_update_kernel / adadelta_kernel restore the snapshot of step_prologue -- so a repeat of the batch moves them exactly once,
     //  whenever the host polls)

@@ -167,7 +167,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     // one set of group slots per layer: the layers of a stacked encoder run concurrently (layer wavefront, encoder_forward)
     m->cl_xbytes = m->Le * enc_cluster_xbuf_bytes((int)B, (int)He); m->cl_pbytes = m->Le * enc_cluster_pbuf_bytes((int)B, (int)He);
     m->cl_xbuf = a.get<unsigned long long>(m->cl_xbytes / 8); m->cl_pbuf = a.get<unsigned long long>(m->cl_pbytes / 8);
-    m->cl_tbytes = ((size_t)m->Le * 2 * ((B + 7) / 8) * 8 + 64) * 8;      // (8-row groups of the forward kernel: twice the slots)
+    m->cl_tbytes = ((size_t)m->Le * 4 * ((B + 15) / 16) * 8 + 64) * 8;    // a layer's 8-row launches start at slot l * 4 * ceil(B / 16) (enc_cluster_forward: gslot * 2) and use 2 * ceil(B / 8) <= 4 * ceil(B / 16) of them
     m->cl_xtab = a.get<unsigned long long>(m->cl_tbytes / 8);      // XCC ids of the members of every group
     m->cl_err = a.get<int>(16 + 256 * 8 + 4096);                 // error flag + the trash slots rows >= B store to + a debugging timeline
     m->bn_snap = a.get<float>(2 * (256 + 512 + 512));            // aocr_bn_state_count() floats
@@ -1075,14 +1075,14 @@ void step_prologue(aocr_model* m, size_t grad_bytes) {             // grad_bytes
   auto ev = [](hipEvent_t& e) { return e || hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
   // (bf16 mode only: in exact-fp32 mode the same move -- gradient zeroing and the 16 per-step weight transposes beside the forward pass -- measured SLOWER, C2 7.52 -> 7.74 ms:
   //  the forward pass there is a chain of ~150 small dependent launches, and the side stream's launches get in their way)
-  const size_t bn_bytes = (size_t)2 * (256 + 512 + 512) * sizeof(float);
+  const int bn_n = 2 * (256 + 512 + 512);
   const bool side = m->bf16 && !m->prof_on && !getenv("AOCR_NO_SIDE_WGRAD") && !env_on("AOCR_NO_SIDE_PROLOGUE") && side_create(m) && ev(m->zero_done) && ev(m->shadow_done) && ev(m->tab_done);
   if (!side) {
-    if (grad_bytes) { hipMemsetAsync(m->grads, 0, grad_bytes, m->s); if (m->bn_snap) hipMemcpyAsync(m->bn_snap, m->bn_state, bn_bytes, hipMemcpyDeviceToDevice, m->s); }
+    if (grad_bytes) { hipMemsetAsync(m->grads, 0, grad_bytes, m->s); if (m->bn_snap) step_snapshot(m->s, m->bn_state, m->bn_snap, bn_n, m->cl_err); }
     return;
   }
   hipEventRecord(m->side_go, m->s); hipStreamWaitEvent(m->side, m->side_go, 0);       // behind whatever wrote the parameters on the model's stream
-  if (grad_bytes && m->bn_snap && m->shadow_host.empty()) hipMemcpyAsync(m->bn_snap, m->bn_state, bn_bytes, hipMemcpyDeviceToDevice, m->s);
+  if (grad_bytes && m->bn_snap && m->shadow_host.empty()) step_snapshot(m->s, m->bn_state, m->bn_snap, bn_n, m->cl_err);
   if (!m->shadow_host.empty()) {
     // conv2's taps first, with an event of their own: conv2 starts as soon as conv1 is done (the rest of the table -- 100 MB of traffic -- runs under conv2
     // and is joined in front of conv3): 25 us off the head of the step at C3, where conv2 waited for the whole table and the cross-stream hand-over
@@ -1093,7 +1093,7 @@ void step_prologue(aocr_model* m, size_t grad_bytes) {             // grad_bytes
       shadow_jobs(m->side, m->shadow_dev, (int)m->shadow_host.size(), m->shadow_tiles - m->shadow_tiles_conv2, m->shadow_tiles_conv2);
     } else shadow_jobs(m->side, m->shadow_dev, (int)m->shadow_host.size(), m->shadow_tiles);
     // snapshot of the running statistics (10 KB; joined with the shadows in front of the first BatchNorm layer, behind conv2's taps so that it delays nothing)
-    if (grad_bytes && m->bn_snap) hipMemcpyAsync(m->bn_snap, m->bn_state, bn_bytes, hipMemcpyDeviceToDevice, m->side);
+    if (grad_bytes && m->bn_snap) step_snapshot(m->side, m->bn_state, m->bn_snap, bn_n, m->cl_err);
     hipEventRecord(m->shadow_done, m->side); m->shadow_pending = true; m->shadow2_pending = split;
   }
   if (grad_bytes) { hipMemsetAsync(m->grads, 0, grad_bytes, m->side); hipEventRecord(m->zero_done, m->side); m->zero_pending = true; }

@@ -197,10 +197,12 @@ void copy2d_pair(hipStream_t s, const float* s0, const float* s1, int64_t lds, f
 struct DecInitArgs { float* c0[4]; float* h0[4]; bf16_t* hb[4]; float* feed0; bf16_t* outb; const float *cfw, *cbw, *hfw, *hbw; int B, He, Hd, Ld, copy_h; };
 void dec_init(hipStream_t s, const DecInitArgs& a);              // the decoder's initial state in one launch (ops_misc.hip)
 void sgd_clip_update(hipStream_t s, float* params, float* grads, const int64_t* group_off /*6 host values*/, float lr,
-                     float clip, float* norms_out, void* scratch, const int* skip = nullptr,
-                     float* bn_state = nullptr, const float* bn_snap = nullptr, int bn_n = 0);   // *skip != 0: no update, and bn_state <- bn_snap (the step's move of the running statistics is taken back)
+                     float clip, float* norms_out, void* scratch, int* err = nullptr,
+                     float* bn_state = nullptr, const float* bn_snap = nullptr, int bn_n = 0);   // err = the time-out word block (cl_err): err[0] != 0: no update, bn_state <- bn_snap (the step's move of the running statistics is taken back), and the code moves to err[CL_ERR_STICKY]
+constexpr int CL_ERR_LATCH = 12, CL_ERR_STICKY = 13;              // words of the cl_err block (0: step in flight, 1..4 encoder diagnostics, 8..11 exchange scratch, 16..: trash slots)
+void step_snapshot(hipStream_t s, const float* bn_state, float* bn_snap, int n, int* err);        // start of a training step (ops_misc.hip)
 size_t sgd_scratch_bytes();
-void adadelta_update(hipStream_t s, float* params, float* grads, float* var, float* acc, int64_t n, float rho, float eps, float wd, const int* skip = nullptr,
+void adadelta_update(hipStream_t s, float* params, float* grads, float* var, float* acc, int64_t n, float rho, float eps, float wd, int* err = nullptr,
                      float* bn_state = nullptr, const float* bn_snap = nullptr, int bn_n = 0);
 // one 2-D piece of the per-step bf16 weight shadow refresh (shadow_jobs_kernel); tile0 = first 32x32 tile of the piece, tx = tiles per row
 struct ShadowJob { const float* w; bf16_t* wb; bf16_t* wtb; int64_t ld, ldb, ldt; int R, C, tile0, tx; };

@@ -1809,8 +1809,28 @@ __global__ __launch_bounds__(256) void sgd_sumsq_kernel(const float* __restrict_
     part[((int64_t)grp * 2 + 1) * SGD_BLOCKS + blockIdx.x] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
   }
 }
-__global__ void sgd_scale_kernel(const double* __restrict__ part, float clip, float* scale, float* norms) {
+// The time-out word of the whole-sequence kernels (cl_err, include/aocr.h: aocr_cluster_status): word 0 = code of the step in flight, CL_ERR_LATCH = the
+// decision THIS optimizer call acts on, CL_ERR_STICKY = the last code the host has not read yet.  The optimizer consumes word 0 (round 6):
+// only the step that timed out is skipped, whenever the host happens to poll.
+__device__ __forceinline__ void cl_err_latch(int* err) {
+  const int c = err[0];
+  err[CL_ERR_LATCH] = c;
+  if (c != 0) { err[CL_ERR_STICKY] = c; err[0] = 0; }
+}
+__global__ void cl_err_latch_kernel(int* err) { cl_err_latch(err); }
+// start of a training step: snapshot of the BatchNorm running statistics (an optimizer call that skips its update restores it) and carry of a code no
+// optimizer call has consumed -- a decode call's -- into the sticky word, so that it cannot cancel this step's update
+__global__ __launch_bounds__(256) void step_snapshot_kernel(const float* __restrict__ bn_state, float* __restrict__ bn_snap, int n, int* err) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) bn_snap[i] = bn_state[i];
+  if (i == 0 && err && err[0] != 0) { err[CL_ERR_STICKY] = err[0]; err[0] = 0; }
+}
+void step_snapshot(hipStream_t s, const float* bn_state, float* bn_snap, int n, int* err) {
+  hipLaunchKernelGGL(step_snapshot_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, bn_state, bn_snap, n, err);
+}
+__global__ void sgd_scale_kernel(const double* __restrict__ part, float clip, float* scale, float* norms, int* err) {
   const int grp = blockIdx.x, lane = threadIdx.x;               // one wave per group
+  if (err && grp == 0 && lane == 0) cl_err_latch(err);          // (this launch sits between the last kernel that can raise the code and the update that reads the latch)
   double sp = 0, sg = 0;
   for (int i = lane; i < SGD_BLOCKS; i += 64) { sp += part[((int64_t)grp * 2) * SGD_BLOCKS + i]; sg += part[((int64_t)grp * 2 + 1) * SGD_BLOCKS + i]; }
   sp = wave_sum_d(sp); sg = wave_sum_d(sg);
@@ -1844,11 +1864,12 @@ __global__ __launch_bounds__(256) void sgd_update_kernel(float* __restrict__ p, 
   }
 }
 void sgd_clip_update(hipStream_t s, float* params, float* grads, const int64_t* group_off, float lr, float clip, float* norms_out,
-                     void* scratch, const int* skip, float* bn_state, const float* bn_snap, int bn_n) {
+                     void* scratch, int* err, float* bn_state, const float* bn_snap, int bn_n) {
+  const int* skip = err ? err + CL_ERR_LATCH : nullptr;
   GroupOff go; for (int i = 0; i < 6; ++i) go.o[i] = group_off[i];
   double* part = (double*)scratch; float* scale = (float*)(part + 5 * 2 * SGD_BLOCKS);
   hipLaunchKernelGGL(sgd_sumsq_kernel, dim3(SGD_BLOCKS, 5), dim3(256), 0, s, params, grads, go, part);
-  hipLaunchKernelGGL(sgd_scale_kernel, dim3(5), dim3(64), 0, s, part, clip, scale, norms_out);
+  hipLaunchKernelGGL(sgd_scale_kernel, dim3(5), dim3(64), 0, s, part, clip, scale, norms_out, err);
   hipLaunchKernelGGL(sgd_update_kernel, dim3(512, 5), dim3(256), 0, s, params, grads, go, scale, lr, skip, bn_state, bn_snap, bn_n);
 }
 
@@ -1876,8 +1897,10 @@ __global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ x, fl
     var[i] = v;
   }
 }
-void adadelta_update(hipStream_t s, float* params, float* grads, float* var, float* acc, int64_t n, float rho, float eps, float wd, const int* skip,
+void adadelta_update(hipStream_t s, float* params, float* grads, float* var, float* acc, int64_t n, float rho, float eps, float wd, int* err,
                      float* bn_state, const float* bn_snap, int bn_n) {
+  const int* skip = err ? err + CL_ERR_LATCH : nullptr;
+  if (err) hipLaunchKernelGGL(cl_err_latch_kernel, dim3(1), dim3(1), 0, s, err);
   hipLaunchKernelGGL(adadelta_kernel, dim3(2048), dim3(256), 0, s, params, grads, var, acc, n, rho, eps, wd, skip, bn_state, bn_snap, bn_n);
 }
 
