@@ -78,12 +78,16 @@ def test_reference_default_he512_fp32_vs_oracle(cuda):
     m.shutdown()
 
 
-@pytest.mark.parametrize("B,big", [(16, False), (48, False), (48, True)])
+@pytest.mark.parametrize("B,big", [(16, False), (48, False), (48, True), (48, "stepl"), (70, "stepl")])
 def test_reference_default_he512_bf16_vs_oracle(cuda, monkeypatch, B, big):
     """The same shape through the production bf16 dispatch (whole-sequence encoder kernels at He = 512, B % 16 == 0).
     big: the large-batch route of the decoder's step products (round 5: 128 x 128 LDS-DMA tiles over [x0 | x1] x [W0 | W1] + an elementwise cell pass --
-    an opt-in route, AOCR_BIG_STEP=1: measured slower than the step kernels at the reference's default batch of 400, see ops_gemm.hip) forced at this batch, against the same oracle bounds."""
-    if big:
+    an opt-in route, AOCR_BIG_STEP=1: measured slower than the step kernels at the reference's default batch of 400, see ops_gemm.hip) forced at this batch, against the same oracle bounds.
+    "stepl": the round-6 large-batch step kernels (stepl.h: LDS-DMA ring, eight waves, four-unit gate epilogue; default from ~320 rows at Hd = 1024) forced at this
+    batch (B = 70: a ragged second row block), against the same oracle bounds."""
+    if big == "stepl":
+        monkeypatch.setenv("AOCR_STEPL_MIN_WGS", "1")
+    elif big:
         monkeypatch.setenv("AOCR_BIG_STEP", "1"); monkeypatch.setenv("AOCR_BIG_STEP_MIN_ROWS", "16")
     m, O, ocfg, P, st, batch = make(REF_DEFAULT, B=B, W=100, maxlen=9, compute="bf16", max_decoder_l=12, max_beam=1)
     img, tgt, tge = tensors(batch)
@@ -114,6 +118,39 @@ def test_reference_default_full_size_properties(cuda):
     m, O, ocfg, P, st, batch = make(REF_DEFAULT, B=B, W=100, maxlen=23, compute="bf16", max_decoder_l=24, max_beam=1)
     _properties(m, ocfg, batch, B, "bf16")
     m.shutdown()
+
+
+@pytest.mark.parametrize("B", [400, 390])
+def test_reference_default_step_kernel_routes_agree(cuda, monkeypatch, B):
+    """The decoder launch chain of the reference-default shape (Hd = 1024: no whole-sequence decoder kernel) at full batch, three routes of its step products:
+    the round-6 large-batch kernels (stepl.h, the default at this size), gemm_step_kernel with two row tiles per workgroup (round 5, AOCR_NO_STEPL=1) and with
+    one (AOCR_NO_STEP_MT2=1).  The two gemm_step_kernel forms do the same arithmetic in the same order -- logits and loss BIT-identical (the
+    two-tile form had no test at the batch that selects it; B = 390: its second row tile is partly, the last workgroup's wholly, past the end); stepl.h sums the
+    K range in another order -- every tensor within summation-order noise of the chain."""
+    out = {}
+    for name, env in (("stepl", {}), ("mt2", {"AOCR_NO_STEPL": "1"}), ("mt1", {"AOCR_NO_STEPL": "1", "AOCR_NO_STEP_MT2": "1"})):
+        for k in ("AOCR_NO_STEPL", "AOCR_NO_STEP_MT2"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m, O, ocfg, P, st, batch = make(REF_DEFAULT, B=B, W=100, maxlen=9, compute="bf16", max_decoder_l=12, max_beam=1)
+        loss = m.train_forward_backward(batch)
+        out[name] = dict(loss=loss, logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        assert m.cluster_status() == 0
+        m.shutdown()
+    a, b, c = out["mt1"], out["mt2"], out["stepl"]
+    assert torch.equal(a["logits"], b["logits"]) and a["loss"] == b["loss"], "two row tiles per workgroup changed the arithmetic"
+    e = (c["logits"] - a["logits"]).abs().max().item()
+    print(f"[parity] B={B} stepl vs step kernels: logits max-abs {e:.3e}, loss {c['loss']:.4f} vs {a['loss']:.4f}")
+    assert e < 5e-3 and abs(c["loss"] - a["loss"]) < 1e-3 * abs(a["loss"])
+    worst = ("", 0.0)
+    for k in a["grads"]:
+        if k in NOISY:
+            continue
+        r, cs = relerr(c["grads"][k], a["grads"][k]), cosine(c["grads"][k], a["grads"][k])
+        if r > worst[1]: worst = (k, r)
+        assert cs > (0.995 if k.startswith("cnn.") else 0.9999) and r < (0.3 if k.startswith("cnn.") else 3e-2), (k, r, cs)
+    print(f"[parity] B={B} stepl vs step kernels: worst gradient rel {worst[1]:.3e} ({worst[0]})")
 
 
 def _properties(m, ocfg, batch, B, compute, lin_tol=None, perm_tol=None):

@@ -81,6 +81,9 @@ struct EpStore {
   // epilogue's own operand loads overlap it instead of adding a second memory round trip after it
   struct Pre {};
   __device__ __forceinline__ Pre prefetch(int, int) const { return Pre{}; }
+  __device__ __forceinline__ void prefetch_zx(Pre&, int, int) const {}
+  static constexpr bool kCell4 = false; struct Pre4 {};             // (no four-unit form: stepl.h)
+  __device__ __forceinline__ bool cell4_ok() const { return false; }
   template <int NT> __device__ __forceinline__ void elem(int row, int n, int nstep, const float (&v)[NT], const Pre&) const {
     if (row >= M) return;
 #pragma unroll
@@ -255,26 +258,44 @@ struct EpGatesFwd {
       }
     }
   }
-  struct Pre { float zin[4]; float cp; };
+  // The epilogue's own operands, requested BEFORE the K loop.  prefetch() only LOADS (round 6): nothing here consumes a loaded value -- no sum of the two
+  // biases, no `+= zx`, no early return around the loads -- because every such use is an s_waitcnt on the spot, and the 8-16 prefetch calls of a thread then
+  // became 8-16 serial memory round trips in front of the K loop (13-28 us of the 31-44 us of a gate launch at 400 rows, tools/ubench/step400.hip).  Absent
+  // operands and rows / columns past the end load a valid dummy element instead (the row's c_prev) and are dropped in elem(); the sums are formed there, in the
+  // order they always had: z = v + ((b1 + b2) + zx).
+  struct Pre { float zx[4]; float b1[4]; float b2[4]; float cp; int32_t tok; };
   __device__ __forceinline__ Pre prefetch(int row, int j) const {
-    Pre p; p.cp = 0.f;
+    Pre p;
+    const int rr = max(min(row, M - 1), 0), jj = min(j, H - 1);
+    const float* const cpp = c_prev + (int64_t)rr * ldcp + jj;
+    const int32_t* const tp = zx_tok ? zx_tok + (int64_t)rr * zx_tok_stride : reinterpret_cast<const int32_t*>(cpp);
+    p.tok = *tp;
+    const float* const b1p = b1 ? b1 + jj : cpp; const float* const b2p = b1 ? b2 + jj : cpp; const int bs = b1 ? H : 0;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) p.zin[g] = 0.f;
-    if (j >= H || row >= M) return p;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (b1) p.zin[g] = b1[g * H + j] + b2[g * H + j];
-      if (zx) p.zin[g] += zx[zrow(row) * ldzx + g * H + j];
-    }
-    p.cp = c_prev[(int64_t)row * ldcp + j];
+    for (int g = 0; g < 4; ++g) { p.b1[g] = b1p[g * bs]; p.b2[g] = b2p[g * bs]; }
+    p.cp = *cpp;
     return p;
+  }
+  // second half of the prefetch: the gate inputs, whose row may be a token looked up by the first half (all first halves are issued before any second half)
+  __device__ __forceinline__ void prefetch_zx(Pre& p, int row, int j) const {
+    const int rr = max(min(row, M - 1), 0), jj = min(j, H - 1);
+    const float* const cpp = c_prev + (int64_t)rr * ldcp + jj;
+    const int64_t zr = zx_tok ? (int64_t)(p.tok - 1) : (int64_t)rr;
+    const float* const zp = zx ? zx + zr * ldzx + jj : cpp; const int zs = zx ? H : 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) p.zx[g] = zp[g * zs];
   }
   template <int NT> __device__ __forceinline__ void elem(int row, int j, int, const float (&v)[NT], const Pre& pre) const {
     static_assert(NT == 4, "gate epilogue needs the 4 gate tiles");
     if (j >= H || row >= M) return;
     float z[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) z[g] = v[g] + pre.zin[g];
+    for (int g = 0; g < 4; ++g) {
+      float zin = 0.f;
+      if (b1) zin = pre.b1[g] + pre.b2[g];
+      if (zx) zin += pre.zx[g];
+      z[g] = v[g] + zin;
+    }
     float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), og = sigmoidf_(z[2]), gg = tanhf_(z[3]);
     float c = fg * pre.cp + ig * gg;
     float hh = og * tanhf_(c);
@@ -287,6 +308,68 @@ struct EpGatesFwd {
     if (gates) {
       float* gp = gates + (int64_t)row * ldg + j;
       gp[0] = ig; gp[H] = fg; gp[2 * H] = og; gp[3 * H] = gg;
+    }
+  }
+  // ---- four consecutive hidden units j .. j+3 of one row per thread (stepl.h): the same arithmetic per unit, 16-byte loads and stores (8-byte for bf16)
+  static constexpr bool kCell4 = true;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef bf16_t v4h __attribute__((ext_vector_type(4)));
+  struct Pre4 { v4f zx[4]; v4f b1[4]; v4f b2[4]; v4f cp; int32_t tok; };
+  __device__ __forceinline__ bool cell4_ok() const {                 // every row start 16-byte aligned (uniform: kernel arguments only)
+    auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    auto a8 = [](const void* q) { return ((uintptr_t)q & 7) == 0; };
+    return H % 4 == 0 && a16(c_prev) && ldcp % 4 == 0 && a16(c_out) && ldc % 4 == 0 && a16(h_out) && ldh % 4 == 0 && (!zx || (a16(zx) && ldzx % 4 == 0)) &&
+           (!b1 || (a16(b1) && a16(b2))) && (!h_out2 || (a16(h_out2) && ldh2 % 4 == 0)) && (!gates || (a16(gates) && ldg % 4 == 0)) &&
+           (!hb || (a8(hb) && ldhb % 4 == 0)) && (!hb2 || (a8(hb2) && ldhb2 % 4 == 0));
+  }
+  __device__ __forceinline__ Pre4 prefetch4(int row, int j) const {      // loads only, as prefetch()
+    Pre4 p;
+    const int rr = max(min(row, M - 1), 0), jj = min(j, H - 4);
+    const float* const cpp = c_prev + (int64_t)rr * ldcp + jj;
+    const int32_t* const tp = zx_tok ? zx_tok + (int64_t)rr * zx_tok_stride : reinterpret_cast<const int32_t*>(cpp);
+    p.tok = *tp;
+    const float* const b1p = b1 ? b1 + jj : cpp; const float* const b2p = b1 ? b2 + jj : cpp; const int bs = b1 ? H : 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { p.b1[g] = *reinterpret_cast<const v4f*>(b1p + g * bs); p.b2[g] = *reinterpret_cast<const v4f*>(b2p + g * bs); }
+    p.cp = *reinterpret_cast<const v4f*>(cpp);
+    return p;
+  }
+  __device__ __forceinline__ void prefetch4_zx(Pre4& p, int row, int j) const {
+    const int rr = max(min(row, M - 1), 0), jj = min(j, H - 4);
+    const float* const cpp = c_prev + (int64_t)rr * ldcp + jj;
+    const int64_t zr = zx_tok ? (int64_t)(p.tok - 1) : (int64_t)rr;
+    const float* const zp = zx ? zx + zr * ldzx + jj : cpp; const int zs = zx ? H : 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) p.zx[g] = *reinterpret_cast<const v4f*>(zp + g * zs);
+  }
+  __device__ __forceinline__ void cell4(int row, int j, const v4f (&v)[4], const Pre4& pre) const {
+    if (j >= H || row >= M) return;
+    v4f gate[4], c4, h4, h24;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float zin = 0.f;
+        if (b1) zin = pre.b1[g][u] + pre.b2[g][u];
+        if (zx) zin += pre.zx[g][u];
+        z[g] = v[g][u] + zin;
+      }
+      const float ig = sigmoidf_(z[0]), fg = sigmoidf_(z[1]), og = sigmoidf_(z[2]), gg = tanhf_(z[3]);
+      const float c = fg * pre.cp[u] + ig * gg;
+      const float hh = og * tanhf_(c);
+      gate[0][u] = ig; gate[1][u] = fg; gate[2][u] = og; gate[3][u] = gg; c4[u] = c; h4[u] = hh;
+      h24[u] = drop.on() ? hh * drop.mask((long long)row * H + j + u) : hh;
+    }
+    *reinterpret_cast<v4f*>(c_out + (int64_t)row * ldc + j) = c4;
+    *reinterpret_cast<v4f*>(h_out + (int64_t)row * ldh + j) = h4;
+    if (h_out2) *reinterpret_cast<v4f*>(h_out2 + (int64_t)row * ldh2 + j) = h24;
+    if (hb) { v4h t; t[0] = (bf16_t)h4[0]; t[1] = (bf16_t)h4[1]; t[2] = (bf16_t)h4[2]; t[3] = (bf16_t)h4[3]; *reinterpret_cast<v4h*>(hb + (int64_t)row * ldhb + j) = t; }
+    if (hb2) { v4h t; t[0] = (bf16_t)h24[0]; t[1] = (bf16_t)h24[1]; t[2] = (bf16_t)h24[2]; t[3] = (bf16_t)h24[3]; *reinterpret_cast<v4h*>(hb2 + (int64_t)row * ldhb2 + j) = t; }
+    if (gates) {
+      float* const gp = gates + (int64_t)row * ldg + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<v4f*>(gp + (int64_t)g * H) = gate[g];
     }
   }
 };
@@ -334,25 +417,34 @@ struct EpGatesBwd {
       dc_out[(int64_t)row * lddco + j] = dc * fg;
     }
   }
-  struct Pre { float dh, dc, ig, fg, og, gg, c, cp; };
+  // loads only, see EpGatesFwd::prefetch: absent terms and rows / columns past the end load the row's c (dropped in elem())
+  struct Pre { float dh1, dh2, dc, ig, fg, og, gg, c, cp; };
   __device__ __forceinline__ Pre prefetch(int row, int j) const {
-    Pre p; p.dh = p.dc = p.ig = p.fg = p.og = p.gg = p.c = p.cp = 0.f;
-    if (j >= H || row >= M) return p;
-    if (dh1) p.dh = dh1[(int64_t)row * ld1 + j];
-    if (dh2) p.dh += dh2[(int64_t)row * ld2 + j];
-    if (dc_in) p.dc = dc_in[(int64_t)row * lddc + j];
-    if (gil) { const float4 g4 = *reinterpret_cast<const float4*>(gates + (int64_t)row * ldg + 4 * j); p.ig = g4.x; p.fg = g4.y; p.og = g4.z; p.gg = g4.w; }
-    else { const float* gp = gates + (int64_t)row * ldg + j; p.ig = gp[0]; p.fg = gp[H]; p.og = gp[2 * H]; p.gg = gp[3 * H]; }
-    p.c = c[(int64_t)row * ldcc + j]; p.cp = c_prev[(int64_t)row * ldcp + j];
+    Pre p;
+    const int rr = max(min(row, M - 1), 0), jj = min(j, H - 1);
+    const float* const cq = c + (int64_t)rr * ldcc + jj;
+    p.dh1 = *(dh1 ? dh1 + (int64_t)rr * ld1 + jj : cq);
+    p.dh2 = *(dh2 ? dh2 + (int64_t)rr * ld2 + jj : cq);
+    p.dc = *(dc_in ? dc_in + (int64_t)rr * lddc + jj : cq);
+    if (gil) { const float4 g4 = *reinterpret_cast<const float4*>(gates + (int64_t)rr * ldg + 4 * jj); p.ig = g4.x; p.fg = g4.y; p.og = g4.z; p.gg = g4.w; }
+    else { const float* gp = gates + (int64_t)rr * ldg + jj; p.ig = gp[0]; p.fg = gp[H]; p.og = gp[2 * H]; p.gg = gp[3 * H]; }
+    p.c = *cq; p.cp = c_prev[(int64_t)rr * ldcp + jj];
     return p;
   }
+  __device__ __forceinline__ void prefetch_zx(Pre&, int, int) const {}
+  static constexpr bool kCell4 = false; struct Pre4 {};
+  __device__ __forceinline__ bool cell4_ok() const { return false; }
   template <int NT> __device__ __forceinline__ void elem(int row, int j, int, const float (&v)[NT], const Pre& pre) const {
     static_assert(NT == 1, "gate backward epilogue is single-tile");
     if (j >= H || row >= M) return;
-    float dh = (drop.on() ? v[0] * drop.mask((long long)row * H + j) : v[0]) + pre.dh;
+    float pdh = 0.f;
+    if (dh1) pdh = pre.dh1;
+    if (dh2) pdh += pre.dh2;
+    const float pdc = dc_in ? pre.dc : 0.f;
+    float dh = (drop.on() ? v[0] * drop.mask((long long)row * H + j) : v[0]) + pdh;
     float ig = pre.ig, fg = pre.fg, og = pre.og, gg = pre.gg;
     float tc = tanhf_(pre.c);
-    float dc = dh * og * (1.f - tc * tc) + pre.dc;
+    float dc = dh * og * (1.f - tc * tc) + pdc;
     float d_o = dh * tc;
     float di = dc * gg, dg = dc * ig, df = dc * pre.cp;
     const float z0 = di * ig * (1.f - ig), z1 = df * fg * (1.f - fg), z2 = d_o * og * (1.f - og), z3 = dg * (1.f - gg * gg);

@@ -2872,6 +2872,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_step_kernel(SmallArgs2<AL, LoadK
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int e = 0; e < E; ++e) pre[mt][e] = g.ep.prefetch(orow + 32 * mt + e, GATES == 2 ? n0 + (r & 15) : n0 + r);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < E; ++e) g.ep.prefetch_zx(pre[mt][e], orow + 32 * mt + e, GATES == 2 ? n0 + (r & 15) : n0 + r);       // (second half: rows looked up through the first half's tokens)
 
   if (kbeg < kend) {
     typename std::conditional<AH, u32x4, float4>::type ra[MT][NA]; u32x4 rb[NT * 4];
@@ -3005,6 +3009,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_step_f32_kernel(SmallArgs2<LoadK
   typename EP::Pre pre[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) pre[e] = g.ep.prefetch(orow + e, QG ? n0 + (r & 7) : n0 + r);
+#pragma unroll
+  for (int e = 0; e < E; ++e) g.ep.prefetch_zx(pre[e], orow + e, QG ? n0 + (r & 7) : n0 + r);
 
   // (free functions over flat arrays of native vector types: float4 arrays handed to lambdas were demoted to scratch.)  Every chunk's loads are
   // issued UNCONDITIONALLY -- past the wave's range they re-read its last chunk -- so that the number of loads in flight is the same on every

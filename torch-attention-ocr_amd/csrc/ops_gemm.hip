@@ -2,6 +2,7 @@
 // gradInput / gradWeight, LSTM.lua:79-88, model_utils.lua:57-116), implicit-GEMM convolutions
 // (cudnn.SpatialConvolution, cnn.lua:17-42) and the fused recurrent-step kernels.
 #include "ops.h"
+#include "stepl.h"
 
 namespace aocr {
 
@@ -311,6 +312,22 @@ static void launch_small_bf16(hipStream_t s, int nz, const ARGS* z, int M, int n
   hipLaunchKernelGGL((gemm_small_kernel<true, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid, dim3(256), 0, s,
                      zz, gate_stride);
 }
+// Large-batch form of the step products (stepl.h): taken when its workgroups (64-row tiles) fill most of the chip -- below that the step kernels' 32-row tiles and
+// half gate tiles spread the launch over more compute units -- and the K range is whole groups of the LDS-DMA ring.  AOCR_NO_STEPL=1: off (A/B runs, parity tests);
+// AOCR_STEPL_MIN_WGS=n: the workgroup count from which it is taken (default 160 of the 256 compute units).
+template <class ARGS>
+static bool stepl_eligible(const ARGS* z, int nz, int M, int wgs) {
+  if (env_is_1("AOCR_NO_STEPL")) return false;
+  const char* const e = getenv("AOCR_STEPL_MIN_WGS");
+  if (wgs < (e ? atoi(e) : 160)) return false;
+  for (int i = 0; i < nz; ++i) {
+    const auto& a = z[i].a; const auto& b = z[i].b;
+    if (z[i].K <= 0 || z[i].K % 128 || a.K0 % 64 || b.K0 != a.K0 || (a.p1 != nullptr) != (b.p1 != nullptr)) return false;
+    if ((int64_t)M * std::max(a.ld0, a.ld1) >= (1ll << 31) || (int64_t)b.rows * std::max(b.ld0, b.ld1) >= (1ll << 31)) return false;      // 32-bit element offsets
+    if (a.ld0 % 8 || (a.p1 && a.ld1 % 8) || b.ld0 % 8 || (b.p1 && b.ld1 % 8)) return false;                                              // 16-byte pieces
+  }
+  return true;
+}
 // both operands from bf16 shadows: only the staged kernel exists (callers check step_ok_hh first)
 template <int NT, bool GATES, class ARGS>
 static void launch_small_bf16_hh(hipStream_t s, int nz, const ARGS* z, int M, int ncols, int gate_stride) {
@@ -318,6 +335,12 @@ static void launch_small_bf16_hh(hipStream_t s, int nz, const ARGS* z, int M, in
   dim3 grid(GATES ? cdiv(ncols, 32) : cdiv(ncols, 32 * NT), cdiv(M, 32), nz);
   SmallArgs2<decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)> zz; zz.z[0] = z[0]; zz.z[1] = z[nz > 1 ? 1 : 0]; zz.z[2] = z[nz > 2 ? 2 : 0];
   if constexpr (GATES && NT == 4) {
+    // large batch (round 6; the reference-default decoder: 400 rows x Hd = 1024): 64 x 128 gate tiles on the LDS-DMA ring, eight waves, four-unit epilogue (stepl.h)
+    if (stepl_eligible(z, nz, M, cdiv(ncols, 32) * cdiv(M, 64) * nz)) {
+      const int gx = ncols / 32, gy = cdiv(M, 64);
+      hipLaunchKernelGGL((gemm_stepl_kernel<2, 4, 1, decltype(z[0].ep), 6, 2, 8, true>), dim3(gx * gy * nz), dim3(512), 0, s, zz, gate_stride, gx, gy);
+      return;
+    }
     if (half_gate_tiles(ncols, M, nz)) {
       if (step_waves8())
         hipLaunchKernelGGL((gemm_step_kernel<2, 2, decltype(z[0].a), decltype(z[0].ep), 8>), dim3(ncols / 16, cdiv(M, 32), nz), dim3(512), 0, s, zz, gate_stride);
@@ -374,7 +397,8 @@ bool big_step_store(hipStream_t s, const LoadKh2& a, const LoadKh2& b, const EpS
 __global__ __launch_bounds__(256) void gates_elem_fwd_kernel(const float* __restrict__ z, int64_t ldz, EpGatesFwd ep) {
   const int j = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
   if (j >= ep.H) return;
-  const EpGatesFwd::Pre pre = ep.prefetch(row, j);
+  EpGatesFwd::Pre pre = ep.prefetch(row, j);
+  ep.prefetch_zx(pre, row, j);
   float v[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) v[g] = z[(int64_t)row * ldz + (int64_t)g * ep.H + j];
