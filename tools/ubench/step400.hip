@@ -84,7 +84,7 @@ static double checksum(const Bufs& b) {
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 400, H = argc > 2 ? atoi(argv[2]) : 1024;
-  for (int mode : {0, 1, 2}) {
+  for (int mode : {0}) {
     g_epmode = mode; const int ld = H;
     Bufs b = make(M, H, ld);
     printf("--- M=%d H=%d K=%d ld=%d epilogue mode %d (0 full, 1 none, 2 c + h only)\n", M, H, 2 * H, ld, mode);
@@ -98,13 +98,35 @@ int main(int argc, char** argv) {
       printf("step<NT2,G2,NW4,MT2> grid %dx%d            : %7.2f us  checksum %.6e\n", H / 16, cdiv(M, 64), us, checksum(b)); }
 #define STEPL(MT, NT, G, NS, SUBS, NW, SPLITN, GX, GY) { float us = time_us([&](int set) { Z zz = args(b, set); hipLaunchKernelGGL((gemm_stepl_kernel<MT, NT, G, EpGatesFwd, NS, SUBS, NW, SPLITN>), dim3((GX) * (GY)), dim3(64 * NW), 0, 0, zz, H, GX, GY); }); \
       printf("stepl<MT%d,NT%d,G%d,NS%d,SUBS%d,NW%d,SPLITN%d> grid %dx%d : %7.2f us  (%.0f TF/s)  checksum %.6e\n", MT, NT, G, NS, SUBS, NW, (int)SPLITN, GX, GY, us, 2.0 * M * 4 * H * 2 * H / us * 1e-6, checksum(b)); }
-    STEPL(2, 4, 1, 6, 2, 4, true, H / 32, cdiv(M, 64))
     STEPL(2, 4, 1, 6, 2, 8, true, H / 32, cdiv(M, 64))
-    STEPL(2, 4, 1, 6, 2, 8, false, H / 32, cdiv(M, 64))
-    STEPL(2, 4, 1, 6, 1, 8, true, H / 32, cdiv(M, 64))
+    STEPL(2, 4, 1, 6, 2, 4, true, H / 32, cdiv(M, 64))
     g_cell4 = false;
     STEPL(2, 4, 1, 6, 2, 8, true, H / 32, cdiv(M, 64))
     g_cell4 = true;
+  }
+  // ---- plain products of the backward step: C[M][N] = A[M][K] . W^T (W^T stored [N][K]), N = Hd, K = 4 Hd (d z W_h2h) and K = Hd, one and three problems per launch
+  for (int KK : {4 * H, H}) {
+    const int N = H;
+    bf16_t *A[3], *W[3]; float* C[3]; bf16_t* Cb[3];
+    for (int i = 0; i < 3; ++i) {
+      CK(hipMalloc(&A[i], (size_t)M * KK * 2)); CK(hipMalloc(&W[i], (size_t)N * KK * 2)); CK(hipMalloc(&C[i], (size_t)M * N * 4)); CK(hipMalloc(&Cb[i], (size_t)M * N * 2));
+      fill<<<512, 256>>>(A[i], (size_t)M * KK, 31 + i, 1.f); fill<<<512, 256>>>(W[i], (size_t)N * KK, 41 + i, 0.03f);
+    }
+    CK(hipDeviceSynchronize());
+    typedef SmallArgs2<LoadKh2, LoadKh2, EpStore> ZS;
+    auto pargs = [&]() { ZS zz; for (int i = 0; i < 3; ++i) { zz.z[i].a = make_loadkh(A[i], KK, M, KK); zz.z[i].b = make_loadkh(W[i], KK, N, KK); zz.z[i].ep = make_store(C[i], N, M, N, nullptr, nullptr, 0); zz.z[i].ep.Cb = Cb[i]; zz.z[i].ep.ldcb = N; zz.z[i].K = KK; } return zz; };
+    auto csum = [&]() { std::vector<float> hh((size_t)M * N); CK(hipMemcpy(hh.data(), C[2], hh.size() * 4, hipMemcpyDeviceToHost)); double q = 0; for (size_t i = 0; i < hh.size(); ++i) q += (double)hh[i] * (double)((i % 7) + 1); return q; };
+    for (int nz : {1, 3}) {
+      printf("--- plain M=%d N=%d K=%d, %d problem(s) per launch\n", M, N, KK, nz);
+      { float us = time_us([&](int) { ZS zz = pargs(); if (nz == 1) zz.z[0] = zz.z[2]; hipLaunchKernelGGL((gemm_step_kernel<1, 0, LoadKh2, EpStore, 8, 1>), dim3(N / 32, cdiv(M, 32), nz), dim3(512), 0, 0, zz, 0); });
+        printf("step<NT1,G0,NW8,MT1> grid %dx%dx%d : %7.2f us  checksum %.6e\n", N / 32, cdiv(M, 32), nz, us, csum()); }
+#define STEPP(MT, NT, NS, SUBS, NW, SPLITN) { const int GX = N / (32 * NT), GY = cdiv(M, 32 * MT); float us = time_us([&](int) { ZS zz = pargs(); if (nz == 1) zz.z[0] = zz.z[2]; hipLaunchKernelGGL((gemm_stepl_kernel<MT, NT, 0, EpStore, NS, SUBS, NW, SPLITN>), dim3(GX * GY * nz), dim3(64 * NW), 0, 0, zz, 0, GX, GY); }); \
+        printf("stepl<MT%d,NT%d,G0,NS%d,SUBS%d,NW%d,SPLITN%d> grid %dx%dx%d : %7.2f us  (%.0f TF/s)  checksum %.6e\n", MT, NT, NS, SUBS, NW, (int)SPLITN, GX, GY, nz, us, 2.0 * nz * M * N * KK / us * 1e-6, csum()); }
+      STEPP(2, 4, 6, 2, 8, true)
+      STEPP(2, 2, 4, 2, 8, true)
+      STEPP(4, 2, 6, 2, 8, false)
+    }
+    for (int i = 0; i < 3; ++i) { hipFree(A[i]); hipFree(W[i]); hipFree(C[i]); hipFree(Cb[i]); }
   }
   return 0;
 }

@@ -79,13 +79,38 @@ struct EpStore {
   }
   // single-element form used by the recurrent-step kernel; prefetch() is issued BEFORE the K loop so that the
   // epilogue's own operand loads overlap it instead of adding a second memory round trip after it
-  struct Pre {};
-  __device__ __forceinline__ Pre prefetch(int, int) const { return Pre{}; }
+  struct Pre { float dg, dout, b, b2, old; };
+  // loads only (see EpGatesFwd::prefetch): the tanh-backward operands, the biases and the value an accumulating store adds to are requested before the K loop
+  // instead of inside elem(), where each was a dependent round trip per element (round 6)
+  __device__ __forceinline__ Pre prefetch(int row, int n) const {
+    Pre p; p.dg = p.dout = p.b = p.b2 = p.old = 0.f;
+    const int rr = max(min(row, M - 1), 0), col = min(n, N - 1);
+    if (bias) p.b = bias[col];
+    if (bias2) p.b2 = bias2[col];
+    if (dg) { p.dg = dg[(int64_t)rr * ldd + col]; p.dout = dout[(int64_t)rr * ldd + col]; }
+    if (flags & EP_ACCUM) p.old = *((C1 && col >= N0) ? C1 + (int64_t)rr * ldc1 + (col - N0) : C + (int64_t)rr * ldc + col);
+    return p;
+  }
   __device__ __forceinline__ void prefetch_zx(Pre&, int, int) const {}
   static constexpr bool kCell4 = false; struct Pre4 {};             // (no four-unit form: stepl.h)
   __device__ __forceinline__ bool cell4_ok() const { return false; }
-  template <int NT> __device__ __forceinline__ void elem(int row, int n, int nstep, const float (&v)[NT], const Pre&) const {
+  template <int NT> __device__ __forceinline__ void elem(int row, int n, int nstep, const float (&v)[NT], const Pre& pre) const {
     if (row >= M) return;
+    if constexpr (NT == 1) {                                    // the prefetched form (every step kernel calls it per column tile)
+      const int col = n;
+      if (col >= N) return;
+      float x = v[0];
+      if (bias) x += pre.b;
+      if (bias2) x += pre.b2;
+      if (flags & EP_RELU) x = fmaxf(x, 0.f);
+      if (flags & EP_TANH) x = tanhf_(x);
+      if (dg) x = (x + pre.dg) * (1.f - pre.dout * pre.dout);
+      float* p = (C1 && col >= N0) ? C1 + (int64_t)row * ldc1 + (col - N0) : C + (int64_t)row * ldc + col;
+      if (flags & EP_ATOMIC) atomicAdd(p, x);
+      else if (flags & EP_ACCUM) *p = pre.old + x;
+      else { *p = x; if (Cb && !(C1 && col >= N0)) Cb[(int64_t)row * ldcb + col] = (bf16_t)x; }
+      return;
+    }
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
       int col = n + nstep * ni;

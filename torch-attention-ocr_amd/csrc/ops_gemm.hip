@@ -356,6 +356,15 @@ static void launch_small_bf16_hh(hipStream_t s, int nz, const ARGS* z, int M, in
         return;
       } }
   }
+  if constexpr (!GATES && NT == 1) {
+    // three plain products per launch at large batch (the backward step's d z W_h2h / input-feed group: 3 x 56 tiles of 64 x 128 fill the chip): stepl.h, 39 -> 29 us
+    // at 400 rows, K = 4096; ONE product per launch (56 tiles) stays below: its 416 small workgroups beat every tile shape of stepl.h (tools/ubench/step400.hip)
+    if (nz == 3 && ncols % 128 == 0 && stepl_eligible(z, nz, M, (ncols / 128) * cdiv(M, 64) * nz)) {
+      const int gx = ncols / 128, gy = cdiv(M, 64);
+      hipLaunchKernelGGL((gemm_stepl_kernel<2, 4, 0, decltype(z[0].ep), 6, 2, 8, true>), dim3(gx * gy * nz), dim3(512), 0, s, zz, gate_stride, gx, gy);
+      return;
+    }
+  }
   // (measured and dropped: 64 x 64 tiles -- NT = 2, MT = 2, eight waves -- for the plain step products of the backward pass at M = 400: 336 workgroups instead of
   //  1248, 350 MB instead of 640 MB per launch, decoder backward 2.27 -> 2.34 ms: there the many small workgroups are what hides the latency)
   if constexpr (NT == 1) {

@@ -12,7 +12,9 @@
 //   * the four K partials meet in LDS (the ring, reused) and the gate epilogue runs on FOUR consecutive hidden units per thread: 16-byte loads of zx / c_prev and
 //     16-byte stores of c, h, the saved gates (8-byte for the bf16 shadows) -- a quarter of the scalar epilogue's memory instructions;
 //   * workgroups renumbered so that an XCD's workgroups share few column blocks (its L2 holds their weights once) x all row blocks.
-// Measured and dropped: padded row strides and a per-workgroup rotation of the K loop (no L2 channel effect: same time), 128 x 64 tiles on half gate tiles (256
+// Measured and dropped: split K over workgroups with the partial tiles meeting in memory (sc1 stores, counter, the last workgroup sums: ~8 us of dependent
+// round trips -- store acknowledgement, atomic, partner loads, epilogue operands -- on kernels of 10-20 us: the plain N = Hd products of a step stay on
+// gemm_step_kernel's 416 small workgroups, 16.4 us at K = 4096 against 17-20 here), padded row strides and a per-workgroup rotation of the K loop (no L2 channel effect: same time), 128 x 64 tiles on half gate tiles (256
 // workgroups, a quarter of them on the 16 rows past 384: slower than 64 x 128 on 224).
 // The fp32 sums meet in a different order than in gemm_step_kernel: results agree to summation-order noise, not bit for bit.
 // Same argument block (SmallArgs2) and epilogue objects as gemm_step_kernel, so it drops into launch_small_bf16_hh.
@@ -110,29 +112,32 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_stepl_kernel(SmallArgs2<LoadK
   constexpr int NP = GATES ? MT / NH : TPW;                                       // prefetch sets per thread: (row tile) for gate tiles, (tile) otherwise
   typename EP::Pre pre[NP][E];
   const int erow = 8 * ((E * kw) >> 2) + 4 * h + ((E * kw) & 3);                   // first of this thread's E rows within a tile
-  if (cell4) {
-    if constexpr (CELL4) {
-#pragma unroll
-      for (int i = 0; i < IT4; ++i) { const int it = tid + 64 * NW * i; pre4[i] = g.ep.prefetch4(m0 + (it >> 3), n0 + 4 * (it & 7)); }
-#pragma unroll
-      for (int i = 0; i < IT4; ++i) { const int it = tid + 64 * NW * i; g.ep.prefetch4_zx(pre4[i], m0 + (it >> 3), n0 + 4 * (it & 7)); }
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < NP; ++q)
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const int mt = GATES ? hf * NP + q : (hf * TPW + q) / NT, ni = GATES ? 0 : (hf * TPW + q) % NT;
-        pre[q][e] = g.ep.prefetch(m0 + 32 * mt + erow + e, n0 + 32 * ni + r);
-      }
-#pragma unroll
-    for (int q = 0; q < NP; ++q)
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const int mt = GATES ? hf * NP + q : (hf * TPW + q) / NT, ni = GATES ? 0 : (hf * TPW + q) % NT;
-        g.ep.prefetch_zx(pre[q][e], m0 + 32 * mt + erow + e, n0 + 32 * ni + r);
-      }
-  }
+#define AOCR_STEPL_PREFETCH()                                                                                                           \
+  if (cell4) {                                                                                                                               \
+    if constexpr (CELL4) {                                                                                                                   \
+  _Pragma("unroll")                                                                                                                          \
+      for (int i = 0; i < IT4; ++i) { const int it = tid + 64 * NW * i; pre4[i] = g.ep.prefetch4(m0 + (it >> 3), n0 + 4 * (it & 7)); }       \
+  _Pragma("unroll")                                                                                                                          \
+      for (int i = 0; i < IT4; ++i) { const int it = tid + 64 * NW * i; g.ep.prefetch4_zx(pre4[i], m0 + (it >> 3), n0 + 4 * (it & 7)); }     \
+    }                                                                                                                                        \
+  } else {                                                                                                                                   \
+  _Pragma("unroll")                                                                                                                          \
+    for (int q = 0; q < NP; ++q)                                                                                                             \
+  _Pragma("unroll")                                                                                                                          \
+      for (int e = 0; e < E; ++e) {                                                                                                          \
+        const int mt = GATES ? hf * NP + q : (hf * TPW + q) / NT, ni = GATES ? 0 : (hf * TPW + q) % NT;                                      \
+        pre[q][e] = g.ep.prefetch(m0 + 32 * mt + erow + e, n0 + 32 * ni + r);                                                                \
+      }                                                                                                                                      \
+  _Pragma("unroll")                                                                                                                          \
+    for (int q = 0; q < NP; ++q)                                                                                                             \
+  _Pragma("unroll")                                                                                                                          \
+      for (int e = 0; e < E; ++e) {                                                                                                          \
+        const int mt = GATES ? hf * NP + q : (hf * TPW + q) / NT, ni = GATES ? 0 : (hf * TPW + q) % NT;                                      \
+        g.ep.prefetch_zx(pre[q][e], m0 + 32 * mt + erow + e, n0 + 32 * ni + r);                                                              \
+      }                                                                                                                                      \
+  }                                                                                                                                         
+  AOCR_STEPL_PREFETCH()
+#undef AOCR_STEPL_PREFETCH
 
 #pragma unroll
   for (int i = 0; i < NG - 1; ++i) AOCR_STEPL_ISSUE()
@@ -174,24 +179,48 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_stepl_kernel(SmallArgs2<LoadK
 #pragma unroll
       for (int e = 0; e < 16; ++e) red[kw * WSTRIDE + (((mt0 + mt) * NT + nt0 + ni) * 16 + e) * 64 + lane] = acc[mt][ni][e];
   __syncthreads();
+  // ---- this thread's sums of the four K slices, as 16-byte units: (a) item i, gate -> vv[4 i + gate] = four consecutive columns; (b) set q, tile ni -> vv[.] = its E = 4 rows
+  constexpr int NVA = CELL4 ? IT4 * 4 : 0, NVB = GATES ? NP * NT : NP, NVM = NVA > NVB ? NVA : NVB;
+  f32x4 vv[NVM];
   if (cell4) {
     if constexpr (CELL4) {
       // element (row, col) of tile t sits at [t][i = 4 (row >> 3) + (row & 3)][lane = 32 ((row >> 2) & 1) + col]: four consecutive columns are 16 contiguous bytes
 #pragma unroll
       for (int i = 0; i < IT4; ++i) {
-        const int it = tid + 64 * NW * i;
-        if (it >= MT * 256) break;
+        const int it = min(tid + 64 * NW * i, MT * 256 - 1);
         const int row = it >> 3, c0 = 4 * (it & 7), mt = row >> 5, rt = row & 31;
         const int base = (mt * NT * 16 + 4 * (rt >> 3) + (rt & 3)) * 64 + 32 * ((rt >> 2) & 1) + c0;
-        f32x4 v[4];
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate) {
           const float* const q = red + base + gate * 1024;
           const f32x4 s0 = *reinterpret_cast<const f32x4*>(q), s1 = *reinterpret_cast<const f32x4*>(q + WSTRIDE), s2 = *reinterpret_cast<const f32x4*>(q + 2 * WSTRIDE),
                       s3 = *reinterpret_cast<const f32x4*>(q + 3 * WSTRIDE);
-          v[gate] = (s0 + s1) + (s2 + s3);
+          vv[4 * i + gate] = (s0 + s1) + (s2 + s3);
         }
-        g.ep.cell4(m0 + row, n0 + c0, v, pre4[i]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int mt = GATES ? hf * NP + q : (hf * TPW + q) / NT, ni0 = GATES ? 0 : (hf * TPW + q) % NT;
+#pragma unroll
+      for (int ni = 0; ni < (GATES ? NT : 1); ++ni)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int idx = ((mt * NT + ni0 + ni) * 16 + E * kw + e) * 64 + lane;
+          vv[q * (GATES ? NT : 1) + ni][e] = (red[idx] + red[idx + WSTRIDE]) + (red[idx + 2 * WSTRIDE] + red[idx + 3 * WSTRIDE]);
+        }
+    }
+  }
+  // ---- epilogue
+  if (cell4) {
+    if constexpr (CELL4) {
+#pragma unroll
+      for (int i = 0; i < IT4; ++i) {
+        const int it = tid + 64 * NW * i;
+        if (it >= MT * 256) break;
+        const f32x4 v[4] = {vv[4 * i], vv[4 * i + 1], vv[4 * i + 2], vv[4 * i + 3]};
+        g.ep.cell4(m0 + (it >> 3), n0 + 4 * (it & 7), v, pre4[i]);
       }
     }
     return;
@@ -203,10 +232,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_stepl_kernel(SmallArgs2<LoadK
     for (int e = 0; e < E; ++e) {
       float v[GATES ? NT : 1];
 #pragma unroll
-      for (int ni = 0; ni < (GATES ? NT : 1); ++ni) {
-        const int idx = ((mt * NT + ni0 + ni) * 16 + E * kw + e) * 64 + lane;
-        v[ni] = (red[idx] + red[idx + WSTRIDE]) + (red[idx + 2 * WSTRIDE] + red[idx + 3 * WSTRIDE]);
-      }
+      for (int ni = 0; ni < (GATES ? NT : 1); ++ni) v[ni] = vv[q * (GATES ? NT : 1) + ni][e];
       g.ep.template elem<(GATES ? NT : 1)>(m0 + 32 * mt + erow + e, n0 + 32 * ni0 + r, 32, v, pre[q][e]);
     }
   }
