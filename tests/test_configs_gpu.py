@@ -101,7 +101,7 @@ def test_reference_default_he512_bf16_vs_oracle(cuda, monkeypatch, B, big):
     assert ec < 2e-2
     assert abs(loss - float(loss_ref) * B) < 5e-3 * abs(loss)
     grads = m.get_gradients()
-    for k in ("proj.w", "dec.attn.wa", "dec.attn.wc", "dec.l1.i2h.w", "dec.l2.h2h.w", "enc_fw.l1.h2h.w", "enc_bw.l1.h2h.w", "enc_fw.l1.i2h.w",
+    for k in ("proj.w", "dec.attn.wa", "dec.attn.wc", "dec.lookup", "dec.l1.i2h.w", "dec.l1.i2h.b", "dec.l2.h2h.w", "enc_fw.l1.h2h.w", "enc_bw.l1.h2h.w", "enc_fw.l1.i2h.w",
               "enc_bw.l1.i2h.b", "cnn.conv7.w", "cnn.bn7.w"):
         c = cosine(grads[k], G[k]); r = relerr(grads[k], G[k])
         print(f"[parity] He=512 bf16 B={B} grad {k:18s} rel {r:.3e} cosine {c:.6f}")

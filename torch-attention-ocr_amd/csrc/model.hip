@@ -958,7 +958,9 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
   // The whole-sequence kernel reads it from the per-token table [V][4 Hd] (what the decode path already does) instead of a (L B, 4 Hd) tensor
   // produced by a gather + a K = E product: the same dot products (same kernel, same k order: bit-identical rows), 39 rows instead of 6144 at C3,
   // and 50 MB less written and read per step.  The backward pass follows (decoder_backward: sums of d z by token).  AOCR_NO_EMB_TABLE=1: the tensor.
-  m->emb_table = use_cl && segsum_supported(4 * Hd, m->V, E) && !env_on("AOCR_NO_EMB_TABLE");
+  // Round 6: the launch chain of bf16 mode takes the table too (its gate epilogue gathers the token's row, as the decode path always did): at the reference-default
+  // shape the (L B, 4 Hd) tensor was a 157 MB product in front of the loop and a K = 4 Hd -> E product + scatter behind it (87 + 99 us of a 8.3 ms step).
+  m->emb_table = (use_cl || (sh && !env_on("AOCR_NO_EMB_TABLE_CHAIN"))) && segsum_supported(4 * Hd, m->V, E) && !env_on("AOCR_NO_EMB_TABLE");
   if (m->tab_ready) { hipStreamWaitEvent(s, m->tab_done, 0); m->tab_ready = false; m->tab_valid = true; }       // step_prologue of this call (joined even when unused: the decode path writes the same buffer)
   if (m->emb_table) { if (!m->tab_valid) { gemm(s, bf, m->lookup, E, true, p1.wi, p1.in, true, m->bzx_tab, 4 * Hd, m->V, 4 * Hd, E, p1.bi, p1.bh, 0); m->tab_valid = true; } }      // (tab_valid: this API call already has the table -- the beam pass in front of a gold pass)
   else {
@@ -998,6 +1000,7 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
   for (int t = 0; t < L; ++t) {
     DecStepIO io; io.R = B; io.ctx_div = 1;
     io.zx1 = m->zx1_all + (size_t)t * B * 4 * Hd; io.feed = m->out_all + (size_t)t * slot;
+    if (m->emb_table) { io.zx1 = m->bzx_tab; io.zx_tok = tgt + (int64_t)t * st; io.zx_tok_stride = sb; }      // row b of step t reads the table row of its token
     for (int l = 0; l < m->Ld; ++l) {
       io.c_prev[l] = m->dcs[l] + (size_t)t * slot; io.h_prev[l] = m->dhs[l] + (size_t)t * slot;
       io.c_new[l] = m->dcs[l] + (size_t)(t + 1) * slot; io.h_new[l] = m->dhs[l] + (size_t)(t + 1) * slot;

@@ -1094,12 +1094,14 @@ __global__ __launch_bounds__(64 * NW) void attn_reg_h512_kernel(const bf16_t* __
 // registers (RW x NC 16-byte fragments per lane) and serves the score pass and the weighted-sum pass -- one read of the context, as in
 // attn_reg_h512_kernel, for T up to 256 (C4's widest bucket is T = 199).  STREAM = true: any T (C5: T = 1785), two passes over the
 // bf16 shadow in chunks of 16 RW rows, scores parked in LDS in between.  Softmax / its backward over T by wave 0.
-template <bool BWD, int NC, int RW, bool STREAM>
-__global__ __launch_bounds__(1024) void attn_bf16_kernel(const bf16_t* __restrict__ ctx, const float* __restrict__ u, int64_t ldu,
+// NW (round 6): 8 waves for T <= 32 at Hd = 1024 (the reference-default decoder: T = 24) -- half the barrier population and half the 64 KB reduction image of the
+// 16-wave form, twice the workgroups per CU: reference-default step 8.42 -> 8.26 ms (48 calls per step; four waves of 8 rows measured slower: 8.32).  AOCR_ATTN_NW16=1: the 16-wave form.
+template <bool BWD, int NC, int RW, bool STREAM, int NW = 16>
+__global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(const bf16_t* __restrict__ ctx, const float* __restrict__ u, int64_t ldu,
                                                          const float* __restrict__ a_in, float* __restrict__ p_out,
                                                          float* __restrict__ o, int64_t ldo, int T, int ctx_div,
                                                          bf16_t* __restrict__ ob, int64_t ldob) {
-  constexpr int NW = 16, Hd = 512 * NC;
+  constexpr int Hd = 512 * NC;
   extern __shared__ float sc[];                                 // T scores / probabilities
   __shared__ __attribute__((aligned(16))) float red[NW][Hd];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1208,6 +1210,8 @@ static void attn_launch(hipStream_t s, const float* ctx, const float* u, int64_t
   else if (bf_ok && Hd == 512 && T <= 128) AOCR_ATTN_BF16(1, 8, false);
   else if (bf_ok && Hd == 512 && T <= 256) AOCR_ATTN_BF16(1, 16, false);
   else if (bf_ok && Hd == 512) AOCR_ATTN_BF16(1, 4, true);
+  else if (bf_ok && Hd == 1024 && T <= 32 && !getenv("AOCR_ATTN_NW16"))
+    hipLaunchKernelGGL((attn_bf16_kernel<BWD, 2, 4, false, 8>), dim3(B), dim3(512), (size_t)T * sizeof(float), s, ctxb, u, ldu, a_in, p_out, o, ldo, T, ctx_div, ob, ldob);
   else if (bf_ok && Hd == 1024 && T <= 64) AOCR_ATTN_BF16(2, 4, false);
   else if (bf_ok && Hd == 1024 && T <= 128) AOCR_ATTN_BF16(2, 8, false);
   else if (bf_ok && Hd == 1024) AOCR_ATTN_BF16(2, 4, true);
