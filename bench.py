@@ -32,7 +32,9 @@ WORKLOADS = {
     "c4": dict(B=64, W=800, L=24, He=256, Le=1, Ld=2, compute="bf16", widths=list(range(64, 801, 32)),
                name="32x{64..800} crops in 24 width buckets, batch 64/GPU, VGG-7 + BiLSTM(256) + 2-layer attn decoder, L=24"),
     # BASELINE.json configs[4]: 128x1024 full-line strips (the CNN leaves 7 x 255 feature positions: T = 1785), 2-layer BiLSTM(512), beam-5 decode
-    "c5": dict(B=16, W=1024, H=128, L=24, He=512, Le=2, Ld=2, compute="bf16", beam=5, name="128x1024 strips, batch 16/GPU, VGG-7 + 2-layer BiLSTM(512) + 2-layer attn decoder, L=24, beam-5 decode"),
+    # BASELINE names no batch.  Round 6: 256 strips per GPU -- the batch at which the encoder's 16-row groups cover the chip (2 directions x 16 groups x 8 CUs; at the
+    # 16 strips of rounds 1-5 they kept 16-32 of 256 CUs busy for 88 % of the step: 0.59 k lines/s was a property of the batch).  `--batch 16|64|128` for the others.
+    "c5": dict(B=256, W=1024, H=128, L=24, He=512, Le=2, Ld=2, compute="bf16", beam=5, name="128x1024 strips, batch 256/GPU, VGG-7 + 2-layer BiLSTM(512) + 2-layer attn decoder, L=24, beam-5 decode"),
 }
 PEAK = {"bf16": 2500.0, "f32": 157.3}          # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0
@@ -130,6 +132,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--compute", default=None, choices=["f32", "bf16"])
+    ap.add_argument("--batch", type=int, default=None, help="lines per GPU instead of the workload's own (c5: BASELINE names no batch; 16 / 64 / 128 are reported)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-steps", type=int, default=20)
@@ -159,6 +162,8 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.compute:
         wl["compute"] = args.compute
+    if args.batch:
+        wl["name"] = wl["name"].replace(f"batch {wl['B']}/GPU", f"batch {args.batch}/GPU"); wl["B"] = args.batch
     rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("AOCR_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit if the run exceeds N seconds
         import faulthandler

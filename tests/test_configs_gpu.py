@@ -272,12 +272,15 @@ def test_c4_bucket_sequence_one_model(cuda):
 
 
 # ------------------------------------------------------------------------------------------------ C5: 128x1024 strips
-def test_c5_full_geometry(cuda):
+@pytest.mark.parametrize("B", [16, 256])
+def test_c5_full_geometry(cuda, B):
     """BASELINE configs[4] at full geometry: 128x1024 strips (the CNN leaves 7 x 255 positions, T = 1785, row-major as View(512,-1)
-    of cnn.lua:44 strings them), 2-layer BiLSTM(512), Hd = 1024, beam-width-5 decode; 16 strips per GPU.  No oracle at this
-    size (the structure is checked against it at 64x40 in test_step_gpu.py::test_tall_strips...): properties with assertions."""
+    of cnn.lua:44 strings them), 2-layer BiLSTM(512), Hd = 1024, beam-width-5 decode; 16 strips per GPU (2 x 2 x 8 compute units of the encoder's
+    groups busy) and 256 -- the batch bench.py reports the configuration at (round 6: BASELINE names none; at 256 the encoder's 16-row groups cover the
+    chip: 2 directions x 16 groups x 8 CUs, and the decoder's step products run on stepl.h).  No oracle at this size (the structure is checked against it
+    at 64x40 in test_step_gpu.py::test_tall_strips...): properties with assertions."""
     import aocr
-    B, H, W, L = 16, 128, 1024, 24
+    H, W, L = 128, 1024, 24
     m = aocr.Model().create(dict(encoder_num_hidden=512, encoder_num_layers=2, decoder_num_layers=2, input_feed=True, batch_size=B,
                                  img_h=H, max_img_w=W, max_decoder_l=30, max_beam=5, compute="bf16", learning_rate=0.1, seed=1))
     img, tgt, tge, nnz = aocr.synth.synth_batch(B, W, seed=5, max_len=L - 1, H=H)
@@ -300,7 +303,7 @@ def test_c5_full_geometry(cuda):
     out2 = m._dec_out
     same = (out2.labels == out1.labels[perm]).all(axis=1)
     print(f"[property] C5 beam 5: {int(same.sum())}/{B} label rows identical under permutation; loss {loss:.3f} vs {lossp:.3f}")
-    assert same.sum() >= B - 1 and lossp == pytest.approx(loss, rel=1e-3)
+    assert same.sum() >= B - max(1, B // 64) and lossp == pytest.approx(loss, rel=1e-3)      # (a near-tie between two hypotheses may fall differently for a row)
     assert np.abs(out2.scores - out1.scores[perm])[same].max() < 2e-2
     # beam 5 never scores below greedy on the same model (the greedy path is inside the beam at every step unless pruned by
     # higher-scoring prefixes; the final answer is the max over the beam, model.lua:574)

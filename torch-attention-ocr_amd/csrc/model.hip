@@ -564,7 +564,7 @@ static void encoder_forward_pipe(aocr_model* m, const Dims& d, int C, int clG, i
         e.w = m->enc[dir][l].swh.wb; e.zx = m->ezx[dir][l]; e.hs = m->ehs[dir][l]; e.cs = m->ecs[dir][l]; e.hsb = m->ehs_b[dir][l];
         e.gates = m->egates[dir][l]; e.ctx = top ? m->context + dir * He : nullptr; e.reverse = dir;
       }
-      enc_cluster_forward(sl, a, clG, clRT, comm_reserved_cus(m));
+      enc_cluster_forward(sl, a, clG, clRT, comm_reserved_cus(m), Le);
       if (!top) hipEventRecord(ev[l * C + c], sl);
     }
   }
@@ -700,7 +700,7 @@ static void encoder_backward_pipe(aocr_model* m, const Dims& d, int C, int clG, 
         e.dz = m->edz[dir][l]; e.dzb = m->edz_b[dir][l]; e.forward_dir = dir == 0;
         e.dbi = m->enc[dir][l].dbi; e.dbh = m->enc[dir][l].dbh;
       }
-      enc_cluster_backward(sl, a, clG, clRT, comm_reserved_cus(m));
+      enc_cluster_backward(sl, a, clG, clRT, comm_reserved_cus(m), Le);
       if (l > 0) {
         for (int dir = 0; dir < 2; ++dir) {                // d x of this chunk's steps: t = T-1-it (the fw direction's BPTT) / it
           const LstmP& p = m->enc[dir][l];

@@ -261,8 +261,8 @@ struct EncClBwdArgs { EncSeqBwdDir d[2]; int B, T, He, groups; unsigned epoch; u
 bool enc_cluster_plan(int B, int He, int T, int cus, int& G, int& RT, int& groups);
 size_t enc_cluster_xbuf_bytes(int B, int He);
 size_t enc_cluster_pbuf_bytes(int B, int He);
-void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a, int G, int RT, int reserve_cus = 0);
-void enc_cluster_backward(hipStream_t s, const EncClBwdArgs& a, int G, int RT, int reserve_cus = 0);
+void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a, int G, int RT, int reserve_cus = 0, int concurrent = 1);      // concurrent: launches of this size that run side by side (layer wavefront): half tiles only if they all fit
+void enc_cluster_backward(hipStream_t s, const EncClBwdArgs& a, int G, int RT, int reserve_cus = 0, int concurrent = 1);
 // teacher-forced decoder loop in one launch (dec_cluster.hip): Hd = 512, two layers, input feed, bf16 mode
 struct DecClFwdArgs {
   int B, T, L; unsigned epoch; int group0 = 0, ngroups = 0, force_remote = 0; int no_early = 0;   /* greedy decode: do not leave the loop when every row of a group has finished (debugging aid) */

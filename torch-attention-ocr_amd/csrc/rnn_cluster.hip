@@ -701,14 +701,15 @@ static int cluster_cus() {
   static const int cus = [] { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
   return cus;
 }
-void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a00, int G, int RT, int reserve_cus) {
+void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a00, int G, int RT, int reserve_cus, int concurrent) {
   EncClFwdArgs a0 = a00; a0.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;    // testing aid: write-through granules even inside one XCD
   // Half tiles (8 batch rows per group) whenever twice the groups still fit the chip in one launch: the step is bound by the output stores of a CU
   // (store_outputs), and half the rows are half the bytes.  C3: 32 + 32 groups of 4 = all 256 CUs instead of 128; AOCR_ENC_RH16=1: 16-row groups.
   a0.rh = 16;
   { static const char* e = getenv("AOCR_ENC_RH16");
     const int g8 = (a0.B + 7) / 8;
-    if (!(e && e[0] == '1') && RT == 1 && a0.B > 8 && 2 * g8 * G <= cluster_cus() - reserve_cus) { a0.rh = 8; a0.groups = g8; a0.gslot = a00.gslot * 2; } }
+    // (layer wavefront, round 6: `concurrent` launches of this size share the chip -- C5 at 128 strips: two layers x 128 CUs on 16-row groups overlap, two x 256 on 8-row groups would queue)
+    if (!(e && e[0] == '1') && RT == 1 && a0.B > 8 && concurrent * 2 * g8 * G <= cluster_cus() - reserve_cus) { a0.rh = 8; a0.groups = g8; a0.gslot = a00.gslot * 2; } }
   const int per_pass = std::max(8, (cluster_cus() - reserve_cus) / (8 * G) * 8);          // groups (gids) one launch can keep resident; reserve_cus: compute units left to a co-resident collective (model.h: comm_reserved_cus)
   for (int g0 = 0; g0 < 2 * a0.groups; g0 += per_pass) {
     EncClFwdArgs a = a0; a.gid0 = g0; a.ngid = std::min(per_pass, 2 * a0.groups - g0);
@@ -718,14 +719,14 @@ void enc_cluster_forward(hipStream_t s, const EncClFwdArgs& a00, int G, int RT, 
 #undef AOCR_CL
   }
 }
-void enc_cluster_backward(hipStream_t s, const EncClBwdArgs& a00, int G, int RT, int reserve_cus) {
+void enc_cluster_backward(hipStream_t s, const EncClBwdArgs& a00, int G, int RT, int reserve_cus, int concurrent) {
   EncClBwdArgs a0 = a00; a0.force_remote = getenv("AOCR_CL_REMOTE") != nullptr;
   // Half tiles as in the forward launch, but only while they leave half the chip free: the hoisted weight-gradient GEMMs run beside this kernel on the
   // side streams (C3: 128 + 128 CUs; 8-row groups there would take all 256).  AOCR_ENC_BWD_RH=8 / 16 forces one.
   a0.rh = 16;
   { static const char* e = getenv("AOCR_ENC_BWD_RH");
     const int g8 = (a0.B + 7) / 8, cus = cluster_cus() - reserve_cus;
-    const bool fits = RT == 1 && a0.B > 8 && 2 * g8 * G <= cus;
+    const bool fits = RT == 1 && a0.B > 8 && concurrent * 2 * g8 * G <= cus;
     if (fits && ((e && e[0] == '8') || (!(e && e[0] == '1') && 2 * g8 * G <= cus / 2))) { a0.rh = 8; a0.groups = g8; a0.gslot = a00.gslot * 2; } }
   const int per_pass = std::max(8, (cluster_cus() - reserve_cus) / (8 * G) * 8);
   for (int g0 = 0; g0 < 2 * a0.groups; g0 += per_pass) {
