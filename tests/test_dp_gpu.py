@@ -180,9 +180,20 @@ def _worker_timeout(rank, world, port, q):
     m.forward_logits(local, training=False)                        # (the parity taps -- the status word among them -- exist once a step has run; evaluation mode: nothing moves)
     p0 = m.params.clone(); bn0 = {k: v.clone() for k, v in m.get_bn_state().items()}
     flag = m.get_tensor_view("cl_err")[:1]
-    if rank == 1:
-        flag.fill_(23)                                              # THIS rank's encoder / decoder kernel "timed out" (injected, as in test_update_is_skipped_...)
     images, targets, targets_eval = m._upload(local)
+    if rank == 1:
+        # THIS rank's encoder / decoder kernel "times out" DURING the step: the code is injected right behind feval, in stream order, in front of the exchange (as in
+        # test_update_is_skipped_...).  (Round 6: a code that is already there when a training step STARTS is a stale one -- a decode call's -- and is moved aside
+        # by the step's prologue, include/aocr.h: aocr_cluster_status; injected before the call it would no longer model a time-out of this step.)
+        import aocr.model as AM
+        orig = AM.lib.aocr_train_forward_backward
+        armed = [True]
+        def feval_then_time_out(*a):
+            r = orig(*a)
+            if armed[0]:
+                armed[0] = False; flag.fill_(23)
+            return r
+        AM.lib.aocr_train_forward_backward = feval_then_time_out
     m.train_step_device(images, targets, targets_eval, 8)           # feval + exchange (the flag travels with it) + clip + update
     torch.cuda.synchronize()
     skipped = bool(torch.equal(m.params, p0))

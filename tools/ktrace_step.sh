@@ -1,7 +1,8 @@
 #!/bin/bash
 # one training step of a bench workload as an ordered kernel list (name, grid, workgroup, us): tools/ktrace_step.sh <workload> [extra bench args]
 # (run via gpurun) -> gpurun_out/ktrace_step_<workload>.txt
-R=$GRAFT_REPO_ROOT; wl=$1; shift; O=$R/gpurun_out/ktrace_step_raw; rm -rf $O; mkdir -p $O
+set -u
+R=${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run through gpurun)}; wl=${1:?usage: ktrace_step.sh <workload> [bench args]}; shift; O=$R/gpurun_out/ktrace_step_raw; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --workload $wl --steps 4 --warmup 2 --no-cpu-baseline --no-secondary --decode-steps 0 --sustain-seconds 0 "$@" > $O/run.log 2>&1
 cd $R

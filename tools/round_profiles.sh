@@ -16,9 +16,11 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $B $SHORT > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -- $B $SHORT > /dev/null 2>&1
 for w in c2 c3s c4 c5 ref; do
-  st=10; wu=3; [ $w = c4 ] && st=48 && wu=24; [ $w = c5 ] && st=5 && wu=2
+  st=10; wu=3; [ $w = c4 ] && st=48 && wu=24; [ $w = c5 ] && st=4 && wu=2
   timeout 300 $B --workload $w --steps $st --warmup $wu --no-cpu-baseline --no-secondary --sustain-seconds 1 > $O/bench_$w.json 2> $O/bench_$w.err
 done
+# BASELINE config 5 names no batch: the default line above is 256 strips per GPU (the encoder's groups cover the chip); the smaller batches beside it
+for b in 16 64 128; do timeout 300 $B --workload c5 --batch $b --steps 4 --warmup 2 --no-cpu-baseline --no-secondary --sustain-seconds 0 > $O/bench_c5_b$b.json 2> $O/bench_c5_b$b.err; done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -- $B --workload c2 --compute f32 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --decode-steps 0 --sustain-seconds 0 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3s -- $B --workload c3s --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --decode-steps 0 --sustain-seconds 0 > /dev/null 2>&1
 cd "$R"
@@ -34,6 +36,7 @@ cp $(ls $O/stats_c2/*/*kernel_stats.csv | head -1) $O/c2_f32_kernel_stats.csv
 # one step of C3 / C2 as an ordered launch list, and the clock / MFMA-busy pass of the fp32 kernels
 bash tools/ktrace_step.sh c3; cp gpurun_out/ktrace_step_c3.txt $O/c3_step_trace.txt
 bash tools/ktrace_step.sh c2 --compute f32; cp gpurun_out/ktrace_step_c2.txt $O/c2_step_trace.txt
+bash tools/ktrace_step.sh ref; cp gpurun_out/ktrace_step_ref.txt $O/ref_step_trace.txt
 bash tools/pmc_clock.sh c2 --compute f32; cp gpurun_out/pmc_clock_c2.txt $O/c2_pmc_clock.txt
 rm -rf $O/stats $O/stats_c3s $O/stats_c2 $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 # cycles per phase of the decoder chain kernels (training forward / backward, beam-5 decode): stamps build of the library

@@ -94,6 +94,8 @@ int main(int argc, char** argv) {
       printf("step<NT4,G1,NW4,MT1> grid %dx%d           : %7.2f us  checksum %.6e\n", H / 32, cdiv(M, 32), us, checksum(b)); }
     { float us = time_us([&](int set) { Z zz = args(b, set); hipLaunchKernelGGL((gemm_step_kernel<2, 2, LoadKh2, EpGatesFwd, 4, 4>), dim3(H / 16, cdiv(M, 128), 1), dim3(256), 0, 0, zz, H); });
       printf("step<NT2,G2,NW4,MT4> grid %dx%d            : %7.2f us  checksum %.6e\n", H / 16, cdiv(M, 128), us, checksum(b)); }
+    { float us = time_us([&](int set) { Z zz = args(b, set); hipLaunchKernelGGL((gemm_step_kernel<2, 2, LoadKh2, EpGatesFwd, 8, 1>), dim3(H / 16, cdiv(M, 32), 1), dim3(512), 0, 0, zz, H); });
+      printf("step<NT2,G2,NW8,MT1> grid %dx%d (the library's half-tile form) : %7.2f us  checksum %.6e\n", H / 16, cdiv(M, 32), us, checksum(b)); }
     { float us = time_us([&](int set) { Z zz = args(b, set); hipLaunchKernelGGL((gemm_step_kernel<2, 2, LoadKh2, EpGatesFwd, 4, 2>), dim3(H / 16, cdiv(M, 64), 1), dim3(256), 0, 0, zz, H); });
       printf("step<NT2,G2,NW4,MT2> grid %dx%d            : %7.2f us  checksum %.6e\n", H / 16, cdiv(M, 64), us, checksum(b)); }
 #define STEPL(MT, NT, G, NS, SUBS, NW, SPLITN, GX, GY) { float us = time_us([&](int set) { Z zz = args(b, set); hipLaunchKernelGGL((gemm_stepl_kernel<MT, NT, G, EpGatesFwd, NS, SUBS, NW, SPLITN>), dim3((GX) * (GY)), dim3(64 * NW), 0, 0, zz, H, GX, GY); }); \

@@ -312,14 +312,17 @@ static void launch_small_bf16(hipStream_t s, int nz, const ARGS* z, int M, int n
   hipLaunchKernelGGL((gemm_small_kernel<true, NT, GATES, decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)>), grid, dim3(256), 0, s,
                      zz, gate_stride);
 }
-// Large-batch form of the step products (stepl.h): taken when its workgroups (64-row tiles) fill most of the chip -- below that the step kernels' 32-row tiles and
-// half gate tiles spread the launch over more compute units -- and the K range is whole groups of the LDS-DMA ring.  AOCR_NO_STEPL=1: off (A/B runs, parity tests);
-// AOCR_STEPL_MIN_WGS=n: the workgroup count from which it is taken (default 160 of the 256 compute units).
+// Large-batch form of the step products (stepl.h).  Shape conditions here; WHEN it is taken is decided per kind of launch from tools/ubench/step400.hip (M = 32 .. 1280,
+// Hd = 512 / 1024, the library's own kernels side by side):
+//   gate products: whenever the half-gate-tile grid of gemm_step_kernel<2, 2, ..., 8 waves> would be more than ONE round of the chip -- in one round that kernel wins
+//     (Hd = 1024: 11.2 against 15.4 us at 128 rows), beyond it stepl.h does (192 rows: 19.2 / 15.9, 400 rows: 31.0 / 18.8; Hd = 512 at 400 rows: 13.9 / 11.6);
+//   three plain products per launch: from 160 workgroups of 64 x 128 (400 rows x N = 1024: 38.8 / 30.8 us; at 256 rows the small tiles win);
+//   one plain product: only at K >= 4096 and >= 160 workgroups (1280 rows: 37.3 / 28.4 us) -- below that its 416+ small workgroups beat every tile shape here.
+// AOCR_NO_STEPL=1: off (A/B runs, parity tests); AOCR_STEPL_MIN_WGS=n: taken from n of its own workgroups, whatever the kind (tests force it at small batch).
+static int stepl_min_wgs() { const char* const e = getenv("AOCR_STEPL_MIN_WGS"); return e ? atoi(e) : -1; }
 template <class ARGS>
-static bool stepl_eligible(const ARGS* z, int nz, int M, int wgs) {
+static bool stepl_eligible(const ARGS* z, int nz, int M) {
   if (env_is_1("AOCR_NO_STEPL")) return false;
-  const char* const e = getenv("AOCR_STEPL_MIN_WGS");
-  if (wgs < (e ? atoi(e) : 160)) return false;
   for (int i = 0; i < nz; ++i) {
     const auto& a = z[i].a; const auto& b = z[i].b;
     if (z[i].K <= 0 || z[i].K % 128 || a.K0 % 64 || b.K0 != a.K0 || (a.p1 != nullptr) != (b.p1 != nullptr)) return false;
@@ -336,7 +339,7 @@ static void launch_small_bf16_hh(hipStream_t s, int nz, const ARGS* z, int M, in
   SmallArgs2<decltype(z[0].a), decltype(z[0].b), decltype(z[0].ep)> zz; zz.z[0] = z[0]; zz.z[1] = z[nz > 1 ? 1 : 0]; zz.z[2] = z[nz > 2 ? 2 : 0];
   if constexpr (GATES && NT == 4) {
     // large batch (round 6; the reference-default decoder: 400 rows x Hd = 1024): 64 x 128 gate tiles on the LDS-DMA ring, eight waves, four-unit epilogue (stepl.h)
-    if (stepl_eligible(z, nz, M, cdiv(ncols, 32) * cdiv(M, 64) * nz)) {
+    if (stepl_eligible(z, nz, M) && (stepl_min_wgs() >= 0 ? (ncols / 32) * cdiv(M, 64) * nz >= stepl_min_wgs() : (ncols / 16) * cdiv(M, 32) * nz > 256)) {
       const int gx = ncols / 32, gy = cdiv(M, 64);
       hipLaunchKernelGGL((gemm_stepl_kernel<2, 4, 1, decltype(z[0].ep), 6, 2, 8, true>), dim3(gx * gy * nz), dim3(512), 0, s, zz, gate_stride, gx, gy);
       return;
@@ -357,9 +360,9 @@ static void launch_small_bf16_hh(hipStream_t s, int nz, const ARGS* z, int M, in
       } }
   }
   if constexpr (!GATES && NT == 1) {
-    // three plain products per launch at large batch (the backward step's d z W_h2h / input-feed group: 3 x 56 tiles of 64 x 128 fill the chip): stepl.h, 39 -> 29 us
-    // at 400 rows, K = 4096; ONE product per launch (56 tiles) stays below: its 416 small workgroups beat every tile shape of stepl.h (tools/ubench/step400.hip)
-    if (nz == 3 && ncols % 128 == 0 && stepl_eligible(z, nz, M, (ncols / 128) * cdiv(M, 64) * nz)) {
+    // plain products at large batch (the backward step's d z W_h2h / input-feed group of three; single deep products from ~1280 rows): stepl.h, see stepl_eligible
+    const int lw = ncols % 128 == 0 ? (ncols / 128) * cdiv(M, 64) * nz : 0;          // its workgroups
+    if (lw > 0 && stepl_eligible(z, nz, M) && (stepl_min_wgs() >= 0 ? lw >= stepl_min_wgs() : lw >= 160 && (nz == 3 || (nz == 1 && z[0].K >= 4096)))) {
       const int gx = ncols / 128, gy = cdiv(M, 64);
       hipLaunchKernelGGL((gemm_stepl_kernel<2, 4, 0, decltype(z[0].ep), 6, 2, 8, true>), dim3(gx * gy * nz), dim3(512), 0, s, zz, gate_stride, gx, gy);
       return;
