@@ -98,6 +98,29 @@ def test_host_datagen_list_and_labels(tmp_path):
         data.DataGen(str(tmp_path), "nope.txt", 8.0)
 
 
+def test_host_datagen_decodes_png_and_jpeg(tmp_path):
+    """data_gen.lua:67 `image.load`: PNG (lossless: exact pixels, gray stays one channel, RGBA / palette become RGB) and JPEG (lossy: close to the source)
+    through Pillow; an undecodable file is a skipped line (None), as a failed image.load is in the reference."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "torch-attention-ocr_amd"))
+    data = pytest.importorskip("aocr.data")
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    gray = rng.integers(0, 256, (20, 64), dtype=np.uint8)
+    rgb = rng.integers(0, 256, (20, 64, 3), dtype=np.uint8)
+    Image.fromarray(gray, "L").save(tmp_path / "g.png")
+    Image.fromarray(rgb, "RGB").save(tmp_path / "c.png")
+    Image.fromarray(np.dstack([rgb, np.full((20, 64), 200, np.uint8)]), "RGBA").save(tmp_path / "a.png")
+    smooth = np.clip(np.add.outer(np.arange(20) * 6, np.arange(64) * 2), 0, 255).astype(np.uint8)
+    Image.fromarray(np.dstack([smooth, smooth // 2, 255 - smooth]), "RGB").save(tmp_path / "s.jpg", quality=95)
+    (tmp_path / "broken.png").write_bytes(b"not a png")
+    np.testing.assert_array_equal(data.load_image(str(tmp_path / "g.png")), gray)
+    np.testing.assert_array_equal(data.load_image(str(tmp_path / "c.png")), rgb)
+    np.testing.assert_array_equal(data.load_image(str(tmp_path / "a.png")), rgb)
+    j = data.load_image(str(tmp_path / "s.jpg"))
+    assert j.shape == (20, 64, 3) and j.dtype == np.uint8 and np.abs(j[..., 0].astype(int) - smooth).mean() < 3
+    assert data.load_image(str(tmp_path / "broken.png")) is None
+
+
 def test_data_oracle_matches_golden():
     """oracle/data_oracle.py against its committed fixture tests/golden/data_path.npz (made by oracle/gen_golden.py)."""
     import importlib.util

@@ -7,8 +7,9 @@ training loop reads the same.  The image arithmetic (255*rgb2y, image.scale to 3
 label -> id conversion (utils.lua:104-118) and the target assembly.  There is no CPU fallback for the image path.
 
 Differences from the reference, all deliberate:
-  * image decoding: the image has no JPEG/PNG decoder library (torch/image links libjpeg/libpng), so a line's file is read
-    as ``.npy`` (H,W or H,W,3 uint8), binary ``.pgm`` (P5) or ``.ppm`` (P6); a custom ``loader`` may be passed;
+  * image decoding (data_gen.lua:67 ``image.load``): ``.npy`` (H,W or H,W,3 uint8), binary ``.pgm`` (P5) / ``.ppm`` (P6) are read directly; every other
+    file (JPEG, PNG, ...) goes through Pillow when it is installed (round 6; torch/image links libjpeg / libpng itself: PNG is lossless, JPEG pixels may
+    differ by an LSB between decoder versions -- unpinned like the rest of the data path); a custom ``loader`` may be passed;
   * ``force_width=100`` reproduces data_gen.lua:78 (the reference overrides the aspect-ratio width with 100);
     ``force_width=None`` applies the aspect-ratio rule of lines 72-77;
   * ``shuffle`` uses numpy's generator instead of Lua's ``math.random`` (not reproducible across the two anyway);
@@ -67,13 +68,27 @@ def _read_pnm(path):
     return a.reshape(h, w) if c == 1 else a.reshape(h, w, 3)
 
 
+def _read_pillow(path):
+    """JPEG / PNG / ... through Pillow: gray files stay one channel, everything else becomes RGB (what 255 * image.rgb2y then reduces, data_gen.lua:68)."""
+    from PIL import Image                                   # optional dependency: a missing Pillow makes the line unreadable (skipped, as a failed image.load is)
+    with Image.open(path) as im:
+        im.load()
+        if im.mode in ("1", "L", "I;16", "I", "F"):
+            im = im.convert("L")
+        elif im.mode != "RGB":
+            im = im.convert("RGB")                          # palette, RGBA (alpha dropped), CMYK, LA
+        return np.asarray(im, dtype=np.uint8)
+
+
 def load_image(path):
     """uint8 (H,W) or (H,W,3) array, or None when the file cannot be read (data_gen.lua:66: a failed load skips the line)."""
     try:
         if path.endswith(".npy"):
             a = np.load(path)
-        else:
+        elif path.lower().endswith((".pgm", ".ppm", ".pnm")):
             a = _read_pnm(path)
+        else:
+            a = _read_pillow(path)
         if a.dtype != np.uint8 or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
             return None
         return np.ascontiguousarray(a)
