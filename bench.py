@@ -512,10 +512,10 @@ def main():
         msw, kflw = m.profile_kernel(1, 20)
         achw = kflw / (msw * 1e-3) / 1e12
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "r05_wgrad_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r06_wgrad_pmc.json")
         if bf16 and args.workload == "c3" and world == 1 and args.scaling == "weak" and os.path.exists(pmc):
             traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
-            traffic_source = ("profiles/r05_wgrad_pmc.json: rocprofv3 --pmc passes of this command on the tagged conv6 filter-gradient launch "
+            traffic_source = ("profiles/r06_wgrad_pmc.json: rocprofv3 --pmc passes of this command on the tagged conv6 filter-gradient launch "
                               "(tools/pmc_traffic.py); PMC counters cannot be read from inside the timed process, so this field is NOT measured in this run")
         step_frac = 3 * fl["total"] * lines_per_s / 1e12 / (peak * world)
         wg_share = (families or {}).get("conv_wgrad", {}).get("ms_per_step", 0.0) / max(1e-9, (families or {}).get("_sum_ms", 1.0))
@@ -527,7 +527,7 @@ def main():
         if bf16:
             # context for `peak` (not a replacement for it): what a K loop that does nothing but v_mfma_f32_32x32x16_bf16 on register-resident RANDOM bf16
             # operands sustains on this chip -- the shader clock falls from 2.4 to ~1.7 GHz under it (power); profiles/r03_gemm4w_ubench.txt, tools/ubench/gemm4w.hip
-            mo, mo_src = None, os.path.join("profiles", "r05_gemm4w_steady.txt")
+            mo, mo_src = None, os.path.join("profiles", "r06_gemm4w_steady.txt")
             try:                                          # tools/ubench/gemm4w after 5000 warm-up launches: the "MFMA on resident random fragments" rows, best of the file
                 mo = max(float(l.split("TFLOP/s")[0].split()[-1]) for l in open(os.path.join(ROOT, mo_src)) if "MFMA on resident random fragments" in l)
             except Exception:
