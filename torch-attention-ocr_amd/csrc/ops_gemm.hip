@@ -467,7 +467,7 @@ void gemm_hh(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64
   // (round 3, again with that kernel's output tile staged through LDS: hoisted GEMMs 0.750 -> 0.760 ms per step: still no faster)
   // hoisted bf16 GEMMs with full 256 x 128 tiles that fill the chip: the narrow LDS-DMA kernel (two workgroups per CU: one's epilogue under the other's 16-step K loop):
   // hoisted GEMMs 0.739 -> 0.713 ms per C3 step (AOCR_NO_HH_NARROW=1: the 128 x 128 kernel)
-  if (!getenv("AOCR_NO_HH_NARROW") && !dma_disabled() && M % 256 == 0 && N % 128 == 0 && K % 32 == 0 && (M / 256) * (N / 128) >= 200) { launch_dma_narrow(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K); return; }
+  if (!getenv("AOCR_NO_HH_NARROW") && !dma_disabled() && (M % 256 == 0 || (M >= 256 && !env_is_1("AOCR_HH_NARROW_FULL_ONLY"))) && N % 128 == 0 && K % 32 == 0 && cdiv(M, 256) * (N / 128) >= 200) { launch_dma_narrow(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K); return; }
   if (dma128_eligible(M, N, K, 32)) { launch_dma128(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K); return; }       // small / ragged M (32-64 lines per GPU)
   launch_lds(s, a, b, make_store(C, ldc, M, N, bias, bias2, flags), M, N, K, 1);
 }
@@ -475,7 +475,7 @@ void gemm_hh(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64
 // C = [A0 | A1] . [B0 | B1]^T  (K = K0 + K1 over two buffer pairs; bf16, K-contiguous), one launch of the narrow LDS-DMA kernel.  Returns false when the
 // shape does not take that kernel (the caller then runs two products).
 bool gemm_hh_cat(hipStream_t s, const bf16_t* A0, const bf16_t* A1, int64_t lda, const bf16_t* B0, const bf16_t* B1, int64_t ldb, float* C, int64_t ldc, int M, int N, int K0, int K1) {
-  if (getenv("AOCR_NO_HH_NARROW") || env_is_1("AOCR_NO_HH_CAT") || dma_disabled() || M % 256 || N % 128 || K0 % 32 || K1 % 32 || (M / 256) * (N / 128) < 200) return false;
+  if (getenv("AOCR_NO_HH_NARROW") || env_is_1("AOCR_NO_HH_CAT") || dma_disabled() || (M % 256 && (M < 256 || env_is_1("AOCR_HH_NARROW_FULL_ONLY"))) || N % 128 || K0 % 32 || K1 % 32 || cdiv(M, 256) * (N / 128) < 200) return false;
   LoadKhCat a; a.p0 = A0; a.p1 = A1; a.ld0 = a.ld1 = lda; a.rows = M; a.K0 = K0; a.K = K0 + K1;
   LoadKhCat b; b.p0 = B0; b.p1 = B1; b.ld0 = b.ld1 = ldb; b.rows = N; b.K0 = K0; b.K = K0 + K1;
   launch_dma_narrow(s, a, b, make_store(C, ldc, M, N, nullptr, nullptr, 0), M, N, K0 + K1);
@@ -487,7 +487,7 @@ void gemm_hh_shadow(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B
   LoadKh a; a.p = A; a.ld = lda; a.rows = M; a.K = K;
   LoadKh b; b.p = B; b.ld = ldb; b.rows = N; b.K = K;
   EpStore e = make_store(C, ldc, M, N, nullptr, nullptr, 0); e.Cb = Cb; e.ldcb = ldcb;
-  if (!getenv("AOCR_NO_HH_NARROW") && !dma_disabled() && M % 256 == 0 && N % 128 == 0 && K % 32 == 0 && (M / 256) * (N / 128) >= 200) {
+  if (!getenv("AOCR_NO_HH_NARROW") && !dma_disabled() && (M % 256 == 0 || (M >= 256 && !env_is_1("AOCR_HH_NARROW_FULL_ONLY"))) && N % 128 == 0 && K % 32 == 0 && cdiv(M, 256) * (N / 128) >= 200) {
     if (!env_is_1("AOCR_NO_NARROW_STAGED")) e.C = nullptr;      // every reader takes the bf16 copy (ctx W_a of the decoder kernels): the staged tile skips the fp32 store (33 MB per C3 step)
     launch_dma_narrow(s, a, b, e, M, N, K); return;
   }
