@@ -153,6 +153,35 @@ def test_reference_default_step_kernel_routes_agree(cuda, monkeypatch, B):
     print(f"[parity] B={B} stepl vs step kernels: worst gradient rel {worst[1]:.3e} ({worst[0]})")
 
 
+@pytest.mark.parametrize("B,W", [(48, 100), (21, 256)])
+def test_reference_default_chain_scores_against_premultiplied_context(cuda, monkeypatch, B, W):
+    """Round 6: the Hd = 1024 launch chain scores attention against bf16(ctx W_a) (LSTM.lua:131-137: ctx[t] . (W_a h) = (ctx W_a)[t] . h), as the whole-sequence
+    kernels of Hd = 512 do: no q = W_a h launch per forward step, no K = Hd product in the second cell launch of the backward step (its attention part comes
+    out of the attention backward kernel as a second weighted sum), q of all steps as one hoisted product for d(context).  Against AOCR_NO_CHAIN_CTXA=1 (q per
+    step): the same number of bf16 roundings per score term in another place -- logits 2e-3, every gradient tensor as two summation orders
+    (W = 256: T = 63, the 16-wave form of the kernel; W = 100: T = 24, the 8-wave form)."""
+    out = {}
+    for knob in ("", "1"):
+        monkeypatch.delenv("AOCR_NO_CHAIN_CTXA", raising=False)
+        if knob:
+            monkeypatch.setenv("AOCR_NO_CHAIN_CTXA", knob)
+        m, O, ocfg, P, st, batch = make(REF_DEFAULT, B=B, W=W, maxlen=9, compute="bf16", max_decoder_l=12, max_beam=1)
+        loss = m.train_forward_backward(batch)
+        out[knob] = dict(loss=loss, logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), dctx=m.get_tensor("dcontext").clone(),
+                         grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.shutdown()
+    a, b = out["1"], out[""]
+    e = (a["logits"] - b["logits"]).abs().max().item()
+    ed = relerr(b["dctx"], a["dctx"])
+    print(f"[parity] chain on ctx W_a vs q per step, B={B} W={W}: logits max-abs {e:.3e}, d(context) rel {ed:.3e}, loss {b['loss']:.4f} vs {a['loss']:.4f}")
+    assert e < 2e-3 and ed < 3e-2 and abs(a["loss"] - b["loss"]) < 1e-3 * abs(a["loss"])
+    for k in a["grads"]:
+        if k in NOISY:
+            continue
+        r, cs = relerr(b["grads"][k], a["grads"][k]), cosine(b["grads"][k], a["grads"][k])
+        assert cs > (0.99 if k.startswith("cnn.") else 0.9995) and r < (0.3 if k.startswith("cnn.") else 5e-2), (k, r, cs)
+
+
 def _properties(m, ocfg, batch, B, compute, lin_tol=None, perm_tol=None):
     img, tgt, tge, nnz, names = batch
     loss1 = m.train_forward_backward(batch, grad_scale=1.0 / B)

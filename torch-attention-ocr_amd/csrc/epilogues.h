@@ -403,6 +403,7 @@ struct EpGatesFwd {
 struct EpGatesBwd {
   const float* dh1; int64_t ld1;          // optional extra d(h_out) terms [m][j]
   const float* dh2; int64_t ld2;
+  const float* dh3 = nullptr; int64_t ld3 = 0;      // (round 6: a third term -- the attention part of d h_top when the chain scores against ctx W_a)
   const float* dc_in; int64_t lddc;       // optional d(c_out) [m][j]
   const float* gates; int64_t ldg;
   const float* c_prev; int64_t ldcp;
@@ -424,6 +425,7 @@ struct EpGatesBwd {
       if (drop.on()) dh *= drop.mask((long long)row * H + j);
       if (dh1) dh += dh1[(int64_t)row * ld1 + j];
       if (dh2) dh += dh2[(int64_t)row * ld2 + j];
+      if (dh3) dh += dh3[(int64_t)row * ld3 + j];
       float ig, fg, og, gg;
       if (gil) { const float4 g4 = *reinterpret_cast<const float4*>(gates + (int64_t)row * ldg + 4 * j); ig = g4.x; fg = g4.y; og = g4.z; gg = g4.w; }
       else { const float* gp = gates + (int64_t)row * ldg + j; ig = gp[0]; fg = gp[H]; og = gp[2 * H]; gg = gp[3 * H]; }
@@ -443,13 +445,14 @@ struct EpGatesBwd {
     }
   }
   // loads only, see EpGatesFwd::prefetch: absent terms and rows / columns past the end load the row's c (dropped in elem())
-  struct Pre { float dh1, dh2, dc, ig, fg, og, gg, c, cp; };
+  struct Pre { float dh1, dh2, dh3, dc, ig, fg, og, gg, c, cp; };
   __device__ __forceinline__ Pre prefetch(int row, int j) const {
     Pre p;
     const int rr = max(min(row, M - 1), 0), jj = min(j, H - 1);
     const float* const cq = c + (int64_t)rr * ldcc + jj;
     p.dh1 = *(dh1 ? dh1 + (int64_t)rr * ld1 + jj : cq);
     p.dh2 = *(dh2 ? dh2 + (int64_t)rr * ld2 + jj : cq);
+    p.dh3 = *(dh3 ? dh3 + (int64_t)rr * ld3 + jj : cq);
     p.dc = *(dc_in ? dc_in + (int64_t)rr * lddc + jj : cq);
     if (gil) { const float4 g4 = *reinterpret_cast<const float4*>(gates + (int64_t)rr * ldg + 4 * jj); p.ig = g4.x; p.fg = g4.y; p.og = g4.z; p.gg = g4.w; }
     else { const float* gp = gates + (int64_t)rr * ldg + jj; p.ig = gp[0]; p.fg = gp[H]; p.og = gp[2 * H]; p.gg = gp[3 * H]; }
@@ -465,6 +468,7 @@ struct EpGatesBwd {
     float pdh = 0.f;
     if (dh1) pdh = pre.dh1;
     if (dh2) pdh += pre.dh2;
+    if (dh3) pdh += pre.dh3;
     const float pdc = dc_in ? pre.dc : 0.f;
     float dh = (drop.on() ? v[0] * drop.mask((long long)row * H + j) : v[0]) + pdh;
     float ig = pre.ig, fg = pre.fg, og = pre.og, gg = pre.gg;

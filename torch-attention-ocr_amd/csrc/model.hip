@@ -171,6 +171,7 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     m->cl_xtab = a.get<unsigned long long>(m->cl_tbytes / 8);      // XCC ids of the members of every group
     m->cl_err = a.get<int>(16 + 256 * 8 + 4096);                 // error flag + the trash slots rows >= B store to + a debugging timeline
     m->bn_snap = a.get<float>(2 * (256 + 512 + 512));            // aocr_bn_state_count() floats
+    if (Hd == 1024) m->ctxa_b = a.get<bf16_t>(B * T * Hd);        // the launch chain scores attention against ctx W_a too (round 6: attn_bf16_kernel<..., DUAL>, taken at T <= 64)
     if (Hd == 512 && m->Ld == 2 && m->cfg.input_feed) {          // the decoder loop as one launch (dec_cluster.hip)
       m->dc_xbytes = dec_cluster_xbuf_bytes((int)B); m->dc_tbytes = dec_cluster_xtab_bytes((int)std::max<size_t>(B, 32 * (size_t)dec_chain_beam_group_cap()));      // (beam search on the chain kernel indexes by the group within a launch: up to one group per XCD)
       m->dc_xbuf = a.get<unsigned long long>(m->dc_xbytes / 8); m->dc_xtab = a.get<unsigned long long>(m->dc_tbytes / 8);
@@ -292,6 +293,7 @@ static void run_store_nn_group(aocr_model* m, int n, const LoadK* a, const ShW* 
 // gate backward: d(h) GEMM part = x W (K may be 0: no GEMM part)
 static void run_gates_bwd(aocr_model* m, int nz, const LoadK* a, const ShW* const* w, const EpGatesBwd* ep, int M, int H,
                           const LoadKh2* ah = nullptr) {
+  if (nz == 1 && a[0].K == 0 && ep[0].drop.thr == 0) { gates_elem_bwd(m->s, ep[0], M, H); return; }      // no GEMM part (round 6: the chain's top cell when the attention backward kernel supplies d h's attention part)
   if (m->bf16 && hh_ok(ah, nz, H)) {
     GatesBwdArgsHH z[2];
     for (int i = 0; i < nz; ++i) { z[i].a = ah[i]; z[i].b = make_loadkh(w[i]->wtb, w[i]->R, w[i]->C, ah[i].K); z[i].ep = ep[i]; z[i].K = ah[i].K; }
@@ -857,6 +859,7 @@ struct DecStepIO {
   const float* c_prev[MAXL]; const float* h_prev[MAXL];
   float* c_new[MAXL]; float* h_new[MAXL]; float* gates[MAXL];
   float *q, *a, *cat, *out;
+  const bf16_t* ctxa = nullptr;                                 // bf16(ctx W_a): scores against it, no q = W_a h launch (training chain at Hd = 1024, T <= 64)
   // bf16 shadows (teacher-forced path in bf16 mode; nullptr otherwise)
   const bf16_t* feed_b = nullptr; const bf16_t* hb_prev[MAXL] = {nullptr, nullptr, nullptr, nullptr};
   bf16_t* hb_new[MAXL] = {nullptr, nullptr, nullptr, nullptr}; bf16_t* cat_b = nullptr; bf16_t* out_b = nullptr;
@@ -896,9 +899,13 @@ static void dec_step_forward(aocr_model* m, const DecStepIO& io, int T) {
   }
   {
     const bool sh = io.hb_new[0] != nullptr;
-    LoadKh2 qa = make_loadkh(sh ? io.hb_new[m->Ld - 1] : nullptr, Hd, R, Hd);
-    run_store_nt(m, make_loadk(io.h_new[m->Ld - 1], Hd, R, Hd), m->swa, make_store(io.q, Hd, R, Hd), R, &qa);      // q = W_a h_top, LSTM.lua:131
-    attention_forward(s, m->context, io.q, io.a, io.cat, 2 * Hd, R, T, Hd, io.ctx_div, io.cat_b, 2 * Hd, m->context_b);
+    if (io.ctxa && attention_dual_ok(T, Hd, m->context_b, io.ctxa))
+      attention_forward_dual(s, io.h_new[m->Ld - 1], Hd, io.a, io.cat, 2 * Hd, R, T, io.ctx_div, io.cat_b, 2 * Hd, m->context_b, io.ctxa);      // ctx[t] . (W_a h) = (ctx W_a)[t] . h
+    else {
+      LoadKh2 qa = make_loadkh(sh ? io.hb_new[m->Ld - 1] : nullptr, Hd, R, Hd);
+      run_store_nt(m, make_loadk(io.h_new[m->Ld - 1], Hd, R, Hd), m->swa, make_store(io.q, Hd, R, Hd), R, &qa);      // q = W_a h_top, LSTM.lua:131
+      attention_forward(s, m->context, io.q, io.a, io.cat, 2 * Hd, R, T, Hd, io.ctx_div, io.cat_b, 2 * Hd, m->context_b);
+    }
     EpStore eo = make_store(io.out, Hd, R, Hd, nullptr, nullptr, EP_TANH);
     eo.Cb = io.out_b; eo.ldcb = Hd;
     LoadKh2 ca = make_loadkh(sh ? io.cat_b : nullptr, 2 * Hd, R, 2 * Hd);
@@ -996,9 +1003,14 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
         hipEventRecord(m->q_done, m->side); m->q_pending = true;
       } else gemm_hh(s, m->dhs_b[1] + slot, Hd, m->swa.wb, Hd, m->q_all, Hd, L * B, Hd, Hd, nullptr, nullptr, 0);
     }
-  } else
+  } else {
+  // the chain at Hd = 1024 scores against the pre-multiplied context as well (bf16 shadows, T <= 64): one hoisted (B T, Hd) x (Hd, Hd) product instead of L launches of q = W_a h
+  const bool chain_ctxa = sh && m->ctxa_b && m->swa.wtb && attention_dual_ok(T, Hd, m->context_b, m->ctxa_b);
+  if (chain_ctxa && !m->ctxa_fresh) gemm_hh_shadow(s, m->context_b, Hd, m->swa.wtb, Hd, m->dctx, Hd, m->ctxa_b, Hd, B * T, Hd, Hd);
+  m->ctxa_fresh = false;
   for (int t = 0; t < L; ++t) {
     DecStepIO io; io.R = B; io.ctx_div = 1;
+    if (chain_ctxa) io.ctxa = m->ctxa_b;
     io.zx1 = m->zx1_all + (size_t)t * B * 4 * Hd; io.feed = m->out_all + (size_t)t * slot;
     if (m->emb_table) { io.zx1 = m->bzx_tab; io.zx_tok = tgt + (int64_t)t * st; io.zx_tok_stride = sb; }      // row b of step t reads the table row of its token
     for (int l = 0; l < m->Ld; ++l) {
@@ -1020,6 +1032,9 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
       io.drop_out = drop_site(m, 16, (long long)t * (long long)slot);
     }
     dec_step_forward(m, io, T);
+  }
+  if (chain_ctxa && keep_gates)                                    // q = W_a h_top of all L steps for the backward pass's d(context) (attention_dctx), as behind the whole-sequence kernel
+    gemm_hh(s, m->dhs_b[m->Ld - 1] + slot, Hd, m->swa.wb, Hd, m->q_all, Hd, L * B, Hd, Hd, nullptr, nullptr, 0);
   }
   prof_mark(m, AOCR_PROF_RNN_GEMM);
   gemm(s, bf, m->out_all + slot, Hd, true, m->wo, Hd, true, m->logits, LOGIT_LD, L * B, m->V, Hd, m->bo, nullptr, 0);
@@ -1150,12 +1165,20 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
                   sh ? m->dpre_b + (size_t)t * slot : nullptr, &dsp); }
     LoadKh2 dpa = make_loadkh(sh ? m->dpre_b + (size_t)t * slot : nullptr, Hd, B, Hd);
     run_store_nn(m, make_loadk(dpre, Hd, B, Hd), m->swc, make_store(dcat, 2 * Hd, B, 2 * Hd), B, &dpa);      // d[c ; h_top] = dpre W_c
+    const bool bwd_ctxa = sh && m->ctxa_b && attention_dual_ok(T, Hd, m->context_b, m->ctxa_b);     // (the forward chain of this step made the same choice: same conditions)
+    if (bwd_ctxa)       // d q as before (d W_a, hoisted) AND d h_top's attention part = sum_t d s[t] (ctx W_a)[t], into the decode path's idle q buffer
+      attention_backward_dual(s, m->a_all + (size_t)t * B * T, dcat, 2 * Hd, m->ds_all + (size_t)t * B * T, m->dq_all + (size_t)t * slot, m->dq_b + (size_t)t * slot, m->bq, B, T, m->context_b, m->ctxa_b);
+    else
     attention_backward(s, m->context, m->q_all + (size_t)t * slot, m->a_all + (size_t)t * B * T, dcat, 2 * Hd,
                        m->ds_all + (size_t)t * B * T, m->dq_all + (size_t)t * slot, B, T, Hd, sh ? m->dq_b + (size_t)t * slot : nullptr, m->context_b);
     // top layer: d h_top = dq W_a + dcat[:, Hd:] + recurrent part
     for (int l = Ld - 1; l >= 0; --l) {
       LoadK la; LoadKh2 lah; EpGatesBwd e; const ShW* ww;
-      if (l == Ld - 1) {
+      if (l == Ld - 1 && bwd_ctxa) {                                  // no product: d h_top = attention part + d cat[:, Hd:] + recurrent part
+        la = make_loadk(m->dq_all + (size_t)t * slot, Hd, B, 0); ww = &m->swa;
+        lah = make_loadkh(nullptr, Hd, B, 0);
+        e.dh1 = dcat + Hd; e.ld1 = 2 * Hd; e.dh3 = m->bq; e.ld3 = Hd;
+      } else if (l == Ld - 1) {
         la = make_loadk(m->dq_all + (size_t)t * slot, Hd, B, Hd); ww = &m->swa;
         lah = make_loadkh(sh ? m->dq_b + (size_t)t * slot : nullptr, Hd, B, Hd);
         e.dh1 = dcat + Hd; e.ld1 = 2 * Hd;

@@ -156,6 +156,12 @@ void bn_relu_backward(hipStream_t s, const float* x, const float* y, const float
 // ctx_div: rows r share context row r / ctx_div (beam search keeps one context per image, model.lua:373)
 void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a, float* c, int64_t ldc, int B, int T, int Hd,
                        int ctx_div = 1, bf16_t* cb = nullptr, int64_t ldcb = 0, const bf16_t* ctxb = nullptr);
+void gates_elem_bwd(hipStream_t s, const EpGatesBwd& ep, int M, int H);       // LSTM cell backward without a product (ops_gemm.hip)
+bool attention_dual_ok(int T, int Hd, const bf16_t* ctxb, const bf16_t* ctxab);     // scores against the pre-multiplied context (round 6, ops_misc.hip: attn_bf16_kernel<..., DUAL>)
+void attention_forward_dual(hipStream_t s, const float* h_top, int64_t ldh, float* a, float* c, int64_t ldc, int B, int T, int ctx_div, bf16_t* cb, int64_t ldcb,
+                            const bf16_t* ctxb, const bf16_t* ctxab);
+void attention_backward_dual(hipStream_t s, const float* a, const float* dc, int64_t lddc, float* ds, float* dq, bf16_t* dqb, float* dh_attn, int B, int T,
+                             const bf16_t* ctxb, const bf16_t* ctxab);
 void attention_backward(hipStream_t s, const float* ctx, const float* q, const float* a, const float* dc, int64_t lddc,
                         float* ds, float* dq, int B, int T, int Hd, bf16_t* dqb = nullptr, const bf16_t* ctxb = nullptr);
 // ctxb: bf16 shadow of ctx, read instead of ctx by the register-resident kernels (T <= 64, Hd in {256, 512})

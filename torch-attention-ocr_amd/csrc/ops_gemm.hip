@@ -416,6 +416,18 @@ __global__ __launch_bounds__(256) void gates_elem_fwd_kernel(const float* __rest
   for (int g = 0; g < 4; ++g) v[g] = z[(int64_t)row * ldz + (int64_t)g * ep.H + j];
   ep.elem<4>(row, j, 0, v, pre);
 }
+// LSTM cell backward with NO product in front of it (d h comes entirely from the epilogue's own terms): one element per thread, operands by the loads-only prefetch
+__global__ __launch_bounds__(256) void gates_elem_bwd_kernel(EpGatesBwd ep) {
+  const int j = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+  if (j >= ep.H) return;
+  const EpGatesBwd::Pre pre = ep.prefetch(row, j);
+  const float v[1] = {0.f};
+  ep.elem<1>(row, j, 0, v, pre);
+}
+void gates_elem_bwd(hipStream_t s, const EpGatesBwd& ep, int M, int H) {
+  if (M <= 0 || H <= 0) return;
+  hipLaunchKernelGGL(gates_elem_bwd_kernel, dim3(cdiv(H, 256), M), dim3(256), 0, s, ep);
+}
 bool big_step_gates_fwd(hipStream_t s, const LoadKh2& a, const LoadKh2& b, const EpGatesFwd& ep, int M, int H, float* zbuf, size_t zbuf_floats) {
   if (!zbuf || zbuf_floats < (size_t)M * 4 * H || !big_step_store(s, a, b, make_store(zbuf, 4 * H, M, 4 * H, nullptr, nullptr, 0), M, 4 * H)) return false;
   hipLaunchKernelGGL(gates_elem_fwd_kernel, dim3(cdiv(H, 256), M), dim3(256), 0, s, zbuf, (int64_t)4 * H, ep);

@@ -1096,16 +1096,23 @@ __global__ __launch_bounds__(64 * NW) void attn_reg_h512_kernel(const bf16_t* __
 // bf16 shadow in chunks of 16 RW rows, scores parked in LDS in between.  Softmax / its backward over T by wave 0.
 // NW (round 6): 8 waves for T <= 32 at Hd = 1024 (the reference-default decoder: T = 24) -- half the barrier population and half the 64 KB reduction image of the
 // 16-wave form, twice the workgroups per CU: reference-default step 8.42 -> 8.26 ms (48 calls per step; four waves of 8 rows measured slower: 8.32).  AOCR_ATTN_NW16=1: the 16-wave form.
-template <bool BWD, int NC, int RW, bool STREAM, int NW = 16>
+// DUAL (round 6, the Hd = 1024 launch chain at T <= 64): scores against the PRE-MULTIPLIED context, as the whole-sequence kernels do -- ctx[t] . (W_a h) =
+// (ctx W_a)[t] . h (LSTM.lua:131-137) -- so the chain has no q = W_a h launch per step and the second cell launch of the backward step no K = Hd product:
+// forward: scores from ctx2 = bf16(ctx W_a) against u = h_top, weighted sum from ctx; backward: scores (d a) and d q from ctx as before, and a SECOND weighted
+// sum of the same d s over ctx2 = d h_top's attention part, written to o2.  The context is read twice per call (19.7 MB each at the reference-default shape).
+template <bool BWD, int NC, int RW, bool STREAM, int NW = 16, bool DUAL = false>
 __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(const bf16_t* __restrict__ ctx, const float* __restrict__ u, int64_t ldu,
                                                          const float* __restrict__ a_in, float* __restrict__ p_out,
                                                          float* __restrict__ o, int64_t ldo, int T, int ctx_div,
-                                                         bf16_t* __restrict__ ob, int64_t ldob) {
+                                                         bf16_t* __restrict__ ob, int64_t ldob,
+                                                         const bf16_t* __restrict__ ctx2 = nullptr, float* __restrict__ o2 = nullptr, int64_t ldo2 = 0) {
+  static_assert(!(DUAL && STREAM), "the two-context form keeps a row's slice in registers");
   constexpr int Hd = 512 * NC;
   extern __shared__ float sc[];                                 // T scores / probabilities
   __shared__ __attribute__((aligned(16))) float red[NW][Hd];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bf16_t* cb = ctx + (int64_t)(b / ctx_div) * T * Hd + lane * 8;
+  const bf16_t* cb2 = DUAL ? ctx2 + (int64_t)(b / ctx_div) * T * Hd + lane * 8 : cb;
   const float* ub = u + (int64_t)b * ldu + lane * 8;
   float uu[NC][8];
 #pragma unroll
@@ -1114,13 +1121,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(const bf16_t* __rest
     uu[cc][0] = u0.x; uu[cc][1] = u0.y; uu[cc][2] = u0.z; uu[cc][3] = u0.w; uu[cc][4] = u1.x; uu[cc][5] = u1.y; uu[cc][6] = u1.z; uu[cc][7] = u1.w;
   }
   bf16x8 c[RW][NC];
-  auto load_rows = [&](int t0) {
+  auto load_rows = [&](const bf16_t* base, int t0) {
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       const int t = t0 + wave + NW * i;
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) {
-        if (t < T) c[i][cc] = *reinterpret_cast<const bf16x8*>(cb + (int64_t)t * Hd + cc * 512);
+        if (t < T) c[i][cc] = *reinterpret_cast<const bf16x8*>(base + (int64_t)t * Hd + cc * 512);
         else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) c[i][cc][e] = (bf16_t)0.f;
@@ -1141,8 +1148,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(const bf16_t* __rest
       if (lane == 0 && t < T) sc[t] = s;
     }
   };
-  if (!STREAM) { load_rows(0); scores(0); }
-  else for (int t0 = 0; t0 < T; t0 += NW * RW) { load_rows(t0); scores(t0); }
+  if (!STREAM) { load_rows((DUAL && !BWD) ? cb2 : cb, 0); scores(0); }
+  else for (int t0 = 0; t0 < T; t0 += NW * RW) { load_rows(cb, t0); scores(t0); }
   __syncthreads();
   if (wave == 0) {                                              // softmax (forward) / softmax backward over T
     if (!BWD) {
@@ -1161,12 +1168,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(const bf16_t* __rest
       for (int t = lane; t < T; t += 64) { const float p = a_in[(int64_t)b * T + t] * (sc[t] - dot); sc[t] = p; p_out[(int64_t)b * T + t] = p; }
     }
   }
+  if (DUAL && !BWD) load_rows(cb, 0);                           // (issued in front of the barrier: the rows arrive under wave 0's softmax)
   __syncthreads();
   float acc[NC][8];
-#pragma unroll
-  for (int cc = 0; cc < NC; ++cc)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[cc][e] = 0.f;
   auto accumulate = [&](int t0) {
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
@@ -1178,20 +1182,37 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(const bf16_t* __rest
         for (int e = 0; e < 8; ++e) acc[cc][e] = fmaf(p, (float)c[i][cc][e], acc[cc][e]);
     }
   };
+  auto reduce_store = [&](float* oo, int64_t ld, bf16_t* oob, int64_t ldb) {
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8]) = make_float4(acc[cc][0], acc[cc][1], acc[cc][2], acc[cc][3]);
+      *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8 + 4]) = make_float4(acc[cc][4], acc[cc][5], acc[cc][6], acc[cc][7]);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < Hd; j += 64 * NW) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; q += 4) v += (red[q][j] + red[q + 1][j]) + (red[q + 2][j] + red[q + 3][j]);
+      oo[(int64_t)b * ld + j] = v;
+      if (oob) oob[(int64_t)b * ldb + j] = (bf16_t)v;
+    }
+  };
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[cc][e] = 0.f;
   if (!STREAM) accumulate(0);
-  else for (int t0 = 0; t0 < T; t0 += NW * RW) { load_rows(t0); accumulate(t0); }
+  else for (int t0 = 0; t0 < T; t0 += NW * RW) { load_rows(cb, t0); accumulate(t0); }
+  if (DUAL && BWD) load_rows(cb2, 0);                           // the second weighted sum's rows, requested under the first one's reduction
+  reduce_store(o, ldo, ob, ldob);
+  if (DUAL && BWD) {
+    __syncthreads();                                            // every thread is done with the reduction image
 #pragma unroll
-  for (int cc = 0; cc < NC; ++cc) {
-    *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8]) = make_float4(acc[cc][0], acc[cc][1], acc[cc][2], acc[cc][3]);
-    *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8 + 4]) = make_float4(acc[cc][4], acc[cc][5], acc[cc][6], acc[cc][7]);
-  }
-  __syncthreads();
-  for (int j = threadIdx.x; j < Hd; j += 64 * NW) {
-    float v = 0.f;
+    for (int cc = 0; cc < NC; ++cc)
 #pragma unroll
-    for (int q = 0; q < NW; q += 4) v += (red[q][j] + red[q + 1][j]) + (red[q + 2][j] + red[q + 3][j]);
-    o[(int64_t)b * ldo + j] = v;
-    if (ob) ob[(int64_t)b * ldob + j] = (bf16_t)v;
+      for (int e = 0; e < 8; ++e) acc[cc][e] = 0.f;
+    accumulate(0);
+    reduce_store(o2, ldo2, nullptr, 0);
   }
 }
 
@@ -1231,6 +1252,19 @@ void attention_backward(hipStream_t s, const float* ctx, const float* q, const f
                         float* ds, float* dq, int B, int T, int Hd, bf16_t* dqb, const bf16_t* ctxb) {
   (void)q;
   attn_launch<true>(s, ctx, dc, lddc, a, ds, dq, (int64_t)Hd, B, T, Hd, 1, dqb, (int64_t)Hd, ctxb);
+}
+
+// Two-context forms (attn_bf16_kernel<..., DUAL>): Hd = 1024, T <= 64, bf16 context and its pre-multiplied copy ctxa = bf16(ctx W_a).  false: shape not taken.
+bool attention_dual_ok(int T, int Hd, const bf16_t* ctxb, const bf16_t* ctxab) { return Hd == 1024 && T <= 64 && ctxb && ctxab && !getenv("AOCR_NO_CHAIN_CTXA"); }
+void attention_forward_dual(hipStream_t s, const float* h_top, int64_t ldh, float* a, float* c, int64_t ldc, int B, int T, int ctx_div, bf16_t* cb, int64_t ldcb,
+                            const bf16_t* ctxb, const bf16_t* ctxab) {
+  if (T <= 32) hipLaunchKernelGGL((attn_bf16_kernel<false, 2, 4, false, 8, true>), dim3(B), dim3(512), (size_t)T * sizeof(float), s, ctxb, h_top, ldh, nullptr, a, c, ldc, T, ctx_div, cb, ldcb, ctxab, nullptr, (int64_t)0);
+  else hipLaunchKernelGGL((attn_bf16_kernel<false, 2, 4, false, 16, true>), dim3(B), dim3(1024), (size_t)T * sizeof(float), s, ctxb, h_top, ldh, nullptr, a, c, ldc, T, ctx_div, cb, ldcb, ctxab, nullptr, (int64_t)0);
+}
+void attention_backward_dual(hipStream_t s, const float* a, const float* dc, int64_t lddc, float* ds, float* dq, bf16_t* dqb, float* dh_attn, int B, int T,
+                             const bf16_t* ctxb, const bf16_t* ctxab) {
+  if (T <= 32) hipLaunchKernelGGL((attn_bf16_kernel<true, 2, 4, false, 8, true>), dim3(B), dim3(512), (size_t)T * sizeof(float), s, ctxb, dc, lddc, a, ds, dq, (int64_t)1024, T, 1, dqb, (int64_t)1024, ctxab, dh_attn, (int64_t)1024);
+  else hipLaunchKernelGGL((attn_bf16_kernel<true, 2, 4, false, 16, true>), dim3(B), dim3(1024), (size_t)T * sizeof(float), s, ctxb, dc, lddc, a, ds, dq, (int64_t)1024, T, 1, dqb, (int64_t)1024, ctxab, dh_attn, (int64_t)1024);
 }
 
 // d(ctx)[b,t,j] = sum_l a[l,b,t]*dc[l,b,j] + ds[l,b,t]*q[l,b,j]  (model.lua:652-653 accumulated over the decoder loop)
