@@ -368,6 +368,17 @@ static void launch_small_bf16_hh(hipStream_t s, int nz, const ARGS* z, int M, in
       return;
     }
   }
+  if constexpr (!GATES && NT == 1) {
+    // ONE deep plain product at large batch (K >= 2048 at >= 320 rows: the backward step's d z_2 W_i2h in front of the lower cell, the out product): two row tiles per workgroup, 64 x 32
+    // tiles on 224 workgroups of 8 waves -- 16.6 -> 14.8 us (tools/ubench/step400.hip; at K = 1024 and for three products per launch the 32 x 32 tiles win).  Same K
+    // split and summation order as the one-tile form: bit-identical.  AOCR_NO_STEP_MT2=1: off
+    { const char* e = getenv("AOCR_NO_STEP_MT2");
+      const char* const mk = getenv("AOCR_STEP_MT2_MINK");        // the K from which the two-tile form is taken (A/B on the reference-default step: decoder 3.31 ms at 4096, 3.26 at 2048, 3.31 at 1024)
+      if (!(e && e[0] == '1') && nz == 1 && z[0].K >= (mk ? atoi(mk) : 2048) && M >= 320 && cdiv(ncols, 32) * cdiv(M, 64) >= 200 && step_waves8()) {
+        hipLaunchKernelGGL((gemm_step_kernel<1, 0, decltype(z[0].a), decltype(z[0].ep), 8, 2>), dim3(cdiv(ncols, 32), cdiv(M, 64), nz), dim3(512), 0, s, zz, gate_stride);
+        return;
+      } }
+  }
   // (measured and dropped: 64 x 64 tiles -- NT = 2, MT = 2, eight waves -- for the plain step products of the backward pass at M = 400: 336 workgroups instead of
   //  1248, 350 MB instead of 640 MB per launch, decoder backward 2.27 -> 2.34 ms: there the many small workgroups are what hides the latency)
   if constexpr (NT == 1) {
