@@ -182,6 +182,40 @@ def test_reference_default_chain_scores_against_premultiplied_context(cuda, monk
         assert cs > (0.99 if k.startswith("cnn.") else 0.9995) and r < (0.3 if k.startswith("cnn.") else 5e-2), (k, r, cs)
 
 
+@pytest.mark.parametrize("beam,B,force", [(1, 21, False), (3, 21, True), (5, 6, False)])
+def test_reference_default_decode_chain_on_shadows(cuda, monkeypatch, beam, B, force):
+    """Round 6: the decode launch chain (Hd = 1024 has no whole-sequence decoder: `-phase test` of the reference-default model, BASELINE config 5's beam-5 decode)
+    keeps bf16 shadows of its beam state -- gate / attention epilogues write them, the gather by parent converts -- so its step products are the training chain's
+    (from ~130 rows stepl.h; scores against ctx W_a) instead of the fp32-activation kernels: 121.7 -> 64.7 us per step at 400 rows.  Both forms round the same
+    fp32 values to bf16, so against AOCR_NO_DECODE_SHADOWS=1: labels equal (a near-tie may move one row), scores / gold scores / loss to bf16-path noise; and
+    against the fp64 oracle's decode_beam.  force: stepl.h at this small batch (AOCR_STEPL_MIN_WGS=1)."""
+    out = {}
+    if force:
+        monkeypatch.setenv("AOCR_STEPL_MIN_WGS", "1")
+    for knob in ("", "1"):
+        monkeypatch.delenv("AOCR_NO_DECODE_SHADOWS", raising=False)
+        if knob:
+            monkeypatch.setenv("AOCR_NO_DECODE_SHADOWS", knob)
+        m, O, ocfg, P, st, batch = make(REF_DEFAULT, B=B, W=100, maxlen=7, compute="bf16", max_decoder_l=12, max_beam=5)
+        st = {k: (v + 0.05 if k.endswith("rm") else v * 1.3) for k, v in st.items()}
+        m.set_parameters(P, st)
+        loss, stats = m.step(batch, True, beam)
+        out[knob] = (loss, m._dec_out.labels.copy(), m._dec_out.scores.copy(), m._dec_out.gold_scores.copy())
+        if not knob and B <= 8:
+            img, tgt, tge = tensors(batch)
+            ref = O.decode_beam(P, st, ocfg, img, tgt, tge, beam=beam, max_decoder_l=12)
+            same = (m._dec_out.labels == ref["labels"].numpy().astype(np.int32)).all(axis=1)
+            print(f"[parity] decode chain on shadows, beam {beam} B={B}: {int(same.sum())}/{B} label rows equal to the oracle's; loss {loss:.4f} vs {float(ref['loss']):.4f}")
+            assert same.sum() >= B - 1 and abs(loss - float(ref["loss"])) < 5e-3 * max(1.0, float(ref["loss"]))
+            assert np.abs(m._dec_out.gold_scores - ref["gold_scores"].numpy()).max() < 5e-2
+        m.shutdown()
+    (l1, lab1, sc1, g1), (l0, lab0, sc0, g0) = out[""], out["1"]
+    same = (lab1 == lab0).all(axis=1)
+    print(f"[parity] decode chain on shadows vs fp32-activation kernels, beam {beam} B={B}: {int(same.sum())}/{B} label rows equal; loss {l1:.4f} vs {l0:.4f}")
+    assert same.sum() >= B - 1 and abs(l1 - l0) < 2e-3 * abs(l0)
+    assert np.abs(sc1 - sc0)[same].max() < 2e-2 and np.abs(g1 - g0).max() < 2e-2
+
+
 def _properties(m, ocfg, batch, B, compute, lin_tol=None, perm_tol=None):
     img, tgt, tge, nnz, names = batch
     loss1 = m.train_forward_backward(batch, grad_scale=1.0 / B)

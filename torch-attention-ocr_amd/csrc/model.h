@@ -96,6 +96,8 @@ struct aocr_model {
   float *dh_rec[aocr::MAXL], *dc_st[aocr::MAXL], *dfeed, *loss_tmp;
   // decode (rows = B*beam)
   float *bc[2][aocr::MAXL], *bh[2][aocr::MAXL], *bfeed[2], *bc_new[aocr::MAXL], *bh_new[aocr::MAXL];
+  // round 6: bf16 shadows of the decode launch chain's beam state (bf16 mode), so that its step products take both operands from shadows like the training chain (stepl.h, scores against ctx W_a)
+  aocr::bf16_t *bh_b[2][aocr::MAXL] = {}, *bfeed_b[2] = {}, *bh_new_b[aocr::MAXL] = {}, *bcat_b = nullptr;
   float *bzx1, *bzx_tab, *bq, *ba, *bcat, *bout, *blogits, *blogp, *beam_scores;     // bzx_tab [V][4Hd]: per-token first-layer gate input
   int32_t *hist_tok, *hist_par, *tgt_pad, *tge_pad, *trie_loc[2];   // trie_loc: dictionary node of every beam (ping-pong)
   void* sgd_scratch;

@@ -154,6 +154,11 @@ int model_carve(aocr_model* m, void* base, size_t bytes) {
     m->bfeed[p] = a.get<float>(R * Hd);
   }
   for (int l = 0; l < m->Ld; ++l) { m->bc_new[l] = a.get<float>(R * Hd); m->bh_new[l] = a.get<float>(R * Hd); }
+  if (m->bf16) {
+    for (int p = 0; p < 2; ++p) { for (int l = 0; l < m->Ld; ++l) m->bh_b[p][l] = a.get<bf16_t>(R * Hd); m->bfeed_b[p] = a.get<bf16_t>(R * Hd); }
+    for (int l = 0; l < m->Ld; ++l) m->bh_new_b[l] = a.get<bf16_t>(R * Hd);
+    m->bcat_b = a.get<bf16_t>(R * 2 * Hd);
+  }
   m->bzx1 = a.get<float>(R * 4 * Hd); m->bzx_tab = a.get<float>((size_t)m->V * 4 * Hd); m->bq = a.get<float>(R * Hd); m->ba = a.get<float>(R * T);
   m->bcat = a.get<float>(R * 2 * Hd); m->bout = a.get<float>(R * Hd); m->blogits = a.get<float>(R * LOGIT_LD);
   m->blogp = a.get<float>(R * m->V); m->beam_scores = a.get<float>(R);
@@ -916,13 +921,14 @@ static void dec_step_forward(aocr_model* m, const DecStepIO& io, int T) {
 }
 
 // initial decoder state from the encoder's final states, model.lua:539-552 (+ quirk S5)
-static void dec_init_state(aocr_model* m, const Dims& d, float* const* c0, float* const* h0, float* feed0, int R, bool shadows = false) {
+static void dec_init_state(aocr_model* m, const Dims& d, float* const* c0, float* const* h0, float* feed0, int R, bool shadows = false,
+                           bf16_t* const* hb0 = nullptr, bf16_t* feedb0 = nullptr) {      // hb0 / feedb0: bf16 copies of the initial state somewhere else than the training buffers (decode chain)
   const int B = d.B, T = d.T, He = m->He, Hd = m->Hd; const size_t slot = (size_t)B * He;
   (void)R;
   const int lt = m->Le - 1;
   DecInitArgs a{};
-  for (int l = 0; l < m->Ld && l < 4; ++l) { a.c0[l] = c0[l]; a.h0[l] = h0[l]; a.hb[l] = shadows ? m->dhs_b[l] : nullptr; }
-  a.feed0 = feed0; a.outb = shadows ? m->out_b : nullptr;
+  for (int l = 0; l < m->Ld && l < 4; ++l) { a.c0[l] = c0[l]; a.h0[l] = h0[l]; a.hb[l] = hb0 ? hb0[l] : (shadows ? m->dhs_b[l] : nullptr); }
+  a.feed0 = feed0; a.outb = feedb0 ? feedb0 : (shadows ? m->out_b : nullptr);
   // c1(0) = [c_fw(T) ; c_bw(1)]; model.lua:549-552 (quirk S5) zeroes h1(0) instead of h2(0) with input feed and two or more layers
   a.cfw = m->ecs[0][lt] + (size_t)T * slot; a.cbw = m->ecs[1][lt] + (size_t)1 * slot;
   a.hfw = m->ehs[0][lt] + (size_t)T * slot; a.hbw = m->ehs[1][lt] + (size_t)1 * slot;
@@ -1374,7 +1380,13 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
     beam_backtrace(s, m->hist_tok, m->hist_par, m->beam_scores, labels, scores, Lt, B, k);
     return;
   }
-  dec_init_state(m, d, c0, h0, m->bfeed[0], B);                    // the launch chain's beam buffers (the greedy cluster kernel above has its own: not initialised for nothing)
+  // Round 6: in bf16 mode the chain keeps bf16 shadows of its beam state (the gate / attention epilogues write them, the gather by parent converts), so its step
+  // products read both operands from shadows -- the kernels of the training chain (from ~130 rows stepl.h; at Hd = 1024 and T <= 64 scores against ctx W_a) instead
+  // of the fp32-activation forms.  The products round the same fp32 values to bf16 either way.  AOCR_NO_DECODE_SHADOWS=1: off
+  const bool dsh = m->bf16 && m->bcat_b && !env_on("AOCR_NO_DECODE_SHADOWS");
+  const bool dctxa = dsh && m->ctxa_b && m->swa.wtb && attention_dual_ok(T, Hd, m->context_b, m->ctxa_b);
+  if (dctxa) { if (!m->ctxa_fresh) gemm_hh_shadow(s, m->context_b, Hd, m->swa.wtb, Hd, m->dctx, Hd, m->ctxa_b, Hd, B * T, Hd, Hd); m->ctxa_fresh = true; }      // (the gold pass of this call scores against the same context)
+  dec_init_state(m, d, c0, h0, m->bfeed[0], B, false, dsh ? m->bh_b[0] : nullptr, dsh ? m->bfeed_b[0] : nullptr);      // the launch chain's beam buffers (the greedy cluster kernel above has its own: not initialised for nothing)
   int cur = 0;
   for (int t = 0; t < Lt; ++t) {
     const int kin = t == 0 ? 1 : k, R = B * kin;
@@ -1391,6 +1403,12 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
     }
     float* out = (direct && m->cfg.input_feed) ? m->bfeed[nxt] : m->bout;
     io.q = m->bq; io.a = m->ba; io.cat = m->bcat; io.out = out;
+    if (dsh) {
+      io.feed_b = m->bfeed_b[cur]; io.cat_b = m->bcat_b;
+      io.out_b = (direct && m->cfg.input_feed) ? m->bfeed_b[nxt] : nullptr;       // (beam > 1: the gather below writes the next feed's shadow from the fp32 rows)
+      for (int l = 0; l < Ld; ++l) { io.hb_prev[l] = m->bh_b[cur][l]; io.hb_new[l] = direct ? m->bh_b[nxt][l] : m->bh_new_b[l]; }
+      if (dctxa) io.ctxa = m->ctxa_b;
+    }
     dec_step_forward(m, io, T);
     // dictionary constraint: the node of every beam ping-pongs between trie_loc[0/1] (model.lua:380-387: all beams start at trie[2])
     TrieView tvs{}; const TrieView* tv = nullptr;
@@ -1412,11 +1430,11 @@ void decode_beam(aocr_model* m, const Dims& d, const int32_t* tgt, int beam, int
     }
     if (!direct) {
       const int32_t* par = m->hist_par + (size_t)t * B * k;
-      const float* gs[2 * MAXL + 1]; float* gd[2 * MAXL + 1]; int ng = 0;      // model.lua:521-535: gather states by parent beam, one launch
-      for (int l = 0; l < Ld; ++l) { gs[ng] = m->bc_new[l]; gd[ng++] = m->bc[nxt][l]; gs[ng] = m->bh_new[l]; gd[ng++] = m->bh[nxt][l]; }
-      if (m->cfg.input_feed) { gs[ng] = m->bout; gd[ng++] = m->bfeed[nxt]; }
-      if (ng <= 8) gather_beam_rows_many(s, ng, gs, gd, Hd, par, B, kin, k, Hd);
-      else for (int i = 0; i < ng; ++i) gather_beam_rows(s, gs[i], Hd, gd[i], Hd, par, B, kin, k, Hd);
+      const float* gs[2 * MAXL + 1]; float* gd[2 * MAXL + 1]; bf16_t* gb[2 * MAXL + 1]; int ng = 0;      // model.lua:521-535: gather states by parent beam, one launch
+      for (int l = 0; l < Ld; ++l) { gs[ng] = m->bc_new[l]; gb[ng] = nullptr; gd[ng++] = m->bc[nxt][l]; gs[ng] = m->bh_new[l]; gb[ng] = dsh ? m->bh_b[nxt][l] : nullptr; gd[ng++] = m->bh[nxt][l]; }
+      if (m->cfg.input_feed) { gs[ng] = m->bout; gb[ng] = dsh ? m->bfeed_b[nxt] : nullptr; gd[ng++] = m->bfeed[nxt]; }
+      if (ng <= 8) gather_beam_rows_many(s, ng, gs, gd, Hd, par, B, kin, k, Hd, dsh ? gb : nullptr);
+      else for (int i = 0; i < ng; ++i) { gather_beam_rows(s, gs[i], Hd, gd[i], Hd, par, B, kin, k, Hd); if (dsh && gb[i]) copy2d_bf16(s, gd[i], Hd, gb[i], Hd, B * k, Hd); }
     }
     cur = nxt;
   }

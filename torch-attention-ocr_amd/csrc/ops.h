@@ -225,7 +225,8 @@ void project_select(hipStream_t s, const float* h, int64_t ldh, const float* wo,
                     const TrieView* tv = nullptr);
 void token_rows(hipStream_t s, const float* table, const int32_t* tok, int64_t stride, float* dst, int R, int width);   // dst[r] = table[tok[r*stride]-1]
 // dst[b*kout+i][:] = src[(kin==1 ? b : b*kin + parents[b*kout+i])][:]
-void gather_beam_rows_many(hipStream_t s, int n, const float* const* src, float* const* dst, int64_t ld, const int32_t* parents, int B, int kin, int kout, int width);
+void gather_beam_rows_many(hipStream_t s, int n, const float* const* src, float* const* dst, int64_t ld, const int32_t* parents, int B, int kin, int kout, int width,
+                           bf16_t* const* dstb = nullptr);      // dstb[i] (optional): bf16 copy of gathered tensor i
 void gather_beam_rows(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, const int32_t* parents, int B,
                       int kin, int kout, int width);
 void beam_backtrace(hipStream_t s, const int32_t* hist_tok, const int32_t* hist_par, const float* beam_scores,

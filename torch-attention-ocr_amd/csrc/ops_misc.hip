@@ -2118,18 +2118,28 @@ void token_rows(hipStream_t s, const float* table, const int32_t* tok, int64_t s
 void gather_beam_rows(hipStream_t s, const float* src, int64_t lds, float* dst, int64_t ldd, const int32_t* parents, int B, int kin, int kout, int width);
 // the same gather for up to 8 state tensors of one decode step in ONE launch (model.lua:521-535 gathers c and h of every layer and the
 // input feed by the same parents: five dependent ~6 us dispatches per beam step before); 16-byte accesses, blockIdx.y = tensor
-struct GatherMany { const float* src[8]; float* dst[8]; };
+struct GatherMany { const float* src[8]; float* dst[8]; bf16_t* dstb[8]; };      // dstb (optional, round 6): a bf16 copy of the gathered rows (the decode chain's shadows)
 __global__ __launch_bounds__(256) void gather_rows_many_kernel(GatherMany g, int64_t ld, const int32_t* __restrict__ parents, int B, int kin, int kout, int width4) {
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (id >= (int64_t)B * kout * width4) return;
   const int c = (int)(id % width4); const int64_t r = id / width4; const int b = (int)(r / kout);
   const int sr = (kin == 1) ? b : b * kin + parents[r];
-  reinterpret_cast<float4*>(g.dst[blockIdx.y] + r * ld)[c] = reinterpret_cast<const float4*>(g.src[blockIdx.y] + (int64_t)sr * ld)[c];
+  const float4 v = reinterpret_cast<const float4*>(g.src[blockIdx.y] + (int64_t)sr * ld)[c];
+  reinterpret_cast<float4*>(g.dst[blockIdx.y] + r * ld)[c] = v;
+  if (bf16_t* const db = g.dstb[blockIdx.y]) {
+    typedef bf16_t bf16x4g __attribute__((ext_vector_type(4)));
+    bf16x4g o; o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+    reinterpret_cast<bf16x4g*>(db + r * ld)[c] = o;
+  }
 }
-void gather_beam_rows_many(hipStream_t s, int n, const float* const* src, float* const* dst, int64_t ld, const int32_t* parents, int B, int kin, int kout, int width) {
+void gather_beam_rows_many(hipStream_t s, int n, const float* const* src, float* const* dst, int64_t ld, const int32_t* parents, int B, int kin, int kout, int width,
+                           bf16_t* const* dstb) {
   if (n <= 0) return;
-  if (width % 4 || ld % 4 || n > 8) { for (int i = 0; i < n; ++i) gather_beam_rows(s, src[i], ld, dst[i], ld, parents, B, kin, kout, width); return; }
-  GatherMany g; for (int i = 0; i < 8; ++i) { g.src[i] = src[i < n ? i : 0]; g.dst[i] = dst[i < n ? i : 0]; }
+  if (width % 4 || ld % 4 || n > 8) {
+    for (int i = 0; i < n; ++i) { gather_beam_rows(s, src[i], ld, dst[i], ld, parents, B, kin, kout, width); if (dstb && dstb[i]) copy2d_bf16(s, dst[i], ld, dstb[i], ld, B * kout, width); }
+    return;
+  }
+  GatherMany g; for (int i = 0; i < 8; ++i) { g.src[i] = src[i < n ? i : 0]; g.dst[i] = dst[i < n ? i : 0]; g.dstb[i] = (dstb && i < n) ? dstb[i] : nullptr; }
   const int64_t items = (int64_t)B * kout * (width / 4);
   hipLaunchKernelGGL(gather_rows_many_kernel, dim3((unsigned)cdiv(items, 256), n), dim3(256), 0, s, g, ld, parents, B, kin, kout, width / 4);
 }
