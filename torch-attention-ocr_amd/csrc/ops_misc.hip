@@ -1216,6 +1216,116 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(const bf16_t* __rest
   }
 }
 
+// Beam decode at long T (round 6; BASELINE config 5: beam 5 over T = 1785 positions): the k hypotheses of an image attend to the SAME context rows
+// (model.lua:373: the context is not replicated), but attn_bf16_kernel<..., STREAM> runs one workgroup per hypothesis, so every context row is read 2 k times per
+// step (9.4 GB per step at 256 strips).  Here ONE workgroup per image: a chunk of rows is loaded once per pass and scored against / accumulated for all k
+// hypotheses (k <= KB query vectors and KB accumulators in registers: 8 waves, <= 256 VGPRs); softmax of row j by wave j; the cross-wave sums of the k outputs go
+// through the same LDS image one after the other.  Forward only (decode has no backward).  Same arithmetic per hypothesis as the per-row kernel up to the order
+// in which the 8 (not 16) waves' partial sums meet.
+template <int NC, int RW, int KB>
+__global__ __launch_bounds__(512) void attn_bf16_beam_kernel(const bf16_t* __restrict__ ctx, const float* __restrict__ u, int64_t ldu, float* __restrict__ p_out,
+                                                            float* __restrict__ o, int64_t ldo, int T, int k, bf16_t* __restrict__ ob, int64_t ldob) {
+  constexpr int NW = 8, Hd = 512 * NC;
+  extern __shared__ float sc[];                                 // [k][T] scores / probabilities
+  __shared__ __attribute__((aligned(16))) float red[NW][Hd];
+  const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bf16_t* cb = ctx + (int64_t)img * T * Hd + lane * 8;
+  float uu[KB][NC][8];
+#pragma unroll
+  for (int j = 0; j < KB; ++j) {
+    const float* ub = u + (int64_t)(img * k + min(j, k - 1)) * ldu + lane * 8;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      const float4 u0 = *reinterpret_cast<const float4*>(ub + cc * 512), u1 = *reinterpret_cast<const float4*>(ub + cc * 512 + 4);
+      uu[j][cc][0] = u0.x; uu[j][cc][1] = u0.y; uu[j][cc][2] = u0.z; uu[j][cc][3] = u0.w; uu[j][cc][4] = u1.x; uu[j][cc][5] = u1.y; uu[j][cc][6] = u1.z; uu[j][cc][7] = u1.w;
+    }
+  }
+  bf16x8 c[RW][NC];
+  auto load_rows = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int t = t0 + wave + NW * i;
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) {
+        if (t < T) c[i][cc] = *reinterpret_cast<const bf16x8*>(cb + (int64_t)t * Hd + cc * 512);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) c[i][cc][e] = (bf16_t)0.f;
+        }
+      }
+    }
+  };
+  for (int t0 = 0; t0 < T; t0 += NW * RW) {
+    load_rows(t0);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int t = t0 + wave + NW * i;
+#pragma unroll
+      for (int j = 0; j < KB; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s = fmaf((float)c[i][cc][e], uu[j][cc][e], s);
+        s = wave_sum(s);
+        if (lane == 0 && t < T && j < k) sc[(int64_t)j * T + t] = s;
+      }
+    }
+  }
+  __syncthreads();
+  if (wave < k) {                                               // softmax over T of hypothesis `wave`
+    float* const sj = sc + (int64_t)wave * T;
+    float m = -INFINITY;
+    for (int t = lane; t < T; t += 64) m = fmaxf(m, sj[t]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int t = lane; t < T; t += 64) { const float e = expf(sj[t] - m); sj[t] = e; sum += e; }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int t = lane; t < T; t += 64) { const float p = sj[t] * inv; sj[t] = p; p_out[(int64_t)(img * k + wave) * T + t] = p; }
+  }
+  __syncthreads();
+  float acc[KB][NC][8];
+#pragma unroll
+  for (int j = 0; j < KB; ++j)
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[j][cc][e] = 0.f;
+  for (int t0 = 0; t0 < T; t0 += NW * RW) {
+    load_rows(t0);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int t = t0 + wave + NW * i;
+#pragma unroll
+      for (int j = 0; j < KB; ++j) {
+        const float p = (t < T && j < k) ? sc[(int64_t)j * T + t] : 0.f;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[j][cc][e] = fmaf(p, (float)c[i][cc][e], acc[j][cc][e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KB; ++j) {
+    if (j >= k) break;
+    if (j > 0) __syncthreads();                                 // every thread is done with the image of hypothesis j - 1
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8]) = make_float4(acc[j][cc][0], acc[j][cc][1], acc[j][cc][2], acc[j][cc][3]);
+      *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8 + 4]) = make_float4(acc[j][cc][4], acc[j][cc][5], acc[j][cc][6], acc[j][cc][7]);
+    }
+    __syncthreads();
+    const int64_t row = (int64_t)img * k + j;
+    for (int q = threadIdx.x; q < Hd; q += 64 * NW) {
+      const float v = ((red[0][q] + red[1][q]) + (red[2][q] + red[3][q])) + ((red[4][q] + red[5][q]) + (red[6][q] + red[7][q]));
+      o[row * ldo + q] = v;
+      if (ob) ob[row * ldob + q] = (bf16_t)v;
+    }
+  }
+}
+
 constexpr int ATTN_NW = 16;
 template <bool BWD>
 static void attn_launch(hipStream_t s, const float* ctx, const float* u, int64_t ldu, const float* a_in, float* p_out, float* o,
@@ -1226,6 +1336,20 @@ static void attn_launch(hipStream_t s, const float* ctx, const float* u, int64_t
     hipLaunchKernelGGL((attn_bf16_kernel<BWD, NC, RW, STREAM>), dim3(B), dim3(1024), (size_t)T * sizeof(float), s, ctxb, u, ldu, a_in, p_out, o, \
                        ldo, T, ctx_div, ob, ldob); } while (0)
   const bool bf_ok = ctxb && ldu % 4 == 0 && !getenv("AOCR_NO_ATTN_BF16");
+  if constexpr (!BWD) {
+    // beam decode over a long context: one workgroup per IMAGE (its k hypotheses share every context row that is loaded); k <= 5, rows = images x k
+    if (bf_ok && ctx_div > 1 && ctx_div <= 5 && B % ctx_div == 0 && T > 64 && (Hd == 1024 || Hd == 512) && (size_t)ctx_div * T * 4 <= 96 * 1024 && !getenv("AOCR_NO_ATTN_BEAM_GROUP")) {
+      const size_t dyn = (size_t)ctx_div * T * sizeof(float);
+      if (Hd == 1024) {
+        if (dyn + 32 * 1024 > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_bf16_beam_kernel<2, 4, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipLaunchKernelGGL((attn_bf16_beam_kernel<2, 4, 5>), dim3(B / ctx_div), dim3(512), dyn, s, ctxb, u, ldu, p_out, o, ldo, T, ctx_div, ob, ldob);
+      } else {
+        if (dyn + 16 * 1024 > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_bf16_beam_kernel<1, 8, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipLaunchKernelGGL((attn_bf16_beam_kernel<1, 8, 5>), dim3(B / ctx_div), dim3(512), dyn, s, ctxb, u, ldu, p_out, o, ldo, T, ctx_div, ob, ldob);
+      }
+      return;
+    }
+  }
   if (T <= 64 && Hd == 512 && ctxb && ldu % 4 == 0)
     hipLaunchKernelGGL((attn_reg_h512_kernel<BWD, ATTN_NW>), dim3(B), dim3(64 * ATTN_NW), 0, s, ctxb, u, ldu, a_in, p_out, o, ldo, T, ctx_div, ob, ldob);
   else if (bf_ok && Hd == 512 && T <= 128) AOCR_ATTN_BF16(1, 8, false);
