@@ -1148,6 +1148,64 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(const bf16_t* __rest
       if (lane == 0 && t < T) sc[t] = s;
     }
   };
+  if constexpr (STREAM && !BWD) {
+    // Round 6: ONE pass over the context for the streamed forward form (C5: T = 1785, 0.94 GB of context per decoder step at 256 strips -- the two passes were
+    // most of that shape's decoder forward and decode time).  Online softmax: every wave keeps a running maximum m, the sum l of e^(s - m) and the weighted sum of
+    // its rows, rescaled when the maximum moves; the waves' (m, l) meet in LDS, each wave scales its accumulator by e^(m_w - M) / L and the usual cross-wave sum
+    // follows.  The raw scores still go through sc[] so that the probabilities (saved for the backward pass) are e^(s - M) / L of the same M, L.
+    float m_run = -INFINITY, l_run = 0.f, acc1[NC][8];
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc1[cc][e] = 0.f;
+    for (int t0 = 0; t0 < T; t0 += NW * RW) {
+      load_rows(cb, t0);
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        const int t = t0 + wave + NW * i;
+        if (t < T) {                                              // (wave-uniform)
+          float sdot = 0.f;
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sdot = fmaf((float)c[i][cc][e], uu[cc][e], sdot);
+          sdot = wave_sum(sdot);
+          if (lane == 0) sc[t] = sdot;
+          const float m_new = fmaxf(m_run, sdot), scale = __expf(m_run - m_new), pe = __expf(sdot - m_new);
+          l_run = l_run * scale + pe; m_run = m_new;
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc1[cc][e] = fmaf(pe, (float)c[i][cc][e], acc1[cc][e] * scale);
+        }
+      }
+    }
+    float* const ml = &red[0][0];                               // [NW][2] = (m_w, l_w): the reduction image is idle until reduce_store
+    if (lane == 0) { ml[2 * wave] = m_run; ml[2 * wave + 1] = l_run; }
+    __syncthreads();
+    float M = -INFINITY, Lsum = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) M = fmaxf(M, ml[2 * q]);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) Lsum += ml[2 * q + 1] * __expf(ml[2 * q] - M);      // (a wave without rows: l = 0, e^(-inf) = 0)
+    const float inv = 1.f / Lsum, wsc = __expf(m_run - M) * inv;
+    for (int t = threadIdx.x; t < T; t += 64 * NW) p_out[(int64_t)b * T + t] = __expf(sc[t] - M) * inv;
+    __syncthreads();                                            // every thread has read (m, l) before the image is overwritten
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8]) = make_float4(acc1[cc][0] * wsc, acc1[cc][1] * wsc, acc1[cc][2] * wsc, acc1[cc][3] * wsc);
+      *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8 + 4]) = make_float4(acc1[cc][4] * wsc, acc1[cc][5] * wsc, acc1[cc][6] * wsc, acc1[cc][7] * wsc);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < Hd; j += 64 * NW) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; q += 4) v += (red[q][j] + red[q + 1][j]) + (red[q + 2][j] + red[q + 3][j]);
+      o[(int64_t)b * ldo + j] = v;
+      if (ob) ob[(int64_t)b * ldob + j] = (bf16_t)v;
+    }
+    return;
+  }
   if (!STREAM) { load_rows((DUAL && !BWD) ? cb2 : cb, 0); scores(0); }
   else for (int t0 = 0; t0 < T; t0 += NW * RW) { load_rows(cb, t0); scores(t0); }
   __syncthreads();
@@ -1255,66 +1313,68 @@ __global__ __launch_bounds__(512) void attn_bf16_beam_kernel(const bf16_t* __res
       }
     }
   };
-  for (int t0 = 0; t0 < T; t0 += NW * RW) {
-    load_rows(t0);
+  // one pass (online softmax, as the streamed per-row kernel): running (m, l) and weighted sum per hypothesis and wave
+  float m_run[KB], l_run[KB], acc[KB][NC][8];
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      const int t = t0 + wave + NW * i;
-#pragma unroll
-      for (int j = 0; j < KB; ++j) {
-        float s = 0.f;
-#pragma unroll
-        for (int cc = 0; cc < NC; ++cc)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) s = fmaf((float)c[i][cc][e], uu[j][cc][e], s);
-        s = wave_sum(s);
-        if (lane == 0 && t < T && j < k) sc[(int64_t)j * T + t] = s;
-      }
-    }
-  }
-  __syncthreads();
-  if (wave < k) {                                               // softmax over T of hypothesis `wave`
-    float* const sj = sc + (int64_t)wave * T;
-    float m = -INFINITY;
-    for (int t = lane; t < T; t += 64) m = fmaxf(m, sj[t]);
-    m = wave_max(m);
-    float sum = 0.f;
-    for (int t = lane; t < T; t += 64) { const float e = expf(sj[t] - m); sj[t] = e; sum += e; }
-    sum = wave_sum(sum);
-    const float inv = 1.f / sum;
-    for (int t = lane; t < T; t += 64) { const float p = sj[t] * inv; sj[t] = p; p_out[(int64_t)(img * k + wave) * T + t] = p; }
-  }
-  __syncthreads();
-  float acc[KB][NC][8];
-#pragma unroll
-  for (int j = 0; j < KB; ++j)
+  for (int j = 0; j < KB; ++j) {
+    m_run[j] = -INFINITY; l_run[j] = 0.f;
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc)
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[j][cc][e] = 0.f;
+  }
   for (int t0 = 0; t0 < T; t0 += NW * RW) {
     load_rows(t0);
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       const int t = t0 + wave + NW * i;
+      if (t < T) {
 #pragma unroll
-      for (int j = 0; j < KB; ++j) {
-        const float p = (t < T && j < k) ? sc[(int64_t)j * T + t] : 0.f;
+        for (int j = 0; j < KB; ++j) {
+          float sdot = 0.f;
 #pragma unroll
-        for (int cc = 0; cc < NC; ++cc)
+          for (int cc = 0; cc < NC; ++cc)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[j][cc][e] = fmaf(p, (float)c[i][cc][e], acc[j][cc][e]);
+            for (int e = 0; e < 8; ++e) sdot = fmaf((float)c[i][cc][e], uu[j][cc][e], sdot);
+          sdot = wave_sum(sdot);
+          if (lane == 0 && j < k) sc[(int64_t)j * T + t] = sdot;
+          const float m_new = fmaxf(m_run[j], sdot), scale = __expf(m_run[j] - m_new), pe = __expf(sdot - m_new);
+          l_run[j] = l_run[j] * scale + pe; m_run[j] = m_new;
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[j][cc][e] = fmaf(pe, (float)c[i][cc][e], acc[j][cc][e] * scale);
+        }
       }
     }
   }
+  float* const ml = &red[0][0];                                 // [KB][NW][2] = (m, l) per hypothesis and wave
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < KB; ++j) { ml[(j * NW + wave) * 2] = m_run[j]; ml[(j * NW + wave) * 2 + 1] = l_run[j]; }
+  }
+  __syncthreads();
+  float wsc[KB];
+#pragma unroll
+  for (int j = 0; j < KB; ++j) {
+    float M = -INFINITY, Lsum = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) M = fmaxf(M, ml[(j * NW + q) * 2]);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) Lsum += ml[(j * NW + q) * 2 + 1] * __expf(ml[(j * NW + q) * 2] - M);
+    const float inv = 1.f / Lsum;
+    wsc[j] = __expf(m_run[j] - M) * inv;
+    if (j < k) for (int t = threadIdx.x; t < T; t += 64 * NW) p_out[(int64_t)(img * k + j) * T + t] = __expf(sc[(int64_t)j * T + t] - M) * inv;
+  }
+  __syncthreads();                                              // every thread has read (m, l) before the image is overwritten
 #pragma unroll
   for (int j = 0; j < KB; ++j) {
     if (j >= k) break;
     if (j > 0) __syncthreads();                                 // every thread is done with the image of hypothesis j - 1
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) {
-      *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8]) = make_float4(acc[j][cc][0], acc[j][cc][1], acc[j][cc][2], acc[j][cc][3]);
-      *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8 + 4]) = make_float4(acc[j][cc][4], acc[j][cc][5], acc[j][cc][6], acc[j][cc][7]);
+      *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8]) = make_float4(acc[j][cc][0] * wsc[j], acc[j][cc][1] * wsc[j], acc[j][cc][2] * wsc[j], acc[j][cc][3] * wsc[j]);
+      *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8 + 4]) = make_float4(acc[j][cc][4] * wsc[j], acc[j][cc][5] * wsc[j], acc[j][cc][6] * wsc[j], acc[j][cc][7] * wsc[j]);
     }
     __syncthreads();
     const int64_t row = (int64_t)img * k + j;
