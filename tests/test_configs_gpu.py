@@ -182,6 +182,37 @@ def test_reference_default_chain_scores_against_premultiplied_context(cuda, monk
         assert cs > (0.99 if k.startswith("cnn.") else 0.9995) and r < (0.3 if k.startswith("cnn.") else 5e-2), (k, r, cs)
 
 
+def test_streamed_attention_backward_one_pass(cuda, monkeypatch):
+    """Round 6: above 128 context rows (Hd = 1024) the attention kernels stream the context instead of holding it in registers; the backward form made two
+    passes (d a_t = ctx_t . d c and dot = sum a_t d a_t first, then d q = sum a_t (d a_t - dot) ctx_t).  It is one pass now: d q = sum_t a_t d a_t ctx_t -
+    dot c_fwd with c_fwd the forward pass's saved weighted context (LSTM.lua:131-145's MixtureTable output).  Against AOCR_ATTN_BWD_TWO_PASS=1 on the
+    reference-default model at W = 560 (T = 139): the forward pass is the same code (logits bit-equal), gradients as two summation orders."""
+    out = {}
+    for knob in ("", "1"):
+        monkeypatch.delenv("AOCR_ATTN_BWD_TWO_PASS", raising=False)
+        if knob:
+            monkeypatch.setenv("AOCR_ATTN_BWD_TWO_PASS", knob)
+        m, O, ocfg, P, st, batch = make(REF_DEFAULT, B=6, W=560, maxlen=9, compute="bf16", max_decoder_l=12, max_beam=1)
+        loss = m.train_forward_backward(batch)
+        assert m.get_tensor("context").shape[1] == 139
+        out[knob] = dict(loss=loss, logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), dctx=m.get_tensor("dcontext").clone(),
+                         grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.shutdown()
+    a, b = out["1"], out[""]
+    assert torch.equal(a["logits"], b["logits"]) and a["loss"] == b["loss"]
+    ed = relerr(b["dctx"], a["dctx"])
+    worst = ("", 0.0)
+    for k in a["grads"]:
+        r, cs = relerr(b["grads"][k], a["grads"][k]), cosine(b["grads"][k], a["grads"][k])
+        if r > worst[1]:
+            worst = (k, r)
+        if k in NOISY:
+            continue
+        assert cs > 0.9999 and r < 1e-2, (k, r, cs)
+    print(f"[parity] streamed attention backward, one pass vs two: d(context) rel {ed:.3e}, worst gradient tensor {worst[0]} rel {worst[1]:.3e}")
+    assert ed < 1e-3
+
+
 @pytest.mark.parametrize("beam,B,force", [(1, 21, False), (3, 21, True), (5, 6, False)])
 def test_reference_default_decode_chain_on_shadows(cuda, monkeypatch, beam, B, force):
     """Round 6: the decode launch chain (Hd = 1024 has no whole-sequence decoder: `-phase test` of the reference-default model, BASELINE config 5's beam-5 decode)

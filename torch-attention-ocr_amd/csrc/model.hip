@@ -1176,7 +1176,8 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
       attention_backward_dual(s, m->a_all + (size_t)t * B * T, dcat, 2 * Hd, m->ds_all + (size_t)t * B * T, m->dq_all + (size_t)t * slot, m->dq_b + (size_t)t * slot, m->bq, B, T, m->context_b, m->ctxa_b);
     else
     attention_backward(s, m->context, m->q_all + (size_t)t * slot, m->a_all + (size_t)t * B * T, dcat, 2 * Hd,
-                       m->ds_all + (size_t)t * B * T, m->dq_all + (size_t)t * slot, B, T, Hd, sh ? m->dq_b + (size_t)t * slot : nullptr, m->context_b);
+                       m->ds_all + (size_t)t * B * T, m->dq_all + (size_t)t * slot, B, T, Hd, sh ? m->dq_b + (size_t)t * slot : nullptr, m->context_b,
+                       m->cat_all + (size_t)t * B * 2 * Hd, 2 * Hd);      // (the forward pass's weighted context: the streamed kernel's one-pass form)
     // top layer: d h_top = dq W_a + dcat[:, Hd:] + recurrent part
     for (int l = Ld - 1; l >= 0; --l) {
       LoadK la; LoadKh2 lah; EpGatesBwd e; const ShW* ww;

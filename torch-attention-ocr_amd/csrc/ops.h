@@ -163,7 +163,8 @@ void attention_forward_dual(hipStream_t s, const float* h_top, int64_t ldh, floa
 void attention_backward_dual(hipStream_t s, const float* a, const float* dc, int64_t lddc, float* ds, float* dq, bf16_t* dqb, float* dh_attn, int B, int T,
                              const bf16_t* ctxb, const bf16_t* ctxab);
 void attention_backward(hipStream_t s, const float* ctx, const float* q, const float* a, const float* dc, int64_t lddc,
-                        float* ds, float* dq, int B, int T, int Hd, bf16_t* dqb = nullptr, const bf16_t* ctxb = nullptr);
+                        float* ds, float* dq, int B, int T, int Hd, bf16_t* dqb = nullptr, const bf16_t* ctxb = nullptr,
+                        const float* cfwd = nullptr, int64_t ldcf = 0);      // cfwd (optional): the forward pass's weighted context of the same rows -- the streamed kernel then makes ONE pass (ops_misc.hip)
 // ctxb: bf16 shadow of ctx, read instead of ctx by the register-resident kernels (T <= 64, Hd in {256, 512})
 // d(ctx)[b,t,:] = sum_l a[l,b,t]*dc[l,b,:] + ds[l,b,t]*q[l,b,:]   (dc row stride lddc)
 void attention_dctx(hipStream_t s, const float* a_all, const float* ds_all, const float* dc_all, int64_t lddc,

@@ -1105,7 +1105,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(const bf16_t* __rest
                                                          const float* __restrict__ a_in, float* __restrict__ p_out,
                                                          float* __restrict__ o, int64_t ldo, int T, int ctx_div,
                                                          bf16_t* __restrict__ ob, int64_t ldob,
-                                                         const bf16_t* __restrict__ ctx2 = nullptr, float* __restrict__ o2 = nullptr, int64_t ldo2 = 0) {
+                                                         const bf16_t* __restrict__ ctx2 = nullptr, float* __restrict__ o2 = nullptr, int64_t ldo2 = 0,
+                                                         const float* __restrict__ cfwd = nullptr, int64_t ldcf = 0) {
   static_assert(!(DUAL && STREAM), "the two-context form keeps a row's slice in registers");
   constexpr int Hd = 512 * NC;
   extern __shared__ float sc[];                                 // T scores / probabilities
@@ -1148,6 +1149,64 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(const bf16_t* __rest
       if (lane == 0 && t < T) sc[t] = s;
     }
   };
+  if constexpr (STREAM && BWD) {
+    if (cfwd) {
+      // Round 6: ONE pass for the streamed BACKWARD form too.  d q = sum_t a_t (d a_t - dot) ctx_t with dot = sum_t a_t d a_t needs dot before the weighted sum -- unless
+      // it is split: d q = [sum_t a_t d a_t ctx_t] - dot [sum_t a_t ctx_t], and the second bracket is the FORWARD pass's weighted context (cfwd: the c half of the saved
+      // [c ; h_top]).  So one sweep computes d a_t = ctx_t . d c, keeps it in sc[] for d s, and accumulates w_t = a_t d a_t into dot and w_t ctx_t into G.
+      // (G and dot cfwd nearly cancel where the attention is peaked: an absolute error of ~1e-7 |d a| |c|, far below the bf16 rounding of the context rows themselves.)
+      float dot_run = 0.f, g1[NC][8];
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g1[cc][e] = 0.f;
+      for (int t0 = 0; t0 < T; t0 += NW * RW) {
+        load_rows(cb, t0);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+          const int t = t0 + wave + NW * i;
+          if (t < T) {                                            // (wave-uniform)
+            float da = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) da = fmaf((float)c[i][cc][e], uu[cc][e], da);
+            da = wave_sum(da);
+            if (lane == 0) sc[t] = da;
+            const float w = a_in[(int64_t)b * T + t] * da;
+            dot_run += w;
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) g1[cc][e] = fmaf(w, (float)c[i][cc][e], g1[cc][e]);
+          }
+        }
+      }
+      float* const dl = &red[0][0];                             // [NW]: the waves' shares of dot
+      if (lane == 0) dl[wave] = dot_run;
+      __syncthreads();
+      float dot = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) dot += dl[q];
+      for (int t = threadIdx.x; t < T; t += 64 * NW) p_out[(int64_t)b * T + t] = a_in[(int64_t)b * T + t] * (sc[t] - dot);
+      __syncthreads();                                          // every thread has read the shares before the image is overwritten
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) {
+        *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8]) = make_float4(g1[cc][0], g1[cc][1], g1[cc][2], g1[cc][3]);
+        *reinterpret_cast<float4*>(&red[wave][cc * 512 + lane * 8 + 4]) = make_float4(g1[cc][4], g1[cc][5], g1[cc][6], g1[cc][7]);
+      }
+      __syncthreads();
+      for (int j = threadIdx.x; j < Hd; j += 64 * NW) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < NW; q += 4) v += (red[q][j] + red[q + 1][j]) + (red[q + 2][j] + red[q + 3][j]);
+        v = fmaf(-dot, cfwd[(int64_t)b * ldcf + j], v);
+        o[(int64_t)b * ldo + j] = v;
+        if (ob) ob[(int64_t)b * ldob + j] = (bf16_t)v;
+      }
+      return;
+    }
+  }
   if constexpr (STREAM && !BWD) {
     // Round 6: ONE pass over the context for the streamed forward form (C5: T = 1785, 0.94 GB of context per decoder step at 256 strips -- the two passes were
     // most of that shape's decoder forward and decode time).  Online softmax: every wave keeps a running maximum m, the sum l of e^(s - m) and the weighted sum of
@@ -1389,12 +1448,13 @@ __global__ __launch_bounds__(512) void attn_bf16_beam_kernel(const bf16_t* __res
 constexpr int ATTN_NW = 16;
 template <bool BWD>
 static void attn_launch(hipStream_t s, const float* ctx, const float* u, int64_t ldu, const float* a_in, float* p_out, float* o,
-                        int64_t ldo, int B, int T, int Hd, int ctx_div, bf16_t* ob, int64_t ldob, const bf16_t* ctxb) {
+                        int64_t ldo, int B, int T, int Hd, int ctx_div, bf16_t* ob, int64_t ldob, const bf16_t* ctxb, const float* cfwd = nullptr, int64_t ldcf = 0) {
+  if (getenv("AOCR_ATTN_BWD_TWO_PASS")) cfwd = nullptr;          // A/B: the streamed backward kernel's two-pass form
 #define AOCR_ATTN_BF16(NC, RW, STREAM) do {                                                                                   \
     if (64 * 1024 + (size_t)T * 4 > 64 * 1024)                                                                                  \
       (void)hipFuncSetAttribute((const void*)attn_bf16_kernel<BWD, NC, RW, STREAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)T * 4)); \
     hipLaunchKernelGGL((attn_bf16_kernel<BWD, NC, RW, STREAM>), dim3(B), dim3(1024), (size_t)T * sizeof(float), s, ctxb, u, ldu, a_in, p_out, o, \
-                       ldo, T, ctx_div, ob, ldob); } while (0)
+                       ldo, T, ctx_div, ob, ldob, (const bf16_t*)nullptr, (float*)nullptr, (int64_t)0, cfwd, ldcf); } while (0)
   const bool bf_ok = ctxb && ldu % 4 == 0 && !getenv("AOCR_NO_ATTN_BF16");
   if constexpr (!BWD) {
     // beam decode over a long context: one workgroup per IMAGE (its k hypotheses share every context row that is loaded); k <= 5, rows = images x k
@@ -1433,9 +1493,9 @@ void attention_forward(hipStream_t s, const float* ctx, const float* q, float* a
   attn_launch<false>(s, ctx, q, (int64_t)Hd, nullptr, a, c, ldc, B, T, Hd, ctx_div, cb, ldcb, ctxb);
 }
 void attention_backward(hipStream_t s, const float* ctx, const float* q, const float* a, const float* dc, int64_t lddc,
-                        float* ds, float* dq, int B, int T, int Hd, bf16_t* dqb, const bf16_t* ctxb) {
+                        float* ds, float* dq, int B, int T, int Hd, bf16_t* dqb, const bf16_t* ctxb, const float* cfwd, int64_t ldcf) {
   (void)q;
-  attn_launch<true>(s, ctx, dc, lddc, a, ds, dq, (int64_t)Hd, B, T, Hd, 1, dqb, (int64_t)Hd, ctxb);
+  attn_launch<true>(s, ctx, dc, lddc, a, ds, dq, (int64_t)Hd, B, T, Hd, 1, dqb, (int64_t)Hd, ctxb, cfwd, ldcf);
 }
 
 // Two-context forms (attn_bf16_kernel<..., DUAL>): Hd = 1024, T <= 64, bf16 context and its pre-multiplied copy ctxa = bf16(ctx W_a).  false: shape not taken.
