@@ -1409,7 +1409,8 @@ def test_grouped_dma_weight_gradients_match_transposed_read_kernel(cuda, monkeyp
 
 
 @pytest.mark.parametrize("switch", ["AOCR_NO_CNN_WGRAD_SIDE", "AOCR_NO_SIDE_PROLOGUE", "AOCR_NO_SIDE2",
-                                    "AOCR_NO_Q_SIDE", "AOCR_SIDE_GO_LATE", "AOCR_NO_SHADOW_SPLIT", "AOCR_ENC_DC_COPY", "AOCR_CONV1_RECOMPUTE"])      # round 5's re-ordered streams (they had no A/B test)
+                                    "AOCR_NO_Q_SIDE", "AOCR_SIDE_GO_LATE", "AOCR_NO_SHADOW_SPLIT", "AOCR_ENC_DC_COPY", "AOCR_CONV1_RECOMPUTE",      # round 5's re-ordered streams (they had no A/B test)
+                                    "AOCR_JOIN_BEFORE_CNN_BWD"])                                                                # round 6: no join between the hoisted recurrent gradients and the CNN backward pass
 def test_side_stream_overlaps_match_in_line_order(cuda, monkeypatch, switch):
     """the round-4 stream-level overlaps -- CNN filter gradients on the side stream over double-buffered gradient maps, the step prologue
     (gradient zeroing, weight shadows, token table) beside conv1, the second side stream -- each against the same steps with the switch that puts the

@@ -378,6 +378,14 @@ void cnn_forward(aocr_model* m, const float* images, const Dims& d, int training
                   (int64_t)B * d.T, 512, training, update_running, B, m->Xb, bsync);
 }
 
+// the filter gradients of the CNN backward pass run on the side stream (cnn_backward; backward_all asks too: the hoisted recurrent weight gradients then need no
+// join in front of the CNN backward pass -- the filter gradients queue behind them on the same stream)
+static bool cnn_wgrad_on_side(aocr_model* m) {
+  auto evok = [](hipEvent_t& e) { return e || hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
+  return m->bf16 && m->G2b && !getenv("AOCR_DBG_STOP") && !m->prof_on && m->side && m->side_done && !getenv("AOCR_NO_SIDE_WGRAD") && !env_on("AOCR_NO_CNN_WGRAD_SIDE") &&
+         evok(m->cw_map[0]) && evok(m->cw_map[1]) && evok(m->cw_done[0]) && evok(m->cw_done[1]) && evok(m->cw_main);
+}
+
 static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   hipStream_t s = m->s; const bool bf = m->bf16; const int B = d.B;
   const BnSync bsync_v{bn_sync_allreduce, m}; const BnSync* bsync = sync_bn_on(m) ? &bsync_v : nullptr;
@@ -390,9 +398,7 @@ static void cnn_backward(aocr_model* m, const float* images, const Dims& d) {
   bf16_t* Gb[2] = {m->G0b, m->G2b}; int gp = 0;
   const char* dbg_stop = getenv("AOCR_DBG_STOP");          // debugging aid: leave the gradient map of a stage in place (tap "g0")
   const int stop = dbg_stop ? atoi(dbg_stop) : 0;
-  auto evok = [](hipEvent_t& e) { return e || hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
-  const bool ws = bf && m->G2b && !stop && !m->prof_on && m->side && m->side_done && !getenv("AOCR_NO_SIDE_WGRAD") && !env_on("AOCR_NO_CNN_WGRAD_SIDE") &&
-                  evok(m->cw_map[0]) && evok(m->cw_map[1]) && evok(m->cw_done[0]) && evok(m->cw_done[1]) && evok(m->cw_main);
+  const bool ws = !stop && cnn_wgrad_on_side(m);
   hipStream_t sw = ws ? m->side : s;
   const bool wg_after = ws && env_on("AOCR_CNN_WGRAD_AFTER_DGRAD");      // A/B: start the filter gradient of a stage behind its data gradient (beside the next elementwise pass only)
   if (!ws) Gb[1] = Gb[0];
@@ -1316,9 +1322,20 @@ void backward_all(aocr_model* m, const float* images, const int32_t* tgt, const 
   const bool hold0 = comm_holds_bucket0(m);
   if (!hold0) hipEventRecord(m->grad_ev[0], m->side_busy ? m->side : m->s);          // decoder + projector gradients complete (on the side stream when it ran them)
   encoder_backward(m, d);
-  if (m->side_busy) { hipEventRecord(m->side_done, m->side); hipStreamWaitEvent(m->s, m->side_done, 0); }   // join before the CNN backward fills the chip
-  if (hold0) hipEventRecord(m->grad_ev[0], m->s);
-  hipEventRecord(m->grad_ev[1], m->s);
+  // Round 6: no join in front of the CNN backward pass when its filter gradients run on the side stream anyway.  The encoder's weight gradients (a 96 us grouped
+  // product + its slab sums at C3) start only when the BPTT kernel ends, so the main stream -- 50 us of d X -- idled ~90 us at the join; now BatchNorm 7's
+  // backward pass and conv7's data gradient run beside them, the side stream's first filter gradient queues behind them (it shares their slab scratch: same
+  // stream, in order), and cnn_backward's own join at its end covers both.  AOCR_JOIN_BEFORE_CNN_BWD=1: the join.
+  const bool through = m->side_busy && cnn_wgrad_on_side(m) && !env_on("AOCR_JOIN_BEFORE_CNN_BWD");
+  if (through) {                                                // the bucket events: behind both streams, recorded on the side stream
+    hipEventRecord(m->cw_main, m->s); hipStreamWaitEvent(m->side, m->cw_main, 0);
+    if (hold0) hipEventRecord(m->grad_ev[0], m->side);
+    hipEventRecord(m->grad_ev[1], m->side);
+  } else {
+    if (m->side_busy) { hipEventRecord(m->side_done, m->side); hipStreamWaitEvent(m->s, m->side_done, 0); }   // join before the CNN backward fills the chip
+    if (hold0) hipEventRecord(m->grad_ev[0], m->s);
+    hipEventRecord(m->grad_ev[1], m->s);
+  }
   cnn_backward(m, images, d);
   hipEventRecord(m->grad_ev[3], m->s);
 }
