@@ -182,6 +182,35 @@ def test_reference_default_chain_scores_against_premultiplied_context(cuda, monk
         assert cs > (0.99 if k.startswith("cnn.") else 0.9995) and r < (0.3 if k.startswith("cnn.") else 5e-2), (k, r, cs)
 
 
+@pytest.mark.parametrize("cfg,B,W", [(C3, 128, 256), (C3, 100, 100), (REF_DEFAULT, 90, 100)])
+def test_projector_criterion_one_launch(cuda, monkeypatch, cfg, B, W):
+    """Round 6: a training step's projector (model.lua:594-612), criterion (criterion.lua:3-9) and projector data gradient (model.lua:648) run as one launch
+    (project_loss_kernel) instead of three between the two decoder passes.  Each part keeps the arithmetic and the order of the launch it replaces, so against
+    AOCR_NO_PROJ_FUSE=1: logits, loss, d logits and d out bit-equal -- and with them every gradient tensor the decoder BPTT computes from d out alone (those
+    summed by split-K atomics differ by their run-to-run order).  B = 100 / 90: a ragged last 32-row block (rows = 1200 / 1080)."""
+    out = {}
+    for knob in ("", "1"):
+        monkeypatch.delenv("AOCR_NO_PROJ_FUSE", raising=False)
+        if knob:
+            monkeypatch.setenv("AOCR_NO_PROJ_FUSE", knob)
+        m, O, ocfg, P, st, batch = make(cfg, B=B, W=W, maxlen=11, compute="bf16", max_decoder_l=12, max_beam=1)
+        loss = m.train_forward_backward(batch)
+        out[knob] = dict(loss=loss, logits=m.get_tensor("logits")[:, :, :ocfg.vocab].clone(), dlogits=m.get_tensor("dlogits").clone(), dout=m.get_tensor("dout_proj").clone(),
+                         dctx=m.get_tensor("dcontext").clone(), grads={k: v.clone() for k, v in m.get_gradients().items()})
+        m.shutdown()
+    a, b = out["1"], out[""]
+    assert a["logits"].shape[0] * a["logits"].shape[1] >= 1024
+    assert torch.equal(a["logits"], b["logits"]) and a["loss"] == b["loss"]
+    assert torch.equal(a["dlogits"], b["dlogits"]) and torch.equal(a["dout"], b["dout"])
+    worst = 0.0
+    for k in a["grads"]:
+        if k in NOISY:
+            continue
+        worst = max(worst, relerr(b["grads"][k], a["grads"][k]))
+    print(f"[parity] projector + criterion + d out in one launch vs three: logits / loss / d logits / d out bit-equal; worst gradient tensor rel {worst:.2e} (atomic split-K order)")
+    assert worst < 2e-5 and relerr(b["dctx"], a["dctx"]) < 2e-5
+
+
 def test_streamed_attention_backward_one_pass(cuda, monkeypatch):
     """Round 6: above 128 context rows (Hd = 1024) the attention kernels stream the context instead of holding it in registers; the backward form made two
     passes (d a_t = ctx_t . d c and dot = sum a_t d a_t first, then d q = sum a_t (d a_t - dot) ctx_t).  It is one pass now: d q = sum_t a_t d a_t ctx_t -

@@ -19,7 +19,8 @@ t0 = int(rows[lo]["Start_Timestamp"])
 for r in rows[lo:hi + 1]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     g = "x".join(r[c] for c in gk[:3]); w = "x".join(r[c] for c in wk[:3])
-    print(f"{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} us  grid {g:>16s} wg {w:>10s}  {r['Kernel_Name'][:150]}")
+    q = r.get("Stream_Id") or r.get("Queue_Id") or "?"       # which HIP stream (hardware queue) the launch went to: the side-stream overlaps are read off this column
+    print(f"{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} us  -> {(e - t0) / 1e3:8.1f}  q{q:>2s}  grid {g:>16s} wg {w:>10s}  {r['Kernel_Name'][:150]}")
 print(f"step: {(int(rows[hi]['End_Timestamp']) - t0) / 1e3:.1f} us, {hi - lo + 1} launches")
 PY
 rm -rf $O

@@ -394,6 +394,8 @@ int aocr_get_tensor(aocr_model* m, const char* name, const void** ptr_dev, int32
   else if (n == "context") { *ptr_dev = m->context; *ndim = 3; shape[0] = d.B; shape[1] = d.T; shape[2] = m->Hd; }
   else if (n == "dcontext") { *ptr_dev = m->dctx; *ndim = 3; shape[0] = d.B; shape[1] = d.T; shape[2] = m->Hd; }
   else if (n == "logits") { *ptr_dev = m->logits; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = LOGIT_LD; }
+  else if (n == "dlogits") { *ptr_dev = m->dlogits; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = LOGIT_LD; }      // (after a training step)
+  else if (n == "dout_proj") { *ptr_dev = m->dout_proj; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = m->Hd; }
   else if (n == "outs") { *ptr_dev = m->out_all + (size_t)d.B * m->Hd; *ndim = 3; shape[0] = d.L; shape[1] = d.B; shape[2] = m->Hd; }
   else if (n == "conv1") { if (m->bf16) bf16_to_f32(m->s, m->A1b, m->A1, (int64_t)d.B * d.H1 * d.W1 * 64); *ptr_dev = m->A1; *ndim = 4; shape[0] = d.B; shape[1] = d.H1; shape[2] = d.W1; shape[3] = 64; }
   else if (n == "conv2") { if (m->bf16) bf16_to_f32(m->s, m->A2b, m->A2, (int64_t)d.B * d.H2 * d.W2 * 128); *ptr_dev = m->A2; *ndim = 4; shape[0] = d.B; shape[1] = d.H2; shape[2] = d.W2; shape[3] = 128; }

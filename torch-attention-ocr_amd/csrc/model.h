@@ -87,6 +87,7 @@ struct aocr_model {
   // step_prologue (start of a training step): table / gradient zeroing / weight shadows enqueued on the side stream, and the events the model's stream waits for
   hipEvent_t tab_done = nullptr, zero_done = nullptr, shadow_done = nullptr, shadow2_done = nullptr; bool tab_ready = false, zero_pending = false, shadow_pending = false, shadow2_pending = false;   // shadow2: conv2's taps (the head of the job table), an event of their own
   int shadow_tiles_conv2 = 0;
+  bool proj_fused = false, dout_ready = false;      // round 6: this training step's projector runs inside loss_and_dlogits (project_loss: logits + criterion + d out in one launch)
   float* loss_pending = nullptr;      // loss_and_dlogits -> decoder_backward: the loss sum still to be enqueued (behind the BPTT kernel)
   hipEvent_t q_go = nullptr, q_done = nullptr; bool q_pending = false;     // q = W_a h_top of all steps on the side stream (decoder_tf_forward -> decoder_backward)
   hipEvent_t enc_ev = nullptr;   // end of an encoder layer's BPTT: its weight gradients start behind it on the side stream (encoder_backward)

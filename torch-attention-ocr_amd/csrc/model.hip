@@ -1049,7 +1049,9 @@ void decoder_tf_forward(aocr_model* m, const Dims& d, const int32_t* tgt, int64_
     gemm_hh(s, m->dhs_b[m->Ld - 1] + slot, Hd, m->swa.wb, Hd, m->q_all, Hd, L * B, Hd, Hd, nullptr, nullptr, 0);
   }
   prof_mark(m, AOCR_PROF_RNN_GEMM);
-  gemm(s, bf, m->out_all + slot, Hd, true, m->wo, Hd, true, m->logits, LOGIT_LD, L * B, m->V, Hd, m->bo, nullptr, 0);
+  // (a training step without dropout: the projector runs in loss_and_dlogits' launch, with the criterion and its own data gradient)
+  m->proj_fused = keep_gates && bf && !m->drop_on && project_loss_ok(L * B, m->V, Hd);
+  if (!m->proj_fused) gemm(s, bf, m->out_all + slot, Hd, true, m->wo, Hd, true, m->logits, LOGIT_LD, L * B, m->V, Hd, m->bo, nullptr, 0);
 }
 
 void loss_and_dlogits(aocr_model* m, const Dims& d, const int32_t* tge, int64_t st, int64_t sb, float grad_scale, bool want_grad,
@@ -1058,7 +1060,16 @@ void loss_and_dlogits(aocr_model* m, const Dims& d, const int32_t* tge, int64_t 
   prof_mark(m, AOCR_PROF_OTHER);
   // (round 5, measured and dropped: d logits and the projector's data gradient d out_proj = d logits W_o in this pass -- d logits kept in the wave, W_o (80 KB, fp32) in LDS,
   //  exact fp32 FMAs instead of the K = 39 bf16 product behind it: 9 + 27 us of launches became one of ~60 us: 39 x 8 dependent LDS reads per row and lane)
-  logsoftmax_nll(m->s, m->logits, LOGIT_LD, tge, st, sb, d.B, nullptr, want_grad ? m->dlogits : nullptr, m->nll_rows, rows, m->V, grad_scale);
+  m->dout_ready = false;
+  if (m->proj_fused && want_grad) {
+    prof_mark(m, AOCR_PROF_RNN_GEMM);
+    project_loss(m->s, m->out_all + (size_t)d.B * m->Hd, m->Hd, m->wo, m->bo, m->logits, m->dlogits, LOGIT_LD, m->nll_rows, m->dout_proj, tge, st, sb, d.B, (int)rows, m->V, m->Hd, grad_scale);
+    m->dout_ready = true;
+  } else {
+    if (m->proj_fused) gemm(m->s, m->bf16, m->out_all + (size_t)d.B * m->Hd, m->Hd, true, m->wo, m->Hd, true, m->logits, LOGIT_LD, (int)rows, m->V, m->Hd, m->bo, nullptr, 0);
+    logsoftmax_nll(m->s, m->logits, LOGIT_LD, tge, st, sb, d.B, nullptr, want_grad ? m->dlogits : nullptr, m->nll_rows, rows, m->V, grad_scale);
+  }
+  m->proj_fused = false;
   // the step's loss (sum of the rows' NLL, fp64 in one workgroup: deterministic): nothing on the device reads it, so a training step sums it behind the decoder BPTT kernel
   // (decoder_backward) instead of between the two whole-sequence kernels (12 us of launch + latency on a mostly idle chip)
   if (loss_dev) { if (want_grad && !m->prof_on) m->loss_pending = loss_dev; else sum_to_scalar(m->s, m->nll_rows, rows, loss_dev); }
@@ -1143,7 +1154,8 @@ static void decoder_backward(aocr_model* m, const Dims& d, const int32_t* tgt) {
   const int rows = L * B;
   // projector backward for all steps at once (model.lua:648): d(out) part, gradWeight, gradBias
   prof_mark(m, AOCR_PROF_RNN_GEMM);
-  gemm(s, bf, m->dlogits, LOGIT_LD, true, m->wo, Hd, false, m->dout_proj, Hd, rows, Hd, V, nullptr, nullptr, 0);
+  if (!m->dout_ready) gemm(s, bf, m->dlogits, LOGIT_LD, true, m->wo, Hd, false, m->dout_proj, Hd, rows, Hd, V, nullptr, nullptr, 0);
+  m->dout_ready = false;
   // (gradWeight of the projector: nothing in this pass reads it -- with the hoisted parameter gradients below, beside the encoder BPTT: 41 us off the main stream at C3)
   ColsumJobs cj; cj.n = 0; cj.total = 0;                          // projector bias + the LSTM biases of every layer: one launch at the end of this pass
   colsum_defer(cj, m->dlogits, LOGIT_LD, rows, V, m->dbo);

@@ -80,6 +80,11 @@ void transpose_f32(hipStream_t s, const float* w, int64_t ld, int R, int C, floa
 void conv_weight_transpose_f32(hipStream_t s, const float* w, float* wt, int Cout, int KK, int Cin);     // wt [Cin][KK][Cout]
 
 // generic GEMM used by the C ABI and the hoisted projections; picks ksplit when allowed (atomic accumulate).
+// projector + LogSoftMax / ClassNLL + d logits + projector data gradient of all L B rows as one launch (ops_gemm.hip: project_loss_kernel; bf16 mode, V <= 40);
+// every output bit-identical to gemm (skinny) + logsoftmax_nll + gemm (K = V)
+bool project_loss_ok(int rows, int V, int Hd);
+void project_loss(hipStream_t s, const float* out, int64_t ldo, const float* wo, const float* bo, float* logits, float* dlogits, int64_t ld, float* nll, float* dout,
+                  const int32_t* tgt, int64_t st, int64_t sb, int Bt, int rows, int V, int Hd, float scale);
 int gemm(hipStream_t s, bool bf16, const float* A, int64_t lda, bool a_kmajor, const float* B, int64_t ldb, bool b_kmajor,
           float* C, int64_t ldc, int M, int N, int K, const float* bias, const float* bias2, int flags);
 

@@ -480,6 +480,116 @@ int gemm(hipStream_t s, bool bf16, const float* A, int64_t lda, bool a_k, const 
   return 0;
 }
 
+// ---- Round 6: projector + criterion + projector data gradient as ONE launch (model.lua:594-612 forward, :648 backward; criterion.lua:3-9).
+// Between the two whole-sequence decoder kernels a training step ran three dependent launches on a nearly idle chip -- logits = out W_o^T + b (39 columns),
+// LogSoftMax + ClassNLL + d logits (one wave per row), d out = d logits W_o (K = 39) -- 14 + 8 + 28 us and their launch gaps at C3.  One workgroup per 32 rows does
+// all three here, each with the arithmetic of the launch it replaces, in the same order (so every output is bit-identical to the three-launch form):
+//   1. gemm_small_body (the skinny-product kernel's body: K quartered over the four waves, partial tiles summed through LDS in wave order), both 32-column tiles,
+//      the epilogue adding the bias into an LDS tile instead of memory;
+//   2. lsm_nll_wave_kernel's row: one wave per row, lane = class, butterfly maximum / sum; logits, NLL and d logits stored, d logits kept as bf16 in LDS;
+//   3. d out tile = three chained v_mfma_f32_32x32x16_bf16 over k = 0..47 (classes past V are zero, as the 128 x 128 kernel pads), W_o fragments straight
+//      from memory (80 KB, L2-resident; k-strided, lanes along Hd).
+struct EpLogitTile {
+  float* tile; const float* bias; int m0, N;
+  template <int NT> __device__ __forceinline__ void quad(int m, int n, int nstep, const float (&v)[NT][4]) const {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      const int col = n + nstep * ni;
+      if (col >= N) continue;
+      float bb = 0.f;
+      if (bias) bb = bias[col];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tile[(m - m0 + i) * 65 + col] = v[ni][i] + bb;
+    }
+  }
+};
+struct ProjLossArgs {
+  LoadK a, b; const float* bias; const float* wo; int64_t ldw;
+  float* logits; float* dlogits; int64_t ld; float* nll; float* dout; int64_t lddo;
+  const int32_t* tgt; int64_t st, sb; int Bt, rows, V, K; float scale;
+};
+__device__ __forceinline__ float pl_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float pl_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__global__ __launch_bounds__(256) void project_loss_kernel(ProjLossArgs g) {
+  __shared__ float red[4 * 2 * 16 * 64];
+  __shared__ float tile[32 * 65];
+  __shared__ __attribute__((aligned(16))) bf16_t dl[32][56];           // d logits as the product's A operand: k = class, padded to 48 (+ 8: rows 112 bytes apart)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * 32;
+  {
+    SmallArgs<LoadK, LoadK, EpLogitTile> sa; sa.a = g.a; sa.b = g.b; sa.ep = EpLogitTile{tile, g.bias, m0, g.V}; sa.K = g.K;
+    gemm_small_body<true, 2, false, 4, false>(sa, 0, red);
+  }
+  __syncthreads();
+  const int V = g.V;
+#pragma unroll 1
+  for (int i = 0; i < 8; ++i) {
+    const int row = wave * 8 + i;
+    const int64_t r = (int64_t)m0 + row;
+    float dv = 0.f;
+    if (r < g.rows) {                                              // (wave-uniform)
+      const float xv = lane < V ? tile[row * 65 + lane] : -INFINITY;
+      const float mx = pl_wave_max(xv);
+      const float sum = pl_wave_sum(lane < V ? expf(xv - mx) : 0.f);
+      const float lse = mx + logf(sum);
+      const int64_t t = r / g.Bt, b = r - t * g.Bt;
+      const int y = g.tgt[t * g.st + b * g.sb] - 1;
+      const float wy = (y == 0) ? 0.f : 1.f;                       // criterion.lua:5: weights[PAD] = 0
+      if (lane < V) g.logits[r * g.ld + lane] = xv;
+      if (lane == y) g.nll[r] = -wy * (xv - lse);
+      const float gs = g.scale * wy;
+      if (lane < V) { dv = gs * (expf(xv - lse) - (lane == y ? 1.f : 0.f)); g.dlogits[r * g.ld + lane] = dv; }
+      for (int v = V + lane; v < g.ld; v += 64) g.dlogits[r * g.ld + v] = 0.f;
+    }
+    if (lane < 56) dl[row][lane] = (bf16_t)dv;
+  }
+  __syncthreads();
+  const int r = lane & 31, h = lane >> 5;
+  bf16x8 af[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) af[c] = *reinterpret_cast<const bf16x8*>(&dl[r][16 * c + 8 * h]);
+  const int ntiles = g.K / 32;                                      // Hd / 32 column tiles of d out, wave w takes w, w + 4, ...
+  for (int nt = wave; nt < ntiles; nt += 4) {
+    const float* wcol = g.wo + 32 * nt + r;
+    Frag<8> fb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 16 * c + 8 * h + j;
+        const float w = wcol[(int64_t)min(k, V - 1) * g.ldw];
+        fb[c].v[j] = k < V ? w : 0.f;
+      }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c], to_bf16x8(fb[c]), acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t row = (int64_t)m0 + 8 * (e >> 2) + 4 * h + (e & 3);
+      if (row < g.rows) g.dout[row * g.lddo + 32 * nt + r] = acc[e] + 0.f;
+    }
+  }
+}
+bool project_loss_ok(int rows, int V, int Hd) {
+  return rows >= 1024 && V >= 2 && V <= 40 && Hd % 64 == 0 && !getenv("AOCR_NO_SKINNY") && !env_is_1("AOCR_NO_PROJ_FUSE");      // rows >= 1024: where gemm() takes the skinny kernel for the logits
+}
+void project_loss(hipStream_t s, const float* out, int64_t ldo, const float* wo, const float* bo, float* logits, float* dlogits, int64_t ld, float* nll, float* dout,
+                  const int32_t* tgt, int64_t st, int64_t sb, int Bt, int rows, int V, int Hd, float scale) {
+  ProjLossArgs g; g.a = make_loadk(out, ldo, rows, Hd); g.b = make_loadk(wo, Hd, V, Hd); g.bias = bo; g.wo = wo; g.ldw = Hd;
+  g.logits = logits; g.dlogits = dlogits; g.ld = ld; g.nll = nll; g.dout = dout; g.lddo = Hd; g.tgt = tgt; g.st = st; g.sb = sb; g.Bt = Bt; g.rows = rows; g.V = V; g.K = Hd; g.scale = scale;
+  hipLaunchKernelGGL(project_loss_kernel, dim3(1, cdiv(rows, 32)), dim3(256), 0, s, g);
+}
+
 void gemm_hh(hipStream_t s, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
              const float* bias, const float* bias2, int flags) {
   LoadKh a; a.p = A; a.ld = lda; a.rows = M; a.K = K;
