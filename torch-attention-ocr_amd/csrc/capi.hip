@@ -461,6 +461,12 @@ int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_p
   auto run = [&]() {
     switch (which) {
     case 0:
+      if (const char* const pl = getenv("AOCR_PROBE_LAYER")) {   // debugging aid (tools/debug/conv_probe.py): the tagged launch of conv3 / conv4 / conv5 forward instead, as cnn_forward makes it
+        int bnc = 0, y16 = 0; const int l = atoi(pl);
+        if (l == 3) { conv_forward(m->s, m->bf16, m->A2, m->conv[3].w, m->conv[3].b, m->Y3, nullptr, d.B, d.H2, d.W2, 128, 256, 3, 1, 0, 0, m->A2b, m->wb[3], nullptr, 1, nullptr, nullptr, nullptr, (double*)m->bn_scratch, &bnc, &y16); break; }
+        if (l == 4) { conv_forward(m->s, m->bf16, m->A3, m->conv[4].w, m->conv[4].b, nullptr, m->idx4, d.B, d.H2, d.W2, 256, 256, 3, 1, 1, 2, m->A3b, m->wb[4], m->A4b, 1); break; }
+        if (l == 5) { conv_forward(m->s, m->bf16, m->A4, m->conv[5].w, m->conv[5].b, m->Y5, nullptr, d.B, d.H4, d.W2, 256, 512, 3, 1, 0, 0, m->A4b, m->wb[5], nullptr, 1, nullptr, nullptr, nullptr, (double*)m->bn_scratch, &bnc, &y16); break; }
+      }
       conv_forward(m->s, m->bf16, m->A5, m->conv[6].w, m->conv[6].b, m->bf16 ? nullptr : m->A6, m->idx6, d.B, d.H4, d.W2, 512, 512, 3, 1, 1, 2, m->A5b, m->wb[6],
                    m->A6b, 1);                              // exactly the launch cnn_forward makes for conv6 (distinct symbol: TAG = 1)
       break;
@@ -512,6 +518,7 @@ int aocr_profile_kernel(aocr_model* m, int32_t which, int32_t iters, float* ms_p
   *ms_per_launch = ms / iters;
   if (which == 0 && getenv("AOCR_PROBE")) {
     unsigned long long pr[8] = {0}; kprobe_read(pr);
+    if (getenv("AOCR_PROBE_LAYER")) for (int k = 1; k >= 0; --k) if (pr[4 * k + 1]) fprintf(stderr, "[aocr] probe: workgroup %d of the tagged launch: start -> K loop %.1f us, K loop %.1f us (%llu cycles = %.2f GHz), whole workgroup (last store acknowledged) %.1f us\n", k ? 17 : 300, pr[4 * k + 2] / 100.0, pr[4 * k + 1] / 100.0, pr[4 * k], pr[4 * k] / (pr[4 * k + 1] * 10.0) , pr[4 * k + 3] / 100.0);
     for (int k = 0; k < 2; ++k) if (pr[4 * k + 1]) fprintf(stderr, "[aocr] probe (%s halo kernel, conv6 forward): K loop of one workgroup %llu shader cycles in %.1f us = %.2f GHz\n", k ? "4-wave" : "8-wave", pr[4 * k], pr[4 * k + 1] / 100.0, pr[4 * k] / (pr[4 * k + 1] * 10.0)), fprintf(stderr, "[aocr]   prologue %.1f us, whole workgroup %.1f us (stores acknowledged)\n", pr[4 * k + 2] / 100.0, pr[4 * k + 3] / 100.0);
   }
   *flops_per_launch = which < 2 ? 2.0 * (double)d.B * d.H4 * d.W2 * 512.0 * (9.0 * 512.0) : bytes;
