@@ -369,10 +369,16 @@ def main():
             # partial logits) -- nothing is streamed from HBM (weights in registers, context in L2).  Floor = 5 x the idle one-hop hand-off price of
             # MI355X_MICROARCH.md ("handoff-1to1", 0.8-1.0 us).  The launch chain instead: 6 dependent launches per step.
             floor = 5 * 1.0 if cluster else 6 * 1.45
-            dec["decode_roofline"] = {"bound": "exchange-latency" if cluster else "launch-latency", "unit": "us per executed decoder step (all rows of the batch advance one step)",
+            bound = "exchange-latency" if cluster else "launch-latency"
+            # long strips (C5: T = 1785): a step's attention streams the bf16 context of every image once (the k hypotheses of an image share the rows:
+            # attn_bf16_beam_kernel) -- past the 256 MB Infinity Cache that is an HBM stream per step, and the larger floor
+            ctx_bytes = float(B) * T * Hd * 2
+            if not cluster and ctx_bytes > 256e6 and ctx_bytes / 8e12 * 1e6 > floor:
+                floor, bound = ctx_bytes / 8e12 * 1e6, "hbm (context stream of the attention step)"
+            dec["decode_roofline"] = {"bound": bound, "unit": "us per executed decoder step (all rows of the batch advance one step)",
                                       "achieved": us, "floor": floor, "frac": floor / us if us > 0 else None, "launches_per_step": 1.0 / 50 if cluster else 6,
-                                      "note": "floor: MI355X_MICROARCH.md price list (handoff-1to1 idle 0.8-1.0 us per dependent hop; boundary 1.45 us per dependent launch); "
-                                              "measured with every step executed (AOCR_NO_DEC_EARLY=1): beam_ms / 50"}
+                                      "note": "floor: MI355X_MICROARCH.md price list (handoff-1to1 idle 0.8-1.0 us per dependent hop; boundary 1.45 us per dependent launch; "
+                                              "HBM 8 TB/s for a context that does not fit the Infinity Cache); measured with every step executed (AOCR_NO_DEC_EARLY=1): beam_ms / 50"}
         m.params.copy_(trained[0]); m.bn_state.copy_(trained[1])
     if args.decode_steps > 0:
         # the same step under -use_dictionary: a synthetic 90 k-word lexicon as a device-resident flat trie (trained parameters: the

@@ -37,6 +37,7 @@ cp $(ls $O/stats_c2/*/*kernel_stats.csv | head -1) $O/c2_f32_kernel_stats.csv
 bash tools/ktrace_step.sh c3; cp gpurun_out/ktrace_step_c3.txt $O/c3_step_trace.txt
 bash tools/ktrace_step.sh c2 --compute f32; cp gpurun_out/ktrace_step_c2.txt $O/c2_step_trace.txt
 bash tools/ktrace_step.sh ref; cp gpurun_out/ktrace_step_ref.txt $O/ref_step_trace.txt
+bash tools/ktrace_step.sh c5; cp gpurun_out/ktrace_step_c5.txt $O/c5_step_trace.txt
 bash tools/pmc_clock.sh c2 --compute f32; cp gpurun_out/pmc_clock_c2.txt $O/c2_pmc_clock.txt
 rm -rf $O/stats $O/stats_c3s $O/stats_c2 $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 # cycles per phase of the decoder chain kernels (training forward / backward, beam-5 decode): stamps build of the library
