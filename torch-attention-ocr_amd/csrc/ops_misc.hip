@@ -1795,7 +1795,7 @@ __global__ __launch_bounds__(256) void emb_scatter_kernel(const float* __restric
   }
   if (rl < nrl) part[rl * E + e] = s;
   __syncthreads();
-  if (threadIdx.x < E) {
+  if ((int)threadIdx.x < E) {
     float t = 0.f;
     for (int i = 0; i < nrl; ++i) t += part[i * E + threadIdx.x];
     if (gridDim.y == 1) dtable[(int64_t)v * E + threadIdx.x] += t;
