@@ -1191,14 +1191,15 @@ def test_narrow_staged_epilogue_matches_quad(cuda, monkeypatch):
     print(f"[parity] staged vs quad epilogue of the narrow LDS-DMA kernel: context / logits / d(feats) bit-identical, loss {a['loss']:.5f}")
 
 
-@pytest.mark.parametrize("B,W", [(8, 256), (3, 128), (2, 384)])
+@pytest.mark.parametrize("B,W", [(8, 256), (3, 128), (2, 384), (5, 100), (3, 200), (2, 232)])
 def test_halo_wgrad_kernel_matches_tap_tiled_kernel(cuda, monkeypatch, B, W):
     """Round 4: conv_wgrad_halo_kernel (filter gradient with N tiles of nine taps x 32 input channels, the input map's halo staged once per
     32-pixel row segment) against the one-tap-per-tile kernels it replaces (AOCR_NO_WGRAD_HALO=1) on the same bf16 operands.  Only the fp32
     summation order over pixels differs (different split-K ranges), so every conv filter gradient must agree to accumulation noise; the
     forward pass and every other gradient do not involve the kernel and must be bit-identical.  W = 256 / 128 / 384 -> feature-map rows of
     64 / 32 / 96 pixels (2 / 1 / 3 segments per row; image borders inside and between the segments); AOCR_FORCE_DMA=1 selects it at these
-    batch sizes."""
+    batch sizes.  Round 6, ragged rows: W = 100 / 200 / 232 -> rows of 25 and 50 / 50 and 100 / 58 and 116 pixels (the reference-default shape's maps: one or
+    two segments per row, the last one 25 / 18 / 4 / 26 / 20 pixels with zero slots behind them)."""
     cfg = dict(enc_hidden=64, enc_layers=1, dec_layers=2, input_feed=True)
     monkeypatch.setenv("AOCR_FORCE_DMA", "1")
     out = {}

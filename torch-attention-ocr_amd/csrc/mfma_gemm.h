@@ -2470,7 +2470,8 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(WgDmaArgs g) {
 //   index (raster pixels), so a piece's pointer advances by a constant and only the two bounds compares change per step.
 // Grid: (Cout / 256) x (Cin / 32) tiles x split-K over whole segments, k-range-major XCD order (the workgroups of an XCD share pixel ranges in its L2);
 // every k range writes its 256 x 288 partial tile with plain stores into its slab (dW layout [Cout][9 Cin]); splitk_reduce sums the slabs.
-// Requires W % 32 == 0 (a K step never straddles an image row), Cout % 256 == 0, Cin % 32 == 0.
+// A K step never straddles an image row: rows of W % 32 != 0 pixels end with a ragged segment whose pixel slots past W are zero in both operands (round 6: the
+// reference-default shape's 25- / 50-wide maps, the width buckets of C4).  Cout % 256 == 0 (128: MG = 2), Cin % 32 == 0.
 // ---------------------------------------------------------------------------
 template <int... I, class F> __device__ __forceinline__ void aocr_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void aocr_static_for(F&& f) { aocr_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
@@ -2496,7 +2497,7 @@ void conv_wgrad_halo_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restr
   const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   const int zsp = lin / (gx * gy), bid = lin - zsp * (gx * gy);
   const int m_blk = (bid / gx) * MT, cchunk = bid % gx;                            // MT output channels x input channels [32 cchunk, +32)
-  const int spr = W >> 5, S = nimg * H * spr;                                      // segments per row, in all
+  const int spr = (W + 31) >> 5, S = nimg * H * spr;                               // segments per row (round 6: the last one of a row may be ragged -- pixel slots past W are zero), in all
   const int s_beg = zsp * segs_per, s_end = min(S, s_beg + segs_per);
   const int nk = s_end > s_beg ? s_end - s_beg : 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2504,14 +2505,19 @@ void conv_wgrad_halo_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restr
 
   // ---- d y staging: pieces 2 wave, 2 wave + 1; piece pi = pixel rows 2 pi, 2 pi + 1; lane -> row 2 pi + (lane >> 5), 16-byte position lane & 31 of the
   // row, which holds logical chunk ((pos >> 2) ^ (row & 3)) << 2 | (pos & 3)   (as conv_wgrad_dma_kernel)
-  const bf16_t* pa[2];
+  // (segment s = (image row s / spr, position s % spr) starts at raster pixel (s / spr) W + 32 (s % spr): the pointers advance by 32 pixels inside a row and by
+  //  what is left of the row, W - 32 (spr - 1), at its end -- both 32 where W % 32 == 0)
+  const int wrap_px = W - 32 * (spr - 1);
+  const int64_t seg0_px = (int64_t)(s_beg / spr) * W + 32 * (s_beg % spr);
+  const bf16_t* pa[2]; int akrow[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int krow = RPP * (2 * wave + j) + lane / LPR, pos = lane & (LPR - 1);
     const int chunk = ((((pos >> 2) ^ (krow & 3)) << 2) | (pos & 3));
-    pa[j] = dy + ((int64_t)s_beg * 32 + krow) * Cout + m_blk + 8 * chunk;
+    akrow[j] = krow;
+    pa[j] = dy + (seg0_px + krow) * Cout + m_blk + 8 * chunk;
   }
-  const int64_t astep = (int64_t)32 * Cout;
+  const int64_t astep = (int64_t)32 * Cout, awrap = (int64_t)wrap_px * Cout;
   // ---- halo staging: piece `wave` (piece 7 is all padding); slot sl = 64 piece + lane -> (halo row ry, pixel cx, chunk c) in image order
   bool bin[HPW]; int bry[HPW], bcx[HPW]; const bf16_t* pb[HPW];
 #pragma unroll
@@ -2520,24 +2526,25 @@ void conv_wgrad_halo_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restr
     bin[j] = sl < 3 * PW * 4;
     const int hry = sl / (PW * 4), hrem = sl - hry * (PW * 4), hcx = hrem >> 2, hc = hrem & 3;
     bry[j] = hry - 1; bcx[j] = hcx - 1;
-    pb[j] = x + ((int64_t)s_beg * 32 + (int64_t)(hry - 1) * W + (hcx - 1)) * Cin + cchunk * 32 + hc * 8;       // never dereferenced while outside the map
+    pb[j] = x + (seg0_px + (int64_t)(hry - 1) * W + (hcx - 1)) * Cin + cchunk * 32 + hc * 8;       // never dereferenced while outside the map
   }
-  const int64_t bstep = (int64_t)32 * Cin;
+  const int64_t bstep = (int64_t)32 * Cin, bwrap = (int64_t)wrap_px * Cin;
   int is = s_beg, ixs = s_beg % spr, iy = (s_beg / spr) % H;                       // the issue stream's segment: index, position in its row, image row
   unsigned char* const wA = lds + (2 * wave) * 1024;
   unsigned char* const wB = lds + BOFF + (HPW * wave) * 1024;
   int islot = 0;
   auto issue = [&]() {
     const bool live = is < s_end;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { dma16(dma_select(live, pa[j], zero), wA + islot * SLOT + j * 1024); pa[j] += astep; }
     const int x0 = ixs << 5;
+    const bool last = ixs + 1 == spr;                   // (uniform) the row ends with this segment
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { dma16(dma_select(live && x0 + akrow[j] < W, pa[j], zero), wA + islot * SLOT + j * 1024); pa[j] += last ? awrap : astep; }
 #pragma unroll
     for (int j = 0; j < HPW; ++j) {
       const bool ok = live && bin[j] && (unsigned)(iy + bry[j]) < (unsigned)H && (unsigned)(x0 + bcx[j]) < (unsigned)W;
-      dma16(dma_select(ok, pb[j], zero), wB + islot * SLOT + j * 1024); pb[j] += bstep;
+      dma16(dma_select(ok, pb[j], zero), wB + islot * SLOT + j * 1024); pb[j] += last ? bwrap : bstep;
     }
-    ++is; if (++ixs == spr) { ixs = 0; if (++iy == H) iy = 0; }
+    ++is; if (last) { ixs = 0; if (++iy == H) iy = 0; } else ++ixs;
     islot = islot == NS - 1 ? 0 : islot + 1;
   };
 

@@ -27,6 +27,7 @@ static const bf16_t* zero_page() {
   static const bf16_t* z = [] { void* p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_page)); return (const bf16_t*)p; }();
   return z;
 }
+static bool env_is_0(const char* name) { const char* e = getenv(name); return e && e[0] == '0'; }
 static bool env_is_1(const char* name) { const char* e = getenv(name); return e && e[0] == '1'; }      // switches are read per call; "0" means off
 static int wgrad_halo_min_n() { const char* e = getenv("AOCR_WGRAD_HALO_MINN"); return e ? atoi(e) : 576; }       // smallest N = 9 Cin that takes conv_wgrad_halo_kernel: conv2 (64 -> 128) upwards; A/B at C3: 2304 -> 1152 (conv3 too) = 5.505 -> 5.455 ms per step, 1152 -> 576 (conv2 too, 128-channel tiles): see DESIGN.md (AOCR_WGRAD_HALO_MINN)
 static bool dma_forced() { const char* e = getenv("AOCR_FORCE_DMA"); return e && e[0] == '1'; }     // read per call: tests toggle it
@@ -817,9 +818,13 @@ void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float*
     // Same-box, same harness (tools/ubench/wgrad_halo.hip) at the C3 shapes: conv4 193 -> 166 us, conv5 180 -> 151 us, conv6 327 -> 276 us.
     // AOCR_NO_WGRAD_HALO=1: the one-tap-per-tile kernels below (the parity reference).
     const int hmt = Cout % 256 == 0 ? 256 : 128;            // tile rows: 256 output channels (eight waves), or 128 for conv2 (four waves)
-    if (ks == 3 && pad == 1 && W % 32 == 0 && Cout % hmt == 0 && Cin % 32 == 0 && part && !dma_disabled() && !env_is_1("AOCR_NO_WGRAD_HALO") && !getenv("AOCR_WGRAD_ATOMIC") &&
+    // (round 6: ragged rows too -- W % 32 != 0 pads every row to whole 32-pixel segments with zero slots; taken while at least 3/4 of the slots are pixels:
+    //  the reference-default shape's 25- / 50-wide maps (0.78).  AOCR_WGRAD_HALO_RAGGED=0: whole segments only, as before)
+    const int spr = (W + 31) / 32;
+    const bool ragged_ok = W % 32 == 0 || (!env_is_0("AOCR_WGRAD_HALO_RAGGED") && W * 4 >= spr * 32 * 3);
+    if (ks == 3 && pad == 1 && ragged_ok && Cout % hmt == 0 && Cin % 32 == 0 && part && !dma_disabled() && !env_is_1("AOCR_NO_WGRAD_HALO") && !getenv("AOCR_WGRAD_ATOMIC") &&
         (dma_forced() || (P >= 8192 && N >= wgrad_halo_min_n()))) {
-      const int htiles = (Cin / 32) * (Cout / hmt), S = B * H * (W / 32);
+      const int htiles = (Cin / 32) * (Cout / hmt), S = B * H * spr;
       int ksh = htiles >= 256 ? 1 : 256 / htiles; if (ksh > S) ksh = S;                   // one round of the 256 CUs
       { const char* ms = getenv("AOCR_WGRAD_HALO_MINSTEPS"); const int minsteps = ms ? atoi(ms) : 0;       // A/B: at small P fewer, longer k ranges (less slab traffic) instead of a full round
         if (minsteps > 0 && S / ksh < minsteps) ksh = std::max(1, S / minsteps); }
