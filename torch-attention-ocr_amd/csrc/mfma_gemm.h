@@ -2475,7 +2475,7 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(WgDmaArgs g) {
 // ---------------------------------------------------------------------------
 template <int... I, class F> __device__ __forceinline__ void aocr_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void aocr_static_for(F&& f) { aocr_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
-template <int TAG = 0, int MG = 4>
+template <int TAG = 0, int MG = 4, bool RG = false>       // RG: ragged rows (W % 32 != 0); the whole-segment form keeps its constant pointer steps and has no validity compare on d y
 __global__ __launch_bounds__(128 * MG, 1)
 void conv_wgrad_halo_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ part, long long pstride,
                             int nimg, int H, int W, int Cin, int Cout, int gx, int gy, int gz, int segs_per, const bf16_t* zero) {
@@ -2536,15 +2536,26 @@ void conv_wgrad_halo_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restr
   auto issue = [&]() {
     const bool live = is < s_end;
     const int x0 = ixs << 5;
-    const bool last = ixs + 1 == spr;                   // (uniform) the row ends with this segment
+    if constexpr (RG) {
+      const bool last = ixs + 1 == spr;                 // (uniform) the row ends with this segment
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { dma16(dma_select(live && x0 + akrow[j] < W, pa[j], zero), wA + islot * SLOT + j * 1024); pa[j] += last ? awrap : astep; }
+      for (int j = 0; j < 2; ++j) { dma16(dma_select(live && x0 + akrow[j] < W, pa[j], zero), wA + islot * SLOT + j * 1024); pa[j] += last ? awrap : astep; }
 #pragma unroll
-    for (int j = 0; j < HPW; ++j) {
-      const bool ok = live && bin[j] && (unsigned)(iy + bry[j]) < (unsigned)H && (unsigned)(x0 + bcx[j]) < (unsigned)W;
-      dma16(dma_select(ok, pb[j], zero), wB + islot * SLOT + j * 1024); pb[j] += last ? bwrap : bstep;
+      for (int j = 0; j < HPW; ++j) {
+        const bool ok = live && bin[j] && (unsigned)(iy + bry[j]) < (unsigned)H && (unsigned)(x0 + bcx[j]) < (unsigned)W;
+        dma16(dma_select(ok, pb[j], zero), wB + islot * SLOT + j * 1024); pb[j] += last ? bwrap : bstep;
+      }
+      ++is; if (last) { ixs = 0; if (++iy == H) iy = 0; } else ++ixs;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { dma16(dma_select(live, pa[j], zero), wA + islot * SLOT + j * 1024); pa[j] += astep; }
+#pragma unroll
+      for (int j = 0; j < HPW; ++j) {
+        const bool ok = live && bin[j] && (unsigned)(iy + bry[j]) < (unsigned)H && (unsigned)(x0 + bcx[j]) < (unsigned)W;
+        dma16(dma_select(ok, pb[j], zero), wB + islot * SLOT + j * 1024); pb[j] += bstep;
+      }
+      ++is; if (++ixs == spr) { ixs = 0; if (++iy == H) iy = 0; }
     }
-    ++is; if (last) { ixs = 0; if (++iy == H) iy = 0; } else ++ixs;
     islot = islot == NS - 1 ? 0 : islot + 1;
   };
 

@@ -831,7 +831,11 @@ void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float*
       const int per = cdiv(S, ksh); ksh = cdiv(S, per);
       const size_t mn = (size_t)Cout * N;
       if (mn * ksh <= part_floats) {
-        if (hmt == 128) hipLaunchKernelGGL((conv_wgrad_halo_kernel<0, 2>), dim3(htiles * ksh), dim3(256), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 128, ksh, per, zero_page());
+        if (W % 32) {                                            // ragged rows: the form with the row-end pointer steps and the d y validity compare
+          if (hmt == 128) hipLaunchKernelGGL((conv_wgrad_halo_kernel<0, 2, true>), dim3(htiles * ksh), dim3(256), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 128, ksh, per, zero_page());
+          else hipLaunchKernelGGL((conv_wgrad_halo_kernel<0, 4, true>), dim3(htiles * ksh), dim3(512), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 256, ksh, per, zero_page());
+        }
+        else if (hmt == 128) hipLaunchKernelGGL((conv_wgrad_halo_kernel<0, 2>), dim3(htiles * ksh), dim3(256), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 128, ksh, per, zero_page());
         else if (profile_tag) hipLaunchKernelGGL((conv_wgrad_halo_kernel<1, 4>), dim3(htiles * ksh), dim3(512), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 256, ksh, per, zero_page());
         else hipLaunchKernelGGL((conv_wgrad_halo_kernel<0, 4>), dim3(htiles * ksh), dim3(512), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 256, ksh, per, zero_page());
         splitk_reduce(s, part, ksh, mn, dw);
