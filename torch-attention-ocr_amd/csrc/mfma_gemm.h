@@ -2475,7 +2475,7 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(WgDmaArgs g) {
 // ---------------------------------------------------------------------------
 template <int... I, class F> __device__ __forceinline__ void aocr_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void aocr_static_for(F&& f) { aocr_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
-template <int TAG = 0, int MG = 4, bool RG = false>       // RG: ragged rows (W % 32 != 0); the whole-segment form keeps its constant pointer steps and has no validity compare on d y
+template <int TAG = 0, int MG = 4, bool RG = false, bool IM = false>       // RG: ragged rows (W % 32 != 0); the whole-segment form keeps its constant pointer steps and has no validity compare on d y.  IM: the DMA issue between the two k-halves' MFMAs, which start as soon as their own fragments are back (AOCR_NO_WGRAD_ISSUE_MID=1: the one-wait form)
 __global__ __launch_bounds__(128 * MG, 1)
 void conv_wgrad_halo_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ part, long long pstride,
                             int nimg, int H, int W, int Cin, int Cout, int gx, int gy, int gz, int segs_per, const bf16_t* zero) {
@@ -2596,14 +2596,8 @@ void conv_wgrad_halo_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restr
       AOCR_TRH(fa[1][0][0], a0, 16 * AROW); AOCR_TRH(fa[1][0][1], a0, 20 * AROW); AOCR_TRH(fa[1][1][0], a1, 16 * AROW); AOCR_TRH(fa[1][1][1], a1, 20 * AROW);
       AOCR_TAPH(1, 0); AOCR_TAPH(1, 1); AOCR_TAPH(1, 2); AOCR_TAPH(1, 3); if constexpr (NTP == 5) AOCR_TAPH(1, NTP - 1);
 #undef AOCR_TAPH
-      issue();                                          // segment kt + 3 -> a slot last read three steps ago
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]), "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]) :: "memory");
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int t = 0; t < NTP; ++t) asm volatile("" : "+v"(fb[s2][t][0]), "+v"(fb[s2][t][1]));
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
+      auto mma_half = [&](auto s2c) {
+        constexpr int s2 = decltype(s2c)::value;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -2611,6 +2605,34 @@ void conv_wgrad_halo_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restr
             const u64x2 av = {fa[s2][mi][0], fa[s2][mi][1]}, bv = {fb[s2][t][0], fb[s2][t][1]};
             acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[mi][t], 0, 0, 0);
           }
+      };
+      if constexpr (!IM) {
+        issue();                                        // segment kt + 3 -> a slot last read three steps ago
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]), "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]) :: "memory");
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int t = 0; t < NTP; ++t) asm volatile("" : "+v"(fb[s2][t][0]), "+v"(fb[s2][t][1]));
+        mma_half(std::integral_constant<int, 0>{}); mma_half(std::integral_constant<int, 1>{});
+      } else {
+        // Round 6: the wave issues in order, and with the two waves of a SIMD behind one barrier per step everything in front of a wave's first MFMA is time the
+        // matrix pipe stands still.  The first k-half's MFMAs now start as soon as ITS 4 + 2 NTP fragment reads are back (LDS returns in order: the second half's
+        // reads, issued behind them, land underneath), and the address work + DMA issue of segment kt + 3 sits between the halves.  Same products, same order.
+        // (Measured beside it: the loop rotated so that the next segment's first-half reads also land under MFMAs -- no better: the 28 transposed reads of a
+        //  wave and step are an LDS-bandwidth cost, 115 KB per CU and step, not a latency.)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]) : "n"(4 + 2 * NTP) : "memory");
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) asm volatile("" : "+v"(fb[0][t][0]), "+v"(fb[0][t][1]));
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        issue();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]) :: "memory");
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) asm volatile("" : "+v"(fb[1][t][0]), "+v"(fb[1][t][1]));
+        mma_half(std::integral_constant<int, 1>{});
+      }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                                    // every wave is out of the K loop: the ring is free

@@ -831,13 +831,17 @@ void conv_backward_filter(hipStream_t s, bool bf16, const float* x, const float*
       const int per = cdiv(S, ksh); ksh = cdiv(S, per);
       const size_t mn = (size_t)Cout * N;
       if (mn * ksh <= part_floats) {
+        // (IM = !AOCR_NO_WGRAD_ISSUE_MID: MFMAs start behind their own k-half's reads, DMA issue between the halves -- mfma_gemm.h)
+#define AOCR_WGH(TAGV, MGV, RGV, IMV, THREADS, MTV) hipLaunchKernelGGL((conv_wgrad_halo_kernel<TAGV, MGV, RGV, IMV>), dim3(htiles * ksh), dim3(THREADS), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / MTV, ksh, per, zero_page())
+        const bool im = !env_is_1("AOCR_NO_WGRAD_ISSUE_MID");
         if (W % 32) {                                            // ragged rows: the form with the row-end pointer steps and the d y validity compare
-          if (hmt == 128) hipLaunchKernelGGL((conv_wgrad_halo_kernel<0, 2, true>), dim3(htiles * ksh), dim3(256), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 128, ksh, per, zero_page());
-          else hipLaunchKernelGGL((conv_wgrad_halo_kernel<0, 4, true>), dim3(htiles * ksh), dim3(512), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 256, ksh, per, zero_page());
+          if (hmt == 128) { if (im) AOCR_WGH(0, 2, true, true, 256, 128); else AOCR_WGH(0, 2, true, false, 256, 128); }
+          else { if (im) AOCR_WGH(0, 4, true, true, 512, 256); else AOCR_WGH(0, 4, true, false, 512, 256); }
         }
-        else if (hmt == 128) hipLaunchKernelGGL((conv_wgrad_halo_kernel<0, 2>), dim3(htiles * ksh), dim3(256), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 128, ksh, per, zero_page());
-        else if (profile_tag) hipLaunchKernelGGL((conv_wgrad_halo_kernel<1, 4>), dim3(htiles * ksh), dim3(512), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 256, ksh, per, zero_page());
-        else hipLaunchKernelGGL((conv_wgrad_halo_kernel<0, 4>), dim3(htiles * ksh), dim3(512), 0, s, dyb, xb, part, (long long)mn, B, H, W, Cin, Cout, Cin / 32, Cout / 256, ksh, per, zero_page());
+        else if (hmt == 128) { if (im) AOCR_WGH(0, 2, false, true, 256, 128); else AOCR_WGH(0, 2, false, false, 256, 128); }
+        else if (profile_tag) { if (im) AOCR_WGH(1, 4, false, true, 512, 256); else AOCR_WGH(1, 4, false, false, 512, 256); }
+        else { if (im) AOCR_WGH(0, 4, false, true, 512, 256); else AOCR_WGH(0, 4, false, false, 512, 256); }
+#undef AOCR_WGH
         splitk_reduce(s, part, ksh, mn, dw);
         if (dbias) colsum_accum(s, dy, Cout, P, Cout, dbias);
         return;
